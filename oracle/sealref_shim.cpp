@@ -1,0 +1,690 @@
+// TEST INFRASTRUCTURE ONLY — never linked into, loaded by, or shipped with seal_amd/.
+//
+// Flat C ABI over the REAL reference (Microsoft SEAL 4.4.3 compiled from /root/reference by
+// oracle/Makefile into oracle/_ref/libsealref.so).  tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg drive it through ctypes as the checker / CPU baseline
+// (cpu_baseline.kind == "reference").  Every entry point wraps the reference API it names;
+// raw slabs use the Ciphertext::data() layout [poly][rns][coeff] (ciphertext.h:337-349).
+//
+// Error convention: 0 = ok, 1 = std::invalid_argument, 2 = std::logic_error,
+// 3 = std::out_of_range, 4 = other exception.  (Mirrors the classes the C export layer maps
+// to HRESULTs at native/src/seal/c/defines.h:75-97.)
+
+#include "seal/seal.h"
+#include "seal/util/galois.h"
+#include "seal/util/ntt.h"
+#include "seal/util/polyarithsmallmod.h"
+#include "seal/util/rns.h"
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <random>
+#include <thread>
+#include <vector>
+
+using namespace seal;
+using namespace seal::util;
+
+namespace
+{
+    struct RefCtx
+    {
+        std::unique_ptr<SEALContext> context;
+        std::unique_ptr<KeyGenerator> keygen;
+        std::unique_ptr<Evaluator> evaluator;
+        PublicKey pk;
+        RelinKeys rlk;
+        GaloisKeys glk;
+        bool have_rlk = false, have_glk = false, have_pk = false;
+        scheme_type scheme;
+
+        std::shared_ptr<const SEALContext::ContextData> level(uint64_t chain_index) const
+        {
+            auto p = context->key_context_data();
+            while (p && p->chain_index() != chain_index)
+                p = p->next_context_data();
+            return p;
+        }
+    };
+
+    struct RefCt
+    {
+        Ciphertext ct;
+    };
+
+#define REF_TRY try {
+#define REF_CATCH                          \
+    }                                      \
+    catch (const std::invalid_argument &)  \
+    {                                      \
+        return 1;                          \
+    }                                      \
+    catch (const std::out_of_range &)      \
+    {                                      \
+        return 3;                          \
+    }                                      \
+    catch (const std::logic_error &)       \
+    {                                      \
+        return 2;                          \
+    }                                      \
+    catch (...)                            \
+    {                                      \
+        return 4;                          \
+    }                                      \
+    return 0;
+} // namespace
+
+extern "C"
+{
+    // ---- parameter helpers -------------------------------------------------------------
+    // CoeffModulus::Create (modulus.cpp) / PlainModulus::Batching (modulus.h:540) / BFVDefault.
+    int ref_coeff_modulus_create(uint64_t n, const int *bit_sizes, uint64_t count, uint64_t *out)
+    {
+        REF_TRY
+        std::vector<int> bits(bit_sizes, bit_sizes + count);
+        auto v = CoeffModulus::Create(n, bits);
+        for (size_t i = 0; i < v.size(); i++)
+            out[i] = v[i].value();
+        REF_CATCH
+    }
+    int ref_plain_modulus_batching(uint64_t n, int bits, uint64_t *out)
+    {
+        REF_TRY
+        *out = PlainModulus::Batching(n, bits).value();
+        REF_CATCH
+    }
+    int ref_bfv_default(uint64_t n, uint64_t *out, uint64_t *count)
+    {
+        REF_TRY
+        auto v = CoeffModulus::BFVDefault(n, sec_level_type::tc128);
+        *count = v.size();
+        for (size_t i = 0; i < v.size(); i++)
+            out[i] = v[i].value();
+        REF_CATCH
+    }
+
+    // ---- context -----------------------------------------------------------------------
+    // scheme: 1 = bfv, 2 = ckks, 3 = bgv (scheme_type, encryptionparams.h).
+    int ref_ctx_create(
+        int scheme, uint64_t n, const uint64_t *primes, uint64_t nprimes, uint64_t plain_modulus, uint64_t seed,
+        void **out)
+    {
+        REF_TRY
+        EncryptionParameters parms(static_cast<scheme_type>(scheme));
+        parms.set_poly_modulus_degree(n);
+        std::vector<Modulus> mods;
+        for (uint64_t i = 0; i < nprimes; i++)
+            mods.emplace_back(primes[i]);
+        parms.set_coeff_modulus(mods);
+        if (scheme != 2)
+            parms.set_plain_modulus(plain_modulus);
+        prng_seed_type s{};
+        s[0] = seed;
+        parms.set_random_generator(std::make_shared<Blake2xbPRNGFactory>(s));
+        auto c = std::make_unique<RefCtx>();
+        c->scheme = static_cast<scheme_type>(scheme);
+        c->context = std::make_unique<SEALContext>(parms, true, sec_level_type::none);
+        if (!c->context->parameters_set())
+            return 1;
+        c->evaluator = std::make_unique<Evaluator>(*c->context);
+        c->keygen = std::make_unique<KeyGenerator>(*c->context);
+        *out = c.release();
+        REF_CATCH
+    }
+    void ref_ctx_destroy(void *ctx)
+    {
+        delete static_cast<RefCtx *>(ctx);
+    }
+    // chain indices: key level = levels-1 ... last = 0 (context.cpp:556-565)
+    int ref_ctx_info(void *ctx, uint64_t *key_chain_index, uint64_t *first_chain_index, int *using_keyswitching)
+    {
+        auto c = static_cast<RefCtx *>(ctx);
+        *key_chain_index = c->context->key_context_data()->chain_index();
+        *first_chain_index = c->context->first_context_data()->chain_index();
+        *using_keyswitching = c->context->using_keyswitching();
+        return 0;
+    }
+    int ref_ctx_level_primes(void *ctx, uint64_t chain_index, uint64_t *out, uint64_t *count)
+    {
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 1;
+        auto &m = l->parms().coeff_modulus();
+        *count = m.size();
+        for (size_t i = 0; i < m.size(); i++)
+            out[i] = m[i].value();
+        return 0;
+    }
+    // NTTTables of prime `idx` at `chain_index`: root, inv_degree and the two tables' operands
+    // (ntt.h:69-183).  out_fwd/out_inv may be null.
+    int ref_ctx_ntt_tables(
+        void *ctx, uint64_t chain_index, uint64_t idx, uint64_t *root, uint64_t *inv_degree, uint64_t *out_fwd,
+        uint64_t *out_inv)
+    {
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 1;
+        auto &t = l->small_ntt_tables()[idx];
+        *root = t.get_root();
+        *inv_degree = t.inv_degree_modulo().operand;
+        size_t n = t.coeff_count();
+        for (size_t i = 0; i < n; i++)
+        {
+            if (out_fwd)
+                out_fwd[i] = t.get_from_root_powers()[i].operand;
+            if (out_inv)
+                out_inv[i] = t.get_from_inv_root_powers()[i].operand;
+        }
+        return 0;
+    }
+    // RNSTool bases of a level (rns.h:246-309): out = [B primes..., m_sk], m_tilde, gamma.
+    int ref_ctx_behz_bases(
+        void *ctx, uint64_t chain_index, uint64_t *bsk, uint64_t *bsk_count, uint64_t *m_tilde, uint64_t *gamma)
+    {
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 1;
+        auto rt = l->rns_tool();
+        *bsk_count = rt->base_Bsk()->size();
+        for (size_t i = 0; i < *bsk_count; i++)
+            bsk[i] = (*rt->base_Bsk())[i].value();
+        *m_tilde = rt->m_tilde().value();
+        *gamma = rt->gamma().value();
+        return 0;
+    }
+
+    // ---- keys --------------------------------------------------------------------------
+    int ref_keygen_relin(void *ctx)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        c->keygen->create_relin_keys(c->rlk);
+        c->have_rlk = true;
+        REF_CATCH
+    }
+    int ref_keygen_galois_elts(void *ctx, const uint32_t *elts, uint64_t count)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        std::vector<uint32_t> v(elts, elts + count);
+        c->keygen->create_galois_keys(v, c->glk);
+        c->have_glk = true;
+        REF_CATCH
+    }
+    int ref_keygen_galois_steps(void *ctx, const int *steps, uint64_t count)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        std::vector<int> v(steps, steps + count);
+        c->keygen->create_galois_keys(v, c->glk);
+        c->have_glk = true;
+        REF_CATCH
+    }
+    int ref_keygen_public(void *ctx)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        c->keygen->create_public_key(c->pk);
+        c->have_pk = true;
+        REF_CATCH
+    }
+    // Copy out one key-switching key: kind 0 = relin (index = RelinKeys::get_index(key_power),
+    // relinkeys.h:58), kind 1 = galois (index = GaloisKeys::get_index(elt), galoiskeys.h:48).
+    // Layout written: [digit J][k in 0..1][rns comp 0..L-1][coeff]  (kswitchkeys.h:340).
+    int ref_key_digits(void *ctx, int kind, uint64_t index, uint64_t *ndigits)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        const KSwitchKeys &k =
+            kind == 0 ? static_cast<const KSwitchKeys &>(c->rlk) : static_cast<const KSwitchKeys &>(c->glk);
+        if (index >= k.data().size())
+            return 3;
+        *ndigits = k.data()[index].size();
+        REF_CATCH
+    }
+    int ref_key_copy(void *ctx, int kind, uint64_t index, uint64_t *out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        const KSwitchKeys &k =
+            kind == 0 ? static_cast<const KSwitchKeys &>(c->rlk) : static_cast<const KSwitchKeys &>(c->glk);
+        if (index >= k.data().size())
+            return 3;
+        auto &vec = k.data()[index];
+        for (size_t j = 0; j < vec.size(); j++)
+        {
+            const Ciphertext &kc = vec[j].data();
+            size_t words = kc.size() * kc.coeff_modulus_size() * kc.poly_modulus_degree();
+            std::memcpy(out, kc.data(), words * sizeof(uint64_t));
+            out += words;
+        }
+        REF_CATCH
+    }
+    uint64_t ref_galois_elt_from_step(void *ctx, int step)
+    {
+        auto c = static_cast<RefCtx *>(ctx);
+        try
+        {
+            return c->context->key_context_data()->galois_tool()->get_elt_from_step(step);
+        }
+        catch (...)
+        {
+            return 0;
+        }
+    }
+
+    // ---- ciphertext handles ------------------------------------------------------------
+    int ref_ct_create(
+        void *ctx, uint64_t chain_index, uint64_t size, int is_ntt, double scale, uint64_t correction_factor,
+        const uint64_t *data, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 1;
+        auto h = std::make_unique<RefCt>();
+        h->ct.resize(*c->context, l->parms_id(), size);
+        h->ct.is_ntt_form() = is_ntt != 0;
+        h->ct.scale() = scale;
+        h->ct.correction_factor() = correction_factor;
+        if (data)
+            std::memcpy(
+                h->ct.data(), data,
+                size * l->parms().coeff_modulus().size() * l->parms().poly_modulus_degree() * sizeof(uint64_t));
+        *out = h.release();
+        REF_CATCH
+    }
+    void ref_ct_destroy(void *ct)
+    {
+        delete static_cast<RefCt *>(ct);
+    }
+    int ref_ct_info(
+        void *ctx, void *ct, uint64_t *chain_index, uint64_t *size, uint64_t *coeff_modulus_size, int *is_ntt,
+        double *scale, uint64_t *correction_factor)
+    {
+        auto c = static_cast<RefCtx *>(ctx);
+        auto &x = static_cast<RefCt *>(ct)->ct;
+        auto l = c->context->get_context_data(x.parms_id());
+        *chain_index = l ? l->chain_index() : ~uint64_t(0);
+        *size = x.size();
+        *coeff_modulus_size = x.coeff_modulus_size();
+        *is_ntt = x.is_ntt_form();
+        *scale = x.scale();
+        *correction_factor = x.correction_factor();
+        return 0;
+    }
+    int ref_ct_data(void *ct, uint64_t *out)
+    {
+        auto &x = static_cast<RefCt *>(ct)->ct;
+        std::memcpy(out, x.data(), x.size() * x.coeff_modulus_size() * x.poly_modulus_degree() * sizeof(uint64_t));
+        return 0;
+    }
+    int ref_ct_copy(void *src, void **out)
+    {
+        REF_TRY
+        auto h = std::make_unique<RefCt>();
+        h->ct = static_cast<RefCt *>(src)->ct;
+        *out = h.release();
+        REF_CATCH
+    }
+
+    // ---- Evaluator ops (evaluator.h) ----------------------------------------------------
+#define CT(x) (static_cast<RefCt *>(x)->ct)
+#define EV (static_cast<RefCtx *>(ctx)->evaluator)
+    int ref_multiply_inplace(void *ctx, void *a, void *b)
+    {
+        REF_TRY EV->multiply_inplace(CT(a), CT(b));
+        REF_CATCH
+    }
+    int ref_square_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->square_inplace(CT(a));
+        REF_CATCH
+    }
+    int ref_relinearize_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->relinearize_inplace(CT(a), static_cast<RefCtx *>(ctx)->rlk);
+        REF_CATCH
+    }
+    int ref_rescale_to_next_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->rescale_to_next_inplace(CT(a));
+        REF_CATCH
+    }
+    int ref_mod_switch_to_next_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->mod_switch_to_next_inplace(CT(a));
+        REF_CATCH
+    }
+    int ref_mod_reduce_to_next_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->mod_reduce_to_next_inplace(CT(a));
+        REF_CATCH
+    }
+    int ref_rotate_vector_inplace(void *ctx, void *a, int steps)
+    {
+        REF_TRY EV->rotate_vector_inplace(CT(a), steps, static_cast<RefCtx *>(ctx)->glk);
+        REF_CATCH
+    }
+    int ref_rotate_rows_inplace(void *ctx, void *a, int steps)
+    {
+        REF_TRY EV->rotate_rows_inplace(CT(a), steps, static_cast<RefCtx *>(ctx)->glk);
+        REF_CATCH
+    }
+    int ref_rotate_columns_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->rotate_columns_inplace(CT(a), static_cast<RefCtx *>(ctx)->glk);
+        REF_CATCH
+    }
+    int ref_complex_conjugate_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->complex_conjugate_inplace(CT(a), static_cast<RefCtx *>(ctx)->glk);
+        REF_CATCH
+    }
+    int ref_apply_galois_inplace(void *ctx, void *a, uint32_t elt)
+    {
+        REF_TRY EV->apply_galois_inplace(CT(a), elt, static_cast<RefCtx *>(ctx)->glk);
+        REF_CATCH
+    }
+    int ref_transform_to_ntt_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->transform_to_ntt_inplace(CT(a));
+        REF_CATCH
+    }
+    int ref_transform_from_ntt_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->transform_from_ntt_inplace(CT(a));
+        REF_CATCH
+    }
+    int ref_add_inplace(void *ctx, void *a, void *b)
+    {
+        REF_TRY EV->add_inplace(CT(a), CT(b));
+        REF_CATCH
+    }
+    int ref_sub_inplace(void *ctx, void *a, void *b)
+    {
+        REF_TRY EV->sub_inplace(CT(a), CT(b));
+        REF_CATCH
+    }
+    int ref_negate_inplace(void *ctx, void *a)
+    {
+        REF_TRY EV->negate_inplace(CT(a));
+        REF_CATCH
+    }
+
+    // ---- L1 kernels on raw components (the HEXL seam, ntt.cpp:394-475, polyarithsmallmod.cpp) ----
+    // mode: 0 fwd, 1 fwd lazy, 2 inv, 3 inv lazy.  data = `count` consecutive RNS components
+    // starting at prime index `first` of level `chain_index` (each N words).
+    int ref_ntt(void *ctx, uint64_t chain_index, uint64_t first, uint64_t count, int mode, uint64_t *data)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 1;
+        size_t n = l->parms().poly_modulus_degree();
+        for (uint64_t i = 0; i < count; i++)
+        {
+            auto &t = l->small_ntt_tables()[first + i];
+            CoeffIter it(data + i * n);
+            switch (mode)
+            {
+            case 0:
+                ntt_negacyclic_harvey(it, t);
+                break;
+            case 1:
+                ntt_negacyclic_harvey_lazy(it, t);
+                break;
+            case 2:
+                inverse_ntt_negacyclic_harvey(it, t);
+                break;
+            default:
+                inverse_ntt_negacyclic_harvey_lazy(it, t);
+            }
+        }
+        REF_CATCH
+    }
+    int ref_dyadic_product(void *ctx, uint64_t chain_index, uint64_t idx, const uint64_t *a, const uint64_t *b, uint64_t *r)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        size_t n = l->parms().poly_modulus_degree();
+        dyadic_product_coeffmod(ConstCoeffIter(a), ConstCoeffIter(b), n, l->parms().coeff_modulus()[idx], CoeffIter(r));
+        REF_CATCH
+    }
+    // GaloisTool::apply_galois (galois.cpp:148) / apply_galois_ntt (galois.cpp:192) on K comps.
+    int ref_apply_galois_raw(void *ctx, uint64_t chain_index, int ntt_form, uint32_t elt, const uint64_t *in, uint64_t *out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        size_t n = l->parms().poly_modulus_degree();
+        size_t k = l->parms().coeff_modulus().size();
+        auto gt = c->context->key_context_data()->galois_tool();
+        if (ntt_form)
+            gt->apply_galois_ntt(ConstRNSIter(in, n), k, elt, RNSIter(out, n));
+        else
+            gt->apply_galois(ConstRNSIter(in, n), k, elt, iter(l->parms().coeff_modulus()), RNSIter(out, n));
+        REF_CATCH
+    }
+    // RNSTool stages (rns.cpp): which = 0 fastbconv_m_tilde (q -> Bsk U m~), 1 sm_mrq (Bsk U m~ -> Bsk),
+    // 2 fast_floor (q U Bsk -> Bsk), 3 fastbconv_sk (Bsk -> q), 4 divide_and_round_q_last_inplace,
+    // 5 divide_and_round_q_last_ntt_inplace.  For 4/5 `out` receives the full in-place buffer.
+    int ref_rns_stage(void *ctx, uint64_t chain_index, int which, const uint64_t *in, uint64_t *out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        size_t n = l->parms().poly_modulus_degree();
+        size_t k = l->parms().coeff_modulus().size();
+        auto rt = l->rns_tool();
+        auto pool = MemoryManager::GetPool();
+        switch (which)
+        {
+        case 0:
+            rt->fastbconv_m_tilde(ConstRNSIter(in, n), RNSIter(out, n), pool);
+            break;
+        case 1:
+            rt->sm_mrq(ConstRNSIter(in, n), RNSIter(out, n), pool);
+            break;
+        case 2:
+            rt->fast_floor(ConstRNSIter(in, n), RNSIter(out, n), pool);
+            break;
+        case 3:
+            rt->fastbconv_sk(ConstRNSIter(in, n), RNSIter(out, n), pool);
+            break;
+        case 4:
+            std::memcpy(out, in, k * n * sizeof(uint64_t));
+            rt->divide_and_round_q_last_inplace(RNSIter(out, n), pool);
+            break;
+        case 5:
+            std::memcpy(out, in, k * n * sizeof(uint64_t));
+            rt->divide_and_round_q_last_ntt_inplace(RNSIter(out, n), iter(l->small_ntt_tables()), pool);
+            break;
+        default:
+            return 1;
+        }
+        REF_CATCH
+    }
+
+    // ---- encode / encrypt / decrypt (host-side helpers for the semantic round-trip tests) ----
+    int ref_ckks_encrypt(void *ctx, const double *values, uint64_t count, double scale, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        if (!c->have_pk)
+        {
+            c->keygen->create_public_key(c->pk);
+            c->have_pk = true;
+        }
+        CKKSEncoder enc(*c->context);
+        Plaintext p;
+        std::vector<double> v(values, values + count);
+        enc.encode(v, scale, p);
+        Encryptor e(*c->context, c->pk);
+        auto h = std::make_unique<RefCt>();
+        e.encrypt(p, h->ct);
+        *out = h.release();
+        REF_CATCH
+    }
+    int ref_ckks_decrypt(void *ctx, void *ct, double *values, uint64_t count)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        Decryptor d(*c->context, c->keygen->secret_key());
+        Plaintext p;
+        d.decrypt(CT(ct), p);
+        CKKSEncoder enc(*c->context);
+        std::vector<double> v;
+        enc.decode(p, v);
+        for (uint64_t i = 0; i < count && i < v.size(); i++)
+            values[i] = v[i];
+        REF_CATCH
+    }
+    int ref_batch_encrypt(void *ctx, const uint64_t *values, uint64_t count, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        if (!c->have_pk)
+        {
+            c->keygen->create_public_key(c->pk);
+            c->have_pk = true;
+        }
+        BatchEncoder enc(*c->context);
+        Plaintext p;
+        std::vector<uint64_t> v(values, values + count);
+        v.resize(enc.slot_count());
+        enc.encode(v, p);
+        Encryptor e(*c->context, c->pk);
+        auto h = std::make_unique<RefCt>();
+        e.encrypt(p, h->ct);
+        *out = h.release();
+        REF_CATCH
+    }
+    int ref_batch_decrypt(void *ctx, void *ct, uint64_t *values, uint64_t count)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        Decryptor d(*c->context, c->keygen->secret_key());
+        Plaintext p;
+        d.decrypt(CT(ct), p);
+        BatchEncoder enc(*c->context);
+        std::vector<uint64_t> v;
+        enc.decode(p, v);
+        for (uint64_t i = 0; i < count && i < v.size(); i++)
+            values[i] = v[i];
+        REF_CATCH
+    }
+
+    // ---- CPU baseline: time the reference Evaluator on the host cores ---------------------
+    // Synthetic size-2 ciphertexts at the first data level, every RNS component uniform in
+    // [0, q_i) from mt19937_64(0x5EA1 + index) (restating BMEnv::randomize_ct_*, native/bench/bench.h:195-270).
+    // pipeline: 0 = CKKS multiply + relinearize + rescale_to_next (north-star),
+    //           1 = BFV multiply + relinearize + mod_switch_to_next,
+    //           2 = rotate_vector(1) (ckks) / rotate_rows(1) (bfv) [+ rescale for ckks],
+    //           3 = forward+inverse NTT of all comps of one size-2 ciphertext.
+    // Each of `threads` threads runs one untimed warm-up pass (pool first-touch, bench.cpp:28-33),
+    // then `reps` timed passes on its own ciphertexts.  Returns seconds for the timed region
+    // (max over threads) in *seconds; processed ciphertexts = threads * reps.
+    int ref_time_pipeline(void *ctx, int pipeline, int threads, int reps, double *seconds)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto &context = *c->context;
+        auto first = context.first_context_data();
+        auto &mods = first->parms().coeff_modulus();
+        size_t n = first->parms().poly_modulus_degree();
+        size_t k = mods.size();
+        bool ckks = c->scheme == scheme_type::ckks;
+        double scale = ckks ? std::pow(2.0, mods.back().bit_count() / 2 - 1) : 1.0;
+        auto make_ct = [&](uint64_t seed) {
+            Ciphertext ct;
+            ct.resize(context, first->parms_id(), 2);
+            std::mt19937_64 rng(seed);
+            for (size_t p = 0; p < 2; p++)
+                for (size_t i = 0; i < k; i++)
+                {
+                    std::uniform_int_distribution<uint64_t> dist(0, mods[i].value() - 1);
+                    uint64_t *d = ct.data(p) + i * n;
+                    for (size_t j = 0; j < n; j++)
+                        d[j] = dist(rng);
+                }
+            ct.is_ntt_form() = ckks;
+            ct.scale() = scale;
+            return ct;
+        };
+        std::vector<double> secs(threads, 0.0);
+        std::vector<int> errs(threads, 0);
+        auto worker = [&](int tid) {
+            try
+            {
+                Ciphertext a = make_ct(0x5EA1 + 2 * tid), b = make_ct(0x5EA1 + 2 * tid + 1), w;
+                auto pass = [&]() {
+                    w = a;
+                    switch (pipeline)
+                    {
+                    case 0:
+                        c->evaluator->multiply_inplace(w, b);
+                        c->evaluator->relinearize_inplace(w, c->rlk);
+                        c->evaluator->rescale_to_next_inplace(w);
+                        break;
+                    case 1:
+                        c->evaluator->multiply_inplace(w, b);
+                        c->evaluator->relinearize_inplace(w, c->rlk);
+                        c->evaluator->mod_switch_to_next_inplace(w);
+                        break;
+                    case 2:
+                        if (ckks)
+                        {
+                            c->evaluator->rotate_vector_inplace(w, 1, c->glk);
+                            c->evaluator->rescale_to_next_inplace(w);
+                        }
+                        else
+                            c->evaluator->rotate_rows_inplace(w, 1, c->glk);
+                        break;
+                    default:
+                        if (ckks)
+                        {
+                            c->evaluator->transform_from_ntt_inplace(w);
+                            c->evaluator->transform_to_ntt_inplace(w);
+                        }
+                        else
+                        {
+                            c->evaluator->transform_to_ntt_inplace(w);
+                            c->evaluator->transform_from_ntt_inplace(w);
+                        }
+                    }
+                };
+                pass(); // warm-up
+                auto t0 = std::chrono::steady_clock::now();
+                for (int r = 0; r < reps; r++)
+                    pass();
+                auto t1 = std::chrono::steady_clock::now();
+                secs[tid] = std::chrono::duration<double>(t1 - t0).count();
+            }
+            catch (...)
+            {
+                errs[tid] = 1;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++)
+            pool.emplace_back(worker, t);
+        for (auto &t : pool)
+            t.join();
+        double mx = 0;
+        for (int t = 0; t < threads; t++)
+        {
+            if (errs[t])
+                return 4;
+            mx = std::max(mx, secs[t]);
+        }
+        *seconds = mx;
+        REF_CATCH
+    }
+}

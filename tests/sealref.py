@@ -1,0 +1,292 @@
+"""ctypes wrapper over oracle/_ref/libsealref.so — the REAL reference (Microsoft SEAL 4.4.3,
+HEXL off) compiled from /root/reference by oracle/Makefile.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+`available()` is False when the prebuilt library is absent (then tests fall back to the
+plain-C restatement in oracle/seal_oracle.c and to tests/golden/ fixtures).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "oracle", "_ref", "libsealref.so")
+
+_lib = None
+
+
+def available():
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(LIB_PATH)
+        _lib.ref_galois_elt_from_step.restype = C.c_uint64
+    return _lib
+
+
+class RefError(Exception):
+    NAMES = {1: "invalid_argument", 2: "logic_error", 3: "out_of_range", 4: "other"}
+
+    def __init__(self, code):
+        super().__init__(self.NAMES.get(code, str(code)))
+        self.code = code
+
+
+def _ck(rc):
+    if rc != 0:
+        raise RefError(rc)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+SCHEME = {"bfv": 1, "ckks": 2, "bgv": 3}
+
+
+def coeff_modulus_create(n, bit_sizes):
+    bits = (C.c_int * len(bit_sizes))(*bit_sizes)
+    out = np.zeros(len(bit_sizes), dtype=np.uint64)
+    _ck(lib().ref_coeff_modulus_create(C.c_uint64(n), bits, C.c_uint64(len(bit_sizes)), _p(out)))
+    return [int(x) for x in out]
+
+
+def plain_modulus_batching(n, bits):
+    out = C.c_uint64()
+    _ck(lib().ref_plain_modulus_batching(C.c_uint64(n), C.c_int(bits), C.byref(out)))
+    return out.value
+
+
+def bfv_default(n):
+    out = np.zeros(64, dtype=np.uint64)
+    cnt = C.c_uint64()
+    _ck(lib().ref_bfv_default(C.c_uint64(n), _p(out), C.byref(cnt)))
+    return [int(x) for x in out[: cnt.value]]
+
+
+class RefCiphertext:
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    def __del__(self):
+        if self.h:
+            lib().ref_ct_destroy(self.h)
+            self.h = None
+
+    def info(self):
+        ci, size, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ntt = C.c_int()
+        scale = C.c_double()
+        cf = C.c_uint64()
+        lib().ref_ct_info(self.ctx.h, self.h, C.byref(ci), C.byref(size), C.byref(k), C.byref(ntt),
+                          C.byref(scale), C.byref(cf))
+        return dict(chain_index=ci.value, size=size.value, coeff_modulus_size=k.value,
+                    is_ntt_form=bool(ntt.value), scale=scale.value, correction_factor=cf.value)
+
+    def data(self):
+        i = self.info()
+        out = np.zeros((i["size"], i["coeff_modulus_size"], self.ctx.n), dtype=np.uint64)
+        lib().ref_ct_data(self.h, _p(out))
+        return out
+
+    def copy(self):
+        h = C.c_void_p()
+        _ck(lib().ref_ct_copy(self.h, C.byref(h)))
+        return RefCiphertext(self.ctx, h)
+
+
+class RefContext:
+    """SEALContext(parms, expand_mod_chain=True, sec_level_type::none) + KeyGenerator + Evaluator."""
+
+    def __init__(self, scheme, n, primes, plain_modulus=0, seed=0x5EA1):
+        self.scheme = scheme
+        self.n = n
+        self.primes = list(primes)
+        self.plain_modulus = plain_modulus
+        arr = np.array(primes, dtype=np.uint64)
+        h = C.c_void_p()
+        _ck(lib().ref_ctx_create(C.c_int(SCHEME[scheme]), C.c_uint64(n), _p(arr), C.c_uint64(len(primes)),
+                                 C.c_uint64(plain_modulus), C.c_uint64(seed), C.byref(h)))
+        self.h = h
+        a, b, u = C.c_uint64(), C.c_uint64(), C.c_int()
+        lib().ref_ctx_info(self.h, C.byref(a), C.byref(b), C.byref(u))
+        self.key_chain_index, self.first_chain_index, self.using_keyswitching = a.value, b.value, bool(u.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ref_ctx_destroy(self.h)
+            self.h = None
+
+    # -- introspection
+    def level_primes(self, chain_index):
+        out = np.zeros(256, dtype=np.uint64)
+        cnt = C.c_uint64()
+        _ck(lib().ref_ctx_level_primes(self.h, C.c_uint64(chain_index), _p(out), C.byref(cnt)))
+        return [int(x) for x in out[: cnt.value]]
+
+    def ntt_tables(self, chain_index, idx, want_tables=True):
+        root, invn = C.c_uint64(), C.c_uint64()
+        fwd = np.zeros(self.n, dtype=np.uint64) if want_tables else None
+        inv = np.zeros(self.n, dtype=np.uint64) if want_tables else None
+        _ck(lib().ref_ctx_ntt_tables(self.h, C.c_uint64(chain_index), C.c_uint64(idx), C.byref(root), C.byref(invn),
+                                     _p(fwd) if want_tables else None, _p(inv) if want_tables else None))
+        return root.value, invn.value, fwd, inv
+
+    def behz_bases(self, chain_index):
+        bsk = np.zeros(260, dtype=np.uint64)
+        cnt, mt, g = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        _ck(lib().ref_ctx_behz_bases(self.h, C.c_uint64(chain_index), _p(bsk), C.byref(cnt), C.byref(mt), C.byref(g)))
+        return [int(x) for x in bsk[: cnt.value]], mt.value, g.value
+
+    # -- keys
+    def keygen_relin(self):
+        _ck(lib().ref_keygen_relin(self.h))
+
+    def keygen_galois_elts(self, elts):
+        a = (C.c_uint32 * len(elts))(*elts)
+        _ck(lib().ref_keygen_galois_elts(self.h, a, C.c_uint64(len(elts))))
+
+    def keygen_galois_steps(self, steps):
+        a = (C.c_int * len(steps))(*steps)
+        _ck(lib().ref_keygen_galois_steps(self.h, a, C.c_uint64(len(steps))))
+
+    def key(self, kind, index):
+        """-> uint64 array [digits][2][L][N]; kind 'relin' | 'galois'."""
+        k = 0 if kind == "relin" else 1
+        nd = C.c_uint64()
+        _ck(lib().ref_key_digits(self.h, C.c_int(k), C.c_uint64(index), C.byref(nd)))
+        L = len(self.primes)
+        out = np.zeros((nd.value, 2, L, self.n), dtype=np.uint64)
+        _ck(lib().ref_key_copy(self.h, C.c_int(k), C.c_uint64(index), _p(out)))
+        return out
+
+    def galois_elt_from_step(self, step):
+        return int(lib().ref_galois_elt_from_step(self.h, C.c_int(step)))
+
+    # -- ciphertexts
+    def ct(self, chain_index, data, is_ntt, scale=1.0, correction_factor=1):
+        data = np.ascontiguousarray(data, dtype=np.uint64)
+        h = C.c_void_p()
+        _ck(lib().ref_ct_create(self.h, C.c_uint64(chain_index), C.c_uint64(data.shape[0]), C.c_int(int(is_ntt)),
+                                C.c_double(scale), C.c_uint64(correction_factor), _p(data), C.byref(h)))
+        return RefCiphertext(self, h)
+
+    def _op1(self, name, ct, *args):
+        _ck(getattr(lib(), name)(self.h, ct.h, *args))
+        return ct
+
+    def multiply_inplace(self, a, b):
+        _ck(lib().ref_multiply_inplace(self.h, a.h, b.h))
+        return a
+
+    def add_inplace(self, a, b):
+        _ck(lib().ref_add_inplace(self.h, a.h, b.h))
+        return a
+
+    def sub_inplace(self, a, b):
+        _ck(lib().ref_sub_inplace(self.h, a.h, b.h))
+        return a
+
+    def square_inplace(self, a):
+        return self._op1("ref_square_inplace", a)
+
+    def negate_inplace(self, a):
+        return self._op1("ref_negate_inplace", a)
+
+    def relinearize_inplace(self, a):
+        return self._op1("ref_relinearize_inplace", a)
+
+    def rescale_to_next_inplace(self, a):
+        return self._op1("ref_rescale_to_next_inplace", a)
+
+    def mod_switch_to_next_inplace(self, a):
+        return self._op1("ref_mod_switch_to_next_inplace", a)
+
+    def mod_reduce_to_next_inplace(self, a):
+        return self._op1("ref_mod_reduce_to_next_inplace", a)
+
+    def rotate_vector_inplace(self, a, steps):
+        return self._op1("ref_rotate_vector_inplace", a, C.c_int(steps))
+
+    def rotate_rows_inplace(self, a, steps):
+        return self._op1("ref_rotate_rows_inplace", a, C.c_int(steps))
+
+    def rotate_columns_inplace(self, a):
+        return self._op1("ref_rotate_columns_inplace", a)
+
+    def complex_conjugate_inplace(self, a):
+        return self._op1("ref_complex_conjugate_inplace", a)
+
+    def apply_galois_inplace(self, a, elt):
+        return self._op1("ref_apply_galois_inplace", a, C.c_uint32(elt))
+
+    def transform_to_ntt_inplace(self, a):
+        return self._op1("ref_transform_to_ntt_inplace", a)
+
+    def transform_from_ntt_inplace(self, a):
+        return self._op1("ref_transform_from_ntt_inplace", a)
+
+    # -- L1 kernels
+    def ntt(self, chain_index, first, data, mode):
+        """data [count][N] consecutive comps starting at prime `first`; mode fwd|fwd_lazy|inv|inv_lazy."""
+        m = {"fwd": 0, "fwd_lazy": 1, "inv": 2, "inv_lazy": 3}[mode]
+        d = np.ascontiguousarray(data, dtype=np.uint64).copy()
+        _ck(lib().ref_ntt(self.h, C.c_uint64(chain_index), C.c_uint64(first), C.c_uint64(d.shape[0]), C.c_int(m), _p(d)))
+        return d
+
+    def dyadic_product(self, chain_index, idx, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        r = np.zeros_like(a)
+        _ck(lib().ref_dyadic_product(self.h, C.c_uint64(chain_index), C.c_uint64(idx), _p(a), _p(b), _p(r)))
+        return r
+
+    def apply_galois_raw(self, chain_index, ntt_form, elt, data):
+        d = np.ascontiguousarray(data, dtype=np.uint64)
+        out = np.zeros_like(d)
+        _ck(lib().ref_apply_galois_raw(self.h, C.c_uint64(chain_index), C.c_int(int(ntt_form)), C.c_uint32(elt),
+                                       _p(d), _p(out)))
+        return out
+
+    def rns_stage(self, chain_index, which, data, out_comps):
+        w = {"fastbconv_m_tilde": 0, "sm_mrq": 1, "fast_floor": 2, "fastbconv_sk": 3,
+             "divide_and_round_q_last": 4, "divide_and_round_q_last_ntt": 5}[which]
+        d = np.ascontiguousarray(data, dtype=np.uint64)
+        out = np.zeros((out_comps, self.n), dtype=np.uint64)
+        _ck(lib().ref_rns_stage(self.h, C.c_uint64(chain_index), C.c_int(w), _p(d), _p(out)))
+        return out
+
+    # -- encode/encrypt helpers
+    def ckks_encrypt(self, values, scale):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        h = C.c_void_p()
+        _ck(lib().ref_ckks_encrypt(self.h, _p(v), C.c_uint64(len(v)), C.c_double(scale), C.byref(h)))
+        return RefCiphertext(self, h)
+
+    def ckks_decrypt(self, ct, count):
+        out = np.zeros(count, dtype=np.float64)
+        _ck(lib().ref_ckks_decrypt(self.h, ct.h, _p(out), C.c_uint64(count)))
+        return out
+
+    def batch_encrypt(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        h = C.c_void_p()
+        _ck(lib().ref_batch_encrypt(self.h, _p(v), C.c_uint64(len(v)), C.byref(h)))
+        return RefCiphertext(self, h)
+
+    def batch_decrypt(self, ct, count):
+        out = np.zeros(count, dtype=np.uint64)
+        _ck(lib().ref_batch_decrypt(self.h, ct.h, _p(out), C.c_uint64(count)))
+        return out
+
+    # -- CPU baseline
+    def time_pipeline(self, pipeline, threads, reps):
+        p = {"ckks_mul_relin_rescale": 0, "bfv_mul_relin_modswitch": 1, "rotate": 2, "ntt": 3}[pipeline]
+        s = C.c_double()
+        _ck(lib().ref_time_pipeline(self.h, C.c_int(p), C.c_int(threads), C.c_int(reps), C.byref(s)))
+        return s.value
