@@ -1,0 +1,205 @@
+/*
+ * sealhip.h — C ABI of libsealhip.so: the MI355X (gfx950) implementation of Microsoft SEAL's
+ * RNS polynomial-arithmetic hot path (negacyclic NTT/INTT, dyadic products, BEHZ base conversion,
+ * and the Evaluator ciphertext operations multiply / relinearize / rescale / rotate / mod_switch).
+ *
+ * The reference has no plugin boundary for this path (seal::Evaluator is a concrete class,
+ * native/src/seal/evaluator.h:79-1387); the FFI it does ship is the flat "sealc" export layer that
+ * the .NET wrapper P/Invokes (native/src/seal/c/, SEAL_C_FUNC ... HRESULT).  This header follows
+ * that layer: the same entry-point names, argument order, HRESULT values and exception-to-HRESULT
+ * mapping (native/src/seal/c/defines.h:36-97), so a binding written against sealc's Evaluator_* /
+ * Ciphertext_* / KSwitchKeys_* / SEALContext_* functions binds to these with two deliberate
+ * differences, both forced by the data living in HBM:
+ *   (1) a Ciphertext handle is a DEVICE-RESIDENT BATCH of `batch` ciphertexts that share metadata
+ *       (parms_id, size, is_ntt_form, scale): word index of coefficient j of RNS component r of
+ *       polynomial p of batch item b is ((p*batch + b)*coeff_modulus_size + r)*N + j — for batch == 1
+ *       this is exactly Ciphertext::data() (native/src/seal/ciphertext.h:337-349);
+ *   (2) the `void *pool` argument of the sealc signatures is kept for signature compatibility and
+ *       must be NULL (a MemoryPoolHandle has no device meaning); work is enqueued on the
+ *       Evaluator's HIP stream (Evaluator_SetStream) and is asynchronous until Evaluator_Synchronize
+ *       or a Ciphertext_CopyToHost.
+ * No C++ type, exception or torch type crosses this boundary.
+ *
+ * Section 2 ("shl_*") is the finer per-kernel seam, the analogue of the reference's only accelerator
+ * hook (the HEXL #ifdef in native/src/seal/util/ntt.cpp:394-475 and polyarithsmallmod.cpp:18-284),
+ * taking raw device pointers; it exists for kernel-level parity tests and roofline measurements.
+ */
+#ifndef SEALHIP_H
+#define SEALHIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* HRESULT values of native/src/seal/c/defines.h:36-60 (non-Windows branch). */
+typedef long SHL_HRESULT;
+#define SHL_S_OK ((SHL_HRESULT)0L)
+#define SHL_S_FALSE ((SHL_HRESULT)1L)
+#define SHL_E_POINTER ((SHL_HRESULT)0x80004003L)
+#define SHL_E_INVALIDARG ((SHL_HRESULT)0x80070057L)
+#define SHL_E_OUTOFMEMORY ((SHL_HRESULT)0x8007000EL)
+#define SHL_E_UNEXPECTED ((SHL_HRESULT)0x8000FFFFL)
+#define SHL_COR_E_IO ((SHL_HRESULT)0x80131620L)             /* std::runtime_error (HIP failure) */
+#define SHL_COR_E_INVALIDOPERATION ((SHL_HRESULT)0x80131509L) /* std::logic_error */
+#define SHL_E_INVALID_INDEX ((SHL_HRESULT)0x80070585L)      /* HRESULT_FROM_WIN32(ERROR_INVALID_INDEX): std::out_of_range */
+
+#define SHL_FUNC SHL_HRESULT
+
+/* scheme_type (native/src/seal/encryptionparams.h): 0 none, 1 bfv, 2 ckks, 3 bgv */
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. sealc-shaped handle API
+ * ---------------------------------------------------------------------------------------------- */
+
+/* library / device */
+SHL_FUNC SealHip_Version(uint32_t *major, uint32_t *minor, uint32_t *patch);
+/* Fails with SHL_COR_E_IO when no gfx950 device is usable: there is no CPU fallback. */
+SHL_FUNC SealHip_DeviceInfo(char *name, uint64_t name_capacity, int *compute_units, uint64_t *hbm_bytes);
+/* last error text of the calling thread (what() of the C++ exception that produced the HRESULT) */
+SHL_FUNC SealHip_LastError(char *outstr, uint64_t *length);
+
+/* CoeffModulus::Create / PlainModulus::Batching (native/src/seal/c/modulus.h CoeffModulus_Create1) */
+SHL_FUNC CoeffModulus_Create1(uint64_t poly_modulus_degree, uint64_t length, int *bit_sizes, uint64_t *coeffs);
+SHL_FUNC PlainModulus_Batching(uint64_t poly_modulus_degree, int bit_size, uint64_t *value);
+
+/* EncryptionParameters (native/src/seal/c/encryptionparameters.h) */
+SHL_FUNC EncParams_Create1(uint8_t scheme, void **enc_params);
+SHL_FUNC EncParams_Destroy(void *thisptr);
+SHL_FUNC EncParams_SetPolyModulusDegree(void *thisptr, uint64_t degree);
+SHL_FUNC EncParams_GetPolyModulusDegree(void *thisptr, uint64_t *degree);
+/* sealc passes Modulus handles; here the prime values directly */
+SHL_FUNC EncParams_SetCoeffModulus(void *thisptr, uint64_t length, const uint64_t *coeffs);
+SHL_FUNC EncParams_GetCoeffModulus(void *thisptr, uint64_t *length, uint64_t *coeffs);
+SHL_FUNC EncParams_SetPlainModulus2(void *thisptr, uint64_t plain_modulus);
+SHL_FUNC EncParams_GetScheme(void *thisptr, uint8_t *scheme);
+
+/* SEALContext (native/src/seal/c/sealcontext.h, contextdata.h).  Builds the whole modulus-switching
+ * chain and uploads NTT tables / RNSTool constants to the current HIP device.  sec_level is accepted
+ * for signature compatibility; the HE-standard bound check is the caller's business (BASELINE configs
+ * use sec_level_type::none). */
+SHL_FUNC SEALContext_Create(void *encryptionParams, bool expand_mod_chain, int sec_level, void **context);
+SHL_FUNC SEALContext_Destroy(void *thisptr);
+SHL_FUNC SEALContext_KeyParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC SEALContext_FirstParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC SEALContext_LastParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC SEALContext_UsingKeyswitching(void *thisptr, bool *using_keyswitching);
+/* ContextData_ChainIndex / ContextData_NextContextData / ContextData_Parms collapsed onto the context */
+SHL_FUNC SEALContext_ChainIndex(void *thisptr, uint64_t *parms_id, uint64_t *chain_index);
+SHL_FUNC SEALContext_ParmsIdAt(void *thisptr, uint64_t chain_index, uint64_t *parms_id);
+SHL_FUNC SEALContext_CoeffModulusAt(void *thisptr, uint64_t chain_index, uint64_t *length, uint64_t *coeffs);
+SHL_FUNC SEALContext_TotalCoeffModulusBitCount(void *thisptr, uint64_t chain_index, int *bit_count);
+/* Register the reference's BLAKE2b parms_id for a level so both sides name levels identically. */
+SHL_FUNC SEALContext_SetParmsId(void *thisptr, uint64_t chain_index, uint64_t *parms_id);
+/* introspection used by the parity tests: minimal primitive 2N-th root of a pool prime, BEHZ base */
+SHL_FUNC SEALContext_NTTRoot(void *thisptr, uint64_t prime_index, uint64_t *root);
+SHL_FUNC SEALContext_BaseBsk(void *thisptr, uint64_t chain_index, uint64_t *length, uint64_t *primes);
+
+/* Ciphertext (native/src/seal/c/ciphertext.h) — device-resident batch */
+SHL_FUNC Ciphertext_Create3(void *context, void *pool, void **cipher);         /* batch = 1, empty */
+SHL_FUNC Ciphertext_CreateBatch(void *context, uint64_t batch, void **cipher); /* empty batch */
+SHL_FUNC Ciphertext_Create2(void *copy, void **cipher);
+SHL_FUNC Ciphertext_Set(void *thisptr, void *assign);
+SHL_FUNC Ciphertext_Destroy(void *thisptr);
+SHL_FUNC Ciphertext_Resize1(void *thisptr, void *context, uint64_t *parms_id, uint64_t size);
+SHL_FUNC Ciphertext_Size(void *thisptr, uint64_t *size);
+SHL_FUNC Ciphertext_BatchCount(void *thisptr, uint64_t *batch);
+SHL_FUNC Ciphertext_PolyModulusDegree(void *thisptr, uint64_t *poly_modulus_degree);
+SHL_FUNC Ciphertext_CoeffModulusSize(void *thisptr, uint64_t *coeff_modulus_size);
+SHL_FUNC Ciphertext_ParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC Ciphertext_IsNTTForm(void *thisptr, bool *is_ntt_form);
+SHL_FUNC Ciphertext_SetIsNTTForm(void *thisptr, bool is_ntt_form);
+SHL_FUNC Ciphertext_Scale(void *thisptr, double *scale);
+SHL_FUNC Ciphertext_SetScale(void *thisptr, double scale);
+SHL_FUNC Ciphertext_CorrectionFactor(void *thisptr, uint64_t *correction_factor);
+SHL_FUNC Ciphertext_SetCorrectionFactor(void *thisptr, uint64_t correction_factor);
+SHL_FUNC Ciphertext_IsTransparent(void *thisptr, bool *result); /* synchronises */
+/* device slab access (replaces Ciphertext_GetDataAt/SetDataAt) */
+SHL_FUNC Ciphertext_DevicePtr(void *thisptr, uint64_t **data, uint64_t *word_count);
+SHL_FUNC Ciphertext_CopyFromHost(void *thisptr, const uint64_t *src, uint64_t word_count);
+SHL_FUNC Ciphertext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count);
+SHL_FUNC Ciphertext_CopyFromDevice(void *thisptr, const uint64_t *src, uint64_t word_count, void *hip_stream);
+
+/* KSwitchKeys / RelinKeys / GaloisKeys (native/src/seal/c/kswitchkeys.h, relinkeys.h, galoiskeys.h).
+ * A key set lives in HBM; one key (index) is uploaded as the concatenation of its decomposition
+ * digits, each a size-2 key-level ciphertext in NTT form: [digit][2][L][N] words
+ * (KSwitchKeys::keys_[index][digit].data(), native/src/seal/kswitchkeys.h:340). */
+SHL_FUNC KSwitchKeys_Create1(void **kswitch_keys);
+SHL_FUNC KSwitchKeys_Destroy(void *thisptr);
+SHL_FUNC KSwitchKeys_Size(void *thisptr, uint64_t *size);
+SHL_FUNC KSwitchKeys_SetKey(void *thisptr, void *context, uint64_t index, uint64_t digits, const uint64_t *host_words);
+SHL_FUNC KSwitchKeys_SetKeyFromDevice(void *thisptr, void *context, uint64_t index, uint64_t digits, const uint64_t *device_words);
+SHL_FUNC KSwitchKeys_HasKey(void *thisptr, uint64_t index, bool *has_key);
+SHL_FUNC RelinKeys_GetIndex(uint64_t key_power, uint64_t *index);
+SHL_FUNC GaloisKeys_GetIndex(uint32_t galois_elt, uint64_t *index);
+/* GaloisTool::get_elt_from_step (native/src/seal/util/galois.cpp:53-95) */
+SHL_FUNC GaloisTool_GetEltFromStep(void *context, int step, uint32_t *galois_elt);
+
+/* Evaluator (native/src/seal/c/evaluator.h).  `destination` may equal `encrypted` (in place). */
+SHL_FUNC Evaluator_Create(void *context, void **evaluator);
+SHL_FUNC Evaluator_Destroy(void *thisptr);
+SHL_FUNC Evaluator_SetStream(void *thisptr, void *hip_stream);
+SHL_FUNC Evaluator_Synchronize(void *thisptr);
+/* SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (evaluator.cpp:386-392) costs a device->host round trip per
+ * operation: off by default for device-resident batches, switch on for drop-in error parity. */
+SHL_FUNC Evaluator_SetTransparentCheck(void *thisptr, bool enabled);
+SHL_FUNC Evaluator_Negate(void *thisptr, void *encrypted, void *destination);
+SHL_FUNC Evaluator_Add(void *thisptr, void *encrypted1, void *encrypted2, void *destination);
+SHL_FUNC Evaluator_Sub(void *thisptr, void *encrypted1, void *encrypted2, void *destination);
+SHL_FUNC Evaluator_Multiply(void *thisptr, void *encrypted1, void *encrypted2, void *destination, void *pool);
+SHL_FUNC Evaluator_Square(void *thisptr, void *encrypted, void *destination, void *pool);
+SHL_FUNC Evaluator_Relinearize(void *thisptr, void *encrypted, void *relinKeys, void *destination, void *pool);
+SHL_FUNC Evaluator_ModSwitchToNext1(void *thisptr, void *encrypted, void *destination, void *pool);
+SHL_FUNC Evaluator_ModSwitchTo1(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool);
+SHL_FUNC Evaluator_RescaleToNext(void *thisptr, void *encrypted, void *destination, void *pool);
+SHL_FUNC Evaluator_RescaleTo(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool);
+SHL_FUNC Evaluator_ModReduceToNext(void *thisptr, void *encrypted, void *destination, void *pool);
+SHL_FUNC Evaluator_TransformToNTT2(void *thisptr, void *encrypted, void *destination_ntt);
+SHL_FUNC Evaluator_TransformFromNTT(void *thisptr, void *encrypted_ntt, void *destination);
+SHL_FUNC Evaluator_ApplyGalois(void *thisptr, void *encrypted, uint32_t galois_elt, void *galoisKeys, void *destination, void *pool);
+SHL_FUNC Evaluator_RotateRows(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *destination, void *pool);
+SHL_FUNC Evaluator_RotateColumns(void *thisptr, void *encrypted, void *galois_keys, void *destination, void *pool);
+SHL_FUNC Evaluator_RotateVector(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *destination, void *pool);
+SHL_FUNC Evaluator_ComplexConjugate(void *thisptr, void *encrypted, void *galoisKeys, void *destination, void *pool);
+SHL_FUNC Evaluator_ContextUsingKeyswitching(void *thisptr, bool *using_keyswitching);
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Per-kernel seam on raw device slabs (device pointers; `stream` is a hipStream_t or NULL)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ntt_negacyclic_harvey[_lazy] / inverse_ntt_negacyclic_harvey[_lazy] (util/ntt.cpp:394-475) over
+ * `polys` polynomials of `comps` consecutive RNS components starting at pool prime `first_prime`;
+ * data = [polys][comps][N].  lazy != 0 leaves the reference's lazy range ([0,4q) fwd / [0,2q) inv). */
+SHL_FUNC shl_ntt_forward(void *context, uint64_t *data, uint64_t polys, uint64_t comps, uint64_t first_prime, int lazy, void *stream);
+SHL_FUNC shl_ntt_inverse(void *context, uint64_t *data, uint64_t polys, uint64_t comps, uint64_t first_prime, int lazy, void *stream);
+/* dyadic_product_coeffmod (util/polyarithsmallmod.cpp:226-284): r = a .* b, operands may be lazy (< 4q) */
+SHL_FUNC shl_dyadic_product(void *context, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t polys, uint64_t comps, uint64_t first_prime, void *stream);
+/* GaloisTool::apply_galois (ntt_form == 0, util/galois.cpp:148) / apply_galois_ntt (!= 0, galois.cpp:192) */
+SHL_FUNC shl_apply_galois(void *context, uint64_t chain_index, int ntt_form, uint32_t galois_elt, const uint64_t *in, uint64_t *out, uint64_t polys, void *stream);
+/* RNSTool stages (util/rns.cpp) on one level, `polys` polynomials each [comps][N]:
+ *   0 fastbconv_m_tilde  q -> Bsk U {m~}      (rns.cpp:1086)     in K comps,        out |Bsk|+1
+ *   1 sm_mrq             Bsk U {m~} -> Bsk    (rns.cpp:979)      in |Bsk|+1,        out |Bsk|
+ *   2 fast_floor         q U Bsk -> Bsk       (rns.cpp:1041)     in K+|Bsk|,        out |Bsk|
+ *   3 fastbconv_sk       Bsk -> q             (rns.cpp:903)      in |Bsk|,          out K
+ *   4 divide_and_round_q_last_inplace         (rns.cpp:789)      in K,              out K-1
+ *   5 divide_and_round_q_last_ntt_inplace     (rns.cpp:830)      in K,              out K-1 */
+SHL_FUNC shl_rns_stage(void *context, uint64_t chain_index, int which, const uint64_t *in, uint64_t *out, uint64_t polys, void *stream);
+/* device memory helpers for bindings without their own allocator */
+SHL_FUNC shl_malloc(uint64_t bytes, void **device_ptr);
+SHL_FUNC shl_free(void *device_ptr);
+SHL_FUNC shl_memcpy_h2d(void *device_dst, const void *host_src, uint64_t bytes);
+SHL_FUNC shl_memcpy_d2h(void *host_dst, const void *device_src, uint64_t bytes);
+SHL_FUNC shl_device_synchronize(void);
+/* HIP-event timing on the library's stream (bench.py measures kernels where they are launched) */
+SHL_FUNC shl_timer_create(void **timer);
+SHL_FUNC shl_timer_destroy(void *timer);
+SHL_FUNC shl_timer_start(void *timer, void *stream);
+SHL_FUNC shl_timer_stop(void *timer, void *stream, float *milliseconds); /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEALHIP_H */

@@ -1,0 +1,530 @@
+"""Host-side mirror of the reference's object model for the hot path, over the C ABI.
+
+Class and method names follow seal::EncryptionParameters / SEALContext / Ciphertext / RelinKeys /
+GaloisKeys / Evaluator (native/src/seal/*.h) so that the parity tests read like the reference's own
+(native/tests/seal/evaluator.cpp).  A `Ciphertext` here is a device-resident *batch* of ciphertexts
+with shared metadata; numpy arrays cross the boundary as [size][batch][K][N] uint64 slabs
+(for batch == 1 that is Ciphertext::data(), ciphertext.h:337-349).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+SCHEME = {"none": 0, "bfv": 1, "ckks": 2, "bgv": 3}
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class CoeffModulus:
+    @staticmethod
+    def Create(poly_modulus_degree, bit_sizes):
+        """CoeffModulus::Create (modulus.cpp:143-184)."""
+        bits = (C.c_int * len(bit_sizes))(*bit_sizes)
+        out = np.zeros(len(bit_sizes), dtype=np.uint64)
+        N.check(N.lib().CoeffModulus_Create1(C.c_uint64(poly_modulus_degree), C.c_uint64(len(bit_sizes)), bits, _p(out)))
+        return [int(x) for x in out]
+
+
+class PlainModulus:
+    @staticmethod
+    def Batching(poly_modulus_degree, bit_size):
+        v = C.c_uint64()
+        N.check(N.lib().PlainModulus_Batching(C.c_uint64(poly_modulus_degree), C.c_int(bit_size), C.byref(v)))
+        return v.value
+
+
+class EncryptionParameters:
+    def __init__(self, scheme):
+        self.scheme = scheme
+        self._h = C.c_void_p()
+        N.check(N.lib().EncParams_Create1(C.c_uint8(SCHEME[scheme]), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().EncParams_Destroy(self._h)
+            self._h = None
+
+    def set_poly_modulus_degree(self, n):
+        N.check(N.lib().EncParams_SetPolyModulusDegree(self._h, C.c_uint64(n)))
+
+    def set_coeff_modulus(self, primes):
+        a = np.array(list(primes), dtype=np.uint64)
+        N.check(N.lib().EncParams_SetCoeffModulus(self._h, C.c_uint64(len(a)), _p(a)))
+
+    def set_plain_modulus(self, t):
+        N.check(N.lib().EncParams_SetPlainModulus2(self._h, C.c_uint64(t)))
+
+    def poly_modulus_degree(self):
+        v = C.c_uint64()
+        N.check(N.lib().EncParams_GetPolyModulusDegree(self._h, C.byref(v)))
+        return v.value
+
+    def coeff_modulus(self):
+        n = C.c_uint64()
+        N.check(N.lib().EncParams_GetCoeffModulus(self._h, C.byref(n), None))
+        out = np.zeros(n.value, dtype=np.uint64)
+        N.check(N.lib().EncParams_GetCoeffModulus(self._h, C.byref(n), _p(out)))
+        return [int(x) for x in out]
+
+
+class SEALContext:
+    """SEALContext(parms, expand_mod_chain, sec_level) — builds and uploads every table."""
+
+    def __init__(self, parms, expand_mod_chain=True, sec_level=0):
+        self.parms = parms
+        self._h = C.c_void_p()
+        N.check(N.lib().SEALContext_Create(parms._h, C.c_bool(expand_mod_chain), C.c_int(sec_level), C.byref(self._h)))
+        self.n = parms.poly_modulus_degree()
+        self.scheme = parms.scheme
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().SEALContext_Destroy(self._h)
+            self._h = None
+
+    def _pid(self, fn):
+        out = (C.c_uint64 * 4)()
+        N.check(getattr(N.lib(), fn)(self._h, out))
+        return tuple(out)
+
+    def key_parms_id(self):
+        return self._pid("SEALContext_KeyParmsId")
+
+    def first_parms_id(self):
+        return self._pid("SEALContext_FirstParmsId")
+
+    def last_parms_id(self):
+        return self._pid("SEALContext_LastParmsId")
+
+    def using_keyswitching(self):
+        b = C.c_bool()
+        N.check(N.lib().SEALContext_UsingKeyswitching(self._h, C.byref(b)))
+        return b.value
+
+    def chain_index(self, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        v = C.c_uint64()
+        N.check(N.lib().SEALContext_ChainIndex(self._h, pid, C.byref(v)))
+        return v.value
+
+    def parms_id_at(self, chain_index):
+        out = (C.c_uint64 * 4)()
+        N.check(N.lib().SEALContext_ParmsIdAt(self._h, C.c_uint64(chain_index), out))
+        return tuple(out)
+
+    def set_parms_id(self, chain_index, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().SEALContext_SetParmsId(self._h, C.c_uint64(chain_index), pid))
+
+    def coeff_modulus_at(self, chain_index):
+        n = C.c_uint64()
+        N.check(N.lib().SEALContext_CoeffModulusAt(self._h, C.c_uint64(chain_index), C.byref(n), None))
+        out = np.zeros(n.value, dtype=np.uint64)
+        N.check(N.lib().SEALContext_CoeffModulusAt(self._h, C.c_uint64(chain_index), C.byref(n), _p(out)))
+        return [int(x) for x in out]
+
+    def total_coeff_modulus_bit_count(self, chain_index):
+        v = C.c_int()
+        N.check(N.lib().SEALContext_TotalCoeffModulusBitCount(self._h, C.c_uint64(chain_index), C.byref(v)))
+        return v.value
+
+    def ntt_root(self, prime_index):
+        v = C.c_uint64()
+        N.check(N.lib().SEALContext_NTTRoot(self._h, C.c_uint64(prime_index), C.byref(v)))
+        return v.value
+
+    def base_bsk(self, chain_index):
+        n = C.c_uint64()
+        N.check(N.lib().SEALContext_BaseBsk(self._h, C.c_uint64(chain_index), C.byref(n), None))
+        out = np.zeros(max(n.value, 1), dtype=np.uint64)
+        N.check(N.lib().SEALContext_BaseBsk(self._h, C.c_uint64(chain_index), C.byref(n), _p(out)))
+        return [int(x) for x in out[: n.value]]
+
+    def galois_elt_from_step(self, step):
+        v = C.c_uint32()
+        N.check(N.lib().GaloisTool_GetEltFromStep(self._h, C.c_int(step), C.byref(v)))
+        return v.value
+
+
+class Ciphertext:
+    def __init__(self, context, batch=1, _copy_of=None):
+        self.context = context
+        self._h = C.c_void_p()
+        if _copy_of is not None:
+            N.check(N.lib().Ciphertext_Create2(_copy_of._h, C.byref(self._h)))
+        else:
+            N.check(N.lib().Ciphertext_CreateBatch(context._h, C.c_uint64(batch), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().Ciphertext_Destroy(self._h)
+            self._h = None
+
+    def copy(self):
+        return Ciphertext(self.context, _copy_of=self)
+
+    # -- metadata
+    def _get(self, fn, ctype):
+        v = ctype()
+        N.check(getattr(N.lib(), fn)(self._h, C.byref(v)))
+        return v.value
+
+    def size(self):
+        return self._get("Ciphertext_Size", C.c_uint64)
+
+    def batch(self):
+        return self._get("Ciphertext_BatchCount", C.c_uint64)
+
+    def coeff_modulus_size(self):
+        return self._get("Ciphertext_CoeffModulusSize", C.c_uint64)
+
+    def poly_modulus_degree(self):
+        return self._get("Ciphertext_PolyModulusDegree", C.c_uint64)
+
+    def is_ntt_form(self):
+        return self._get("Ciphertext_IsNTTForm", C.c_bool)
+
+    def scale(self):
+        return self._get("Ciphertext_Scale", C.c_double)
+
+    def correction_factor(self):
+        return self._get("Ciphertext_CorrectionFactor", C.c_uint64)
+
+    def parms_id(self):
+        out = (C.c_uint64 * 4)()
+        N.check(N.lib().Ciphertext_ParmsId(self._h, out))
+        return tuple(out)
+
+    def chain_index(self):
+        return self.context.chain_index(self.parms_id())
+
+    def set_is_ntt_form(self, v):
+        N.check(N.lib().Ciphertext_SetIsNTTForm(self._h, C.c_bool(v)))
+
+    def set_scale(self, v):
+        N.check(N.lib().Ciphertext_SetScale(self._h, C.c_double(v)))
+
+    def set_correction_factor(self, v):
+        N.check(N.lib().Ciphertext_SetCorrectionFactor(self._h, C.c_uint64(v)))
+
+    def is_transparent(self):
+        return self._get("Ciphertext_IsTransparent", C.c_bool)
+
+    def resize(self, parms_id, size):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Ciphertext_Resize1(self._h, self.context._h, pid, C.c_uint64(size)))
+
+    # -- data
+    def shape(self):
+        return (self.size(), self.batch(), self.coeff_modulus_size(), self.poly_modulus_degree())
+
+    def device_ptr(self):
+        ptr = C.c_void_p()
+        words = C.c_uint64()
+        N.check(N.lib().Ciphertext_DevicePtr(self._h, C.byref(ptr), C.byref(words)))
+        return ptr.value, words.value
+
+    def load(self, array):
+        """Host -> device.  array: uint64 [size][batch][K][N] (or [size][K][N] for batch == 1)."""
+        a = np.ascontiguousarray(array, dtype=np.uint64)
+        N.check(N.lib().Ciphertext_CopyFromHost(self._h, _p(a), C.c_uint64(a.size)))
+
+    def load_device(self, device_ptr, words, stream=None):
+        N.check(N.lib().Ciphertext_CopyFromDevice(self._h, C.c_void_p(device_ptr), C.c_uint64(words), C.c_void_p(stream or 0)))
+
+    def to_numpy(self):
+        out = np.zeros(self.shape(), dtype=np.uint64)
+        if out.size:
+            N.check(N.lib().Ciphertext_CopyToHost(self._h, _p(out), C.c_uint64(out.size)))
+        return out
+
+    @staticmethod
+    def from_numpy(context, array, parms_id, is_ntt_form, scale=1.0, correction_factor=1):
+        a = np.ascontiguousarray(array, dtype=np.uint64)
+        if a.ndim == 3:
+            a = a[:, None, :, :]
+        ct = Ciphertext(context, batch=a.shape[1])
+        ct.resize(parms_id, a.shape[0])
+        ct.set_is_ntt_form(is_ntt_form)
+        ct.set_scale(scale)
+        ct.set_correction_factor(correction_factor)
+        ct.load(a)
+        return ct
+
+
+class KSwitchKeys:
+    """Device-resident key-switching keys; slab per index: [digits][2][L][N] (kswitchkeys.h:340)."""
+
+    def __init__(self, context):
+        self.context = context
+        self._h = C.c_void_p()
+        N.check(N.lib().KSwitchKeys_Create1(C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().KSwitchKeys_Destroy(self._h)
+            self._h = None
+
+    def set_key(self, index, array):
+        a = np.ascontiguousarray(array, dtype=np.uint64)
+        N.check(N.lib().KSwitchKeys_SetKey(self._h, self.context._h, C.c_uint64(index), C.c_uint64(a.shape[0]), _p(a)))
+
+    def set_key_device(self, index, digits, device_ptr):
+        N.check(N.lib().KSwitchKeys_SetKeyFromDevice(self._h, self.context._h, C.c_uint64(index), C.c_uint64(digits),
+                                                     C.c_void_p(device_ptr)))
+
+    def has_index(self, index):
+        b = C.c_bool()
+        N.check(N.lib().KSwitchKeys_HasKey(self._h, C.c_uint64(index), C.byref(b)))
+        return b.value
+
+    def size(self):
+        v = C.c_uint64()
+        N.check(N.lib().KSwitchKeys_Size(self._h, C.byref(v)))
+        return v.value
+
+
+class RelinKeys(KSwitchKeys):
+    @staticmethod
+    def get_index(key_power):
+        v = C.c_uint64()
+        N.check(N.lib().RelinKeys_GetIndex(C.c_uint64(key_power), C.byref(v)))
+        return v.value
+
+    def has_key(self, key_power):
+        return self.has_index(self.get_index(key_power))
+
+
+class GaloisKeys(KSwitchKeys):
+    @staticmethod
+    def get_index(galois_elt):
+        v = C.c_uint64()
+        N.check(N.lib().GaloisKeys_GetIndex(C.c_uint32(galois_elt), C.byref(v)))
+        return v.value
+
+    def has_key(self, galois_elt):
+        return self.has_index(self.get_index(galois_elt))
+
+
+class Evaluator:
+    """seal::Evaluator's hot-path surface (evaluator.h:79-1387), in-place and destination forms."""
+
+    def __init__(self, context):
+        self.context = context
+        self._h = C.c_void_p()
+        N.check(N.lib().Evaluator_Create(context._h, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().Evaluator_Destroy(self._h)
+            self._h = None
+
+    def set_stream(self, stream):
+        N.check(N.lib().Evaluator_SetStream(self._h, C.c_void_p(stream or 0)))
+
+    def set_transparent_check(self, on):
+        N.check(N.lib().Evaluator_SetTransparentCheck(self._h, C.c_bool(on)))
+
+    def synchronize(self):
+        N.check(N.lib().Evaluator_Synchronize(self._h))
+
+    def _u(self, fn, a, dest, *extra, pool=False):
+        d = a if dest is None else dest
+        args = [self._h, a._h] + list(extra) + [d._h]
+        if pool:
+            args.append(None)
+        N.check(getattr(N.lib(), fn)(*args))
+        return d
+
+    def negate_inplace(self, a):
+        return self._u("Evaluator_Negate", a, None)
+
+    def negate(self, a, destination):
+        return self._u("Evaluator_Negate", a, destination)
+
+    def add_inplace(self, a, b):
+        N.check(N.lib().Evaluator_Add(self._h, a._h, b._h, a._h))
+        return a
+
+    def add(self, a, b, destination):
+        N.check(N.lib().Evaluator_Add(self._h, a._h, b._h, destination._h))
+        return destination
+
+    def sub_inplace(self, a, b):
+        N.check(N.lib().Evaluator_Sub(self._h, a._h, b._h, a._h))
+        return a
+
+    def sub(self, a, b, destination):
+        N.check(N.lib().Evaluator_Sub(self._h, a._h, b._h, destination._h))
+        return destination
+
+    def multiply_inplace(self, a, b):
+        N.check(N.lib().Evaluator_Multiply(self._h, a._h, b._h, a._h, None))
+        return a
+
+    def multiply(self, a, b, destination):
+        N.check(N.lib().Evaluator_Multiply(self._h, a._h, b._h, destination._h, None))
+        return destination
+
+    def square_inplace(self, a):
+        return self._u("Evaluator_Square", a, None, pool=True)
+
+    def square(self, a, destination):
+        return self._u("Evaluator_Square", a, destination, pool=True)
+
+    def relinearize_inplace(self, a, relin_keys):
+        N.check(N.lib().Evaluator_Relinearize(self._h, a._h, relin_keys._h, a._h, None))
+        return a
+
+    def relinearize(self, a, relin_keys, destination):
+        N.check(N.lib().Evaluator_Relinearize(self._h, a._h, relin_keys._h, destination._h, None))
+        return destination
+
+    def mod_switch_to_next_inplace(self, a):
+        return self._u("Evaluator_ModSwitchToNext1", a, None, pool=True)
+
+    def mod_switch_to_next(self, a, destination):
+        return self._u("Evaluator_ModSwitchToNext1", a, destination, pool=True)
+
+    def mod_switch_to_inplace(self, a, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Evaluator_ModSwitchTo1(self._h, a._h, pid, a._h, None))
+        return a
+
+    def rescale_to_next_inplace(self, a):
+        return self._u("Evaluator_RescaleToNext", a, None, pool=True)
+
+    def rescale_to_next(self, a, destination):
+        return self._u("Evaluator_RescaleToNext", a, destination, pool=True)
+
+    def rescale_to_inplace(self, a, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Evaluator_RescaleTo(self._h, a._h, pid, a._h, None))
+        return a
+
+    def mod_reduce_to_next_inplace(self, a):
+        return self._u("Evaluator_ModReduceToNext", a, None, pool=True)
+
+    def transform_to_ntt_inplace(self, a):
+        return self._u("Evaluator_TransformToNTT2", a, None)
+
+    def transform_from_ntt_inplace(self, a):
+        return self._u("Evaluator_TransformFromNTT", a, None)
+
+    def apply_galois_inplace(self, a, galois_elt, galois_keys):
+        N.check(N.lib().Evaluator_ApplyGalois(self._h, a._h, C.c_uint32(galois_elt), galois_keys._h, a._h, None))
+        return a
+
+    def rotate_rows_inplace(self, a, steps, galois_keys):
+        N.check(N.lib().Evaluator_RotateRows(self._h, a._h, C.c_int(steps), galois_keys._h, a._h, None))
+        return a
+
+    def rotate_columns_inplace(self, a, galois_keys):
+        N.check(N.lib().Evaluator_RotateColumns(self._h, a._h, galois_keys._h, a._h, None))
+        return a
+
+    def rotate_vector_inplace(self, a, steps, galois_keys):
+        N.check(N.lib().Evaluator_RotateVector(self._h, a._h, C.c_int(steps), galois_keys._h, a._h, None))
+        return a
+
+    def complex_conjugate_inplace(self, a, galois_keys):
+        N.check(N.lib().Evaluator_ComplexConjugate(self._h, a._h, galois_keys._h, a._h, None))
+        return a
+
+
+# ---- per-kernel seam on raw device slabs -------------------------------------------------------
+class DeviceBuffer:
+    """A raw uint64 slab in HBM (shl_malloc) for the per-kernel entry points."""
+
+    def __init__(self, words):
+        self.words = int(words)
+        self._ptr = C.c_void_p()
+        N.check(N.lib().shl_malloc(C.c_uint64(self.words * 8), C.byref(self._ptr)))
+
+    def __del__(self):
+        if getattr(self, "_ptr", None) and self._ptr.value:
+            N.lib().shl_free(self._ptr)
+            self._ptr = None
+
+    @property
+    def ptr(self):
+        return self._ptr.value
+
+    @staticmethod
+    def from_numpy(a):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = DeviceBuffer(a.size)
+        N.check(N.lib().shl_memcpy_h2d(b._ptr, _p(a), C.c_uint64(a.size * 8)))
+        return b
+
+    def to_numpy(self, shape):
+        out = np.zeros(shape, dtype=np.uint64)
+        N.check(N.lib().shl_memcpy_d2h(_p(out), self._ptr, C.c_uint64(out.size * 8)))
+        return out
+
+
+def ntt_forward(context, buf, polys, comps, first_prime=0, lazy=False, stream=None):
+    N.check(N.lib().shl_ntt_forward(context._h, C.c_void_p(buf.ptr), C.c_uint64(polys), C.c_uint64(comps),
+                                    C.c_uint64(first_prime), C.c_int(int(lazy)), C.c_void_p(stream or 0)))
+
+
+def ntt_inverse(context, buf, polys, comps, first_prime=0, lazy=False, stream=None):
+    N.check(N.lib().shl_ntt_inverse(context._h, C.c_void_p(buf.ptr), C.c_uint64(polys), C.c_uint64(comps),
+                                    C.c_uint64(first_prime), C.c_int(int(lazy)), C.c_void_p(stream or 0)))
+
+
+def dyadic_product(context, a, b, r, polys, comps, first_prime=0, stream=None):
+    N.check(N.lib().shl_dyadic_product(context._h, C.c_void_p(a.ptr), C.c_void_p(b.ptr), C.c_void_p(r.ptr),
+                                       C.c_uint64(polys), C.c_uint64(comps), C.c_uint64(first_prime),
+                                       C.c_void_p(stream or 0)))
+
+
+def apply_galois(context, chain_index, ntt_form, galois_elt, src, dst, polys, stream=None):
+    N.check(N.lib().shl_apply_galois(context._h, C.c_uint64(chain_index), C.c_int(int(ntt_form)), C.c_uint32(galois_elt),
+                                     C.c_void_p(src.ptr), C.c_void_p(dst.ptr), C.c_uint64(polys), C.c_void_p(stream or 0)))
+
+
+RNS_STAGE = {"fastbconv_m_tilde": 0, "sm_mrq": 1, "fast_floor": 2, "fastbconv_sk": 3,
+             "divide_and_round_q_last": 4, "divide_and_round_q_last_ntt": 5}
+
+
+def rns_stage(context, chain_index, which, src, dst, polys, stream=None):
+    N.check(N.lib().shl_rns_stage(context._h, C.c_uint64(chain_index), C.c_int(RNS_STAGE[which]), C.c_void_p(src.ptr),
+                                  C.c_void_p(dst.ptr), C.c_uint64(polys), C.c_void_p(stream or 0)))
+
+
+def device_synchronize():
+    N.check(N.lib().shl_device_synchronize())
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cus = C.c_int()
+    mem = C.c_uint64()
+    N.check(N.lib().SealHip_DeviceInfo(name, C.c_uint64(256), C.byref(cus), C.byref(mem)))
+    return name.value.decode(), cus.value, mem.value
+
+
+class HipTimer:
+    """HIP-event timer on a given stream (shl_timer_*)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        N.check(N.lib().shl_timer_create(C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().shl_timer_destroy(self._h)
+            self._h = None
+
+    def start(self, stream=None):
+        N.check(N.lib().shl_timer_start(self._h, C.c_void_p(stream or 0)))
+
+    def stop(self, stream=None):
+        ms = C.c_float()
+        N.check(N.lib().shl_timer_stop(self._h, C.c_void_p(stream or 0), C.byref(ms)))
+        return ms.value

@@ -1,0 +1,325 @@
+// BEHZ base conversions for BFV multiplication, one thread per coefficient.
+//
+// Restates RNSTool::fastbconv_m_tilde (util/rns.cpp:1086-1131), sm_mrq (979-1039), fast_floor
+// (1041-1084), fastbconv_sk (903-977) and BaseConverter::fast_convert_array (418-463).  These are
+// approximate conversions whose integer formulas must be reproduced literally: the
+// conversion result is x + alpha*Q with alpha fixed by exact integer arithmetic, so every dot
+// product below is the exact sum mod p (128-bit accumulate + Barrett-128), like dot_product_mod
+// (util/uintarithsmallmod.cpp:110-175).
+//
+// Shape: an O(|ibase| x |obase|) integer mat-vec per coefficient.  It stays on the VALU (64-bit
+// modular words, 128-bit accumulators — not an MFMA contraction).  Threads of a wave take
+// consecutive coefficients so every global access is a coalesced 512-byte row segment; the
+// per-coefficient input vector is parked in LDS as [component][thread] (conflict-free) so the
+// output loop can re-read it with the matrix row held in scalar registers.
+#include "poly_kernels.h"
+
+namespace sealhip
+{
+    namespace
+    {
+        constexpr unsigned kBlock = 256;
+
+        __device__ __forceinline__ void mac128(uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b)
+        {
+            uint64_t pl, ph;
+            mul_wide(a, b, pl, ph);
+            lo += pl;
+            hi += ph + (lo < pl);
+        }
+
+        // y_i = x_i * (Q/q_i)^-1 mod q_i (canonical) for i < count, staged in LDS as y[i*kBlock + tid].
+        // Then out_j = sum_i y_i * M[j*count + i] mod p_j.
+        __device__ __forceinline__ uint64_t dot_lds(const uint64_t *y, const uint64_t *row, unsigned count, const ModDesc &m)
+        {
+            uint64_t lo = 0, hi = 0;
+            for (unsigned i = 0; i < count; i++)
+                mac128(lo, hi, y[i * kBlock + threadIdx.x], row[i]);
+            return barrett128(lo, hi, m);
+        }
+
+        // ---- stage 0: q -> Bsk U {m~}   (fastbconv_m_tilde)
+        __device__ __forceinline__ void stage_fastbconv_m_tilde(
+            const ModDesc *mods, const LevelDev &lv, const uint64_t *in, uint64_t *out, size_t N, size_t j, uint64_t *y)
+        {
+            const unsigned K = lv.K;
+            for (unsigned i = 0; i < K; i++)
+            {
+                const uint64_t q = mods[i].q;
+                const ShoupOp mt = lv.m_tilde_mod_q[i], ip = lv.inv_punct_q[i];
+                uint64_t v = mul_shoup(in[i * N + j], mt.w, mt.wq, q);  // x * m~ mod q_i   (rns.cpp:1120)
+                y[i * kBlock + threadIdx.x] = mul_shoup(v, ip.w, ip.wq, q); // * (Q/q_i)^-1   (rns.cpp:439-456)
+            }
+            for (unsigned jj = 0; jj < lv.nBsk; jj++)
+                out[jj * N + j] = dot_lds(y, lv.q_to_bsk + jj * K, K, mods[lv.bsk_prime[jj]]);
+            uint64_t s = 0;
+            for (unsigned i = 0; i < K; i++)
+                s += y[i * kBlock + threadIdx.x] * lv.q_to_mtilde[i];
+            out[lv.nBsk * N + j] = s & (lv.m_tilde - 1); // modulus m~ = 2^32
+        }
+
+        // ---- stage 1: Bsk U {m~} -> Bsk   (sm_mrq)
+        __device__ __forceinline__ void stage_sm_mrq(
+            const ModDesc *mods, const LevelDev &lv, const uint64_t *in, uint64_t *out, size_t N, size_t j)
+        {
+            const uint64_t mt = lv.m_tilde;
+            uint64_t r = (in[lv.nBsk * N + j] * lv.neg_inv_prod_q_mod_mtilde) & (mt - 1);
+            for (unsigned jj = 0; jj < lv.nBsk; jj++)
+            {
+                const ModDesc md = mods[lv.bsk_prime[jj]];
+                uint64_t tmp = r;
+                if (tmp >= (mt >> 1))
+                    tmp += md.q - mt; // centered reduction (rns.cpp:1027-1031)
+                uint64_t lo, hi;
+                mul_wide(tmp, lv.prod_q_mod_bsk[jj], lo, hi);
+                uint64_t c = in[jj * N + j];
+                lo += c;
+                hi += lo < c;
+                uint64_t v = barrett128(lo, hi, md);
+                const ShoupOp im = lv.inv_mtilde_mod_bsk[jj];
+                out[jj * N + j] = mul_shoup(v, im.w, im.wq, md.q);
+            }
+        }
+
+        // ---- stage 2: q U Bsk -> Bsk   (fast_floor); input comps [0,K) base q, [K, K+nBsk) base Bsk
+        __device__ __forceinline__ void stage_fast_floor(
+            const ModDesc *mods, const LevelDev &lv, const uint64_t *in, uint64_t *out, size_t N, size_t j, uint64_t *y)
+        {
+            const unsigned K = lv.K;
+            for (unsigned i = 0; i < K; i++)
+            {
+                const ShoupOp ip = lv.inv_punct_q[i];
+                y[i * kBlock + threadIdx.x] = mul_shoup(in[i * N + j], ip.w, ip.wq, mods[i].q);
+            }
+            for (unsigned jj = 0; jj < lv.nBsk; jj++)
+            {
+                const ModDesc md = mods[lv.bsk_prime[jj]];
+                uint64_t conv = dot_lds(y, lv.q_to_bsk + jj * K, K, md);
+                const ShoupOp iq = lv.inv_prod_q_mod_bsk[jj];
+                out[jj * N + j] = mul_shoup(in[(K + jj) * N + j] + (md.q - conv), iq.w, iq.wq, md.q);
+            }
+        }
+
+        // ---- stage 3: Bsk -> q   (fastbconv_sk)
+        __device__ __forceinline__ void stage_fastbconv_sk(
+            const ModDesc *mods, const LevelDev &lv, const uint64_t *in, uint64_t *out, size_t N, size_t j, uint64_t *y)
+        {
+            const unsigned K = lv.K, nB = lv.nB;
+            for (unsigned i = 0; i < nB; i++)
+            {
+                const ShoupOp ip = lv.inv_punct_b[i];
+                y[i * kBlock + threadIdx.x] = mul_shoup(in[i * N + j], ip.w, ip.wq, mods[lv.bsk_prime[i]].q);
+            }
+            const ModDesc msk = mods[lv.msk_prime];
+            uint64_t conv_sk = dot_lds(y, lv.b_to_msk, nB, msk);
+            uint64_t alpha = mul_shoup(conv_sk + (msk.q - in[nB * N + j]), lv.inv_prod_b_mod_msk.w, lv.inv_prod_b_mod_msk.wq, msk.q);
+            const bool negative = alpha > (msk.q >> 1);
+            const uint64_t mag = negative ? msk.q - alpha : alpha;
+            for (unsigned i = 0; i < K; i++)
+            {
+                const ModDesc md = mods[i];
+                uint64_t g = dot_lds(y, lv.b_to_q + i * nB, nB, md);
+                uint64_t pb = lv.prod_b_mod_q[i];
+                uint64_t factor = negative ? pb : md.q - pb; // rns.cpp:962-975
+                uint64_t lo, hi;
+                mul_wide(mag, factor, lo, hi);
+                lo += g;
+                hi += lo < g;
+                out[i * N + j] = barrett128(lo, hi, md);
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) behz_stage_kernel(
+            const ModDesc *mods, LevelDev lv, int which, const uint64_t *in, uint64_t *out, unsigned n_log, size_t items,
+            unsigned in_comps, unsigned out_comps)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, y)
+            const size_t N = size_t(1) << n_log;
+            const size_t total = items << n_log;
+            for (size_t t = blockIdx.x * (size_t)kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock)
+            {
+                const size_t item = t >> n_log, j = t & (N - 1);
+                const uint64_t *ip = in + item * in_comps * N;
+                uint64_t *op = out + item * out_comps * N;
+                if (which == 0)
+                    stage_fastbconv_m_tilde(mods, lv, ip, op, N, j, y);
+                else if (which == 1)
+                    stage_sm_mrq(mods, lv, ip, op, N, j);
+                else if (which == 2)
+                    stage_fast_floor(mods, lv, ip, op, N, j, y);
+                else
+                    stage_fastbconv_sk(mods, lv, ip, op, N, j, y);
+            }
+        }
+
+        // fused lift: fastbconv_m_tilde + sm_mrq without the Bsk U {m~} round trip through HBM
+        __global__ void __launch_bounds__(kBlock) behz_lift_kernel(
+            const ModDesc *mods, LevelDev lv, const uint64_t *in, uint64_t *out, unsigned n_log, size_t items)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, y)
+            const size_t N = size_t(1) << n_log;
+            const size_t total = items << n_log;
+            const unsigned K = lv.K;
+            const uint64_t mt = lv.m_tilde;
+            for (size_t t = blockIdx.x * (size_t)kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock)
+            {
+                const size_t item = t >> n_log, j = t & (N - 1);
+                const uint64_t *ip = in + item * K * N;
+                uint64_t *op = out + item * lv.nBsk * N;
+                uint64_t s = 0;
+                for (unsigned i = 0; i < K; i++)
+                {
+                    const uint64_t q = mods[i].q;
+                    const ShoupOp m = lv.m_tilde_mod_q[i], pq = lv.inv_punct_q[i];
+                    uint64_t v = mul_shoup(mul_shoup(ip[i * N + j], m.w, m.wq, q), pq.w, pq.wq, q);
+                    y[i * kBlock + threadIdx.x] = v;
+                    s += v * lv.q_to_mtilde[i];
+                }
+                uint64_t r = (((s & (mt - 1)) * lv.neg_inv_prod_q_mod_mtilde)) & (mt - 1);
+                for (unsigned jj = 0; jj < lv.nBsk; jj++)
+                {
+                    const ModDesc md = mods[lv.bsk_prime[jj]];
+                    uint64_t c = dot_lds(y, lv.q_to_bsk + jj * K, K, md);
+                    uint64_t tmp = r;
+                    if (tmp >= (mt >> 1))
+                        tmp += md.q - mt;
+                    uint64_t lo, hi;
+                    mul_wide(tmp, lv.prod_q_mod_bsk[jj], lo, hi);
+                    lo += c;
+                    hi += lo < c;
+                    const ShoupOp im = lv.inv_mtilde_mod_bsk[jj];
+                    op[jj * N + j] = mul_shoup(barrett128(lo, hi, md), im.w, im.wq, md.q);
+                }
+            }
+        }
+
+        // fused tail: (x t) -> fast_floor -> fastbconv_sk   (evaluator.cpp:549-566)
+        __global__ void __launch_bounds__(kBlock) behz_floor_sk_kernel(
+            const ModDesc *mods, LevelDev lv, const uint64_t *dq, const uint64_t *dbsk, uint64_t *out, unsigned n_log,
+            size_t items)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const size_t N = size_t(1) << n_log;
+            const size_t total = items << n_log;
+            const unsigned K = lv.K, nB = lv.nB, nBsk = lv.nBsk;
+            uint64_t *y = lds;                      // [max(K, nB)][kBlock]
+            uint64_t *f = lds + (K > nB ? K : nB) * kBlock; // [nBsk][kBlock]
+            for (size_t t = blockIdx.x * (size_t)kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock)
+            {
+                const size_t item = t >> n_log, j = t & (N - 1);
+                const uint64_t *qp = dq + item * K * N;
+                const uint64_t *bp = dbsk + item * nBsk * N;
+                uint64_t *op = out + item * K * N;
+                for (unsigned i = 0; i < K; i++)
+                {
+                    const uint64_t q = mods[i].q;
+                    const ShoupOp tm = lv.t_mod_q[i], pq = lv.inv_punct_q[i];
+                    uint64_t z = mul_shoup(qp[i * N + j], tm.w, tm.wq, q); // step (6), evaluator.cpp:554
+                    y[i * kBlock + threadIdx.x] = mul_shoup(z, pq.w, pq.wq, q);
+                }
+                for (unsigned jj = 0; jj < nBsk; jj++)
+                {
+                    const ModDesc md = mods[lv.bsk_prime[jj]];
+                    uint64_t conv = dot_lds(y, lv.q_to_bsk + jj * K, K, md);
+                    const ShoupOp tm = lv.t_mod_bsk[jj], iq = lv.inv_prod_q_mod_bsk[jj];
+                    uint64_t zb = mul_shoup(bp[jj * N + j], tm.w, tm.wq, md.q);
+                    f[jj * kBlock + threadIdx.x] = mul_shoup(zb + (md.q - conv), iq.w, iq.wq, md.q); // step (7)
+                }
+                // step (8): Shenoy-Kumaresan
+                for (unsigned i = 0; i < nB; i++)
+                {
+                    const ShoupOp ib = lv.inv_punct_b[i];
+                    y[i * kBlock + threadIdx.x] = mul_shoup(f[i * kBlock + threadIdx.x], ib.w, ib.wq, mods[lv.bsk_prime[i]].q);
+                }
+                const ModDesc msk = mods[lv.msk_prime];
+                uint64_t conv_sk = dot_lds(y, lv.b_to_msk, nB, msk);
+                uint64_t alpha = mul_shoup(
+                    conv_sk + (msk.q - f[nB * kBlock + threadIdx.x]), lv.inv_prod_b_mod_msk.w, lv.inv_prod_b_mod_msk.wq, msk.q);
+                const bool negative = alpha > (msk.q >> 1);
+                const uint64_t mag = negative ? msk.q - alpha : alpha;
+                for (unsigned i = 0; i < K; i++)
+                {
+                    const ModDesc md = mods[i];
+                    uint64_t g = dot_lds(y, lv.b_to_q + i * nB, nB, md);
+                    uint64_t pb = lv.prod_b_mod_q[i];
+                    uint64_t factor = negative ? pb : md.q - pb;
+                    uint64_t lo, hi;
+                    mul_wide(mag, factor, lo, hi);
+                    lo += g;
+                    hi += lo < g;
+                    op[i * N + j] = barrett128(lo, hi, md);
+                }
+            }
+        }
+
+        inline unsigned grid_for(size_t work)
+        {
+            size_t b = (work + kBlock - 1) / kBlock;
+            if (b > 2048)
+                b = 2048;
+            if (b == 0)
+                b = 1;
+            return (unsigned)b;
+        }
+    } // namespace
+
+    hipError_t k_behz_lift(
+        const ModDesc *mods, const LevelDev &lv, const uint64_t *in, uint64_t *out, unsigned n_log, size_t items, hipStream_t s)
+    {
+        size_t work = items << n_log;
+        if (!work)
+            return hipSuccess;
+        size_t shmem = (size_t)lv.K * kBlock * sizeof(uint64_t);
+        hipLaunchKernelGGL(behz_lift_kernel, dim3(grid_for(work)), dim3(kBlock), shmem, s, mods, lv, in, out, n_log, items);
+        return hipGetLastError();
+    }
+
+    hipError_t k_behz_floor_sk(
+        const ModDesc *mods, const LevelDev &lv, const uint64_t *dq, const uint64_t *dbsk, uint64_t *out, unsigned n_log,
+        size_t items, hipStream_t s)
+    {
+        size_t work = items << n_log;
+        if (!work)
+            return hipSuccess;
+        size_t shmem = ((size_t)(lv.K > lv.nB ? lv.K : lv.nB) + lv.nBsk) * kBlock * sizeof(uint64_t);
+        hipLaunchKernelGGL(
+            behz_floor_sk_kernel, dim3(grid_for(work)), dim3(kBlock), shmem, s, mods, lv, dq, dbsk, out, n_log, items);
+        return hipGetLastError();
+    }
+
+    hipError_t k_behz_stage(
+        const ModDesc *mods, const LevelDev &lv, int which, const uint64_t *in, uint64_t *out, unsigned n_log, size_t items,
+        hipStream_t s)
+    {
+        size_t work = items << n_log;
+        if (!work)
+            return hipSuccess;
+        unsigned in_comps, out_comps;
+        switch (which)
+        {
+        case 0:
+            in_comps = lv.K;
+            out_comps = lv.nBsk + 1;
+            break;
+        case 1:
+            in_comps = lv.nBsk + 1;
+            out_comps = lv.nBsk;
+            break;
+        case 2:
+            in_comps = lv.K + lv.nBsk;
+            out_comps = lv.nBsk;
+            break;
+        case 3:
+            in_comps = lv.nBsk;
+            out_comps = lv.K;
+            break;
+        default:
+            return hipErrorInvalidValue;
+        }
+        size_t shmem = (size_t)(lv.K > lv.nB ? lv.K : lv.nB) * kBlock * sizeof(uint64_t);
+        hipLaunchKernelGGL(
+            behz_stage_kernel, dim3(grid_for(work)), dim3(kBlock), shmem, s, mods, lv, which, in, out, n_log, items, in_comps,
+            out_comps);
+        return hipGetLastError();
+    }
+} // namespace sealhip

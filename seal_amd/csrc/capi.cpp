@@ -1,0 +1,1004 @@
+// extern "C" layer of libsealhip.so — see include/sealhip.h.  Every body is closed by the same
+// exception-to-HRESULT ladder as the reference's C export layer (SEAL_C_CATCH_ALL,
+// native/src/seal/c/defines.h:75-97); null handles return E_POINTER like IfNullRet
+// (native/src/seal/c/utilities.h).
+#include "../../include/sealhip.h"
+#include "evaluator.h"
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace sealhip;
+
+namespace
+{
+    thread_local std::string g_last_error;
+
+    struct EncParams
+    {
+        uint8_t scheme = 0;
+        uint64_t n = 0;
+        std::vector<uint64_t> coeff_modulus;
+        uint64_t plain_modulus = 0;
+    };
+    struct Timer
+    {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+    };
+
+#define SHL_TRY \
+    try         \
+    {
+#define SHL_CATCH                               \
+    }                                           \
+    catch (const std::invalid_argument &e)      \
+    {                                           \
+        g_last_error = e.what();                \
+        return SHL_E_INVALIDARG;                \
+    }                                           \
+    catch (const std::out_of_range &e)          \
+    {                                           \
+        g_last_error = e.what();                \
+        return SHL_E_INVALID_INDEX;             \
+    }                                           \
+    catch (const std::logic_error &e)           \
+    {                                           \
+        g_last_error = e.what();                \
+        return SHL_COR_E_INVALIDOPERATION;      \
+    }                                           \
+    catch (const std::runtime_error &e)         \
+    {                                           \
+        g_last_error = e.what();                \
+        return SHL_COR_E_IO;                    \
+    }                                           \
+    catch (const std::bad_alloc &)              \
+    {                                           \
+        g_last_error = "out of device memory";  \
+        return SHL_E_OUTOFMEMORY;               \
+    }                                           \
+    catch (...)                                 \
+    {                                           \
+        g_last_error = "unexpected exception";  \
+        return SHL_E_UNEXPECTED;                \
+    }                                           \
+    return SHL_S_OK;
+
+#define IfNullRet(p, r) \
+    if (!(p))           \
+    return (r)
+
+    template <typename T>
+    T *as(void *p)
+    {
+        return static_cast<T *>(p);
+    }
+
+    void hip_ok(hipError_t e, const char *what)
+    {
+        if (e != hipSuccess)
+            throw std::runtime_error(std::string("HIP failure in ") + what + ": " + hipGetErrorString(e));
+    }
+
+    // dest = src unless they are the same object (the sealc "destination" convention)
+    Ciphertext &prepare_dest(void *encrypted, void *destination)
+    {
+        Ciphertext *src = as<Ciphertext>(encrypted), *dst = as<Ciphertext>(destination);
+        if (src != dst)
+            *dst = *src;
+        return *dst;
+    }
+} // namespace
+
+extern "C"
+{
+    // ------------------------------------------------------------------ library / device
+    SHL_FUNC SealHip_Version(uint32_t *major, uint32_t *minor, uint32_t *patch)
+    {
+        IfNullRet(major, SHL_E_POINTER);
+        IfNullRet(minor, SHL_E_POINTER);
+        IfNullRet(patch, SHL_E_POINTER);
+        *major = 0;
+        *minor = 1;
+        *patch = 0;
+        return SHL_S_OK;
+    }
+    SHL_FUNC SealHip_DeviceInfo(char *name, uint64_t name_capacity, int *compute_units, uint64_t *hbm_bytes)
+    {
+        SHL_TRY
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            throw std::runtime_error("no HIP device visible: libsealhip has no CPU fallback");
+        int dev = 0;
+        hip_ok(hipGetDevice(&dev), "hipGetDevice");
+        hipDeviceProp_t prop;
+        hip_ok(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+        if (name && name_capacity)
+        {
+            std::strncpy(name, prop.name, name_capacity - 1);
+            name[name_capacity - 1] = 0;
+        }
+        if (compute_units)
+            *compute_units = prop.multiProcessorCount;
+        if (hbm_bytes)
+            *hbm_bytes = prop.totalGlobalMem;
+        SHL_CATCH
+    }
+    SHL_FUNC SealHip_LastError(char *outstr, uint64_t *length)
+    {
+        IfNullRet(length, SHL_E_POINTER);
+        if (outstr && *length > g_last_error.size())
+            std::memcpy(outstr, g_last_error.c_str(), g_last_error.size() + 1);
+        *length = g_last_error.size() + 1;
+        return SHL_S_OK;
+    }
+
+    // ------------------------------------------------------------------ parameter helpers
+    SHL_FUNC CoeffModulus_Create1(uint64_t poly_modulus_degree, uint64_t length, int *bit_sizes, uint64_t *coeffs)
+    {
+        IfNullRet(bit_sizes, SHL_E_POINTER);
+        IfNullRet(coeffs, SHL_E_POINTER);
+        SHL_TRY
+        if (poly_modulus_degree < 2 || poly_modulus_degree > 131072 || (poly_modulus_degree & (poly_modulus_degree - 1)))
+            throw std::invalid_argument("poly_modulus_degree is invalid");
+        std::vector<int> bits(bit_sizes, bit_sizes + length);
+        auto v = host::coeff_modulus_create(poly_modulus_degree, bits);
+        for (size_t i = 0; i < v.size(); i++)
+            coeffs[i] = v[i];
+        SHL_CATCH
+    }
+    SHL_FUNC PlainModulus_Batching(uint64_t poly_modulus_degree, int bit_size, uint64_t *value)
+    {
+        IfNullRet(value, SHL_E_POINTER);
+        SHL_TRY
+        *value = host::plain_modulus_batching(poly_modulus_degree, bit_size);
+        SHL_CATCH
+    }
+
+    SHL_FUNC EncParams_Create1(uint8_t scheme, void **enc_params)
+    {
+        IfNullRet(enc_params, SHL_E_POINTER);
+        SHL_TRY
+        if (scheme > 3)
+            throw std::invalid_argument("unsupported scheme");
+        auto p = new EncParams();
+        p->scheme = scheme;
+        *enc_params = p;
+        SHL_CATCH
+    }
+    SHL_FUNC EncParams_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<EncParams>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC EncParams_SetPolyModulusDegree(void *thisptr, uint64_t degree)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        as<EncParams>(thisptr)->n = degree;
+        return SHL_S_OK;
+    }
+    SHL_FUNC EncParams_GetPolyModulusDegree(void *thisptr, uint64_t *degree)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(degree, SHL_E_POINTER);
+        *degree = as<EncParams>(thisptr)->n;
+        return SHL_S_OK;
+    }
+    SHL_FUNC EncParams_SetCoeffModulus(void *thisptr, uint64_t length, const uint64_t *coeffs)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(coeffs, SHL_E_POINTER);
+        SHL_TRY
+        if (length < 1 || length > kMaxComps)
+            throw std::invalid_argument("coeff_modulus is invalid");
+        as<EncParams>(thisptr)->coeff_modulus.assign(coeffs, coeffs + length);
+        SHL_CATCH
+    }
+    SHL_FUNC EncParams_GetCoeffModulus(void *thisptr, uint64_t *length, uint64_t *coeffs)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(length, SHL_E_POINTER);
+        auto &v = as<EncParams>(thisptr)->coeff_modulus;
+        *length = v.size();
+        if (coeffs)
+            std::memcpy(coeffs, v.data(), v.size() * 8);
+        return SHL_S_OK;
+    }
+    SHL_FUNC EncParams_SetPlainModulus2(void *thisptr, uint64_t plain_modulus)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        SHL_TRY
+        auto p = as<EncParams>(thisptr);
+        // EncryptionParameters::set_plain_modulus (encryptionparams.h): CKKS takes none
+        if (p->scheme == 2 && plain_modulus != 0)
+            throw std::logic_error("plain_modulus is not supported for this scheme");
+        p->plain_modulus = plain_modulus;
+        SHL_CATCH
+    }
+    SHL_FUNC EncParams_GetScheme(void *thisptr, uint8_t *scheme)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(scheme, SHL_E_POINTER);
+        *scheme = as<EncParams>(thisptr)->scheme;
+        return SHL_S_OK;
+    }
+
+    // ------------------------------------------------------------------ SEALContext
+    SHL_FUNC SEALContext_Create(void *encryptionParams, bool expand_mod_chain, int sec_level, void **context)
+    {
+        (void)sec_level;
+        IfNullRet(encryptionParams, SHL_E_POINTER);
+        IfNullRet(context, SHL_E_POINTER);
+        SHL_TRY
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            throw std::runtime_error("no HIP device visible: libsealhip has no CPU fallback");
+        auto p = as<EncParams>(encryptionParams);
+        *context = new Context(static_cast<Scheme>(p->scheme), p->n, p->coeff_modulus, p->plain_modulus, expand_mod_chain);
+        SHL_CATCH
+    }
+    SHL_FUNC SEALContext_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<Context>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC SEALContext_KeyParmsId(void *thisptr, uint64_t *parms_id)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        std::memcpy(parms_id, as<Context>(thisptr)->key_level().parms_id, 32);
+        return SHL_S_OK;
+    }
+    SHL_FUNC SEALContext_FirstParmsId(void *thisptr, uint64_t *parms_id)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        std::memcpy(parms_id, as<Context>(thisptr)->first_level().parms_id, 32);
+        return SHL_S_OK;
+    }
+    SHL_FUNC SEALContext_LastParmsId(void *thisptr, uint64_t *parms_id)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        std::memcpy(parms_id, as<Context>(thisptr)->last_level().parms_id, 32);
+        return SHL_S_OK;
+    }
+    SHL_FUNC SEALContext_UsingKeyswitching(void *thisptr, bool *using_keyswitching)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(using_keyswitching, SHL_E_POINTER);
+        *using_keyswitching = as<Context>(thisptr)->using_keyswitching();
+        return SHL_S_OK;
+    }
+    SHL_FUNC SEALContext_ChainIndex(void *thisptr, uint64_t *parms_id, uint64_t *chain_index)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(chain_index, SHL_E_POINTER);
+        SHL_TRY
+        auto l = as<Context>(thisptr)->level_by_parms_id(parms_id);
+        if (!l)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        *chain_index = l->chain_index;
+        SHL_CATCH
+    }
+    SHL_FUNC SEALContext_ParmsIdAt(void *thisptr, uint64_t chain_index, uint64_t *parms_id)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        SHL_TRY
+        auto l = as<Context>(thisptr)->level_by_chain_index(chain_index);
+        if (!l)
+            throw std::out_of_range("chain_index");
+        std::memcpy(parms_id, l->parms_id, 32);
+        SHL_CATCH
+    }
+    SHL_FUNC SEALContext_CoeffModulusAt(void *thisptr, uint64_t chain_index, uint64_t *length, uint64_t *coeffs)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(length, SHL_E_POINTER);
+        SHL_TRY
+        auto c = as<Context>(thisptr);
+        auto l = c->level_by_chain_index(chain_index);
+        if (!l)
+            throw std::out_of_range("chain_index");
+        *length = l->K;
+        if (coeffs)
+            std::memcpy(coeffs, c->coeff_modulus().data(), l->K * 8);
+        SHL_CATCH
+    }
+    SHL_FUNC SEALContext_TotalCoeffModulusBitCount(void *thisptr, uint64_t chain_index, int *bit_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(bit_count, SHL_E_POINTER);
+        SHL_TRY
+        auto l = as<Context>(thisptr)->level_by_chain_index(chain_index);
+        if (!l)
+            throw std::out_of_range("chain_index");
+        *bit_count = l->total_coeff_modulus_bit_count;
+        SHL_CATCH
+    }
+    SHL_FUNC SEALContext_SetParmsId(void *thisptr, uint64_t chain_index, uint64_t *parms_id)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        SHL_TRY
+        auto c = as<Context>(thisptr);
+        if (!c->level_by_chain_index(chain_index))
+            throw std::out_of_range("chain_index");
+        c->set_parms_id(chain_index, parms_id);
+        SHL_CATCH
+    }
+    SHL_FUNC SEALContext_NTTRoot(void *thisptr, uint64_t prime_index, uint64_t *root)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(root, SHL_E_POINTER);
+        SHL_TRY
+        auto c = as<Context>(thisptr);
+        if (prime_index >= c->pool_primes().size())
+            throw std::out_of_range("prime_index");
+        *root = c->ntt_root((unsigned)prime_index);
+        SHL_CATCH
+    }
+    SHL_FUNC SEALContext_BaseBsk(void *thisptr, uint64_t chain_index, uint64_t *length, uint64_t *primes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(length, SHL_E_POINTER);
+        SHL_TRY
+        auto l = as<Context>(thisptr)->level_by_chain_index(chain_index);
+        if (!l)
+            throw std::out_of_range("chain_index");
+        *length = l->bsk.size();
+        if (primes)
+            std::memcpy(primes, l->bsk.data(), l->bsk.size() * 8);
+        SHL_CATCH
+    }
+
+    // ------------------------------------------------------------------ Ciphertext
+    SHL_FUNC Ciphertext_Create3(void *context, void *pool, void **cipher)
+    {
+        (void)pool;
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(cipher, SHL_E_POINTER);
+        SHL_TRY
+        *cipher = new Ciphertext(*as<Context>(context), 1);
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_CreateBatch(void *context, uint64_t batch, void **cipher)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(cipher, SHL_E_POINTER);
+        SHL_TRY
+        if (batch == 0)
+            throw std::invalid_argument("batch must be positive");
+        *cipher = new Ciphertext(*as<Context>(context), batch);
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_Create2(void *copy, void **cipher)
+    {
+        IfNullRet(copy, SHL_E_POINTER);
+        IfNullRet(cipher, SHL_E_POINTER);
+        SHL_TRY
+        hip_ok(hipDeviceSynchronize(), "sync");
+        *cipher = new Ciphertext(*as<Ciphertext>(copy));
+        hip_ok(hipDeviceSynchronize(), "sync");
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_Set(void *thisptr, void *assign)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(assign, SHL_E_POINTER);
+        SHL_TRY
+        hip_ok(hipDeviceSynchronize(), "sync");
+        *as<Ciphertext>(thisptr) = *as<Ciphertext>(assign);
+        hip_ok(hipDeviceSynchronize(), "sync");
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<Ciphertext>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC Ciphertext_Resize1(void *thisptr, void *context, uint64_t *parms_id, uint64_t size)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        SHL_TRY
+        auto ct = as<Ciphertext>(thisptr);
+        auto c = as<Context>(context);
+        if (&ct->context() != c)
+            throw std::invalid_argument("ciphertext belongs to another context");
+        ct->resize(c->level_by_parms_id(parms_id), size, nullptr);
+        SHL_CATCH
+    }
+#define CT_GET(fn, type, expr)                      \
+    SHL_FUNC fn(void *thisptr, type *out)           \
+    {                                               \
+        IfNullRet(thisptr, SHL_E_POINTER);          \
+        IfNullRet(out, SHL_E_POINTER);              \
+        auto ct = as<Ciphertext>(thisptr);          \
+        *out = (expr);                              \
+        return SHL_S_OK;                            \
+    }
+    CT_GET(Ciphertext_Size, uint64_t, ct->size())
+    CT_GET(Ciphertext_BatchCount, uint64_t, ct->batch())
+    CT_GET(Ciphertext_PolyModulusDegree, uint64_t, ct->poly_modulus_degree())
+    CT_GET(Ciphertext_CoeffModulusSize, uint64_t, ct->coeff_modulus_size())
+    CT_GET(Ciphertext_IsNTTForm, bool, ct->is_ntt_form())
+    CT_GET(Ciphertext_Scale, double, ct->scale())
+    CT_GET(Ciphertext_CorrectionFactor, uint64_t, ct->correction_factor())
+    SHL_FUNC Ciphertext_ParmsId(void *thisptr, uint64_t *parms_id)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        auto ct = as<Ciphertext>(thisptr);
+        if (ct->level())
+            std::memcpy(parms_id, ct->level()->parms_id, 32);
+        else
+            std::memset(parms_id, 0, 32); // parms_id_zero
+        return SHL_S_OK;
+    }
+    SHL_FUNC Ciphertext_SetIsNTTForm(void *thisptr, bool is_ntt_form)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        as<Ciphertext>(thisptr)->is_ntt_form() = is_ntt_form;
+        return SHL_S_OK;
+    }
+    SHL_FUNC Ciphertext_SetScale(void *thisptr, double scale)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        as<Ciphertext>(thisptr)->scale() = scale;
+        return SHL_S_OK;
+    }
+    SHL_FUNC Ciphertext_SetCorrectionFactor(void *thisptr, uint64_t correction_factor)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        as<Ciphertext>(thisptr)->correction_factor() = correction_factor;
+        return SHL_S_OK;
+    }
+    SHL_FUNC Ciphertext_IsTransparent(void *thisptr, bool *result)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(result, SHL_E_POINTER);
+        SHL_TRY
+        auto ct = as<Ciphertext>(thisptr);
+        Evaluator ev(ct->context());
+        hip_ok(hipDeviceSynchronize(), "sync");
+        *result = ev.is_transparent(*ct);
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_DevicePtr(void *thisptr, uint64_t **data, uint64_t *word_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(data, SHL_E_POINTER);
+        auto ct = as<Ciphertext>(thisptr);
+        *data = ct->data();
+        if (word_count)
+            *word_count = ct->word_count();
+        return SHL_S_OK;
+    }
+    SHL_FUNC Ciphertext_CopyFromHost(void *thisptr, const uint64_t *src, uint64_t word_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(src, SHL_E_POINTER);
+        SHL_TRY
+        auto ct = as<Ciphertext>(thisptr);
+        if (word_count != ct->word_count())
+            throw std::invalid_argument("word_count does not match the ciphertext slab");
+        hip_ok(hipDeviceSynchronize(), "sync");
+        hip_ok(hipMemcpy(ct->data(), src, word_count * 8, hipMemcpyHostToDevice), "H2D");
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(dst, SHL_E_POINTER);
+        SHL_TRY
+        auto ct = as<Ciphertext>(thisptr);
+        if (word_count != ct->word_count())
+            throw std::invalid_argument("word_count does not match the ciphertext slab");
+        hip_ok(hipDeviceSynchronize(), "sync");
+        hip_ok(hipMemcpy(dst, ct->data(), word_count * 8, hipMemcpyDeviceToHost), "D2H");
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_CopyFromDevice(void *thisptr, const uint64_t *src, uint64_t word_count, void *hip_stream)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(src, SHL_E_POINTER);
+        SHL_TRY
+        auto ct = as<Ciphertext>(thisptr);
+        if (word_count != ct->word_count())
+            throw std::invalid_argument("word_count does not match the ciphertext slab");
+        hip_ok(hipMemcpyAsync(ct->data(), src, word_count * 8, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream), "D2D");
+        SHL_CATCH
+    }
+
+    // ------------------------------------------------------------------ KSwitchKeys
+    SHL_FUNC KSwitchKeys_Create1(void **kswitch_keys)
+    {
+        IfNullRet(kswitch_keys, SHL_E_POINTER);
+        SHL_TRY
+        *kswitch_keys = new KSwitchKeys();
+        SHL_CATCH
+    }
+    SHL_FUNC KSwitchKeys_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<KSwitchKeys>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC KSwitchKeys_Size(void *thisptr, uint64_t *size)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(size, SHL_E_POINTER);
+        *size = as<KSwitchKeys>(thisptr)->size();
+        return SHL_S_OK;
+    }
+    SHL_FUNC KSwitchKeys_SetKey(void *thisptr, void *context, uint64_t index, uint64_t digits, const uint64_t *host_words)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(host_words, SHL_E_POINTER);
+        SHL_TRY
+        as<KSwitchKeys>(thisptr)->set_key(*as<Context>(context), index, digits, host_words, false);
+        SHL_CATCH
+    }
+    SHL_FUNC KSwitchKeys_SetKeyFromDevice(void *thisptr, void *context, uint64_t index, uint64_t digits, const uint64_t *device_words)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(device_words, SHL_E_POINTER);
+        SHL_TRY
+        as<KSwitchKeys>(thisptr)->set_key(*as<Context>(context), index, digits, device_words, true);
+        SHL_CATCH
+    }
+    SHL_FUNC KSwitchKeys_HasKey(void *thisptr, uint64_t index, bool *has_key)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(has_key, SHL_E_POINTER);
+        *has_key = as<KSwitchKeys>(thisptr)->has_key(index);
+        return SHL_S_OK;
+    }
+    SHL_FUNC RelinKeys_GetIndex(uint64_t key_power, uint64_t *index)
+    {
+        IfNullRet(index, SHL_E_POINTER);
+        SHL_TRY
+        *index = Evaluator::relin_index(key_power);
+        SHL_CATCH
+    }
+    SHL_FUNC GaloisKeys_GetIndex(uint32_t galois_elt, uint64_t *index)
+    {
+        IfNullRet(index, SHL_E_POINTER);
+        SHL_TRY
+        *index = Evaluator::galois_index(galois_elt);
+        SHL_CATCH
+    }
+    SHL_FUNC GaloisTool_GetEltFromStep(void *context, int step, uint32_t *galois_elt)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(galois_elt, SHL_E_POINTER);
+        SHL_TRY
+        Evaluator ev(*as<Context>(context));
+        *galois_elt = ev.galois_elt_from_step(step);
+        SHL_CATCH
+    }
+
+    // ------------------------------------------------------------------ Evaluator
+    SHL_FUNC Evaluator_Create(void *context, void **evaluator)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(evaluator, SHL_E_POINTER);
+        SHL_TRY
+        *evaluator = new Evaluator(*as<Context>(context));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<Evaluator>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC Evaluator_SetStream(void *thisptr, void *hip_stream)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        as<Evaluator>(thisptr)->set_stream((hipStream_t)hip_stream);
+        return SHL_S_OK;
+    }
+    SHL_FUNC Evaluator_SetTransparentCheck(void *thisptr, bool enabled)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        as<Evaluator>(thisptr)->set_transparent_check(enabled);
+        return SHL_S_OK;
+    }
+    SHL_FUNC Evaluator_Synchronize(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->synchronize();
+        SHL_CATCH
+    }
+#define EV_UNARY(fn, call)                                           \
+    SHL_FUNC fn(void *thisptr, void *encrypted, void *destination)   \
+    {                                                                \
+        IfNullRet(thisptr, SHL_E_POINTER);                           \
+        IfNullRet(encrypted, SHL_E_POINTER);                         \
+        IfNullRet(destination, SHL_E_POINTER);                       \
+        SHL_TRY                                                      \
+        auto ev = as<Evaluator>(thisptr);                            \
+        Ciphertext &d = prepare_dest(encrypted, destination);        \
+        ev->call(d);                                                 \
+        SHL_CATCH                                                    \
+    }
+#define EV_UNARY_POOL(fn, call)                                                  \
+    SHL_FUNC fn(void *thisptr, void *encrypted, void *destination, void *pool)   \
+    {                                                                            \
+        (void)pool;                                                              \
+        IfNullRet(thisptr, SHL_E_POINTER);                                       \
+        IfNullRet(encrypted, SHL_E_POINTER);                                     \
+        IfNullRet(destination, SHL_E_POINTER);                                   \
+        SHL_TRY                                                                  \
+        auto ev = as<Evaluator>(thisptr);                                        \
+        Ciphertext &d = prepare_dest(encrypted, destination);                    \
+        ev->call(d);                                                             \
+        SHL_CATCH                                                                \
+    }
+    EV_UNARY(Evaluator_Negate, negate_inplace)
+    EV_UNARY(Evaluator_TransformToNTT2, transform_to_ntt_inplace)
+    EV_UNARY(Evaluator_TransformFromNTT, transform_from_ntt_inplace)
+    EV_UNARY_POOL(Evaluator_Square, square_inplace)
+    EV_UNARY_POOL(Evaluator_ModSwitchToNext1, mod_switch_to_next_inplace)
+    EV_UNARY_POOL(Evaluator_RescaleToNext, rescale_to_next_inplace)
+    EV_UNARY_POOL(Evaluator_ModReduceToNext, mod_reduce_to_next_inplace)
+
+    SHL_FUNC Evaluator_Add(void *thisptr, void *encrypted1, void *encrypted2, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted1, SHL_E_POINTER);
+        IfNullRet(encrypted2, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        auto ev = as<Evaluator>(thisptr);
+        if (encrypted2 == destination && encrypted1 != destination)
+            ev->add_inplace(*as<Ciphertext>(destination), *as<Ciphertext>(encrypted1)); // evaluator.h add(): commutes
+        else
+            ev->add_inplace(prepare_dest(encrypted1, destination), *as<Ciphertext>(encrypted2));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_Sub(void *thisptr, void *encrypted1, void *encrypted2, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted1, SHL_E_POINTER);
+        IfNullRet(encrypted2, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        auto ev = as<Evaluator>(thisptr);
+        if (encrypted2 == destination && encrypted1 != destination)
+        {
+            // evaluator.h sub(): destination = e2 - e1, then negate
+            ev->sub_inplace(*as<Ciphertext>(destination), *as<Ciphertext>(encrypted1));
+            ev->negate_inplace(*as<Ciphertext>(destination));
+        }
+        else
+            ev->sub_inplace(prepare_dest(encrypted1, destination), *as<Ciphertext>(encrypted2));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_Multiply(void *thisptr, void *encrypted1, void *encrypted2, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted1, SHL_E_POINTER);
+        IfNullRet(encrypted2, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        auto ev = as<Evaluator>(thisptr);
+        if (encrypted2 == destination && encrypted1 != destination)
+            ev->multiply_inplace(*as<Ciphertext>(destination), *as<Ciphertext>(encrypted1)); // evaluator.h multiply(): commutes
+        else if (encrypted1 == encrypted2)
+        {
+            Ciphertext &d = prepare_dest(encrypted1, destination);
+            ev->multiply_inplace(d, d);
+        }
+        else
+            ev->multiply_inplace(prepare_dest(encrypted1, destination), *as<Ciphertext>(encrypted2));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_Relinearize(void *thisptr, void *encrypted, void *relinKeys, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(relinKeys, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->relinearize_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(relinKeys));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ModSwitchTo1(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->mod_switch_to_inplace(prepare_dest(encrypted, destination), parms_id);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_RescaleTo(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->rescale_to_inplace(prepare_dest(encrypted, destination), parms_id);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ApplyGalois(void *thisptr, void *encrypted, uint32_t galois_elt, void *galoisKeys, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(galoisKeys, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->apply_galois_inplace(prepare_dest(encrypted, destination), galois_elt, *as<KSwitchKeys>(galoisKeys));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_RotateRows(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(galoisKeys, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->rotate_rows_inplace(prepare_dest(encrypted, destination), steps, *as<KSwitchKeys>(galoisKeys));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_RotateColumns(void *thisptr, void *encrypted, void *galois_keys, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(galois_keys, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->rotate_columns_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(galois_keys));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_RotateVector(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(galoisKeys, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->rotate_vector_inplace(prepare_dest(encrypted, destination), steps, *as<KSwitchKeys>(galoisKeys));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ComplexConjugate(void *thisptr, void *encrypted, void *galoisKeys, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(galoisKeys, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->complex_conjugate_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(galoisKeys));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ContextUsingKeyswitching(void *thisptr, bool *using_keyswitching)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(using_keyswitching, SHL_E_POINTER);
+        *using_keyswitching = as<Evaluator>(thisptr)->context().using_keyswitching();
+        return SHL_S_OK;
+    }
+
+    // ------------------------------------------------------------------ per-kernel seam
+    SHL_FUNC shl_ntt_forward(void *context, uint64_t *data, uint64_t polys, uint64_t comps, uint64_t first_prime, int lazy, void *stream)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(data, SHL_E_POINTER);
+        SHL_TRY
+        auto c = as<Context>(context);
+        if (first_prime + comps > c->pool_primes().size())
+            throw std::out_of_range("first_prime + comps");
+        NttBatch b{};
+        b.data = data;
+        b.outer_stride = (size_t)comps * c->n();
+        b.ncomp = (unsigned)comps;
+        b.nouter = (unsigned)polys;
+        b.prime_first = (unsigned)first_prime;
+        hip_ok(ntt_forward(c->ntt_tables(), b, lazy, (hipStream_t)stream), "ntt_forward");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_ntt_inverse(void *context, uint64_t *data, uint64_t polys, uint64_t comps, uint64_t first_prime, int lazy, void *stream)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(data, SHL_E_POINTER);
+        SHL_TRY
+        auto c = as<Context>(context);
+        if (first_prime + comps > c->pool_primes().size())
+            throw std::out_of_range("first_prime + comps");
+        NttBatch b{};
+        b.data = data;
+        b.outer_stride = (size_t)comps * c->n();
+        b.ncomp = (unsigned)comps;
+        b.nouter = (unsigned)polys;
+        b.prime_first = (unsigned)first_prime;
+        hip_ok(ntt_inverse(c->ntt_tables(), b, lazy, (hipStream_t)stream), "ntt_inverse");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_dyadic_product(
+        void *context, const uint64_t *a, const uint64_t *b, uint64_t *r, uint64_t polys, uint64_t comps, uint64_t first_prime,
+        void *stream)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(a, SHL_E_POINTER);
+        IfNullRet(b, SHL_E_POINTER);
+        IfNullRet(r, SHL_E_POINTER);
+        SHL_TRY
+        auto c = as<Context>(context);
+        if (first_prime + comps > c->pool_primes().size())
+            throw std::out_of_range("first_prime + comps");
+        hip_ok(k_dyadic(c->dev_mods(), a, b, r, (unsigned)c->log_n(), (unsigned)comps, (unsigned)first_prime, polys, (hipStream_t)stream), "dyadic");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_apply_galois(
+        void *context, uint64_t chain_index, int ntt_form, uint32_t galois_elt, const uint64_t *in, uint64_t *out, uint64_t polys,
+        void *stream)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(in, SHL_E_POINTER);
+        IfNullRet(out, SHL_E_POINTER);
+        SHL_TRY
+        auto c = as<Context>(context);
+        auto l = c->level_by_chain_index(chain_index);
+        if (!l)
+            throw std::out_of_range("chain_index");
+        if (!(galois_elt & 1) || galois_elt >= 2 * c->n())
+            throw std::invalid_argument("Galois element is not valid");
+        if (in == out)
+            throw std::invalid_argument("result cannot point to the same value as operand");
+        PlaneGeom g{ (unsigned)c->log_n(), l->K, (unsigned)polys };
+        hip_ok(k_apply_galois(c->dev_mods(), in, out, galois_elt, ntt_form, g, 1, (hipStream_t)stream), "apply_galois");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_rns_stage(void *context, uint64_t chain_index, int which, const uint64_t *in, uint64_t *out, uint64_t polys, void *stream)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(in, SHL_E_POINTER);
+        IfNullRet(out, SHL_E_POINTER);
+        SHL_TRY
+        auto c = as<Context>(context);
+        auto l = c->level_by_chain_index(chain_index);
+        if (!l)
+            throw std::out_of_range("chain_index");
+        hipStream_t s = (hipStream_t)stream;
+        const unsigned n_log = (unsigned)c->log_n();
+        if (which >= 0 && which <= 3)
+        {
+            if (c->scheme() != Scheme::bfv)
+                throw std::logic_error("BEHZ stages exist only for BFV contexts");
+            hip_ok(k_behz_stage(c->dev_mods(), l->dev, which, in, out, n_log, polys, s), "behz stage");
+        }
+        else if (which == 4)
+        {
+            if (l->K < 2)
+                throw std::invalid_argument("level has a single modulus");
+            hip_ok(k_bfv_modswitch(c->dev_mods(), l->dev, in, out, n_log, polys, s), "divide_and_round_q_last");
+        }
+        else if (which == 5)
+        {
+            if (l->K < 2)
+                throw std::invalid_argument("level has a single modulus");
+            const unsigned K = l->K;
+            const size_t N = c->n();
+            Scratch copy(polys * K * N), tt(polys * (K - 1) * N);
+            hip_ok(hipMemcpyAsync(copy.p, in, polys * K * N * 8, hipMemcpyDeviceToDevice, s), "copy");
+            uint64_t *last = copy.p + (size_t)(K - 1) * N;
+            NttBatch bi{};
+            bi.data = last;
+            bi.outer_stride = (size_t)K * N;
+            bi.ncomp = 1;
+            bi.nouter = (unsigned)polys;
+            bi.prime_first = K - 1;
+            hip_ok(ntt_inverse(c->ntt_tables(), bi, 0, s), "intt last");
+            NttBatch b{};
+            b.data = tt.p;
+            b.outer_stride = (size_t)(K - 1) * N;
+            b.ncomp = K - 1;
+            b.nouter = (unsigned)polys;
+            b.src = last;
+            b.src_outer_stride = (size_t)K * N;
+            b.src_ncomp = 1;
+            b.src_mode = 2;
+            b.src_half = l->dev.half_q_last;
+            b.src_q = l->dev.q_last;
+            b.src_fix = l->dev.round_fix;
+            hip_ok(ntt_forward(c->ntt_tables(), b, 1, s), "ntt correction");
+            hip_ok(k_rescale_combine(c->dev_mods(), l->dev.inv_q_last_mod_q, copy.p, tt.p, out, n_log, K, polys, s), "combine");
+            hip_ok(hipStreamSynchronize(s), "sync");
+        }
+        else
+            throw std::invalid_argument("unknown stage");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_malloc(uint64_t bytes, void **device_ptr)
+    {
+        IfNullRet(device_ptr, SHL_E_POINTER);
+        SHL_TRY
+        if (hipMalloc(device_ptr, bytes) != hipSuccess)
+            throw std::bad_alloc();
+        SHL_CATCH
+    }
+    SHL_FUNC shl_free(void *device_ptr)
+    {
+        SHL_TRY
+        hip_ok(hipFree(device_ptr), "hipFree");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_memcpy_h2d(void *device_dst, const void *host_src, uint64_t bytes)
+    {
+        SHL_TRY
+        hip_ok(hipMemcpy(device_dst, host_src, bytes, hipMemcpyHostToDevice), "H2D");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_memcpy_d2h(void *host_dst, const void *device_src, uint64_t bytes)
+    {
+        SHL_TRY
+        hip_ok(hipDeviceSynchronize(), "sync");
+        hip_ok(hipMemcpy(host_dst, device_src, bytes, hipMemcpyDeviceToHost), "D2H");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_device_synchronize(void)
+    {
+        SHL_TRY
+        hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_timer_create(void **timer)
+    {
+        IfNullRet(timer, SHL_E_POINTER);
+        SHL_TRY
+        auto t = new Timer();
+        hip_ok(hipEventCreate(&t->e0), "hipEventCreate");
+        hip_ok(hipEventCreate(&t->e1), "hipEventCreate");
+        *timer = t;
+        SHL_CATCH
+    }
+    SHL_FUNC shl_timer_destroy(void *timer)
+    {
+        IfNullRet(timer, SHL_E_POINTER);
+        auto t = as<Timer>(timer);
+        (void)hipEventDestroy(t->e0);
+        (void)hipEventDestroy(t->e1);
+        delete t;
+        return SHL_S_OK;
+    }
+    SHL_FUNC shl_timer_start(void *timer, void *stream)
+    {
+        IfNullRet(timer, SHL_E_POINTER);
+        SHL_TRY
+        hip_ok(hipEventRecord(as<Timer>(timer)->e0, (hipStream_t)stream), "hipEventRecord");
+        SHL_CATCH
+    }
+    SHL_FUNC shl_timer_stop(void *timer, void *stream, float *milliseconds)
+    {
+        IfNullRet(timer, SHL_E_POINTER);
+        IfNullRet(milliseconds, SHL_E_POINTER);
+        SHL_TRY
+        auto t = as<Timer>(timer);
+        hip_ok(hipEventRecord(t->e1, (hipStream_t)stream), "hipEventRecord");
+        hip_ok(hipEventSynchronize(t->e1), "hipEventSynchronize");
+        hip_ok(hipEventElapsedTime(milliseconds, t->e0, t->e1), "hipEventElapsedTime");
+        SHL_CATCH
+    }
+}

@@ -1,0 +1,143 @@
+// Device mirror of a SEALContext: the modulus-switching chain and every per-level constant
+// the hot path reads, built on the host with the reference's own definitions and uploaded once.
+//
+// Mirrors (by behaviour, not by structure):
+//   SEALContext / ContextData chain            native/src/seal/context.cpp:495-575, context.h:322-346
+//   NTTTables::initialize                      native/src/seal/util/ntt.cpp:241-300
+//   RNSTool::initialize (BEHZ bases, inverses) native/src/seal/util/rns.cpp:578-787
+//   RNSBase::initialize (CRT data)             native/src/seal/util/rns.cpp:212-257
+//   BaseConverter::initialize                  native/src/seal/util/rns.cpp:541-562
+// HBM layout: one "prime pool" (coefficient primes first, then the BEHZ auxiliary primes) with
+// ModDesc[], forward/inverse twiddle tables [prime][N] of 16-byte Shoup pairs, and one flat
+// constant block per level.
+#pragma once
+#include "hostmath.h"
+#include "ntt_kernels.h"
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace sealhip
+{
+    enum class Scheme : uint8_t
+    {
+        none = 0,
+        bfv = 1,
+        ckks = 2,
+        bgv = 3
+    };
+
+    typedef uint64_t parms_id_type[4];
+
+    constexpr unsigned kMaxComps = 64; // SEAL_COEFF_MOD_COUNT_MAX (defines.h:52)
+
+    // Constants of one level, as the kernels see them (device pointers into one allocation).
+    struct LevelDev
+    {
+        unsigned K = 0;     // coeff_modulus_size at this level
+        unsigned nB = 0;    // |B|
+        unsigned nBsk = 0;  // |B| + 1
+        // rescale / mod-switch (RNSTool::inv_q_last_mod_q_, rns.cpp:769-776)
+        const ShoupOp *inv_q_last_mod_q = nullptr; // [K-1]
+        // q_i - (floor(q_last/2) mod q_i): the rounding correction of rns.cpp:874-877 /
+        // evaluator.cpp:2831, added on load by the NTT (NttBatch::src_mode 2)
+        const uint64_t *round_fix = nullptr;       // [K-1]
+        // floor(q_last/2) mod q_i (coefficient-domain variant, rns.cpp:816-817)
+        const uint64_t *half_mod_q = nullptr;      // [K-1]
+        uint64_t q_last = 0, half_q_last = 0;
+        // BEHZ (BFV multiply); all null when the scheme is CKKS
+        const uint32_t *bsk_prime = nullptr;       // [nBsk] pool index of each Bsk prime (B..., m_sk)
+        const ShoupOp *inv_punct_q = nullptr;      // [K]     (Q/q_i)^-1 mod q_i
+        const ShoupOp *m_tilde_mod_q = nullptr;    // [K]     m~ mod q_i as multiplier
+        const uint64_t *q_to_bsk = nullptr;        // [nBsk][K]   (Q/q_i) mod p_j
+        const uint64_t *q_to_mtilde = nullptr;     // [K]         (Q/q_i) mod m~
+        const uint64_t *prod_q_mod_bsk = nullptr;  // [nBsk]
+        const ShoupOp *inv_mtilde_mod_bsk = nullptr; // [nBsk]
+        const ShoupOp *inv_prod_q_mod_bsk = nullptr; // [nBsk]
+        const ShoupOp *inv_punct_b = nullptr;      // [nB]    (B/b_i)^-1 mod b_i
+        const uint64_t *b_to_q = nullptr;          // [K][nB]     (B/b_i) mod q_j
+        const uint64_t *b_to_msk = nullptr;        // [nB]        (B/b_i) mod m_sk
+        const uint64_t *prod_b_mod_q = nullptr;    // [K]
+        const ShoupOp *t_mod_q = nullptr;          // [K]     plain modulus as multiplier
+        const ShoupOp *t_mod_bsk = nullptr;        // [nBsk]
+        ShoupOp inv_prod_b_mod_msk{ 0, 0 };
+        uint64_t neg_inv_prod_q_mod_mtilde = 0;
+        uint64_t m_tilde = 0;
+        uint32_t msk_prime = 0;                    // pool index of m_sk
+    };
+
+    struct Level
+    {
+        size_t chain_index = 0;
+        unsigned K = 0;
+        parms_id_type parms_id{ 0, 0, 0, 0 };
+        int total_coeff_modulus_bit_count = 0;
+        std::vector<uint64_t> bsk;  // host copy of Bsk primes (B..., m_sk)
+        LevelDev dev;
+        void *dev_block = nullptr;  // owning allocation behind dev's pointers
+    };
+
+    class Context
+    {
+    public:
+        // Throws std::invalid_argument / std::logic_error with the reference's conditions
+        // (context.cpp:142-460) when the parameters are not usable.
+        Context(Scheme scheme, size_t poly_modulus_degree, const std::vector<uint64_t> &coeff_modulus,
+                uint64_t plain_modulus, bool expand_mod_chain);
+        ~Context();
+        Context(const Context &) = delete;
+        Context &operator=(const Context &) = delete;
+
+        Scheme scheme() const { return scheme_; }
+        size_t n() const { return n_; }
+        int log_n() const { return log_n_; }
+        uint64_t plain_modulus() const { return plain_modulus_; }
+        const std::vector<uint64_t> &coeff_modulus() const { return primes_; }
+        bool using_keyswitching() const { return using_keyswitching_; }
+        bool using_batching() const { return using_batching_; }
+
+        // chain: levels_[0] is the key level (chain_index = size-1) ... back() has chain_index 0
+        const std::vector<Level> &levels() const { return levels_; }
+        const Level &key_level() const { return levels_.front(); }
+        const Level &first_level() const { return levels_[using_keyswitching_ ? 1 : 0]; }
+        const Level &last_level() const { return levels_.back(); }
+        const Level *level_by_chain_index(size_t chain_index) const;
+        const Level *level_by_parms_id(const uint64_t *parms_id) const;
+        const Level *next_level(const Level &l) const;
+        void set_parms_id(size_t chain_index, const uint64_t *parms_id);
+
+        // prime pool
+        const std::vector<uint64_t> &pool_primes() const { return pool_; }
+        unsigned aux_first() const { return (unsigned)primes_.size(); } // pool index of m_sk
+        const NttTables &ntt_tables() const { return tables_; }
+        const ModDesc *dev_mods() const { return d_mods_; }
+        // host copies (tests / introspection)
+        uint64_t ntt_root(unsigned pool_index) const { return roots_[pool_index]; }
+        const std::vector<ModDesc> &host_mods() const { return h_mods_; }
+
+        // special prime P^-1 mod q_i for key switching (key level's inv_q_last_mod_q)
+        const ShoupOp *dev_inv_special_mod_q() const { return key_level().dev.inv_q_last_mod_q; }
+
+    private:
+        void build_pool_and_tables();
+        void build_level(Level &lvl);
+
+        Scheme scheme_;
+        size_t n_;
+        int log_n_;
+        uint64_t plain_modulus_;
+        std::vector<uint64_t> primes_;  // coefficient primes (key level order)
+        std::vector<uint64_t> pool_;    // primes_ + [m_sk, gamma, B_0, B_1, ...]
+        std::vector<uint64_t> roots_;   // minimal primitive 2N-th root per pool prime (0 = none)
+        std::vector<ModDesc> h_mods_;
+        std::vector<Level> levels_;
+        bool using_keyswitching_ = false;
+        bool using_batching_ = false;
+
+        ModDesc *d_mods_ = nullptr;
+        ShoupOp *d_fwd_ = nullptr;
+        ShoupOp *d_inv_ = nullptr;
+        ShoupOp *d_ninv_ = nullptr;
+        NttTables tables_{};
+    };
+} // namespace sealhip

@@ -1,0 +1,976 @@
+#include "evaluator.h"
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace sealhip
+{
+    namespace
+    {
+        void ck(hipError_t e, const char *what)
+        {
+            if (e != hipSuccess)
+                throw std::runtime_error(std::string("HIP failure in ") + what + ": " + hipGetErrorString(e));
+        }
+
+        // util::are_close<double> (util/common.h:574-578)
+        bool are_close(double a, double b)
+        {
+            double scale_factor = std::max({ std::fabs(a), std::fabs(b), 1.0 });
+            return std::fabs(a - b) < std::numeric_limits<double>::epsilon() * scale_factor;
+        }
+
+        // util::naf (util/numth.h:22-42)
+        std::vector<int> naf(int value)
+        {
+            std::vector<int> res;
+            bool sign = value < 0;
+            value = std::abs(value);
+            for (int i = 0; value; i++)
+            {
+                int zi = (value & 1) ? 2 - (value & 3) : 0;
+                value = (value - zi) >> 1;
+                if (zi)
+                    res.push_back((sign ? -zi : zi) * (1 << i));
+            }
+            return res;
+        }
+
+        NttBatch plain_batch(uint64_t *data, size_t outer_stride, unsigned ncomp, unsigned nouter, unsigned prime_first)
+        {
+            NttBatch b{};
+            b.data = data;
+            b.outer_stride = outer_stride;
+            b.ncomp = ncomp;
+            b.nouter = nouter;
+            b.comp_prime = nullptr;
+            b.prime_first = prime_first;
+            b.src = nullptr;
+            return b;
+        }
+    } // namespace
+
+    // ---------------------------------------------------------------- DevicePool
+    DevicePool &DevicePool::global()
+    {
+        static DevicePool pool;
+        return pool;
+    }
+    uint64_t *DevicePool::alloc_words(size_t words)
+    {
+        size_t bytes = words * 8;
+        const size_t gran = size_t(256) << 10;
+        bytes = (bytes + gran - 1) / gran * gran;
+        if (!bytes)
+            bytes = gran;
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = free_.lower_bound(bytes);
+        if (it != free_.end() && it->first <= bytes + bytes / 4 + gran)
+        {
+            uint64_t *p = it->second;
+            live_[p] = it->first;
+            free_.erase(it);
+            return p;
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess)
+        {
+            // drop the cache and retry once
+            for (auto &kv : free_)
+            {
+                (void)hipFree(kv.second);
+                held_ -= kv.first;
+            }
+            free_.clear();
+            e = hipMalloc(&p, bytes);
+            if (e != hipSuccess)
+                throw std::bad_alloc();
+        }
+        held_ += bytes;
+        live_[(uint64_t *)p] = bytes;
+        return (uint64_t *)p;
+    }
+    void DevicePool::free_words(uint64_t *p)
+    {
+        if (!p)
+            return;
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = live_.find(p);
+        if (it == live_.end())
+            return;
+        free_.emplace(it->second, p);
+        live_.erase(it);
+    }
+    void DevicePool::release_all()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto &kv : free_)
+        {
+            (void)hipFree(kv.second);
+            held_ -= kv.first;
+        }
+        free_.clear();
+    }
+    DevicePool::~DevicePool()
+    {
+        // process teardown: the HIP runtime may already be gone; leak rather than crash
+    }
+
+    // ---------------------------------------------------------------- Ciphertext
+    Ciphertext::~Ciphertext()
+    {
+        release();
+    }
+    void Ciphertext::release()
+    {
+        DevicePool::global().free_words(data_);
+        data_ = nullptr;
+        capacity_words_ = 0;
+        size_ = 0;
+        level_ = nullptr;
+    }
+    Ciphertext::Ciphertext(const Ciphertext &o) : ctx_(o.ctx_), batch_(o.batch_)
+    {
+        *this = o;
+    }
+    Ciphertext &Ciphertext::operator=(const Ciphertext &o)
+    {
+        if (this == &o)
+            return *this;
+        if (ctx_ != o.ctx_ || batch_ != o.batch_)
+        {
+            release();
+            ctx_ = o.ctx_;
+            batch_ = o.batch_;
+        }
+        size_t words = o.word_count();
+        if (capacity_words_ < words)
+        {
+            DevicePool::global().free_words(data_);
+            data_ = DevicePool::global().alloc_words(words);
+            capacity_words_ = words;
+        }
+        level_ = o.level_;
+        size_ = o.size_;
+        is_ntt_form_ = o.is_ntt_form_;
+        scale_ = o.scale_;
+        correction_factor_ = o.correction_factor_;
+        if (words)
+            ck(hipMemcpyAsync(data_, o.data_, words * 8, hipMemcpyDeviceToDevice, nullptr), "Ciphertext copy");
+        return *this;
+    }
+    void Ciphertext::resize(const Level *level, size_t size, hipStream_t stream)
+    {
+        if (!level)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if ((size < 2 && size != 0) || size > 16) // SEAL_CIPHERTEXT_SIZE_MIN/MAX (defines.h)
+            throw std::invalid_argument("invalid size");
+        size_t pw = batch_ * level->K * ctx_->n();
+        size_t need = size * pw;
+        bool same_level = (level == level_);
+        size_t keep = same_level ? std::min(size_, size) * pw : 0;
+        if (need > capacity_words_)
+        {
+            uint64_t *nd = DevicePool::global().alloc_words(need);
+            if (keep)
+                ck(hipMemcpyAsync(nd, data_, keep * 8, hipMemcpyDeviceToDevice, stream), "Ciphertext resize copy");
+            DevicePool::global().free_words(data_);
+            data_ = nd;
+            capacity_words_ = need;
+        }
+        if (need > keep)
+            ck(hipMemsetAsync(data_ + keep, 0, (need - keep) * 8, stream), "Ciphertext resize zero");
+        level_ = level;
+        size_ = size;
+    }
+    void Ciphertext::adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words)
+    {
+        DevicePool::global().free_words(data_);
+        data_ = slab;
+        capacity_words_ = capacity_words;
+        level_ = level;
+        size_ = size;
+    }
+
+    // ---------------------------------------------------------------- KSwitchKeys
+    KSwitchKeys::~KSwitchKeys()
+    {
+        for (auto &k : keys_)
+            if (k.dev)
+                (void)hipFree(k.dev);
+    }
+    size_t KSwitchKeys::size() const
+    {
+        size_t c = 0;
+        for (auto &k : keys_)
+            c += k.dev != nullptr;
+        return c;
+    }
+    void KSwitchKeys::set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device)
+    {
+        if (!ctx.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        if (ctx_ && ctx_ != &ctx)
+            throw std::invalid_argument("kswitch_keys belongs to another context");
+        if (!words || digits == 0)
+            throw std::invalid_argument("empty key");
+        ctx_ = &ctx;
+        if (index >= keys_.size())
+            keys_.resize(index + 1);
+        size_t L = ctx.key_level().K;
+        size_t bytes = digits * 2 * L * ctx.n() * 8;
+        if (keys_[index].dev)
+            (void)hipFree(keys_[index].dev);
+        void *p = nullptr;
+        ck(hipMalloc(&p, bytes), "hipMalloc key");
+        ck(hipMemcpy(p, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key");
+        keys_[index].dev = (uint64_t *)p;
+        keys_[index].digits = digits;
+    }
+
+    // ---------------------------------------------------------------- Evaluator
+    Evaluator::Evaluator(const Context &context) : context_(context)
+    {
+        void *p = nullptr;
+        ck(hipMalloc(&p, sizeof(unsigned)), "hipMalloc flag");
+        d_flag_ = (unsigned *)p;
+    }
+    Evaluator::~Evaluator()
+    {
+        for (auto &kv : ks_maps_)
+            (void)hipFree(kv.second);
+        if (d_flag_)
+            (void)hipFree(d_flag_);
+    }
+    void Evaluator::synchronize() const
+    {
+        ck(hipStreamSynchronize(stream_), "stream synchronize");
+    }
+
+    size_t Evaluator::relin_index(size_t key_power)
+    {
+        if (key_power < 2)
+            throw std::invalid_argument("key_power cannot be less than 2");
+        return key_power - 2;
+    }
+    size_t Evaluator::galois_index(uint32_t galois_elt)
+    {
+        if (!(galois_elt & 1))
+            throw std::invalid_argument("galois_elt is not valid");
+        return (galois_elt - 1) >> 1;
+    }
+    uint32_t Evaluator::galois_elt_from_step(int step) const
+    {
+        // GaloisTool::get_elt_from_step (util/galois.cpp:53-95), generator 3
+        uint32_t n = (uint32_t)context_.n();
+        uint32_t m32 = n * 2;
+        uint64_t m = m32;
+        if (step == 0)
+            return (uint32_t)(m - 1);
+        bool sign = step < 0;
+        uint32_t pos_step = (uint32_t)std::abs(step);
+        if (pos_step >= (n >> 1))
+            throw std::invalid_argument("step count too large");
+        pos_step &= m32 - 1;
+        int s = sign ? (int)(n >> 1) - (int)pos_step : (int)pos_step;
+        uint64_t elt = 1;
+        while (s--)
+        {
+            elt *= 3;
+            elt &= m - 1;
+        }
+        return (uint32_t)elt;
+    }
+
+    const uint32_t *Evaluator::ks_comp_prime(unsigned K) const
+    {
+        auto it = ks_maps_.find(K);
+        if (it != ks_maps_.end())
+            return it->second;
+        // [ (I*K + J) -> prime(I) for I in 0..K ] followed by [ i -> prime(i) for i in 0..K ]
+        unsigned L = context_.key_level().K;
+        std::vector<uint32_t> m;
+        for (unsigned I = 0; I <= K; I++)
+            for (unsigned J = 0; J < K; J++)
+                m.push_back(I == K ? L - 1 : I);
+        for (unsigned I = 0; I <= K; I++)
+            m.push_back(I == K ? L - 1 : I);
+        void *p = nullptr;
+        ck(hipMalloc(&p, m.size() * 4), "hipMalloc ks map");
+        ck(hipMemcpy(p, m.data(), m.size() * 4, hipMemcpyHostToDevice), "upload ks map");
+        ks_maps_[K] = (uint32_t *)p;
+        return (uint32_t *)p;
+    }
+
+    bool Evaluator::scale_within_bounds(double scale, const Level &lvl) const
+    {
+        // is_scale_within_bounds (evaluator.cpp:29-48)
+        int bound = 0;
+        switch (context_.scheme())
+        {
+        case Scheme::bfv:
+        case Scheme::bgv:
+            bound = host::bit_count(context_.plain_modulus());
+            break;
+        case Scheme::ckks:
+            bound = lvl.total_coeff_modulus_bit_count;
+            break;
+        default:
+            bound = -1;
+        }
+        return !(!std::isnormal(scale) || scale <= 0 || (static_cast<int>(std::log2(scale)) >= bound));
+    }
+
+    void Evaluator::check_valid(const Ciphertext &ct, const char *what) const
+    {
+        // is_metadata_valid_for + is_buffer_valid (valcheck.cpp:81-139, 221-237)
+        bool ok = &ct.context() == &context_ && ct.level() != nullptr;
+        if (ok)
+        {
+            const Level &l = *ct.level();
+            ok = l.chain_index <= context_.first_level().chain_index;
+            size_t size = ct.size();
+            ok = ok && !((size < 2 && size != 0) || size > 16);
+            double scale = ct.scale();
+            Scheme s = context_.scheme();
+            if (s == Scheme::bfv || s == Scheme::bgv)
+                ok = ok && scale == 1.0;
+            else
+                ok = ok && (std::isnormal(scale) && scale > 0);
+            uint64_t cf = ct.correction_factor();
+            if (s == Scheme::bgv)
+                ok = ok && !(cf == 0 || cf >= context_.plain_modulus());
+            else
+                ok = ok && cf == 1;
+            ok = ok && (ct.word_count() == 0 || ct.data() != nullptr);
+        }
+        if (!ok)
+            throw std::invalid_argument(std::string(what) + " is not valid for encryption parameters");
+    }
+
+    bool Evaluator::is_transparent(const Ciphertext &ct) const
+    {
+        // Ciphertext::is_transparent (ciphertext.h:451-456)
+        if (!ct.word_count() || ct.size() < 2)
+            return true;
+        unsigned zero = 0;
+        ck(hipMemcpyAsync(d_flag_, &zero, sizeof(zero), hipMemcpyHostToDevice, stream_), "flag reset");
+        ck(k_any_nonzero(ct.plane(1), (ct.size() - 1) * ct.plane_words(), d_flag_, stream_), "any_nonzero");
+        unsigned flag = 0;
+        ck(hipMemcpyAsync(&flag, d_flag_, sizeof(flag), hipMemcpyDeviceToHost, stream_), "flag read");
+        ck(hipStreamSynchronize(stream_), "flag sync");
+        return flag == 0;
+    }
+    void Evaluator::throw_if_transparent(const Ciphertext &ct) const
+    {
+        if (transparent_check_ && is_transparent(ct))
+            throw std::logic_error("result ciphertext is transparent");
+    }
+
+    // ---- negate / add / sub (evaluator.cpp:130-350)
+    void Evaluator::negate_inplace(Ciphertext &e) const
+    {
+        check_valid(e, "encrypted");
+        PlaneGeom g{ (unsigned)context_.log_n(), e.level()->K, (unsigned)e.batch() };
+        if (e.size())
+            ck(k_addsub(context_.dev_mods(), e.data(), nullptr, e.data(), 2, g, (unsigned)e.size(), stream_), "negate");
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::add_inplace(Ciphertext &e1, const Ciphertext &e2) const
+    {
+        check_valid(e1, "encrypted1");
+        check_valid(e2, "encrypted2");
+        if (e1.level() != e2.level())
+            throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        if (e1.is_ntt_form() != e2.is_ntt_form())
+            throw std::invalid_argument("NTT form mismatch");
+        if (!are_close(e1.scale(), e2.scale()))
+            throw std::invalid_argument("scale mismatch");
+        if (e1.batch() != e2.batch())
+            throw std::invalid_argument("batch mismatch");
+        if (e1.correction_factor() != e2.correction_factor())
+            throw std::logic_error("BGV correction-factor balancing is not implemented on the device path");
+        size_t s1 = e1.size(), s2 = e2.size();
+        size_t mx = std::max(s1, s2), mn = std::min(s1, s2);
+        e1.resize(e1.level(), mx, stream_);
+        PlaneGeom g{ (unsigned)context_.log_n(), e1.level()->K, (unsigned)e1.batch() };
+        if (mn)
+            ck(k_addsub(context_.dev_mods(), e1.data(), e2.data(), e1.data(), 0, g, (unsigned)mn, stream_), "add");
+        if (s1 < s2)
+            ck(hipMemcpyAsync(e1.plane(s1), e2.plane(mn), (s2 - s1) * e1.plane_words() * 8, hipMemcpyDeviceToDevice, stream_),
+               "add copy tail");
+        throw_if_transparent(e1);
+    }
+
+    void Evaluator::sub_inplace(Ciphertext &e1, const Ciphertext &e2) const
+    {
+        check_valid(e1, "encrypted1");
+        check_valid(e2, "encrypted2");
+        if (e1.level() != e2.level())
+            throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        if (e1.is_ntt_form() != e2.is_ntt_form())
+            throw std::invalid_argument("NTT form mismatch");
+        if (!are_close(e1.scale(), e2.scale()))
+            throw std::invalid_argument("scale mismatch");
+        if (e1.batch() != e2.batch())
+            throw std::invalid_argument("batch mismatch");
+        if (e1.correction_factor() != e2.correction_factor())
+            throw std::logic_error("BGV correction-factor balancing is not implemented on the device path");
+        size_t s1 = e1.size(), s2 = e2.size();
+        size_t mx = std::max(s1, s2), mn = std::min(s1, s2);
+        e1.resize(e1.level(), mx, stream_);
+        PlaneGeom g{ (unsigned)context_.log_n(), e1.level()->K, (unsigned)e1.batch() };
+        if (mn)
+            ck(k_addsub(context_.dev_mods(), e1.data(), e2.data(), e1.data(), 1, g, (unsigned)mn, stream_), "sub");
+        if (s1 < s2)
+            ck(k_addsub(context_.dev_mods(), e2.plane(mn), nullptr, e1.plane(mn), 2, g, (unsigned)(s2 - mn), stream_), "sub negate tail");
+        throw_if_transparent(e1);
+    }
+
+    // ---- transforms (evaluator.cpp:2289-2382)
+    void Evaluator::transform_to_ntt_inplace(Ciphertext &e) const
+    {
+        check_valid(e, "encrypted");
+        if (e.is_ntt_form())
+            throw std::invalid_argument("encrypted is already in NTT form");
+        unsigned K = e.level()->K;
+        NttBatch b = plain_batch(e.data(), (size_t)K * context_.n(), K, (unsigned)(e.size() * e.batch()), 0);
+        ck(ntt_forward(context_.ntt_tables(), b, 0, stream_), "ntt_forward");
+        e.is_ntt_form() = true;
+        throw_if_transparent(e);
+    }
+    void Evaluator::transform_from_ntt_inplace(Ciphertext &e) const
+    {
+        check_valid(e, "encrypted");
+        if (!e.is_ntt_form())
+            throw std::invalid_argument("encrypted_ntt is not in NTT form");
+        unsigned K = e.level()->K;
+        NttBatch b = plain_batch(e.data(), (size_t)K * context_.n(), K, (unsigned)(e.size() * e.batch()), 0);
+        ck(ntt_inverse(context_.ntt_tables(), b, 0, stream_), "ntt_inverse");
+        e.is_ntt_form() = false;
+        throw_if_transparent(e);
+    }
+
+    // ---- multiply (evaluator.cpp:352-708)
+    void Evaluator::multiply_inplace(Ciphertext &e1, const Ciphertext &e2) const
+    {
+        check_valid(e1, "encrypted1");
+        check_valid(e2, "encrypted2");
+        if (e1.level() != e2.level())
+            throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        if (e1.batch() != e2.batch())
+            throw std::invalid_argument("batch mismatch");
+        switch (context_.scheme())
+        {
+        case Scheme::bfv:
+            bfv_multiply(e1, e2);
+            break;
+        case Scheme::ckks:
+            ckks_multiply(e1, e2);
+            break;
+        case Scheme::bgv:
+            throw std::logic_error("BGV multiply is not implemented on the device path");
+        default:
+            throw std::invalid_argument("unsupported scheme");
+        }
+        throw_if_transparent(e1);
+    }
+    void Evaluator::square_inplace(Ciphertext &e) const
+    {
+        // ckks_square / bfv_square compute (c0^2, 2 c0 c1, c1^2) = the product of e with itself
+        // (evaluator.cpp:878-1142); canonical results coincide with multiply(e, e).
+        check_valid(e, "encrypted");
+        multiply_inplace(e, e);
+    }
+
+    void Evaluator::ckks_multiply(Ciphertext &e1, const Ciphertext &e2) const
+    {
+        if (!(e1.is_ntt_form() && e2.is_ntt_form()))
+            throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+        const Level &lvl = *e1.level();
+        size_t s1 = e1.size(), s2 = e2.size();
+        if (s1 < 2 || s2 < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+        size_t dest = s1 + s2 - 1;
+        if (dest > 16)
+            throw std::logic_error("invalid parameters");
+        const bool self = (&e1 == &e2);
+        double new_scale = e1.scale() * e2.scale();
+        PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
+        if (dest == 3)
+        {
+            e1.resize(&lvl, 3, stream_);
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, e1.data(), self ? e1.data() : e2.data(), g, stream_), "ckks_multiply");
+        }
+        else
+        {
+            size_t words = dest * g.words();
+            uint64_t *out = DevicePool::global().alloc_words(words);
+            ck(k_multiply_general(context_.dev_mods(), nullptr, e1.data(), (unsigned)s1, e2.data(), (unsigned)s2, out, g, stream_),
+               "ckks_multiply general");
+            e1.adopt(&lvl, dest, out, words);
+        }
+        e1.scale() = new_scale;
+        if (!scale_within_bounds(e1.scale(), lvl))
+            throw std::invalid_argument("scale out of bounds");
+    }
+
+    void Evaluator::bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const
+    {
+        if (e1.is_ntt_form() || e2.is_ntt_form())
+            throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
+        const Level &lvl = *e1.level();
+        const LevelDev &lv = lvl.dev;
+        const unsigned K = lvl.K, nBsk = lv.nBsk;
+        const size_t N = context_.n(), B = e1.batch();
+        const unsigned n_log = (unsigned)context_.log_n();
+        size_t s1 = e1.size(), s2 = e2.size();
+        if (s1 < 2 || s2 < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+        size_t dest = s1 + s2 - 1;
+        if (dest > 16)
+            throw std::logic_error("invalid parameters");
+        const bool self = (&e1 == &e2);
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+
+        // steps (1)-(3): lift each input to q U Bsk and transform (evaluator.cpp:456-489)
+        auto lift = [&](const Ciphertext &x, Scratch &xq, Scratch &xb) {
+            size_t items = x.size() * B;
+            ck(hipMemcpyAsync(xq.p, x.data(), items * K * N * 8, hipMemcpyDeviceToDevice, stream_), "bfv copy");
+            ck(ntt_forward(tb, plain_batch(xq.p, (size_t)K * N, K, (unsigned)items, 0), 0, stream_), "bfv ntt q");
+            ck(k_behz_lift(mods, lv, x.data(), xb.p, n_log, items, stream_), "behz lift");
+            NttBatch bb = plain_batch(xb.p, (size_t)nBsk * N, nBsk, (unsigned)items, 0);
+            bb.comp_prime = lv.bsk_prime;
+            ck(ntt_forward(tb, bb, 0, stream_), "bfv ntt Bsk");
+        };
+        Scratch x_q(s1 * B * K * N), x_b(s1 * B * nBsk * N);
+        lift(e1, x_q, x_b);
+        std::unique_ptr<Scratch> y_q, y_b;
+        if (!self)
+        {
+            y_q.reset(new Scratch(s2 * B * K * N));
+            y_b.reset(new Scratch(s2 * B * nBsk * N));
+            lift(e2, *y_q, *y_b);
+        }
+        const uint64_t *yq = self ? x_q.p : y_q->p;
+        const uint64_t *yb = self ? x_b.p : y_b->p;
+
+        // step (4): dyadic ciphertext product in both bases (evaluator.cpp:497-541)
+        Scratch d_q(dest * B * K * N), d_b(dest * B * nBsk * N);
+        PlaneGeom gq{ n_log, K, (unsigned)B }, gb{ n_log, nBsk, (unsigned)B };
+        ck(k_multiply_general(mods, nullptr, x_q.p, (unsigned)s1, yq, (unsigned)s2, d_q.p, gq, stream_), "bfv tensor q");
+        ck(k_multiply_general(mods, lv.bsk_prime, x_b.p, (unsigned)s1, yb, (unsigned)s2, d_b.p, gb, stream_), "bfv tensor Bsk");
+
+        // step (5): back to coefficient form
+        ck(ntt_inverse(tb, plain_batch(d_q.p, (size_t)K * N, K, (unsigned)(dest * B), 0), 0, stream_), "bfv intt q");
+        NttBatch ib = plain_batch(d_b.p, (size_t)nBsk * N, nBsk, (unsigned)(dest * B), 0);
+        ib.comp_prime = lv.bsk_prime;
+        ck(ntt_inverse(tb, ib, 0, stream_), "bfv intt Bsk");
+
+        // steps (6)-(8)
+        size_t words = dest * B * K * N;
+        uint64_t *out = DevicePool::global().alloc_words(words);
+        ck(k_behz_floor_sk(mods, lv, d_q.p, d_b.p, out, n_log, dest * B, stream_), "behz floor_sk");
+        e1.adopt(&lvl, dest, out, words);
+    }
+
+    // ---- relinearize (evaluator.cpp:1144-1199)
+    void Evaluator::relinearize_inplace(Ciphertext &e, const KSwitchKeys &relin_keys) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (relin_keys.context() != &context_)
+            throw std::invalid_argument("relin_keys is not valid for encryption parameters");
+        size_t size = e.size();
+        const size_t destination_size = 2;
+        if (destination_size > size)
+            throw std::invalid_argument("destination_size must be at least 2 and less than or equal to current count");
+        if (relin_keys.size() < size - 2)
+            throw std::invalid_argument("not enough relinearization keys");
+        if (destination_size == size)
+            return;
+        size_t relins_needed = size - destination_size;
+        // the reference passes the LAST polynomial as the target of every step (evaluator.cpp:1180-1188)
+        for (size_t I = 0; I < relins_needed; I++)
+            switch_key_inplace(e, e.plane(size - 1), relin_keys, relin_index(size - 1 - I));
+        e.resize(e.level(), destination_size, stream_);
+        throw_if_transparent(e);
+    }
+
+    // ---- switch_key_inplace (evaluator.cpp:2561-2867)
+    void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const
+    {
+        check_valid(e, "encrypted");
+        if (!target)
+            throw std::invalid_argument("target_iter");
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        if (keys.context() != &context_)
+            throw std::invalid_argument("parameter mismatch");
+        if (key_index >= keys.slots())
+            throw std::out_of_range("kswitch_keys_index");
+        const Scheme scheme = context_.scheme();
+        if (scheme == Scheme::bfv && e.is_ntt_form())
+            throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+        if (scheme == Scheme::ckks && !e.is_ntt_form())
+            throw std::invalid_argument("CKKS encrypted must be in NTT form");
+        if (scheme == Scheme::bgv && !e.is_ntt_form())
+            throw std::invalid_argument("BGV encrypted must be in NTT form");
+        if (!keys.has_key(key_index))
+            throw std::invalid_argument("kswitch_keys is not valid for encryption parameters");
+        const KSwitchKeys::Key &key = keys.key(key_index);
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K;
+        if (key.digits < K)
+            throw std::invalid_argument("kswitch_keys inner dimension is too small");
+        if (scheme == Scheme::bgv)
+            throw std::logic_error("BGV key switching is not implemented on the device path");
+        if (e.size() < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+
+        const size_t N = context_.n();
+        const unsigned B = (unsigned)e.batch();
+        const unsigned n_log = (unsigned)context_.log_n();
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        const uint32_t *map = ks_comp_prime(K);
+
+        // t_target: coefficient form of every decomposition digit (evaluator.cpp:2651-2658)
+        Scratch t((size_t)B * K * N);
+        ck(hipMemcpyAsync(t.p, target, (size_t)B * K * N * 8, hipMemcpyDeviceToDevice, stream_), "ks copy target");
+        if (scheme == Scheme::ckks)
+            ck(ntt_inverse(tb, plain_batch(t.p, (size_t)K * N, K, B, 0), 0, stream_), "ks intt target");
+
+        // u[b][I][J] = NTT_I(t_J mod q_I), I over the K data primes and the special prime
+        // (evaluator.cpp:2663-2701).  The reference skips the transform when I == J in CKKS because
+        // NTT_J(INTT_J(x)) = x; computing it gives the same canonical words.
+        Scratch u((size_t)B * (K + 1) * K * N);
+        {
+            NttBatch b{};
+            b.data = u.p;
+            b.outer_stride = (size_t)(K + 1) * K * N;
+            b.ncomp = (K + 1) * K;
+            b.nouter = B;
+            b.comp_prime = map;
+            b.prime_first = 0;
+            b.src = t.p;
+            b.src_outer_stride = (size_t)K * N;
+            b.src_ncomp = K;
+            b.src_mode = 1;
+            ck(ntt_forward(tb, b, 0, stream_), "ks ntt digits");
+        }
+
+        // inner product with the key (evaluator.cpp:2703-2755)
+        Scratch acc((size_t)B * 2 * (K + 1) * N);
+        ck(k_keyswitch_mac(mods, u.p, key.dev, acc.p, n_log, K, L, B, stream_), "ks mac");
+
+        // mod-down by the special prime P and accumulate into (c0, c1) (evaluator.cpp:2806-2864)
+        const uint64_t P = context_.coeff_modulus()[L - 1];
+        if (scheme == Scheme::ckks)
+        {
+            NttBatch bi = plain_batch(acc.p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
+            ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
+            Scratch tt((size_t)B * 2 * K * N);
+            NttBatch b{};
+            b.data = tt.p;
+            b.outer_stride = (size_t)K * N;
+            b.ncomp = K;
+            b.nouter = 2 * B;
+            b.comp_prime = nullptr;
+            b.prime_first = 0;
+            b.src = acc.p + (size_t)K * N;
+            b.src_outer_stride = (size_t)(K + 1) * N;
+            b.src_ncomp = 1;
+            b.src_mode = 2;
+            b.src_half = P >> 1;
+            b.src_q = P;
+            b.src_fix = klvl.dev.round_fix;
+            ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction");
+            ck(k_keyswitch_tail_ckks(mods, klvl.dev.inv_q_last_mod_q, e.plane(0), e.plane(1), acc.p, tt.p, n_log, K, B, stream_),
+               "ks tail");
+        }
+        else
+        {
+            NttBatch bi = plain_batch(acc.p, (size_t)(K + 1) * N, K + 1, 2 * B, 0);
+            bi.comp_prime = map + (size_t)(K + 1) * K;
+            ck(ntt_inverse(tb, bi, 0, stream_), "ks intt all");
+            ck(k_keyswitch_tail_bfv(
+                   mods, klvl.dev.inv_q_last_mod_q, klvl.dev.round_fix, P >> 1, P, e.plane(0), e.plane(1), acc.p, n_log, K, B,
+                   stream_),
+               "ks tail bfv");
+        }
+    }
+
+    // ---- modulus switching (evaluator.cpp:1201-1647)
+    void Evaluator::mod_switch_scale_to_next(Ciphertext &e) const
+    {
+        const Scheme scheme = context_.scheme();
+        if (scheme == Scheme::bfv && e.is_ntt_form())
+            throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+        if (scheme == Scheme::ckks && !e.is_ntt_form())
+            throw std::invalid_argument("CKKS encrypted must be in NTT form");
+        if (scheme == Scheme::bgv && !e.is_ntt_form())
+            throw std::invalid_argument("BGV encrypted must be in NTT form");
+        const Level &lvl = *e.level();
+        const Level *next = context_.next_level(lvl);
+        double destination_scale = 1.0;
+        if (scheme == Scheme::ckks)
+        {
+            if (!scale_within_bounds(e.scale(), lvl))
+                throw std::invalid_argument("scale out of bounds");
+            destination_scale = e.scale() / static_cast<double>(context_.coeff_modulus()[lvl.K - 1]);
+            if (!scale_within_bounds(destination_scale, *next))
+                throw std::invalid_argument("scale out of bounds");
+        }
+        if (scheme == Scheme::bgv)
+            throw std::logic_error("BGV mod switching is not implemented on the device path");
+
+        const unsigned K = lvl.K;
+        const size_t N = context_.n();
+        const size_t items = e.size() * e.batch();
+        const unsigned n_log = (unsigned)context_.log_n();
+        const ModDesc *mods = context_.dev_mods();
+        size_t words = items * (K - 1) * N;
+        uint64_t *out = DevicePool::global().alloc_words(words);
+        try
+        {
+            if (scheme == Scheme::bfv)
+            {
+                ck(k_bfv_modswitch(mods, lvl.dev, e.data(), out, n_log, items, stream_), "bfv modswitch");
+            }
+            else
+            {
+                // divide_and_round_q_last_ntt_inplace (rns.cpp:830-901)
+                const NttTables &tb = context_.ntt_tables();
+                uint64_t *last = e.data() + (size_t)(K - 1) * N;
+                ck(ntt_inverse(tb, plain_batch(last, (size_t)K * N, 1, (unsigned)items, K - 1), 0, stream_), "rescale intt last");
+                Scratch tt(words);
+                NttBatch b{};
+                b.data = tt.p;
+                b.outer_stride = (size_t)(K - 1) * N;
+                b.ncomp = K - 1;
+                b.nouter = (unsigned)items;
+                b.comp_prime = nullptr;
+                b.prime_first = 0;
+                b.src = last;
+                b.src_outer_stride = (size_t)K * N;
+                b.src_ncomp = 1;
+                b.src_mode = 2;
+                b.src_half = lvl.dev.half_q_last;
+                b.src_q = lvl.dev.q_last;
+                b.src_fix = lvl.dev.round_fix;
+                ck(ntt_forward(tb, b, 1, stream_), "rescale ntt correction");
+                ck(k_rescale_combine(mods, lvl.dev.inv_q_last_mod_q, e.data(), tt.p, out, n_log, K, items, stream_), "rescale combine");
+            }
+        }
+        catch (...)
+        {
+            DevicePool::global().free_words(out);
+            throw;
+        }
+        size_t size = e.size();
+        e.adopt(next, size, out, words);
+        if (scheme == Scheme::ckks)
+            e.scale() = destination_scale;
+    }
+
+    void Evaluator::mod_switch_drop_to_next(Ciphertext &e) const
+    {
+        const Scheme scheme = context_.scheme();
+        if (scheme == Scheme::bfv && e.is_ntt_form())
+            throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+        if (scheme == Scheme::ckks && !e.is_ntt_form())
+            throw std::invalid_argument("CKKS encrypted must be in NTT form");
+        if (scheme == Scheme::bgv && !e.is_ntt_form())
+            throw std::invalid_argument("BGV encrypted must be in NTT form");
+        const Level &lvl = *e.level();
+        const Level *next = context_.next_level(lvl);
+        if (!scale_within_bounds(e.scale(), *next))
+            throw std::invalid_argument("scale out of bounds");
+        const unsigned K = lvl.K;
+        const size_t items = e.size() * e.batch();
+        size_t words = items * (K - 1) * context_.n();
+        uint64_t *out = DevicePool::global().alloc_words(words);
+        ck(k_drop_last(e.data(), out, (unsigned)context_.log_n(), K, items, stream_), "drop last");
+        size_t size = e.size();
+        e.adopt(next, size, out, words);
+    }
+
+    void Evaluator::mod_switch_to_next_inplace(Ciphertext &e) const
+    {
+        check_valid(e, "encrypted");
+        if (e.level() == &context_.last_level())
+            throw std::invalid_argument("end of modulus switching chain reached");
+        switch (context_.scheme())
+        {
+        case Scheme::bfv:
+            mod_switch_scale_to_next(e);
+            break;
+        case Scheme::ckks:
+            mod_switch_drop_to_next(e);
+            break;
+        case Scheme::bgv:
+            mod_switch_scale_to_next(e);
+            break;
+        default:
+            throw std::invalid_argument("unsupported scheme");
+        }
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::mod_switch_to_inplace(Ciphertext &e, const uint64_t *parms_id) const
+    {
+        const Level *target = context_.level_by_parms_id(parms_id);
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (!target)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (e.level()->chain_index < target->chain_index)
+            throw std::invalid_argument("cannot switch to higher level modulus");
+        while (e.level() != target)
+            mod_switch_to_next_inplace(e);
+    }
+
+    void Evaluator::rescale_to_next_inplace(Ciphertext &e) const
+    {
+        check_valid(e, "encrypted");
+        if (e.level() == &context_.last_level())
+            throw std::invalid_argument("end of modulus switching chain reached");
+        switch (context_.scheme())
+        {
+        case Scheme::bfv:
+        case Scheme::bgv:
+            throw std::invalid_argument("unsupported operation for scheme type");
+        case Scheme::ckks:
+            mod_switch_scale_to_next(e);
+            break;
+        default:
+            throw std::invalid_argument("unsupported scheme");
+        }
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::rescale_to_inplace(Ciphertext &e, const uint64_t *parms_id) const
+    {
+        check_valid(e, "encrypted");
+        const Level *target = context_.level_by_parms_id(parms_id);
+        if (!target)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (e.level()->chain_index < target->chain_index)
+            throw std::invalid_argument("cannot switch to higher level modulus");
+        if (context_.scheme() != Scheme::ckks)
+            throw std::invalid_argument("unsupported operation for scheme type");
+        while (e.level() != target)
+            mod_switch_scale_to_next(e);
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::mod_reduce_to_next_inplace(Ciphertext &e) const
+    {
+        check_valid(e, "encrypted");
+        if (e.level() == &context_.last_level())
+            throw std::invalid_argument("end of modulus switching chain reached");
+        mod_switch_drop_to_next(e);
+        throw_if_transparent(e);
+    }
+
+    // ---- Galois automorphisms and rotations (evaluator.cpp:2384-2559, evaluator.h:1072-1375)
+    void Evaluator::apply_galois_inplace(Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys) const
+    {
+        check_valid(e, "encrypted");
+        if (galois_keys.context() != &context_)
+            throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+        const Level &lvl = *e.level();
+        const size_t N = context_.n();
+        uint64_t m = 2 * (uint64_t)N;
+        if (!(galois_elt & 1) || galois_elt >= m)
+        {
+            // has_key() throws invalid_argument for an even element before this check in the
+            // reference (galoiskeys.h:48-57); either way the class is invalid_argument
+            throw std::invalid_argument("Galois element is not valid");
+        }
+        if (!galois_keys.has_key(galois_index(galois_elt)))
+            throw std::invalid_argument("Galois key not present");
+        if (e.size() != 2)
+            throw std::invalid_argument("encrypted size must be 2");
+        const Scheme scheme = context_.scheme();
+        if (scheme == Scheme::bfv && e.is_ntt_form())
+            throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+        if (scheme == Scheme::ckks && !e.is_ntt_form())
+            throw std::invalid_argument("CKKS encrypted must be in NTT form");
+        if (scheme == Scheme::bgv && !e.is_ntt_form())
+            throw std::invalid_argument("BGV encrypted must be in NTT form");
+
+        PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e.batch() };
+        const int ntt_form = scheme == Scheme::bfv ? 0 : 1;
+        Scratch perm(2 * g.words()); // [pi(c0), pi(c1)]
+        ck(k_apply_galois(context_.dev_mods(), e.data(), perm.p, galois_elt, ntt_form, g, 2, stream_), "apply_galois");
+        ck(hipMemcpyAsync(e.plane(0), perm.p, g.words() * 8, hipMemcpyDeviceToDevice, stream_), "galois copy c0");
+        ck(hipMemsetAsync(e.plane(1), 0, g.words() * 8, stream_), "galois zero c1");
+        switch_key_inplace(e, perm.p + g.words(), galois_keys, galois_index(galois_elt));
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::rotate_internal(Ciphertext &e, int steps, const KSwitchKeys &galois_keys) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (!context_.using_batching())
+            throw std::logic_error("encryption parameters do not support batching");
+        if (galois_keys.context() != &context_)
+            throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+        if (steps == 0)
+            return;
+        size_t coeff_count = context_.n();
+        uint32_t elt = galois_elt_from_step(steps);
+        if (galois_keys.has_key(galois_index(elt)))
+        {
+            apply_galois_inplace(e, elt, galois_keys);
+        }
+        else
+        {
+            std::vector<int> naf_steps = naf(steps);
+            if (naf_steps.size() == 1)
+                throw std::invalid_argument("Galois key not present");
+            for (int step : naf_steps)
+                if ((size_t)std::abs(step) != (coeff_count >> 1))
+                    rotate_internal(e, step, galois_keys);
+        }
+    }
+    void Evaluator::conjugate_internal(Ciphertext &e, const KSwitchKeys &galois_keys) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (!context_.using_batching())
+            throw std::logic_error("encryption parameters do not support batching");
+        apply_galois_inplace(e, galois_elt_from_step(0), galois_keys);
+    }
+    void Evaluator::rotate_rows_inplace(Ciphertext &e, int steps, const KSwitchKeys &gk) const
+    {
+        if (context_.scheme() != Scheme::bfv && context_.scheme() != Scheme::bgv)
+            throw std::logic_error("unsupported scheme");
+        rotate_internal(e, steps, gk);
+    }
+    void Evaluator::rotate_columns_inplace(Ciphertext &e, const KSwitchKeys &gk) const
+    {
+        if (context_.scheme() != Scheme::bfv && context_.scheme() != Scheme::bgv)
+            throw std::logic_error("unsupported scheme");
+        conjugate_internal(e, gk);
+    }
+    void Evaluator::rotate_vector_inplace(Ciphertext &e, int steps, const KSwitchKeys &gk) const
+    {
+        if (context_.scheme() != Scheme::ckks)
+            throw std::logic_error("unsupported scheme");
+        rotate_internal(e, steps, gk);
+    }
+    void Evaluator::complex_conjugate_inplace(Ciphertext &e, const KSwitchKeys &gk) const
+    {
+        if (context_.scheme() != Scheme::ckks)
+            throw std::logic_error("unsupported scheme");
+        conjugate_internal(e, gk);
+    }
+} // namespace sealhip

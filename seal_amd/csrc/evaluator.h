@@ -1,0 +1,178 @@
+// Host orchestration: the device-resident counterparts of seal::Ciphertext, seal::KSwitchKeys and
+// seal::Evaluator for the hot path.  Same method names, argument meaning, metadata updates and
+// exception classes as the reference (native/src/seal/evaluator.h:79-1387, evaluator.cpp); the
+// arithmetic is enqueued on a HIP stream as the kernels of ntt_kernels.hip / poly_kernels.hip /
+// behz_kernels.hip.
+#pragma once
+#include "context.h"
+#include "poly_kernels.h"
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <vector>
+
+namespace sealhip
+{
+    // Size-bucketed caching allocator for HBM scratch and ciphertext slabs (hipMalloc/hipFree
+    // synchronise the device; the reference's MemoryPool plays the same role on the host,
+    // native/src/seal/util/mempool.h).  Blocks are reused in stream order by a single stream.
+    class DevicePool
+    {
+    public:
+        static DevicePool &global();
+        uint64_t *alloc_words(size_t words);
+        void free_words(uint64_t *p);
+        void release_all();
+        size_t bytes_held() const { return held_; }
+        ~DevicePool();
+
+    private:
+        std::mutex mu_;
+        std::multimap<size_t, uint64_t *> free_;
+        std::map<uint64_t *, size_t> live_;
+        size_t held_ = 0;
+    };
+
+    struct Scratch
+    {
+        uint64_t *p = nullptr;
+        explicit Scratch(size_t words) : p(DevicePool::global().alloc_words(words)) {}
+        ~Scratch() { DevicePool::global().free_words(p); }
+        Scratch(const Scratch &) = delete;
+        Scratch &operator=(const Scratch &) = delete;
+    };
+
+    // A batch of `batch` ciphertexts sharing metadata; slab layout [poly][batch][K][N].
+    class Ciphertext
+    {
+    public:
+        explicit Ciphertext(const Context &ctx, size_t batch = 1) : ctx_(&ctx), batch_(batch ? batch : 1) {}
+        ~Ciphertext();
+        Ciphertext(const Ciphertext &o);
+        Ciphertext &operator=(const Ciphertext &o);
+
+        const Context &context() const { return *ctx_; }
+        size_t batch() const { return batch_; }
+        size_t size() const { return size_; }
+        const Level *level() const { return level_; }
+        size_t coeff_modulus_size() const { return level_ ? level_->K : 0; }
+        size_t poly_modulus_degree() const { return level_ ? ctx_->n() : 0; }
+        bool &is_ntt_form() { return is_ntt_form_; }
+        bool is_ntt_form() const { return is_ntt_form_; }
+        double &scale() { return scale_; }
+        double scale() const { return scale_; }
+        uint64_t &correction_factor() { return correction_factor_; }
+        uint64_t correction_factor() const { return correction_factor_; }
+        uint64_t *data() { return data_; }
+        const uint64_t *data() const { return data_; }
+        size_t plane_words() const { return level_ ? batch_ * level_->K * ctx_->n() : 0; }
+        size_t word_count() const { return size_ * plane_words(); }
+        uint64_t *plane(size_t p) { return data_ + p * plane_words(); }
+        const uint64_t *plane(size_t p) const { return data_ + p * plane_words(); }
+
+        // Ciphertext::resize(context, parms_id, size) (ciphertext.cpp:101-116): keeps the leading
+        // polynomials when only `size` changes at the same level; contents are unspecified after a
+        // level change.  New polynomials are zero (the reference's DynArray zero-fills).
+        void resize(const Level *level, size_t size, hipStream_t stream);
+        // adopt a freshly computed slab (takes ownership of `words` from the pool)
+        void adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words);
+        void release();
+
+    private:
+        const Context *ctx_;
+        size_t batch_;
+        size_t size_ = 0;
+        const Level *level_ = nullptr;
+        bool is_ntt_form_ = false;
+        double scale_ = 1.0;
+        uint64_t correction_factor_ = 1;
+        uint64_t *data_ = nullptr;
+        size_t capacity_words_ = 0;
+    };
+
+    // KSwitchKeys::keys_ (kswitchkeys.h:340): per index, `digits` size-2 key-level ciphertexts in NTT
+    // form, stored as one slab [digit][2][L][N].
+    class KSwitchKeys
+    {
+    public:
+        struct Key
+        {
+            uint64_t *dev = nullptr;
+            size_t digits = 0;
+        };
+        ~KSwitchKeys();
+        void set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device);
+        bool has_key(size_t index) const { return index < keys_.size() && keys_[index].dev != nullptr; }
+        const Key &key(size_t index) const { return keys_[index]; }
+        size_t slots() const { return keys_.size(); }
+        size_t size() const;
+        const Context *context() const { return ctx_; }
+
+    private:
+        std::vector<Key> keys_;
+        const Context *ctx_ = nullptr;
+    };
+
+    class Evaluator
+    {
+    public:
+        explicit Evaluator(const Context &context);
+        ~Evaluator();
+
+        const Context &context() const { return context_; }
+        void set_stream(hipStream_t s) { stream_ = s; }
+        hipStream_t stream() const { return stream_; }
+        void synchronize() const;
+        // SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (evaluator.cpp:386-392) needs a device->host round trip
+        // per operation; off by default for device-resident batches, on for drop-in parity checks.
+        void set_transparent_check(bool on) { transparent_check_ = on; }
+
+        void negate_inplace(Ciphertext &encrypted) const;
+        void add_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const;
+        void sub_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const;
+        void multiply_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const;
+        void square_inplace(Ciphertext &encrypted) const;
+        void relinearize_inplace(Ciphertext &encrypted, const KSwitchKeys &relin_keys) const;
+        void mod_switch_to_next_inplace(Ciphertext &encrypted) const;
+        void mod_switch_to_inplace(Ciphertext &encrypted, const uint64_t *parms_id) const;
+        void rescale_to_next_inplace(Ciphertext &encrypted) const;
+        void rescale_to_inplace(Ciphertext &encrypted, const uint64_t *parms_id) const;
+        void mod_reduce_to_next_inplace(Ciphertext &encrypted) const;
+        void transform_to_ntt_inplace(Ciphertext &encrypted) const;
+        void transform_from_ntt_inplace(Ciphertext &encrypted_ntt) const;
+        void apply_galois_inplace(Ciphertext &encrypted, uint32_t galois_elt, const KSwitchKeys &galois_keys) const;
+        void rotate_rows_inplace(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
+        void rotate_columns_inplace(Ciphertext &encrypted, const KSwitchKeys &galois_keys) const;
+        void rotate_vector_inplace(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
+        void complex_conjugate_inplace(Ciphertext &encrypted, const KSwitchKeys &galois_keys) const;
+
+        bool is_transparent(const Ciphertext &ct) const; // synchronises
+
+        static size_t relin_index(size_t key_power);       // RelinKeys::get_index  (relinkeys.h:58)
+        static size_t galois_index(uint32_t galois_elt);   // GaloisKeys::get_index (galoiskeys.h:48)
+        uint32_t galois_elt_from_step(int step) const;      // GaloisTool::get_elt_from_step (galois.cpp:53)
+
+        // switch_key_inplace (evaluator.cpp:2561): encrypted (size >= 2) += KS(target), target = one
+        // plane [batch][K][N] in the scheme's native form.
+        void switch_key_inplace(Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const;
+
+    private:
+        void check_valid(const Ciphertext &ct, const char *what) const;
+        bool scale_within_bounds(double scale, const Level &lvl) const;
+        void bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const;
+        void ckks_multiply(Ciphertext &e1, const Ciphertext &e2) const;
+        void mod_switch_scale_to_next(Ciphertext &encrypted) const;
+        void mod_switch_drop_to_next(Ciphertext &encrypted) const;
+        void rotate_internal(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
+        void conjugate_internal(Ciphertext &encrypted, const KSwitchKeys &galois_keys) const;
+        void throw_if_transparent(const Ciphertext &ct) const;
+        const uint32_t *ks_comp_prime(unsigned K) const;
+
+        const Context &context_;
+        hipStream_t stream_ = nullptr;
+        bool transparent_check_ = false;
+        mutable std::map<unsigned, uint32_t *> ks_maps_;
+        mutable unsigned *d_flag_ = nullptr;
+    };
+} // namespace sealhip

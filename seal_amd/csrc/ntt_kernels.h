@@ -1,0 +1,58 @@
+// Negacyclic NTT / INTT for gfx950 — device-side building blocks and launch interface.
+//
+// Replaces the reference's DWTHandler::transform_to_rev / transform_from_rev
+// (native/src/seal/util/dwthandler.h:94-356) and the ntt_negacyclic_harvey* wrappers
+// (native/src/seal/util/ntt.cpp:394-475).  Same mathematical transform — root psi =
+// NTTTables::get_root(), natural-order input, bit-reversed output (SURVEY §8(a') "NTT") — but
+// decomposed for the GPU: a transform of 2^n points is one or two "passes"; a pass executes D
+// consecutive radix-2 stages for a tile held in LDS, as ceil(D/R) register phases of R stages on
+// 2^R coefficients per thread (radix-2^R blocks), exchanging through LDS between phases.  The
+// first pass of a two-pass transform works on strided columns (coalesced along the contiguous
+// low index), the last pass on contiguous rows; the merged psi-power twiddles of the reference's
+// bit-reversed table are what lets the two passes compose without an extra twiddle multiply.
+#pragma once
+#include "modarith.h"
+
+namespace sealhip
+{
+    // Per-prime table set resident in HBM.  fwd[i] = psi^bitrev_n(i), inv[i] = fwd[i]^-1
+    // (our own layout for the inverse: same index as the forward stage that it undoes).
+    struct NttTables
+    {
+        const ModDesc *mods;  // [nprimes]
+        const ShoupOp *fwd;   // [nprimes][N]
+        const ShoupOp *inv;   // [nprimes][N]
+        const ShoupOp *ninv;  // [nprimes][2]: {N^-1, N^-1 * inv[1]}
+        int log_n;
+    };
+
+    // One batched launch: transforms live at data + outer*outer_stride + comp*N, comp in
+    // [0, ncomp), outer in [0, nouter); prime of a component = comp_prime[comp] (device array) or
+    // prime_first + comp when comp_prime == nullptr.
+    struct NttBatch
+    {
+        uint64_t *data;
+        size_t outer_stride; // words
+        unsigned ncomp;
+        unsigned nouter;
+        const uint32_t *comp_prime;
+        unsigned prime_first;
+        // Optional separate source for the first pass (forward only): src + outer*src_outer_stride
+        // + (comp % src_ncomp)*N is read instead of data and mapped into the target prime:
+        //   src_mode 1: x mod q                      (key-switch mod-raise, evaluator.cpp:2690-2701)
+        //   src_mode 2: ((x + src_half) mod src_q) mod q + src_fix[comp]
+        //               (the "+half, mod q_i, -half" rounding step fused into the load:
+        //                rns.cpp:858-881 rescale, evaluator.cpp:2813-2832 key-switch mod-down)
+        const uint64_t *src;
+        size_t src_outer_stride;
+        unsigned src_ncomp;
+        int src_mode;
+        uint64_t src_half;
+        uint64_t src_q;
+        const uint64_t *src_fix; // [ncomp], device
+    };
+
+    // out_range: 0 = canonical [0,q); 1 = lazy ([0,4q) forward / [0,2q) inverse).
+    hipError_t ntt_forward(const NttTables &t, const NttBatch &b, int out_lazy, hipStream_t stream);
+    hipError_t ntt_inverse(const NttTables &t, const NttBatch &b, int out_lazy, hipStream_t stream);
+} // namespace sealhip

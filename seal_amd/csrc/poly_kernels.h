@@ -1,0 +1,88 @@
+// Element-wise RNS polynomial kernels (HBM-bound glue between the transforms) and the
+// key-switching inner product.  Launch wrappers only; kernels are in poly_kernels.hip.
+//
+// Reference functions covered (results canonical, hence bit-identical):
+//   dyadic_product_coeffmod / add_/sub_/negate_poly_coeffmod   util/polyarithsmallmod.cpp:43-284
+//   ckks_multiply tile loop (x0y0, x0y1+x1y0, x1y1)            evaluator.cpp:604-663
+//   GaloisTool::apply_galois / apply_galois_ntt                 util/galois.cpp:148-218
+//   divide_and_round_q_last[_ntt]_inplace tail                  util/rns.cpp:789-901
+//   switch_key_inplace inner product and mod-down tail          evaluator.cpp:2663-2864
+//
+// Plane layout everywhere: a "plane" is one polynomial of every batch item, [batch][K][N] words.
+#pragma once
+#include "context.h"
+
+namespace sealhip
+{
+    struct PlaneGeom
+    {
+        unsigned n_log;   // log2 N
+        unsigned K;       // components per item in this plane
+        unsigned batch;   // items
+        size_t words() const { return ((size_t)batch * K) << n_log; }
+    };
+
+    // x (size 2, in place -> size 3) *= y (size 2).  Planes are plane_words apart.
+    // comp_prime (device, may be null = identity) maps a component to its pool prime.
+    hipError_t k_ckks_multiply_2x2(
+        const ModDesc *mods, const uint32_t *comp_prime, uint64_t *x, const uint64_t *y, PlaneGeom g, hipStream_t s);
+    // out[I] = sum_a x[a] * y[I-a] for general sizes; out must not alias x or y.
+    hipError_t k_multiply_general(
+        const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, unsigned size_x, const uint64_t *y,
+        unsigned size_y, uint64_t *out, PlaneGeom g, hipStream_t s);
+    // r = a .* b over `count` polys of `comps` comps (first_prime..): the raw dyadic seam
+    hipError_t k_dyadic(
+        const ModDesc *mods, const uint64_t *a, const uint64_t *b, uint64_t *r, unsigned n_log, unsigned comps,
+        unsigned first_prime, size_t polys, hipStream_t s);
+    // op: 0 add, 1 sub, 2 negate (b ignored).  `planes` planes of geometry g.
+    hipError_t k_addsub(
+        const ModDesc *mods, const uint64_t *a, const uint64_t *b, uint64_t *r, int op, PlaneGeom g, unsigned planes,
+        hipStream_t s);
+    // Galois automorphism on `planes` planes; ntt_form selects the NTT-domain gather or the
+    // coefficient-domain signed scatter.  in != out.
+    hipError_t k_apply_galois(
+        const ModDesc *mods, const uint64_t *in, uint64_t *out, uint32_t galois_elt, int ntt_form, PlaneGeom g,
+        unsigned planes, hipStream_t s);
+
+    // CKKS rescale tail: out[item][i] = (c[item][i] - t[item][i]) * q_last^-1 mod q_i, i < K-1;
+    // c has K comps per item, t and out K-1; t is lazy (< 4 q_i).
+    hipError_t k_rescale_combine(
+        const ModDesc *mods, const ShoupOp *inv_q_last, const uint64_t *c, const uint64_t *t, uint64_t *out,
+        unsigned n_log, unsigned K, size_t items, hipStream_t s);
+    // BFV mod-switch (coefficient domain), whole formula in one kernel.
+    hipError_t k_bfv_modswitch(
+        const ModDesc *mods, const LevelDev &lv, const uint64_t *c, uint64_t *out, unsigned n_log, size_t items,
+        hipStream_t s);
+    // drop the last component: out[item][i] = c[item][i], i < K-1
+    hipError_t k_drop_last(const uint64_t *c, uint64_t *out, unsigned n_log, unsigned K, size_t items, hipStream_t s);
+
+    // Key-switch inner product.  u: [batch][K+1][K][N] (target digit J raised to modulus I, NTT form,
+    // canonical); key: [digits][2][L][N]; acc: [batch][2][K+1][N] canonical.  Modulus index I == K
+    // means the special prime (pool/key component L-1).
+    hipError_t k_keyswitch_mac(
+        const ModDesc *mods, const uint64_t *u, const uint64_t *key, uint64_t *acc, unsigned n_log, unsigned K,
+        unsigned L, unsigned batch, hipStream_t s);
+    // Key-switch tail (CKKS): ct_k[b][i] += (acc[b][k][i] - t[b][k][i]) * P^-1 mod q_i.
+    // ct planes: ct0 and ct1, each [batch][K][N]; acc [batch][2][K+1][N]; t [batch][2][K][N] lazy.
+    hipError_t k_keyswitch_tail_ckks(
+        const ModDesc *mods, const ShoupOp *inv_p, uint64_t *ct0, uint64_t *ct1, const uint64_t *acc,
+        const uint64_t *t, unsigned n_log, unsigned K, unsigned batch, hipStream_t s);
+    // Key-switch tail (BFV): acc comps 0..K-1 already in coefficient form (canonical); r = acc comp K
+    // in coefficient form canonical; ct_k[b][i] += (acc_i - ((r+half mod P) mod q_i - half mod q_i)) * P^-1.
+    hipError_t k_keyswitch_tail_bfv(
+        const ModDesc *mods, const ShoupOp *inv_p, const uint64_t *round_fix, uint64_t half_p, uint64_t p,
+        uint64_t *ct0, uint64_t *ct1, const uint64_t *acc, unsigned n_log, unsigned K, unsigned batch, hipStream_t s);
+    // BEHZ (BFV multiply) per-coefficient base conversions, util/rns.cpp:903-1131.
+    // lift: fastbconv_m_tilde + sm_mrq.  in [items][K][N] canonical -> out [items][nBsk][N] canonical.
+    hipError_t k_behz_lift(const ModDesc *mods, const LevelDev &lv, const uint64_t *in, uint64_t *out, unsigned n_log,
+                           size_t items, hipStream_t s);
+    // floor_sk: (x t) -> fast_floor -> fastbconv_sk.  dq [items][K][N] (< 2q), dbsk [items][nBsk][N] (< 2p)
+    // -> out [items][K][N] canonical.
+    hipError_t k_behz_floor_sk(const ModDesc *mods, const LevelDev &lv, const uint64_t *dq, const uint64_t *dbsk,
+                               uint64_t *out, unsigned n_log, size_t items, hipStream_t s);
+    // the four RNSTool stages separately (per-kernel parity seam): see shl_rns_stage in sealhip.h
+    hipError_t k_behz_stage(const ModDesc *mods, const LevelDev &lv, int which, const uint64_t *in, uint64_t *out,
+                            unsigned n_log, size_t items, hipStream_t s);
+    // any nonzero word in [data, data+words)?  *flag (device) |= 1
+    hipError_t k_any_nonzero(const uint64_t *data, size_t words, unsigned *flag, hipStream_t s);
+} // namespace sealhip

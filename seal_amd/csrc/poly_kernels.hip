@@ -1,0 +1,413 @@
+// Element-wise RNS polynomial kernels and the key-switching inner product for gfx950.
+// All of these are HBM-streaming kernels: one coalesced pass over the operands, 64-bit words,
+// grid-stride over a capped grid (256 CUs x 8 workgroups).  See poly_kernels.h for the map to
+// the reference functions.
+#include "poly_kernels.h"
+
+namespace sealhip
+{
+    namespace
+    {
+        constexpr unsigned kBlock = 256;
+        inline unsigned grid_for(size_t work)
+        {
+            size_t b = (work + kBlock - 1) / kBlock;
+            if (b > 2048)
+                b = 2048;
+            if (b == 0)
+                b = 1;
+            return (unsigned)b;
+        }
+
+        // 128-bit accumulate: (hi:lo) += a*b
+        __device__ __forceinline__ void mac128(uint64_t &lo, uint64_t &hi, uint64_t a, uint64_t b)
+        {
+            uint64_t pl, ph;
+            mul_wide(a, b, pl, ph);
+            lo += pl;
+            hi += ph + (lo < pl);
+        }
+
+        __global__ void __launch_bounds__(kBlock) ckks_multiply_2x2_kernel(
+            const ModDesc *mods, const uint32_t *comp_prime, uint64_t *x, const uint64_t *y, unsigned n_log, unsigned K,
+            size_t plane_words)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < plane_words; i += (size_t)gridDim.x * kBlock)
+            {
+                const unsigned comp = (unsigned)((i >> n_log) % K);
+                const ModDesc md = mods[comp_prime ? comp_prime[comp] : comp];
+                uint64_t x0 = x[i], x1 = x[plane_words + i];
+                uint64_t y0 = y[i], y1 = y[plane_words + i];
+                uint64_t lo = 0, hi = 0;
+                mac128(lo, hi, x0, y1);
+                mac128(lo, hi, x1, y0);
+                x[i] = mul_mod(x0, y0, md);
+                x[plane_words + i] = barrett128(lo, hi, md);
+                x[2 * plane_words + i] = mul_mod(x1, y1, md);
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) multiply_general_kernel(
+            const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, unsigned sx, const uint64_t *y, unsigned sy,
+            uint64_t *out, unsigned n_log, unsigned K, size_t plane_words)
+        {
+            const unsigned dest = sx + sy - 1;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < plane_words; i += (size_t)gridDim.x * kBlock)
+            {
+                const unsigned comp = (unsigned)((i >> n_log) % K);
+                const ModDesc md = mods[comp_prime ? comp_prime[comp] : comp];
+                for (unsigned I = 0; I < dest; I++)
+                {
+                    // a ranges over max(0, I-(sy-1)) .. min(I, sx-1)   (evaluator.cpp:670-681)
+                    unsigned a_lo = I > sy - 1 ? I - (sy - 1) : 0;
+                    unsigned a_hi = I < sx - 1 ? I : sx - 1;
+                    uint64_t acc = 0;
+                    for (unsigned a = a_lo; a <= a_hi; a++)
+                        acc = add_mod(acc, mul_mod(x[a * plane_words + i], y[(I - a) * plane_words + i], md), md.q);
+                    out[I * plane_words + i] = acc;
+                }
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) dyadic_kernel(
+            const ModDesc *mods, const uint64_t *a, const uint64_t *b, uint64_t *r, unsigned n_log, unsigned comps,
+            unsigned first_prime, size_t words)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const unsigned comp = (unsigned)((i >> n_log) % comps);
+                r[i] = mul_mod(a[i], b[i], mods[first_prime + comp]);
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) addsub_kernel(
+            const ModDesc *mods, const uint64_t *a, const uint64_t *b, uint64_t *r, int op, unsigned n_log, unsigned K,
+            size_t words)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const unsigned comp = (unsigned)((i >> n_log) % K);
+                const uint64_t q = mods[comp].q;
+                uint64_t v;
+                if (op == 0)
+                    v = add_mod(a[i], b[i], q);
+                else if (op == 1)
+                    v = sub_mod(a[i], b[i], q);
+                else
+                    v = neg_mod(a[i], q);
+                r[i] = v;
+            }
+        }
+
+        // NTT-domain automorphism: result[i] = operand[T[i]],
+        // T[i] = bitrev_n(((elt * bitrev_{n+1}(i + N)) >> 1) & (N-1))   (galois.cpp:18-51), computed
+        // on the fly (v_bfrev_b32) instead of read from a table.
+        __global__ void __launch_bounds__(kBlock) galois_ntt_kernel(
+            const uint64_t *in, uint64_t *out, uint32_t elt, unsigned n_log, size_t words)
+        {
+            const unsigned N = 1u << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const unsigned j = (unsigned)(i & (N - 1));
+                const size_t base = i - j;
+                unsigned rev = __brev(j + N) >> (32 - (n_log + 1));
+                uint64_t raw = ((uint64_t)elt * rev) >> 1;
+                unsigned idx = (unsigned)raw & (N - 1);
+                unsigned src = n_log ? (__brev(idx) >> (32 - n_log)) : 0;
+                out[i] = in[base + src];
+            }
+        }
+
+        // Coefficient-domain automorphism: result[(i*elt) mod N] = +-operand[i]  (galois.cpp:148-190)
+        __global__ void __launch_bounds__(kBlock) galois_coeff_kernel(
+            const ModDesc *mods, const uint64_t *in, uint64_t *out, uint32_t elt, unsigned n_log, unsigned K, size_t words)
+        {
+            const unsigned N = 1u << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const unsigned j = (unsigned)(i & (N - 1));
+                const size_t base = i - j;
+                const unsigned comp = (unsigned)((i >> n_log) % K);
+                const uint64_t q = mods[comp].q;
+                uint64_t raw = (uint64_t)j * elt;
+                unsigned idx = (unsigned)raw & (N - 1);
+                uint64_t v = in[i];
+                if ((raw >> n_log) & 1)
+                    v = neg_mod(v, q);
+                out[base + idx] = v;
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) rescale_combine_kernel(
+            const ModDesc *mods, const ShoupOp *inv_q_last, const uint64_t *c, const uint64_t *t, uint64_t *out,
+            unsigned n_log, unsigned K, size_t out_words)
+        {
+            const unsigned Km1 = K - 1;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < out_words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t row = i >> n_log; // item*(K-1) + comp
+                const unsigned comp = (unsigned)(row % Km1);
+                const size_t item = row / Km1;
+                const size_t j = i & ((size_t(1) << n_log) - 1);
+                const uint64_t q = mods[comp].q;
+                const ShoupOp iq = inv_q_last[comp];
+                uint64_t cv = c[((item * K + comp) << n_log) + j];
+                uint64_t tv = t[i];
+                // c in [0,q), t in [0,4q): c + 4q - t in (0, 5q)
+                out[i] = mul_shoup(cv + 4 * q - tv, iq.w, iq.wq, q);
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) bfv_modswitch_kernel(
+            const ModDesc *mods, const ShoupOp *inv_q_last, const uint64_t *half_mod_q, uint64_t q_last, uint64_t half,
+            const uint64_t *c, uint64_t *out, unsigned n_log, unsigned K, size_t out_words)
+        {
+            const unsigned Km1 = K - 1;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < out_words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t row = i >> n_log;
+                const unsigned comp = (unsigned)(row % Km1);
+                const size_t item = row / Km1;
+                const size_t j = i & ((size_t(1) << n_log) - 1);
+                const ModDesc md = mods[comp];
+                const ShoupOp iq = inv_q_last[comp];
+                uint64_t last = c[((item * K + Km1) << n_log) + j];
+                uint64_t r = csub(last + half, q_last);                 // (c_last + half) mod q_last
+                uint64_t u = sub_mod(barrett64(r, md), half_mod_q[comp], md.q);
+                uint64_t cv = c[((item * K + comp) << n_log) + j];
+                out[i] = mul_shoup(sub_mod(cv, u, md.q), iq.w, iq.wq, md.q);
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) drop_last_kernel(
+            const uint64_t *c, uint64_t *out, unsigned n_log, unsigned K, size_t out_words)
+        {
+            const unsigned Km1 = K - 1;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < out_words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t row = i >> n_log;
+                const unsigned comp = (unsigned)(row % Km1);
+                const size_t item = row / Km1;
+                const size_t j = i & ((size_t(1) << n_log) - 1);
+                out[i] = c[((item * K + comp) << n_log) + j];
+            }
+        }
+
+        // acc[b][k][I][j] = sum_J u[b][I][J][j] * key[J][k][comp(I)][j]  mod q_I, 128-bit lazy sum.
+        // One thread = one coefficient j of one target modulus I for KS_BI batch items: the key words
+        // are loaded once and reused across the batch items (the key is the dominant HBM stream).
+        constexpr unsigned KS_BI = 4;
+        __global__ void __launch_bounds__(kBlock) keyswitch_mac_kernel(
+            const ModDesc *mods, const uint64_t *u, const uint64_t *key, uint64_t *acc, unsigned n_log, unsigned K,
+            unsigned L, unsigned batch)
+        {
+            const size_t N = size_t(1) << n_log;
+            const unsigned I = blockIdx.y;
+            const unsigned b0 = blockIdx.z * KS_BI;
+            const unsigned kc = (I == K) ? L - 1 : I; // key component / pool prime of target modulus I
+            const ModDesc md = mods[kc];
+            const unsigned nb = (batch - b0) < KS_BI ? (batch - b0) : KS_BI;
+            for (size_t j = blockIdx.x * (size_t)kBlock + threadIdx.x; j < N; j += (size_t)gridDim.x * kBlock)
+            {
+                uint64_t lo[KS_BI][2], hi[KS_BI][2];
+#pragma unroll
+                for (unsigned bi = 0; bi < KS_BI; bi++)
+                    lo[bi][0] = lo[bi][1] = hi[bi][0] = hi[bi][1] = 0;
+                for (unsigned J = 0; J < K; J++)
+                {
+                    const uint64_t k0 = key[(((size_t)J * 2 + 0) * L + kc) * N + j];
+                    const uint64_t k1 = key[(((size_t)J * 2 + 1) * L + kc) * N + j];
+#pragma unroll
+                    for (unsigned bi = 0; bi < KS_BI; bi++)
+                    {
+                        if (bi < nb)
+                        {
+                            const uint64_t uv = u[((((size_t)(b0 + bi)) * (K + 1) + I) * K + J) * N + j];
+                            mac128(lo[bi][0], hi[bi][0], uv, k0);
+                            mac128(lo[bi][1], hi[bi][1], uv, k1);
+                        }
+                    }
+                }
+#pragma unroll
+                for (unsigned bi = 0; bi < KS_BI; bi++)
+                {
+                    if (bi < nb)
+                    {
+                        acc[((((size_t)(b0 + bi)) * 2 + 0) * (K + 1) + I) * N + j] = barrett128(lo[bi][0], hi[bi][0], md);
+                        acc[((((size_t)(b0 + bi)) * 2 + 1) * (K + 1) + I) * N + j] = barrett128(lo[bi][1], hi[bi][1], md);
+                    }
+                }
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) keyswitch_tail_ckks_kernel(
+            const ModDesc *mods, const ShoupOp *inv_p, uint64_t *ct0, uint64_t *ct1, const uint64_t *acc,
+            const uint64_t *t, unsigned n_log, unsigned K, size_t words /* batch*K*N */)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t row = i >> n_log; // b*K + comp
+                const unsigned comp = (unsigned)(row % K);
+                const size_t b = row / K;
+                const size_t j = i & ((size_t(1) << n_log) - 1);
+                const uint64_t q = mods[comp].q;
+                const ShoupOp ip = inv_p[comp];
+#pragma unroll
+                for (unsigned k = 0; k < 2; k++)
+                {
+                    uint64_t a = acc[(((b * 2 + k) * (K + 1) + comp) << n_log) + j];
+                    uint64_t tv = t[(((b * 2 + k) * K + comp) << n_log) + j];
+                    uint64_t v = mul_shoup(a + 4 * q - tv, ip.w, ip.wq, q);
+                    uint64_t *ct = k ? ct1 : ct0;
+                    ct[i] = add_mod(ct[i], v, q);
+                }
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) keyswitch_tail_bfv_kernel(
+            const ModDesc *mods, const ShoupOp *inv_p, const uint64_t *round_fix, uint64_t half_p, uint64_t p,
+            uint64_t *ct0, uint64_t *ct1, const uint64_t *acc, unsigned n_log, unsigned K, size_t words)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t row = i >> n_log;
+                const unsigned comp = (unsigned)(row % K);
+                const size_t b = row / K;
+                const size_t j = i & ((size_t(1) << n_log) - 1);
+                const ModDesc md = mods[comp];
+                const ShoupOp ip = inv_p[comp];
+#pragma unroll
+                for (unsigned k = 0; k < 2; k++)
+                {
+                    uint64_t a = acc[(((b * 2 + k) * (K + 1) + comp) << n_log) + j];
+                    uint64_t r = acc[(((b * 2 + k) * (K + 1) + K) << n_log) + j];
+                    uint64_t s = csub(r + half_p, p);
+                    uint64_t uu = barrett64(s, md) + round_fix[comp]; // (s mod q_i) - (half mod q_i) + q_i, in [1, 2q)
+                    uint64_t v = mul_shoup(a + 2 * md.q - uu, ip.w, ip.wq, md.q);
+                    uint64_t *ct = k ? ct1 : ct0;
+                    ct[i] = add_mod(ct[i], v, md.q);
+                }
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) any_nonzero_kernel(const uint64_t *data, size_t words, unsigned *flag)
+        {
+            unsigned nz = 0;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+                nz |= data[i] != 0;
+            if (nz)
+                *flag = 1;
+        }
+    } // namespace
+
+    hipError_t k_ckks_multiply_2x2(
+        const ModDesc *mods, const uint32_t *comp_prime, uint64_t *x, const uint64_t *y, PlaneGeom g, hipStream_t s)
+    {
+        size_t w = g.words();
+        hipLaunchKernelGGL(
+            ckks_multiply_2x2_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, comp_prime, x, y, g.n_log, g.K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_multiply_general(
+        const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, unsigned sx, const uint64_t *y, unsigned sy,
+        uint64_t *out, PlaneGeom g, hipStream_t s)
+    {
+        size_t w = g.words();
+        hipLaunchKernelGGL(
+            multiply_general_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, comp_prime, x, sx, y, sy, out, g.n_log,
+            g.K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_dyadic(
+        const ModDesc *mods, const uint64_t *a, const uint64_t *b, uint64_t *r, unsigned n_log, unsigned comps,
+        unsigned first_prime, size_t polys, hipStream_t s)
+    {
+        size_t w = (polys * comps) << n_log;
+        hipLaunchKernelGGL(dyadic_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, a, b, r, n_log, comps, first_prime, w);
+        return hipGetLastError();
+    }
+    hipError_t k_addsub(
+        const ModDesc *mods, const uint64_t *a, const uint64_t *b, uint64_t *r, int op, PlaneGeom g, unsigned planes,
+        hipStream_t s)
+    {
+        size_t w = g.words() * planes;
+        hipLaunchKernelGGL(addsub_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, a, b, r, op, g.n_log, g.K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_apply_galois(
+        const ModDesc *mods, const uint64_t *in, uint64_t *out, uint32_t elt, int ntt_form, PlaneGeom g, unsigned planes,
+        hipStream_t s)
+    {
+        size_t w = g.words() * planes;
+        if (ntt_form)
+            hipLaunchKernelGGL(galois_ntt_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, in, out, elt, g.n_log, w);
+        else
+            hipLaunchKernelGGL(galois_coeff_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, in, out, elt, g.n_log, g.K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_rescale_combine(
+        const ModDesc *mods, const ShoupOp *inv_q_last, const uint64_t *c, const uint64_t *t, uint64_t *out,
+        unsigned n_log, unsigned K, size_t items, hipStream_t s)
+    {
+        size_t w = (items * (K - 1)) << n_log;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(rescale_combine_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, inv_q_last, c, t, out, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_bfv_modswitch(
+        const ModDesc *mods, const LevelDev &lv, const uint64_t *c, uint64_t *out, unsigned n_log, size_t items, hipStream_t s)
+    {
+        size_t w = (items * (lv.K - 1)) << n_log;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(
+            bfv_modswitch_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, lv.inv_q_last_mod_q, lv.half_mod_q,
+            lv.q_last, lv.half_q_last, c, out, n_log, lv.K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_drop_last(const uint64_t *c, uint64_t *out, unsigned n_log, unsigned K, size_t items, hipStream_t s)
+    {
+        size_t w = (items * (K - 1)) << n_log;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(drop_last_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, c, out, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_keyswitch_mac(
+        const ModDesc *mods, const uint64_t *u, const uint64_t *key, uint64_t *acc, unsigned n_log, unsigned K, unsigned L,
+        unsigned batch, hipStream_t s)
+    {
+        size_t N = size_t(1) << n_log;
+        unsigned gx = (unsigned)((N + kBlock - 1) / kBlock);
+        dim3 grid(gx, K + 1, (batch + KS_BI - 1) / KS_BI);
+        hipLaunchKernelGGL(keyswitch_mac_kernel, grid, dim3(kBlock), 0, s, mods, u, key, acc, n_log, K, L, batch);
+        return hipGetLastError();
+    }
+    hipError_t k_keyswitch_tail_ckks(
+        const ModDesc *mods, const ShoupOp *inv_p, uint64_t *ct0, uint64_t *ct1, const uint64_t *acc, const uint64_t *t,
+        unsigned n_log, unsigned K, unsigned batch, hipStream_t s)
+    {
+        size_t w = ((size_t)batch * K) << n_log;
+        hipLaunchKernelGGL(
+            keyswitch_tail_ckks_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, inv_p, ct0, ct1, acc, t, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_keyswitch_tail_bfv(
+        const ModDesc *mods, const ShoupOp *inv_p, const uint64_t *round_fix, uint64_t half_p, uint64_t p, uint64_t *ct0,
+        uint64_t *ct1, const uint64_t *acc, unsigned n_log, unsigned K, unsigned batch, hipStream_t s)
+    {
+        size_t w = ((size_t)batch * K) << n_log;
+        hipLaunchKernelGGL(
+            keyswitch_tail_bfv_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, inv_p, round_fix, half_p, p, ct0, ct1,
+            acc, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_any_nonzero(const uint64_t *data, size_t words, unsigned *flag, hipStream_t s)
+    {
+        if (!words)
+            return hipSuccess;
+        hipLaunchKernelGGL(any_nonzero_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, data, words, flag);
+        return hipGetLastError();
+    }
+} // namespace sealhip
