@@ -1,0 +1,218 @@
+"""Parity cases shared by the CPU (fiber-emulated, index arithmetic only) and GPU (the real thing) test
+files.  Every comparison is bit-exact (np.array_equal on uint64 slabs): the path is integer work.
+Each case mirrors a reference test or bench case (cited)."""
+import numpy as np
+
+import seal_amd as S
+from harness import DeviceSide
+from oracle import Oracle, coeff_modulus_create, plain_modulus_batching, rand_ct
+
+
+def _eq(got, exp, what):
+    assert got.shape == exp.shape, "%s: shape %s vs %s" % (what, got.shape, exp.shape)
+    if not np.array_equal(got, exp):
+        bad = np.argwhere(got != exp)
+        raise AssertionError("%s: %d of %d words differ, first at %s: got %d expected %d" % (
+            what, len(bad), got.size, tuple(bad[0]), got[tuple(bad[0])], exp[tuple(bad[0])]))
+
+
+# ---- NTT: native/tests/seal/util/ntt.cpp:103-133 (round trip) + ciphertext-level parity (SURVEY §4 ii)
+def case_ntt(n, bits, polys=2, seed=1):
+    primes = coeff_modulus_create(n, bits)
+    o = Oracle("ckks", n, primes)
+    d = DeviceSide("ckks", n, primes)
+    L = len(primes)
+    for i in range(L):
+        assert d.ctx.ntt_root(i) == o.ntt_root(i), "minimal primitive root of prime %d" % i
+    rng = np.random.default_rng(seed)
+    x = np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(L)]) for _ in range(polys)])
+    buf = S.DeviceBuffer.from_numpy(x)
+    S.ntt_forward(d.ctx, buf, polys, L)
+    fwd = buf.to_numpy(x.shape)
+    for p in range(polys):
+        _eq(fwd[p], o.ntt(0, x[p], "fwd"), "ntt_negacyclic_harvey poly %d" % p)
+    S.ntt_inverse(d.ctx, buf, polys, L)
+    _eq(buf.to_numpy(x.shape), x, "inverse(forward(x)) == x")
+    buf = S.DeviceBuffer.from_numpy(x)
+    S.ntt_inverse(d.ctx, buf, polys, L)
+    inv = buf.to_numpy(x.shape)
+    for p in range(polys):
+        _eq(inv[p], o.ntt(0, x[p], "inv"), "inverse_ntt_negacyclic_harvey poly %d" % p)
+    # lazy variants: same residues, inside the reference's lazy ranges (ntt.h:30-61)
+    q = np.array(primes, dtype=np.uint64)[None, :, None]
+    buf = S.DeviceBuffer.from_numpy(x)
+    S.ntt_forward(d.ctx, buf, polys, L, lazy=True)
+    lz = buf.to_numpy(x.shape)
+    assert (lz < 4 * q).all()
+    _eq(lz % q, fwd, "lazy forward mod q")
+    buf = S.DeviceBuffer.from_numpy(x)
+    S.ntt_inverse(d.ctx, buf, polys, L, lazy=True)
+    lz = buf.to_numpy(x.shape)
+    assert (lz < 2 * q).all()
+    _eq(lz % q, inv, "lazy inverse mod q")
+
+
+# ---- dyadic product: native/tests/seal/util/polyarithsmallmod.cpp:545-641
+def case_dyadic(n, bits, seed=2):
+    primes = coeff_modulus_create(n, bits)
+    o = Oracle("ckks", n, primes)
+    d = DeviceSide("ckks", n, primes)
+    L = len(primes)
+    rng = np.random.default_rng(seed)
+    a = np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(L)])
+    b = np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(L)])
+    da, db, dr = S.DeviceBuffer.from_numpy(a), S.DeviceBuffer.from_numpy(b), S.DeviceBuffer(a.size)
+    S.dyadic_product(d.ctx, da, db, dr, 1, L)
+    got = dr.to_numpy(a.shape)
+    for i in range(L):
+        _eq(got[i], o.dyadic(i, a[i], b[i]), "dyadic_product_coeffmod prime %d" % i)
+
+
+# ---- CKKS: CKKSEncryptMultiplyRelinRescaleDecrypt / CKKSEncryptRotateDecrypt
+#      (native/tests/seal/evaluator.cpp:3513, 4326) at ciphertext level; bench cases native/bench/ckks.cpp
+def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=True):
+    primes = coeff_modulus_create(n, bits)
+    L = len(primes)
+    K = L - 1
+    probe = Oracle("ckks", n, primes)
+    elts = [probe.galois_elt_from_step(s) for s in steps]
+    o = Oracle("ckks", n, primes, galois_elts=elts)
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    for s, e in zip(steps, elts):
+        assert d.ctx.galois_elt_from_step(s) == e
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    cx, cy = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10)
+
+    d.ev.multiply_inplace(cx, cy)  # ckks_multiply, evaluator.cpp:569
+    assert cx.size() == 3 and cx.is_ntt_form() and cx.scale() == 2.0 ** 20
+    cur = d.out(cx)
+    for b in range(batch):
+        _eq(cur[b], o.multiply(xs[b], ys[b]), "multiply item %d" % b)
+
+    d.ev.relinearize_inplace(cx, d.rlk)  # evaluator.cpp:1144
+    assert cx.size() == 2
+    nxt = d.out(cx)
+    for b in range(batch):
+        _eq(nxt[b], o.relinearize(cur[b]), "relinearize item %d" % b)
+    cur = nxt
+
+    if K >= 2:
+        cx.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+        d.ev.rescale_to_next_inplace(cx)  # evaluator.cpp:1503
+        assert cx.coeff_modulus_size() == K - 1 and cx.scale() == (float(primes[K - 1]) * 2.0 ** 10) / float(primes[K - 1])
+        nxt = d.out(cx)
+        for b in range(batch):
+            _eq(nxt[b], o.rescale(cur[b]), "rescale_to_next item %d" % b)
+        cur = nxt
+
+    for s in steps:
+        d.ev.rotate_vector_inplace(cx, s, d.glk)  # evaluator.h:1209
+        nxt = d.out(cx)
+        e = o.galois_elt_from_step(s)
+        for b in range(batch):
+            _eq(nxt[b], o.apply_galois(cur[b], e), "rotate_vector(%d) item %d" % (s, b))
+        cur = nxt
+
+    if cx.coeff_modulus_size() >= 2:
+        d.ev.mod_switch_to_next_inplace(cx)  # CKKS: drop last component, evaluator.cpp:1296
+        nxt = d.out(cx)
+        for b in range(batch):
+            _eq(nxt[b], o.mod_switch_to_next(cur[b]), "mod_switch_to_next item %d" % b)
+        cur = nxt
+
+    if check_transforms:
+        d.ev.transform_from_ntt_inplace(cx)  # evaluator.cpp:2337
+        assert not cx.is_ntt_form()
+        nxt = d.out(cx)
+        for b in range(batch):
+            _eq(nxt[b], o.transform(cur[b], False), "transform_from_ntt item %d" % b)
+        d.ev.transform_to_ntt_inplace(cx)
+        back = d.out(cx)
+        for b in range(batch):
+            _eq(back[b], cur[b], "transform_to_ntt(transform_from_ntt(x)) item %d" % b)
+
+
+# ---- BFV: BFVEncryptMultiplyDecrypt / BFVRelinearize / BFVEncryptModSwitchToNextDecrypt /
+#      BFVEncryptRotateMatrixDecrypt (native/tests/seal/evaluator.cpp:1356, 2430, 5722, 5670)
+def case_bfv_pipeline(n, primes, t, batch=2, seed=4):
+    L = len(primes)
+    K = L - 1
+    probe = Oracle("bfv", n, primes, t)
+    elts = [probe.galois_elt_from_step(1), 2 * n - 1]
+    o = Oracle("bfv", n, primes, t, galois_elts=elts)
+    d = DeviceSide("bfv", n, primes, t)
+    d.upload_keys(o)
+    ci = d.chain_index_for_K(K)
+    assert d.ctx.base_bsk(ci) == o.base_bsk(K), "BEHZ base Bsk"
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    cx, cy = d.ct(xs), d.ct(ys)
+
+    d.ev.multiply_inplace(cx, cy)  # bfv_multiply, evaluator.cpp:395
+    assert cx.size() == 3 and not cx.is_ntt_form()
+    cur = d.out(cx)
+    for b in range(batch):
+        _eq(cur[b], o.multiply(xs[b], ys[b]), "bfv multiply item %d" % b)
+
+    d.ev.relinearize_inplace(cx, d.rlk)
+    nxt = d.out(cx)
+    for b in range(batch):
+        _eq(nxt[b], o.relinearize(cur[b]), "bfv relinearize item %d" % b)
+    cur = nxt
+
+    d.ev.rotate_rows_inplace(cx, 1, d.glk)
+    nxt = d.out(cx)
+    for b in range(batch):
+        _eq(nxt[b], o.apply_galois(cur[b], elts[0]), "rotate_rows(1) item %d" % b)
+    cur = nxt
+
+    d.ev.rotate_columns_inplace(cx, d.glk)
+    nxt = d.out(cx)
+    for b in range(batch):
+        _eq(nxt[b], o.apply_galois(cur[b], elts[1]), "rotate_columns item %d" % b)
+    cur = nxt
+
+    if K >= 2:
+        d.ev.mod_switch_to_next_inplace(cx)  # divide_and_round_q_last_inplace, rns.cpp:789
+        assert cx.coeff_modulus_size() == K - 1
+        nxt = d.out(cx)
+        for b in range(batch):
+            _eq(nxt[b], o.mod_switch_to_next(cur[b]), "bfv mod_switch_to_next item %d" % b)
+        cur = nxt
+
+    d.ev.square_inplace(cx)  # bfv_square, evaluator.cpp:878
+    nxt = d.out(cx)
+    for b in range(batch):
+        _eq(nxt[b], o.multiply(cur[b], cur[b]), "bfv square item %d" % b)
+
+
+# ---- BEHZ stages: native/tests/seal/util/rns.cpp:460-854
+def case_rns_stages(n, primes, t, seed=5):
+    L = len(primes)
+    K = L - 1
+    o = Oracle("bfv", n, primes, t)
+    d = DeviceSide("bfv", n, primes, t)
+    ci = d.chain_index_for_K(K)
+    nBsk = len(o.base_bsk(K))
+    rng = np.random.default_rng(seed)
+    x = np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)])
+
+    def run(which, inp, out_comps):
+        src, dst = S.DeviceBuffer.from_numpy(inp), S.DeviceBuffer(out_comps * n)
+        S.rns_stage(d.ctx, ci, which, src, dst, 1)
+        got = dst.to_numpy((out_comps, n))
+        _eq(got, o.rns_stage(K, which, inp, out_comps), which)
+        return got
+
+    e0 = run("fastbconv_m_tilde", x, nBsk + 1)
+    e1 = run("sm_mrq", e0, nBsk)
+    e2 = run("fast_floor", np.concatenate([x, e1]), nBsk)
+    run("fastbconv_sk", e2, K)
+
+
+def default_bfv_params(n, bits, t_bits):
+    return coeff_modulus_create(n, bits), plain_modulus_batching(n, t_bits)

@@ -1,0 +1,177 @@
+"""CPU (emulated kernels): error behaviour and metadata semantics of the Evaluator mirror, following
+the reference's negative tests (native/tests/seal/evaluator.cpp:2505-2632, 5590 and the throw sites in
+native/src/seal/evaluator.cpp) and the C layer's exception -> HRESULT mapping
+(native/src/seal/c/defines.h:75-97)."""
+import numpy as np
+import pytest
+
+from harness import DeviceSide
+from oracle import Oracle, coeff_modulus_create, plain_modulus_batching, rand_ct
+
+
+@pytest.fixture()
+def ckks(emu):
+    n, bits = 64, [40, 30, 30, 40]
+    primes = coeff_modulus_create(n, bits)
+    o = Oracle("ckks", n, primes, galois_elts=[3], kind="port")
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(1)
+    return emu, d, o, primes, rng
+
+
+def test_multiply_requires_ntt_form(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64), is_ntt=False)
+    with pytest.raises(S.InvalidArgument):   # "encrypted1 or encrypted2 must be in NTT form" evaluator.cpp:572
+        d.ev.multiply_inplace(x, x.copy())
+
+
+def test_parameter_mismatch(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64))
+    y = d.ct(rand_ct(rng, primes, 2, 64))
+    with pytest.raises(S.InvalidArgument):   # evaluator.cpp:363
+        d.ev.multiply_inplace(x, y)
+    with pytest.raises(S.InvalidArgument):
+        d.ev.add_inplace(x, y)
+
+
+def test_scale_out_of_bounds(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64), scale=2.0 ** 60)
+    with pytest.raises(S.InvalidArgument):   # scale^2 exceeds total_coeff_modulus_bit_count, evaluator.cpp:704
+        d.ev.multiply_inplace(x, x.copy())
+    z = d.ct(rand_ct(rng, primes, 3, 64), scale=-1.0)
+    with pytest.raises(S.InvalidArgument):   # is_metadata_valid_for: scale must be positive normal
+        d.ev.negate_inplace(z)
+
+
+def test_scale_mismatch_on_add(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64), scale=2.0 ** 20)
+    y = d.ct(rand_ct(rng, primes, 3, 64), scale=2.0 ** 21)
+    with pytest.raises(S.InvalidArgument):   # "scale mismatch" evaluator.cpp:172
+        d.ev.add_inplace(x, y)
+
+
+def test_rescale_at_end_of_chain(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 1, 64))
+    with pytest.raises(S.InvalidArgument):   # "end of modulus switching chain reached" evaluator.cpp:1512
+        d.ev.rescale_to_next_inplace(x)
+    with pytest.raises(S.InvalidArgument):
+        d.ev.mod_switch_to_next_inplace(x)
+
+
+def test_galois_key_missing_and_bad_element(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64))
+    with pytest.raises(S.InvalidArgument):   # "Galois key not present" evaluator.cpp:2416
+        d.ev.apply_galois_inplace(x, 5, d.glk)
+    with pytest.raises(S.InvalidArgument):   # even element: "Galois element is not valid"
+        d.ev.apply_galois_inplace(x, 4, d.glk)
+    y = d.ct(rand_ct(rng, primes, 3, 64, size=3))
+    with pytest.raises(S.InvalidArgument):   # "encrypted size must be 2" evaluator.cpp:2427
+        d.ev.apply_galois_inplace(y, 3, d.glk)
+
+
+def test_apply_galois_rejects_wrong_ntt_form_without_mutating(ckks):
+    """ApplyGaloisRejectsWrongNttFormWithoutMutating, native/tests/seal/evaluator.cpp:5590"""
+    S, d, o, primes, rng = ckks
+    data = rand_ct(rng, primes, 3, 64)
+    x = d.ct(data, is_ntt=False)
+    with pytest.raises(S.InvalidArgument):
+        d.ev.apply_galois_inplace(x, 3, d.glk)
+    assert np.array_equal(d.out(x)[0], data)
+
+
+def test_rotate_scheme_checks(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64))
+    with pytest.raises(S.LogicError):        # rotate_rows on CKKS: "unsupported scheme" evaluator.h:1079
+        d.ev.rotate_rows_inplace(x, 1, d.glk)
+    with pytest.raises(S.InvalidArgument):   # step count too large, galois.cpp:68
+        d.ev.rotate_vector_inplace(x, 32, d.glk)
+
+
+def test_rotate_naf_fallback_without_exact_key(ckks):
+    """rotate_internal decomposes the step in NAF form when the exact key is absent
+    (evaluator.cpp:2536-2558); a lone power of two without a key is an error."""
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64))
+    with pytest.raises(S.InvalidArgument):
+        d.ev.rotate_vector_inplace(x, 2, d.glk)   # NAF(2) has one term and no key for it
+
+
+def test_relinearize_needs_keys_and_index_range(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64, size=3))
+    empty = S.RelinKeys(d.ctx)
+    with pytest.raises(S.InvalidArgument):
+        d.ev.relinearize_inplace(x, empty)
+    with pytest.raises(S.InvalidArgument):   # RelinKeys::get_index: key_power >= 2
+        S.RelinKeys.get_index(1)
+    with pytest.raises(S.InvalidArgument):   # GaloisKeys::get_index: odd elements only
+        S.GaloisKeys.get_index(4)
+
+
+def test_transparent_check_is_logic_error(ckks):
+    """SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT: a result whose c1.. are all zero is refused (evaluator.cpp:386)."""
+    S, d, o, primes, rng = ckks
+    data = rand_ct(rng, primes, 3, 64)
+    data[1] = 0
+    x = d.ct(data)
+    assert x.is_transparent()
+    d.ev.set_transparent_check(True)
+    with pytest.raises(S.LogicError):
+        d.ev.negate_inplace(x)
+    d.ev.set_transparent_check(False)
+    d.ev.negate_inplace(x)  # default for device-resident batches: not checked per op
+
+
+def test_bfv_form_and_scheme_errors(emu):
+    S = emu
+    n = 32
+    primes = coeff_modulus_create(n, [30, 30, 30])
+    t = plain_modulus_batching(n, 12)
+    d = DeviceSide("bfv", n, primes, t)
+    rng = np.random.default_rng(2)
+    x = d.ct(rand_ct(rng, primes, 2, n), is_ntt=True)
+    with pytest.raises(S.InvalidArgument):   # "encrypted1 or encrypted2 cannot be in NTT form" evaluator.cpp:397
+        d.ev.multiply_inplace(x, x.copy())
+    y = d.ct(rand_ct(rng, primes, 2, n))
+    with pytest.raises(S.InvalidArgument):   # rescale is CKKS-only, evaluator.cpp:1522
+        d.ev.rescale_to_next_inplace(y)
+    with pytest.raises(S.LogicError):        # rotate_vector is CKKS-only, evaluator.h:1215
+        d.ev.rotate_vector_inplace(y, 1, S.GaloisKeys(d.ctx))
+
+
+def test_invalid_parameters_are_rejected(emu):
+    S = emu
+    p = S.EncryptionParameters("ckks")
+    p.set_poly_modulus_degree(64)
+    p.set_coeff_modulus([17])            # 17 != 1 mod 128: no NTT (invalid_coeff_modulus_no_ntt)
+    with pytest.raises(S.InvalidArgument):
+        S.SEALContext(p)
+    p.set_coeff_modulus([1 << 30])       # not prime
+    with pytest.raises(S.InvalidArgument):
+        S.SEALContext(p)
+    p.set_poly_modulus_degree(48)        # not a power of two
+    with pytest.raises(S.InvalidArgument):
+        S.SEALContext(p)
+    with pytest.raises(S.LogicError):    # CKKS has no plain modulus (encryptionparams.h)
+        p.set_plain_modulus(65537)
+
+
+def test_destination_forms_leave_operands_untouched(ckks):
+    S, d, o, primes, rng = ckks
+    a, b = rand_ct(rng, primes, 3, 64), rand_ct(rng, primes, 3, 64)
+    x, y = d.ct(a, scale=2.0 ** 10), d.ct(b, scale=2.0 ** 10)
+    dest = S.Ciphertext(d.ctx)
+    d.ev.multiply(x, y, dest)
+    assert np.array_equal(d.out(x)[0], a) and np.array_equal(d.out(y)[0], b)
+    assert np.array_equal(d.out(dest)[0], o.multiply(a, b))
+    d.ev.sub(x, y, y)   # destination aliases the second operand (evaluator.h sub())
+    q = np.array(primes[:3], dtype=np.uint64)[None, :, None]
+    assert np.array_equal(d.out(y)[0], (a + q - b) % q)

@@ -1,0 +1,270 @@
+"""GPU (MI355X) parity tests — the tests proper.  Everything goes through the C ABI of the gfx950 build
+(seal_amd/lib/libsealhip.so); outputs are compared bit-for-bit with the oracle (the real reference when
+oracle/_ref travelled with the repo, else the plain-C restatement) on identical inputs and key words,
+at test sizes, at the BASELINE.json configurations, and against the committed golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+import parity_cases as P
+import sealref as R
+from harness import DeviceSide
+from oracle import Oracle, coeff_modulus_create, kind_available, plain_modulus_batching, rand_ct
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_native_library_is_the_one_loaded(gpu):
+    """The HIP extension must be what runs: in-tree .so, real device, no fallback."""
+    from seal_amd import _native
+    assert _native._lib_path.endswith(os.path.join("seal_amd", "lib", "libsealhip.so"))
+    name, cus, mem = gpu.device_info()
+    assert cus >= 64 and mem > (64 << 30)
+    with open("/proc/self/maps") as f:
+        assert any("libsealhip.so" in line for line in f)
+
+
+# ---- NTT at every plan, incl. BASELINE config 2 (CKKS N=8192, L=4: fwd + inv over all components)
+@pytest.mark.parametrize("n,bits,polys", [
+    (2, [30, 30], 2), (16, [30, 30], 3), (64, [40, 50], 3), (128, [40, 50], 2), (256, [50, 60], 2), (512, [50], 5),
+    (1024, [50, 60], 2), (2048, [60], 3), (4096, [36, 36, 37], 4),
+    (8192, [60, 40, 40, 60], 6),            # BASELINE configs[1]
+    (16384, [60, 50, 50], 3), (32768, [55, 55], 2), (65536, [60, 50, 60], 2), (131072, [60], 1),
+])
+def test_ntt(gpu, n, bits, polys):
+    P.case_ntt(n, bits, polys=polys)
+
+
+def test_dyadic(gpu):
+    P.case_dyadic(4096, [60, 40, 30])
+
+
+def test_kats_on_device(gpu):
+    """native/tests/seal/util/ntt.cpp:75-101 and galois.cpp:86-120 through the GPU path."""
+    S = gpu
+    d = DeviceSide("ckks", 2, [0xFFFFFFFFFFC0001])
+    assert d.ctx.ntt_root(0) == 288794978602139552
+    buf = S.DeviceBuffer.from_numpy(np.array([1, 1], dtype=np.uint64))
+    S.ntt_forward(d.ctx, buf, 1, 1)
+    assert list(buf.to_numpy((2,))) == [288794978602139553, 864126526004445282]
+    d = DeviceSide("ckks", 8, [17])
+    src = S.DeviceBuffer.from_numpy(np.arange(8, dtype=np.uint64))
+    dst = S.DeviceBuffer(8)
+    S.apply_galois(d.ctx, 0, False, 3, src, dst, 1)
+    assert list(dst.to_numpy((8,))) == [0, 14, 6, 1, 13, 7, 2, 12]
+    S.apply_galois(d.ctx, 0, True, 3, src, dst, 1)
+    assert list(dst.to_numpy((8,))) == [4, 5, 7, 6, 1, 0, 2, 3]
+
+
+# ---- CKKS pipelines: small, ragged batch, and BASELINE configs 3 and 5
+@pytest.mark.parametrize("n,bits,batch,steps", [
+    (16, [30, 30, 30, 30], 3, (1, -1)),
+    (1024, [50, 40, 40, 50], 5, (1,)),
+    (8192, [60, 40, 40, 60], 2, (1, 7)),
+    (16384, [60, 50, 50, 50, 50, 50, 50, 60], 2, (1,)),                 # BASELINE configs[2]
+])
+def test_ckks_pipeline(gpu, n, bits, batch, steps):
+    P.case_ckks_pipeline(n, bits, batch=batch, steps=steps)
+
+
+def test_ckks_north_star_config(gpu):
+    """BASELINE configs[4] / north-star: CKKS N=65536, L=16 ({60, 14x50, 60}): multiply + relinearize +
+    rescale_to_next, then rotate_vector(1) + mod_switch, batch of 2, bit-exact."""
+    P.case_ckks_pipeline(65536, [60] + [50] * 14 + [60], batch=2, steps=(1,), check_transforms=False)
+
+
+# ---- BFV pipelines: small, BASELINE config 1 (N=4096 BFVDefault sizes) and config 4 (N=32768, 14 primes)
+@pytest.mark.parametrize("n,bits,tb,batch", [
+    (16, [30, 30, 30, 30], 12, 3),
+    (4096, [36, 36, 37], 20, 2),            # BASELINE configs[0]
+    (8192, [55] * 5, 20, 1),
+])
+def test_bfv_pipeline(gpu, n, bits, tb, batch):
+    primes, t = P.default_bfv_params(n, bits, tb)
+    P.case_bfv_pipeline(n, primes, t, batch=batch)
+
+
+def test_bfv_config4(gpu):
+    """BASELINE configs[3]: BFV N=32768, 14x55-bit chain, Batching(32768, 20): multiply + relinearize +
+    mod_switch (one ciphertext here; the 1024-ciphertext sharding is bench.py's job)."""
+    primes, t = P.default_bfv_params(32768, [55] * 14, 20)
+    P.case_bfv_pipeline(32768, primes, t, batch=1)
+
+
+def test_rns_stages(gpu):
+    primes, t = P.default_bfv_params(2048, [50, 50, 50, 50], 20)
+    P.case_rns_stages(2048, primes, t)
+
+
+# ---- golden vectors produced by the real reference (tests/golden/make_golden.py)
+def test_golden_ckks(gpu):
+    S = gpu
+    g = np.load(os.path.join(GOLDEN, "ckks_n64.npz"))
+    n, primes = int(g["n"]), [int(x) for x in g["primes"]]
+    d = DeviceSide("ckks", n, primes)
+    assert [d.ctx.ntt_root(i) for i in range(len(primes))] == [int(x) for x in g["roots"]]
+    d.rlk = S.RelinKeys(d.ctx)
+    d.rlk.set_key(0, g["relin_key"])
+    d.glk = S.GaloisKeys(d.ctx)
+    elt = int(g["galois_elt"])
+    d.glk.set_key(S.GaloisKeys.get_index(elt), g["galois_key"])
+    K = len(primes) - 1
+    x, y = d.ct(g["a"], scale=2.0 ** 10), d.ct(g["b"], scale=2.0 ** 10)
+    d.ev.multiply_inplace(x, y)
+    assert np.array_equal(d.out(x)[0], g["multiply"])
+    d.ev.relinearize_inplace(x, d.rlk)
+    assert np.array_equal(d.out(x)[0], g["relinearize"])
+    x.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+    d.ev.rescale_to_next_inplace(x)
+    assert np.array_equal(d.out(x)[0], g["rescale"])
+    assert x.scale() == float(g["rescale_scale"])
+    d.ev.rotate_vector_inplace(x, 1, d.glk)
+    assert np.array_equal(d.out(x)[0], g["rotate1"])
+    d.ev.mod_switch_to_next_inplace(x)
+    assert np.array_equal(d.out(x)[0], g["mod_switch"])
+
+
+def test_golden_bfv(gpu):
+    S = gpu
+    g = np.load(os.path.join(GOLDEN, "bfv_n32.npz"))
+    n, primes, t = int(g["n"]), [int(x) for x in g["primes"]], int(g["t"])
+    d = DeviceSide("bfv", n, primes, t)
+    K = len(primes) - 1
+    assert d.ctx.base_bsk(d.chain_index_for_K(K)) == [int(x) for x in g["bsk"]]
+    d.rlk = S.RelinKeys(d.ctx)
+    d.rlk.set_key(0, g["relin_key"])
+    d.glk = S.GaloisKeys(d.ctx)
+    elt = int(g["galois_elt"])
+    d.glk.set_key(S.GaloisKeys.get_index(elt), g["galois_key"])
+    d.glk.set_key(S.GaloisKeys.get_index(2 * n - 1), g["conj_key"])
+    x, y = d.ct(g["a"]), d.ct(g["b"])
+    d.ev.multiply_inplace(x, y)
+    assert np.array_equal(d.out(x)[0], g["multiply"])
+    d.ev.relinearize_inplace(x, d.rlk)
+    assert np.array_equal(d.out(x)[0], g["relinearize"])
+    d.ev.rotate_rows_inplace(x, 1, d.glk)
+    assert np.array_equal(d.out(x)[0], g["rotate_rows1"])
+    d.ev.rotate_columns_inplace(x, d.glk)
+    assert np.array_equal(d.out(x)[0], g["rotate_columns"])
+    d.ev.mod_switch_to_next_inplace(x)
+    assert np.array_equal(d.out(x)[0], g["mod_switch"])
+
+
+# ---- size-independent properties at full size (no oracle needed)
+def test_full_size_properties(gpu):
+    S = gpu
+    n, bits = 65536, [60] + [50] * 14 + [60]
+    primes = coeff_modulus_create(n, bits)
+    L = len(primes)
+    d = DeviceSide("ckks", n, primes)
+    rng = np.random.default_rng(9)
+    q = np.array(primes, dtype=np.uint64)[None, :, None]
+    a = np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(L)])[None]
+    b = np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(L)])[None]
+    both = np.concatenate([a, b, (a + b) % q])
+    buf = S.DeviceBuffer.from_numpy(both)
+    S.ntt_forward(d.ctx, buf, 3, L)
+    f = buf.to_numpy(both.shape)
+    assert np.array_equal((f[0] + f[1]) % q[0], f[2]), "NTT is linear"
+    S.ntt_inverse(d.ctx, buf, 3, L)
+    assert np.array_equal(buf.to_numpy(both.shape), both), "INTT(NTT(x)) == x at N=65536, 16 primes"
+    # negacyclic convolution theorem on one prime: NTT^-1(NTT(a) . NTT(x)) = a * x mod (X^N + 1), x = X
+    x1 = np.zeros((1, L, n), dtype=np.uint64)
+    x1[0, :, 1] = 1
+    ba, bx, br = S.DeviceBuffer.from_numpy(a), S.DeviceBuffer.from_numpy(x1), S.DeviceBuffer(a.size)
+    S.ntt_forward(d.ctx, ba, 1, L)
+    S.ntt_forward(d.ctx, bx, 1, L)
+    S.dyadic_product(d.ctx, ba, bx, br, 1, L)
+    S.ntt_inverse(d.ctx, br, 1, L)
+    prod = br.to_numpy(a.shape)
+    shifted = np.roll(a, 1, axis=2)
+    shifted[0, :, 0] = (q[0, :, 0] - a[0, :, n - 1]) % q[0, :, 0]
+    assert np.array_equal(prod, shifted), "multiplication by X is a negacyclic shift"
+
+
+def test_batch_items_are_independent(gpu):
+    """A batch must equal the same operations applied to each ciphertext alone (ragged sizes too)."""
+    n, bits = 4096, [50, 40, 40, 50]
+    primes = coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    o = Oracle("ckks", n, primes, kind="port")
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(10)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(7)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(7)]
+
+    def run(xl, yl):
+        cx, cy = d.ct(xl, scale=2.0 ** 10), d.ct(yl, scale=2.0 ** 10)
+        d.ev.multiply_inplace(cx, cy)
+        d.ev.relinearize_inplace(cx, d.rlk)
+        cx.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+        d.ev.rescale_to_next_inplace(cx)
+        return d.out(cx)
+
+    whole = run(xs, ys)
+    for i in (0, 3, 6):
+        assert np.array_equal(run([xs[i]], [ys[i]])[0], whole[i])
+
+
+# ---- one semantic end-to-end check per scheme (needs the real reference for encrypt/decrypt)
+@pytest.mark.skipif(not R.available(), reason="needs oracle/_ref for encode/encrypt/decrypt")
+def test_semantic_ckks_multiply_relin_rescale(gpu):
+    """CKKSEncryptMultiplyRelinRescaleDecrypt (native/tests/seal/evaluator.cpp:3513): encrypt with the
+    reference, evaluate on the GPU, decrypt with the reference, |error| < 0.5 (the reference's bound)."""
+    S = gpu
+    n, bits = 8192, [60, 40, 40, 60]
+    primes = R.coeff_modulus_create(n, bits)
+    ref = R.RefContext("ckks", n, primes)
+    ref.keygen_relin()
+    d = DeviceSide("ckks", n, primes)
+    d.rlk = S.RelinKeys(d.ctx)
+    d.rlk.set_key(0, ref.key("relin", 0))
+    rng = np.random.default_rng(11)
+    v1, v2 = rng.uniform(-8, 8, n // 2), rng.uniform(-8, 8, n // 2)
+    scale = 2.0 ** 40
+    e1, e2 = ref.ckks_encrypt(v1, scale), ref.ckks_encrypt(v2, scale)
+    x, y = d.ct(e1.data(), scale=scale), d.ct(e2.data(), scale=scale)
+    d.ev.multiply_inplace(x, y)
+    d.ev.relinearize_inplace(x, d.rlk)
+    d.ev.rescale_to_next_inplace(x)
+    back = ref.ct(x.chain_index(), d.out(x)[0], True, x.scale())
+    got = ref.ckks_decrypt(back, n // 2)
+    assert np.max(np.abs(got - v1 * v2)) < 0.5
+
+
+@pytest.mark.skipif(not R.available(), reason="needs oracle/_ref for encode/encrypt/decrypt")
+def test_semantic_bfv_multiply_rotate(gpu):
+    """BFVEncryptMultiplyDecrypt / BFVEncryptRotateMatrixDecrypt (evaluator.cpp:1356, 5670)."""
+    S = gpu
+    n = 4096
+    primes = R.bfv_default(n)
+    t = R.plain_modulus_batching(n, 20)
+    ref = R.RefContext("bfv", n, primes, t)
+    ref.keygen_relin()
+    elt = ref.galois_elt_from_step(1)
+    ref.keygen_galois_elts([elt])
+    d = DeviceSide("bfv", n, primes, t)
+    d.rlk = S.RelinKeys(d.ctx)
+    d.rlk.set_key(0, ref.key("relin", 0))
+    d.glk = S.GaloisKeys(d.ctx)
+    d.glk.set_key(S.GaloisKeys.get_index(elt), ref.key("galois", (elt - 1) >> 1))
+    rng = np.random.default_rng(12)
+    v1, v2 = rng.integers(0, 1000, n, dtype=np.uint64), rng.integers(0, 1000, n, dtype=np.uint64)
+    e1, e2 = ref.batch_encrypt(v1), ref.batch_encrypt(v2)
+    x, y = d.ct(e1.data()), d.ct(e2.data())
+    d.ev.multiply_inplace(x, y)
+    d.ev.relinearize_inplace(x, d.rlk)
+    d.ev.rotate_rows_inplace(x, 1, d.glk)
+    back = ref.ct(x.chain_index(), d.out(x)[0], False)
+    got = ref.batch_decrypt(back, n)
+    prod = (v1 * v2) % np.uint64(t)
+    half = n // 2
+    expect = np.concatenate([np.roll(prod[:half], -1), np.roll(prod[half:], -1)])
+    assert np.array_equal(got, expect)
+
+
+def test_oracle_kind_is_reported(gpu):
+    print("oracle kind used for GPU parity:", kind_available())
