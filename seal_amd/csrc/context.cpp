@@ -1,5 +1,6 @@
 #include "context.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace sealhip
@@ -135,6 +136,14 @@ namespace sealhip
             (void)hipFree(d_inv_);
         if (d_ninv_)
             (void)hipFree(d_ninv_);
+        if (d_fpd_)
+            (void)hipFree(d_fpd_);
+        if (d_fwd_d_)
+            (void)hipFree(d_fwd_d_);
+        if (d_inv_d_)
+            (void)hipFree(d_inv_d_);
+        if (d_ninv_d_)
+            (void)hipFree(d_ninv_d_);
     }
 
     const Level *Context::level_by_chain_index(size_t chain_index) const
@@ -236,6 +245,40 @@ namespace sealhip
             ninv[2 * p] = make_shoup(ni, q);
             ninv[2 * p + 1] = make_shoup(mulmod(ni, n_ > 1 ? iv[1].w : 1, q), q);
         }
+        // double-precision twins of the tables for primes below 2^kFpMaxBits (field.h); only the
+        // two-pass engine (ntt2_kernels.hip) reads them, so they are built for its sizes only
+        h_fpd_.assign(np, FpDesc{ 0.0, 0.0, 0.0, 0 });
+        const bool want_fp = log_n_ >= 13 && log_n_ <= 16 && !std::getenv("SEALHIP_NO_FP");
+        std::vector<double> fwd_d(want_fp ? np * n_ : 1), inv_d(want_fp ? np * n_ : 1), ninv_d(np * 2);
+        for (size_t p = 0; want_fp && p < np; p++)
+        {
+            uint64_t q = pool_[p];
+            if (!roots_[p] || (q >> kFpMaxBits))
+                continue;
+            h_fpd_[p].q = (double)q;
+            h_fpd_[p].qinv = 1.0 / (double)q;
+            h_fpd_[p].two32 = (double)((uint64_t(1) << 32) % q);
+            h_fpd_[p].qi = q;
+            for (size_t i = 0; i < n_; i++)
+            {
+                fwd_d[p * n_ + i] = (double)fwd[p * n_ + i].w;
+                inv_d[p * n_ + i] = (double)inv[p * n_ + i].w;
+            }
+            ninv_d[2 * p] = (double)ninv[2 * p].w;
+            ninv_d[2 * p + 1] = (double)ninv[2 * p + 1].w;
+        }
+        check_hip(hipMalloc(&d_fpd_, np * sizeof(FpDesc)), "hipMalloc fpd");
+        check_hip(hipMalloc(&d_fwd_d_, fwd_d.size() * 8), "hipMalloc fwd_d");
+        check_hip(hipMalloc(&d_inv_d_, inv_d.size() * 8), "hipMalloc inv_d");
+        check_hip(hipMalloc(&d_ninv_d_, ninv_d.size() * 8), "hipMalloc ninv_d");
+        check_hip(hipMemcpy(d_fpd_, h_fpd_.data(), np * sizeof(FpDesc), hipMemcpyHostToDevice), "upload fpd");
+        check_hip(hipMemcpy(d_fwd_d_, fwd_d.data(), fwd_d.size() * 8, hipMemcpyHostToDevice), "upload fwd_d");
+        check_hip(hipMemcpy(d_inv_d_, inv_d.data(), inv_d.size() * 8, hipMemcpyHostToDevice), "upload inv_d");
+        check_hip(hipMemcpy(d_ninv_d_, ninv_d.data(), ninv_d.size() * 8, hipMemcpyHostToDevice), "upload ninv_d");
+        tables_.fpd = d_fpd_;
+        tables_.fwd_d = d_fwd_d_;
+        tables_.inv_d = d_inv_d_;
+        tables_.ninv_d = d_ninv_d_;
         check_hip(hipMalloc(&d_mods_, np * sizeof(ModDesc)), "hipMalloc mods");
         check_hip(hipMalloc(&d_fwd_, fwd.size() * sizeof(ShoupOp)), "hipMalloc fwd tables");
         check_hip(hipMalloc(&d_inv_, inv.size() * sizeof(ShoupOp)), "hipMalloc inv tables");

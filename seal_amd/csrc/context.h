@@ -114,6 +114,8 @@ namespace sealhip
         // host copies (tests / introspection)
         uint64_t ntt_root(unsigned pool_index) const { return roots_[pool_index]; }
         const std::vector<ModDesc> &host_mods() const { return h_mods_; }
+        // true when pool prime p runs on the double-precision back end (field.h)
+        bool fp_prime(unsigned pool_index) const { return h_fpd_[pool_index].qi != 0; }
 
         // special prime P^-1 mod q_i for key switching (key level's inv_q_last_mod_q)
         const ShoupOp *dev_inv_special_mod_q() const { return key_level().dev.inv_q_last_mod_q; }
@@ -138,6 +140,9 @@ namespace sealhip
         ShoupOp *d_fwd_ = nullptr;
         ShoupOp *d_inv_ = nullptr;
         ShoupOp *d_ninv_ = nullptr;
+        FpDesc *d_fpd_ = nullptr;
+        double *d_fwd_d_ = nullptr, *d_inv_d_ = nullptr, *d_ninv_d_ = nullptr;
+        std::vector<FpDesc> h_fpd_;
         NttTables tables_{};
     };
 } // namespace sealhip

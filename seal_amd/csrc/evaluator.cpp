@@ -1,5 +1,6 @@
 #include "evaluator.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -224,9 +225,20 @@ namespace sealhip
             (void)hipFree(keys_[index].dev);
         void *p = nullptr;
         ck(hipMalloc(&p, bytes), "hipMalloc key");
-        ck(hipMemcpy(p, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key");
+        const bool reorder = ntt2_supports(ctx.log_n()) && !std::getenv("SEALHIP_OLD_KS");
+        if (reorder)
+        {
+            // upload to a staging block, then lay the key out for the fused kernel
+            Scratch stage(bytes / 8);
+            ck(hipMemcpy(stage.p, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key");
+            ck(key_to_register_order(ctx.ntt_tables(), stage.p, (uint64_t *)p, (unsigned)L, digits * 2, nullptr), "key layout");
+            ck(hipDeviceSynchronize(), "key layout sync");
+        }
+        else
+            ck(hipMemcpy(p, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key");
         keys_[index].dev = (uint64_t *)p;
         keys_[index].digits = digits;
+        keys_[index].register_order = reorder;
     }
 
     // ---------------------------------------------------------------- Evaluator
@@ -240,6 +252,8 @@ namespace sealhip
     {
         for (auto &kv : ks_maps_)
             (void)hipFree(kv.second);
+        for (auto &kv : ks_targets_)
+            (void)hipFree(kv.second.dev);
         if (d_flag_)
             (void)hipFree(d_flag_);
     }
@@ -301,6 +315,41 @@ namespace sealhip
         ck(hipMemcpy(p, m.data(), m.size() * 4, hipMemcpyHostToDevice), "upload ks map");
         ks_maps_[K] = (uint32_t *)p;
         return (uint32_t *)p;
+    }
+
+    const Evaluator::KsTargets &Evaluator::ks_targets(unsigned K) const
+    {
+        auto it = ks_targets_.find(K);
+        if (it != ks_targets_.end())
+            return it->second;
+        // target moduli of a key switch at a level with K data primes: q_0..q_{K-1} and the special
+        // prime (slot I = K, pool prime and key component L-1), split by arithmetic back end
+        const unsigned L = context_.key_level().K;
+        std::vector<uint32_t> t1[2], t2[2];
+        for (unsigned I = 0; I <= K; I++)
+        {
+            const unsigned prime = I == K ? L - 1 : I;
+            const int fp = context_.fp_prime(prime) ? 1 : 0;
+            t1[fp].push_back(I);
+            t1[fp].push_back(prime);
+            t2[fp].push_back(I);
+            t2[fp].push_back(prime);
+            t2[fp].push_back(prime);
+        }
+        KsTargets kt;
+        kt.n_int = (unsigned)t1[0].size() / 2;
+        kt.n_fp = (unsigned)t1[1].size() / 2;
+        std::vector<uint32_t> all;
+        for (int fp = 0; fp < 2; fp++)
+        {
+            all.insert(all.end(), t1[fp].begin(), t1[fp].end());
+            all.insert(all.end(), t2[fp].begin(), t2[fp].end());
+        }
+        void *p = nullptr;
+        ck(hipMalloc(&p, all.size() * 4 + 4), "hipMalloc ks targets");
+        ck(hipMemcpy(p, all.data(), all.size() * 4, hipMemcpyHostToDevice), "upload ks targets");
+        kt.dev = (uint32_t *)p;
+        return ks_targets_[K] = kt;
     }
 
     bool Evaluator::scale_within_bounds(double scale, const Level &lvl) const
@@ -645,6 +694,32 @@ namespace sealhip
         if (scheme == Scheme::ckks)
             ck(ntt_inverse(tb, plain_batch(t.p, (size_t)K * N, K, B, 0), 0, stream_), "ks intt target");
 
+        Scratch acc((size_t)B * 2 * (K + 1) * N);
+        if (key.register_order)
+        {
+            // fused path (ntt2_kernels.hip): the K(K+1) raised digits go through HBM once, between
+            // the two passes, and are multiplied into the key inside the second pass
+            const KsTargets &kt = ks_targets(K);
+            Scratch mid((size_t)B * (K + 1) * K * N);
+            KsFusedArgs ka{};
+            ka.t = t.p;
+            ka.target_ntt = scheme == Scheme::ckks ? target : nullptr;
+            ka.key = key.dev;
+            ka.mid = mid.p;
+            ka.acc = acc.p;
+            ka.targets1_int = kt.dev;
+            ka.targets2_int = kt.dev + 2 * kt.n_int;
+            ka.targets1_fp = kt.dev + 5 * kt.n_int;
+            ka.targets2_fp = kt.dev + 5 * kt.n_int + 2 * kt.n_fp;
+            ka.n_int = kt.n_int;
+            ka.n_fp = kt.n_fp;
+            ka.K = K;
+            ka.L = L;
+            ka.batch = B;
+            ck(ks_fused(tb, ka, stream_), "ks fused");
+        }
+        else
+        {
         // u[b][I][J] = NTT_I(t_J mod q_I), I over the K data primes and the special prime
         // (evaluator.cpp:2663-2701).  The reference skips the transform when I == J in CKKS because
         // NTT_J(INTT_J(x)) = x; computing it gives the same canonical words.
@@ -665,8 +740,8 @@ namespace sealhip
         }
 
         // inner product with the key (evaluator.cpp:2703-2755)
-        Scratch acc((size_t)B * 2 * (K + 1) * N);
         ck(k_keyswitch_mac(mods, u.p, key.dev, acc.p, n_log, K, L, B, stream_), "ks mac");
+        }
 
         // mod-down by the special prime P and accumulate into (c0, c1) (evaluator.cpp:2806-2864)
         const uint64_t P = context_.coeff_modulus()[L - 1];

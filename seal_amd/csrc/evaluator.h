@@ -6,6 +6,8 @@
 #pragma once
 #include "context.h"
 #include "poly_kernels.h"
+#include "pool.h"
+#include "ntt2_kernels.h"
 #include <map>
 #include <memory>
 #include <mutex>
@@ -14,35 +16,6 @@
 
 namespace sealhip
 {
-    // Size-bucketed caching allocator for HBM scratch and ciphertext slabs (hipMalloc/hipFree
-    // synchronise the device; the reference's MemoryPool plays the same role on the host,
-    // native/src/seal/util/mempool.h).  Blocks are reused in stream order by a single stream.
-    class DevicePool
-    {
-    public:
-        static DevicePool &global();
-        uint64_t *alloc_words(size_t words);
-        void free_words(uint64_t *p);
-        void release_all();
-        size_t bytes_held() const { return held_; }
-        ~DevicePool();
-
-    private:
-        std::mutex mu_;
-        std::multimap<size_t, uint64_t *> free_;
-        std::map<uint64_t *, size_t> live_;
-        size_t held_ = 0;
-    };
-
-    struct Scratch
-    {
-        uint64_t *p = nullptr;
-        explicit Scratch(size_t words) : p(DevicePool::global().alloc_words(words)) {}
-        ~Scratch() { DevicePool::global().free_words(p); }
-        Scratch(const Scratch &) = delete;
-        Scratch &operator=(const Scratch &) = delete;
-    };
-
     // A batch of `batch` ciphertexts sharing metadata; slab layout [poly][batch][K][N].
     class Ciphertext
     {
@@ -100,6 +73,9 @@ namespace sealhip
         {
             uint64_t *dev = nullptr;
             size_t digits = 0;
+            // true: every component is stored in the register order of the fused key-switch
+            // kernel, as doubles for primes of the double-precision back end (ntt2_kernels.h)
+            bool register_order = false;
         };
         ~KSwitchKeys();
         void set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device);
@@ -168,11 +144,18 @@ namespace sealhip
         void conjugate_internal(Ciphertext &encrypted, const KSwitchKeys &galois_keys) const;
         void throw_if_transparent(const Ciphertext &ct) const;
         const uint32_t *ks_comp_prime(unsigned K) const;
+        struct KsTargets
+        {
+            uint32_t *dev = nullptr; // [t1_int | t2_int | t1_fp | t2_fp]
+            unsigned n_int = 0, n_fp = 0;
+        };
+        const KsTargets &ks_targets(unsigned K) const;
 
         const Context &context_;
         hipStream_t stream_ = nullptr;
         bool transparent_check_ = false;
         mutable std::map<unsigned, uint32_t *> ks_maps_;
+        mutable std::map<unsigned, KsTargets> ks_targets_;
         mutable unsigned *d_flag_ = nullptr;
     };
 } // namespace sealhip

@@ -1,0 +1,282 @@
+// Two arithmetic back ends for the residue field Z_q inside the gfx950 NTT / key-switch kernels.
+//
+// gfx950 issues every VALU instruction at the same rate (tools/microbench/valu_rates.hip: a
+// v_mad_u64_u32, a 32-bit add and a v_fma_f64 all cost one ~4-cycle issue slot per wave64), so a
+// kernel's speed is its instruction count.  A 64x64->128 product costs four v_mad_u64_u32 plus
+// carries, which makes the reference's Shoup/Harvey butterfly (uintarithsmallmod.h:292-326,
+// ntt.h:20-67) ~27 instructions per butterfly in 32-bit limbs.  For primes below 2^50 — every
+// "scaling" prime of a typical CKKS chain — the same residue arithmetic can be done EXACTLY in
+// double precision with error-free transformations at 8 instructions per butterfly:
+//
+//     h = fl(y*w); l = fma(y,w,-h)            y*w = h + l exactly (the product error is a double)
+//     k = rint(fl(h*qinv))                    an integer near y*w/q
+//     r = fma(-k,q,h) + l                     = y*w - k*q exactly: both steps are exact because
+//                                               the results are integers of magnitude < 2^53
+//
+// r is congruent to y*w mod q whatever k was; only |r| depends on how good the quotient estimate
+// is: |r| <= q*(1/2 + 3*2^-53*|y*w/q|) (three roundings), i.e. |r| <= q*(0.5 + 0.375*B) when
+// |y| <= B*q and q < 2^50.  Values are kept as signed ("balanced") integers in doubles; sums stay
+// exact while every magnitude is below 2^53 = 8*2^50, which the kernels guarantee by calling
+// fix() (x - rint(x*qinv)*q, |result| <= q/2 + eps) after at most four butterfly stages:
+//     forward (CT):  B -> 1.375*B + 0.5 per stage:  1 -> 1.9 -> 3.1 -> 4.7 -> 7.0   (< 8)
+//     inverse (GS):  B -> 2*B per stage:            0.5 -> 1 -> 2 -> 4 -> 8 (sum < 8q <= 2^53, exact)
+// Only canonical residues in [0,q) ever leave a kernel, so results are bit-identical to the
+// integer path and to the reference: the representation is internal.
+//
+// IntField is the general path (any q < 2^61) and follows the reference's lazy ranges:
+// forward values in [0,4q), inverse values in [0,2q).
+#pragma once
+#include "modarith.h"
+
+namespace sealhip
+{
+    // q < 2^kFpMaxBits is eligible for the double-precision back end.
+    constexpr int kFpMaxBits = 50;
+
+    // Per-prime constants of the double-precision back end.
+    struct __attribute__((aligned(16))) FpDesc
+    {
+        double q;      // the prime
+        double qinv;   // fl(1/q)
+        double two32;  // 2^32 mod q
+        uint64_t qi;   // the prime as an integer (0 = prime not eligible)
+    };
+
+    SHL_HD double fp_from_bits(uint64_t b)
+    {
+        return __builtin_bit_cast(double, b);
+    }
+    SHL_HD uint64_t fp_to_bits(double d)
+    {
+        return __builtin_bit_cast(uint64_t, d);
+    }
+
+    // x*w - k*q with k = rint(x*w/q): exact residue of the product, |result| <= q*(0.5 + 0.375*|x|/q)
+    SHL_HD double fp_mulmod(double x, double w, double q, double qinv)
+    {
+        double h = x * w;
+        double l = __builtin_fma(x, w, -h);
+        double k = __builtin_rint(h * qinv);
+        double v = __builtin_fma(-k, q, h);
+        return v + l;
+    }
+    // |x| < 2^53 -> congruent value with |result| <= q/2 (+ a few ulp of q)
+    SHL_HD double fp_fix(double x, double q, double qinv)
+    {
+        double k = __builtin_rint(x * qinv);
+        return __builtin_fma(-k, q, x);
+    }
+    // integer x < 2^52 -> the same value as a double (exponent trick: 2^52 + x has x in its mantissa)
+    SHL_HD double fp_from_u52(uint64_t x)
+    {
+        return fp_from_bits(x | 0x4330000000000000ull) - 4503599627370496.0;
+    }
+    // any 64-bit x -> value congruent to x mod q with magnitude < q + 2^32
+    SHL_HD double fp_from_u64(uint64_t x, const FpDesc &m)
+    {
+        double hi = fp_from_u52(x >> 32), lo = fp_from_u52(x & 0xffffffffull);
+        return fp_mulmod(hi, m.two32, m.q, m.qinv) + lo;
+    }
+    // |x| < q (integer-valued) -> canonical residue in [0,q) as an integer
+    SHL_HD uint64_t fp_to_canon(double x, const FpDesc &m)
+    {
+        double y = x < 0.0 ? x + m.q : x;
+        return fp_to_bits(y + 4503599627370496.0) & 0x000fffffffffffffull;
+    }
+
+    template <bool FP>
+    struct Field;
+
+    // ---- 64-bit integer back end (Shoup multiplication, Harvey lazy butterflies)
+    template <>
+    struct Field<false>
+    {
+        typedef uint64_t elem;
+        typedef ShoupOp tw_t;
+        struct Mod
+        {
+            uint64_t q, two_q;
+            ModDesc md;
+        };
+        static constexpr int tw_words = 2;
+
+        static SHL_HD Mod make_mod(const ModDesc &md, const FpDesc &)
+        {
+            return Mod{ md.q, md.two_q, md };
+        }
+        static SHL_HD elem from_canon(uint64_t x, const Mod &)
+        {
+            return x;
+        }
+        static SHL_HD elem from_any(uint64_t x, const Mod &m)
+        {
+            return barrett64(x, m.md);
+        }
+        // X,Y in [0,4q) -> [0,4q)   (Arithmetic<>::guard/add/sub/mul_root, ntt.h:30-61)
+        static SHL_HD void bfly_fwd(elem &X, elem &Y, const tw_t &w, const Mod &m)
+        {
+            uint64_t x = X >= m.two_q ? X - m.two_q : X;
+            uint64_t t = mul_shoup_lazy(Y, w.w, w.wq, m.q);
+            X = x + t;
+            Y = x - t + m.two_q;
+        }
+        // X,Y in [0,2q) -> [0,2q)   (dwthandler.h:202-356)
+        static SHL_HD void bfly_inv(elem &X, elem &Y, const tw_t &w, const Mod &m)
+        {
+            uint64_t s = X + Y, d = X - Y + m.two_q;
+            X = s >= m.two_q ? s - m.two_q : s;
+            Y = mul_shoup_lazy(d, w.w, w.wq, m.q);
+        }
+        // last inverse stage with N^-1 folded in (dwthandler.h:273-314): ni = N^-1, nw = N^-1 * w
+        static SHL_HD void bfly_inv_last(elem &X, elem &Y, const tw_t &ni, const tw_t &nw, const Mod &m)
+        {
+            uint64_t s = X + Y, d = X - Y + m.two_q;
+            X = mul_shoup_lazy(s, ni.w, ni.wq, m.q);
+            Y = mul_shoup_lazy(d, nw.w, nw.wq, m.q);
+        }
+        static SHL_HD void fix(elem &, const Mod &)
+        {}
+        // forward result ([0,4q)) -> [0,q)
+        static SHL_HD uint64_t fwd_to_canon(elem x, const Mod &m)
+        {
+            x = x >= m.two_q ? x - m.two_q : x;
+            return csub(x, m.q);
+        }
+        static SHL_HD uint64_t fwd_to_lazy(elem x, const Mod &)
+        {
+            return x;
+        }
+        // inverse result ([0,2q)) -> [0,q)
+        static SHL_HD uint64_t inv_to_canon(elem x, const Mod &m)
+        {
+            return csub(x, m.q);
+        }
+        static SHL_HD uint64_t inv_to_lazy(elem x, const Mod &)
+        {
+            return x;
+        }
+        static SHL_HD uint64_t raw(elem x)
+        {
+            return x;
+        }
+        static SHL_HD elem unraw(uint64_t x)
+        {
+            return x;
+        }
+
+        // key-switch inner product: 128-bit lazy sum of x*key, x in [0,4q), key canonical
+        struct Acc
+        {
+            uint64_t lo, hi;
+        };
+        typedef uint64_t key_t;
+        static SHL_HD Acc acc_zero()
+        {
+            return Acc{ 0, 0 };
+        }
+        static SHL_HD void mac(Acc &a, elem x, key_t k, const Mod &)
+        {
+            uint64_t pl, ph;
+            mul_wide(x, k, pl, ph);
+            a.lo += pl;
+            a.hi += ph + (a.lo < pl);
+        }
+        static SHL_HD void acc_fix(Acc &, const Mod &)
+        {}
+        static SHL_HD uint64_t acc_to_canon(const Acc &a, const Mod &m)
+        {
+            return barrett128(a.lo, a.hi, m.md);
+        }
+    };
+
+    // ---- double-precision back end (q < 2^50)
+    template <>
+    struct Field<true>
+    {
+        typedef double elem;
+        typedef double tw_t;
+        typedef FpDesc Mod;
+        static constexpr int tw_words = 1;
+
+        static SHL_HD Mod make_mod(const ModDesc &, const FpDesc &f)
+        {
+            return f;
+        }
+        static SHL_HD elem from_canon(uint64_t x, const Mod &)
+        {
+            return fp_from_u52(x);
+        }
+        static SHL_HD elem from_any(uint64_t x, const Mod &m)
+        {
+            return fp_from_u64(x, m);
+        }
+        static SHL_HD void bfly_fwd(elem &X, elem &Y, const tw_t &w, const Mod &m)
+        {
+            double t = fp_mulmod(Y, w, m.q, m.qinv);
+            Y = X - t;
+            X = X + t;
+        }
+        static SHL_HD void bfly_inv(elem &X, elem &Y, const tw_t &w, const Mod &m)
+        {
+            double d = X - Y;
+            X = X + Y;
+            Y = fp_mulmod(d, w, m.q, m.qinv);
+        }
+        static SHL_HD void bfly_inv_last(elem &X, elem &Y, const tw_t &ni, const tw_t &nw, const Mod &m)
+        {
+            double s = X + Y, d = X - Y;
+            X = fp_mulmod(s, ni, m.q, m.qinv);
+            Y = fp_mulmod(d, nw, m.q, m.qinv);
+        }
+        static SHL_HD void fix(elem &x, const Mod &m)
+        {
+            x = fp_fix(x, m.q, m.qinv);
+        }
+        // callers fix() before converting, so |x| <= q/2 + eps
+        static SHL_HD uint64_t fwd_to_canon(elem x, const Mod &m)
+        {
+            return fp_to_canon(x, m);
+        }
+        static SHL_HD uint64_t fwd_to_lazy(elem x, const Mod &m)
+        {
+            return fp_to_canon(x, m);
+        }
+        static SHL_HD uint64_t inv_to_canon(elem x, const Mod &m)
+        {
+            return fp_to_canon(x, m);
+        }
+        static SHL_HD uint64_t inv_to_lazy(elem x, const Mod &m)
+        {
+            return fp_to_canon(x, m);
+        }
+        static SHL_HD uint64_t raw(elem x)
+        {
+            return fp_to_bits(x);
+        }
+        static SHL_HD elem unraw(uint64_t x)
+        {
+            return fp_from_bits(x);
+        }
+
+        // key-switch inner product: each product is reduced to |r| <= 0.69q and summed exactly;
+        // acc_fix() is called every 8 terms so the sum stays below 8q <= 2^53.
+        typedef double Acc;
+        typedef double key_t; // the key component is stored as doubles for eligible primes
+        static SHL_HD Acc acc_zero()
+        {
+            return 0.0;
+        }
+        static SHL_HD void mac(Acc &a, elem x, key_t k, const Mod &m)
+        {
+            a += fp_mulmod(x, k, m.q, m.qinv);
+        }
+        static SHL_HD void acc_fix(Acc &a, const Mod &m)
+        {
+            a = fp_fix(a, m.q, m.qinv);
+        }
+        static SHL_HD uint64_t acc_to_canon(const Acc &a, const Mod &m)
+        {
+            return fp_to_canon(fp_fix(a, m.q, m.qinv), m);
+        }
+    };
+} // namespace sealhip

@@ -1,0 +1,36 @@
+// Two-pass NTT engine (2^13 <= N <= 2^16) and fused key-switching kernels: launch interface.
+// See ntt2_kernels.hip for the decomposition and field.h for the two arithmetic back ends.
+#pragma once
+#include "ntt_kernels.h"
+
+namespace sealhip
+{
+    bool ntt2_supports(int log_n);
+
+    // Same contract as ntt_forward (ntt_kernels.h); `mid` is a scratch buffer of
+    // nouter * ncomp * N words that holds the transforms between the two passes (tile order).
+    hipError_t ntt2_forward(const NttTables &t, const NttBatch &b, int out_lazy, uint64_t *mid, hipStream_t stream);
+
+    // switch_key_inplace inner part (evaluator.cpp:2663-2755):
+    //   acc[b][k][I] = sum_J NTT_I(t[b][J] mod q_I) (.) key[J][k][comp(I)]   canonical, natural order
+    // t: [batch][K][N] coefficient form.  target_ntt (CKKS) = the same digits in NTT form, used for
+    // I == J instead of transforming (null for BFV).  key: register order (key_to_register_order).
+    // targets*: device arrays, one entry per target modulus of the class (integer / double):
+    //   targets1: pairs (I, pool prime); targets2: triples (I, pool prime, key component)
+    struct KsFusedArgs
+    {
+        const uint64_t *t;
+        const uint64_t *target_ntt;
+        const uint64_t *key;
+        uint64_t *mid; // [batch][K+1][K][N] scratch
+        uint64_t *acc; // [batch][2][K+1][N]
+        const uint32_t *targets1_int, *targets2_int, *targets1_fp, *targets2_fp;
+        unsigned n_int, n_fp;
+        unsigned K, L, batch;
+    };
+    hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);
+
+    // [polys][L][N] natural-order key words -> register order of ks2 (doubles for eligible primes)
+    hipError_t key_to_register_order(
+        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream);
+} // namespace sealhip

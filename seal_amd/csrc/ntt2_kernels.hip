@@ -1,0 +1,758 @@
+// Two-pass negacyclic NTT engine for 2^12 <= N <= 2^16 and the fused key-switching kernels.
+//
+// What it replaces in the reference (results are canonical residues, hence bit-identical):
+//   ntt_negacyclic_harvey[_lazy]              native/src/seal/util/ntt.cpp:394-437 (dwthandler.h:94-191)
+//   the I/J loop of switch_key_inplace        native/src/seal/evaluator.cpp:2663-2755
+//
+// Decomposition (D1 = n - 8, forward, Cooley-Tukey, natural -> bit-reversed order as the reference):
+//   pass 1: stages 0..D1-1 on strided "columns" of the N/256 x 256 matrix; a workgroup owns a
+//           tile of 2^D1 rows x C columns (C = 4096 / 2^D1, always 4096 coefficients, 256 threads,
+//           16 coefficients per thread); D1-4 stages in registers, one LDS exchange, 4 stages;
+//           the tile is written to a private intermediate buffer in *tile order*
+//              mid[(hg*16 + col_hi)*256 + h_lo*16 + col_lo],  h = 16*hg + h_lo the row, col = 16*col_hi + col_lo
+//   pass 2: stages D1..D1+7 on 16 contiguous rows (hg) of 256 coefficients; thanks to the tile
+//           order every load is a fully coalesced 2 KiB wave access; 4 stages, a wave-local LDS
+//           exchange (the 16 lanes that own one row sit in one wavefront: no s_barrier), 4 stages.
+// Twiddles are the reference's merged psi powers in bit-reversed order (ntt.cpp:273-278), so the
+// two passes compose without a twist multiply.  Phase-A twiddles of pass 1 are wave-uniform and
+// live in SGPRs; the others are staged through LDS or loaded per thread.
+//
+// Arithmetic is a template parameter (field.h): the general 64-bit Shoup/Harvey back end, or the
+// exact double-precision back end for primes below 2^50 (3x fewer VALU instructions per butterfly).
+//
+// Fused key switching (ks1/ks2): pass 1 loops over all target moduli I for one decomposition
+// digit J (the digit is read once), pass 2 loops over the digits J of one target modulus I, keeps
+// the 2x16 running sums of (digit x key) per thread in registers and writes only the reduced sums:
+// the K(K+1) transformed digits never reach HBM in NTT form.
+#include "ntt2_kernels.h"
+
+namespace sealhip
+{
+    namespace
+    {
+        constexpr int kThreads = 256;
+
+        template <int D1>
+        struct Geo
+        {
+            static constexpr int rA = D1 - 4;                 // stages in phase A of pass 1
+            static constexpr int LC = 12 - D1;                // log2(columns per pass-1 tile)
+            static constexpr int C = 1 << LC;
+            static constexpr int CP = C + (C == 16 ? 1 : 0);  // padded LDS row (words)
+            static constexpr int ROWS = 1 << D1;
+            static constexpr int TILES = 1 << (D1 - 4);       // tiles per transform, both passes
+            static constexpr int n = D1 + 8;
+            static constexpr size_t lds1_words = (size_t)ROWS * CP;
+        };
+        // pass-2 wave-local exchange buffer: 16 rows of 256 words, 2 pad words per 16
+        constexpr int kRowWords = 16 * 18;
+        constexpr size_t kLds2Words = 16 * kRowWords;
+
+        template <bool FP>
+        __device__ __forceinline__ const typename Field<FP>::tw_t *tw_table(const NttTables &t, bool inverse, unsigned prime)
+        {
+            if constexpr (FP)
+                return (inverse ? t.inv_d : t.fwd_d) + ((size_t)prime << t.log_n);
+            else
+                return (inverse ? t.inv : t.fwd) + ((size_t)prime << t.log_n);
+        }
+
+        // One radix-2 stage over the 16 registers of a thread, pairing register-index bit BIT.
+        // tw(g) supplies the twiddle of group g = e >> (BIT+1).
+        template <bool FP, int BIT, class TwFn>
+        __device__ __forceinline__ void stage_fwd(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
+        {
+#pragma unroll
+            for (int g = 0; g < (8 >> BIT); g++)
+            {
+                const typename Field<FP>::tw_t w = tw(g);
+#pragma unroll
+                for (int k = 0; k < (1 << BIT); k++)
+                {
+                    const int e0 = (g << (BIT + 1)) | k;
+                    Field<FP>::bfly_fwd(x[e0], x[e0 | (1 << BIT)], w, m);
+                }
+            }
+        }
+
+        // R (<= 4) consecutive stages on register bits 3, 2, ...; twiddle of (stage t, group g) = tw(t, g)
+        template <bool FP, int R, class TwFn>
+        __device__ __forceinline__ void phase_fwd(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
+        {
+            if constexpr (R >= 1)
+                stage_fwd<FP, 3>(x, m, [&](int g) { return tw(0, g); });
+            if constexpr (R >= 2)
+                stage_fwd<FP, 2>(x, m, [&](int g) { return tw(1, g); });
+            if constexpr (R >= 3)
+                stage_fwd<FP, 1>(x, m, [&](int g) { return tw(2, g); });
+            if constexpr (R >= 4)
+                stage_fwd<FP, 0>(x, m, [&](int g) { return tw(3, g); });
+        }
+
+        // The 15 twiddles of a 4-stage phase held in registers: slot (1<<t)+g.
+        template <bool FP>
+        struct TwRegs;
+        template <>
+        struct TwRegs<true>
+        {
+            double w[16];
+            __device__ __forceinline__ void set(int slot, double v) { w[slot] = v; }
+            __device__ __forceinline__ double get(int slot) const { return w[slot]; }
+        };
+        template <>
+        struct TwRegs<false>
+        {
+            uint64_t w[16], wq[16];
+            __device__ __forceinline__ void set(int slot, const ShoupOp &v)
+            {
+                w[slot] = v.w;
+                wq[slot] = v.wq;
+            }
+            __device__ __forceinline__ ShoupOp get(int slot) const { return ShoupOp{ w[slot], wq[slot] }; }
+        };
+
+        // Load the twiddles of R stages whose table rows start at base(t) = first index of stage t
+        // for this thread; stage t needs 2^t consecutive entries.
+        template <bool FP, int R, class BaseFn>
+        __device__ __forceinline__ void load_tw(TwRegs<FP> &r, const typename Field<FP>::tw_t *tab, BaseFn base)
+        {
+#pragma unroll
+            for (int t = 0; t < R; t++)
+            {
+                const unsigned b = base(t);
+#pragma unroll
+                for (int g = 0; g < (1 << t); g++)
+                    r.set((1 << t) + g, tab[b + g]);
+            }
+        }
+
+        // ---------------------------------------------------------------------------------------
+        // source mapping of pass 1 (NttBatch::src_mode)
+        // ---------------------------------------------------------------------------------------
+        struct SrcMap
+        {
+            int mode; // 0 own residue, 1 foreign residue (x mod q), 2 ((x + half) mod src_q) mod q + fix
+            uint64_t half, src_q, fix;
+        };
+        template <bool FP>
+        __device__ __forceinline__ typename Field<FP>::elem map_src(uint64_t v, const SrcMap &s, const typename Field<FP>::Mod &m)
+        {
+            typedef Field<FP> F;
+            if (s.mode == 0)
+                return F::from_canon(v, m);
+            if (s.mode == 1)
+                return F::from_any(v, m);
+            uint64_t r = csub(v + s.half, s.src_q);
+            typename F::elem x = F::from_any(r, m) + F::from_canon(s.fix, m);
+            F::fix(x, m); // the sum may reach 1.5q: bring it back before four butterfly stages
+            return x;
+        }
+
+        // ---------------------------------------------------------------------------------------
+        // pass 1 body: src (natural order, column tile cg) -> D1 stages -> mid (tile order)
+        // ---------------------------------------------------------------------------------------
+        template <bool FP, int D1>
+        __device__ __forceinline__ void p1_tile(
+            typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
+            uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            const unsigned c = tid & (G::C - 1);
+            const unsigned hi = tid >> G::LC; // rbl in phase A, ra in phase B
+            if constexpr (G::rA > 0)
+            {
+                // phase A: register a = ra*2^(4-rA) + rbh; stage s pairs register bit 3-s; twiddle 2^s + group: uniform
+                phase_fwd<FP, G::rA>(x, m, [&](int t, int g) { return tab[(1u << t) + g]; });
+                if constexpr (FP)
+                {
+#pragma unroll
+                    for (int a = 0; a < 16; a++)
+                        F::fix(x[a], m);
+                }
+                __syncthreads(); // previous users of the exchange buffer are done
+#pragma unroll
+                for (int a = 0; a < 16; a++)
+                {
+                    const unsigned ra = a >> (4 - G::rA), rbh = a & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + hi;
+                    lds[R * G::CP + c] = F::raw(x[a]);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int rb = 0; rb < 16; rb++)
+                    x[rb] = F::unraw(lds[(hi * 16 + rb) * G::CP + c]);
+            }
+            // phase B: thread (c, ra = hi); register rb; stage rA+t pairs rb bit 3-t; twiddle 2^(rA+t) + ra*2^t + group
+            TwRegs<FP> tw;
+            load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (G::rA + t)) + (hi << t); });
+            phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+            if constexpr (FP)
+            {
+#pragma unroll
+                for (int a = 0; a < 16; a++)
+                    F::fix(x[a], m);
+            }
+            // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
+            const unsigned col = cg * G::C + c;
+            uint64_t *o = mid_tr + ((size_t)(hi * 16 + (col >> 4)) << 8) + (col & 15);
+#pragma unroll
+            for (int rb = 0; rb < 16; rb++)
+                o[rb * 16] = F::raw(x[rb]);
+        }
+
+        // ---------------------------------------------------------------------------------------
+        // pass 2 body: 16 registers loaded from mid (tile order) -> 8 stages -> 16 contiguous
+        // coefficients (col = 16 v' + e') of row h = 16 hg + u in registers.  lds = this wave's rows.
+        // TW_LDS: twiddles of both phases are taken from LDS tables staged by the caller:
+        //   twa[t][u][g] (t<4, g<2^t) at twa[(16 << t) - 16 + (u << t) + g]
+        //   twb[t][g][tid]            at twb[((256 << t) - 256) + g*256 + tid]
+        // ---------------------------------------------------------------------------------------
+        template <bool FP, int D1, bool TW_LDS>
+        __device__ __forceinline__ void p2_tile(
+            typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
+            const typename Field<FP>::tw_t *twa, const typename Field<FP>::tw_t *twb, uint64_t *lds_wave, unsigned hg, unsigned tid)
+        {
+            typedef Field<FP> F;
+            const unsigned v = tid & 15, u = tid >> 4;
+            const unsigned h = hg * 16 + u;
+            const unsigned ul = u & 3; // row inside this wave's buffer
+            {
+                TwRegs<FP> tw;
+                if constexpr (TW_LDS)
+                    load_tw<FP, 4>(tw, twa, [&](int t) { return (16u << t) - 16u + (u << t); });
+                else
+                    load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + t)) + (h << t); });
+                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+            }
+            if constexpr (FP)
+            {
+#pragma unroll
+                for (int a = 0; a < 16; a++)
+                    F::fix(x[a], m);
+            }
+            // wave-local exchange: (e, v) -> (v', e')
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                lds_wave[ul * kRowWords + e * 18 + v] = F::raw(x[e]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                x[e] = F::unraw(lds_wave[ul * kRowWords + v * 18 + e]);
+            __builtin_amdgcn_wave_barrier(); // the buffer may be rewritten by the caller's next tile
+            {
+                TwRegs<FP> tw;
+                if constexpr (TW_LDS)
+                {
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int g = 0; g < (1 << t); g++)
+                            tw.set((1 << t) + g, twb[((256u << t) - 256u) + g * 256 + tid]);
+                }
+                else
+                    load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
+                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+            }
+            if constexpr (FP)
+            {
+#pragma unroll
+                for (int a = 0; a < 16; a++)
+                    F::fix(x[a], m);
+            }
+        }
+
+        // registers (row u, cols 16 v' + e') -> wave-local transpose -> 16 coalesced 512-byte stores
+        // of this wave's 4 rows to natural order at `rows` (= address of row 16*hg + 4*wave).
+        __device__ __forceinline__ void store_rows(const uint64_t (&val)[16], uint64_t *lds_wave, uint64_t *rows, unsigned tid)
+        {
+            const unsigned v = tid & 15, ul = (tid >> 4) & 3, lane = tid & 63;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                lds_wave[ul * kRowWords + v * 18 + e] = val[e];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+            {
+                const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
+                rows[row * 256 + col] = lds_wave[row * kRowWords + col + 2 * (col >> 4)];
+            }
+        }
+        __device__ __forceinline__ void load_rows(uint64_t (&val)[16], uint64_t *lds_wave, const uint64_t *rows, unsigned tid)
+        {
+            const unsigned v = tid & 15, ul = (tid >> 4) & 3, lane = tid & 63;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+            {
+                const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
+                lds_wave[row * kRowWords + col + 2 * (col >> 4)] = rows[row * 256 + col];
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                val[e] = lds_wave[ul * kRowWords + v * 18 + e];
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // ---------------------------------------------------------------------------------------
+        // generic forward transform kernels
+        // ---------------------------------------------------------------------------------------
+        struct FwdArgs
+        {
+            uint64_t *data;
+            size_t outer_stride;
+            uint64_t *mid; // [nouter][ncomp][N], tile order
+            const uint64_t *src;
+            size_t src_outer_stride;
+            unsigned src_ncomp;
+            int src_mode;
+            uint64_t src_half, src_q;
+            const uint64_t *src_fix;
+            const uint32_t *comp_prime;
+            unsigned prime_first;
+            unsigned ncomp;
+            int lazy;
+            NttTables t;
+        };
+
+        template <bool FP, int D1>
+        __device__ __forceinline__ void fwd_p1_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            const unsigned tid = threadIdx.x, cg = blockIdx.x;
+            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
+            const uint64_t *in;
+            SrcMap sm{ 0, 0, 0, 0 };
+            if (a.src)
+            {
+                in = a.src + (size_t)outer * a.src_outer_stride + ((size_t)(comp % a.src_ncomp) << G::n);
+                sm.mode = a.src_mode;
+                sm.half = a.src_half;
+                sm.src_q = a.src_q;
+                sm.fix = a.src_mode == 2 ? a.src_fix[comp] : 0;
+            }
+            else
+                in = a.data + (size_t)outer * a.outer_stride + ((size_t)comp << G::n);
+            const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
+            typename F::elem x[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+                x[e] = map_src<FP>(in[(size_t)R * 256 + cg * G::C + c], sm, m);
+            }
+            uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
+            p1_tile<FP, D1>(x, m, tab, lds, mid_tr, cg, tid);
+        }
+
+        template <int D1>
+        __global__ void __launch_bounds__(kThreads) ntt2_fwd_p1(FwdArgs a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y, outer = blockIdx.z;
+            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            if (a.t.fpd[prime].qi)
+                fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
+            else
+                fwd_p1_body<false, D1>(a, prime, comp, outer, lds);
+        }
+
+        template <bool FP, int D1>
+        __device__ __forceinline__ void fwd_p2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            const unsigned tid = threadIdx.x, hg = blockIdx.x;
+            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
+            const uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n) + ((size_t)hg << 12);
+            typename F::elem x[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                x[e] = F::unraw(mid_tr[e * 256 + tid]);
+            uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
+            p2_tile<FP, D1, false>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
+            uint64_t val[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                val[e] = a.lazy ? F::fwd_to_lazy(x[e], m) : F::fwd_to_canon(x[e], m);
+            uint64_t *rows = a.data + (size_t)outer * a.outer_stride + ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+            store_rows(val, lds_wave, rows, tid);
+        }
+
+        template <int D1>
+        __global__ void __launch_bounds__(kThreads) ntt2_fwd_p2(FwdArgs a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y, outer = blockIdx.z;
+            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            if (a.t.fpd[prime].qi)
+                fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
+            else
+                fwd_p2_body<false, D1>(a, prime, comp, outer, lds);
+        }
+
+        // ---------------------------------------------------------------------------------------
+        // fused key switching, pass 1: one workgroup = (column tile cg, digit J, batch item b);
+        // loops over the target moduli in `targets` (entries: slot I in the K+1 x K grid, pool prime).
+        // ---------------------------------------------------------------------------------------
+        struct Ks1Args
+        {
+            const uint64_t *t;   // [batch][K][N] coefficient form, canonical mod q_J
+            uint64_t *mid;       // [batch][K+1][K][N] tile order, raw field elements
+            const uint32_t *targets; // [ntargets] pairs (I, prime)
+            unsigned ntargets;
+            unsigned K;
+            int skip_diag;       // CKKS: (I == J) is the input itself, not transformed
+            NttTables tb;
+        };
+
+        template <bool FP, int D1>
+        __global__ void __launch_bounds__(kThreads) ks1_kernel(Ks1Args a)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned tid = threadIdx.x, cg = blockIdx.x, J = blockIdx.y, b = blockIdx.z;
+            const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
+            const uint64_t *in = a.t + (((size_t)b * a.K + J) << G::n);
+            uint64_t src[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+                src[e] = in[(size_t)R * 256 + cg * G::C + c];
+            }
+            for (unsigned it = 0; it < a.ntargets; it++)
+            {
+                const unsigned I = a.targets[2 * it], prime = a.targets[2 * it + 1];
+                if (a.skip_diag && I == J)
+                    continue;
+                const typename F::Mod m = F::make_mod(a.tb.mods[prime], a.tb.fpd[prime]);
+                const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
+                typename F::elem x[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    x[e] = F::from_any(src[e], m);
+                uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
+                p1_tile<FP, D1>(x, m, tab, lds, mid_tr, cg, tid);
+            }
+        }
+
+        // ---------------------------------------------------------------------------------------
+        // fused key switching, pass 2 + inner product with the key.
+        // one workgroup = (target modulus I, row tile hg, batch item b); loops over the digits J.
+        //   acc[b][k][I][natural order] = sum_J NTT_I(t_J mod q_I) * key[J][k][comp(I)]   (canonical)
+        // key layout: [J][2][L][N] with every component in "register order"
+        //   pos(hg, e', tid) = hg*4096 + e'*256 + tid   <->   natural hg*4096 + (tid>>4)*256 + (tid&15)*16 + e'
+        // and stored as doubles for double-precision primes (KSwitchKeys::set_key).
+        // ---------------------------------------------------------------------------------------
+        struct Ks2Args
+        {
+            const uint64_t *mid;     // [batch][K+1][K][N]
+            const uint64_t *target;  // [batch][K][N] NTT form (CKKS diagonal shortcut) or null
+            const uint64_t *key;     // [digits][2][L][N] register order
+            uint64_t *acc;           // [batch][2][K+1][N] natural order, canonical
+            const uint32_t *targets; // [ntargets] triples (I, prime, key component)
+            unsigned ntargets;
+            unsigned K, L;
+            unsigned batch;
+            NttTables tb;
+        };
+
+        template <bool FP, int D1>
+        __global__ void __launch_bounds__(kThreads, FP ? 2 : 1) ks2_kernel(Ks2Args a)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned tid = threadIdx.x;
+            // XCD-aware order: blockIdx % 8 selects the XCD; keep every batch item of one (I, hg)
+            // on one XCD and adjacent in time so the key tile is served by that XCD's L2.
+            const unsigned ntile = a.ntargets * G::TILES;
+            unsigned bid = blockIdx.x;
+            const unsigned xcd = bid & 7, rest = bid >> 3;
+            const unsigned b = rest % a.batch, tile_hi = rest / a.batch;
+            const unsigned tile = tile_hi * 8 + xcd;
+            if (tile >= ntile)
+                return;
+            const unsigned it = tile / G::TILES, hg = tile % G::TILES;
+            const unsigned I = a.targets[3 * it], prime = a.targets[3 * it + 1], kc = a.targets[3 * it + 2];
+            const typename F::Mod m = F::make_mod(a.tb.mods[prime], a.tb.fpd[prime]);
+            const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
+
+            uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
+            const typename F::tw_t *twa = nullptr, *twb = nullptr;
+            if constexpr (FP)
+            {
+                // stage this tile's twiddles in LDS once: reused by all K digits
+                typename F::tw_t *la = reinterpret_cast<typename F::tw_t *>(lds + kLds2Words);
+                typename F::tw_t *lb = la + 240;
+                if (tid < 240)
+                {
+                    // entry (t, r): t = floor(log2(tid/16 + 1)), r = tid - (16<<t) + 16
+                    const unsigned t = 31 - __builtin_clz(tid / 16 + 1);
+                    const unsigned r = tid - ((16u << t) - 16u);
+                    la[tid] = tab[(1u << (D1 + t)) + ((hg * 16) << t) + r];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+#pragma unroll
+                    for (int g = 0; g < (1 << t); g++)
+                        lb[((256u << t) - 256u) + g * 256 + tid] = tab[(1u << (D1 + 4 + t)) + ((hg * 256 + tid) << t) + g];
+                twa = la;
+                twb = lb;
+                __syncthreads();
+            }
+
+            typename F::Acc acc0[16], acc1[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                acc0[e] = F::acc_zero();
+                acc1[e] = F::acc_zero();
+            }
+            const typename F::key_t *key = reinterpret_cast<const typename F::key_t *>(a.key);
+            const size_t N = (size_t)1 << G::n;
+            const uint64_t *mid0 = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K) << G::n) + ((size_t)hg << 12) + tid;
+            for (unsigned J = 0; J < a.K; J++)
+            {
+                typename F::elem x[16];
+                if (a.target && I == J)
+                {
+                    // NTT_J(INTT_J(target_J)) = target_J (evaluator.cpp:2682-2685)
+                    uint64_t raw[16];
+                    load_rows(raw, lds_wave, a.target + (((size_t)b * a.K + J) << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8), tid);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = F::from_canon(raw[e], m);
+                }
+                else
+                {
+                    const uint64_t *mp = mid0 + ((size_t)J << G::n);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = F::unraw(mp[e * 256]);
+                    p2_tile<FP, D1, FP>(x, m, tab, twa, twb, lds_wave, hg, tid);
+                    if constexpr (!FP)
+                    {
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            x[e] = F::fwd_to_canon(x[e], m);
+                    }
+                }
+                const typename F::key_t *k0 = key + (((size_t)J * 2 + 0) * a.L + kc) * N + ((size_t)hg << 12) + tid;
+                const typename F::key_t *k1 = k0 + (size_t)a.L * N;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    F::mac(acc0[e], x[e], k0[e * 256], m);
+                    F::mac(acc1[e], x[e], k1[e * 256], m);
+                }
+                if ((J & 7) == 7)
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                    {
+                        F::acc_fix(acc0[e], m);
+                        F::acc_fix(acc1[e], m);
+                    }
+                }
+            }
+            uint64_t val[16];
+            uint64_t *out = a.acc + ((((size_t)b * 2 + 0) * (a.K + 1) + I) << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                val[e] = F::acc_to_canon(acc0[e], m);
+            store_rows(val, lds_wave, out, tid);
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                val[e] = F::acc_to_canon(acc1[e], m);
+            store_rows(val, lds_wave, out + ((size_t)(a.K + 1) << G::n), tid);
+        }
+
+        // natural order (u64) -> register order, optionally converted to double
+        __global__ void __launch_bounds__(kThreads) key_layout_kernel(
+            const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys)
+        {
+            const size_t N = (size_t)1 << n_log;
+            const size_t total = polys * L * N;
+            for (size_t i = blockIdx.x * (size_t)kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads)
+            {
+                const size_t p = i & (N - 1), slab = i >> n_log;
+                const unsigned comp = (unsigned)(slab % L);
+                // destination position p = hg*4096 + e*256 + tid  <-  natural hg*4096 + (tid>>4)*256 + (tid&15)*16 + e
+                const size_t hg = p >> 12;
+                const unsigned e = (unsigned)(p >> 8) & 15, tid = (unsigned)p & 255;
+                const size_t nat = (hg << 12) + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 4) + e;
+                const uint64_t v = in[(slab << n_log) + nat];
+                out[i] = fpd[comp].qi ? fp_to_bits(fp_from_u52(v)) : v;
+            }
+        }
+
+        template <int D1>
+        hipError_t launch_fwd(const FwdArgs &a, unsigned nouter, hipStream_t s)
+        {
+            typedef Geo<D1> G;
+            dim3 grid(G::TILES, a.ncomp, nouter);
+            size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
+            hipLaunchKernelGGL(ntt2_fwd_p1<D1>, grid, dim3(kThreads), l1, s, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess)
+                return e;
+            hipLaunchKernelGGL(ntt2_fwd_p2<D1>, grid, dim3(kThreads), kLds2Words * 8, s, a);
+            return hipGetLastError();
+        }
+
+        template <bool FP, int D1>
+        hipError_t launch_ks(const Ks1Args &a1, const Ks2Args &a2, unsigned batch, hipStream_t s)
+        {
+            typedef Geo<D1> G;
+            if (a1.ntargets == 0)
+                return hipSuccess;
+            size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
+            hipLaunchKernelGGL((ks1_kernel<FP, D1>), dim3(G::TILES, a1.K, batch), dim3(kThreads), l1, s, a1);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess)
+                return e;
+            const unsigned ntile = a2.ntargets * G::TILES;
+            const unsigned blocks = ((ntile + 7) / 8) * batch * 8;
+            size_t l2 = kLds2Words * 8 + (FP ? (240 + 3840) * sizeof(double) : 0);
+            if (l2 > 65536)
+            {
+                // more than the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU)
+                static bool raised = false;
+                if (!raised)
+                {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<FP, D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess)
+                        return hipErrorInvalidValue;
+                    raised = true;
+                }
+            }
+            hipLaunchKernelGGL((ks2_kernel<FP, D1>), dim3(blocks), dim3(kThreads), l2, s, a2);
+            return hipGetLastError();
+        }
+    } // namespace
+
+    bool ntt2_supports(int log_n)
+    {
+        return log_n >= 13 && log_n <= 16;
+    }
+
+    hipError_t ntt2_forward(const NttTables &t, const NttBatch &b, int out_lazy, uint64_t *mid, hipStream_t stream)
+    {
+        if (b.ncomp == 0 || b.nouter == 0)
+            return hipSuccess;
+        FwdArgs a;
+        a.data = b.data;
+        a.outer_stride = b.outer_stride;
+        a.mid = mid;
+        a.src = b.src;
+        a.src_outer_stride = b.src_outer_stride;
+        a.src_ncomp = b.src_ncomp ? b.src_ncomp : 1;
+        a.src_mode = b.src ? b.src_mode : 0;
+        a.src_half = b.src_half;
+        a.src_q = b.src_q;
+        a.src_fix = b.src_fix;
+        a.comp_prime = b.comp_prime;
+        a.prime_first = b.prime_first;
+        a.ncomp = b.ncomp;
+        a.lazy = out_lazy;
+        a.t = t;
+        const unsigned zmax = 65535;
+        for (unsigned z0 = 0; z0 < b.nouter; z0 += zmax)
+        {
+            unsigned nz = b.nouter - z0 < zmax ? b.nouter - z0 : zmax;
+            FwdArgs az = a;
+            az.data = a.data + (size_t)z0 * a.outer_stride;
+            az.mid = a.mid + (((size_t)z0 * a.ncomp) << t.log_n);
+            if (az.src)
+                az.src = a.src + (size_t)z0 * a.src_outer_stride;
+            hipError_t e;
+            switch (t.log_n)
+            {
+            case 13:
+                e = launch_fwd<5>(az, nz, stream);
+                break;
+            case 14:
+                e = launch_fwd<6>(az, nz, stream);
+                break;
+            case 15:
+                e = launch_fwd<7>(az, nz, stream);
+                break;
+            case 16:
+                e = launch_fwd<8>(az, nz, stream);
+                break;
+            default:
+                return hipErrorInvalidValue;
+            }
+            if (e != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
+
+    hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream)
+    {
+        for (int fp = 0; fp < 2; fp++)
+        {
+            Ks1Args a1;
+            a1.t = k.t;
+            a1.mid = k.mid;
+            a1.targets = fp ? k.targets1_fp : k.targets1_int;
+            a1.ntargets = fp ? k.n_fp : k.n_int;
+            a1.K = k.K;
+            a1.skip_diag = k.target_ntt != nullptr;
+            a1.tb = t;
+            Ks2Args a2;
+            a2.mid = k.mid;
+            a2.target = k.target_ntt;
+            a2.key = k.key;
+            a2.acc = k.acc;
+            a2.targets = fp ? k.targets2_fp : k.targets2_int;
+            a2.ntargets = a1.ntargets;
+            a2.K = k.K;
+            a2.L = k.L;
+            a2.batch = k.batch;
+            a2.tb = t;
+            hipError_t e;
+            switch (t.log_n)
+            {
+            case 13:
+                e = fp ? launch_ks<true, 5>(a1, a2, k.batch, stream) : launch_ks<false, 5>(a1, a2, k.batch, stream);
+                break;
+            case 14:
+                e = fp ? launch_ks<true, 6>(a1, a2, k.batch, stream) : launch_ks<false, 6>(a1, a2, k.batch, stream);
+                break;
+            case 15:
+                e = fp ? launch_ks<true, 7>(a1, a2, k.batch, stream) : launch_ks<false, 7>(a1, a2, k.batch, stream);
+                break;
+            case 16:
+                e = fp ? launch_ks<true, 8>(a1, a2, k.batch, stream) : launch_ks<false, 8>(a1, a2, k.batch, stream);
+                break;
+            default:
+                return hipErrorInvalidValue;
+            }
+            if (e != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
+
+    hipError_t key_to_register_order(
+        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream)
+    {
+        size_t total = (polys * L) << t.log_n;
+        size_t blocks = (total + kThreads - 1) / kThreads;
+        if (blocks > 4096)
+            blocks = 4096;
+        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, L, (unsigned)t.log_n, polys);
+        return hipGetLastError();
+    }
+} // namespace sealhip

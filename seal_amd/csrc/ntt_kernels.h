@@ -11,7 +11,7 @@
 // low index), the last pass on contiguous rows; the merged psi-power twiddles of the reference's
 // bit-reversed table are what lets the two passes compose without an extra twiddle multiply.
 #pragma once
-#include "modarith.h"
+#include "field.h"
 
 namespace sealhip
 {
@@ -23,6 +23,12 @@ namespace sealhip
         const ShoupOp *fwd;   // [nprimes][N]
         const ShoupOp *inv;   // [nprimes][N]
         const ShoupOp *ninv;  // [nprimes][2]: {N^-1, N^-1 * inv[1]}
+        // double-precision back end (field.h): the same tables as doubles for primes below 2^50;
+        // fpd[p].qi == 0 marks a prime that only the integer back end may use.
+        const FpDesc *fpd;    // [nprimes]
+        const double *fwd_d;  // [nprimes][N]
+        const double *inv_d;  // [nprimes][N]
+        const double *ninv_d; // [nprimes][2]
         int log_n;
     };
 

@@ -7,6 +7,8 @@
 // leave through the non-lazy entry points, so results equal ntt_negacyclic_harvey /
 // inverse_ntt_negacyclic_harvey (ntt.cpp:408-475) bit for bit.
 #include "ntt_kernels.h"
+#include "ntt2_kernels.h"
+#include "pool.h"
 
 namespace sealhip
 {
@@ -666,6 +668,12 @@ namespace sealhip
 
     hipError_t ntt_forward(const NttTables &t, const NttBatch &b, int out_lazy, hipStream_t stream)
     {
+        if (ntt2_supports(t.log_n))
+        {
+            // two-pass engine; the scratch block goes back to the pool in stream order
+            Scratch mid(((size_t)b.nouter * b.ncomp) << t.log_n);
+            return ntt2_forward(t, b, out_lazy, mid.p, stream);
+        }
         return run(t, b, out_lazy, false, stream);
     }
     hipError_t ntt_inverse(const NttTables &t, const NttBatch &b, int out_lazy, hipStream_t stream)

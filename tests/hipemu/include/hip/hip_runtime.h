@@ -80,6 +80,19 @@ static inline void __syncthreads()
 {
     hipemu::syncthreads();
 }
+// A wavefront executes in lockstep on the GPU, so a compiler-level barrier is all the hardware
+// needs between a wave-local LDS write and the reads of other lanes; fibers run one lane at a
+// time, so here it has to be a real rendezvous (every kernel calls it in uniform control flow).
+#define __builtin_amdgcn_wave_barrier() hipemu::syncthreads()
+enum hipFuncAttribute
+{
+    hipFuncAttributeMaxDynamicSharedMemorySize = 8
+};
+template <typename Fn>
+static inline int hipFuncSetAttribute(Fn, hipFuncAttribute, int)
+{
+    return 0;
+}
 
 template <typename T>
 static inline T __shfl(T v, int src_lane, int width = 64)
