@@ -694,15 +694,10 @@ extern "C"
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
         auto ev = as<Evaluator>(thisptr);
-        if (encrypted2 == destination && encrypted1 != destination)
-            ev->multiply_inplace(*as<Ciphertext>(destination), *as<Ciphertext>(encrypted1)); // evaluator.h multiply(): commutes
-        else if (encrypted1 == encrypted2)
-        {
-            Ciphertext &d = prepare_dest(encrypted1, destination);
-            ev->multiply_inplace(d, d);
-        }
+        if (encrypted1 == encrypted2 && encrypted1 == destination)
+            ev->multiply_inplace(*as<Ciphertext>(destination), *as<Ciphertext>(destination));
         else
-            ev->multiply_inplace(prepare_dest(encrypted1, destination), *as<Ciphertext>(encrypted2));
+            ev->multiply(*as<Ciphertext>(encrypted1), *as<Ciphertext>(encrypted2), *as<Ciphertext>(destination));
         SHL_CATCH
     }
     SHL_FUNC Evaluator_Relinearize(void *thisptr, void *encrypted, void *relinKeys, void *destination, void *pool)

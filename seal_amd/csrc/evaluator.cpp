@@ -185,6 +185,18 @@ namespace sealhip
         level_ = level;
         size_ = size;
     }
+    void Ciphertext::reshape_uninitialized(const Level *level, size_t size)
+    {
+        size_t need = size * batch_ * level->K * ctx_->n();
+        if (need > capacity_words_)
+        {
+            DevicePool::global().free_words(data_);
+            data_ = DevicePool::global().alloc_words(need);
+            capacity_words_ = need;
+        }
+        level_ = level;
+        size_ = size;
+    }
     void Ciphertext::adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words)
     {
         DevicePool::global().free_words(data_);
@@ -526,6 +538,45 @@ namespace sealhip
         }
         throw_if_transparent(e1);
     }
+    void Evaluator::multiply(const Ciphertext &e1, const Ciphertext &e2, Ciphertext &dest) const
+    {
+        // evaluator.h:239-247: destination = encrypted1; multiply_inplace(destination, encrypted2).
+        // Device-resident fast path: the common size-2 x size-2 CKKS product writes the three result
+        // polynomials straight into `dest` instead of copying encrypted1 first.
+        if (&dest == &e1)
+            return multiply_inplace(dest, e2);
+        if (&dest == &e2)
+            return multiply_inplace(dest, e1);
+        if (context_.scheme() == Scheme::ckks && e1.size() == 2 && e2.size() == 2 && &dest.context() == &context_ &&
+            dest.batch() == e1.batch())
+        {
+            check_valid(e1, "encrypted1");
+            check_valid(e2, "encrypted2");
+            if (e1.level() != e2.level())
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            if (e1.batch() != e2.batch())
+                throw std::invalid_argument("batch mismatch");
+            if (!(e1.is_ntt_form() && e2.is_ntt_form()))
+                throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+            const Level &lvl = *e1.level();
+            PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
+            dest.reshape_uninitialized(&lvl, 3);
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, e1.data(), e2.data(), dest.data(), g, stream_), "ckks_multiply");
+            dest.is_ntt_form() = true;
+            dest.correction_factor() = 1;
+            dest.scale() = e1.scale() * e2.scale();
+            if (!scale_within_bounds(dest.scale(), lvl))
+                throw std::invalid_argument("scale out of bounds");
+            throw_if_transparent(dest);
+            return;
+        }
+        dest = e1;
+        if (&e1 == &e2)
+            multiply_inplace(dest, dest);
+        else
+            multiply_inplace(dest, e2);
+    }
+
     void Evaluator::square_inplace(Ciphertext &e) const
     {
         // ckks_square / bfv_square compute (c0^2, 2 c0 c1, c1^2) = the product of e with itself
@@ -551,7 +602,8 @@ namespace sealhip
         if (dest == 3)
         {
             e1.resize(&lvl, 3, stream_);
-            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, e1.data(), self ? e1.data() : e2.data(), g, stream_), "ckks_multiply");
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, e1.data(), self ? e1.data() : e2.data(), e1.data(), g, stream_),
+               "ckks_multiply");
         }
         else
         {
@@ -690,9 +742,20 @@ namespace sealhip
 
         // t_target: coefficient form of every decomposition digit (evaluator.cpp:2651-2658)
         Scratch t((size_t)B * K * N);
-        ck(hipMemcpyAsync(t.p, target, (size_t)B * K * N * 8, hipMemcpyDeviceToDevice, stream_), "ks copy target");
-        if (scheme == Scheme::ckks)
-            ck(ntt_inverse(tb, plain_batch(t.p, (size_t)K * N, K, B, 0), 0, stream_), "ks intt target");
+        if (scheme == Scheme::ckks && ntt2_supports(context_.log_n()))
+        {
+            // out-of-place: the two-pass engine reads the target and writes t
+            NttBatch bt = plain_batch(t.p, (size_t)K * N, K, B, 0);
+            bt.src = target;
+            bt.src_outer_stride = (size_t)K * N;
+            ck(ntt_inverse(tb, bt, 0, stream_), "ks intt target");
+        }
+        else
+        {
+            ck(hipMemcpyAsync(t.p, target, (size_t)B * K * N * 8, hipMemcpyDeviceToDevice, stream_), "ks copy target");
+            if (scheme == Scheme::ckks)
+                ck(ntt_inverse(tb, plain_batch(t.p, (size_t)K * N, K, B, 0), 0, stream_), "ks intt target");
+        }
 
         Scratch acc((size_t)B * 2 * (K + 1) * N);
         if (key.register_order)

@@ -50,6 +50,8 @@ namespace sealhip
         void resize(const Level *level, size_t size, hipStream_t stream);
         // adopt a freshly computed slab (takes ownership of `words` from the pool)
         void adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words);
+        // same shape change as resize() but the contents are left undefined (the caller overwrites them)
+        void reshape_uninitialized(const Level *level, size_t size);
         void release();
 
     private:
@@ -108,6 +110,7 @@ namespace sealhip
         void add_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const;
         void sub_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const;
         void multiply_inplace(Ciphertext &encrypted1, const Ciphertext &encrypted2) const;
+        void multiply(const Ciphertext &encrypted1, const Ciphertext &encrypted2, Ciphertext &destination) const;
         void square_inplace(Ciphertext &encrypted) const;
         void relinearize_inplace(Ciphertext &encrypted, const KSwitchKeys &relin_keys) const;
         void mod_switch_to_next_inplace(Ciphertext &encrypted) const;

@@ -11,6 +11,10 @@ namespace sealhip
     // nouter * ncomp * N words that holds the transforms between the two passes (tile order).
     hipError_t ntt2_forward(const NttTables &t, const NttBatch &b, int out_lazy, uint64_t *mid, hipStream_t stream);
 
+    // Same contract as ntt_inverse; when b.src is set the input is read from src (natural order,
+    // same component layout as data, stride src_outer_stride) and data is only written.
+    hipError_t ntt2_inverse(const NttTables &t, const NttBatch &b, int out_lazy, uint64_t *mid, hipStream_t stream);
+
     // switch_key_inplace inner part (evaluator.cpp:2663-2755):
     //   acc[b][k][I] = sum_J NTT_I(t[b][J] mod q_I) (.) key[J][k][comp(I)]   canonical, natural order
     // t: [batch][K][N] coefficient form.  target_ntt (CKKS) = the same digits in NTT form, used for

@@ -25,6 +25,7 @@
 // the 2x16 running sums of (digit x key) per thread in registers and writes only the reduced sums:
 // the K(K+1) transformed digits never reach HBM in NTT form.
 #include "ntt2_kernels.h"
+#include <cstdlib>
 
 namespace sealhip
 {
@@ -87,6 +88,36 @@ namespace sealhip
                 stage_fwd<FP, 1>(x, m, [&](int g) { return tw(2, g); });
             if constexpr (R >= 4)
                 stage_fwd<FP, 0>(x, m, [&](int g) { return tw(3, g); });
+        }
+
+        // Inverse (Gentleman-Sande) counterparts: the stages of a phase are undone last-to-first.
+        template <bool FP, int BIT, class TwFn>
+        __device__ __forceinline__ void stage_inv(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
+        {
+#pragma unroll
+            for (int g = 0; g < (8 >> BIT); g++)
+            {
+                const typename Field<FP>::tw_t w = tw(g);
+#pragma unroll
+                for (int k = 0; k < (1 << BIT); k++)
+                {
+                    const int e0 = (g << (BIT + 1)) | k;
+                    Field<FP>::bfly_inv(x[e0], x[e0 | (1 << BIT)], w, m);
+                }
+            }
+        }
+        // undo stages t = R-1 .. FIRST of a phase (FIRST = 1 leaves stage 0 to the caller)
+        template <bool FP, int R, int FIRST, class TwFn>
+        __device__ __forceinline__ void phase_inv(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
+        {
+            if constexpr (R >= 4 && FIRST <= 3)
+                stage_inv<FP, 0>(x, m, [&](int g) { return tw(3, g); });
+            if constexpr (R >= 3 && FIRST <= 2)
+                stage_inv<FP, 1>(x, m, [&](int g) { return tw(2, g); });
+            if constexpr (R >= 2 && FIRST <= 1)
+                stage_inv<FP, 2>(x, m, [&](int g) { return tw(1, g); });
+            if constexpr (R >= 1 && FIRST <= 0)
+                stage_inv<FP, 3>(x, m, [&](int g) { return tw(0, g); });
         }
 
         // The 15 twiddles of a 4-stage phase held in registers: slot (1<<t)+g.
@@ -208,7 +239,7 @@ namespace sealhip
         //   twa[t][u][g] (t<4, g<2^t) at twa[(16 << t) - 16 + (u << t) + g]
         //   twb[t][g][tid]            at twb[((256 << t) - 256) + g*256 + tid]
         // ---------------------------------------------------------------------------------------
-        template <bool FP, int D1, bool TW_LDS>
+        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false>
         __device__ __forceinline__ void p2_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const typename Field<FP>::tw_t *twa, const typename Field<FP>::tw_t *twb, uint64_t *lds_wave, unsigned hg, unsigned tid)
@@ -217,6 +248,16 @@ namespace sealhip
             const unsigned v = tid & 15, u = tid >> 4;
             const unsigned h = hg * 16 + u;
             const unsigned ul = u & 3; // row inside this wave's buffer
+            if constexpr (LOWREG && TW_LDS)
+            {
+                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
+            }
+            else if constexpr (LOWREG)
+            {
+                // register-lean variant: each twiddle is fetched where it is used
+                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tab[(1u << (D1 + t)) + (h << t) + g]; });
+            }
+            else
             {
                 TwRegs<FP> tw;
                 if constexpr (TW_LDS)
@@ -236,10 +277,26 @@ namespace sealhip
             for (int e = 0; e < 16; e++)
                 lds_wave[ul * kRowWords + e * 18 + v] = F::raw(x[e]);
             __builtin_amdgcn_wave_barrier();
+            {
+                const ulonglong2 *rp = reinterpret_cast<const ulonglong2 *>(lds_wave + ul * kRowWords + v * 18);
 #pragma unroll
-            for (int e = 0; e < 16; e++)
-                x[e] = F::unraw(lds_wave[ul * kRowWords + v * 18 + e]);
+                for (int e = 0; e < 8; e++)
+                {
+                    const ulonglong2 pr = rp[e];
+                    x[2 * e] = F::unraw(pr.x);
+                    x[2 * e + 1] = F::unraw(pr.y);
+                }
+            }
             __builtin_amdgcn_wave_barrier(); // the buffer may be rewritten by the caller's next tile
+            if constexpr (LOWREG && TW_LDS)
+            {
+                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return twb[((256u << t) - 256u) + g * 256 + tid]; });
+            }
+            else if constexpr (LOWREG)
+            {
+                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tab[(1u << (D1 + 4 + t)) + ((h * 16 + v) << t) + g]; });
+            }
+            else
             {
                 TwRegs<FP> tw;
                 if constexpr (TW_LDS)
@@ -398,6 +455,162 @@ namespace sealhip
         }
 
         // ---------------------------------------------------------------------------------------
+        // generic inverse transform kernels (bit-reversed order -> natural order, scaled by N^-1):
+        // pass A = the mirror of forward pass 2 (rows), pass B = the mirror of forward pass 1 (columns)
+        // ---------------------------------------------------------------------------------------
+        struct InvArgs
+        {
+            uint64_t *data;
+            size_t outer_stride;
+            const uint64_t *src; // natural-order input (= data when in place)
+            size_t src_outer_stride;
+            uint64_t *mid;
+            const uint32_t *comp_prime;
+            unsigned prime_first;
+            unsigned ncomp;
+            int lazy;
+            NttTables t;
+        };
+
+        template <bool FP, int D1>
+        __device__ __forceinline__ void inv_pa_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            const unsigned tid = threadIdx.x, hg = blockIdx.x;
+            const unsigned v = tid & 15, u = tid >> 4, ul = u & 3;
+            const unsigned h = hg * 16 + u;
+            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::tw_t *tab = tw_table<FP>(a.t, true, prime);
+            uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
+            uint64_t raw[16];
+            load_rows(raw, lds_wave, a.src + (size_t)outer * a.src_outer_stride + ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8), tid);
+            typename F::elem x[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                x[e] = F::from_canon(raw[e], m);
+                F::fix(x[e], m);
+            }
+            {
+                TwRegs<FP> tw;
+                load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
+                phase_inv<FP, 4, 0>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                F::fix(x[e], m);
+            // wave-local exchange: (v', e') -> (e, v)
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                lds_wave[ul * kRowWords + v * 18 + e] = F::raw(x[e]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                x[e] = F::unraw(lds_wave[ul * kRowWords + e * 18 + v]);
+            {
+                TwRegs<FP> tw;
+                load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + t)) + (h << t); });
+                phase_inv<FP, 4, 0>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                F::fix(x[e], m);
+            uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n) + ((size_t)hg << 12);
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                mid_tr[e * 256 + tid] = F::raw(x[e]);
+        }
+
+        template <int D1>
+        __global__ void __launch_bounds__(kThreads) ntt2_inv_pa(InvArgs a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y, outer = blockIdx.z;
+            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            if (a.t.fpd[prime].qi)
+                inv_pa_body<true, D1>(a, prime, comp, outer, lds);
+            else
+                inv_pa_body<false, D1>(a, prime, comp, outer, lds);
+        }
+
+        template <bool FP, int D1>
+        __device__ __forceinline__ void inv_pb_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            static_assert(G::rA >= 1, "the N^-1 stage is handled in phase A");
+            const unsigned tid = threadIdx.x, cg = blockIdx.x;
+            const unsigned c = tid & (G::C - 1), hi = tid >> G::LC;
+            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::tw_t *tab = tw_table<FP>(a.t, true, prime);
+            const unsigned col = cg * G::C + c;
+            const uint64_t *i = a.mid + (((size_t)outer * a.ncomp + comp) << G::n) + ((size_t)(hi * 16 + (col >> 4)) << 8) + (col & 15);
+            typename F::elem x[16];
+#pragma unroll
+            for (int rb = 0; rb < 16; rb++)
+                x[rb] = F::unraw(i[rb * 16]);
+            {
+                TwRegs<FP> tw;
+                load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (G::rA + t)) + (hi << t); });
+                phase_inv<FP, 4, 0>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                F::fix(x[e], m);
+#pragma unroll
+            for (int rb = 0; rb < 16; rb++)
+                lds[(hi * 16 + rb) * G::CP + c] = F::raw(x[rb]);
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                const unsigned R = ra * 16 + (rbh << G::rA) + hi;
+                x[e] = F::unraw(lds[R * G::CP + c]);
+            }
+            // phase A undone: stages rA-1 .. 1 with uniform twiddles, then stage 0 with N^-1 folded in
+            phase_inv<FP, G::rA, 1>(x, m, [&](int t, int g) { return tab[(1u << t) + g]; });
+            {
+                typename F::tw_t ni, nw;
+                if constexpr (FP)
+                {
+                    ni = a.t.ninv_d[2 * prime];
+                    nw = a.t.ninv_d[2 * prime + 1];
+                }
+                else
+                {
+                    ni = a.t.ninv[2 * prime];
+                    nw = a.t.ninv[2 * prime + 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    F::bfly_inv_last(x[k], x[k | 8], ni, nw, m);
+            }
+            uint64_t *o = a.data + (size_t)outer * a.outer_stride + ((size_t)comp << G::n);
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                F::fix(x[e], m);
+                const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                const unsigned R = ra * 16 + (rbh << G::rA) + hi;
+                o[(size_t)R * 256 + col] = a.lazy ? F::inv_to_lazy(x[e], m) : F::inv_to_canon(x[e], m);
+            }
+        }
+
+        template <int D1>
+        __global__ void __launch_bounds__(kThreads) ntt2_inv_pb(InvArgs a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y, outer = blockIdx.z;
+            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            if (a.t.fpd[prime].qi)
+                inv_pb_body<true, D1>(a, prime, comp, outer, lds);
+            else
+                inv_pb_body<false, D1>(a, prime, comp, outer, lds);
+        }
+
+        // ---------------------------------------------------------------------------------------
         // fused key switching, pass 1: one workgroup = (column tile cg, digit J, batch item b);
         // loops over the target moduli in `targets` (entries: slot I in the K+1 x K grid, pool prime).
         // ---------------------------------------------------------------------------------------
@@ -467,7 +680,7 @@ namespace sealhip
         };
 
         template <bool FP, int D1>
-        __global__ void __launch_bounds__(kThreads, FP ? 2 : 1) ks2_kernel(Ks2Args a)
+        __global__ void __launch_bounds__(kThreads, 2) ks2_kernel(Ks2Args a)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
@@ -521,25 +734,65 @@ namespace sealhip
             const typename F::key_t *key = reinterpret_cast<const typename F::key_t *>(a.key);
             const size_t N = (size_t)1 << G::n;
             const uint64_t *mid0 = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K) << G::n) + ((size_t)hg << 12) + tid;
-            for (unsigned J = 0; J < a.K; J++)
-            {
-                typename F::elem x[16];
-                if (a.target && I == J)
+            // diagonal digit (CKKS): NTT_J(INTT_J(target_J)) = target_J (evaluator.cpp:2682-2685); read the
+            // thread's 16 contiguous coefficients of row 16 hg + u straight from the input polynomial
+            const uint64_t *diag = a.target && I < a.K
+                                       ? a.target + (((size_t)b * a.K + I) << G::n) + ((size_t)hg << 12) + (size_t)tid * 16
+                                       : nullptr;
+            uint64_t nxt[16]; // digit J+1 is in flight while digit J is transformed
+            auto fetch = [&](unsigned J) {
+                if (diag && J == I)
                 {
-                    // NTT_J(INTT_J(target_J)) = target_J (evaluator.cpp:2682-2685)
-                    uint64_t raw[16];
-                    load_rows(raw, lds_wave, a.target + (((size_t)b * a.K + J) << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8), tid);
 #pragma unroll
                     for (int e = 0; e < 16; e++)
-                        x[e] = F::from_canon(raw[e], m);
+                        nxt[e] = diag[e];
                 }
                 else
                 {
                     const uint64_t *mp = mid0 + ((size_t)J << G::n);
 #pragma unroll
                     for (int e = 0; e < 16; e++)
-                        x[e] = F::unraw(mp[e * 256]);
-                    p2_tile<FP, D1, FP>(x, m, tab, twa, twb, lds_wave, hg, tid);
+                        nxt[e] = mp[e * 256];
+                }
+            };
+            if constexpr (FP)
+                fetch(0);
+            for (unsigned J = 0; J < a.K; J++)
+            {
+                typename F::elem x[16];
+                const bool is_diag = diag && J == I;
+                if constexpr (!FP)
+                    fetch(J); // the integer back end has no registers to spare for a prefetch
+                if (is_diag)
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = F::from_canon(nxt[e], m);
+                }
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = F::unraw(nxt[e]);
+                }
+                const typename F::key_t *k0 = key + (((size_t)J * 2 + 0) * a.L + kc) * N + ((size_t)hg << 12) + tid;
+                const typename F::key_t *k1 = k0 + (size_t)a.L * N;
+                typename F::key_t kr0[16], kr1[16];
+                if constexpr (FP)
+                {
+                    // the key words of this digit and the next digit travel while this digit is transformed
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                    {
+                        kr0[e] = k0[e * 256];
+                        kr1[e] = k1[e * 256];
+                    }
+                    if (J + 1 < a.K)
+                        fetch(J + 1);
+                }
+                if (!is_diag)
+                {
+                    p2_tile<FP, D1, FP, true>(x, m, tab, twa, twb, lds_wave, hg, tid);
                     if constexpr (!FP)
                     {
 #pragma unroll
@@ -547,13 +800,23 @@ namespace sealhip
                             x[e] = F::fwd_to_canon(x[e], m);
                     }
                 }
-                const typename F::key_t *k0 = key + (((size_t)J * 2 + 0) * a.L + kc) * N + ((size_t)hg << 12) + tid;
-                const typename F::key_t *k1 = k0 + (size_t)a.L * N;
-#pragma unroll
-                for (int e = 0; e < 16; e++)
+                if constexpr (FP)
                 {
-                    F::mac(acc0[e], x[e], k0[e * 256], m);
-                    F::mac(acc1[e], x[e], k1[e * 256], m);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                    {
+                        F::mac(acc0[e], x[e], kr0[e], m);
+                        F::mac(acc1[e], x[e], kr1[e], m);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                    {
+                        F::mac(acc0[e], x[e], k0[e * 256], m);
+                        F::mac(acc1[e], x[e], k1[e * 256], m);
+                    }
                 }
                 if ((J & 7) == 7)
                 {
@@ -607,6 +870,19 @@ namespace sealhip
             if (e != hipSuccess)
                 return e;
             hipLaunchKernelGGL(ntt2_fwd_p2<D1>, grid, dim3(kThreads), kLds2Words * 8, s, a);
+            return hipGetLastError();
+        }
+
+        template <int D1>
+        hipError_t launch_inv(const InvArgs &a, unsigned nouter, hipStream_t s)
+        {
+            typedef Geo<D1> G;
+            dim3 grid(G::TILES, a.ncomp, nouter);
+            hipLaunchKernelGGL(ntt2_inv_pa<D1>, grid, dim3(kThreads), kLds2Words * 8, s, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess)
+                return e;
+            hipLaunchKernelGGL(ntt2_inv_pb<D1>, grid, dim3(kThreads), G::lds1_words * 8, s, a);
             return hipGetLastError();
         }
 
@@ -665,7 +941,18 @@ namespace sealhip
         a.ncomp = b.ncomp;
         a.lazy = out_lazy;
         a.t = t;
-        const unsigned zmax = 65535;
+        // Work through the batch in chunks whose intermediate (ncomp * N words per outer item) stays
+        // resident in the 256 MiB Infinity Cache between pass 1 and pass 2.
+        unsigned zmax = 65535;
+        {
+            static const size_t chunk_bytes = std::getenv("SEALHIP_NTT_CHUNK_MB") ? (size_t)atol(std::getenv("SEALHIP_NTT_CHUNK_MB")) << 20 : 0;
+            if (chunk_bytes)
+            {
+                size_t per = ((size_t)b.ncomp << t.log_n) * 8;
+                size_t z = chunk_bytes / per;
+                zmax = (unsigned)(z < 1 ? 1 : (z > 65535 ? 65535 : z));
+            }
+        }
         for (unsigned z0 = 0; z0 < b.nouter; z0 += zmax)
         {
             unsigned nz = b.nouter - z0 < zmax ? b.nouter - z0 : zmax;
@@ -688,6 +975,53 @@ namespace sealhip
                 break;
             case 16:
                 e = launch_fwd<8>(az, nz, stream);
+                break;
+            default:
+                return hipErrorInvalidValue;
+            }
+            if (e != hipSuccess)
+                return e;
+        }
+        return hipSuccess;
+    }
+
+    hipError_t ntt2_inverse(const NttTables &t, const NttBatch &b, int out_lazy, uint64_t *mid, hipStream_t stream)
+    {
+        if (b.ncomp == 0 || b.nouter == 0)
+            return hipSuccess;
+        InvArgs a;
+        a.data = b.data;
+        a.outer_stride = b.outer_stride;
+        a.src = b.src ? b.src : b.data;
+        a.src_outer_stride = b.src ? b.src_outer_stride : b.outer_stride;
+        a.mid = mid;
+        a.comp_prime = b.comp_prime;
+        a.prime_first = b.prime_first;
+        a.ncomp = b.ncomp;
+        a.lazy = out_lazy;
+        a.t = t;
+        const unsigned zmax = 65535;
+        for (unsigned z0 = 0; z0 < b.nouter; z0 += zmax)
+        {
+            unsigned nz = b.nouter - z0 < zmax ? b.nouter - z0 : zmax;
+            InvArgs az = a;
+            az.data = a.data + (size_t)z0 * a.outer_stride;
+            az.src = a.src + (size_t)z0 * a.src_outer_stride;
+            az.mid = a.mid + (((size_t)z0 * a.ncomp) << t.log_n);
+            hipError_t e;
+            switch (t.log_n)
+            {
+            case 13:
+                e = launch_inv<5>(az, nz, stream);
+                break;
+            case 14:
+                e = launch_inv<6>(az, nz, stream);
+                break;
+            case 15:
+                e = launch_inv<7>(az, nz, stream);
+                break;
+            case 16:
+                e = launch_inv<8>(az, nz, stream);
                 break;
             default:
                 return hipErrorInvalidValue;

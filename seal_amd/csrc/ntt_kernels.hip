@@ -678,6 +678,13 @@ namespace sealhip
     }
     hipError_t ntt_inverse(const NttTables &t, const NttBatch &b, int out_lazy, hipStream_t stream)
     {
+        if (ntt2_supports(t.log_n))
+        {
+            Scratch mid(((size_t)b.nouter * b.ncomp) << t.log_n);
+            return ntt2_inverse(t, b, out_lazy, mid.p, stream);
+        }
+        if (b.src)
+            return hipErrorInvalidValue; // out-of-place input is a feature of the two-pass engine only
         return run(t, b, out_lazy, true, stream);
     }
 } // namespace sealhip

@@ -22,10 +22,11 @@ namespace sealhip
         size_t words() const { return ((size_t)batch * K) << n_log; }
     };
 
-    // x (size 2, in place -> size 3) *= y (size 2).  Planes are plane_words apart.
+    // out (size 3) = x (size 2) * y (size 2); out may be x (in place).  Planes are plane_words apart.
     // comp_prime (device, may be null = identity) maps a component to its pool prime.
     hipError_t k_ckks_multiply_2x2(
-        const ModDesc *mods, const uint32_t *comp_prime, uint64_t *x, const uint64_t *y, PlaneGeom g, hipStream_t s);
+        const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out, PlaneGeom g,
+        hipStream_t s);
     // out[I] = sum_a x[a] * y[I-a] for general sizes; out must not alias x or y.
     hipError_t k_multiply_general(
         const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, unsigned size_x, const uint64_t *y,

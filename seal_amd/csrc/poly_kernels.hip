@@ -29,8 +29,8 @@ namespace sealhip
         }
 
         __global__ void __launch_bounds__(kBlock) ckks_multiply_2x2_kernel(
-            const ModDesc *mods, const uint32_t *comp_prime, uint64_t *x, const uint64_t *y, unsigned n_log, unsigned K,
-            size_t plane_words)
+            const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out, unsigned n_log,
+            unsigned K, size_t plane_words)
         {
             for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < plane_words; i += (size_t)gridDim.x * kBlock)
             {
@@ -41,9 +41,9 @@ namespace sealhip
                 uint64_t lo = 0, hi = 0;
                 mac128(lo, hi, x0, y1);
                 mac128(lo, hi, x1, y0);
-                x[i] = mul_mod(x0, y0, md);
-                x[plane_words + i] = barrett128(lo, hi, md);
-                x[2 * plane_words + i] = mul_mod(x1, y1, md);
+                out[i] = mul_mod(x0, y0, md);
+                out[plane_words + i] = barrett128(lo, hi, md);
+                out[2 * plane_words + i] = mul_mod(x1, y1, md);
             }
         }
 
@@ -301,11 +301,12 @@ namespace sealhip
     } // namespace
 
     hipError_t k_ckks_multiply_2x2(
-        const ModDesc *mods, const uint32_t *comp_prime, uint64_t *x, const uint64_t *y, PlaneGeom g, hipStream_t s)
+        const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out, PlaneGeom g,
+        hipStream_t s)
     {
         size_t w = g.words();
         hipLaunchKernelGGL(
-            ckks_multiply_2x2_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, comp_prime, x, y, g.n_log, g.K, w);
+            ckks_multiply_2x2_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, comp_prime, x, y, out, g.n_log, g.K, w);
         return hipGetLastError();
     }
     hipError_t k_multiply_general(

@@ -32,6 +32,10 @@ struct dim3
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_)
     {}
 };
+struct alignas(16) ulonglong2
+{
+    unsigned long long x, y;
+};
 struct uint3_emu
 {
     unsigned x, y, z;
