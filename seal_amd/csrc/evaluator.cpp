@@ -812,7 +812,7 @@ namespace sealhip
         {
             NttBatch bi = plain_batch(acc.p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
             ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
-            Scratch tt((size_t)B * 2 * K * N);
+            Scratch tt(ntt2_supports(context_.log_n()) ? 1 : (size_t)B * 2 * K * N);
             NttBatch b{};
             b.data = tt.p;
             b.outer_stride = (size_t)K * N;
@@ -827,9 +827,25 @@ namespace sealhip
             b.src_half = P >> 1;
             b.src_q = P;
             b.src_fix = klvl.dev.round_fix;
-            ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction");
-            ck(k_keyswitch_tail_ckks(mods, klvl.dev.inv_q_last_mod_q, e.plane(0), e.plane(1), acc.p, tt.p, n_log, K, B, stream_),
-               "ks tail");
+            if (ntt2_supports(context_.log_n()))
+            {
+                // the tail is the epilogue of the transform: tt is never stored
+                b.data = nullptr;
+                b.epi = 2;
+                b.epi_a = acc.p;
+                b.epi_a_stride = (size_t)(K + 1) * N;
+                b.epi_mul = klvl.dev.inv_q_last_mod_q;
+                b.epi_out0 = e.plane(0);
+                b.epi_out1 = e.plane(1);
+                b.epi_out_stride = (size_t)K * N;
+                ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction + tail");
+            }
+            else
+            {
+                ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction");
+                ck(k_keyswitch_tail_ckks(mods, klvl.dev.inv_q_last_mod_q, e.plane(0), e.plane(1), acc.p, tt.p, n_log, K, B, stream_),
+                   "ks tail");
+            }
         }
         else
         {
@@ -886,7 +902,7 @@ namespace sealhip
                 const NttTables &tb = context_.ntt_tables();
                 uint64_t *last = e.data() + (size_t)(K - 1) * N;
                 ck(ntt_inverse(tb, plain_batch(last, (size_t)K * N, 1, (unsigned)items, K - 1), 0, stream_), "rescale intt last");
-                Scratch tt(words);
+                Scratch tt(ntt2_supports(context_.log_n()) ? 1 : words);
                 NttBatch b{};
                 b.data = tt.p;
                 b.outer_stride = (size_t)(K - 1) * N;
@@ -901,8 +917,23 @@ namespace sealhip
                 b.src_half = lvl.dev.half_q_last;
                 b.src_q = lvl.dev.q_last;
                 b.src_fix = lvl.dev.round_fix;
-                ck(ntt_forward(tb, b, 1, stream_), "rescale ntt correction");
-                ck(k_rescale_combine(mods, lvl.dev.inv_q_last_mod_q, e.data(), tt.p, out, n_log, K, items, stream_), "rescale combine");
+                if (ntt2_supports(context_.log_n()))
+                {
+                    b.data = nullptr;
+                    b.epi = 1;
+                    b.epi_a = e.data();
+                    b.epi_a_stride = (size_t)K * N;
+                    b.epi_mul = lvl.dev.inv_q_last_mod_q;
+                    b.epi_out0 = out;
+                    b.epi_out1 = nullptr;
+                    b.epi_out_stride = (size_t)(K - 1) * N;
+                    ck(ntt_forward(tb, b, 1, stream_), "rescale ntt correction + combine");
+                }
+                else
+                {
+                    ck(ntt_forward(tb, b, 1, stream_), "rescale ntt correction");
+                    ck(k_rescale_combine(mods, lvl.dev.inv_q_last_mod_q, e.data(), tt.p, out, n_log, K, items, stream_), "rescale combine");
+                }
             }
         }
         catch (...)

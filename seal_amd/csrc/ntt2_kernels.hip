@@ -336,6 +336,23 @@ namespace sealhip
                 rows[row * 256 + col] = lds_wave[row * kRowWords + col + 2 * (col >> 4)];
             }
         }
+        // the same transposition, handing each coalesced (offset, value) pair to `sink`
+        template <class Sink>
+        __device__ __forceinline__ void emit_rows(const uint64_t (&val)[16], uint64_t *lds_wave, unsigned tid, Sink sink)
+        {
+            const unsigned v = tid & 15, ul = (tid >> 4) & 3, lane = tid & 63;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                lds_wave[ul * kRowWords + v * 18 + e] = val[e];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+            {
+                const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
+                sink(row * 256 + col, lds_wave[row * kRowWords + col + 2 * (col >> 4)]);
+            }
+        }
         __device__ __forceinline__ void load_rows(uint64_t (&val)[16], uint64_t *lds_wave, const uint64_t *rows, unsigned tid)
         {
             const unsigned v = tid & 15, ul = (tid >> 4) & 3, lane = tid & 63;
@@ -371,6 +388,12 @@ namespace sealhip
             unsigned prime_first;
             unsigned ncomp;
             int lazy;
+            int epi;
+            const uint64_t *epi_a;
+            size_t epi_a_stride;
+            const ShoupOp *epi_mul;
+            uint64_t *epi_out0, *epi_out1;
+            size_t epi_out_stride;
             NttTables t;
         };
 
@@ -435,11 +458,36 @@ namespace sealhip
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             p2_tile<FP, D1, false>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
             uint64_t val[16];
+            const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+            if (a.epi == 0)
+            {
 #pragma unroll
-            for (int e = 0; e < 16; e++)
-                val[e] = a.lazy ? F::fwd_to_lazy(x[e], m) : F::fwd_to_canon(x[e], m);
-            uint64_t *rows = a.data + (size_t)outer * a.outer_stride + ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
-            store_rows(val, lds_wave, rows, tid);
+                for (int e = 0; e < 16; e++)
+                    val[e] = a.lazy ? F::fwd_to_lazy(x[e], m) : F::fwd_to_canon(x[e], m);
+                store_rows(val, lds_wave, a.data + (size_t)outer * a.outer_stride + row0, tid);
+            }
+            else
+            {
+                // fused tail: the transform is consumed here and never stored
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    val[e] = F::fwd_to_lazy(x[e], m); // < 4q
+                const uint64_t q = a.t.mods[prime].q;
+                const ShoupOp mul = a.epi_mul[comp];
+                const uint64_t *A = a.epi_a + (size_t)outer * a.epi_a_stride + row0;
+                if (a.epi == 1)
+                {
+                    uint64_t *O = a.epi_out0 + (size_t)outer * a.epi_out_stride + row0;
+                    emit_rows(val, lds_wave, tid, [&](unsigned off, uint64_t tv) { O[off] = mul_shoup(A[off] + 4 * q - tv, mul.w, mul.wq, q); });
+                }
+                else
+                {
+                    uint64_t *O = ((outer & 1) ? a.epi_out1 : a.epi_out0) + (size_t)(outer >> 1) * a.epi_out_stride + row0;
+                    emit_rows(val, lds_wave, tid, [&](unsigned off, uint64_t tv) {
+                        O[off] = add_mod(O[off], mul_shoup(A[off] + 4 * q - tv, mul.w, mul.wq, q), q);
+                    });
+                }
+            }
         }
 
         template <int D1>
@@ -940,6 +988,13 @@ namespace sealhip
         a.prime_first = b.prime_first;
         a.ncomp = b.ncomp;
         a.lazy = out_lazy;
+        a.epi = b.epi;
+        a.epi_a = b.epi_a;
+        a.epi_a_stride = b.epi_a_stride;
+        a.epi_mul = b.epi_mul;
+        a.epi_out0 = b.epi_out0;
+        a.epi_out1 = b.epi_out1;
+        a.epi_out_stride = b.epi_out_stride;
         a.t = t;
         // Work through the batch in chunks whose intermediate (ncomp * N words per outer item) stays
         // resident in the 256 MiB Infinity Cache between pass 1 and pass 2.
@@ -957,10 +1012,20 @@ namespace sealhip
         {
             unsigned nz = b.nouter - z0 < zmax ? b.nouter - z0 : zmax;
             FwdArgs az = a;
-            az.data = a.data + (size_t)z0 * a.outer_stride;
+            az.data = a.data ? a.data + (size_t)z0 * a.outer_stride : nullptr;
             az.mid = a.mid + (((size_t)z0 * a.ncomp) << t.log_n);
             if (az.src)
                 az.src = a.src + (size_t)z0 * a.src_outer_stride;
+            if (a.epi)
+            {
+                if (z0 & 1)
+                    return hipErrorInvalidValue;
+                az.epi_a = a.epi_a + (size_t)z0 * a.epi_a_stride;
+                const size_t zo = a.epi == 2 ? z0 >> 1 : z0;
+                az.epi_out0 = a.epi_out0 + zo * a.epi_out_stride;
+                if (a.epi_out1)
+                    az.epi_out1 = a.epi_out1 + zo * a.epi_out_stride;
+            }
             hipError_t e;
             switch (t.log_n)
             {

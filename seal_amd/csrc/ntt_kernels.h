@@ -56,6 +56,19 @@ namespace sealhip
         uint64_t src_half;
         uint64_t src_q;
         const uint64_t *src_fix; // [ncomp], device
+        // Optional fused epilogue of the forward transform (two-pass engine only): instead of storing
+        // the transform T to `data`, combine it with a resident operand and store the result,
+        //   v = (A[outer][comp] - T) * mul[comp]  mod q                        (A canonical)
+        //   epi 1: out[outer][comp] = v                      rescale tail, rns.cpp:890-899
+        //   epi 2: ct_{outer&1}[outer>>1][comp] += v         key-switch tail, evaluator.cpp:2845-2863
+        // A = epi_a + outer*epi_a_stride + comp*N; epi 1 writes epi_out0 + outer*epi_out_stride + comp*N,
+        // epi 2 updates epi_out{0,1} + (outer>>1)*epi_out_stride + comp*N.
+        int epi;
+        const uint64_t *epi_a;
+        size_t epi_a_stride;
+        const ShoupOp *epi_mul; // [ncomp]
+        uint64_t *epi_out0, *epi_out1;
+        size_t epi_out_stride;
     };
 
     // out_range: 0 = canonical [0,q); 1 = lazy ([0,4q) forward / [0,2q) inverse).

@@ -668,6 +668,8 @@ namespace sealhip
 
     hipError_t ntt_forward(const NttTables &t, const NttBatch &b, int out_lazy, hipStream_t stream)
     {
+        if (b.epi && !ntt2_supports(t.log_n))
+            return hipErrorInvalidValue;
         if (ntt2_supports(t.log_n))
         {
             // two-pass engine; the scratch block goes back to the pool in stream order
