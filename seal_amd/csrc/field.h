@@ -112,27 +112,48 @@ namespace sealhip
         {
             return barrett64(x, m.md);
         }
+        // x*w - floor(x*wq / 2^64)*q in 32-bit limbs, written so that it compiles to 8 + 8 VALU
+        // instructions: the quotient word h = hi64(x*wq), then the low 64 bits of x*w + h*(-q) as one
+        // v_mad_u64_u32 chain for the low limbs and four v_mul_lo_u32 feeding two v_add3_u32 for the
+        // high limb (no carry chain, no separate subtraction).  Result in [0,2q) for any 64-bit x.
+        static SHL_HD uint64_t mul_lazy(uint64_t x, const tw_t &w, const Mod &m)
+        {
+            const uint64_t h = mul_hi64(x, w.wq);
+            const uint64_t nq = 0 - m.q;
+            const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w.w, w1 = (uint32_t)(w.w >> 32);
+            const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32), n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
+            uint64_t lo = (uint64_t)x0 * w0;
+            lo += (uint64_t)h0 * n0;
+            const uint32_t hi = (uint32_t)(lo >> 32) + x0 * w1 + x1 * w0 + h0 * n1 + h1 * n0;
+            return ((uint64_t)hi << 32) | (uint32_t)lo;
+        }
+        // [0,4q) -> [0,2q) without a carry chain: the sign of x - 2q selects
+        static SHL_HD uint64_t guard(uint64_t x, const Mod &m)
+        {
+            const uint64_t d = x - m.two_q;
+            return (int64_t)d < 0 ? x : d;
+        }
         // X,Y in [0,4q) -> [0,4q)   (Arithmetic<>::guard/add/sub/mul_root, ntt.h:30-61)
         static SHL_HD void bfly_fwd(elem &X, elem &Y, const tw_t &w, const Mod &m)
         {
-            uint64_t x = X >= m.two_q ? X - m.two_q : X;
-            uint64_t t = mul_shoup_lazy(Y, w.w, w.wq, m.q);
+            uint64_t x = guard(X, m);
+            uint64_t t = mul_lazy(Y, w, m);
             X = x + t;
-            Y = x - t + m.two_q;
+            Y = x + m.two_q - t;
         }
         // X,Y in [0,2q) -> [0,2q)   (dwthandler.h:202-356)
         static SHL_HD void bfly_inv(elem &X, elem &Y, const tw_t &w, const Mod &m)
         {
-            uint64_t s = X + Y, d = X - Y + m.two_q;
-            X = s >= m.two_q ? s - m.two_q : s;
-            Y = mul_shoup_lazy(d, w.w, w.wq, m.q);
+            uint64_t s = X + Y, d = X + m.two_q - Y;
+            X = guard(s, m);
+            Y = mul_lazy(d, w, m);
         }
         // last inverse stage with N^-1 folded in (dwthandler.h:273-314): ni = N^-1, nw = N^-1 * w
         static SHL_HD void bfly_inv_last(elem &X, elem &Y, const tw_t &ni, const tw_t &nw, const Mod &m)
         {
-            uint64_t s = X + Y, d = X - Y + m.two_q;
-            X = mul_shoup_lazy(s, ni.w, ni.wq, m.q);
-            Y = mul_shoup_lazy(d, nw.w, nw.wq, m.q);
+            uint64_t s = X + Y, d = X + m.two_q - Y;
+            X = mul_lazy(s, ni, m);
+            Y = mul_lazy(d, nw, m);
         }
         static SHL_HD void fix(elem &, const Mod &)
         {}

@@ -179,13 +179,20 @@ namespace sealhip
             return x;
         }
 
+        template <bool FP, int D1>
+        __device__ __forceinline__ void p1_load_tw(TwRegs<FP> &tw, const typename Field<FP>::tw_t *tab, unsigned tid)
+        {
+            const unsigned hi = tid >> Geo<D1>::LC;
+            load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (Geo<D1>::rA + t)) + (hi << t); });
+        }
+
         // ---------------------------------------------------------------------------------------
         // pass 1 body: src (natural order, column tile cg) -> D1 stages -> mid (tile order)
         // ---------------------------------------------------------------------------------------
         template <bool FP, int D1>
         __device__ __forceinline__ void p1_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
-            uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
+            const TwRegs<FP> &tw, uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
@@ -215,8 +222,7 @@ namespace sealhip
                     x[rb] = F::unraw(lds[(hi * 16 + rb) * G::CP + c]);
             }
             // phase B: thread (c, ra = hi); register rb; stage rA+t pairs rb bit 3-t; twiddle 2^(rA+t) + ra*2^t + group
-            TwRegs<FP> tw;
-            load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (G::rA + t)) + (hi << t); });
+            // (tw = p1_load_tw(), loop-invariant for callers that transform many tiles with one prime)
             phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             if constexpr (FP)
             {
@@ -387,6 +393,7 @@ namespace sealhip
             const uint32_t *comp_prime;
             unsigned prime_first;
             unsigned ncomp;
+            unsigned nouter;  // outer items; a workgroup handles z, z + gridDim.z, ... (twiddles stay in registers)
             int lazy;
             int epi;
             const uint64_t *epi_a;
@@ -405,29 +412,50 @@ namespace sealhip
             const unsigned tid = threadIdx.x, cg = blockIdx.x;
             const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
-            const uint64_t *in;
             SrcMap sm{ 0, 0, 0, 0 };
+            const uint64_t *in0;
+            size_t in_stride;
             if (a.src)
             {
-                in = a.src + (size_t)outer * a.src_outer_stride + ((size_t)(comp % a.src_ncomp) << G::n);
+                in0 = a.src + ((size_t)(comp % a.src_ncomp) << G::n);
+                in_stride = a.src_outer_stride;
                 sm.mode = a.src_mode;
                 sm.half = a.src_half;
                 sm.src_q = a.src_q;
                 sm.fix = a.src_mode == 2 ? a.src_fix[comp] : 0;
             }
             else
-                in = a.data + (size_t)outer * a.outer_stride + ((size_t)comp << G::n);
-            const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
-            typename F::elem x[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++)
             {
-                const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
-                const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
-                x[e] = map_src<FP>(in[(size_t)R * 256 + cg * G::C + c], sm, m);
+                in0 = a.data + ((size_t)comp << G::n);
+                in_stride = a.outer_stride;
             }
-            uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
-            p1_tile<FP, D1>(x, m, tab, lds, mid_tr, cg, tid);
+            const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
+            in0 += cg * G::C + c;
+            TwRegs<FP> tw;
+            p1_load_tw<FP, D1>(tw, tab, tid);
+            uint64_t nxt[16];
+            auto fetch = [&](unsigned z) {
+                const uint64_t *in = in0 + (size_t)z * in_stride;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+                    nxt[e] = in[(size_t)R * 256];
+                }
+            };
+            fetch(outer);
+            for (; outer < a.nouter; outer += gridDim.z)
+            {
+                typename F::elem x[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    x[e] = map_src<FP>(nxt[e], sm, m);
+                if (outer + gridDim.z < a.nouter)
+                    fetch(outer + gridDim.z);
+                uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
+                p1_tile<FP, D1>(x, m, tab, tw, lds, mid_tr, cg, tid);
+            }
         }
 
         template <int D1>
@@ -450,12 +478,24 @@ namespace sealhip
             const unsigned tid = threadIdx.x, hg = blockIdx.x;
             const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
-            const uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n) + ((size_t)hg << 12);
+            const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + tid;
+            uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
+            uint64_t nxt[16];
+            auto fetch = [&](unsigned z) {
+                const uint64_t *mp = mid0 + (((size_t)z * a.ncomp) << G::n);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    nxt[e] = mp[e * 256];
+            };
+            fetch(outer);
+            for (; outer < a.nouter; outer += gridDim.z)
+            {
             typename F::elem x[16];
 #pragma unroll
             for (int e = 0; e < 16; e++)
-                x[e] = F::unraw(mid_tr[e * 256 + tid]);
-            uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
+                x[e] = F::unraw(nxt[e]);
+            if (outer + gridDim.z < a.nouter)
+                fetch(outer + gridDim.z);
             p2_tile<FP, D1, false>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
             uint64_t val[16];
             const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
@@ -487,6 +527,7 @@ namespace sealhip
                         O[off] = add_mod(O[off], mul_shoup(A[off] + 4 * q - tv, mul.w, mul.wq, q), q);
                     });
                 }
+            }
             }
         }
 
@@ -669,6 +710,7 @@ namespace sealhip
             const uint32_t *targets; // [ntargets] pairs (I, prime)
             unsigned ntargets;
             unsigned K;
+            unsigned batch;
             int skip_diag;       // CKKS: (I == J) is the input itself, not transformed
             NttTables tb;
         };
@@ -679,30 +721,86 @@ namespace sealhip
             typedef Field<FP> F;
             typedef Geo<D1> G;
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned tid = threadIdx.x, cg = blockIdx.x, J = blockIdx.y, b = blockIdx.z;
+            const unsigned tid = threadIdx.x;
+            // one workgroup = (column tile cg, target modulus, batch item), looping over the digits J:
+            // the modulus constants and all twiddles are loop-invariant, the next digit is prefetched.
+            // Blocks that share (b, cg) - they read the same digit tiles - sit on one XCD (blockIdx % 8).
+            const unsigned bid = blockIdx.x;
+            const unsigned low = bid & 7, rest = bid >> 3;
+            const unsigned it = rest % a.ntargets, grp = (rest / a.ntargets) * 8 + low; // grp = b*TILES + cg
+            if (grp >= a.batch * G::TILES)
+                return;
+            const unsigned b = grp / G::TILES, cg = grp % G::TILES;
+            const unsigned I = a.targets[2 * it], prime = a.targets[2 * it + 1];
+            const typename F::Mod m = F::make_mod(a.tb.mods[prime], a.tb.fpd[prime]);
+            const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
+            TwRegs<FP> tw;
+            p1_load_tw<FP, D1>(tw, tab, tid);
             const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
-            const uint64_t *in = a.t + (((size_t)b * a.K + J) << G::n);
-            uint64_t src[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++)
-            {
-                const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
-                const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
-                src[e] = in[(size_t)R * 256 + cg * G::C + c];
-            }
-            for (unsigned it = 0; it < a.ntargets; it++)
-            {
-                const unsigned I = a.targets[2 * it], prime = a.targets[2 * it + 1];
-                if (a.skip_diag && I == J)
-                    continue;
-                const typename F::Mod m = F::make_mod(a.tb.mods[prime], a.tb.fpd[prime]);
-                const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
-                typename F::elem x[16];
+            // thread's 16 source words of digit J: rows R(e), column cg*C + c
+            const uint64_t *in0 = a.t + (((size_t)b * a.K) << G::n) + cg * G::C + c;
+            uint64_t nxt[16];
+            auto fetch = [&](unsigned J) {
+                const uint64_t *in = in0 + ((size_t)J << G::n);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    x[e] = F::from_any(src[e], m);
+                {
+                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+                    nxt[e] = in[(size_t)R * 256];
+                }
+            };
+            const unsigned Jskip = a.skip_diag ? I : ~0u;
+            unsigned J = Jskip == 0 ? 1 : 0;
+            if (J < a.K)
+                fetch(J);
+            while (J < a.K)
+            {
+                const uint64_t src_q = a.tb.mods[J].q; // digit J is a residue modulo data prime J
+                typename F::elem x[16];
+                if constexpr (FP)
+                {
+                    if (src_q >> 52)
+                    {
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            x[e] = F::from_any(nxt[e], m);
+                    }
+                    else
+                    {
+                        // digit below 2^52: exact as a double, one fix() brings it under q_I / 2
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                        {
+                            x[e] = fp_from_u52(nxt[e]);
+                            F::fix(x[e], m);
+                        }
+                    }
+                }
+                else
+                {
+                    if (src_q < 4 * m.q)
+                    {
+                        // already inside the butterflies' lazy input range [0, 4 q_I)
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            x[e] = nxt[e];
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            x[e] = F::from_any(nxt[e], m);
+                    }
+                }
+                unsigned Jn = J + 1;
+                if (Jn == Jskip)
+                    Jn++;
+                if (Jn < a.K)
+                    fetch(Jn);
                 uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
-                p1_tile<FP, D1>(x, m, tab, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                J = Jn;
             }
         }
 
@@ -911,7 +1009,15 @@ namespace sealhip
         hipError_t launch_fwd(const FwdArgs &a, unsigned nouter, hipStream_t s)
         {
             typedef Geo<D1> G;
-            dim3 grid(G::TILES, a.ncomp, nouter);
+            // enough workgroups to fill the chip several times over, each looping over its share of
+            // the outer items with the next tile in flight
+            unsigned per = G::TILES * a.ncomp;
+            unsigned chunks = (4096 + per - 1) / per;
+            if (chunks > nouter)
+                chunks = nouter;
+            if (chunks > 65535)
+                chunks = 65535;
+            dim3 grid(G::TILES, a.ncomp, chunks);
             size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
             hipLaunchKernelGGL(ntt2_fwd_p1<D1>, grid, dim3(kThreads), l1, s, a);
             hipError_t e = hipGetLastError();
@@ -941,7 +1047,8 @@ namespace sealhip
             if (a1.ntargets == 0)
                 return hipSuccess;
             size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
-            hipLaunchKernelGGL((ks1_kernel<FP, D1>), dim3(G::TILES, a1.K, batch), dim3(kThreads), l1, s, a1);
+            const unsigned groups = batch * G::TILES;
+            hipLaunchKernelGGL((ks1_kernel<FP, D1>), dim3(((groups + 7) / 8) * a1.ntargets * 8), dim3(kThreads), l1, s, a1);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess)
                 return e;
@@ -987,6 +1094,7 @@ namespace sealhip
         a.comp_prime = b.comp_prime;
         a.prime_first = b.prime_first;
         a.ncomp = b.ncomp;
+        a.nouter = b.nouter;
         a.lazy = out_lazy;
         a.epi = b.epi;
         a.epi_a = b.epi_a;
@@ -996,58 +1104,19 @@ namespace sealhip
         a.epi_out1 = b.epi_out1;
         a.epi_out_stride = b.epi_out_stride;
         a.t = t;
-        // Work through the batch in chunks whose intermediate (ncomp * N words per outer item) stays
-        // resident in the 256 MiB Infinity Cache between pass 1 and pass 2.
-        unsigned zmax = 65535;
+        switch (t.log_n)
         {
-            static const size_t chunk_bytes = std::getenv("SEALHIP_NTT_CHUNK_MB") ? (size_t)atol(std::getenv("SEALHIP_NTT_CHUNK_MB")) << 20 : 0;
-            if (chunk_bytes)
-            {
-                size_t per = ((size_t)b.ncomp << t.log_n) * 8;
-                size_t z = chunk_bytes / per;
-                zmax = (unsigned)(z < 1 ? 1 : (z > 65535 ? 65535 : z));
-            }
+        case 13:
+            return launch_fwd<5>(a, b.nouter, stream);
+        case 14:
+            return launch_fwd<6>(a, b.nouter, stream);
+        case 15:
+            return launch_fwd<7>(a, b.nouter, stream);
+        case 16:
+            return launch_fwd<8>(a, b.nouter, stream);
+        default:
+            return hipErrorInvalidValue;
         }
-        for (unsigned z0 = 0; z0 < b.nouter; z0 += zmax)
-        {
-            unsigned nz = b.nouter - z0 < zmax ? b.nouter - z0 : zmax;
-            FwdArgs az = a;
-            az.data = a.data ? a.data + (size_t)z0 * a.outer_stride : nullptr;
-            az.mid = a.mid + (((size_t)z0 * a.ncomp) << t.log_n);
-            if (az.src)
-                az.src = a.src + (size_t)z0 * a.src_outer_stride;
-            if (a.epi)
-            {
-                if (z0 & 1)
-                    return hipErrorInvalidValue;
-                az.epi_a = a.epi_a + (size_t)z0 * a.epi_a_stride;
-                const size_t zo = a.epi == 2 ? z0 >> 1 : z0;
-                az.epi_out0 = a.epi_out0 + zo * a.epi_out_stride;
-                if (a.epi_out1)
-                    az.epi_out1 = a.epi_out1 + zo * a.epi_out_stride;
-            }
-            hipError_t e;
-            switch (t.log_n)
-            {
-            case 13:
-                e = launch_fwd<5>(az, nz, stream);
-                break;
-            case 14:
-                e = launch_fwd<6>(az, nz, stream);
-                break;
-            case 15:
-                e = launch_fwd<7>(az, nz, stream);
-                break;
-            case 16:
-                e = launch_fwd<8>(az, nz, stream);
-                break;
-            default:
-                return hipErrorInvalidValue;
-            }
-            if (e != hipSuccess)
-                return e;
-        }
-        return hipSuccess;
     }
 
     hipError_t ntt2_inverse(const NttTables &t, const NttBatch &b, int out_lazy, uint64_t *mid, hipStream_t stream)
@@ -1107,6 +1176,7 @@ namespace sealhip
             a1.targets = fp ? k.targets1_fp : k.targets1_int;
             a1.ntargets = fp ? k.n_fp : k.n_int;
             a1.K = k.K;
+            a1.batch = k.batch;
             a1.skip_diag = k.target_ntt != nullptr;
             a1.tb = t;
             Ks2Args a2;
