@@ -68,6 +68,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     import seal_amd as S
+    from seal_amd import shard
 
     n, B = N_POLY, args.batch
     primes = S.CoeffModulus.Create(n, BITS)
@@ -107,29 +108,12 @@ def main():
         ev.relinearize_inplace(work, rlk)
         ev.rescale_to_next_inplace(work)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     result = {}
     if not args.ntt_only:
-        for _ in range(args.warmup):
-            step()
-        sync_all()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        elapsed = shard.timed_steps(step, args.steps, args.warmup, dist if world > 1 else None, torch.cuda.synchronize, torch, device)
         assert work.size() == 2 and work.coeff_modulus_size() == K - 1
-        total_ct = B * world * args.steps
-        result = dict(value=total_ct / elapsed, ms_per_step=1e3 * elapsed / args.steps)
+        rate = shard.whole_job_rate(B, args.steps, elapsed, dist if world > 1 else None, torch, device)
+        result = dict(value=rate, ms_per_step=1e3 * elapsed / args.steps)
 
     # ---- roofline leg: the batched forward NTT over the resident batch (2*B polys x K comps)
     roofline = None
@@ -156,7 +140,7 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = dict(bound="hbm", kernel="ntt_forward (column pass + row pass), %d transforms of 2^16 per launch" % (K * polys),
+        roofline = dict(bound="hbm", kernel="ntt_forward = ntt2_fwd_p1 + ntt2_fwd_p2 (two-pass engine), %d transforms of 2^16 per launch" % (K * polys),
                         achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
                         traffic=traffic, ms_per_launch=round(ms, 4), algorithmic_bytes_per_launch=alg_bytes)
         assert buf_words == 2 * B * K * n

@@ -263,6 +263,25 @@ extern "C"
         }
         REF_CATCH
     }
+    // Overwrite the words of an existing key (same layout as ref_key_copy) with caller-supplied residues:
+    // lets a test use a seeded synthetic key, so that golden fixtures need not store key material.
+    int ref_key_set(void *ctx, int kind, uint64_t index, const uint64_t *in)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        KSwitchKeys &k = kind == 0 ? static_cast<KSwitchKeys &>(c->rlk) : static_cast<KSwitchKeys &>(c->glk);
+        if (index >= k.data().size())
+            return 3;
+        auto &vec = k.data()[index];
+        for (size_t j = 0; j < vec.size(); j++)
+        {
+            Ciphertext &kc = vec[j].data();
+            size_t words = kc.size() * kc.coeff_modulus_size() * kc.poly_modulus_degree();
+            std::memcpy(kc.data(), in, words * sizeof(uint64_t));
+            in += words;
+        }
+        REF_CATCH
+    }
     uint64_t ref_galois_elt_from_step(void *ctx, int step)
     {
         auto c = static_cast<RefCtx *>(ctx);

@@ -1,0 +1,64 @@
+"""Worker of tests/test_dist_gloo.py: one rank of a world_size-2 gloo job running the sharded
+pipeline on the fiber-emulated library (CPU).  Every rank builds the same seeded global batch, processes
+its shard (seal_amd.shard.split) and rank 0 checks the gathered results against the oracle."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    import seal_amd as S
+    from seal_amd import shard
+    import parity_cases as P
+    from harness import DeviceSide
+    from oracle import Oracle, coeff_modulus_create, rand_ct
+
+    S.load(os.path.join(HERE, "hipemu", "libsealhip_emu.so"))
+    rank, world, _ = shard.env_world()
+    dist.init_process_group(backend="gloo")
+    n, bits, total = 64, [40, 30, 30, 40], 5
+    primes = coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    o = Oracle("ckks", n, primes)
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(0x5EA1)  # same global batch on every rank
+    xs = [rand_ct(rng, primes, K, n) for _ in range(total)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(total)]
+    start, count = shard.split(total, world, rank)
+    assert count >= 1
+    cx, cy = d.ct(xs[start:start + count], scale=2.0 ** 10), d.ct(ys[start:start + count], scale=2.0 ** 10)
+    work = S.Ciphertext(d.ctx, batch=count)
+
+    def step():
+        d.ev.multiply(cx, cy, work)
+        d.ev.relinearize_inplace(work, d.rlk)
+        work.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+        d.ev.rescale_to_next_inplace(work)
+
+    elapsed = shard.timed_steps(step, 2, 1, dist, lambda: None, torch, torch.device("cpu"))
+    rate = shard.whole_job_rate(count, 2, elapsed, dist, torch, torch.device("cpu"))
+    mine = [(start + i, a) for i, a in enumerate(d.out(work))]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if rank == 0:
+        got = dict(kv for part in gathered for kv in part)
+        assert sorted(got) == list(range(total)), sorted(got)
+        for i in range(total):
+            exp = o.rescale(o.relinearize(o.multiply(xs[i], ys[i])))
+            assert np.array_equal(got[i], exp), "item %d differs from the oracle" % i
+        assert rate > 0 and elapsed > 0
+        print("DIST_OK world=%d items=%d rate=%.1f" % (world, total, rate), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

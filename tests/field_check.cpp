@@ -1,0 +1,79 @@
+// TEST ONLY: exactness and range checks of the double-precision residue arithmetic of
+// seal_amd/csrc/field.h against 128-bit integer arithmetic (built with g++ against the emulator's
+// stand-in hip_runtime.h; the same source the kernels include).
+#include "field.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+using namespace sealhip;
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+static int fails = 0;
+#define EXPECT(c, ...) do { if (!(c)) { if (fails < 10) { printf("FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } fails++; } } while (0)
+
+static uint64_t canon(i128 v, uint64_t q)
+{
+    i128 r = v % (i128)q;
+    if (r < 0) r += q;
+    return (uint64_t)r;
+}
+
+int main()
+{
+    std::mt19937_64 rng(0x5EA1);
+    // primes = 1 (mod 2^17) just under each bit size (primality is irrelevant to the arithmetic identities)
+    const uint64_t qs[] = { (1ull << 50) - (1ull << 17) * 3 + 1, (1ull << 49) + (1ull << 17) + 1, (1ull << 40) + (1ull << 17) * 7 + 1,
+                            (1ull << 30) - (1ull << 17) + 1, (1ull << 20) + 1, 1125899906826241ull, 1125899906629633ull };
+    for (uint64_t q : qs)
+    {
+        FpDesc m{ (double)q, 1.0 / (double)q, (double)((1ull << 32) % q), q };
+        const double qd = (double)q;
+        for (int it = 0; it < 400000; it++)
+        {
+            // x: signed, magnitude up to 8q (the largest the kernels feed a multiplication); w in [0,q)
+            uint64_t w = rng() % q;
+            int64_t x;
+            switch (it & 7)
+            {
+            case 0: x = (int64_t)(rng() % q); break;
+            case 1: x = -(int64_t)(rng() % q); break;
+            case 2: x = (int64_t)(8 * q - 1 - (rng() & 1023)); break;
+            case 3: x = -(int64_t)(8 * q - 1 - (rng() & 1023)); break;
+            case 4: x = (int64_t)(q / 2 + (rng() & 3)); break;
+            case 5: w = q - 1 - (rng() & 3); x = (int64_t)(8 * q - 1); break;
+            default: x = (int64_t)(rng() % (8 * q)) - (int64_t)(4 * q); break;
+            }
+            if ((u128)(x < 0 ? -x : x) >= ((u128)1 << 53))
+                continue;
+            double r = fp_mulmod((double)x, (double)w, m.q, m.qinv);
+            EXPECT(r == std::floor(r), "mulmod result not an integer");
+            EXPECT(canon((i128)r, q) == canon((i128)x * (i128)w, q), "mulmod residue q=%llu x=%lld w=%llu", (unsigned long long)q, (long long)x, (unsigned long long)w);
+            double bound = qd * (0.5 + 3.0 * std::ldexp(std::fabs((double)x) * ((double)w / qd), -53)) + 2.0;
+            EXPECT(std::fabs(r) <= bound, "mulmod magnitude %.1f > %.1f", std::fabs(r), bound);
+            // fix(): any |v| < 2^53 -> |result| <= q/2 + small, same residue
+            int64_t v = (int64_t)(rng() >> 11) * ((rng() & 1) ? 1 : -1);
+            double f = fp_fix((double)v, m.q, m.qinv);
+            EXPECT(canon((i128)f, q) == canon((i128)v, q), "fix residue");
+            EXPECT(std::fabs(f) <= qd / 2 + qd * std::ldexp(1.0, -40) + 1.0, "fix magnitude");
+            // conversions
+            uint64_t c = rng() % q;
+            EXPECT(fp_from_u52(c) == (double)c, "from_u52");
+            EXPECT(fp_to_canon(f, m) == canon((i128)f, q), "to_canon");
+            uint64_t any = rng();
+            double a = fp_from_u64(any, m);
+            EXPECT(canon((i128)a, q) == any % q, "from_u64 residue");
+            EXPECT(std::fabs(a) < qd + 4294967296.0, "from_u64 magnitude");
+        }
+    }
+    // growth of four forward / inverse stages from the documented starting bounds stays below 2^53
+    {
+        double B = 1.0;
+        for (int s = 0; s < 4; s++) B = B + 0.5 + 0.375 * B;
+        if (!(B < 8.0)) { printf("forward bound %.3f\n", B); fails++; }
+    }
+    if (fails) { printf("%d failures\n", fails); return 1; }
+    printf("field_check ok\n");
+    return 0;
+}

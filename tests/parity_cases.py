@@ -216,3 +216,47 @@ def case_rns_stages(n, primes, t, seed=5):
 
 def default_bfv_params(n, bits, t_bits):
     return coeff_modulus_create(n, bits), plain_modulus_batching(n, t_bits)
+
+
+# ---- digests of the REAL reference's outputs at two-pass-engine sizes (tests/golden/make_golden_engine.py):
+#      inputs and keys are regenerated from the stored seeds, outputs compared by SHA-256
+def case_golden_engine(name):
+    import hashlib
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = json.load(open(os.path.join(here, "golden", "engine_digests.json")))[name]
+    n, bits = g["n"], g["bits"]
+    primes = coeff_modulus_create(n, bits)
+    L, K = len(primes), len(primes) - 1
+    rng = np.random.default_rng(g["seed"])
+    ct = lambda: np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)]) for _ in range(2)])
+    a, b = ct(), ct()
+    key = lambda: np.stack([np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(L)])
+                                      for _ in range(2)]) for _ in range(K)])
+    rlk, glk = key(), key()
+    dg = lambda arr: hashlib.sha256(np.ascontiguousarray(arr, dtype=np.uint64).tobytes()).hexdigest()
+    want = g["digests"]
+    d = DeviceSide("ckks", n, primes)
+    elt = g["galois_elt"]
+    assert d.ctx.galois_elt_from_step(1) == elt
+    d.rlk = S.RelinKeys(d.ctx)
+    d.rlk.set_key(0, rlk)
+    d.glk = S.GaloisKeys(d.ctx)
+    d.glk.set_key(S.GaloisKeys.get_index(elt), glk)
+    buf = S.DeviceBuffer.from_numpy(a[0])
+    S.ntt_forward(d.ctx, buf, 1, K)
+    assert dg(buf.to_numpy(a[0].shape)) == want["ntt_fwd_a0"], "ntt_negacyclic_harvey"
+    buf = S.DeviceBuffer.from_numpy(a[0])
+    S.ntt_inverse(d.ctx, buf, 1, K)
+    assert dg(buf.to_numpy(a[0].shape)) == want["ntt_inv_a0"], "inverse_ntt_negacyclic_harvey"
+    x, y = d.ct(a, scale=2.0 ** 10), d.ct(b, scale=2.0 ** 10)
+    d.ev.multiply_inplace(x, y)
+    assert dg(d.out(x)[0]) == want["multiply"], "multiply"
+    d.ev.relinearize_inplace(x, d.rlk)
+    assert dg(d.out(x)[0]) == want["relinearize"], "relinearize"
+    x.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+    d.ev.rescale_to_next_inplace(x)
+    assert dg(d.out(x)[0]) == want["rescale"], "rescale_to_next"
+    d.ev.rotate_vector_inplace(x, 1, d.glk)
+    assert dg(d.out(x)[0]) == want["rotate1"], "rotate_vector(1)"

@@ -165,6 +165,12 @@ class RefContext:
         _ck(lib().ref_key_copy(self.h, C.c_int(k), C.c_uint64(index), _p(out)))
         return out
 
+    def set_key(self, kind, index, words):
+        """overwrite an existing key with caller-supplied residues [digits][2][L][N] (synthetic seeded keys)"""
+        k = 0 if kind == "relin" else 1
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        _ck(lib().ref_key_set(self.h, C.c_int(k), C.c_uint64(index), _p(w)))
+
     def galois_elt_from_step(self, step):
         return int(lib().ref_galois_elt_from_step(self.h, C.c_int(step)))
 

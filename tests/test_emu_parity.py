@@ -20,6 +20,55 @@ def test_ntt_all_plans(emu, n, bits):
     P.case_ntt(n, bits, polys=2 if n <= 4096 else 1)
 
 
+# two-pass engine (ntt2_kernels.hip): every D1 geometry, both arithmetic back ends in one context
+@pytest.mark.parametrize("n,bits", [
+    (8192, [50, 30, 60]), (8192, [20, 25]), (16384, [50, 50, 45, 60]), (32768, [40, 50]), (65536, [50, 60, 36]),
+])
+def test_ntt_two_pass_engine_mixed_primes(emu, n, bits):
+    P.case_ntt(n, bits, polys=2)
+
+
+def test_ntt_two_pass_engine_integer_only(emu, monkeypatch):
+    """SEALHIP_NO_FP=1: the same primes on the 64-bit integer back end give the same words."""
+    monkeypatch.setenv("SEALHIP_NO_FP", "1")
+    P.case_ntt(8192, [50, 30, 60], polys=1)
+
+
+# fused key switching + fused tails at engine sizes: CKKS (diagonal shortcut), BFV (no shortcut, BEHZ)
+@pytest.mark.parametrize("n,bits,batch,steps", [
+    (8192, [50, 40, 60, 50], 2, (1,)),
+    (8192, [60, 40, 40, 60], 1, (-1,)),
+    (16384, [60, 50, 50, 60], 1, (1,)),
+])
+def test_ckks_pipeline_engine_sizes(emu, n, bits, batch, steps):
+    P.case_ckks_pipeline(n, bits, batch=batch, steps=steps)
+
+
+def test_bfv_pipeline_engine_size(emu):
+    primes, t = P.default_bfv_params(8192, [50, 55, 56], 20)
+    P.case_bfv_pipeline(8192, primes, t, batch=1)
+
+
+def test_golden_engine_digests_index_arithmetic(emu):
+    """same digests through the emulated kernels (index arithmetic + host logic only)"""
+    P.case_golden_engine("ckks_n8192_fp_and_int")
+
+
+def test_field_arithmetic_exact():
+    """seal_amd/csrc/field.h: the double-precision residue arithmetic is exact and stays inside its
+    documented ranges (checked against 128-bit integers, 2.8 M random and adversarial cases)."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = os.path.join(here, "hipemu", "obj", "field_check")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-I" + os.path.join(here, "hipemu", "include"),
+                           "-I" + os.path.join(root, "seal_amd", "csrc"), os.path.join(here, "field_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "field_check ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_dyadic(emu):
     P.case_dyadic(256, [60, 40, 30])
 

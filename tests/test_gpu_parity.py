@@ -126,6 +126,12 @@ def test_golden_ckks(gpu):
     assert np.array_equal(d.out(x)[0], g["mod_switch"])
 
 
+@pytest.mark.parametrize("name", ["ckks_n8192_fp_and_int", "ckks_n16384_50bit"])
+def test_golden_engine_digests(gpu, name):
+    """two-pass engine + fused key switch against SHA-256 digests of the real reference's outputs"""
+    P.case_golden_engine(name)
+
+
 def test_golden_bfv(gpu):
     S = gpu
     g = np.load(os.path.join(GOLDEN, "bfv_n32.npz"))
