@@ -276,6 +276,10 @@ namespace sealhip
         check_hip(hipMemcpy(d_inv_d_, inv_d.data(), inv_d.size() * 8, hipMemcpyHostToDevice), "upload inv_d");
         check_hip(hipMemcpy(d_ninv_d_, ninv_d.data(), ninv_d.size() * 8, hipMemcpyHostToDevice), "upload ninv_d");
         tables_.fpd = d_fpd_;
+        h_fp_flag_.resize(np);
+        for (size_t p = 0; p < np; p++)
+            h_fp_flag_[p] = h_fpd_[p].qi != 0;
+        tables_.fp_host = h_fp_flag_.data();
         tables_.fwd_d = d_fwd_d_;
         tables_.inv_d = d_inv_d_;
         tables_.ninv_d = d_ninv_d_;

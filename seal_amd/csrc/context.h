@@ -143,6 +143,7 @@ namespace sealhip
         FpDesc *d_fpd_ = nullptr;
         double *d_fwd_d_ = nullptr, *d_inv_d_ = nullptr, *d_ninv_d_ = nullptr;
         std::vector<FpDesc> h_fpd_;
+        std::vector<unsigned char> h_fp_flag_;
         NttTables tables_{};
     };
 } // namespace sealhip

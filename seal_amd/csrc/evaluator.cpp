@@ -351,12 +351,12 @@ namespace sealhip
         KsTargets kt;
         kt.n_int = (unsigned)t1[0].size() / 2;
         kt.n_fp = (unsigned)t1[1].size() / 2;
+        // [targets1: int..., fp...][targets2: int..., fp...]
         std::vector<uint32_t> all;
         for (int fp = 0; fp < 2; fp++)
-        {
             all.insert(all.end(), t1[fp].begin(), t1[fp].end());
+        for (int fp = 0; fp < 2; fp++)
             all.insert(all.end(), t2[fp].begin(), t2[fp].end());
-        }
         void *p = nullptr;
         ck(hipMalloc(&p, all.size() * 4 + 4), "hipMalloc ks targets");
         ck(hipMemcpy(p, all.data(), all.size() * 4, hipMemcpyHostToDevice), "upload ks targets");
@@ -770,12 +770,10 @@ namespace sealhip
             ka.key = key.dev;
             ka.mid = mid.p;
             ka.acc = acc.p;
-            ka.targets1_int = kt.dev;
-            ka.targets2_int = kt.dev + 2 * kt.n_int;
-            ka.targets1_fp = kt.dev + 5 * kt.n_int;
-            ka.targets2_fp = kt.dev + 5 * kt.n_int + 2 * kt.n_fp;
+            ka.targets1 = kt.dev;
+            ka.targets2 = kt.dev + 2 * (kt.n_int + kt.n_fp);
+            ka.ntargets = kt.n_int + kt.n_fp;
             ka.n_int = kt.n_int;
-            ka.n_fp = kt.n_fp;
             ka.K = K;
             ka.L = L;
             ka.batch = B;

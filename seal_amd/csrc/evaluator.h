@@ -149,7 +149,7 @@ namespace sealhip
         const uint32_t *ks_comp_prime(unsigned K) const;
         struct KsTargets
         {
-            uint32_t *dev = nullptr; // [t1_int | t2_int | t1_fp | t2_fp]
+            uint32_t *dev = nullptr; // [targets1: int, fp | targets2: int, fp]
             unsigned n_int = 0, n_fp = 0;
         };
         const KsTargets &ks_targets(unsigned K) const;

@@ -19,8 +19,10 @@ namespace sealhip
     //   acc[b][k][I] = sum_J NTT_I(t[b][J] mod q_I) (.) key[J][k][comp(I)]   canonical, natural order
     // t: [batch][K][N] coefficient form.  target_ntt (CKKS) = the same digits in NTT form, used for
     // I == J instead of transforming (null for BFV).  key: register order (key_to_register_order).
-    // targets*: device arrays, one entry per target modulus of the class (integer / double):
+    // targets*: device arrays, one entry per target modulus, the integer-back-end (60-bit) moduli first:
     //   targets1: pairs (I, pool prime); targets2: triples (I, pool prime, key component)
+    // Pass 1 runs one launch per back end; pass 2 is one launch that picks the back end per workgroup from
+    // NttTables::fpd (both bodies need the same registers; the heavy 60-bit tiles start first).
     struct KsFusedArgs
     {
         const uint64_t *t;
@@ -28,8 +30,8 @@ namespace sealhip
         const uint64_t *key;
         uint64_t *mid; // [batch][K+1][K][N] scratch
         uint64_t *acc; // [batch][2][K+1][N]
-        const uint32_t *targets1_int, *targets2_int, *targets1_fp, *targets2_fp;
-        unsigned n_int, n_fp;
+        const uint32_t *targets1, *targets2;
+        unsigned ntargets, n_int; // all targets; how many of them (the leading ones) are integer-back-end moduli
         unsigned K, L, batch;
     };
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);

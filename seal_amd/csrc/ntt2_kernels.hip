@@ -26,13 +26,22 @@
 // the K(K+1) transformed digits never reach HBM in NTT form.
 #include "ntt2_kernels.h"
 #include <cstdlib>
+#include <vector>
+
+// minimum waves per SIMD requested for the double-precision-only forward kernels (register budget
+// 512 / waves): 4 keeps them at 128 VGPRs with a handful of spilled words
+#ifndef SEALHIP_FP_WAVES_P1
+#define SEALHIP_FP_WAVES_P1 4
+#endif
+#ifndef SEALHIP_FP_WAVES_P2
+#define SEALHIP_FP_WAVES_P2 4
+#endif
 
 namespace sealhip
 {
     namespace
     {
         constexpr int kThreads = 256;
-
         template <int D1>
         struct Geo
         {
@@ -393,7 +402,8 @@ namespace sealhip
             const uint32_t *comp_prime;
             unsigned prime_first;
             unsigned ncomp;
-            unsigned nouter;  // outer items; a workgroup handles z, z + gridDim.z, ... (twiddles stay in registers)
+            unsigned comp0; // this launch covers components [comp0, comp0 + gridDim.y)
+            unsigned nouter;  // outer items; a workgroup handles y, y + gridDim.y, ... (twiddles stay in registers)
             int lazy;
             int epi;
             const uint64_t *epi_a;
@@ -444,27 +454,34 @@ namespace sealhip
                     nxt[e] = in[(size_t)R * 256];
                 }
             };
+            const unsigned ostride = gridDim.z;
             fetch(outer);
-            for (; outer < a.nouter; outer += gridDim.z)
+            for (; outer < a.nouter; outer += ostride)
             {
                 typename F::elem x[16];
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     x[e] = map_src<FP>(nxt[e], sm, m);
-                if (outer + gridDim.z < a.nouter)
-                    fetch(outer + gridDim.z);
+                if (outer + ostride < a.nouter)
+                    fetch(outer + ostride);
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
                 p1_tile<FP, D1>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
         }
 
-        template <int D1>
-        __global__ void __launch_bounds__(kThreads) ntt2_fwd_p1(FwdArgs a)
+        // CLS: 0 = every component of the launch uses the integer back end, 1 = the double-precision one,
+        // 2 = decided per workgroup (costs the registers of both bodies)
+        template <int D1, int CLS>
+        __global__ void __launch_bounds__(kThreads, CLS == 1 ? SEALHIP_FP_WAVES_P1 : 2) ntt2_fwd_p1(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y, outer = blockIdx.z;
+            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
             const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
-            if (a.t.fpd[prime].qi)
+            if constexpr (CLS == 1)
+                fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
+            else if constexpr (CLS == 0)
+                fwd_p1_body<false, D1>(a, prime, comp, outer, lds);
+            else if (a.t.fpd[prime].qi)
                 fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
             else
                 fwd_p1_body<false, D1>(a, prime, comp, outer, lds);
@@ -487,15 +504,16 @@ namespace sealhip
                 for (int e = 0; e < 16; e++)
                     nxt[e] = mp[e * 256];
             };
+            const unsigned ostride = gridDim.z;
             fetch(outer);
-            for (; outer < a.nouter; outer += gridDim.z)
+            for (; outer < a.nouter; outer += ostride)
             {
             typename F::elem x[16];
 #pragma unroll
             for (int e = 0; e < 16; e++)
                 x[e] = F::unraw(nxt[e]);
-            if (outer + gridDim.z < a.nouter)
-                fetch(outer + gridDim.z);
+            if (outer + ostride < a.nouter)
+                fetch(outer + ostride);
             p2_tile<FP, D1, false>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
             uint64_t val[16];
             const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
@@ -531,13 +549,17 @@ namespace sealhip
             }
         }
 
-        template <int D1>
-        __global__ void __launch_bounds__(kThreads) ntt2_fwd_p2(FwdArgs a)
+        template <int D1, int CLS>
+        __global__ void __launch_bounds__(kThreads, CLS == 1 ? SEALHIP_FP_WAVES_P2 : 2) ntt2_fwd_p2(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y, outer = blockIdx.z;
+            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
             const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
-            if (a.t.fpd[prime].qi)
+            if constexpr (CLS == 1)
+                fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
+            else if constexpr (CLS == 0)
+                fwd_p2_body<false, D1>(a, prime, comp, outer, lds);
+            else if (a.t.fpd[prime].qi)
                 fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
             else
                 fwd_p2_body<false, D1>(a, prime, comp, outer, lds);
@@ -557,6 +579,7 @@ namespace sealhip
             const uint32_t *comp_prime;
             unsigned prime_first;
             unsigned ncomp;
+            unsigned comp0; // as FwdArgs
             int lazy;
             NttTables t;
         };
@@ -611,13 +634,17 @@ namespace sealhip
                 mid_tr[e * 256 + tid] = F::raw(x[e]);
         }
 
-        template <int D1>
+        template <int D1, int CLS>
         __global__ void __launch_bounds__(kThreads) ntt2_inv_pa(InvArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y, outer = blockIdx.z;
+            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
             const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
-            if (a.t.fpd[prime].qi)
+            if constexpr (CLS == 1)
+                inv_pa_body<true, D1>(a, prime, comp, outer, lds);
+            else if constexpr (CLS == 0)
+                inv_pa_body<false, D1>(a, prime, comp, outer, lds);
+            else if (a.t.fpd[prime].qi)
                 inv_pa_body<true, D1>(a, prime, comp, outer, lds);
             else
                 inv_pa_body<false, D1>(a, prime, comp, outer, lds);
@@ -687,13 +714,17 @@ namespace sealhip
             }
         }
 
-        template <int D1>
+        template <int D1, int CLS>
         __global__ void __launch_bounds__(kThreads) ntt2_inv_pb(InvArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y, outer = blockIdx.z;
+            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
             const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
-            if (a.t.fpd[prime].qi)
+            if constexpr (CLS == 1)
+                inv_pb_body<true, D1>(a, prime, comp, outer, lds);
+            else if constexpr (CLS == 0)
+                inv_pb_body<false, D1>(a, prime, comp, outer, lds);
+            else if (a.t.fpd[prime].qi)
                 inv_pb_body<true, D1>(a, prime, comp, outer, lds);
             else
                 inv_pb_body<false, D1>(a, prime, comp, outer, lds);
@@ -716,22 +747,11 @@ namespace sealhip
         };
 
         template <bool FP, int D1>
-        __global__ void __launch_bounds__(kThreads) ks1_kernel(Ks1Args a)
+        __device__ __forceinline__ void ks1_body(const Ks1Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned b, unsigned cg)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
-            HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned tid = threadIdx.x;
-            // one workgroup = (column tile cg, target modulus, batch item), looping over the digits J:
-            // the modulus constants and all twiddles are loop-invariant, the next digit is prefetched.
-            // Blocks that share (b, cg) - they read the same digit tiles - sit on one XCD (blockIdx % 8).
-            const unsigned bid = blockIdx.x;
-            const unsigned low = bid & 7, rest = bid >> 3;
-            const unsigned it = rest % a.ntargets, grp = (rest / a.ntargets) * 8 + low; // grp = b*TILES + cg
-            if (grp >= a.batch * G::TILES)
-                return;
-            const unsigned b = grp / G::TILES, cg = grp % G::TILES;
-            const unsigned I = a.targets[2 * it], prime = a.targets[2 * it + 1];
             const typename F::Mod m = F::make_mod(a.tb.mods[prime], a.tb.fpd[prime]);
             const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
             TwRegs<FP> tw;
@@ -804,6 +824,26 @@ namespace sealhip
             }
         }
 
+        // One launch per arithmetic back end: the double-precision body needs ~127 VGPRs (4 waves per
+        // SIMD), the integer body ~214 (2 waves); a merged kernel would run both at the lower occupancy.
+        template <bool FP, int D1>
+        __global__ void __launch_bounds__(kThreads) ks1_kernel(Ks1Args a)
+        {
+            typedef Geo<D1> G;
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            // one workgroup = (column tile cg, target modulus, batch item), looping over the digits J:
+            // the modulus constants and all twiddles are loop-invariant, the next digit is prefetched.
+            // Blocks that share (b, cg) - they read the same digit tiles - sit on one XCD (blockIdx % 8).
+            const unsigned bid = blockIdx.x;
+            const unsigned low = bid & 7, rest = bid >> 3;
+            const unsigned it = rest % a.ntargets, grp = (rest / a.ntargets) * 8 + low; // grp = b*TILES + cg
+            if (grp >= a.batch * G::TILES)
+                return;
+            const unsigned b = grp / G::TILES, cg = grp % G::TILES;
+            const unsigned I = a.targets[2 * it], prime = a.targets[2 * it + 1];
+            ks1_body<FP, D1>(a, lds, I, prime, b, cg);
+        }
+
         // ---------------------------------------------------------------------------------------
         // fused key switching, pass 2 + inner product with the key.
         // one workgroup = (target modulus I, row tile hg, batch item b); loops over the digits J.
@@ -826,23 +866,11 @@ namespace sealhip
         };
 
         template <bool FP, int D1>
-        __global__ void __launch_bounds__(kThreads, 2) ks2_kernel(Ks2Args a)
+        __device__ __forceinline__ void ks2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
-            HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned tid = threadIdx.x;
-            // XCD-aware order: blockIdx % 8 selects the XCD; keep every batch item of one (I, hg)
-            // on one XCD and adjacent in time so the key tile is served by that XCD's L2.
-            const unsigned ntile = a.ntargets * G::TILES;
-            unsigned bid = blockIdx.x;
-            const unsigned xcd = bid & 7, rest = bid >> 3;
-            const unsigned b = rest % a.batch, tile_hi = rest / a.batch;
-            const unsigned tile = tile_hi * 8 + xcd;
-            if (tile >= ntile)
-                return;
-            const unsigned it = tile / G::TILES, hg = tile % G::TILES;
-            const unsigned I = a.targets[3 * it], prime = a.targets[3 * it + 1], kc = a.targets[3 * it + 2];
             const typename F::Mod m = F::make_mod(a.tb.mods[prime], a.tb.fpd[prime]);
             const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
 
@@ -986,6 +1014,28 @@ namespace sealhip
             store_rows(val, lds_wave, out + ((size_t)(a.K + 1) << G::n), tid);
         }
 
+        template <int D1>
+        __global__ void __launch_bounds__(kThreads, 2) ks2_kernel(Ks2Args a)
+        {
+            typedef Geo<D1> G;
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            // XCD-aware order: blockIdx % 8 selects the XCD; keep every batch item of one (I, hg)
+            // on one XCD and adjacent in time so the key tile is served by that XCD's L2.
+            const unsigned ntile = a.ntargets * G::TILES;
+            const unsigned bid = blockIdx.x;
+            const unsigned xcd = bid & 7, rest = bid >> 3;
+            const unsigned b = rest % a.batch, tile_hi = rest / a.batch;
+            const unsigned tile = tile_hi * 8 + xcd;
+            if (tile >= ntile)
+                return;
+            const unsigned it = tile / G::TILES, hg = tile % G::TILES;
+            const unsigned I = a.targets[3 * it], prime = a.targets[3 * it + 1], kc = a.targets[3 * it + 2];
+            if (a.tb.fpd[prime].qi)
+                ks2_body<true, D1>(a, lds, I, prime, kc, b, hg);
+            else
+                ks2_body<false, D1>(a, lds, I, prime, kc, b, hg);
+        }
+
         // natural order (u64) -> register order, optionally converted to double
         __global__ void __launch_bounds__(kThreads) key_layout_kernel(
             const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys)
@@ -1005,6 +1055,89 @@ namespace sealhip
             }
         }
 
+        // Components [c0, c0 + nc) of one launch, all of arithmetic class cls (0 int, 1 fp, 2 mixed)
+        struct CompRun
+        {
+            unsigned c0, nc;
+            int cls;
+        };
+        // Split the components of a batch into runs of one arithmetic class (known on the host only when
+        // the prime of a component is prime_first + comp): the single-class kernels need about half the
+        // registers of the mixed one (128 vs 256 VGPRs for the double-precision forward passes).
+        // Measured on MI355X (bench.py, C5): +2 % on the multiply+relinearize+rescale pipeline.  Two
+        // alternatives were measured and dropped: a (tile, outer, comp) grid order (-5 % on the NTT) and
+        // splitting a batch so that the intermediate stays below 128 MiB (-2 %).
+        std::vector<CompRun> comp_runs(const NttTables &t, const uint32_t *comp_prime, unsigned prime_first, unsigned ncomp)
+        {
+            std::vector<CompRun> runs;
+            static const bool split = !std::getenv("SEALHIP_NTT_NOSPLIT");
+            unsigned c = 0;
+            while (c < ncomp)
+            {
+                int cls = 2;
+                unsigned e = ncomp;
+                if (split && !comp_prime && t.fp_host)
+                {
+                    cls = t.fp_host[prime_first + c] ? 1 : 0;
+                    e = c + 1;
+                    while (e < ncomp && (t.fp_host[prime_first + e] ? 1 : 0) == cls)
+                        e++;
+                }
+                runs.push_back(CompRun{ c, e - c, cls });
+                c = e;
+            }
+            return runs;
+        }
+
+        // Runs of different classes touch disjoint components (and disjoint parts of the intermediate):
+        // the short ones go to a side stream between a fork and a join event so that their few
+        // workgroups share the chip with the long run instead of running alone before it.
+        struct SideStream
+        {
+            hipStream_t stream = nullptr;
+            hipEvent_t fork = nullptr, join = nullptr;
+            bool ok = false;
+            SideStream()
+            {
+                ok = !std::getenv("SEALHIP_NTT_NOFORK") && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
+            }
+        };
+        SideStream &side_stream()
+        {
+            static thread_local SideStream s;
+            return s;
+        }
+        // run(r, stream) launches the kernels of one run; the longest run stays on `s`
+        template <class RunFn>
+        hipError_t launch_runs(const std::vector<CompRun> &runs, hipStream_t s, RunFn run)
+        {
+            size_t longest = 0;
+            for (size_t i = 1; i < runs.size(); i++)
+                if (runs[i].nc > runs[longest].nc)
+                    longest = i;
+            SideStream &ss = side_stream();
+            const bool fork = runs.size() > 1 && ss.ok;
+            hipError_t e;
+            if (fork)
+            {
+                if ((e = hipEventRecord(ss.fork, s)) != hipSuccess || (e = hipStreamWaitEvent(ss.stream, ss.fork, 0)) != hipSuccess)
+                    return e;
+                for (size_t i = 0; i < runs.size(); i++)
+                    if (i != longest && (e = run(runs[i], ss.stream)) != hipSuccess)
+                        return e;
+                if ((e = hipEventRecord(ss.join, ss.stream)) != hipSuccess)
+                    return e;
+            }
+            for (size_t i = 0; i < runs.size(); i++)
+                if ((!fork || i == longest) && (e = run(runs[i], s)) != hipSuccess)
+                    return e;
+            if (fork && (e = hipStreamWaitEvent(s, ss.join, 0)) != hipSuccess)
+                return e;
+            return hipSuccess;
+        }
+
         template <int D1>
         hipError_t launch_fwd(const FwdArgs &a, unsigned nouter, hipStream_t s)
         {
@@ -1017,56 +1150,99 @@ namespace sealhip
                 chunks = nouter;
             if (chunks > 65535)
                 chunks = 65535;
-            dim3 grid(G::TILES, a.ncomp, chunks);
             size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
-            hipLaunchKernelGGL(ntt2_fwd_p1<D1>, grid, dim3(kThreads), l1, s, a);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess)
-                return e;
-            hipLaunchKernelGGL(ntt2_fwd_p2<D1>, grid, dim3(kThreads), kLds2Words * 8, s, a);
-            return hipGetLastError();
+            return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp), s, [&](const CompRun &r, hipStream_t st) {
+                FwdArgs g = a;
+                g.comp0 = r.c0;
+                dim3 grid(G::TILES, r.nc, chunks);
+                if (r.cls == 1)
+                    hipLaunchKernelGGL((ntt2_fwd_p1<D1, 1>), grid, dim3(kThreads), l1, st, g);
+                else if (r.cls == 0)
+                    hipLaunchKernelGGL((ntt2_fwd_p1<D1, 0>), grid, dim3(kThreads), l1, st, g);
+                else
+                    hipLaunchKernelGGL((ntt2_fwd_p1<D1, 2>), grid, dim3(kThreads), l1, st, g);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess)
+                    return e;
+                if (r.cls == 1)
+                    hipLaunchKernelGGL((ntt2_fwd_p2<D1, 1>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                else if (r.cls == 0)
+                    hipLaunchKernelGGL((ntt2_fwd_p2<D1, 0>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                else
+                    hipLaunchKernelGGL((ntt2_fwd_p2<D1, 2>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                return hipGetLastError();
+            });
         }
 
         template <int D1>
         hipError_t launch_inv(const InvArgs &a, unsigned nouter, hipStream_t s)
         {
             typedef Geo<D1> G;
-            dim3 grid(G::TILES, a.ncomp, nouter);
-            hipLaunchKernelGGL(ntt2_inv_pa<D1>, grid, dim3(kThreads), kLds2Words * 8, s, a);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess)
-                return e;
-            hipLaunchKernelGGL(ntt2_inv_pb<D1>, grid, dim3(kThreads), G::lds1_words * 8, s, a);
-            return hipGetLastError();
+            return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp), s, [&](const CompRun &r, hipStream_t st) {
+                InvArgs g = a;
+                g.comp0 = r.c0;
+                dim3 grid(G::TILES, r.nc, nouter);
+                if (r.cls == 1)
+                    hipLaunchKernelGGL((ntt2_inv_pa<D1, 1>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                else if (r.cls == 0)
+                    hipLaunchKernelGGL((ntt2_inv_pa<D1, 0>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                else
+                    hipLaunchKernelGGL((ntt2_inv_pa<D1, 2>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess)
+                    return e;
+                if (r.cls == 1)
+                    hipLaunchKernelGGL((ntt2_inv_pb<D1, 1>), grid, dim3(kThreads), G::lds1_words * 8, st, g);
+                else if (r.cls == 0)
+                    hipLaunchKernelGGL((ntt2_inv_pb<D1, 0>), grid, dim3(kThreads), G::lds1_words * 8, st, g);
+                else
+                    hipLaunchKernelGGL((ntt2_inv_pb<D1, 2>), grid, dim3(kThreads), G::lds1_words * 8, st, g);
+                return hipGetLastError();
+            });
         }
 
-        template <bool FP, int D1>
-        hipError_t launch_ks(const Ks1Args &a1, const Ks2Args &a2, unsigned batch, hipStream_t s)
+        template <int D1>
+        hipError_t launch_ks(const Ks1Args &a1, const Ks2Args &a2, unsigned batch, unsigned n_int, hipStream_t s)
         {
             typedef Geo<D1> G;
             if (a1.ntargets == 0)
                 return hipSuccess;
             size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
             const unsigned groups = batch * G::TILES;
-            hipLaunchKernelGGL((ks1_kernel<FP, D1>), dim3(((groups + 7) / 8) * a1.ntargets * 8), dim3(kThreads), l1, s, a1);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess)
-                return e;
+            hipError_t e;
+            if (n_int)
+            {
+                Ks1Args c = a1; // targets1 = [integer moduli..., double-precision moduli...]
+                c.ntargets = n_int;
+                hipLaunchKernelGGL((ks1_kernel<false, D1>), dim3(((groups + 7) / 8) * n_int * 8), dim3(kThreads), l1, s, c);
+                if ((e = hipGetLastError()) != hipSuccess)
+                    return e;
+            }
+            if (a1.ntargets > n_int)
+            {
+                Ks1Args c = a1;
+                c.targets = a1.targets + 2 * n_int;
+                c.ntargets = a1.ntargets - n_int;
+                hipLaunchKernelGGL((ks1_kernel<true, D1>), dim3(((groups + 7) / 8) * c.ntargets * 8), dim3(kThreads), l1, s, c);
+                if ((e = hipGetLastError()) != hipSuccess)
+                    return e;
+            }
             const unsigned ntile = a2.ntargets * G::TILES;
             const unsigned blocks = ((ntile + 7) / 8) * batch * 8;
-            size_t l2 = kLds2Words * 8 + (FP ? (240 + 3840) * sizeof(double) : 0);
+            // the double-precision back end stages its tile's twiddles in LDS
+            size_t l2 = kLds2Words * 8 + (a1.ntargets > n_int ? (240 + 3840) * sizeof(double) : 0);
             if (l2 > 65536)
             {
                 // more than the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU)
                 static bool raised = false;
                 if (!raised)
                 {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<FP, D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess)
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess)
                         return hipErrorInvalidValue;
                     raised = true;
                 }
             }
-            hipLaunchKernelGGL((ks2_kernel<FP, D1>), dim3(blocks), dim3(kThreads), l2, s, a2);
+            hipLaunchKernelGGL((ks2_kernel<D1>), dim3(blocks), dim3(kThreads), l2, s, a2);
             return hipGetLastError();
         }
     } // namespace
@@ -1094,6 +1270,7 @@ namespace sealhip
         a.comp_prime = b.comp_prime;
         a.prime_first = b.prime_first;
         a.ncomp = b.ncomp;
+        a.comp0 = 0;
         a.nouter = b.nouter;
         a.lazy = out_lazy;
         a.epi = b.epi;
@@ -1132,6 +1309,7 @@ namespace sealhip
         a.comp_prime = b.comp_prime;
         a.prime_first = b.prime_first;
         a.ncomp = b.ncomp;
+        a.comp0 = 0;
         a.lazy = out_lazy;
         a.t = t;
         const unsigned zmax = 65535;
@@ -1168,50 +1346,39 @@ namespace sealhip
 
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream)
     {
-        for (int fp = 0; fp < 2; fp++)
+        Ks1Args a1;
+        a1.t = k.t;
+        a1.mid = k.mid;
+        a1.targets = k.targets1;
+        a1.ntargets = k.ntargets;
+        a1.K = k.K;
+        a1.batch = k.batch;
+        a1.skip_diag = k.target_ntt != nullptr;
+        a1.tb = t;
+        Ks2Args a2;
+        a2.mid = k.mid;
+        a2.target = k.target_ntt;
+        a2.key = k.key;
+        a2.acc = k.acc;
+        a2.targets = k.targets2;
+        a2.ntargets = k.ntargets;
+        a2.K = k.K;
+        a2.L = k.L;
+        a2.batch = k.batch;
+        a2.tb = t;
+        switch (t.log_n)
         {
-            Ks1Args a1;
-            a1.t = k.t;
-            a1.mid = k.mid;
-            a1.targets = fp ? k.targets1_fp : k.targets1_int;
-            a1.ntargets = fp ? k.n_fp : k.n_int;
-            a1.K = k.K;
-            a1.batch = k.batch;
-            a1.skip_diag = k.target_ntt != nullptr;
-            a1.tb = t;
-            Ks2Args a2;
-            a2.mid = k.mid;
-            a2.target = k.target_ntt;
-            a2.key = k.key;
-            a2.acc = k.acc;
-            a2.targets = fp ? k.targets2_fp : k.targets2_int;
-            a2.ntargets = a1.ntargets;
-            a2.K = k.K;
-            a2.L = k.L;
-            a2.batch = k.batch;
-            a2.tb = t;
-            hipError_t e;
-            switch (t.log_n)
-            {
-            case 13:
-                e = fp ? launch_ks<true, 5>(a1, a2, k.batch, stream) : launch_ks<false, 5>(a1, a2, k.batch, stream);
-                break;
-            case 14:
-                e = fp ? launch_ks<true, 6>(a1, a2, k.batch, stream) : launch_ks<false, 6>(a1, a2, k.batch, stream);
-                break;
-            case 15:
-                e = fp ? launch_ks<true, 7>(a1, a2, k.batch, stream) : launch_ks<false, 7>(a1, a2, k.batch, stream);
-                break;
-            case 16:
-                e = fp ? launch_ks<true, 8>(a1, a2, k.batch, stream) : launch_ks<false, 8>(a1, a2, k.batch, stream);
-                break;
-            default:
-                return hipErrorInvalidValue;
-            }
-            if (e != hipSuccess)
-                return e;
+        case 13:
+            return launch_ks<5>(a1, a2, k.batch, k.n_int, stream);
+        case 14:
+            return launch_ks<6>(a1, a2, k.batch, k.n_int, stream);
+        case 15:
+            return launch_ks<7>(a1, a2, k.batch, k.n_int, stream);
+        case 16:
+            return launch_ks<8>(a1, a2, k.batch, k.n_int, stream);
+        default:
+            return hipErrorInvalidValue;
         }
-        return hipSuccess;
     }
 
     hipError_t key_to_register_order(

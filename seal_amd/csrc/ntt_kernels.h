@@ -29,6 +29,9 @@ namespace sealhip
         const double *fwd_d;  // [nprimes][N]
         const double *inv_d;  // [nprimes][N]
         const double *ninv_d; // [nprimes][2]
+        // HOST copy of "fpd[p].qi != 0" per prime (null = unknown): lets the launcher pick kernels
+        // specialised for one back end, which need far fewer registers than the mixed ones
+        const unsigned char *fp_host;
         int log_n;
     };
 

@@ -212,6 +212,22 @@ static inline hipError_t hipEventCreate(hipEvent_t *e)
     *e = nullptr;
     return hipSuccess;
 }
+// streams are synchronous in the emulator: creation hands out a dummy handle, waits are no-ops
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
+{
+    *s = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned)
+{
+    *e = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned)
+{
+    return hipSuccess;
+}
 static inline hipError_t hipEventDestroy(hipEvent_t)
 {
     return hipSuccess;

@@ -34,6 +34,12 @@ def test_ntt_two_pass_engine_integer_only(emu, monkeypatch):
     P.case_ntt(8192, [50, 30, 60], polys=1)
 
 
+def test_ntt_two_pass_engine_mixed_kernel(emu, monkeypatch):
+    """SEALHIP_NTT_NOSPLIT=1: one mixed-back-end launch instead of one launch per class run."""
+    monkeypatch.setenv("SEALHIP_NTT_NOSPLIT", "1")
+    P.case_ntt(8192, [60, 50, 30], polys=2)
+
+
 # fused key switching + fused tails at engine sizes: CKKS (diagonal shortcut), BFV (no shortcut, BEHZ)
 @pytest.mark.parametrize("n,bits,batch,steps", [
     (8192, [50, 40, 60, 50], 2, (1,)),
