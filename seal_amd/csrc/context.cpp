@@ -305,7 +305,7 @@ namespace sealhip
         Block blk;
         struct Off
         {
-            size_t inv_q_last = 0, round_fix = 0, half_mod_q = 0, bsk_prime = 0, inv_punct_q = 0, m_tilde_mod_q = 0, q_to_bsk = 0, q_to_mtilde = 0,
+            size_t inv_q_last = 0, round_fix = 0, half_mod_q = 0, q_last_mod_q = 0, bsk_prime = 0, inv_punct_q = 0, m_tilde_mod_q = 0, q_to_bsk = 0, q_to_mtilde = 0,
                    prod_q_mod_bsk = 0, inv_mtilde_mod_bsk = 0, inv_prod_q_mod_bsk = 0, inv_punct_b = 0, b_to_q = 0,
                    b_to_msk = 0, prod_b_mod_q = 0, t_mod_q = 0, t_mod_bsk = 0;
         } off;
@@ -325,6 +325,12 @@ namespace sealhip
             }
             off.round_fix = blk.put(fix);
             off.half_mod_q = blk.put(hm);
+            std::vector<uint64_t> qlm;
+            for (unsigned i = 0; i + 1 < K; i++)
+                qlm.push_back(q[K - 1] % q[i]);
+            off.q_last_mod_q = blk.put(qlm);
+            if (scheme_ == Scheme::bgv)
+                lvl.dev.inv_q_last_mod_t = invmod(q[K - 1] % plain_modulus_, plain_modulus_);
             lvl.dev.q_last = q[K - 1];
             lvl.dev.half_q_last = half;
         }
@@ -410,6 +416,7 @@ namespace sealhip
         lvl.dev.inv_q_last_mod_q = reinterpret_cast<const ShoupOp *>(d + off.inv_q_last);
         lvl.dev.round_fix = d + off.round_fix;
         lvl.dev.half_mod_q = d + off.half_mod_q;
+        lvl.dev.q_last_mod_q = d + off.q_last_mod_q;
         if (behz)
         {
             lvl.dev.bsk_prime = reinterpret_cast<const uint32_t *>(d + off.bsk_prime);

@@ -45,6 +45,10 @@ namespace sealhip
         // floor(q_last/2) mod q_i (coefficient-domain variant, rns.cpp:816-817)
         const uint64_t *half_mod_q = nullptr;      // [K-1]
         uint64_t q_last = 0, half_q_last = 0;
+        // BGV (mod_t_and_divide_q_last_ntt_inplace, rns.cpp:1193-1236): q_last mod q_i and q_last^-1 mod t
+        // (RNSTool::inv_q_last_mod_t_, rns.cpp:778-786); unused unless the scheme is BGV
+        const uint64_t *q_last_mod_q = nullptr;    // [K-1]
+        uint64_t inv_q_last_mod_t = 0;
         // BEHZ (BFV multiply); all null when the scheme is CKKS
         const uint32_t *bsk_prime = nullptr;       // [nBsk] pool index of each Bsk prime (B..., m_sk)
         const ShoupOp *inv_punct_q = nullptr;      // [K]     (Q/q_i)^-1 mod q_i

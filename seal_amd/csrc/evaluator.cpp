@@ -1,6 +1,7 @@
 #include "evaluator.h"
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <limits>
 
@@ -35,6 +36,52 @@ namespace sealhip
                     res.push_back((sign ? -zi : zi) * (1 << i));
             }
             return res;
+        }
+
+        // balance_correction_factors (evaluator.cpp:50-117): (f, e1, e2) with e1*factor1 = e2*factor2 = f mod t,
+        // gcd(e1,t) = gcd(e2,t) = 1 and |e1| + |e2| minimal in balanced representation
+        void balance_correction_factors(uint64_t factor1, uint64_t factor2, uint64_t t, uint64_t &f, uint64_t &e1, uint64_t &e2)
+        {
+            const uint64_t half_t = t / 2;
+            auto sum_abs = [&](uint64_t x, uint64_t y) {
+                int64_t xb = static_cast<int64_t>(x > half_t ? x - t : x);
+                int64_t yb = static_cast<int64_t>(y > half_t ? y - t : y);
+                return std::abs(xb) + std::abs(yb);
+            };
+            if (std::__gcd(factor1 % t, t) != 1 || factor1 % t == 0)
+                throw std::logic_error("invalid correction factor1");
+            uint64_t ratio = host::mulmod(host::invmod(factor1 % t, t), factor2 % t, t);
+            e1 = ratio;
+            e2 = 1;
+            int64_t sum = sum_abs(e1, e2);
+            int64_t prev_a = static_cast<int64_t>(t), prev_b = 0, a = static_cast<int64_t>(ratio), b = 1;
+            while (a != 0)
+            {
+                int64_t q = prev_a / a;
+                int64_t temp = prev_a % a;
+                prev_a = a;
+                a = temp;
+                temp = prev_b - b * q;
+                prev_b = b;
+                b = temp;
+                uint64_t a_mod = static_cast<uint64_t>(std::abs(a)) % t;
+                if (a < 0)
+                    a_mod = a_mod ? t - a_mod : 0;
+                uint64_t b_mod = static_cast<uint64_t>(std::abs(b)) % t;
+                if (b < 0)
+                    b_mod = b_mod ? t - b_mod : 0;
+                if (a_mod != 0 && std::__gcd(a_mod, t) == 1)
+                {
+                    int64_t new_sum = sum_abs(a_mod, b_mod);
+                    if (new_sum < sum)
+                    {
+                        sum = new_sum;
+                        e1 = a_mod;
+                        e2 = b_mod;
+                    }
+                }
+            }
+            f = host::mulmod(e1, factor1 % t, t);
         }
 
         NttBatch plain_batch(uint64_t *data, size_t outer_stride, unsigned ncomp, unsigned nouter, unsigned prime_first)
@@ -452,7 +499,21 @@ namespace sealhip
         if (e1.batch() != e2.batch())
             throw std::invalid_argument("batch mismatch");
         if (e1.correction_factor() != e2.correction_factor())
-            throw std::logic_error("BGV correction-factor balancing is not implemented on the device path");
+        {
+            // balance the correction factors and scale both operands first (BGV, evaluator.cpp:173-192)
+            uint64_t f, m1, m2;
+            balance_correction_factors(e1.correction_factor(), e2.correction_factor(), context_.plain_modulus(), f, m1, m2);
+            PlaneGeom gg{ (unsigned)context_.log_n(), e1.level()->K, (unsigned)e1.batch() };
+            if (e1.size())
+                ck(k_mul_scalar(context_.dev_mods(), e1.data(), e1.data(), m1, gg, (unsigned)e1.size(), stream_), "add: scale encrypted1");
+            Ciphertext copy(e2);
+            if (copy.size())
+                ck(k_mul_scalar(context_.dev_mods(), copy.data(), copy.data(), m2, gg, (unsigned)copy.size(), stream_), "add: scale encrypted2");
+            e1.correction_factor() = f;
+            copy.correction_factor() = f;
+            add_inplace(e1, copy);
+            return;
+        }
         size_t s1 = e1.size(), s2 = e2.size();
         size_t mx = std::max(s1, s2), mn = std::min(s1, s2);
         e1.resize(e1.level(), mx, stream_);
@@ -478,7 +539,21 @@ namespace sealhip
         if (e1.batch() != e2.batch())
             throw std::invalid_argument("batch mismatch");
         if (e1.correction_factor() != e2.correction_factor())
-            throw std::logic_error("BGV correction-factor balancing is not implemented on the device path");
+        {
+            // evaluator.cpp:259-278
+            uint64_t f, m1, m2;
+            balance_correction_factors(e1.correction_factor(), e2.correction_factor(), context_.plain_modulus(), f, m1, m2);
+            PlaneGeom gg{ (unsigned)context_.log_n(), e1.level()->K, (unsigned)e1.batch() };
+            if (e1.size())
+                ck(k_mul_scalar(context_.dev_mods(), e1.data(), e1.data(), m1, gg, (unsigned)e1.size(), stream_), "sub: scale encrypted1");
+            Ciphertext copy(e2);
+            if (copy.size())
+                ck(k_mul_scalar(context_.dev_mods(), copy.data(), copy.data(), m2, gg, (unsigned)copy.size(), stream_), "sub: scale encrypted2");
+            e1.correction_factor() = f;
+            copy.correction_factor() = f;
+            sub_inplace(e1, copy);
+            return;
+        }
         size_t s1 = e1.size(), s2 = e2.size();
         size_t mx = std::max(s1, s2), mn = std::min(s1, s2);
         e1.resize(e1.level(), mx, stream_);
@@ -532,7 +607,8 @@ namespace sealhip
             ckks_multiply(e1, e2);
             break;
         case Scheme::bgv:
-            throw std::logic_error("BGV multiply is not implemented on the device path");
+            bgv_multiply(e1, e2);
+            break;
         default:
             throw std::invalid_argument("unsupported scheme");
         }
@@ -616,6 +692,39 @@ namespace sealhip
         e1.scale() = new_scale;
         if (!scale_within_bounds(e1.scale(), lvl))
             throw std::invalid_argument("scale out of bounds");
+    }
+
+    // bgv_multiply / bgv_square (evaluator.cpp:710-841, 1079-1142): the tensor product of ckks_multiply on
+    // NTT-form operands; the scale is untouched and the correction factors multiply modulo t.
+    void Evaluator::bgv_multiply(Ciphertext &e1, const Ciphertext &e2) const
+    {
+        if (!(e1.is_ntt_form() && e2.is_ntt_form()))
+            throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
+        const Level &lvl = *e1.level();
+        size_t s1 = e1.size(), s2 = e2.size();
+        if (s1 < 2 || s2 < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+        size_t dest = s1 + s2 - 1;
+        if (dest > 16)
+            throw std::logic_error("invalid parameters");
+        const bool self = (&e1 == &e2);
+        const uint64_t cf = host::mulmod(e1.correction_factor(), e2.correction_factor(), context_.plain_modulus());
+        PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
+        if (dest == 3)
+        {
+            e1.resize(&lvl, 3, stream_);
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, e1.data(), self ? e1.data() : e2.data(), e1.data(), g, stream_),
+               "bgv_multiply");
+        }
+        else
+        {
+            size_t words = dest * g.words();
+            uint64_t *out = DevicePool::global().alloc_words(words);
+            ck(k_multiply_general(context_.dev_mods(), nullptr, e1.data(), (unsigned)s1, e2.data(), (unsigned)s2, out, g, stream_),
+               "bgv_multiply general");
+            e1.adopt(&lvl, dest, out, words);
+        }
+        e1.correction_factor() = cf;
     }
 
     void Evaluator::bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const
@@ -728,8 +837,6 @@ namespace sealhip
         const unsigned K = lvl.K, L = klvl.K;
         if (key.digits < K)
             throw std::invalid_argument("kswitch_keys inner dimension is too small");
-        if (scheme == Scheme::bgv)
-            throw std::logic_error("BGV key switching is not implemented on the device path");
         if (e.size() < 2)
             throw std::invalid_argument("encrypted size must be at least 2");
 
@@ -742,7 +849,8 @@ namespace sealhip
 
         // t_target: coefficient form of every decomposition digit (evaluator.cpp:2651-2658)
         Scratch t((size_t)B * K * N);
-        if (scheme == Scheme::ckks && ntt2_supports(context_.log_n()))
+        const bool ntt_target = scheme == Scheme::ckks || scheme == Scheme::bgv; // the target is in NTT form
+        if (ntt_target && ntt2_supports(context_.log_n()))
         {
             // out-of-place: the two-pass engine reads the target and writes t
             NttBatch bt = plain_batch(t.p, (size_t)K * N, K, B, 0);
@@ -753,7 +861,7 @@ namespace sealhip
         else
         {
             ck(hipMemcpyAsync(t.p, target, (size_t)B * K * N * 8, hipMemcpyDeviceToDevice, stream_), "ks copy target");
-            if (scheme == Scheme::ckks)
+            if (ntt_target)
                 ck(ntt_inverse(tb, plain_batch(t.p, (size_t)K * N, K, B, 0), 0, stream_), "ks intt target");
         }
 
@@ -766,7 +874,7 @@ namespace sealhip
             Scratch mid((size_t)B * (K + 1) * K * N);
             KsFusedArgs ka{};
             ka.t = t.p;
-            ka.target_ntt = scheme == Scheme::ckks ? target : nullptr;
+            ka.target_ntt = ntt_target ? target : nullptr; // the I == J shortcut of evaluator.cpp:2682-2685
             ka.key = key.dev;
             ka.mid = mid.p;
             ka.acc = acc.p;
@@ -806,7 +914,20 @@ namespace sealhip
 
         // mod-down by the special prime P and accumulate into (c0, c1) (evaluator.cpp:2806-2864)
         const uint64_t P = context_.coeff_modulus()[L - 1];
-        if (scheme == Scheme::ckks)
+        if (scheme == Scheme::bgv)
+        {
+            // evaluator.cpp:2762-2805: t_last = INTT_P(S_k[P]); delta = (-(t_last mod t) P^-1 mod t) P + t_last (mod q_i);
+            // ct_k[i] += (S_k[q_i] - NTT_i(delta)) P^-1
+            NttBatch bi = plain_batch(acc.p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
+            ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
+            Scratch delta((size_t)B * 2 * K * N);
+            ck(k_bgv_delta(mods, host::make_mod(context_.plain_modulus()), klvl.dev.inv_q_last_mod_t, klvl.dev.q_last_mod_q,
+                           acc.p + (size_t)K * N, (size_t)(K + 1) * N, delta.p, n_log, K, (size_t)2 * B, stream_),
+               "ks bgv delta");
+            bgv_correct_and_combine(delta, acc.p, (size_t)(K + 1) * N, klvl.dev.inv_q_last_mod_q, K, 2 * B, e.plane(0), e.plane(1),
+                                    (size_t)K * N, 2);
+        }
+        else if (scheme == Scheme::ckks)
         {
             NttBatch bi = plain_batch(acc.p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
             ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
@@ -857,6 +978,50 @@ namespace sealhip
         }
     }
 
+    // NTT the BGV correction polynomials `delta` ([items][ncomp][N], coefficient form, canonical) and fold them
+    // into the resident operand: v = (A - NTT(delta)) * mul  (mod q_i), A = a + item*a_stride + comp*N;
+    //   epi 1: out0[item][comp] = v;   epi 2: ct_{item&1}[item>>1][comp] += v
+    void Evaluator::bgv_correct_and_combine(
+        Scratch &delta, const uint64_t *a, size_t a_stride, const ShoupOp *mul, unsigned ncomp, size_t items, uint64_t *out0,
+        uint64_t *out1, size_t out_stride, int epi) const
+    {
+        const size_t N = context_.n();
+        const unsigned n_log = (unsigned)context_.log_n();
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        if (ntt2_supports(context_.log_n()))
+        {
+            NttBatch b{};
+            b.data = nullptr;
+            b.outer_stride = (size_t)ncomp * N;
+            b.ncomp = ncomp;
+            b.nouter = (unsigned)items;
+            b.prime_first = 0;
+            b.src = delta.p;
+            b.src_outer_stride = (size_t)ncomp * N;
+            b.src_ncomp = ncomp;
+            b.src_mode = 0;
+            b.epi = epi;
+            b.epi_a = a;
+            b.epi_a_stride = a_stride;
+            b.epi_mul = mul;
+            b.epi_out0 = out0;
+            b.epi_out1 = out1;
+            b.epi_out_stride = out_stride;
+            ck(ntt_forward(tb, b, 1, stream_), "bgv ntt correction + combine");
+            return;
+        }
+        ck(ntt_forward(tb, plain_batch(delta.p, (size_t)ncomp * N, ncomp, (unsigned)items, 0), 1, stream_), "bgv ntt correction");
+        if (epi == 1)
+        {
+            if (a_stride != (size_t)(ncomp + 1) * N)
+                throw std::logic_error("bgv combine layout");
+            ck(k_rescale_combine(mods, mul, a, delta.p, out0, n_log, ncomp + 1, items, stream_), "bgv combine");
+        }
+        else
+            ck(k_keyswitch_tail_ckks(mods, mul, out0, out1, a, delta.p, n_log, ncomp, (unsigned)(items / 2), stream_), "bgv ks tail");
+    }
+
     // ---- modulus switching (evaluator.cpp:1201-1647)
     void Evaluator::mod_switch_scale_to_next(Ciphertext &e) const
     {
@@ -878,9 +1043,6 @@ namespace sealhip
             if (!scale_within_bounds(destination_scale, *next))
                 throw std::invalid_argument("scale out of bounds");
         }
-        if (scheme == Scheme::bgv)
-            throw std::logic_error("BGV mod switching is not implemented on the device path");
-
         const unsigned K = lvl.K;
         const size_t N = context_.n();
         const size_t items = e.size() * e.batch();
@@ -893,6 +1055,19 @@ namespace sealhip
             if (scheme == Scheme::bfv)
             {
                 ck(k_bfv_modswitch(mods, lvl.dev, e.data(), out, n_log, items, stream_), "bfv modswitch");
+            }
+            else if (scheme == Scheme::bgv)
+            {
+                // mod_t_and_divide_q_last_ntt_inplace (rns.cpp:1193-1236)
+                const NttTables &tb = context_.ntt_tables();
+                uint64_t *last = e.data() + (size_t)(K - 1) * N;
+                ck(ntt_inverse(tb, plain_batch(last, (size_t)K * N, 1, (unsigned)items, K - 1), 0, stream_), "bgv modswitch intt last");
+                Scratch delta(words);
+                ck(k_bgv_delta(mods, host::make_mod(context_.plain_modulus()), lvl.dev.inv_q_last_mod_t, lvl.dev.q_last_mod_q, last,
+                               (size_t)K * N, delta.p, n_log, K - 1, items, stream_),
+                   "bgv modswitch delta");
+                bgv_correct_and_combine(delta, e.data(), (size_t)K * N, lvl.dev.inv_q_last_mod_q, K - 1, items, out, nullptr,
+                                        (size_t)(K - 1) * N, 1);
             }
             else
             {
@@ -943,6 +1118,9 @@ namespace sealhip
         e.adopt(next, size, out, words);
         if (scheme == Scheme::ckks)
             e.scale() = destination_scale;
+        else if (scheme == Scheme::bgv)
+            // evaluator.cpp:1286-1292
+            e.correction_factor() = host::mulmod(e.correction_factor(), lvl.dev.inv_q_last_mod_t, context_.plain_modulus());
     }
 
     void Evaluator::mod_switch_drop_to_next(Ciphertext &e) const

@@ -140,6 +140,10 @@ namespace sealhip
         void check_valid(const Ciphertext &ct, const char *what) const;
         bool scale_within_bounds(double scale, const Level &lvl) const;
         void bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const;
+        void bgv_multiply(Ciphertext &e1, const Ciphertext &e2) const;
+        void bgv_correct_and_combine(
+            Scratch &delta, const uint64_t *a, size_t a_stride, const ShoupOp *mul, unsigned ncomp, size_t items, uint64_t *out0,
+            uint64_t *out1, size_t out_stride, int epi) const;
         void ckks_multiply(Ciphertext &e1, const Ciphertext &e2) const;
         void mod_switch_scale_to_next(Ciphertext &encrypted) const;
         void mod_switch_drop_to_next(Ciphertext &encrypted) const;

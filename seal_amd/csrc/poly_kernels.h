@@ -39,6 +39,10 @@ namespace sealhip
     hipError_t k_addsub(
         const ModDesc *mods, const uint64_t *a, const uint64_t *b, uint64_t *r, int op, PlaneGeom g, unsigned planes,
         hipStream_t s);
+    // r = a * (scalar mod q_i) mod q_i over `planes` planes (multiply_poly_scalar_coeffmod,
+    // util/polyarithsmallmod.h:440-448 / .cpp:197-224); r may be a.
+    hipError_t k_mul_scalar(
+        const ModDesc *mods, const uint64_t *a, uint64_t *r, uint64_t scalar, PlaneGeom g, unsigned planes, hipStream_t s);
     // Galois automorphism on `planes` planes; ntt_form selects the NTT-domain gather or the
     // coefficient-domain signed scatter.  in != out.
     hipError_t k_apply_galois(
@@ -50,6 +54,13 @@ namespace sealhip
     hipError_t k_rescale_combine(
         const ModDesc *mods, const ShoupOp *inv_q_last, const uint64_t *c, const uint64_t *t, uint64_t *out,
         unsigned n_log, unsigned K, size_t items, hipStream_t s);
+    // BGV correction polynomial of mod_t_and_divide_q_last_ntt_inplace (rns.cpp:1203-1229) and of the
+    // BGV key-switch mod-down (evaluator.cpp:2762-2791), coefficient form:
+    //   k = -(c mod t) * q_last^-1 mod t;   delta[item][i] = ((k mod q_i) * (q_last mod q_i) + (c mod q_i)) mod q_i
+    // c = c_last + item*c_stride, canonical mod q_last; delta [items][ncomp][N] canonical.
+    hipError_t k_bgv_delta(
+        const ModDesc *mods, ModDesc t, uint64_t inv_q_last_mod_t, const uint64_t *q_last_mod_q, const uint64_t *c_last,
+        size_t c_stride, uint64_t *delta, unsigned n_log, unsigned ncomp, size_t items, hipStream_t s);
     // BFV mod-switch (coefficient domain), whole formula in one kernel.
     hipError_t k_bfv_modswitch(
         const ModDesc *mods, const LevelDev &lv, const uint64_t *c, uint64_t *out, unsigned n_log, size_t items,

@@ -158,6 +158,36 @@ namespace sealhip
             }
         }
 
+        __global__ void __launch_bounds__(kBlock) mul_scalar_kernel(
+            const ModDesc *mods, const uint64_t *a, uint64_t *r, uint64_t scalar, unsigned n_log, unsigned K, size_t words)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const ModDesc md = mods[(i >> n_log) % K];
+                r[i] = mul_mod(a[i], barrett64(scalar, md), md);
+            }
+        }
+
+        __global__ void __launch_bounds__(kBlock) bgv_delta_kernel(
+            const ModDesc *mods, ModDesc t, uint64_t inv_t, const uint64_t *q_last_mod_q, const uint64_t *c_last, size_t c_stride,
+            uint64_t *delta, unsigned n_log, unsigned ncomp, size_t out_words)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < out_words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t row = i >> n_log; // item*ncomp + comp
+                const unsigned comp = (unsigned)(row % ncomp);
+                const size_t item = row / ncomp;
+                const size_t j = i & ((size_t(1) << n_log) - 1);
+                const ModDesc md = mods[comp];
+                const uint64_t c = c_last[item * c_stride + j];
+                uint64_t k = neg_mod(barrett64(c, t), t.q);
+                if (inv_t != 1)
+                    k = mul_mod(k, inv_t, t);
+                const uint64_t d = mul_mod(barrett64(k, md), q_last_mod_q[comp], md);
+                delta[i] = add_mod(d, barrett64(c, md), md.q);
+            }
+        }
+
         __global__ void __launch_bounds__(kBlock) bfv_modswitch_kernel(
             const ModDesc *mods, const ShoupOp *inv_q_last, const uint64_t *half_mod_q, uint64_t q_last, uint64_t half,
             const uint64_t *c, uint64_t *out, unsigned n_log, unsigned K, size_t out_words)
@@ -354,6 +384,27 @@ namespace sealhip
         if (!w)
             return hipSuccess;
         hipLaunchKernelGGL(rescale_combine_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, inv_q_last, c, t, out, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_mul_scalar(
+        const ModDesc *mods, const uint64_t *a, uint64_t *r, uint64_t scalar, PlaneGeom g, unsigned planes, hipStream_t s)
+    {
+        size_t w = g.words() * planes;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(mul_scalar_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, a, r, scalar, g.n_log, g.K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_bgv_delta(
+        const ModDesc *mods, ModDesc t, uint64_t inv_q_last_mod_t, const uint64_t *q_last_mod_q, const uint64_t *c_last,
+        size_t c_stride, uint64_t *delta, unsigned n_log, unsigned ncomp, size_t items, hipStream_t s)
+    {
+        size_t w = (items * ncomp) << n_log;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(
+            bgv_delta_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, t, inv_q_last_mod_t, q_last_mod_q, c_last, c_stride, delta,
+            n_log, ncomp, w);
         return hipGetLastError();
     }
     hipError_t k_bfv_modswitch(

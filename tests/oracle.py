@@ -97,12 +97,20 @@ class Oracle:
         # chain_index of the level with K data primes: key level (K == L) has the highest index
         return self.ref.key_chain_index - (self.L - K)
 
-    def _ct(self, data, scale=None):
+    def _ct(self, data, scale=None, cf=1):
         K = data.shape[1]
-        is_ntt = self.scheme == "ckks"
+        is_ntt = self.scheme in ("ckks", "bgv")
         if scale is None:
             scale = 2.0 ** 20 if self.scheme == "ckks" else 1.0
-        return self.ref.ct(self._ci(K), data, is_ntt, scale)
+        return self.ref.ct(self._ci(K), data, is_ntt, scale, cf)
+
+    def run(self, op, operands, *args):
+        """Generic reference call (reference kind only): operands = [(data, correction_factor), ...];
+        op = name of a RefContext in-place method; returns (data, info dict) of the first operand."""
+        assert self.kind == "reference"
+        cts = [self._ct(d, None, cf) for d, cf in operands]
+        getattr(self.ref, op)(*cts, *args)
+        return cts[0].data(), cts[0].info()
 
     # ---- L1
     def ntt(self, first, data, mode):

@@ -190,6 +190,87 @@ def case_bfv_pipeline(n, primes, t, batch=2, seed=4):
         _eq(nxt[b], o.multiply(cur[b], cur[b]), "bfv square item %d" % b)
 
 
+# ---- BGV: BGVEncryptMultiplyDecrypt / BGVRelinearize / BGVEncryptModSwitchToNextDecrypt / BGVEncryptRotateMatrixDecrypt /
+#      BGVEncryptAddDecrypt with unequal correction factors (native/tests/seal/evaluator.cpp, BGV cases) at ciphertext level.
+#      Reference oracle only (the plain-C restatement does not cover BGV).
+def case_bgv_pipeline(n, primes, t, batch=2, seed=6):
+    L = len(primes)
+    K = L - 1
+    probe = Oracle("bgv", n, primes, t)
+    assert probe.kind == "reference", "BGV parity needs oracle/_ref"
+    elts = [probe.galois_elt_from_step(1), 2 * n - 1]
+    o = Oracle("bgv", n, primes, t, galois_elts=elts)
+    d = DeviceSide("bgv", n, primes, t)
+    d.upload_keys(o)
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    cfx, cfy = 3, 5 % t if t > 5 else 1
+
+    def dev(slabs, cf):
+        c = d.ct(slabs, is_ntt=True)
+        c.set_correction_factor(cf)
+        return c
+
+    # add / sub with unequal correction factors: balance_correction_factors (evaluator.cpp:50-117, 173-192)
+    for op in ("add_inplace", "sub_inplace"):
+        cx, cy = dev(xs, cfx), dev(ys, cfy)
+        getattr(d.ev, op)(cx, cy)
+        got = d.out(cx)
+        for b in range(batch):
+            exp, info = o.run(op, [(xs[b], cfx), (ys[b], cfy)])
+            _eq(got[b], exp, "bgv %s item %d" % (op, b))
+            assert cx.correction_factor() == info["correction_factor"], op
+
+    cx, cy = dev(xs, cfx), dev(ys, cfy)
+    d.ev.multiply_inplace(cx, cy)  # bgv_multiply, evaluator.cpp:710
+    assert cx.size() == 3 and cx.is_ntt_form()
+    cur = d.out(cx)
+    for b in range(batch):
+        exp, info = o.run("multiply_inplace", [(xs[b], cfx), (ys[b], cfy)])
+        _eq(cur[b], exp, "bgv multiply item %d" % b)
+        assert cx.correction_factor() == info["correction_factor"]
+    cf = cx.correction_factor()
+
+    d.ev.relinearize_inplace(cx, d.rlk)  # switch_key_inplace BGV branch, evaluator.cpp:2762
+    nxt = d.out(cx)
+    for b in range(batch):
+        exp, info = o.run("relinearize_inplace", [(cur[b], cf)])
+        _eq(nxt[b], exp, "bgv relinearize item %d" % b)
+    cur = nxt
+
+    d.ev.rotate_rows_inplace(cx, 1, d.glk)
+    nxt = d.out(cx)
+    for b in range(batch):
+        exp, _ = o.run("apply_galois_inplace", [(cur[b], cf)], elts[0])
+        _eq(nxt[b], exp, "bgv rotate_rows(1) item %d" % b)
+    cur = nxt
+
+    d.ev.rotate_columns_inplace(cx, d.glk)
+    nxt = d.out(cx)
+    for b in range(batch):
+        exp, _ = o.run("apply_galois_inplace", [(cur[b], cf)], elts[1])
+        _eq(nxt[b], exp, "bgv rotate_columns item %d" % b)
+    cur = nxt
+
+    if K >= 2:
+        d.ev.mod_switch_to_next_inplace(cx)  # mod_t_and_divide_q_last_ntt_inplace, rns.cpp:1193
+        assert cx.coeff_modulus_size() == K - 1
+        nxt = d.out(cx)
+        for b in range(batch):
+            exp, info = o.run("mod_switch_to_next_inplace", [(cur[b], cf)])
+            _eq(nxt[b], exp, "bgv mod_switch_to_next item %d" % b)
+            assert cx.correction_factor() == info["correction_factor"]
+        cur, cf = nxt, cx.correction_factor()
+
+    d.ev.square_inplace(cx)  # bgv_square, evaluator.cpp:1079
+    nxt = d.out(cx)
+    for b in range(batch):
+        exp, info = o.run("square_inplace", [(cur[b], cf)])
+        _eq(nxt[b], exp, "bgv square item %d" % b)
+        assert cx.correction_factor() == info["correction_factor"]
+
+
 # ---- BEHZ stages: native/tests/seal/util/rns.cpp:460-854
 def case_rns_stages(n, primes, t, seed=5):
     L = len(primes)

@@ -98,6 +98,19 @@ def test_bfv_pipeline(emu, n, bits, tb, batch):
     P.case_bfv_pipeline(n, primes, t, batch=batch)
 
 
+@pytest.mark.parametrize("n,bits,tb,batch", [
+    (16, [30, 30, 30, 30], 12, 2),
+    (1024, [40, 40, 41, 42], 16, 1),
+    (8192, [50, 55, 56], 20, 1),      # two-pass engine: fused epilogues with the BGV correction as the source
+])
+def test_bgv_pipeline(emu, n, bits, tb, batch):
+    import sealref
+    if not sealref.available():
+        pytest.skip("BGV parity needs the real reference (oracle/_ref)")
+    primes, t = P.default_bfv_params(n, bits, tb)
+    P.case_bgv_pipeline(n, primes, t, batch=batch)
+
+
 def test_rns_stages(emu):
     primes, t = P.default_bfv_params(64, [40, 40, 40, 40], 13)
     P.case_rns_stages(64, primes, t)

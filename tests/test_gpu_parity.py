@@ -93,6 +93,20 @@ def test_bfv_config4(gpu):
     P.case_bfv_pipeline(32768, primes, t, batch=1)
 
 
+# ---- BGV pipelines (SURVEY §8a E2, E6 BGV branch, E8 BGV branch): small, single-pass and two-pass engine sizes
+@pytest.mark.parametrize("n,bits,tb,batch", [
+    (16, [30, 30, 30, 30], 12, 3),
+    (4096, [36, 36, 37], 20, 2),
+    (8192, [50, 55, 56, 60], 20, 2),
+    (32768, [55] * 6, 20, 1),
+])
+def test_bgv_pipeline(gpu, n, bits, tb, batch):
+    if not R.available():
+        pytest.skip("BGV parity needs the real reference (oracle/_ref)")
+    primes, t = P.default_bfv_params(n, bits, tb)
+    P.case_bgv_pipeline(n, primes, t, batch=batch)
+
+
 def test_rns_stages(gpu):
     primes, t = P.default_bfv_params(2048, [50, 50, 50, 50], 20)
     P.case_rns_stages(2048, primes, t)
