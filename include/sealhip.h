@@ -132,6 +132,10 @@ SHL_FUNC KSwitchKeys_Destroy(void *thisptr);
 SHL_FUNC KSwitchKeys_Size(void *thisptr, uint64_t *size);
 SHL_FUNC KSwitchKeys_SetKey(void *thisptr, void *context, uint64_t index, uint64_t digits, const uint64_t *host_words);
 SHL_FUNC KSwitchKeys_SetKeyFromDevice(void *thisptr, void *context, uint64_t index, uint64_t digits, const uint64_t *device_words);
+/* digit-parallel key switching (section 1b): upload only the decomposition digits [digit_first, digit_first + digits)
+ * of key `index` (host_words = those digits, [digits][2][L][N]); this rank then serves exactly that digit range */
+SHL_FUNC KSwitchKeys_SetKeyDigits(void *thisptr, void *context, uint64_t index, uint64_t digit_first, uint64_t digits,
+                                  const uint64_t *host_words);
 SHL_FUNC KSwitchKeys_HasKey(void *thisptr, uint64_t index, bool *has_key);
 SHL_FUNC RelinKeys_GetIndex(uint64_t key_power, uint64_t *index);
 SHL_FUNC GaloisKeys_GetIndex(uint32_t galois_elt, uint64_t *index);
@@ -165,6 +169,24 @@ SHL_FUNC Evaluator_RotateColumns(void *thisptr, void *encrypted, void *galois_ke
 SHL_FUNC Evaluator_RotateVector(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *destination, void *pool);
 SHL_FUNC Evaluator_ComplexConjugate(void *thisptr, void *encrypted, void *galoisKeys, void *destination, void *pool);
 SHL_FUNC Evaluator_ContextUsingKeyswitching(void *thisptr, bool *using_keyswitching);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1b. Digit-parallel key switching over the GPUs of one node (BASELINE configs[4]).
+ * switch_key_inplace (native/src/seal/evaluator.cpp:2561-2867) is linear in the decomposition digits J up to its
+ * mod-down tail, so the digits can be spread over ranks: every rank holds the same ciphertext, computes the
+ * canonical partial sums S_k[I] = sum_{J in its range} NTT_I(t_J mod q_I) * key[J][k][I] for all K+1 target moduli
+ * (`*Partial`), the ranks add their buffers (ONE all-reduce of 2 (K+1) N words per ciphertext, done by the caller,
+ * e.g. torch.distributed.all_reduce over RCCL), and every rank finishes locally (`*Finish`: reduce mod q_I, mod-down by
+ * the special prime, accumulate into (c0, c1)).  device_acc = caller-owned device buffer of Evaluator_SwitchKeyAccWords
+ * 64-bit words; parts = number of summed buffers (<= 8: eight residues below 2^60 still fit one word).
+ * Results equal Evaluator_Relinearize / Evaluator_ApplyGalois bit for bit. */
+SHL_FUNC Evaluator_SwitchKeyAccWords(void *thisptr, void *encrypted, uint64_t *words);
+SHL_FUNC Evaluator_RelinearizePartial(void *thisptr, void *encrypted /* size 3 */, void *relinKeys, uint64_t digit_first,
+                                      uint64_t digit_count, uint64_t *device_acc);
+SHL_FUNC Evaluator_RelinearizeFinish(void *thisptr, void *encrypted, uint64_t *device_acc, uint64_t parts);
+SHL_FUNC Evaluator_ApplyGaloisPartial(void *thisptr, void *encrypted /* size 2 */, uint32_t galois_elt, void *galoisKeys,
+                                      uint64_t digit_first, uint64_t digit_count, uint64_t *device_acc);
+SHL_FUNC Evaluator_ApplyGaloisFinish(void *thisptr, void *encrypted, uint64_t *device_acc, uint64_t parts);
 
 /* ------------------------------------------------------------------------------------------------
  * 2. Per-kernel seam on raw device slabs (device pointers; `stream` is a hipStream_t or NULL)

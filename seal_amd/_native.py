@@ -63,13 +63,15 @@ Ciphertext_IsNTTForm Ciphertext_SetIsNTTForm Ciphertext_Scale Ciphertext_SetScal
 Ciphertext_SetCorrectionFactor Ciphertext_IsTransparent Ciphertext_DevicePtr Ciphertext_CopyFromHost
 Ciphertext_CopyToHost Ciphertext_CopyFromDevice
 KSwitchKeys_Create1 KSwitchKeys_Destroy KSwitchKeys_Size KSwitchKeys_SetKey KSwitchKeys_SetKeyFromDevice
-KSwitchKeys_HasKey RelinKeys_GetIndex GaloisKeys_GetIndex GaloisTool_GetEltFromStep
+KSwitchKeys_SetKeyDigits KSwitchKeys_HasKey RelinKeys_GetIndex GaloisKeys_GetIndex GaloisTool_GetEltFromStep
 Evaluator_Create Evaluator_Destroy Evaluator_SetStream Evaluator_Synchronize Evaluator_SetTransparentCheck
 Evaluator_Negate Evaluator_Add Evaluator_Sub Evaluator_Multiply Evaluator_Square Evaluator_Relinearize
 Evaluator_ModSwitchToNext1 Evaluator_ModSwitchTo1 Evaluator_RescaleToNext Evaluator_RescaleTo
 Evaluator_ModReduceToNext Evaluator_TransformToNTT2 Evaluator_TransformFromNTT Evaluator_ApplyGalois
 Evaluator_RotateRows Evaluator_RotateColumns Evaluator_RotateVector Evaluator_ComplexConjugate
 Evaluator_ContextUsingKeyswitching
+Evaluator_SwitchKeyAccWords Evaluator_RelinearizePartial Evaluator_RelinearizeFinish Evaluator_ApplyGaloisPartial
+Evaluator_ApplyGaloisFinish
 shl_ntt_forward shl_ntt_inverse shl_dyadic_product shl_apply_galois shl_rns_stage shl_malloc shl_free
 shl_memcpy_h2d shl_memcpy_d2h shl_device_synchronize shl_timer_create shl_timer_destroy shl_timer_start
 shl_timer_stop

@@ -273,6 +273,12 @@ class KSwitchKeys:
         a = np.ascontiguousarray(array, dtype=np.uint64)
         N.check(N.lib().KSwitchKeys_SetKey(self._h, self.context._h, C.c_uint64(index), C.c_uint64(a.shape[0]), _p(a)))
 
+    def set_key_digits(self, index, digit_first, array):
+        """upload only the digits [digit_first, digit_first + len(array)) of key `index` (digit-parallel key switching)"""
+        a = np.ascontiguousarray(array, dtype=np.uint64)
+        N.check(N.lib().KSwitchKeys_SetKeyDigits(self._h, self.context._h, C.c_uint64(index), C.c_uint64(digit_first),
+                                                 C.c_uint64(a.shape[0]), _p(a)))
+
     def set_key_device(self, index, digits, device_ptr):
         N.check(N.lib().KSwitchKeys_SetKeyFromDevice(self._h, self.context._h, C.c_uint64(index), C.c_uint64(digits),
                                                      C.c_void_p(device_ptr)))
@@ -430,6 +436,26 @@ class Evaluator:
     def rotate_vector_inplace(self, a, steps, galois_keys):
         N.check(N.lib().Evaluator_RotateVector(self._h, a._h, C.c_int(steps), galois_keys._h, a._h, None))
         return a
+
+    # ---- digit-parallel key switching (sealhip.h section 1b); acc_ptr = device pointer of switch_key_acc_words words
+    def switch_key_acc_words(self, a):
+        v = C.c_uint64()
+        N.check(N.lib().Evaluator_SwitchKeyAccWords(self._h, a._h, C.byref(v)))
+        return v.value
+
+    def relinearize_partial(self, a, relin_keys, digit_first, digit_count, acc_ptr):
+        N.check(N.lib().Evaluator_RelinearizePartial(self._h, a._h, relin_keys._h, C.c_uint64(digit_first), C.c_uint64(digit_count),
+                                                     C.c_void_p(acc_ptr)))
+
+    def relinearize_finish(self, a, acc_ptr, parts):
+        N.check(N.lib().Evaluator_RelinearizeFinish(self._h, a._h, C.c_void_p(acc_ptr), C.c_uint64(parts)))
+
+    def apply_galois_partial(self, a, galois_elt, galois_keys, digit_first, digit_count, acc_ptr):
+        N.check(N.lib().Evaluator_ApplyGaloisPartial(self._h, a._h, C.c_uint32(galois_elt), galois_keys._h, C.c_uint64(digit_first),
+                                                     C.c_uint64(digit_count), C.c_void_p(acc_ptr)))
+
+    def apply_galois_finish(self, a, acc_ptr, parts):
+        N.check(N.lib().Evaluator_ApplyGaloisFinish(self._h, a._h, C.c_void_p(acc_ptr), C.c_uint64(parts)))
 
     def complex_conjugate_inplace(self, a, galois_keys):
         N.check(N.lib().Evaluator_ComplexConjugate(self._h, a._h, galois_keys._h, a._h, None))

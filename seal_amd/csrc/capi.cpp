@@ -555,6 +555,16 @@ extern "C"
         as<KSwitchKeys>(thisptr)->set_key(*as<Context>(context), index, digits, device_words, true);
         SHL_CATCH
     }
+    SHL_FUNC KSwitchKeys_SetKeyDigits(void *thisptr, void *context, uint64_t index, uint64_t digit_first, uint64_t digits,
+                                      const uint64_t *host_words)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(host_words, SHL_E_POINTER);
+        SHL_TRY
+        as<KSwitchKeys>(thisptr)->set_key(*as<Context>(context), index, digits, host_words, false, digit_first);
+        SHL_CATCH
+    }
     SHL_FUNC KSwitchKeys_HasKey(void *thisptr, uint64_t index, bool *has_key)
     {
         IfNullRet(thisptr, SHL_E_POINTER);
@@ -709,6 +719,57 @@ extern "C"
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
         as<Evaluator>(thisptr)->relinearize_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(relinKeys));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_SwitchKeyAccWords(void *thisptr, void *encrypted, uint64_t *words)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(words, SHL_E_POINTER);
+        SHL_TRY
+        *words = as<Evaluator>(thisptr)->switch_key_acc_words(*as<Ciphertext>(encrypted));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_RelinearizePartial(void *thisptr, void *encrypted, void *relinKeys, uint64_t digit_first, uint64_t digit_count,
+                                          uint64_t *device_acc)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(relinKeys, SHL_E_POINTER);
+        IfNullRet(device_acc, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->relinearize_partial(*as<Ciphertext>(encrypted), *as<KSwitchKeys>(relinKeys), (unsigned)digit_first,
+                                                    (unsigned)(digit_first + digit_count), device_acc);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_RelinearizeFinish(void *thisptr, void *encrypted, uint64_t *device_acc, uint64_t parts)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(device_acc, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->relinearize_finish(*as<Ciphertext>(encrypted), device_acc, (unsigned)parts);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ApplyGaloisPartial(void *thisptr, void *encrypted, uint32_t galois_elt, void *galoisKeys, uint64_t digit_first,
+                                          uint64_t digit_count, uint64_t *device_acc)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(galoisKeys, SHL_E_POINTER);
+        IfNullRet(device_acc, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->apply_galois_partial(*as<Ciphertext>(encrypted), galois_elt, *as<KSwitchKeys>(galoisKeys),
+                                                     (unsigned)digit_first, (unsigned)(digit_first + digit_count), device_acc);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ApplyGaloisFinish(void *thisptr, void *encrypted, uint64_t *device_acc, uint64_t parts)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(device_acc, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->apply_galois_finish(*as<Ciphertext>(encrypted), device_acc, (unsigned)parts);
         SHL_CATCH
     }
     SHL_FUNC Evaluator_ModSwitchTo1(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool)

@@ -267,7 +267,7 @@ namespace sealhip
             c += k.dev != nullptr;
         return c;
     }
-    void KSwitchKeys::set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device)
+    void KSwitchKeys::set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device, size_t digit0)
     {
         if (!ctx.using_keyswitching())
             throw std::logic_error("keyswitching is not supported by the context");
@@ -297,6 +297,7 @@ namespace sealhip
             ck(hipMemcpy(p, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key");
         keys_[index].dev = (uint64_t *)p;
         keys_[index].digits = digits;
+        keys_[index].digit0 = digit0;
         keys_[index].register_order = reorder;
     }
 
@@ -810,12 +811,76 @@ namespace sealhip
         throw_if_transparent(e);
     }
 
-    // ---- switch_key_inplace (evaluator.cpp:2561-2867)
-    void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const
+    void Evaluator::relinearize_partial(Ciphertext &e, const KSwitchKeys &relin_keys, unsigned j0, unsigned j1, uint64_t *acc) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (relin_keys.context() != &context_)
+            throw std::invalid_argument("relin_keys is not valid for encryption parameters");
+        if (e.size() != 3)
+            throw std::invalid_argument("digit-parallel relinearization takes a size-3 ciphertext");
+        switch_key_partial(e, e.plane(2), relin_keys, relin_index(2), j0, j1, acc);
+    }
+    void Evaluator::relinearize_finish(Ciphertext &e, uint64_t *acc, unsigned parts) const
+    {
+        if (&e.context() != &context_ || !e.level() || e.size() != 3)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        switch_key_finish(e, acc, parts);
+        e.resize(e.level(), 2, stream_);
+        throw_if_transparent(e);
+    }
+    void Evaluator::apply_galois_partial(
+        Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys, unsigned j0, unsigned j1, uint64_t *acc) const
+    {
+        check_valid(e, "encrypted");
+        if (galois_keys.context() != &context_)
+            throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+        uint64_t m = 2 * (uint64_t)context_.n();
+        if (!(galois_elt & 1) || galois_elt >= m)
+            throw std::invalid_argument("Galois element is not valid");
+        if (!galois_keys.has_key(galois_index(galois_elt)))
+            throw std::invalid_argument("Galois key not present");
+        if (e.size() != 2)
+            throw std::invalid_argument("encrypted size must be 2");
+        const Scheme scheme = context_.scheme();
+        PlaneGeom g{ (unsigned)context_.log_n(), e.level()->K, (unsigned)e.batch() };
+        const int ntt_form = scheme == Scheme::bfv ? 0 : 1;
+        if ((ntt_form != 0) != e.is_ntt_form())
+            throw std::invalid_argument(ntt_form ? "encrypted must be in NTT form" : "BFV encrypted cannot be in NTT form");
+        Scratch perm(2 * g.words()); // [pi(c0), pi(c1)]
+        ck(k_apply_galois(context_.dev_mods(), e.data(), perm.p, galois_elt, ntt_form, g, 2, stream_), "apply_galois");
+        ck(hipMemcpyAsync(e.plane(0), perm.p, g.words() * 8, hipMemcpyDeviceToDevice, stream_), "galois copy c0");
+        ck(hipMemsetAsync(e.plane(1), 0, g.words() * 8, stream_), "galois zero c1");
+        switch_key_partial(e, perm.p + g.words(), galois_keys, galois_index(galois_elt), j0, j1, acc);
+    }
+    void Evaluator::apply_galois_finish(Ciphertext &e, uint64_t *acc, unsigned parts) const
+    {
+        if (&e.context() != &context_ || !e.level() || e.size() != 2)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        switch_key_finish(e, acc, parts);
+        throw_if_transparent(e);
+    }
+
+    // ---- switch_key_inplace (evaluator.cpp:2561-2867), in two halves so that the decomposition digits can be
+    // spread over the GPUs of a node: partial = the I/J loop restricted to the digits [j0, j1)
+    // (canonical partial sums S_k[I]), finish = mod-down by the special prime and accumulation into (c0, c1).
+    // Between the halves the caller may add the partial sums of several ranks (one all-reduce of 2(K+1)N words).
+    size_t Evaluator::switch_key_acc_words(const Ciphertext &e) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        return (size_t)e.batch() * 2 * (e.level()->K + 1) * context_.n();
+    }
+
+    void Evaluator::switch_key_partial(
+        const Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, unsigned j0, unsigned j1,
+        uint64_t *acc_out) const
     {
         check_valid(e, "encrypted");
         if (!target)
             throw std::invalid_argument("target_iter");
+        if (!acc_out)
+            throw std::invalid_argument("acc");
         if (!context_.using_keyswitching())
             throw std::logic_error("keyswitching is not supported by the context");
         if (keys.context() != &context_)
@@ -835,7 +900,9 @@ namespace sealhip
         const Level &lvl = *e.level();
         const Level &klvl = context_.key_level();
         const unsigned K = lvl.K, L = klvl.K;
-        if (key.digits < K)
+        if (j1 > K || j0 > j1)
+            throw std::invalid_argument("digit range");
+        if (j0 < j1 && (key.digit0 > j0 || key.digit0 + key.digits < j1))
             throw std::invalid_argument("kswitch_keys inner dimension is too small");
         if (e.size() < 2)
             throw std::invalid_argument("encrypted size must be at least 2");
@@ -865,7 +932,6 @@ namespace sealhip
                 ck(ntt_inverse(tb, plain_batch(t.p, (size_t)K * N, K, B, 0), 0, stream_), "ks intt target");
         }
 
-        Scratch acc((size_t)B * 2 * (K + 1) * N);
         if (key.register_order)
         {
             // fused path (ntt2_kernels.hip): the K(K+1) raised digits go through HBM once, between
@@ -877,7 +943,7 @@ namespace sealhip
             ka.target_ntt = ntt_target ? target : nullptr; // the I == J shortcut of evaluator.cpp:2682-2685
             ka.key = key.dev;
             ka.mid = mid.p;
-            ka.acc = acc.p;
+            ka.acc = acc_out;
             ka.targets1 = kt.dev;
             ka.targets2 = kt.dev + 2 * (kt.n_int + kt.n_fp);
             ka.ntargets = kt.n_int + kt.n_fp;
@@ -885,15 +951,17 @@ namespace sealhip
             ka.K = K;
             ka.L = L;
             ka.batch = B;
+            ka.j0 = j0;
+            ka.j1 = j1;
+            ka.key_digit0 = (unsigned)key.digit0;
             ck(ks_fused(tb, ka, stream_), "ks fused");
         }
         else
         {
-        // u[b][I][J] = NTT_I(t_J mod q_I), I over the K data primes and the special prime
-        // (evaluator.cpp:2663-2701).  The reference skips the transform when I == J in CKKS because
-        // NTT_J(INTT_J(x)) = x; computing it gives the same canonical words.
-        Scratch u((size_t)B * (K + 1) * K * N);
-        {
+            // u[b][I][J] = NTT_I(t_J mod q_I), I over the K data primes and the special prime
+            // (evaluator.cpp:2663-2701).  The reference skips the transform when I == J in CKKS because
+            // NTT_J(INTT_J(x)) = x; computing it gives the same canonical words.
+            Scratch u((size_t)B * (K + 1) * K * N);
             NttBatch b{};
             b.data = u.p;
             b.outer_stride = (size_t)(K + 1) * K * N;
@@ -906,11 +974,38 @@ namespace sealhip
             b.src_ncomp = K;
             b.src_mode = 1;
             ck(ntt_forward(tb, b, 0, stream_), "ks ntt digits");
+            // inner product with the key (evaluator.cpp:2703-2755)
+            ck(k_keyswitch_mac(mods, u.p, key.dev, acc_out, n_log, K, L, B, j0, j1, (unsigned)key.digit0, stream_), "ks mac");
         }
+    }
 
-        // inner product with the key (evaluator.cpp:2703-2755)
-        ck(k_keyswitch_mac(mods, u.p, key.dev, acc.p, n_log, K, L, B, stream_), "ks mac");
-        }
+    void Evaluator::switch_key_finish(Ciphertext &e, uint64_t *acc_p, unsigned parts) const
+    {
+        check_valid(e, "encrypted");
+        if (!acc_p)
+            throw std::invalid_argument("acc");
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        if (e.size() < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+        if (parts < 1 || parts > 8)
+            throw std::invalid_argument("parts"); // 8 canonical residues below 2^60 still fit a 64-bit word
+        const Scheme scheme = context_.scheme();
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K;
+        const size_t N = context_.n();
+        const unsigned B = (unsigned)e.batch();
+        const unsigned n_log = (unsigned)context_.log_n();
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        const uint32_t *map = ks_comp_prime(K);
+        struct AccRef
+        {
+            uint64_t *p;
+        } acc{ acc_p };
+        if (parts > 1)
+            ck(k_keyswitch_reduce(mods, acc.p, n_log, K, L, B, stream_), "ks reduce partial sums");
 
         // mod-down by the special prime P and accumulate into (c0, c1) (evaluator.cpp:2806-2864)
         const uint64_t P = context_.coeff_modulus()[L - 1];
@@ -976,6 +1071,15 @@ namespace sealhip
                    stream_),
                "ks tail bfv");
         }
+    }
+
+    void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        Scratch acc(switch_key_acc_words(e));
+        switch_key_partial(e, target, keys, key_index, 0, e.level()->K, acc.p);
+        switch_key_finish(e, acc.p, 1);
     }
 
     // NTT the BGV correction polynomials `delta` ([items][ncomp][N], coefficient form, canonical) and fold them

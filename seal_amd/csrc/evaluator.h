@@ -74,13 +74,15 @@ namespace sealhip
         struct Key
         {
             uint64_t *dev = nullptr;
-            size_t digits = 0;
+            size_t digits = 0; // decomposition digits resident in `dev`
+            size_t digit0 = 0; // index of the first of them (non-zero only for a digit-parallel slice)
             // true: every component is stored in the register order of the fused key-switch
             // kernel, as doubles for primes of the double-precision back end (ntt2_kernels.h)
             bool register_order = false;
         };
         ~KSwitchKeys();
-        void set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device);
+        // words: `digits` digits starting at digit `digit0` of key `index`, each 2 x L x N words
+        void set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device, size_t digit0 = 0);
         bool has_key(size_t index) const { return index < keys_.size() && keys_[index].dev != nullptr; }
         const Key &key(size_t index) const { return keys_[index]; }
         size_t slots() const { return keys_.size(); }
@@ -135,6 +137,20 @@ namespace sealhip
         // switch_key_inplace (evaluator.cpp:2561): encrypted (size >= 2) += KS(target), target = one
         // plane [batch][K][N] in the scheme's native form.
         void switch_key_inplace(Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const;
+        // the two halves of switch_key_inplace for digit-parallel key switching over several GPUs:
+        // acc = [batch][2][K+1][N] words (switch_key_acc_words); partial fills it with the canonical partial sums of
+        // the digits [j0, j1); finish reduces the sum of `parts` such buffers and applies the mod-down to encrypted.
+        size_t switch_key_acc_words(const Ciphertext &encrypted) const;
+        void switch_key_partial(const Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index,
+                                unsigned j0, unsigned j1, uint64_t *acc) const;
+        void switch_key_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts) const;
+        // relinearize (size 3 -> 2) and apply_galois (size 2) split the same way: *_partial leaves `encrypted` ready for
+        // the finish call (for apply_galois: c0 <- pi(c0), c1 <- 0) and writes this rank's partial sums to acc
+        void relinearize_partial(Ciphertext &encrypted, const KSwitchKeys &relin_keys, unsigned j0, unsigned j1, uint64_t *acc) const;
+        void relinearize_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts) const;
+        void apply_galois_partial(Ciphertext &encrypted, uint32_t galois_elt, const KSwitchKeys &galois_keys, unsigned j0, unsigned j1,
+                                  uint64_t *acc) const;
+        void apply_galois_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts) const;
 
     private:
         void check_valid(const Ciphertext &ct, const char *what) const;

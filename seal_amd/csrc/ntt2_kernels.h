@@ -33,6 +33,9 @@ namespace sealhip
         const uint32_t *targets1, *targets2;
         unsigned ntargets, n_int; // all targets; how many of them (the leading ones) are integer-back-end moduli
         unsigned K, L, batch;
+        // digit-parallel key switching: only the digits [j0, j1) contribute to acc;
+        // `key` holds digits [key_digit0, key_digit0 + resident) of the full key
+        unsigned j0, j1, key_digit0;
     };
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);
 

@@ -742,6 +742,7 @@ namespace sealhip
             unsigned ntargets;
             unsigned K;
             unsigned batch;
+            unsigned j0, j1;     // digits handled by this call (digit-parallel key switching)
             int skip_diag;       // CKKS: (I == J) is the input itself, not transformed
             NttTables tb;
         };
@@ -771,10 +772,10 @@ namespace sealhip
                 }
             };
             const unsigned Jskip = a.skip_diag ? I : ~0u;
-            unsigned J = Jskip == 0 ? 1 : 0;
-            if (J < a.K)
+            unsigned J = Jskip == a.j0 ? a.j0 + 1 : a.j0;
+            if (J < a.j1)
                 fetch(J);
-            while (J < a.K)
+            while (J < a.j1)
             {
                 const uint64_t src_q = a.tb.mods[J].q; // digit J is a residue modulo data prime J
                 typename F::elem x[16];
@@ -816,7 +817,7 @@ namespace sealhip
                 unsigned Jn = J + 1;
                 if (Jn == Jskip)
                     Jn++;
-                if (Jn < a.K)
+                if (Jn < a.j1)
                     fetch(Jn);
                 uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
                 p1_tile<FP, D1>(x, m, tab, tw, lds, mid_tr, cg, tid);
@@ -862,6 +863,7 @@ namespace sealhip
             unsigned ntargets;
             unsigned K, L;
             unsigned batch;
+            unsigned j0, j1, key_digit0; // digits handled by this call; first digit resident in `key`
             NttTables tb;
         };
 
@@ -930,8 +932,11 @@ namespace sealhip
                 }
             };
             if constexpr (FP)
-                fetch(0);
-            for (unsigned J = 0; J < a.K; J++)
+            {
+                if (a.j0 < a.j1)
+                    fetch(a.j0);
+            }
+            for (unsigned J = a.j0; J < a.j1; J++)
             {
                 typename F::elem x[16];
                 const bool is_diag = diag && J == I;
@@ -949,7 +954,7 @@ namespace sealhip
                     for (int e = 0; e < 16; e++)
                         x[e] = F::unraw(nxt[e]);
                 }
-                const typename F::key_t *k0 = key + (((size_t)J * 2 + 0) * a.L + kc) * N + ((size_t)hg << 12) + tid;
+                const typename F::key_t *k0 = key + (((size_t)(J - a.key_digit0) * 2 + 0) * a.L + kc) * N + ((size_t)hg << 12) + tid;
                 const typename F::key_t *k1 = k0 + (size_t)a.L * N;
                 typename F::key_t kr0[16], kr1[16];
                 if constexpr (FP)
@@ -961,7 +966,7 @@ namespace sealhip
                         kr0[e] = k0[e * 256];
                         kr1[e] = k1[e * 256];
                     }
-                    if (J + 1 < a.K)
+                    if (J + 1 < a.j1)
                         fetch(J + 1);
                 }
                 if (!is_diag)
@@ -992,7 +997,7 @@ namespace sealhip
                         F::mac(acc1[e], x[e], k1[e * 256], m);
                     }
                 }
-                if ((J & 7) == 7)
+                if (((J - a.j0) & 7) == 7)
                 {
 #pragma unroll
                     for (int e = 0; e < 16; e++)
@@ -1354,6 +1359,8 @@ namespace sealhip
         a1.K = k.K;
         a1.batch = k.batch;
         a1.skip_diag = k.target_ntt != nullptr;
+        a1.j0 = k.j0;
+        a1.j1 = k.j1;
         a1.tb = t;
         Ks2Args a2;
         a2.mid = k.mid;
@@ -1365,6 +1372,9 @@ namespace sealhip
         a2.K = k.K;
         a2.L = k.L;
         a2.batch = k.batch;
+        a2.j0 = k.j0;
+        a2.j1 = k.j1;
+        a2.key_digit0 = k.key_digit0;
         a2.tb = t;
         switch (t.log_n)
         {

@@ -71,9 +71,12 @@ namespace sealhip
     // Key-switch inner product.  u: [batch][K+1][K][N] (target digit J raised to modulus I, NTT form,
     // canonical); key: [digits][2][L][N]; acc: [batch][2][K+1][N] canonical.  Modulus index I == K
     // means the special prime (pool/key component L-1).
+    // Only the digits [j0, j1) are summed; key holds the digits from key_digit0 on.
     hipError_t k_keyswitch_mac(
         const ModDesc *mods, const uint64_t *u, const uint64_t *key, uint64_t *acc, unsigned n_log, unsigned K,
-        unsigned L, unsigned batch, hipStream_t s);
+        unsigned L, unsigned batch, unsigned j0, unsigned j1, unsigned key_digit0, hipStream_t s);
+    // acc <- acc mod q_I in place after partial sums of several ranks were added (each canonical, at most 8 of them)
+    hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s);
     // Key-switch tail (CKKS): ct_k[b][i] += (acc[b][k][i] - t[b][k][i]) * P^-1 mod q_i.
     // ct planes: ct0 and ct1, each [batch][K][N]; acc [batch][2][K+1][N]; t [batch][2][K][N] lazy.
     hipError_t k_keyswitch_tail_ckks(

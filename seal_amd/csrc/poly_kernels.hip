@@ -229,7 +229,7 @@ namespace sealhip
         constexpr unsigned KS_BI = 4;
         __global__ void __launch_bounds__(kBlock) keyswitch_mac_kernel(
             const ModDesc *mods, const uint64_t *u, const uint64_t *key, uint64_t *acc, unsigned n_log, unsigned K,
-            unsigned L, unsigned batch)
+            unsigned L, unsigned batch, unsigned j0, unsigned j1, unsigned key_digit0)
         {
             const size_t N = size_t(1) << n_log;
             const unsigned I = blockIdx.y;
@@ -243,10 +243,10 @@ namespace sealhip
 #pragma unroll
                 for (unsigned bi = 0; bi < KS_BI; bi++)
                     lo[bi][0] = lo[bi][1] = hi[bi][0] = hi[bi][1] = 0;
-                for (unsigned J = 0; J < K; J++)
+                for (unsigned J = j0; J < j1; J++)
                 {
-                    const uint64_t k0 = key[(((size_t)J * 2 + 0) * L + kc) * N + j];
-                    const uint64_t k1 = key[(((size_t)J * 2 + 1) * L + kc) * N + j];
+                    const uint64_t k0 = key[(((size_t)(J - key_digit0) * 2 + 0) * L + kc) * N + j];
+                    const uint64_t k1 = key[(((size_t)(J - key_digit0) * 2 + 1) * L + kc) * N + j];
 #pragma unroll
                     for (unsigned bi = 0; bi < KS_BI; bi++)
                     {
@@ -267,6 +267,17 @@ namespace sealhip
                         acc[((((size_t)(b0 + bi)) * 2 + 1) * (K + 1) + I) * N + j] = barrett128(lo[bi][1], hi[bi][1], md);
                     }
                 }
+            }
+        }
+
+        // acc[item][I][j] <- acc mod q_I: the sum of `parts` canonical partial sums (digit-parallel key switching)
+        __global__ void __launch_bounds__(kBlock) keyswitch_reduce_kernel(
+            const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, size_t words)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const unsigned I = (unsigned)((i >> n_log) % (K + 1));
+                acc[i] = barrett64(acc[i], mods[I == K ? L - 1 : I]);
             }
         }
 
@@ -428,12 +439,20 @@ namespace sealhip
     }
     hipError_t k_keyswitch_mac(
         const ModDesc *mods, const uint64_t *u, const uint64_t *key, uint64_t *acc, unsigned n_log, unsigned K, unsigned L,
-        unsigned batch, hipStream_t s)
+        unsigned batch, unsigned j0, unsigned j1, unsigned key_digit0, hipStream_t s)
     {
         size_t N = size_t(1) << n_log;
         unsigned gx = (unsigned)((N + kBlock - 1) / kBlock);
         dim3 grid(gx, K + 1, (batch + KS_BI - 1) / KS_BI);
-        hipLaunchKernelGGL(keyswitch_mac_kernel, grid, dim3(kBlock), 0, s, mods, u, key, acc, n_log, K, L, batch);
+        hipLaunchKernelGGL(keyswitch_mac_kernel, grid, dim3(kBlock), 0, s, mods, u, key, acc, n_log, K, L, batch, j0, j1, key_digit0);
+        return hipGetLastError();
+    }
+    hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s)
+    {
+        size_t w = ((size_t)batch * 2 * (K + 1)) << n_log;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w);
         return hipGetLastError();
     }
     hipError_t k_keyswitch_tail_ckks(

@@ -1,4 +1,12 @@
-"""Batch sharding of independent ciphertexts over the GPUs of one node.
+"""Sharding of the hot path over the GPUs of one node.
+
+1. Batch sharding of independent ciphertexts (8(e).1, the throughput mode bench.py measures): no data-path
+   collective at all.
+2. Digit-parallel key switching (8(e).2, BASELINE configs[4]: "decomposition parallel across GPUs"): `DigitParallel`
+   below - every rank holds the same ciphertext and a slice of the key-switching key's decomposition digits, computes
+   its partial sums, ONE all-reduce (sum of 2 (K+1) N 64-bit words per ciphertext) joins them, every rank finishes
+   the mod-down locally.  The exchange is torch.distributed.all_reduce: RCCL over xGMI on the GPU box ("nccl"
+   backend), gloo in the CPU tests.
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests).
 The hot path has no exchange step between independent ciphertexts, so the only collectives are the
@@ -57,3 +65,62 @@ def whole_job_rate(items_per_rank_per_step, steps, elapsed, dist, torch=None, de
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         n = float(t.item())
     return n / elapsed
+
+
+class DigitParallel:
+    """Key switching with the decomposition digits spread over the ranks of `dist` (sealhip.h section 1b).
+
+    ev: seal_amd.Evaluator of this rank; torch/dist: the initialised process group; device: where the exchange
+    buffer lives (cuda:<local_rank> on the GPU box, cpu under gloo).  Every rank must call the same methods in
+    the same order with equal ciphertexts; results are bit-identical to Evaluator.relinearize_inplace /
+    apply_galois_inplace on one GPU.  Keys: KSwitchKeys.set_key_digits(index, *digit_range(K), full_key[range])
+    keeps only this rank's slice resident (a full key works too)."""
+
+    def __init__(self, ev, torch, dist, device):
+        self.ev, self.torch, self.dist, self.device = ev, torch, dist, device
+        self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        if self.world > 8:
+            raise ValueError("at most 8 partial sums fit a 64-bit word (residues are below 2^60)")
+        self._acc = None
+
+    def digit_range(self, K):
+        """(first, count) of the decomposition digits this rank serves at a level with K data primes"""
+        return split(K, self.world, self.rank)
+
+    def _buffer(self, words):
+        if self._acc is None or self._acc.numel() < words:
+            self._acc = self.torch.empty(words, dtype=self.torch.int64, device=self.device)
+        return self._acc[:words]
+
+    def _exchange(self, acc):
+        # the partial sums were written by kernels on the evaluator's stream: make them visible to the collective
+        self.ev.synchronize()
+        if self.world > 1:
+            self.dist.all_reduce(acc, op=self.dist.ReduceOp.SUM)  # < 8 * 2^60 < 2^63: no overflow as int64
+            if acc.is_cuda:
+                self.torch.cuda.current_stream().synchronize()
+
+    def relinearize_inplace(self, ct, relin_keys):
+        """size 3 -> 2 (Evaluator::relinearize_inplace, evaluator.cpp:1144-1199)"""
+        first, count = self.digit_range(ct.coeff_modulus_size())
+        acc = self._buffer(self.ev.switch_key_acc_words(ct))
+        self.ev.relinearize_partial(ct, relin_keys, first, count, acc.data_ptr())
+        self._exchange(acc)
+        self.ev.relinearize_finish(ct, acc.data_ptr(), self.world)
+        return ct
+
+    def apply_galois_inplace(self, ct, galois_elt, galois_keys):
+        """Evaluator::apply_galois_inplace (evaluator.cpp:2384-2502) on a size-2 ciphertext"""
+        first, count = self.digit_range(ct.coeff_modulus_size())
+        acc = self._buffer(self.ev.switch_key_acc_words(ct))
+        self.ev.apply_galois_partial(ct, galois_elt, galois_keys, first, count, acc.data_ptr())
+        self._exchange(acc)
+        self.ev.apply_galois_finish(ct, acc.data_ptr(), self.world)
+        return ct
+
+    def rotate_vector_inplace(self, ct, steps, galois_keys):
+        """CKKS rotate_vector with the exact Galois key present (evaluator.h:1209)"""
+        if steps == 0:
+            return ct
+        return self.apply_galois_inplace(ct, ct.context.galois_elt_from_step(steps), galois_keys)

@@ -57,6 +57,32 @@ def main():
         assert rate > 0 and elapsed > 0
         print("DIST_OK world=%d items=%d rate=%.1f" % (world, total, rate), flush=True)
     dist.barrier()
+
+    # ---- digit-parallel key switching (seal_amd.shard.DigitParallel): the same ciphertexts on every rank, each rank
+    #      holds only its slice of the key digits, one all-reduce per key switch; every rank checks against the oracle
+    elt = o.galois_elt_from_step(1) if o.galois_elts else None
+    dp = shard.DigitParallel(d.ev, torch, dist, torch.device("cpu"))
+    first, cnt = dp.digit_range(K)
+    rlk = S.RelinKeys(d.ctx)
+    rlk.set_key_digits(0, first, o.relin_key()[first:first + cnt])
+    x3 = [rand_ct(rng, primes, K, n, size=3) for _ in range(2)]
+    c3 = d.ct(x3, scale=2.0 ** 10)
+    dp.relinearize_inplace(c3, rlk)
+    got = d.out(c3)
+    for i in range(2):
+        assert np.array_equal(got[i], o.relinearize(x3[i])), "digit-parallel relinearize item %d (rank %d)" % (i, rank)
+    o2 = Oracle("ckks", n, primes, galois_elts=[o.galois_elt_from_step(1)])
+    e1 = o2.galois_elt_from_step(1)
+    glk = S.GaloisKeys(d.ctx)
+    glk.set_key_digits(S.GaloisKeys.get_index(e1), first, o2.galois_key(e1)[first:first + cnt])
+    x2 = [rand_ct(rng, primes, K, n) for _ in range(2)]
+    c2 = d.ct(x2, scale=2.0 ** 10)
+    dp.rotate_vector_inplace(c2, 1, glk)
+    got = d.out(c2)
+    for i in range(2):
+        assert np.array_equal(got[i], o2.apply_galois(x2[i], e1)), "digit-parallel rotate item %d (rank %d)" % (i, rank)
+    print("DIGIT_PARALLEL_OK rank=%d digits=[%d,%d)" % (rank, first, first + cnt), flush=True)
+    dist.barrier()
     dist.destroy_process_group()
 
 

@@ -271,6 +271,75 @@ def case_bgv_pipeline(n, primes, t, batch=2, seed=6):
         assert cx.correction_factor() == info["correction_factor"]
 
 
+# ---- digit-parallel key switching (sealhip.h section 1b) emulated in ONE process: the digits are split
+#      over `parts` virtual ranks, each with only its key slice resident; the partial sums are added on the host (what the
+#      all-reduce does) and every result must equal the single-GPU relinearize / rotate AND the oracle, bit for bit.
+def case_digit_parallel(scheme, n, primes, t=0, parts=2, batch=2, seed=7):
+    from seal_amd import shard
+    L = len(primes)
+    K = L - 1
+    probe = Oracle(scheme, n, primes, t)
+    elt = probe.galois_elt_from_step(1)
+    o = Oracle(scheme, n, primes, t, galois_elts=[elt])
+    d = DeviceSide(scheme, n, primes, t)
+    d.upload_keys(o)
+    rlk_words, glk_words = o.relin_key(), o.galois_key(elt)
+    rng = np.random.default_rng(seed)
+    x3 = [rand_ct(rng, primes, K, n, size=3) for _ in range(batch)]
+    x2 = [rand_ct(rng, primes, K, n, size=2) for _ in range(batch)]
+    ranges = [shard.split(K, parts, r) for r in range(parts)]
+    assert sum(c for _, c in ranges) == K
+    # one key object per virtual rank, holding only that rank's digits
+    rlks, glks = [], []
+    for first, count in ranges:
+        rk, gk = S.RelinKeys(d.ctx), S.GaloisKeys(d.ctx)
+        if count:
+            rk.set_key_digits(0, first, rlk_words[first:first + count])
+            gk.set_key_digits(S.GaloisKeys.get_index(elt), first, glk_words[first:first + count])
+        else:  # a rank without digits still takes part in the exchange
+            rk.set_key(0, rlk_words)
+            gk.set_key(S.GaloisKeys.get_index(elt), glk_words)
+        rlks.append(rk)
+        glks.append(gk)
+
+    def run(make_ct, partial, finish, single):
+        ref_ct = make_ct()
+        single(ref_ct)
+        want = d.out(ref_ct)
+        words = d.ev.switch_key_acc_words(make_ct())
+        total = np.zeros(words, dtype=np.uint64)
+        cts = []
+        for r, (first, count) in enumerate(ranges):
+            c = make_ct()
+            acc = S.DeviceBuffer(words)
+            partial(c, r, first, count, acc)
+            total += acc.to_numpy((words,))
+            cts.append(c)
+        for c in cts:  # every rank finishes on the same sum
+            acc = S.DeviceBuffer.from_numpy(total)
+            finish(c, acc)
+            got = d.out(c)
+            for b in range(batch):
+                _eq(got[b], want[b], "digit-parallel == single GPU, item %d" % b)
+        return want
+
+    want = run(lambda: d.ct(x3, is_ntt=scheme != "bfv"),
+               lambda c, r, f, cnt, acc: d.ev.relinearize_partial(c, rlks[r], f, cnt, acc.ptr),
+               lambda c, acc: d.ev.relinearize_finish(c, acc.ptr, parts),
+               lambda c: d.ev.relinearize_inplace(c, d.rlk))
+    is_ntt = scheme != "bfv"
+    for b in range(batch):
+        exp = o.run("relinearize_inplace", [(x3[b], 1)])[0] if scheme == "bgv" else o.relinearize(x3[b])
+        _eq(want[b], exp, "relinearize item %d vs oracle" % b)
+    want = run(lambda: d.ct(x2, is_ntt=is_ntt),
+               lambda c, r, f, cnt, acc: d.ev.apply_galois_partial(c, elt, glks[r], f, cnt, acc.ptr),
+               lambda c, acc: d.ev.apply_galois_finish(c, acc.ptr, parts),
+               lambda c: d.ev.apply_galois_inplace(c, elt, d.glk))
+    for b in range(batch):
+        exp = o.run("apply_galois_inplace", [(x2[b], 1)], elt)[0] if scheme == "bgv" else o.apply_galois(x2[b], elt)
+        _eq(want[b], exp, "apply_galois item %d vs oracle" % b)
+
+
 # ---- BEHZ stages: native/tests/seal/util/rns.cpp:460-854
 def case_rns_stages(n, primes, t, seed=5):
     L = len(primes)

@@ -1,4 +1,6 @@
-"""CPU, world_size 2, gloo: the N>1 path of bench.py (seal_amd/shard.py: shard the batch, barrier-bracketed
+"""CPU, world_size 2, gloo: the N>1 paths - batch sharding as bench.py runs it, and digit-parallel key switching
+(seal_amd.shard.DigitParallel: key digits split over the ranks, one all-reduce per key switch).
+The N>1 path of bench.py (seal_amd/shard.py: shard the batch, barrier-bracketed
 timing, max over ranks, whole-job rate) on the fiber-emulated library, results checked against the oracle."""
 import os
 import subprocess
@@ -42,3 +44,6 @@ def test_world_size_2_gloo(emu):
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "DIST_OK world=2 items=5" in outs[0], outs[0]
+    # digit-parallel key switching: ranks 0 and 1 served digits [0,2) and [2,3) of K = 3 and both match the oracle
+    assert "DIGIT_PARALLEL_OK rank=0 digits=[0,2)" in outs[0], outs[0]
+    assert "DIGIT_PARALLEL_OK rank=1 digits=[2,3)" in outs[1], outs[1]

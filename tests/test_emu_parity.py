@@ -111,6 +111,19 @@ def test_bgv_pipeline(emu, n, bits, tb, batch):
     P.case_bgv_pipeline(n, primes, t, batch=batch)
 
 
+@pytest.mark.parametrize("scheme,n,bits,tb,parts", [
+    ("ckks", 64, [40, 30, 30, 40], 0, 2),
+    ("ckks", 8192, [50, 40, 60, 50, 50], 0, 3),      # fused kernels, both back ends, uneven split (2, 1, 1)
+    ("ckks", 8192, [60, 40, 60], 0, 4),               # more ranks than digits: two ranks contribute zeros
+    ("bfv", 256, [40, 40, 41], 16, 2),
+    ("bgv", 128, [40, 40, 41, 42], 16, 2),
+])
+def test_digit_parallel_key_switch(emu, scheme, n, bits, tb, parts):
+    primes = coeff_modulus_create(n, bits)
+    t = plain_modulus_batching(n, tb) if tb else 0
+    P.case_digit_parallel(scheme, n, primes, t, parts=parts, batch=2)
+
+
 def test_rns_stages(emu):
     primes, t = P.default_bfv_params(64, [40, 40, 40, 40], 13)
     P.case_rns_stages(64, primes, t)

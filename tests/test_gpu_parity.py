@@ -107,6 +107,22 @@ def test_bgv_pipeline(gpu, n, bits, tb, batch):
     P.case_bgv_pipeline(n, primes, t, batch=batch)
 
 
+# ---- digit-parallel key switching (sealhip.h section 1b; BASELINE configs[4]), ranks emulated in one process
+@pytest.mark.parametrize("scheme,n,bits,tb,parts,batch", [
+    ("ckks", 1024, [50, 40, 40, 50], 0, 2, 2),
+    ("ckks", 8192, [60, 40, 40, 50, 60], 0, 3, 2),
+    ("bfv", 8192, [55] * 4, 20, 2, 1),
+    ("bgv", 8192, [55] * 4, 20, 3, 1),
+    ("ckks", 65536, [60] + [50] * 14 + [60], 0, 8, 1),      # north-star parameters, 15 digits over 8 ranks
+])
+def test_digit_parallel_key_switch(gpu, scheme, n, bits, tb, parts, batch):
+    if scheme == "bgv" and not R.available():
+        pytest.skip("BGV parity needs the real reference (oracle/_ref)")
+    primes = coeff_modulus_create(n, bits)
+    t = plain_modulus_batching(n, tb) if tb else 0
+    P.case_digit_parallel(scheme, n, primes, t, parts=parts, batch=batch)
+
+
 def test_rns_stages(gpu):
     primes, t = P.default_bfv_params(2048, [50, 50, 50, 50], 20)
     P.case_rns_stages(2048, primes, t)
