@@ -127,6 +127,23 @@ SHL_FUNC Ciphertext_CopyFromDevice(void *thisptr, const uint64_t *src, uint64_t 
  * A key set lives in HBM; one key (index) is uploaded as the concatenation of its decomposition
  * digits, each a size-2 key-level ciphertext in NTT form: [digit][2][L][N] words
  * (KSwitchKeys::keys_[index][digit].data(), native/src/seal/kswitchkeys.h:340). */
+/* Plaintext (native/src/seal/c/plaintext.h:16-75; class seal::Plaintext, native/src/seal/plaintext.h), device resident.
+ * Coefficient form: `count` coefficients modulo t (BFV/BGV), parms_id = zero.  NTT form: K*N words at a level
+ * (Plaintext_Set4 the words, then Plaintext_SetParmsId; CKKS plaintexts are always in this form).  One plaintext is
+ * applied to every item of a ciphertext batch.  Create1 takes the context where sealc takes a pool handle. */
+SHL_FUNC Plaintext_Create1(void *context, void **plaintext);
+SHL_FUNC Plaintext_Create5(void *copy, void **plaintext);
+SHL_FUNC Plaintext_Destroy(void *thisptr);
+SHL_FUNC Plaintext_Set4(void *thisptr, uint64_t count, uint64_t *coeffs);
+SHL_FUNC Plaintext_SetFromDevice(void *thisptr, uint64_t count, const uint64_t *device_coeffs);
+SHL_FUNC Plaintext_CoeffCount(void *thisptr, uint64_t *coeff_count);
+SHL_FUNC Plaintext_IsNTTForm(void *thisptr, bool *is_ntt_form);
+SHL_FUNC Plaintext_GetParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC Plaintext_SetParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC Plaintext_Scale(void *thisptr, double *scale);
+SHL_FUNC Plaintext_SetScale(void *thisptr, double scale);
+SHL_FUNC Plaintext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count); /* synchronises */
+
 SHL_FUNC KSwitchKeys_Create1(void **kswitch_keys);
 SHL_FUNC KSwitchKeys_Destroy(void *thisptr);
 SHL_FUNC KSwitchKeys_Size(void *thisptr, uint64_t *size);
@@ -154,6 +171,18 @@ SHL_FUNC Evaluator_Negate(void *thisptr, void *encrypted, void *destination);
 SHL_FUNC Evaluator_Add(void *thisptr, void *encrypted1, void *encrypted2, void *destination);
 SHL_FUNC Evaluator_Sub(void *thisptr, void *encrypted1, void *encrypted2, void *destination);
 SHL_FUNC Evaluator_Multiply(void *thisptr, void *encrypted1, void *encrypted2, void *destination, void *pool);
+/* plaintext operands and many-operand forms (native/src/seal/c/evaluator.h:24-37, 47-49, 59-64;
+ * Evaluator::add_many / add_plain / sub_plain / multiply_plain / multiply_many / exponentiate /
+ * transform_to_ntt(Plaintext) / mod_switch_to[_next](Plaintext), native/src/seal/evaluator.cpp:242-261, 1369-1402, 1649-2287) */
+SHL_FUNC Evaluator_AddMany(void *thisptr, uint64_t count, void **encrypteds, void *destination);
+SHL_FUNC Evaluator_AddPlain(void *thisptr, void *encrypted, void *plain, void *destination);
+SHL_FUNC Evaluator_SubPlain(void *thisptr, void *encrypted, void *plain, void *destination);
+SHL_FUNC Evaluator_MultiplyMany(void *thisptr, uint64_t count, void **encrypteds, void *relin_keys, void *destination, void *pool);
+SHL_FUNC Evaluator_MultiplyPlain(void *thisptr, void *encrypted, void *plain, void *destination, void *pool);
+SHL_FUNC Evaluator_Exponentiate(void *thisptr, void *encrypted, uint64_t exponent, void *relin_keys, void *destination, void *pool);
+SHL_FUNC Evaluator_TransformToNTT1(void *thisptr, void *plain, uint64_t *parms_id, void *destination_ntt, void *pool);
+SHL_FUNC Evaluator_ModSwitchToNext2(void *thisptr, void *plain, void *destination);
+SHL_FUNC Evaluator_ModSwitchTo2(void *thisptr, void *plain, uint64_t *parms_id, void *destination);
 SHL_FUNC Evaluator_Square(void *thisptr, void *encrypted, void *destination, void *pool);
 SHL_FUNC Evaluator_Relinearize(void *thisptr, void *encrypted, void *relinKeys, void *destination, void *pool);
 SHL_FUNC Evaluator_ModSwitchToNext1(void *thisptr, void *encrypted, void *destination, void *pool);

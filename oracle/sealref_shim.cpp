@@ -435,6 +435,114 @@ extern "C"
         REF_CATCH
     }
 
+    // ---- plaintext operands (evaluator.cpp:1649-2287): plaintext handles built from raw words --------------
+    // chain_index == ~0: coefficient form (parms_id_zero), `count` coefficients modulo t (BFV/BGV);
+    // otherwise NTT form at that level, count must be K*N words.
+    struct RefPt
+    {
+        Plaintext pt;
+    };
+    int ref_pt_create(void *ctx, uint64_t chain_index, uint64_t count, double scale, const uint64_t *data, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto h = std::make_unique<RefPt>();
+        h->pt.resize(count);
+        std::memcpy(h->pt.data(), data, count * sizeof(uint64_t));
+        if (chain_index != ~uint64_t(0))
+        {
+            auto l = c->level(chain_index);
+            if (!l)
+                return 1;
+            h->pt.parms_id() = l->parms_id();
+        }
+        h->pt.scale() = scale;
+        *out = h.release();
+        REF_CATCH
+    }
+    void ref_pt_destroy(void *pt)
+    {
+        delete static_cast<RefPt *>(pt);
+    }
+    int ref_pt_info(void *ctx, void *pt, uint64_t *chain_index, uint64_t *count, int *is_ntt, double *scale)
+    {
+        auto c = static_cast<RefCtx *>(ctx);
+        auto &x = static_cast<RefPt *>(pt)->pt;
+        auto l = x.is_ntt_form() ? c->context->get_context_data(x.parms_id()) : nullptr;
+        *chain_index = l ? l->chain_index() : ~uint64_t(0);
+        *count = x.coeff_count();
+        *is_ntt = x.is_ntt_form();
+        *scale = x.scale();
+        return 0;
+    }
+    int ref_pt_data(void *pt, uint64_t *out)
+    {
+        auto &x = static_cast<RefPt *>(pt)->pt;
+        std::memcpy(out, x.data(), x.coeff_count() * sizeof(uint64_t));
+        return 0;
+    }
+#define PT(x) (static_cast<RefPt *>(x)->pt)
+    int ref_add_plain_inplace(void *ctx, void *a, void *p)
+    {
+        REF_TRY EV->add_plain_inplace(CT(a), PT(p));
+        REF_CATCH
+    }
+    int ref_sub_plain_inplace(void *ctx, void *a, void *p)
+    {
+        REF_TRY EV->sub_plain_inplace(CT(a), PT(p));
+        REF_CATCH
+    }
+    int ref_multiply_plain_inplace(void *ctx, void *a, void *p)
+    {
+        REF_TRY EV->multiply_plain_inplace(CT(a), PT(p));
+        REF_CATCH
+    }
+    int ref_pt_transform_to_ntt_inplace(void *ctx, void *p, uint64_t chain_index)
+    {
+        REF_TRY
+        auto l = static_cast<RefCtx *>(ctx)->level(chain_index);
+        if (!l)
+            return 1;
+        EV->transform_to_ntt_inplace(PT(p), l->parms_id());
+        REF_CATCH
+    }
+    int ref_pt_mod_switch_to_next_inplace(void *ctx, void *p)
+    {
+        REF_TRY EV->mod_switch_to_next_inplace(PT(p));
+        REF_CATCH
+    }
+    // add_many / multiply_many / exponentiate (evaluator.cpp:298-350, 1649-1757); result replaces cts[0]
+    int ref_add_many(void *ctx, void **cts, uint64_t count)
+    {
+        REF_TRY
+        std::vector<Ciphertext> v;
+        for (uint64_t i = 0; i < count; i++)
+            v.push_back(CT(cts[i]));
+        Ciphertext dest;
+        EV->add_many(v, dest);
+        CT(cts[0]) = dest;
+        REF_CATCH
+    }
+    int ref_multiply_many(void *ctx, void **cts, uint64_t count)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        std::vector<Ciphertext> v;
+        for (uint64_t i = 0; i < count; i++)
+            v.push_back(CT(cts[i]));
+        Ciphertext dest;
+        EV->multiply_many(v, c->rlk, dest);
+        CT(cts[0]) = dest;
+        REF_CATCH
+    }
+    int ref_exponentiate_inplace(void *ctx, void *a, uint64_t exponent)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        EV->exponentiate_inplace(CT(a), exponent, c->rlk);
+        REF_CATCH
+    }
+
     // ---- L1 kernels on raw components (the HEXL seam, ntt.cpp:394-475, polyarithsmallmod.cpp) ----
     // mode: 0 fwd, 1 fwd lazy, 2 inv, 3 inv lazy.  data = `count` consecutive RNS components
     // starting at prime index `first` of level `chain_index` (each N words).

@@ -62,6 +62,10 @@ Ciphertext_Size Ciphertext_BatchCount Ciphertext_PolyModulusDegree Ciphertext_Co
 Ciphertext_IsNTTForm Ciphertext_SetIsNTTForm Ciphertext_Scale Ciphertext_SetScale Ciphertext_CorrectionFactor
 Ciphertext_SetCorrectionFactor Ciphertext_IsTransparent Ciphertext_DevicePtr Ciphertext_CopyFromHost
 Ciphertext_CopyToHost Ciphertext_CopyFromDevice
+Plaintext_Create1 Plaintext_Create5 Plaintext_Destroy Plaintext_Set4 Plaintext_SetFromDevice Plaintext_CoeffCount
+Plaintext_IsNTTForm Plaintext_GetParmsId Plaintext_SetParmsId Plaintext_Scale Plaintext_SetScale Plaintext_CopyToHost
+Evaluator_AddMany Evaluator_AddPlain Evaluator_SubPlain Evaluator_MultiplyMany Evaluator_MultiplyPlain Evaluator_Exponentiate
+Evaluator_TransformToNTT1 Evaluator_ModSwitchToNext2 Evaluator_ModSwitchTo2
 KSwitchKeys_Create1 KSwitchKeys_Destroy KSwitchKeys_Size KSwitchKeys_SetKey KSwitchKeys_SetKeyFromDevice
 KSwitchKeys_SetKeyDigits KSwitchKeys_HasKey RelinKeys_GetIndex GaloisKeys_GetIndex GaloisTool_GetEltFromStep
 Evaluator_Create Evaluator_Destroy Evaluator_SetStream Evaluator_Synchronize Evaluator_SetTransparentCheck

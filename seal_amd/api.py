@@ -256,6 +256,69 @@ class Ciphertext:
         return ct
 
 
+class Plaintext:
+    """seal::Plaintext resident in HBM (sealhip.h): coefficient form (<= N coefficients mod t) or NTT form (K*N words)."""
+
+    def __init__(self, context, _copy_of=None):
+        self.context = context
+        self._h = C.c_void_p()
+        if _copy_of is not None:
+            N.check(N.lib().Plaintext_Create5(_copy_of._h, C.byref(self._h)))
+        else:
+            N.check(N.lib().Plaintext_Create1(context._h, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().Plaintext_Destroy(self._h)
+            self._h = None
+
+    def copy(self):
+        return Plaintext(self.context, _copy_of=self)
+
+    @staticmethod
+    def from_numpy(context, array, parms_id=None, scale=1.0):
+        """coefficients (1-D, coefficient form) or [K][N] residues with the level's parms_id (NTT form)"""
+        p = Plaintext(context)
+        a = np.ascontiguousarray(array, dtype=np.uint64).reshape(-1)
+        N.check(N.lib().Plaintext_Set4(p._h, C.c_uint64(a.size), _p(a)))
+        if parms_id is not None:
+            p.set_parms_id(parms_id)
+        p.set_scale(scale)
+        return p
+
+    def coeff_count(self):
+        v = C.c_uint64()
+        N.check(N.lib().Plaintext_CoeffCount(self._h, C.byref(v)))
+        return v.value
+
+    def is_ntt_form(self):
+        v = C.c_bool()
+        N.check(N.lib().Plaintext_IsNTTForm(self._h, C.byref(v)))
+        return v.value
+
+    def parms_id(self):
+        pid = (C.c_uint64 * 4)()
+        N.check(N.lib().Plaintext_GetParmsId(self._h, pid))
+        return tuple(pid)
+
+    def set_parms_id(self, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Plaintext_SetParmsId(self._h, pid))
+
+    def scale(self):
+        v = C.c_double()
+        N.check(N.lib().Plaintext_Scale(self._h, C.byref(v)))
+        return v.value
+
+    def set_scale(self, v):
+        N.check(N.lib().Plaintext_SetScale(self._h, C.c_double(v)))
+
+    def to_numpy(self):
+        out = np.zeros(self.coeff_count(), dtype=np.uint64)
+        N.check(N.lib().Plaintext_CopyToHost(self._h, _p(out), C.c_uint64(out.size)))
+        return out
+
+
 class KSwitchKeys:
     """Device-resident key-switching keys; slab per index: [digits][2][L][N] (kswitchkeys.h:340)."""
 
@@ -435,6 +498,53 @@ class Evaluator:
 
     def rotate_vector_inplace(self, a, steps, galois_keys):
         N.check(N.lib().Evaluator_RotateVector(self._h, a._h, C.c_int(steps), galois_keys._h, a._h, None))
+        return a
+
+    # ---- plaintext operands and many-operand forms
+    def _pl(self, fn, a, plain, dest, pool=False):
+        d = a if dest is None else dest
+        args = [self._h, a._h, plain._h, d._h] + ([None] if pool else [])
+        N.check(getattr(N.lib(), fn)(*args))
+        return d
+
+    def add_plain_inplace(self, a, plain):
+        return self._pl("Evaluator_AddPlain", a, plain, None)
+
+    def sub_plain_inplace(self, a, plain):
+        return self._pl("Evaluator_SubPlain", a, plain, None)
+
+    def multiply_plain_inplace(self, a, plain):
+        return self._pl("Evaluator_MultiplyPlain", a, plain, None, pool=True)
+
+    def multiply_plain(self, a, plain, destination):
+        return self._pl("Evaluator_MultiplyPlain", a, plain, destination, pool=True)
+
+    def transform_plain_to_ntt_inplace(self, plain, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Evaluator_TransformToNTT1(self._h, plain._h, pid, plain._h, None))
+        return plain
+
+    def mod_switch_plain_to_next_inplace(self, plain):
+        N.check(N.lib().Evaluator_ModSwitchToNext2(self._h, plain._h, plain._h))
+        return plain
+
+    def mod_switch_plain_to_inplace(self, plain, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Evaluator_ModSwitchTo2(self._h, plain._h, pid, plain._h))
+        return plain
+
+    def add_many(self, cts, destination):
+        arr = (C.c_void_p * len(cts))(*[c._h for c in cts])
+        N.check(N.lib().Evaluator_AddMany(self._h, C.c_uint64(len(cts)), arr, destination._h))
+        return destination
+
+    def multiply_many(self, cts, relin_keys, destination):
+        arr = (C.c_void_p * len(cts))(*[c._h for c in cts])
+        N.check(N.lib().Evaluator_MultiplyMany(self._h, C.c_uint64(len(cts)), arr, relin_keys._h, destination._h, None))
+        return destination
+
+    def exponentiate_inplace(self, a, exponent, relin_keys):
+        N.check(N.lib().Evaluator_Exponentiate(self._h, a._h, C.c_uint64(exponent), relin_keys._h, a._h, None))
         return a
 
     # ---- digit-parallel key switching (sealhip.h section 1b); acc_ptr = device pointer of switch_key_acc_words words

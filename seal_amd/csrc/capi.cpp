@@ -663,6 +663,220 @@ extern "C"
     EV_UNARY_POOL(Evaluator_RescaleToNext, rescale_to_next_inplace)
     EV_UNARY_POOL(Evaluator_ModReduceToNext, mod_reduce_to_next_inplace)
 
+    // ------------------------------------------------------------------ Plaintext (native/src/seal/c/plaintext.h)
+    SHL_FUNC Plaintext_Create1(void *context, void **plaintext)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(plaintext, SHL_E_POINTER);
+        SHL_TRY
+        *plaintext = new Plaintext(*as<Context>(context));
+        SHL_CATCH
+    }
+    SHL_FUNC Plaintext_Create5(void *copy, void **plaintext)
+    {
+        IfNullRet(copy, SHL_E_POINTER);
+        IfNullRet(plaintext, SHL_E_POINTER);
+        SHL_TRY
+        *plaintext = new Plaintext(*as<Plaintext>(copy));
+        SHL_CATCH
+    }
+    SHL_FUNC Plaintext_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<Plaintext>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC Plaintext_Set4(void *thisptr, uint64_t count, uint64_t *coeffs)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        if (count)
+            IfNullRet(coeffs, SHL_E_POINTER);
+        SHL_TRY
+        as<Plaintext>(thisptr)->set(coeffs, count, false);
+        SHL_CATCH
+    }
+    SHL_FUNC Plaintext_SetFromDevice(void *thisptr, uint64_t count, const uint64_t *device_coeffs)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        if (count)
+            IfNullRet(device_coeffs, SHL_E_POINTER);
+        SHL_TRY
+        as<Plaintext>(thisptr)->set(device_coeffs, count, true);
+        SHL_CATCH
+    }
+    SHL_FUNC Plaintext_CoeffCount(void *thisptr, uint64_t *coeff_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(coeff_count, SHL_E_POINTER);
+        *coeff_count = as<Plaintext>(thisptr)->coeff_count();
+        return SHL_S_OK;
+    }
+    SHL_FUNC Plaintext_IsNTTForm(void *thisptr, bool *is_ntt_form)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(is_ntt_form, SHL_E_POINTER);
+        *is_ntt_form = as<Plaintext>(thisptr)->is_ntt_form();
+        return SHL_S_OK;
+    }
+    SHL_FUNC Plaintext_GetParmsId(void *thisptr, uint64_t *parms_id)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        auto pt = as<Plaintext>(thisptr);
+        if (pt->level())
+            std::memcpy(parms_id, pt->level()->parms_id, 32);
+        else
+            std::memset(parms_id, 0, 32); // parms_id_zero
+        return SHL_S_OK;
+    }
+    SHL_FUNC Plaintext_SetParmsId(void *thisptr, uint64_t *parms_id)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        SHL_TRY
+        auto pt = as<Plaintext>(thisptr);
+        static const uint64_t zero[4] = { 0, 0, 0, 0 };
+        if (!std::memcmp(parms_id, zero, 32))
+            pt->set_level(nullptr);
+        else
+        {
+            const Level *l = pt->context().level_by_parms_id(parms_id);
+            if (!l)
+                throw std::invalid_argument("parms_id is not valid for encryption parameters");
+            pt->set_level(l);
+        }
+        SHL_CATCH
+    }
+    SHL_FUNC Plaintext_Scale(void *thisptr, double *scale)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(scale, SHL_E_POINTER);
+        *scale = as<Plaintext>(thisptr)->scale();
+        return SHL_S_OK;
+    }
+    SHL_FUNC Plaintext_SetScale(void *thisptr, double scale)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        as<Plaintext>(thisptr)->scale() = scale;
+        return SHL_S_OK;
+    }
+    SHL_FUNC Plaintext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(dst, SHL_E_POINTER);
+        SHL_TRY
+        auto pt = as<Plaintext>(thisptr);
+        if (word_count != pt->coeff_count())
+            throw std::invalid_argument("word_count does not match the plaintext");
+        if (word_count)
+        {
+            if (hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(dst, pt->data(), word_count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                throw std::runtime_error("HIP failure in Plaintext_CopyToHost");
+        }
+        SHL_CATCH
+    }
+
+    // ------------------------------------------------------------------ plaintext operands, many-operand forms
+#define EV_PLAIN(fn, call)                                                       \
+    SHL_FUNC fn(void *thisptr, void *encrypted, void *plain, void *destination)  \
+    {                                                                            \
+        IfNullRet(thisptr, SHL_E_POINTER);                                       \
+        IfNullRet(encrypted, SHL_E_POINTER);                                     \
+        IfNullRet(plain, SHL_E_POINTER);                                         \
+        IfNullRet(destination, SHL_E_POINTER);                                   \
+        SHL_TRY                                                                  \
+        as<Evaluator>(thisptr)->call(prepare_dest(encrypted, destination), *as<Plaintext>(plain)); \
+        SHL_CATCH                                                                \
+    }
+    EV_PLAIN(Evaluator_AddPlain, add_plain_inplace)
+    EV_PLAIN(Evaluator_SubPlain, sub_plain_inplace)
+    SHL_FUNC Evaluator_MultiplyPlain(void *thisptr, void *encrypted, void *plain, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(plain, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->multiply_plain_inplace(prepare_dest(encrypted, destination), *as<Plaintext>(plain));
+        SHL_CATCH
+    }
+    static Plaintext &prepare_plain_dest(void *plain, void *destination)
+    {
+        Plaintext *src = as<Plaintext>(plain), *dst = as<Plaintext>(destination);
+        if (src != dst)
+            *dst = *src;
+        return *dst;
+    }
+    SHL_FUNC Evaluator_TransformToNTT1(void *thisptr, void *plain, uint64_t *parms_id, void *destination_ntt, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plain, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination_ntt, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->transform_to_ntt_inplace(prepare_plain_dest(plain, destination_ntt), parms_id);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ModSwitchToNext2(void *thisptr, void *plain, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plain, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->mod_switch_to_next_inplace(prepare_plain_dest(plain, destination));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ModSwitchTo2(void *thisptr, void *plain, uint64_t *parms_id, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plain, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->mod_switch_to_inplace(prepare_plain_dest(plain, destination), parms_id);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_AddMany(void *thisptr, uint64_t count, void **encrypteds, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypteds, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        std::vector<const Ciphertext *> v;
+        for (uint64_t i = 0; i < count; i++)
+            v.push_back(as<Ciphertext>(encrypteds[i]));
+        as<Evaluator>(thisptr)->add_many(v, *as<Ciphertext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_MultiplyMany(void *thisptr, uint64_t count, void **encrypteds, void *relin_keys, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypteds, SHL_E_POINTER);
+        IfNullRet(relin_keys, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        std::vector<const Ciphertext *> v;
+        for (uint64_t i = 0; i < count; i++)
+            v.push_back(as<Ciphertext>(encrypteds[i]));
+        as<Evaluator>(thisptr)->multiply_many(v, *as<KSwitchKeys>(relin_keys), *as<Ciphertext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_Exponentiate(void *thisptr, void *encrypted, uint64_t exponent, void *relin_keys, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(relin_keys, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->exponentiate_inplace(prepare_dest(encrypted, destination), exponent, *as<KSwitchKeys>(relin_keys));
+        SHL_CATCH
+    }
+
     SHL_FUNC Evaluator_Add(void *thisptr, void *encrypted1, void *encrypted2, void *destination)
     {
         IfNullRet(thisptr, SHL_E_POINTER);

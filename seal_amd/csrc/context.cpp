@@ -305,7 +305,7 @@ namespace sealhip
         Block blk;
         struct Off
         {
-            size_t inv_q_last = 0, round_fix = 0, half_mod_q = 0, q_last_mod_q = 0, bsk_prime = 0, inv_punct_q = 0, m_tilde_mod_q = 0, q_to_bsk = 0, q_to_mtilde = 0,
+            size_t inv_q_last = 0, round_fix = 0, half_mod_q = 0, q_last_mod_q = 0, delta_mod_q = 0, upper_half_inc = 0, bsk_prime = 0, inv_punct_q = 0, m_tilde_mod_q = 0, q_to_bsk = 0, q_to_mtilde = 0,
                    prod_q_mod_bsk = 0, inv_mtilde_mod_bsk = 0, inv_prod_q_mod_bsk = 0, inv_punct_b = 0, b_to_q = 0,
                    b_to_msk = 0, prod_b_mod_q = 0, t_mod_q = 0, t_mod_bsk = 0;
         } off;
@@ -331,6 +331,23 @@ namespace sealhip
             off.q_last_mod_q = blk.put(qlm);
             if (scheme_ == Scheme::bgv)
                 lvl.dev.inv_q_last_mod_t = invmod(q[K - 1] % plain_modulus_, plain_modulus_);
+            if (scheme_ != Scheme::ckks)
+            {
+                // floor(Q/t) = (Q - (Q mod t)) / t exactly, and Q = 0 mod q_i, hence floor(Q/t) = -(Q mod t) t^-1 (mod q_i)
+                const uint64_t t = plain_modulus_;
+                const uint64_t r = prod_mod(q, t);
+                std::vector<uint64_t> dl, inc;
+                for (unsigned i = 0; i < K; i++)
+                {
+                    const uint64_t rm = r % q[i];
+                    dl.push_back(mulmod(rm ? q[i] - rm : 0, invmod(t % q[i], q[i]), q[i]));
+                    inc.push_back((q[i] - t % q[i]) % q[i]);
+                }
+                off.delta_mod_q = blk.put(dl);
+                off.upper_half_inc = blk.put(inc);
+                lvl.dev.q_mod_t = r;
+                lvl.dev.plain_upper_half_threshold = (t + 1) >> 1;
+            }
             lvl.dev.q_last = q[K - 1];
             lvl.dev.half_q_last = half;
         }
@@ -417,6 +434,11 @@ namespace sealhip
         lvl.dev.round_fix = d + off.round_fix;
         lvl.dev.half_mod_q = d + off.half_mod_q;
         lvl.dev.q_last_mod_q = d + off.q_last_mod_q;
+        if (scheme_ != Scheme::ckks)
+        {
+            lvl.dev.delta_mod_q = d + off.delta_mod_q;
+            lvl.dev.upper_half_inc = d + off.upper_half_inc;
+        }
         if (behz)
         {
             lvl.dev.bsk_prime = reinterpret_cast<const uint32_t *>(d + off.bsk_prime);

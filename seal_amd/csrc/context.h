@@ -49,6 +49,13 @@ namespace sealhip
         // (RNSTool::inv_q_last_mod_t_, rns.cpp:778-786); unused unless the scheme is BGV
         const uint64_t *q_last_mod_q = nullptr;    // [K-1]
         uint64_t inv_q_last_mod_t = 0;
+        // plaintext lifting and scaling (BFV/BGV; context.cpp:332-376 of the reference):
+        //   delta_mod_q[i] = floor(Q/t) mod q_i ("coeff_div_plain_modulus"), upper_half_inc[i] = (Q - t) mod q_i,
+        //   q_mod_t = Q mod t, plain_upper_half_threshold = (t+1)/2
+        const uint64_t *delta_mod_q = nullptr;     // [K]
+        const uint64_t *upper_half_inc = nullptr;  // [K]
+        uint64_t q_mod_t = 0;
+        uint64_t plain_upper_half_threshold = 0;
         // BEHZ (BFV multiply); all null when the scheme is CKKS
         const uint32_t *bsk_prime = nullptr;       // [nBsk] pool index of each Bsk prime (B..., m_sk)
         const ShoupOp *inv_punct_q = nullptr;      // [K]     (Q/q_i)^-1 mod q_i

@@ -253,6 +253,66 @@ namespace sealhip
         size_ = size;
     }
 
+    // ---------------------------------------------------------------- Plaintext
+    Plaintext::~Plaintext()
+    {
+        DevicePool::global().free_words(data_);
+    }
+    Plaintext::Plaintext(const Plaintext &o) : ctx_(o.ctx_)
+    {
+        *this = o;
+    }
+    Plaintext &Plaintext::operator=(const Plaintext &o)
+    {
+        if (this == &o)
+            return *this;
+        ctx_ = o.ctx_;
+        if (capacity_words_ < o.coeff_count_)
+        {
+            DevicePool::global().free_words(data_);
+            data_ = DevicePool::global().alloc_words(o.coeff_count_);
+            capacity_words_ = o.coeff_count_;
+        }
+        coeff_count_ = o.coeff_count_;
+        level_ = o.level_;
+        scale_ = o.scale_;
+        if (coeff_count_)
+            ck(hipMemcpyAsync(data_, o.data_, coeff_count_ * 8, hipMemcpyDeviceToDevice, nullptr), "Plaintext copy");
+        return *this;
+    }
+    void Plaintext::resize(size_t coeff_count, hipStream_t stream)
+    {
+        if (level_)
+            throw std::logic_error("cannot resize an NTT transformed Plaintext"); // plaintext.h:274-277
+        if (coeff_count > capacity_words_)
+        {
+            uint64_t *nd = DevicePool::global().alloc_words(coeff_count);
+            if (coeff_count_)
+                ck(hipMemcpyAsync(nd, data_, coeff_count_ * 8, hipMemcpyDeviceToDevice, stream), "Plaintext resize copy");
+            DevicePool::global().free_words(data_);
+            data_ = nd;
+            capacity_words_ = coeff_count;
+        }
+        if (coeff_count > coeff_count_)
+            ck(hipMemsetAsync(data_ + coeff_count_, 0, (coeff_count - coeff_count_) * 8, stream), "Plaintext resize zero");
+        coeff_count_ = coeff_count;
+    }
+    void Plaintext::set(const uint64_t *words, size_t count, bool from_device)
+    {
+        level_ = nullptr;
+        coeff_count_ = 0;
+        resize(count, nullptr);
+        if (count)
+            ck(hipMemcpy(data_, words, count * 8, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "Plaintext set");
+    }
+    void Plaintext::adopt(uint64_t *slab, size_t count, size_t capacity_words)
+    {
+        DevicePool::global().free_words(data_);
+        data_ = slab;
+        coeff_count_ = count;
+        capacity_words_ = capacity_words;
+    }
+
     // ---------------------------------------------------------------- KSwitchKeys
     KSwitchKeys::~KSwitchKeys()
     {
@@ -588,6 +648,343 @@ namespace sealhip
         ck(ntt_inverse(context_.ntt_tables(), b, 0, stream_), "ntt_inverse");
         e.is_ntt_form() = false;
         throw_if_transparent(e);
+    }
+
+    // ---- plaintext operands (evaluator.cpp:1760-2287) and many-operand forms (242-261, 1649-1757)
+    void Evaluator::check_valid(const Plaintext &p) const
+    {
+        // is_metadata_valid_for(Plaintext) + is_buffer_valid (valcheck.cpp:28-79, 209-219)
+        bool ok = &p.context() == &context_;
+        if (ok && p.is_ntt_form())
+        {
+            const Level &l = *p.level();
+            ok = l.chain_index <= context_.first_level().chain_index && p.coeff_count() == (size_t)l.K * context_.n();
+        }
+        else if (ok)
+            ok = p.coeff_count() <= context_.n();
+        if (ok && context_.scheme() == Scheme::ckks)
+            ok = std::isnormal(p.scale()) && p.scale() > 0;
+        ok = ok && (p.coeff_count() == 0 || p.data() != nullptr);
+        if (!ok)
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+    }
+
+    // coefficients modulo t -> [K][N] residues of the centred lift (evaluator.cpp:2098-2125, 2243-2282), times scale_by mod t
+    void Evaluator::plain_to_rns(const Plaintext &plain, const Level &lvl, uint64_t scale_by, uint64_t *out) const
+    {
+        if (context_.scheme() == Scheme::ckks)
+            throw std::invalid_argument("CKKS plain must be in NTT form");
+        ck(k_plain_lift(context_.dev_mods(), host::make_mod(context_.plain_modulus()), plain.data(), plain.coeff_count(), scale_by,
+                        lvl.dev.plain_upper_half_threshold, lvl.dev.upper_half_inc, out, (unsigned)context_.log_n(), lvl.K, stream_),
+           "plain lift");
+    }
+
+    void Evaluator::transform_to_ntt_inplace(Plaintext &plain, const uint64_t *parms_id) const
+    {
+        check_valid(plain);
+        const Level *lvl = context_.level_by_parms_id(parms_id);
+        if (!lvl)
+            throw std::invalid_argument("parms_id is not valid for the current context");
+        if (plain.is_ntt_form())
+            throw std::invalid_argument("plain is already in NTT form");
+        const size_t words = (size_t)lvl->K * context_.n();
+        uint64_t *out = DevicePool::global().alloc_words(words);
+        try
+        {
+            plain_to_rns(plain, *lvl, 1, out);
+            ck(ntt_forward(context_.ntt_tables(), plain_batch(out, words, lvl->K, 1, 0), 0, stream_), "plain ntt");
+        }
+        catch (...)
+        {
+            DevicePool::global().free_words(out);
+            throw;
+        }
+        plain.adopt(out, words, words);
+        plain.set_level(lvl);
+    }
+
+    void Evaluator::mod_switch_to_next_inplace(Plaintext &plain) const
+    {
+        // mod_switch_drop_to_next(Plaintext) (evaluator.cpp:1369-1402): the flat [K][N] array keeps its first K-1 components
+        check_valid(plain);
+        if (!plain.is_ntt_form())
+            throw std::invalid_argument("plain is not in NTT form");
+        const Level *next = context_.next_level(*plain.level());
+        if (!next)
+            throw std::invalid_argument("end of modulus switching chain reached");
+        if (!scale_within_bounds(plain.scale(), *next))
+            throw std::invalid_argument("scale out of bounds");
+        plain.adopt_count((size_t)next->K * context_.n());
+        plain.set_level(next);
+    }
+    void Evaluator::mod_switch_to_inplace(Plaintext &plain, const uint64_t *parms_id) const
+    {
+        check_valid(plain);
+        const Level *target = context_.level_by_parms_id(parms_id);
+        if (!plain.is_ntt_form())
+            throw std::invalid_argument("plain is not in NTT form");
+        if (!target)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (plain.level()->chain_index < target->chain_index)
+            throw std::invalid_argument("cannot switch to higher level modulus");
+        while (plain.level() != target)
+            mod_switch_to_next_inplace(plain);
+    }
+
+    void Evaluator::add_plain_inplace(Ciphertext &e, const Plaintext &plain) const
+    {
+        // add_plain_inplace / sub_plain_inplace share everything but the sign
+        check_valid(e, "encrypted");
+        check_valid(plain);
+        addsub_plain(e, plain, 0);
+    }
+    void Evaluator::sub_plain_inplace(Ciphertext &e, const Plaintext &plain) const
+    {
+        check_valid(e, "encrypted");
+        check_valid(plain);
+        addsub_plain(e, plain, 1);
+    }
+    void Evaluator::addsub_plain(Ciphertext &e, const Plaintext &plain, int op) const
+    {
+        const Scheme scheme = context_.scheme();
+        if (scheme == Scheme::bfv)
+        {
+            if (e.is_ntt_form())
+                throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+            if (plain.is_ntt_form())
+                throw std::invalid_argument("BFV plain cannot be in NTT form");
+        }
+        else if (scheme == Scheme::ckks)
+        {
+            if (!e.is_ntt_form())
+                throw std::invalid_argument("CKKS encrypted must be in NTT form");
+            if (!plain.is_ntt_form())
+                throw std::invalid_argument("CKKS plain must be in NTT form");
+            if (e.level() != plain.level())
+                throw std::invalid_argument("encrypted and plain parameter mismatch");
+            if (!are_close(e.scale(), plain.scale()))
+                throw std::invalid_argument("scale mismatch");
+        }
+        else
+        {
+            if (!e.is_ntt_form())
+                throw std::invalid_argument("BGV encrypted must be in NTT form");
+            if (plain.is_ntt_form())
+                throw std::invalid_argument("BGV plain cannot be in NTT form");
+        }
+        if (e.size() < 1)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        const Level &lvl = *e.level();
+        const unsigned n_log = (unsigned)context_.log_n();
+        const ModDesc *mods = context_.dev_mods();
+        switch (scheme)
+        {
+        case Scheme::bfv:
+            // multiply_add/sub_plain_with_scaling_variant (util/scalingvariant.cpp:70-175)
+            ck(k_bfv_addsub_plain(mods, host::make_mod(context_.plain_modulus()), plain.data(), plain.coeff_count(), lvl.dev.q_mod_t,
+                                  lvl.dev.plain_upper_half_threshold, lvl.dev.delta_mod_q, e.plane(0), op, n_log, lvl.K, e.batch(), stream_),
+               "bfv add/sub plain");
+            break;
+        case Scheme::ckks:
+            ck(k_addsub_plain(mods, e.plane(0), plain.data(), op, n_log, lvl.K, e.batch(), stream_), "ckks add/sub plain");
+            break;
+        case Scheme::bgv:
+        {
+            // plain * correction_factor mod t, lifted and transformed at the ciphertext's level (evaluator.cpp:1836-1847)
+            Scratch tmp((size_t)lvl.K * context_.n());
+            plain_to_rns(plain, lvl, e.correction_factor(), tmp.p);
+            ck(ntt_forward(context_.ntt_tables(), plain_batch(tmp.p, (size_t)lvl.K * context_.n(), lvl.K, 1, 0), 0, stream_), "plain ntt");
+            ck(k_addsub_plain(mods, e.plane(0), tmp.p, op, n_log, lvl.K, e.batch(), stream_), "bgv add/sub plain");
+            break;
+        }
+        default:
+            throw std::invalid_argument("unsupported scheme");
+        }
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::multiply_plain_ntt(Ciphertext &e, const uint64_t *plain_rns, const Level *plain_level, double plain_scale) const
+    {
+        // multiply_plain_ntt (evaluator.cpp:2157-2194)
+        if (e.level() != plain_level)
+            throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+        const Level &lvl = *e.level();
+        ck(k_dyadic_plain(context_.dev_mods(), e.data(), plain_rns, e.data(), (unsigned)context_.log_n(), lvl.K, e.size() * e.batch(), stream_),
+           "multiply_plain");
+        e.scale() *= plain_scale;
+        if (!scale_within_bounds(e.scale(), lvl))
+            throw std::invalid_argument("scale out of bounds");
+    }
+
+    // The monomial shortcut of multiply_plain_normal (evaluator.cpp:2051-2095).  It is not merely faster: with the
+    // "fast plain lift" (t below every q_i) the reference multiplies by the RAW coefficient even when it lies in the
+    // upper half, i.e. by m instead of m - t; the ciphertext words differ from the generic path (by t * ct * x^e), so
+    // the branch has to be reproduced.  Costs one 24-byte read-back per coefficient-form multiply_plain.
+    bool Evaluator::mul_plain_monomial(Ciphertext &e, const Plaintext &plain) const
+    {
+        const Level &lvl = *e.level();
+        Scratch stats(3);
+        ck(k_plain_stats(plain.data(), plain.coeff_count(), stats.p, stream_), "plain stats");
+        uint64_t st[3];
+        ck(hipMemcpyAsync(st, stats.p, 24, hipMemcpyDeviceToHost, stream_), "plain stats read");
+        ck(hipStreamSynchronize(stream_), "plain stats sync");
+        if (st[0] != 1)
+            return false;
+        const size_t mono_exponent = (size_t)st[1] - 1;
+        const uint64_t c = st[2], t = context_.plain_modulus();
+        const std::vector<uint64_t> &q = context_.coeff_modulus();
+        bool fast_lift = true; // qualifiers.using_fast_plain_lift: t smaller than every prime of this level
+        for (unsigned i = 0; i < lvl.K; i++)
+            fast_lift = fast_lift && t < q[i];
+        std::vector<uint64_t> sc(lvl.K);
+        for (unsigned i = 0; i < lvl.K; i++)
+        {
+            sc[i] = c % q[i];
+            if (c >= lvl.dev.plain_upper_half_threshold && !fast_lift)
+                sc[i] = (sc[i] + (q[i] - t % q[i]) % q[i]) % q[i]; // (c + Q - t) mod q_i
+        }
+        Scratch dsc(lvl.K);
+        ck(hipMemcpyAsync(dsc.p, sc.data(), lvl.K * 8, hipMemcpyHostToDevice, stream_), "mono scalars");
+        const size_t words = e.word_count();
+        uint64_t *out = DevicePool::global().alloc_words(words);
+        ck(k_negacyclic_mul_mono(context_.dev_mods(), e.data(), out, dsc.p, mono_exponent, (unsigned)context_.log_n(), lvl.K,
+                                 e.size() * e.batch(), stream_),
+           "multiply_plain monomial");
+        ck(hipStreamSynchronize(stream_), "mono sync"); // sc lives on this stack frame
+        const size_t size = e.size();
+        e.adopt(&lvl, size, out, words);
+        if (context_.scheme() == Scheme::ckks)
+        {
+            e.scale() *= plain.scale();
+            if (!scale_within_bounds(e.scale(), lvl))
+                throw std::invalid_argument("scale out of bounds");
+        }
+        return true;
+    }
+
+    void Evaluator::multiply_plain_inplace(Ciphertext &e, const Plaintext &plain) const
+    {
+        check_valid(e, "encrypted");
+        check_valid(plain);
+        const Level &lvl = *e.level();
+        const size_t pw = (size_t)lvl.K * context_.n();
+        if (e.is_ntt_form() && plain.is_ntt_form())
+            multiply_plain_ntt(e, plain.data(), plain.level(), plain.scale());
+        else if (!plain.is_ntt_form())
+        {
+            // multiply_plain_normal (evaluator.cpp:2021-2155) and the "encrypted in NTT form, plain not" branch (2006-2011):
+            // lift the plaintext at the ciphertext's level, transform it, and multiply in the NTT domain.  The reference's
+            // monomial shortcut computes the same product, so the canonical result is identical.
+            const bool ct_ntt = e.is_ntt_form();
+            const unsigned items = (unsigned)(e.size() * e.batch());
+            if (!ct_ntt && mul_plain_monomial(e, plain))
+            {
+                throw_if_transparent(e);
+                return;
+            }
+            Scratch tmp(pw);
+            plain_to_rns(plain, lvl, 1, tmp.p);
+            ck(ntt_forward(context_.ntt_tables(), plain_batch(tmp.p, pw, lvl.K, 1, 0), 0, stream_), "plain ntt");
+            if (!ct_ntt)
+                ck(ntt_forward(context_.ntt_tables(), plain_batch(e.data(), pw, lvl.K, items, 0), 1, stream_), "multiply_plain ntt");
+            if (ct_ntt)
+                multiply_plain_ntt(e, tmp.p, &lvl, plain.scale());
+            else
+            {
+                ck(k_dyadic_plain(context_.dev_mods(), e.data(), tmp.p, e.data(), (unsigned)context_.log_n(), lvl.K, items, stream_),
+                   "multiply_plain");
+                ck(ntt_inverse(context_.ntt_tables(), plain_batch(e.data(), pw, lvl.K, items, 0), 0, stream_), "multiply_plain intt");
+                if (context_.scheme() == Scheme::ckks)
+                {
+                    e.scale() *= plain.scale();
+                    if (!scale_within_bounds(e.scale(), lvl))
+                        throw std::invalid_argument("scale out of bounds");
+                }
+            }
+        }
+        else
+        {
+            // encrypted not in NTT form, plain in NTT form (evaluator.cpp:2012-2017)
+            transform_to_ntt_inplace(e);
+            multiply_plain_ntt(e, plain.data(), plain.level(), plain.scale());
+            transform_from_ntt_inplace(e);
+        }
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::add_many(const std::vector<const Ciphertext *> &encrypteds, Ciphertext &destination) const
+    {
+        if (encrypteds.empty())
+            throw std::invalid_argument("encrypteds cannot be empty");
+        for (const Ciphertext *c : encrypteds)
+            if (!c || c == &destination)
+                throw std::invalid_argument("encrypteds must be different from destination");
+        destination = *encrypteds[0];
+        for (size_t i = 1; i < encrypteds.size(); i++)
+            add_inplace(destination, *encrypteds[i]);
+    }
+
+    void Evaluator::multiply_many(const std::vector<const Ciphertext *> &encrypteds, const KSwitchKeys &relin_keys, Ciphertext &destination) const
+    {
+        // the product tree of evaluator.cpp:1649-1723, every product relinearized
+        if (encrypteds.empty())
+            throw std::invalid_argument("encrypteds vector must not be empty");
+        for (const Ciphertext *c : encrypteds)
+            if (!c || c == &destination)
+                throw std::invalid_argument("encrypteds must be different from destination");
+        if (&encrypteds[0]->context() != &context_ || !encrypteds[0]->level())
+            throw std::invalid_argument("encrypteds is not valid for encryption parameters");
+        if (context_.scheme() != Scheme::bfv && context_.scheme() != Scheme::bgv)
+            throw std::logic_error("unsupported scheme");
+        if (encrypteds.size() == 1)
+        {
+            destination = *encrypteds[0];
+            return;
+        }
+        std::vector<std::unique_ptr<Ciphertext>> owned;
+        std::vector<const Ciphertext *> prod;
+        for (size_t i = 0; i + 1 < encrypteds.size(); i += 2)
+        {
+            std::unique_ptr<Ciphertext> temp(new Ciphertext(context_, encrypteds[i]->batch()));
+            if (encrypteds[i]->data() == encrypteds[i + 1]->data())
+            {
+                *temp = *encrypteds[i];
+                square_inplace(*temp);
+            }
+            else
+                multiply(*encrypteds[i], *encrypteds[i + 1], *temp);
+            relinearize_inplace(*temp, relin_keys);
+            prod.push_back(temp.get());
+            owned.push_back(std::move(temp));
+        }
+        if (encrypteds.size() & 1)
+            prod.push_back(encrypteds.back());
+        for (size_t i = 0; i + 1 < prod.size(); i += 2)
+        {
+            std::unique_ptr<Ciphertext> temp(new Ciphertext(context_, prod[i]->batch()));
+            multiply(*prod[i], *prod[i + 1], *temp);
+            relinearize_inplace(*temp, relin_keys);
+            prod.push_back(temp.get());
+            owned.push_back(std::move(temp));
+        }
+        destination = *prod.back();
+    }
+
+    void Evaluator::exponentiate_inplace(Ciphertext &e, uint64_t exponent, const KSwitchKeys &relin_keys) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (relin_keys.context() != &context_)
+            throw std::invalid_argument("relin_keys is not valid for encryption parameters");
+        if (exponent == 0)
+            throw std::invalid_argument("exponent cannot be 0");
+        if (exponent == 1)
+            return;
+        // multiply_many over `exponent` copies (evaluator.cpp:1725-1757); the copies share one buffer here, so the
+        // first tree level squares it, exactly as the reference does for identical operands
+        Ciphertext base(e);
+        std::vector<const Ciphertext *> v((size_t)exponent, &base);
+        multiply_many(v, relin_keys, e);
     }
 
     // ---- multiply (evaluator.cpp:352-708)

@@ -66,6 +66,42 @@ namespace sealhip
         size_t capacity_words_ = 0;
     };
 
+    // seal::Plaintext (plaintext.h) resident in HBM: either coeff_count <= N coefficients modulo t (BFV/BGV,
+    // parms_id_zero) or, in NTT form, K*N words at a level (CKKS always; BFV/BGV after transform_to_ntt_inplace).
+    // One plaintext is applied to every item of a ciphertext batch.
+    class Plaintext
+    {
+    public:
+        explicit Plaintext(const Context &ctx) : ctx_(&ctx) {}
+        ~Plaintext();
+        Plaintext(const Plaintext &o);
+        Plaintext &operator=(const Plaintext &o);
+
+        const Context &context() const { return *ctx_; }
+        size_t coeff_count() const { return coeff_count_; }
+        const Level *level() const { return level_; } // parms_id: null = parms_id_zero = not in NTT form
+        void set_level(const Level *l) { level_ = l; }
+        bool is_ntt_form() const { return level_ != nullptr; }
+        double &scale() { return scale_; }
+        double scale() const { return scale_; }
+        uint64_t *data() { return data_; }
+        const uint64_t *data() const { return data_; }
+        // Plaintext::resize (plaintext.h:268-290): new coefficients are zero
+        void resize(size_t coeff_count, hipStream_t stream);
+        // Plaintext_Set4: coefficient form, `count` words from host or device memory
+        void set(const uint64_t *words, size_t count, bool from_device);
+        void adopt(uint64_t *slab, size_t count, size_t capacity_words);
+        void adopt_count(size_t count) { coeff_count_ = count; } // shrink in place (plaintext mod switching)
+
+    private:
+        const Context *ctx_;
+        size_t coeff_count_ = 0;
+        const Level *level_ = nullptr;
+        double scale_ = 1.0;
+        uint64_t *data_ = nullptr;
+        size_t capacity_words_ = 0;
+    };
+
     // KSwitchKeys::keys_ (kswitchkeys.h:340): per index, `digits` size-2 key-level ciphertexts in NTT
     // form, stored as one slab [digit][2][L][N].
     class KSwitchKeys
@@ -121,6 +157,16 @@ namespace sealhip
         void rescale_to_inplace(Ciphertext &encrypted, const uint64_t *parms_id) const;
         void mod_reduce_to_next_inplace(Ciphertext &encrypted) const;
         void transform_to_ntt_inplace(Ciphertext &encrypted) const;
+        // plaintext operands and the many-operand forms (evaluator.cpp:242-261, 1649-2287, 1369-1402)
+        void add_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const;
+        void sub_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const;
+        void multiply_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const;
+        void transform_to_ntt_inplace(Plaintext &plain, const uint64_t *parms_id) const;
+        void mod_switch_to_next_inplace(Plaintext &plain) const;
+        void mod_switch_to_inplace(Plaintext &plain, const uint64_t *parms_id) const;
+        void add_many(const std::vector<const Ciphertext *> &encrypteds, Ciphertext &destination) const;
+        void multiply_many(const std::vector<const Ciphertext *> &encrypteds, const KSwitchKeys &relin_keys, Ciphertext &destination) const;
+        void exponentiate_inplace(Ciphertext &encrypted, uint64_t exponent, const KSwitchKeys &relin_keys) const;
         void transform_from_ntt_inplace(Ciphertext &encrypted_ntt) const;
         void apply_galois_inplace(Ciphertext &encrypted, uint32_t galois_elt, const KSwitchKeys &galois_keys) const;
         void rotate_rows_inplace(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
@@ -157,6 +203,11 @@ namespace sealhip
         bool scale_within_bounds(double scale, const Level &lvl) const;
         void bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const;
         void bgv_multiply(Ciphertext &e1, const Ciphertext &e2) const;
+        void check_valid(const Plaintext &plain) const;
+        void addsub_plain(Ciphertext &encrypted, const Plaintext &plain, int op) const;
+        bool mul_plain_monomial(Ciphertext &encrypted, const Plaintext &plain) const;
+        void plain_to_rns(const Plaintext &plain, const Level &lvl, uint64_t scale_by, uint64_t *out) const;
+        void multiply_plain_ntt(Ciphertext &encrypted_ntt, const uint64_t *plain_rns, const Level *plain_level, double plain_scale) const;
         void bgv_correct_and_combine(
             Scratch &delta, const uint64_t *a, size_t a_stride, const ShoupOp *mul, unsigned ncomp, size_t items, uint64_t *out0,
             uint64_t *out1, size_t out_stride, int epi) const;

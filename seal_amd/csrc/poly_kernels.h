@@ -43,6 +43,30 @@ namespace sealhip
     // util/polyarithsmallmod.h:440-448 / .cpp:197-224); r may be a.
     hipError_t k_mul_scalar(
         const ModDesc *mods, const uint64_t *a, uint64_t *r, uint64_t scalar, PlaneGeom g, unsigned planes, hipStream_t s);
+    // ---- plaintext operands (one polynomial applied to every batch item)
+    // r[item][k] = a[item][k] .* p[k]: multiply_plain_ntt (evaluator.cpp:2157-2194); items = size * batch
+    hipError_t k_dyadic_plain(const ModDesc *mods, const uint64_t *a, const uint64_t *p, uint64_t *r, unsigned n_log, unsigned K,
+                              size_t items, hipStream_t s);
+    // c[item][k] (+/-)= p[k] for the items of one plane (op 0 add, 1 sub): CKKS / BGV add_plain, sub_plain
+    hipError_t k_addsub_plain(const ModDesc *mods, uint64_t *c, const uint64_t *p, int op, unsigned n_log, unsigned K, size_t items,
+                              hipStream_t s);
+    // plaintext coefficients modulo t -> RNS form [K][N] (the lift of transform_to_ntt_inplace / multiply_plain_normal,
+    // evaluator.cpp:2098-2125, 2243-2282): out[i][j] = m_j mod q_i, plus upper_half_inc[i] (mod q_i) when
+    // m_j >= threshold; zero beyond coeff_count.  scale_by != 1 first multiplies m_j by it modulo t (BGV add_plain).
+    hipError_t k_plain_lift(const ModDesc *mods, ModDesc t, const uint64_t *m, size_t coeff_count, uint64_t scale_by,
+                            uint64_t threshold, const uint64_t *upper_half_inc, uint64_t *out, unsigned n_log, unsigned K, hipStream_t s);
+    // nonzero_coeff_count, significant_coeff_count - 1 and the coefficient there (plaintext.h:371-399), written to
+    // stats[0..2] (device): decides the monomial shortcut of multiply_plain_normal (evaluator.cpp:2051-2095)
+    hipError_t k_plain_stats(const uint64_t *m, size_t coeff_count, uint64_t *stats, hipStream_t s);
+    // negacyclic_multiply_poly_mono_coeffmod (util/polyarithsmallmod.cpp:286-334): out = in * (scalar_k x^e) per component
+    // k, scalar_k canonical modulo q_k (device array [K]); out != in
+    hipError_t k_negacyclic_mul_mono(const ModDesc *mods, const uint64_t *in, uint64_t *out, const uint64_t *scalars, size_t e,
+                                     unsigned n_log, unsigned K, size_t items, hipStream_t s);
+    // BFV add_plain / sub_plain: multiply_add/sub_plain_with_scaling_variant (util/scalingvariant.cpp:70-175):
+    //   fix = floor((m (Q mod t) + (t+1)/2) / t);  c0[item][i][j] (+/-)= (m delta_i + fix) mod q_i
+    hipError_t k_bfv_addsub_plain(const ModDesc *mods, ModDesc t, const uint64_t *m, size_t coeff_count, uint64_t q_mod_t,
+                                  uint64_t threshold, const uint64_t *delta_mod_q, uint64_t *c0, int op, unsigned n_log, unsigned K,
+                                  size_t items, hipStream_t s);
     // Galois automorphism on `planes` planes; ntt_form selects the NTT-domain gather or the
     // coefficient-domain signed scatter.  in != out.
     hipError_t k_apply_galois(

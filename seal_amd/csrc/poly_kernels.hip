@@ -158,6 +158,137 @@ namespace sealhip
             }
         }
 
+        __global__ void __launch_bounds__(kBlock) dyadic_plain_kernel(
+            const ModDesc *mods, const uint64_t *a, const uint64_t *p, uint64_t *r, unsigned n_log, unsigned K, size_t words)
+        {
+            const size_t pw = (size_t)K << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t pi = i % pw;
+                r[i] = mul_mod(a[i], p[pi], mods[pi >> n_log]);
+            }
+        }
+        __global__ void __launch_bounds__(kBlock) addsub_plain_kernel(
+            const ModDesc *mods, uint64_t *c, const uint64_t *p, int op, unsigned n_log, unsigned K, size_t words)
+        {
+            const size_t pw = (size_t)K << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t pi = i % pw;
+                const uint64_t q = mods[pi >> n_log].q;
+                c[i] = op ? sub_mod(c[i], p[pi], q) : add_mod(c[i], p[pi], q);
+            }
+        }
+        __global__ void __launch_bounds__(kBlock) plain_lift_kernel(
+            const ModDesc *mods, ModDesc t, const uint64_t *m, size_t coeff_count, uint64_t scale_by, uint64_t threshold,
+            const uint64_t *inc, uint64_t *out, unsigned n_log, unsigned K)
+        {
+            const size_t N = size_t(1) << n_log, words = (size_t)K << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t j = i & (N - 1);
+                const unsigned k = (unsigned)(i >> n_log);
+                uint64_t v = 0;
+                if (j < coeff_count)
+                {
+                    uint64_t mv = m[j];
+                    if (scale_by != 1)
+                        mv = mul_mod(mv, scale_by, t);
+                    const ModDesc md = mods[k];
+                    v = barrett64(mv, md);
+                    if (mv >= threshold)
+                        v = add_mod(v, inc[k], md.q);
+                }
+                out[i] = v;
+            }
+        }
+        __global__ void __launch_bounds__(kBlock) plain_stats_kernel(const uint64_t *m, size_t count, uint64_t *stats)
+        {
+            // one workgroup; stats[0] = number of nonzero coefficients, stats[1] = index of the last one + 1 (0 if none),
+            // stats[2] = that coefficient
+            __shared__ unsigned long long s_nz[kBlock], s_last[kBlock];
+            unsigned long long nz = 0, last = 0;
+            for (size_t i = threadIdx.x; i < count; i += kBlock)
+                if (m[i])
+                {
+                    nz++;
+                    last = i + 1;
+                }
+            s_nz[threadIdx.x] = nz;
+            s_last[threadIdx.x] = last;
+            __syncthreads();
+            if (threadIdx.x == 0)
+            {
+                for (unsigned k = 1; k < kBlock; k++)
+                {
+                    nz += s_nz[k];
+                    last = s_last[k] > last ? s_last[k] : last;
+                }
+                stats[0] = nz;
+                stats[1] = last;
+                stats[2] = last ? m[last - 1] : 0;
+            }
+        }
+        __global__ void __launch_bounds__(kBlock) negacyclic_mul_mono_kernel(
+            const ModDesc *mods, const uint64_t *in, uint64_t *out, const uint64_t *scalars, size_t e, unsigned n_log, unsigned K,
+            size_t words)
+        {
+            const size_t N = size_t(1) << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t j = i & (N - 1), row = i >> n_log;
+                const unsigned k = (unsigned)(row % K);
+                const ModDesc md = mods[k];
+                uint64_t v = mul_mod(in[i], scalars[k], md);
+                const size_t idx = j + e; // e < N
+                if (idx >= N)
+                    v = neg_mod(v, md.q);
+                out[(row << n_log) + (idx & (N - 1))] = v;
+            }
+        }
+        // floor((hi:lo) / t) for a quotient below 2^64, with t's Barrett constant floor(2^128 / t)
+        __device__ __forceinline__ uint64_t div128_by(uint64_t lo, uint64_t hi, const ModDesc &t)
+        {
+            uint64_t t1 = mul_hi64(lo, t.ratio_lo);
+            uint64_t a_lo, a_hi, b_lo, b_hi;
+            mul_wide(lo, t.ratio_hi, a_lo, a_hi);
+            mul_wide(hi, t.ratio_lo, b_lo, b_hi);
+            uint64_t mid = t1 + a_lo;
+            uint64_t c = mid < t1;
+            uint64_t mid2 = mid + b_lo;
+            c += mid2 < mid;
+            uint64_t qest = hi * t.ratio_hi + a_hi + b_hi + c; // low by at most 2
+            uint64_t r = lo - qest * t.q;
+            while (r >= t.q)
+            {
+                r -= t.q;
+                qest++;
+            }
+            return qest;
+        }
+        __global__ void __launch_bounds__(kBlock) bfv_addsub_plain_kernel(
+            const ModDesc *mods, ModDesc t, const uint64_t *m, size_t coeff_count, uint64_t q_mod_t, uint64_t threshold,
+            const uint64_t *delta, uint64_t *c0, int op, unsigned n_log, unsigned K, size_t words)
+        {
+            const size_t N = size_t(1) << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t j = i & (N - 1);
+                if (j >= coeff_count)
+                    continue;
+                const unsigned k = (unsigned)((i >> n_log) % K);
+                const ModDesc md = mods[k];
+                const uint64_t mv = m[j];
+                uint64_t lo, hi;
+                mul_wide(mv, q_mod_t, lo, hi);
+                lo += threshold;
+                hi += lo < threshold;
+                const uint64_t fix = div128_by(lo, hi, t);
+                const uint64_t scaled = add_mod(mul_mod(mv, delta[k], md), barrett64(fix, md), md.q);
+                c0[i] = op ? sub_mod(c0[i], scaled, md.q) : add_mod(c0[i], scaled, md.q);
+            }
+        }
+
         __global__ void __launch_bounds__(kBlock) mul_scalar_kernel(
             const ModDesc *mods, const uint64_t *a, uint64_t *r, uint64_t scalar, unsigned n_log, unsigned K, size_t words)
         {
@@ -395,6 +526,60 @@ namespace sealhip
         if (!w)
             return hipSuccess;
         hipLaunchKernelGGL(rescale_combine_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, inv_q_last, c, t, out, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_dyadic_plain(const ModDesc *mods, const uint64_t *a, const uint64_t *p, uint64_t *r, unsigned n_log, unsigned K,
+                              size_t items, hipStream_t s)
+    {
+        size_t w = (items * K) << n_log;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(dyadic_plain_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, a, p, r, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_addsub_plain(const ModDesc *mods, uint64_t *c, const uint64_t *p, int op, unsigned n_log, unsigned K, size_t items,
+                              hipStream_t s)
+    {
+        size_t w = (items * K) << n_log;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(addsub_plain_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, c, p, op, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_plain_lift(const ModDesc *mods, ModDesc t, const uint64_t *m, size_t coeff_count, uint64_t scale_by,
+                            uint64_t threshold, const uint64_t *upper_half_inc, uint64_t *out, unsigned n_log, unsigned K, hipStream_t s)
+    {
+        size_t w = (size_t)K << n_log;
+        hipLaunchKernelGGL(plain_lift_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, t, m, coeff_count, scale_by, threshold,
+                           upper_half_inc, out, n_log, K);
+        return hipGetLastError();
+    }
+    hipError_t k_plain_stats(const uint64_t *m, size_t coeff_count, uint64_t *stats, hipStream_t s)
+    {
+        hipError_t e = hipMemsetAsync(stats, 0, 24, s);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL(plain_stats_kernel, dim3(1), dim3(kBlock), 0, s, m, coeff_count, stats);
+        return hipGetLastError();
+    }
+    hipError_t k_negacyclic_mul_mono(const ModDesc *mods, const uint64_t *in, uint64_t *out, const uint64_t *scalars, size_t e,
+                                     unsigned n_log, unsigned K, size_t items, hipStream_t s)
+    {
+        size_t w = (items * K) << n_log;
+        if (!w)
+            return hipSuccess;
+        hipLaunchKernelGGL(negacyclic_mul_mono_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, in, out, scalars, e, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_bfv_addsub_plain(const ModDesc *mods, ModDesc t, const uint64_t *m, size_t coeff_count, uint64_t q_mod_t,
+                                  uint64_t threshold, const uint64_t *delta_mod_q, uint64_t *c0, int op, unsigned n_log, unsigned K,
+                                  size_t items, hipStream_t s)
+    {
+        size_t w = (items * K) << n_log;
+        if (!w || !coeff_count)
+            return hipSuccess;
+        hipLaunchKernelGGL(bfv_addsub_plain_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, t, m, coeff_count, q_mod_t, threshold,
+                           delta_mod_q, c0, op, n_log, K, w);
         return hipGetLastError();
     }
     hipError_t k_mul_scalar(

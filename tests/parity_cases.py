@@ -340,6 +340,115 @@ def case_digit_parallel(scheme, n, primes, t=0, parts=2, batch=2, seed=7):
         _eq(want[b], exp, "apply_galois item %d vs oracle" % b)
 
 
+# ---- plaintext operands and many-operand forms: add_plain / sub_plain / multiply_plain in every form
+#      combination, transform_to_ntt(Plaintext), mod_switch_to_next(Plaintext), add_many, multiply_many, exponentiate
+#      (native/tests/seal/evaluator.cpp: *AddPlain*, *SubPlain*, *MultiplyPlain*, *MultiplyMany*, *Exponentiate*,
+#      TransformPlainToNTT) at ciphertext level against the real reference.
+def case_plain_ops(scheme, n, primes, t=0, batch=2, seed=8):
+    L = len(primes)
+    K = L - 1
+    o = Oracle(scheme, n, primes, t)
+    assert o.kind == "reference", "plaintext-operand parity needs oracle/_ref"
+    d = DeviceSide(scheme, n, primes, t)
+    d.upload_keys(o)
+    rng = np.random.default_rng(seed)
+    ci = o._ci(K)
+    pid = d.parms_id_for_K(K)
+    is_ntt = scheme != "bfv"
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    cf = 3 if scheme == "bgv" else 1
+    scale = 2.0 ** 10 if scheme == "ckks" else 1.0
+
+    def dev_ct(slabs=None, ntt=None):
+        c = d.ct(xs if slabs is None else slabs, scale=scale, is_ntt=is_ntt if ntt is None else ntt)
+        c.set_correction_factor(cf)
+        return c
+
+    def ref_ct(slab, ntt=None):
+        return o.ref.ct(ci, slab, is_ntt if ntt is None else ntt, scale, cf)
+
+    def check(name, cdev, ref_fn, slabs=None, ntt=None):
+        got = d.out(cdev)
+        for b in range(batch):
+            r = ref_ct((xs if slabs is None else slabs)[b], ntt)
+            ref_fn(r)
+            _eq(got[b], r.data(), "%s item %d" % (name, b))
+            i = r.info()
+            assert cdev.scale() == i["scale"] and cdev.correction_factor() == i["correction_factor"], name
+            assert cdev.is_ntt_form() == i["is_ntt_form"], name
+
+    if scheme == "ckks":
+        pr = np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)])
+        pl_d = S.Plaintext.from_numpy(d.ctx, pr, pid, scale)
+        pl_r = lambda: o.ref.pt(pr, ci, scale)
+        for op in ("add_plain_inplace", "sub_plain_inplace", "multiply_plain_inplace"):
+            c = dev_ct()
+            getattr(d.ev, op)(c, pl_d)
+            check(op, c, lambda r: getattr(o.ref, op)(r, pl_r()))
+        # mod_switch_to_next(Plaintext): drop the last component
+        if K >= 2:
+            pm = pl_d.copy()
+            d.ev.mod_switch_plain_to_next_inplace(pm)
+            rp = o.ref.pt_mod_switch_to_next_inplace(pl_r())
+            assert pm.coeff_count() == rp.info()["coeff_count"] and np.array_equal(pm.to_numpy(), rp.data())
+    else:
+        # coefficient-form plaintexts: full length with values on both sides of the (t+1)/2 threshold, a short one
+        # (coeff_count < N) and a monomial (the reference's negacyclic_multiply_poly_mono shortcut)
+        full = rng.integers(0, t, n, dtype=np.uint64)
+        short = rng.integers(0, t, max(1, n // 4), dtype=np.uint64)
+        mono = np.zeros(5, dtype=np.uint64)
+        mono[4] = t - 2
+        for name, m in (("full", full), ("short", short), ("mono", mono)):
+            pl_d = S.Plaintext.from_numpy(d.ctx, m)
+            pl_r = lambda m=m: o.ref.pt(m)
+            for op in ("add_plain_inplace", "sub_plain_inplace", "multiply_plain_inplace"):
+                c = dev_ct()
+                getattr(d.ev, op)(c, pl_d)
+                check("%s(%s)" % (op, name), c, lambda r: getattr(o.ref, op)(r, pl_r()))
+            # transform_to_ntt_inplace(Plaintext, parms_id), then multiply_plain on the other form combinations
+            pn = pl_d.copy()
+            d.ev.transform_plain_to_ntt_inplace(pn, pid)
+            rn = o.ref.pt_transform_to_ntt_inplace(pl_r(), ci)
+            assert pn.is_ntt_form() and np.array_equal(pn.to_numpy(), rn.data()), "transform_to_ntt(Plaintext) %s" % name
+            c = dev_ct(ntt=not is_ntt)  # the other ciphertext form
+            if scheme == "bfv":  # BFV ciphertext in NTT form x NTT plain, and x coefficient-form plain
+                d.ev.multiply_plain_inplace(c, pn)
+                check("multiply_plain ntt x ntt (%s)" % name, c, lambda r: o.ref.multiply_plain_inplace(r, rn), ntt=True)
+                c = dev_ct(ntt=True)
+                d.ev.multiply_plain_inplace(c, pl_d)
+                check("multiply_plain ntt x coeff (%s)" % name, c, lambda r: o.ref.multiply_plain_inplace(r, pl_r()), ntt=True)
+                c = dev_ct()
+                d.ev.multiply_plain_inplace(c, pn)
+                check("multiply_plain coeff x ntt (%s)" % name, c, lambda r: o.ref.multiply_plain_inplace(r, rn))
+            else:        # BGV ciphertext (NTT form) x NTT plain
+                c = dev_ct()
+                d.ev.multiply_plain_inplace(c, pn)
+                check("multiply_plain ntt x ntt (%s)" % name, c, lambda r: o.ref.multiply_plain_inplace(r, rn))
+
+    # add_many
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    zs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    dest = S.Ciphertext(d.ctx, batch=batch)
+    d.ev.add_many([dev_ct(xs), dev_ct(ys), dev_ct(zs)], dest)
+    got = d.out(dest)
+    for b in range(batch):
+        r = o.ref.add_many([ref_ct(xs[b]), ref_ct(ys[b]), ref_ct(zs[b])])
+        _eq(got[b], r.data(), "add_many item %d" % b)
+    if scheme != "ckks":
+        # multiply_many (5 operands: products, relinearizations, the odd one carried) and exponentiate (x^3)
+        ops = [[rand_ct(rng, primes, K, n) for _ in range(batch)] for _ in range(5)]
+        dest = S.Ciphertext(d.ctx, batch=batch)
+        d.ev.multiply_many([dev_ct(s) for s in ops], d.rlk, dest)
+        got = d.out(dest)
+        for b in range(batch):
+            r = o.ref.multiply_many([ref_ct(s[b]) for s in ops])
+            _eq(got[b], r.data(), "multiply_many item %d" % b)
+            assert dest.correction_factor() == r.info()["correction_factor"]
+        c = dev_ct()
+        d.ev.exponentiate_inplace(c, 3, d.rlk)
+        check("exponentiate(3)", c, lambda r: o.ref.exponentiate_inplace(r, 3))
+
+
 # ---- BEHZ stages: native/tests/seal/util/rns.cpp:460-854
 def case_rns_stages(n, primes, t, seed=5):
     L = len(primes)

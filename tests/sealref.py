@@ -100,6 +100,30 @@ class RefCiphertext:
         return RefCiphertext(self.ctx, h)
 
 
+class RefPlaintext:
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    def __del__(self):
+        if self.h:
+            lib().ref_pt_destroy(self.h)
+            self.h = None
+
+    def info(self):
+        ci, cnt = C.c_uint64(), C.c_uint64()
+        ntt = C.c_int()
+        scale = C.c_double()
+        lib().ref_pt_info(self.ctx.h, self.h, C.byref(ci), C.byref(cnt), C.byref(ntt), C.byref(scale))
+        return dict(chain_index=None if ci.value == 2 ** 64 - 1 else ci.value, coeff_count=cnt.value,
+                    is_ntt_form=bool(ntt.value), scale=scale.value)
+
+    def data(self):
+        out = np.zeros(self.info()["coeff_count"], dtype=np.uint64)
+        lib().ref_pt_data(self.h, _p(out))
+        return out
+
+
 class RefContext:
     """SEALContext(parms, expand_mod_chain=True, sec_level_type::none) + KeyGenerator + Evaluator."""
 
@@ -236,6 +260,49 @@ class RefContext:
 
     def transform_from_ntt_inplace(self, a):
         return self._op1("ref_transform_from_ntt_inplace", a)
+
+    # -- plaintext operands and many-operand forms
+    def pt(self, data, chain_index=None, scale=1.0):
+        """coefficient form (chain_index None) or NTT form at chain_index ([K][N] residues)"""
+        d = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1)
+        h = C.c_void_p()
+        ci = 2 ** 64 - 1 if chain_index is None else chain_index
+        _ck(lib().ref_pt_create(self.h, C.c_uint64(ci), C.c_uint64(d.size), C.c_double(scale), _p(d), C.byref(h)))
+        return RefPlaintext(self, h)
+
+    def add_plain_inplace(self, a, p):
+        _ck(lib().ref_add_plain_inplace(self.h, a.h, p.h))
+        return a
+
+    def sub_plain_inplace(self, a, p):
+        _ck(lib().ref_sub_plain_inplace(self.h, a.h, p.h))
+        return a
+
+    def multiply_plain_inplace(self, a, p):
+        _ck(lib().ref_multiply_plain_inplace(self.h, a.h, p.h))
+        return a
+
+    def pt_transform_to_ntt_inplace(self, p, chain_index):
+        _ck(lib().ref_pt_transform_to_ntt_inplace(self.h, p.h, C.c_uint64(chain_index)))
+        return p
+
+    def pt_mod_switch_to_next_inplace(self, p):
+        _ck(lib().ref_pt_mod_switch_to_next_inplace(self.h, p.h))
+        return p
+
+    def add_many(self, cts):
+        arr = (C.c_void_p * len(cts))(*[c.h for c in cts])
+        _ck(lib().ref_add_many(self.h, arr, C.c_uint64(len(cts))))
+        return cts[0]
+
+    def multiply_many(self, cts):
+        arr = (C.c_void_p * len(cts))(*[c.h for c in cts])
+        _ck(lib().ref_multiply_many(self.h, arr, C.c_uint64(len(cts))))
+        return cts[0]
+
+    def exponentiate_inplace(self, a, exponent):
+        _ck(lib().ref_exponentiate_inplace(self.h, a.h, C.c_uint64(exponent)))
+        return a
 
     # -- L1 kernels
     def ntt(self, chain_index, first, data, mode):

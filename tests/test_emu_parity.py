@@ -124,6 +124,22 @@ def test_digit_parallel_key_switch(emu, scheme, n, bits, tb, parts):
     P.case_digit_parallel(scheme, n, primes, t, parts=parts, batch=2)
 
 
+@pytest.mark.parametrize("scheme,n,bits,tb", [
+    ("ckks", 64, [40, 30, 30, 40], 0),
+    ("bfv", 64, [40, 40, 41], 13),
+    ("bfv", 128, [30, 30, 30], 40),       # t above every q_i: the lift cannot use the "fast plain lift" shortcut
+    ("bgv", 64, [40, 40, 41], 13),
+    ("bfv", 8192, [50, 55, 56], 20),      # two-pass engine
+])
+def test_plain_operands_and_many(emu, scheme, n, bits, tb):
+    import sealref
+    if not sealref.available():
+        pytest.skip("needs the real reference (oracle/_ref)")
+    primes = coeff_modulus_create(n, bits)
+    t = plain_modulus_batching(n, tb) if tb else 0
+    P.case_plain_ops(scheme, n, primes, t, batch=2 if n < 4096 else 1)
+
+
 def test_rns_stages(emu):
     primes, t = P.default_bfv_params(64, [40, 40, 40, 40], 13)
     P.case_rns_stages(64, primes, t)

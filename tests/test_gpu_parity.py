@@ -123,6 +123,23 @@ def test_digit_parallel_key_switch(gpu, scheme, n, bits, tb, parts, batch):
     P.case_digit_parallel(scheme, n, primes, t, parts=parts, batch=batch)
 
 
+# ---- plaintext operands and many-operand forms, against the real reference
+@pytest.mark.parametrize("scheme,n,bits,tb,batch", [
+    ("ckks", 4096, [40, 30, 30, 40], 0, 2),
+    ("ckks", 16384, [60, 50, 50, 60], 0, 2),
+    ("bfv", 1024, [40, 40, 41], 16, 2),
+    ("bfv", 128, [30, 30, 30], 40, 2),      # t above every q_i: no fast plain lift
+    ("bfv", 8192, [50, 55, 56, 60], 20, 1),
+    ("bgv", 8192, [50, 55, 56, 60], 20, 1),
+])
+def test_plain_operands_and_many(gpu, scheme, n, bits, tb, batch):
+    if not R.available():
+        pytest.skip("needs the real reference (oracle/_ref)")
+    primes = coeff_modulus_create(n, bits)
+    t = plain_modulus_batching(n, tb) if tb else 0
+    P.case_plain_ops(scheme, n, primes, t, batch=batch)
+
+
 def test_rns_stages(gpu):
     primes, t = P.default_bfv_params(2048, [50, 50, 50, 50], 20)
     P.case_rns_stages(2048, primes, t)
