@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="ciphertexts per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="ciphertexts per GPU per step (SURVEY 8(d): device-resident throughput batches of 64 / 256 / 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--cpu-reps", type=int, default=4)
@@ -133,11 +133,15 @@ def main():
         ms = timer.stop() / reps
         alg_bytes = 16.0 * n * K * polys
         achieved = alg_bytes / (ms * 1e-3) / 1e9
+        # HBM bytes of one launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes,
+        # MI355X_MICROARCH.md).  The passes record their own launch shape; traffic per transform does not depend on
+        # the batch, so a different shape is scaled by the number of transforms.
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_ntt_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                traffic = int(round(pj["hbm_bytes_per_launch"] * (K * polys) / float(pj.get("transforms_per_launch", 480))))
             except Exception:
                 traffic = None
         roofline = dict(bound="hbm", kernel="ntt_forward = ntt2_fwd_p1 + ntt2_fwd_p2 (two-pass engine), %d transforms of 2^16 per launch" % (K * polys),
