@@ -198,7 +198,9 @@ namespace sealhip
         // ---------------------------------------------------------------------------------------
         // pass 1 body: src (natural order, column tile cg) -> D1 stages -> mid (tile order)
         // ---------------------------------------------------------------------------------------
-        template <bool FP, int D1>
+        // BS = words between consecutive 256-word blocks of the tile-order intermediate (256 in HBM; 272 when the
+        // intermediate lives in LDS, so that the 16-lane runs of one wave instruction fall on different banks)
+        template <bool FP, int D1, int BS = 256>
         __device__ __forceinline__ void p1_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const TwRegs<FP> &tw, uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
@@ -241,7 +243,7 @@ namespace sealhip
             }
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
             const unsigned col = cg * G::C + c;
-            uint64_t *o = mid_tr + ((size_t)(hi * 16 + (col >> 4)) << 8) + (col & 15);
+            uint64_t *o = mid_tr + (size_t)(hi * 16 + (col >> 4)) * BS + (col & 15);
 #pragma unroll
             for (int rb = 0; rb < 16; rb++)
                 o[rb * 16] = F::raw(x[rb]);
@@ -595,6 +597,83 @@ namespace sealhip
                 fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
             else
                 fwd_p2_body<false, D1>(a, prime, comp, outer, lds);
+        }
+
+        // ---------------------------------------------------------------------------------------
+        // N = 2^13: both passes in ONE launch with the intermediate in LDS (the transform is 64 KiB).
+        // A workgroup of 512 threads = two teams of 256; team k runs pass 1 on column tile k, the
+        // teams meet at a barrier, team k runs pass 2 on row tile k: every coefficient crosses HBM
+        // once in each direction (algorithmic traffic) instead of twice.  Plain in-place transforms
+        // only; the mapped-source and epilogue variants stay on the two-launch engine.
+        // ---------------------------------------------------------------------------------------
+        constexpr int kFusedD1 = 5;
+        constexpr int kFusedBS = 272;                                           // padded block of the LDS intermediate
+        constexpr size_t kFusedMidWords = (size_t)Geo<kFusedD1>::TILES * 16 * kFusedBS;
+        constexpr size_t kFusedTeamWords = kLds2Words > Geo<kFusedD1>::lds1_words ? kLds2Words : Geo<kFusedD1>::lds1_words;
+        constexpr size_t kFusedLdsBytes = (kFusedMidWords + Geo<kFusedD1>::TILES * kFusedTeamWords) * 8;
+
+        template <bool FP>
+        __device__ __forceinline__ void fwd_fused_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<FP> F;
+            constexpr int D1 = kFusedD1;
+            typedef Geo<D1> G;
+            const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
+            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
+            uint64_t *mid = lds;
+            uint64_t *scratch = lds + kFusedMidWords + team * kFusedTeamWords;
+            uint64_t *lds_wave = scratch + (tid >> 6) * (4 * kRowWords);
+            const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
+            uint64_t *base = a.data + ((size_t)comp << G::n);
+            TwRegs<FP> tw;
+            p1_load_tw<FP, D1>(tw, tab, tid);
+            uint64_t nxt[16];
+            auto fetch = [&](unsigned z) {
+                const uint64_t *in = base + (size_t)z * a.outer_stride + team * G::C + c;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+                    nxt[e] = in[(size_t)R * 256];
+                }
+            };
+            const unsigned ostride = gridDim.z;
+            fetch(outer);
+            for (; outer < a.nouter; outer += ostride)
+            {
+                typename F::elem x[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    x[e] = F::from_canon(nxt[e], m);
+                if (outer + ostride < a.nouter)
+                    fetch(outer + ostride);
+                // pass 1 on column tile `team` -> LDS intermediate (p1_tile synchronises the workgroup around its exchange)
+                p1_tile<FP, D1, kFusedBS>(x, m, tab, tw, scratch, mid, team, tid);
+                __syncthreads();
+                // pass 2 on row tile `team`
+                const uint64_t *mp = mid + (size_t)(team * 16) * kFusedBS + tid;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    x[e] = F::unraw(mp[e * kFusedBS]);
+                p2_tile<FP, D1, false>(x, m, tab, nullptr, nullptr, lds_wave, team, tid);
+                uint64_t val[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    val[e] = a.lazy ? F::fwd_to_lazy(x[e], m) : F::fwd_to_canon(x[e], m);
+                store_rows(val, lds_wave, base + (size_t)outer * a.outer_stride + ((size_t)(team * 16 + (tid >> 6) * 4) << 8), tid);
+                __syncthreads(); // the intermediate and the exchange buffers are free again
+            }
+        }
+
+        // double-precision back end only: the integer butterflies do not fit 256 VGPRs next to the prefetch
+        __global__ void __launch_bounds__(2 * kThreads) ntt2_fwd_fused(FwdArgs a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
+            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            fwd_fused_body<true>(a, prime, comp, outer, lds);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1188,9 +1267,38 @@ namespace sealhip
             if (chunks > 65535)
                 chunks = 65535;
             size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
+            bool fused = false;
+            unsigned fchunks = 1;
+            if constexpr (D1 == kFusedD1)
+            {
+                static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED");
+                if (fused_ok && !a.src && a.epi == 0)
+                {
+                    static bool raised = false;
+                    if (!raised)
+                    {
+                        // above the default 64 KiB of dynamic LDS
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsBytes) != hipSuccess)
+                            return hipErrorInvalidValue;
+                        raised = true;
+                    }
+                    fused = true;
+                    // one 512-thread workgroup per CU fits (142 KiB of LDS): a few loop iterations per workgroup
+                    fchunks = (1024 + a.ncomp - 1) / a.ncomp;
+                    if (fchunks > nouter)
+                        fchunks = nouter;
+                    if (fchunks > 65535)
+                        fchunks = 65535;
+                }
+            }
             return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp), s, [&](const CompRun &r, hipStream_t st) {
                 FwdArgs g = a;
                 g.comp0 = r.c0;
+                if (fused && r.cls == 1)
+                {
+                    hipLaunchKernelGGL(ntt2_fwd_fused, dim3(1, r.nc, fchunks), dim3(2 * kThreads), kFusedLdsBytes, st, g);
+                    return hipGetLastError();
+                }
                 dim3 grid(G::TILES, r.nc, chunks);
                 if (r.cls == 1)
                     hipLaunchKernelGGL((ntt2_fwd_p1<D1, 1>), grid, dim3(kThreads), l1, st, g);
