@@ -1354,43 +1354,62 @@ namespace sealhip
             typedef Geo<D1> G;
             if (a1.ntargets == 0)
                 return hipSuccess;
-            size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
+            const size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
             const unsigned groups = batch * G::TILES;
-            hipError_t e;
-            if (n_int)
-            {
-                Ks1Args c = a1; // targets1 = [integer moduli..., double-precision moduli...]
-                c.ntargets = n_int;
-                hipLaunchKernelGGL((ks1_kernel<false, D1>), dim3(((groups + 7) / 8) * n_int * 8), dim3(kThreads), l1, s, c);
-                if ((e = hipGetLastError()) != hipSuccess)
-                    return e;
-            }
-            if (a1.ntargets > n_int)
-            {
-                Ks1Args c = a1;
-                c.targets = a1.targets + 2 * n_int;
-                c.ntargets = a1.ntargets - n_int;
-                hipLaunchKernelGGL((ks1_kernel<true, D1>), dim3(((groups + 7) / 8) * c.ntargets * 8), dim3(kThreads), l1, s, c);
-                if ((e = hipGetLastError()) != hipSuccess)
-                    return e;
-            }
-            const unsigned ntile = a2.ntargets * G::TILES;
-            const unsigned blocks = ((ntile + 7) / 8) * batch * 8;
-            // the double-precision back end stages its tile's twiddles in LDS
-            size_t l2 = kLds2Words * 8 + (a1.ntargets > n_int ? (240 + 3840) * sizeof(double) : 0);
-            if (l2 > 65536)
+            const unsigned n_fp = a1.ntargets - n_int;
+            const size_t l2_fp = kLds2Words * 8 + (240 + 3840) * sizeof(double); // the tile's twiddles staged in LDS
+            if (n_fp && l2_fp > 65536)
             {
                 // more than the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU)
                 static bool raised = false;
                 if (!raised)
                 {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) != hipSuccess)
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2_fp) != hipSuccess)
                         return hipErrorInvalidValue;
                     raised = true;
                 }
             }
-            hipLaunchKernelGGL((ks2_kernel<D1>), dim3(blocks), dim3(kThreads), l2, s, a2);
-            return hipGetLastError();
+            // both passes for the targets of one arithmetic class (targets = [integer moduli..., double-precision moduli...])
+            auto run_class = [&](bool fp, hipStream_t st) -> hipError_t {
+                const unsigned t0 = fp ? n_int : 0, nt = fp ? n_fp : n_int;
+                if (!nt)
+                    return hipSuccess;
+                Ks1Args c1 = a1;
+                c1.targets = a1.targets + 2 * t0;
+                c1.ntargets = nt;
+                const dim3 g1(((groups + 7) / 8) * nt * 8);
+                if (fp)
+                    hipLaunchKernelGGL((ks1_kernel<true, D1>), g1, dim3(kThreads), l1, st, c1);
+                else
+                    hipLaunchKernelGGL((ks1_kernel<false, D1>), g1, dim3(kThreads), l1, st, c1);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess)
+                    return e;
+                Ks2Args c2 = a2;
+                c2.targets = a2.targets + 3 * t0;
+                c2.ntargets = nt;
+                const unsigned ntile = nt * G::TILES;
+                hipLaunchKernelGGL((ks2_kernel<D1>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), fp ? l2_fp : kLds2Words * 8, st, c2);
+                return hipGetLastError();
+            };
+            // The integer-back-end targets (60-bit moduli) are latency-bound at two waves per SIMD, the
+            // double-precision ones are issue-bound: on two streams their workgroups share the CUs.
+            SideStream &ss = side_stream();
+            static const bool fork_ok = !std::getenv("SEALHIP_KS_NOFORK");
+            hipError_t e;
+            if (n_int && n_fp && ss.ok && fork_ok)
+            {
+                if ((e = hipEventRecord(ss.fork, s)) != hipSuccess || (e = hipStreamWaitEvent(ss.stream, ss.fork, 0)) != hipSuccess)
+                    return e;
+                if ((e = run_class(false, ss.stream)) != hipSuccess || (e = hipEventRecord(ss.join, ss.stream)) != hipSuccess)
+                    return e;
+                if ((e = run_class(true, s)) != hipSuccess)
+                    return e;
+                return hipStreamWaitEvent(s, ss.join, 0);
+            }
+            if ((e = run_class(false, s)) != hipSuccess)
+                return e;
+            return run_class(true, s);
         }
     } // namespace
 
