@@ -175,3 +175,91 @@ def test_destination_forms_leave_operands_untouched(ckks):
     d.ev.sub(x, y, y)   # destination aliases the second operand (evaluator.h sub())
     q = np.array(primes[:3], dtype=np.uint64)[None, :, None]
     assert np.array_equal(d.out(y)[0], (a + q - b) % q)
+
+
+# ---- plaintext operands, many-operand forms, digit-parallel halves: the reference's throw sites
+#      (native/src/seal/evaluator.cpp:242-261, 1649-1757, 1760-2020, 2196-2230; valcheck.cpp:28-79)
+def test_plain_operand_errors(ckks):
+    S, d, o, primes, rng = ckks
+    pid3, pid2 = d.parms_id_for_K(3), d.parms_id_for_K(2)
+    x = d.ct(rand_ct(rng, primes, 3, 64), scale=2.0 ** 20)
+    good = S.Plaintext.from_numpy(d.ctx, np.stack([rng.integers(0, primes[i], 64, dtype=np.uint64) for i in range(3)]), pid3, 2.0 ** 20)
+    d.ev.add_plain_inplace(x, good)
+    with pytest.raises(S.InvalidArgument):   # "CKKS plain must be in NTT form" evaluator.cpp:1793
+        d.ev.add_plain_inplace(x, S.Plaintext.from_numpy(d.ctx, np.arange(8, dtype=np.uint64)))
+    lower = S.Plaintext.from_numpy(d.ctx, np.zeros((2, 64), dtype=np.uint64), pid2, 2.0 ** 20)
+    with pytest.raises(S.InvalidArgument):   # "encrypted and plain parameter mismatch" evaluator.cpp:1797
+        d.ev.add_plain_inplace(x, lower)
+    other_scale = S.Plaintext.from_numpy(d.ctx, np.zeros((3, 64), dtype=np.uint64), pid3, 2.0 ** 21)
+    with pytest.raises(S.InvalidArgument):   # "scale mismatch" evaluator.cpp:1801
+        d.ev.sub_plain_inplace(x, other_scale)
+    bad_count = S.Plaintext.from_numpy(d.ctx, np.zeros(65, dtype=np.uint64))
+    bad_count.set_parms_id(pid3)
+    with pytest.raises(S.InvalidArgument):   # is_metadata_valid_for: coeff_count != K*N, valcheck.cpp:56-59
+        d.ev.multiply_plain_inplace(x, bad_count)
+    with pytest.raises(S.InvalidArgument):   # "plain is already in NTT form" evaluator.cpp:2211
+        d.ev.transform_plain_to_ntt_inplace(good, pid3)
+    big = S.Plaintext.from_numpy(d.ctx, np.ones((3, 64), dtype=np.uint64), pid3, 2.0 ** 90)
+    with pytest.raises(S.InvalidArgument):   # "scale out of bounds" evaluator.cpp:2191
+        d.ev.multiply_plain_inplace(x, big)
+    # mod switching a plaintext follows the chain and stops at its end (evaluator.cpp:1377-1380)
+    p = good.copy()
+    d.ev.mod_switch_plain_to_next_inplace(p)
+    d.ev.mod_switch_plain_to_next_inplace(p)
+    assert p.coeff_count() == 64
+    with pytest.raises(S.InvalidArgument):
+        d.ev.mod_switch_plain_to_next_inplace(p)
+
+
+def test_many_operand_errors(ckks):
+    S, d, o, primes, rng = ckks
+    x = d.ct(rand_ct(rng, primes, 3, 64))
+    dest = S.Ciphertext(d.ctx)
+    with pytest.raises(S.InvalidArgument):   # "encrypteds cannot be empty" evaluator.cpp:244
+        d.ev.add_many([], dest)
+    with pytest.raises(S.InvalidArgument):   # "encrypteds must be different from destination" evaluator.cpp:250
+        d.ev.add_many([x, x.copy()], x)
+    with pytest.raises(S.LogicError):        # multiply_many is BFV/BGV only, evaluator.cpp:1682
+        d.ev.multiply_many([x, x.copy()], d.rlk, dest)
+    with pytest.raises(S.InvalidArgument):   # "exponent cannot be 0" evaluator.cpp:1743
+        d.ev.exponentiate_inplace(x, 0, d.rlk)
+    d.ev.exponentiate_inplace(x, 1, d.rlk)    # exponent 1 returns before the scheme check (evaluator.cpp:1747-1750)
+
+
+def test_digit_parallel_argument_checks(ckks):
+    S, d, o, primes, rng = ckks
+    x3 = d.ct(rand_ct(rng, primes, 3, 64, size=3))
+    words = d.ev.switch_key_acc_words(x3)
+    assert words == 2 * (3 + 1) * 64
+    acc = S.DeviceBuffer(words)
+    with pytest.raises(S.InvalidArgument):   # digit range beyond the K = 3 digits of this level
+        d.ev.relinearize_partial(x3, d.rlk, 2, 2, acc.ptr)
+    sliced = S.RelinKeys(d.ctx)
+    sliced.set_key_digits(0, 1, o.relin_key()[1:2])
+    with pytest.raises(S.InvalidArgument):   # the resident key slice [1, 2) does not cover digits [0, 2)
+        d.ev.relinearize_partial(x3, sliced, 0, 2, acc.ptr)
+    d.ev.relinearize_partial(x3, sliced, 1, 1, acc.ptr)
+    with pytest.raises(S.InvalidArgument):   # more than eight partial sums do not fit a 64-bit word
+        d.ev.relinearize_finish(x3, acc.ptr, 9)
+    x2 = d.ct(rand_ct(rng, primes, 3, 64))
+    with pytest.raises(S.InvalidArgument):   # digit-parallel relinearization takes a size-3 ciphertext
+        d.ev.relinearize_partial(x2, d.rlk, 0, 3, acc.ptr)
+
+
+def test_bgv_correction_factor_validation(emu):
+    S = emu
+    n = 64
+    primes = coeff_modulus_create(n, [40, 40, 41])
+    t = plain_modulus_batching(n, 13)
+    d = DeviceSide("bgv", n, primes, t)
+    rng = np.random.default_rng(5)
+    x = d.ct(rand_ct(rng, primes, 2, n), is_ntt=True)
+    x.set_correction_factor(0)
+    with pytest.raises(S.InvalidArgument):   # is_metadata_valid_for: correction factor must be in [1, t), valcheck.cpp:118-123
+        d.ev.negate_inplace(x)
+    x.set_correction_factor(t)
+    with pytest.raises(S.InvalidArgument):
+        d.ev.negate_inplace(x)
+    y = d.ct(rand_ct(rng, primes, 2, n), is_ntt=False)
+    with pytest.raises(S.InvalidArgument):   # "encrypted1 or encrypted2 must be in NTT form" evaluator.cpp:712
+        d.ev.multiply_inplace(y, y.copy())
