@@ -21,8 +21,8 @@ namespace sealhip
     // I == J instead of transforming (null for BFV).  key: register order (key_to_register_order).
     // targets*: device arrays, one entry per target modulus, the integer-back-end (60-bit) moduli first:
     //   targets1: pairs (I, pool prime); targets2: triples (I, pool prime, key component)
-    // Pass 1 runs one launch per back end; pass 2 is one launch that picks the back end per workgroup from
-    // NttTables::fpd (both bodies need the same registers; the heavy 60-bit tiles start first).
+    // Both passes run one launch per back end; the integer-back-end launches go to a side stream so that their
+    // latency-bound workgroups share the CUs with the issue-bound double-precision ones.
     struct KsFusedArgs
     {
         const uint64_t *t;

@@ -37,6 +37,7 @@
 #define SEALHIP_FP_WAVES_P2 4
 #endif
 
+
 namespace sealhip
 {
     namespace
@@ -1042,7 +1043,10 @@ namespace sealhip
                         nxt[e] = mp[e * 256];
                 }
             };
-            if constexpr (FP)
+            // The integer back end has no registers to spare for the prefetch: measured on MI355X, prefetching with
+            // the overflow spilled to scratch gains nothing and one wave per SIMD (512 registers) loses 10 %.
+            constexpr bool PF = FP;
+            if constexpr (PF)
             {
                 if (a.j0 < a.j1)
                     fetch(a.j0);
@@ -1051,8 +1055,8 @@ namespace sealhip
             {
                 typename F::elem x[16];
                 const bool is_diag = diag && J == I;
-                if constexpr (!FP)
-                    fetch(J); // the integer back end has no registers to spare for a prefetch
+                if constexpr (!PF)
+                    fetch(J);
                 if (is_diag)
                 {
 #pragma unroll
@@ -1130,7 +1134,8 @@ namespace sealhip
             store_rows(val, lds_wave, out + ((size_t)(a.K + 1) << G::n), tid);
         }
 
-        template <int D1>
+        // CLS: 0 integer-back-end targets only, 1 double-precision targets only
+        template <int D1, int CLS>
         __global__ void __launch_bounds__(kThreads, 2) ks2_kernel(Ks2Args a)
         {
             typedef Geo<D1> G;
@@ -1146,7 +1151,7 @@ namespace sealhip
                 return;
             const unsigned it = tile / G::TILES, hg = tile % G::TILES;
             const unsigned I = a.targets[3 * it], prime = a.targets[3 * it + 1], kc = a.targets[3 * it + 2];
-            if (a.tb.fpd[prime].qi)
+            if constexpr (CLS == 1)
                 ks2_body<true, D1>(a, lds, I, prime, kc, b, hg);
             else
                 ks2_body<false, D1>(a, lds, I, prime, kc, b, hg);
@@ -1364,7 +1369,7 @@ namespace sealhip
                 static bool raised = false;
                 if (!raised)
                 {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2_fp) != hipSuccess)
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<D1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2_fp) != hipSuccess)
                         return hipErrorInvalidValue;
                     raised = true;
                 }
@@ -1389,7 +1394,10 @@ namespace sealhip
                 c2.targets = a2.targets + 3 * t0;
                 c2.ntargets = nt;
                 const unsigned ntile = nt * G::TILES;
-                hipLaunchKernelGGL((ks2_kernel<D1>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), fp ? l2_fp : kLds2Words * 8, st, c2);
+                if (fp)
+                    hipLaunchKernelGGL((ks2_kernel<D1, 1>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), l2_fp, st, c2);
+                else
+                    hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), kLds2Words * 8, st, c2);
                 return hipGetLastError();
             };
             // The integer-back-end targets (60-bit moduli) are latency-bound at two waves per SIMD, the
