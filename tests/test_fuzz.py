@@ -1,0 +1,47 @@
+"""Randomised operation sequences against the real reference (tests/fuzz_cases.py).  CPU: small degrees on the fiber
+emulator (host logic + index arithmetic); GPU: the same generator over every kernel family (small single-pass kernels,
+the two-pass engine with both arithmetic back ends in one context, BEHZ, BGV)."""
+import numpy as np
+import pytest
+
+import fuzz_cases as F
+import sealref
+
+
+def _configs(seed, count, degrees):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        scheme = ["ckks", "bfv", "bgv"][int(rng.integers(0, 3))]
+        n = int(degrees[rng.integers(0, len(degrees))])
+        L = int(rng.integers(3, 7))
+        lo = 32 if n >= 4096 else (24 if n >= 64 else 20)
+        bits = [int(b) for b in rng.integers(lo, 61, L)]
+        if scheme != "ckks":
+            bits = [max(b, 30) for b in bits]
+        tb = 20 if n >= 1024 else int(rng.integers(13, 21))   # PlainModulus::Batching(n, 20) exists for every degree used here
+        out.append((scheme, n, bits, tb, int(rng.integers(1, 4)), int(rng.integers(4, 9)), 1000 * seed + i))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _configs(11, 12, [16, 64, 128, 256]), ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+def test_random_sequences_emulated(emu, cfg):
+    if not sealref.available():
+        pytest.skip("needs the real reference (oracle/_ref)")
+    try:
+        F.run_sequence(*cfg)
+    except sealref.RefError as e:   # a parameter set the reference itself rejects (e.g. no batching prime of that size)
+        pytest.skip("reference rejected the parameters: %s" % e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", _configs(7, 36, [32, 512, 2048, 4096, 8192, 8192, 16384, 16384, 32768]) +
+                         _configs(8, 24, [64, 1024, 8192, 16384, 32768, 65536]),
+                         ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+def test_random_sequences_gpu(gpu, cfg):
+    if not sealref.available():
+        pytest.skip("needs the real reference (oracle/_ref)")
+    try:
+        F.run_sequence(*cfg)
+    except sealref.RefError as e:
+        pytest.skip("reference rejected the parameters: %s" % e)
