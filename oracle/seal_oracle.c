@@ -485,6 +485,87 @@ void so_bfv_mod_switch(const so_ctx *c, int K, const uint64_t *in, int size, uin
         }
     }
 }
+void so_bgv_mod_switch(const so_ctx *c, int K, const uint64_t *in, int size, uint64_t *out)
+{
+    /* mod_t_and_divide_q_last_ntt_inplace (rns.cpp:1193-1236): c_l = INTT(c[l]); k = -(c_l mod t) q_l^-1 mod t;
+       delta_i = ((k mod q_i) q_l + c_l) mod q_i; c'_i = (c_i - NTT_i(delta_i)) q_l^-1 mod q_i */
+    uint64_t n = c->n, ql = c->q[K - 1], t = c->t, inv_t = invmod(ql % t, t);
+    uint64_t *r = (uint64_t *)malloc(n * 8), *u = (uint64_t *)malloc(n * 8);
+    for (int p = 0; p < size; p++)
+    {
+        const uint64_t *poly = in + (size_t)p * K * n;
+        memcpy(r, poly + (size_t)(K - 1) * n, n * 8);
+        so_ntt_inverse(c, K - 1, r);
+        for (int i = 0; i + 1 < K; i++)
+        {
+            uint64_t qi = c->q[i], inv = invmod(ql % qi, qi);
+            for (uint64_t j = 0; j < n; j++)
+            {
+                uint64_t k = mulmod(submod(0, r[j] % t, t), inv_t, t);
+                u[j] = addmod(mulmod(k % qi, ql % qi, qi), r[j] % qi, qi);
+            }
+            so_ntt_forward(c, i, u);
+            uint64_t *op = out + ((size_t)p * (K - 1) + i) * n;
+            for (uint64_t j = 0; j < n; j++)
+                op[j] = mulmod(submod(poly[(size_t)i * n + j], u[j], qi), inv, qi);
+        }
+    }
+    free(r);
+    free(u);
+}
+uint64_t so_bgv_mod_switch_correction(const so_ctx *c, int K, uint64_t correction_factor)
+{
+    /* evaluator.cpp:1286-1292 */
+    return mulmod(correction_factor % c->t, invmod(c->q[K - 1] % c->t, c->t), c->t);
+}
+
+/* ---------------------------------------------------------------- plaintext operands (evaluator.cpp:1760-2287) */
+void so_plain_lift(const so_ctx *c, int K, const uint64_t *m, uint64_t count, uint64_t scale_by, uint64_t *out)
+{
+    /* the centred lift of transform_to_ntt_inplace(Plaintext) / multiply_plain_normal (:2098-2125, :2243-2282):
+       m >= (t+1)/2 represents m - t, i.e. m + (Q - t) modulo every q_i; coefficients beyond `count` are zero */
+    uint64_t n = c->n, t = c->t, thr = (t + 1) >> 1;
+    for (int i = 0; i < K; i++)
+    {
+        uint64_t qi = c->q[i], inc = (qi - t % qi) % qi;
+        for (uint64_t j = 0; j < n; j++)
+        {
+            uint64_t v = 0;
+            if (j < count)
+            {
+                uint64_t mv = scale_by == 1 ? m[j] : mulmod(m[j], scale_by % t, t);
+                v = mv % qi;
+                if (mv >= thr)
+                    v = addmod(v, inc, qi);
+            }
+            out[(size_t)i * n + j] = v;
+        }
+    }
+}
+void so_bfv_addsub_plain(const so_ctx *c, int K, uint64_t *c0, const uint64_t *m, uint64_t count, int sub)
+{
+    /* multiply_add/sub_plain_with_scaling_variant (util/scalingvariant.cpp:70-175):
+       fix = floor((m (Q mod t) + (t+1)/2) / t); c0_i +/-= (m floor(Q/t) + fix) mod q_i */
+    uint64_t n = c->n, t = c->t, thr = (t + 1) >> 1;
+    uint64_t q_mod_t = 1;
+    for (int i = 0; i < K; i++)
+        q_mod_t = mulmod(q_mod_t, c->q[i] % t, t);
+    for (int i = 0; i < K; i++)
+    {
+        uint64_t qi = c->q[i];
+        /* floor(Q/t) = (Q - Q mod t)/t and Q = 0 (mod q_i): floor(Q/t) = -(Q mod t) t^-1 (mod q_i) */
+        uint64_t delta = mulmod(submod(0, q_mod_t % qi, qi), invmod(t % qi, qi), qi);
+        for (uint64_t j = 0; j < count && j < n; j++)
+        {
+            unsigned __int128 num = (unsigned __int128)m[j] * q_mod_t + thr;
+            uint64_t fix = (uint64_t)(num / t);
+            uint64_t scaled = addmod(mulmod(m[j] % qi, delta, qi), fix % qi, qi);
+            uint64_t *p = c0 + (size_t)i * n + j;
+            *p = sub ? submod(*p, scaled, qi) : addmod(*p, scaled, qi);
+        }
+    }
+}
+
 void so_drop_last(const so_ctx *c, int K, const uint64_t *in, int size, uint64_t *out)
 {
     /* mod_switch_drop_to_next (evaluator.cpp:1296-1367) */
@@ -502,9 +583,9 @@ void so_switch_key(const so_ctx *c, int K, uint64_t *ct, const uint64_t *target,
     uint64_t *S = (uint64_t *)calloc((size_t)2 * (K + 1) * n, 8); /* S[k][I] */
     uint64_t *tmp = (uint64_t *)malloc(n * 8);
     memcpy(t, target, (size_t)K * n * 8);
-    if (c->scheme == 2)
+    if (c->scheme != 1)
         for (int J = 0; J < K; J++)
-            so_ntt_inverse(c, J, t + (size_t)J * n); /* :2651-2658 */
+            so_ntt_inverse(c, J, t + (size_t)J * n); /* CKKS and BGV targets are in NTT form :2651-2658 */
     for (int I = 0; I <= K; I++)
     {
         int pi = I == K ? L - 1 : I; /* key_index :2664 */
@@ -522,6 +603,35 @@ void so_switch_key(const so_ctx *c, int K, uint64_t *ct, const uint64_t *target,
                     sp[j] = addmod(sp[j], mulmod(tmp[j], kp[j], m), m); /* :2705-2755 */
             }
         }
+    }
+    if (c->scheme == 3)
+    {
+        /* BGV mod-down (:2762-2805): k = -(t_last mod t) P^-1 mod t; delta = (k mod q_i) P + t_last (mod q_i);
+           ct_k[i] += (S_k[q_i] - NTT_i(delta)) P^-1 */
+        const uint64_t tt = c->t, pinv_t = invmod(P % tt, tt);
+        for (int k = 0; k < 2; k++)
+        {
+            uint64_t *r = S + ((size_t)k * (K + 1) + K) * n;
+            ntt_inv_generic(r, n, c->logn, P, c->psi[L - 1]);
+            for (int i = 0; i < K; i++)
+            {
+                uint64_t qi = c->q[i], pinv = invmod(P % qi, qi);
+                uint64_t *sp = S + ((size_t)k * (K + 1) + i) * n;
+                uint64_t *cp = ct + ((size_t)k * K + i) * n;
+                for (uint64_t j = 0; j < n; j++)
+                {
+                    uint64_t kk = mulmod(submod(0, r[j] % tt, tt), pinv_t, tt);
+                    tmp[j] = addmod(mulmod(kk % qi, P % qi, qi), r[j] % qi, qi);
+                }
+                so_ntt_forward(c, i, tmp);
+                for (uint64_t j = 0; j < n; j++)
+                    cp[j] = addmod(cp[j], mulmod(submod(sp[j], tmp[j], qi), pinv, qi), qi);
+            }
+        }
+        free(t);
+        free(S);
+        free(tmp);
+        return;
     }
     for (int k = 0; k < 2; k++)
     {

@@ -11,7 +11,7 @@
 
 typedef struct so_ctx so_ctx;
 
-/* scheme: 1 bfv, 2 ckks.  primes = full coeff_modulus (last one is the special key-switching prime). */
+/* scheme: 1 bfv, 2 ckks, 3 bgv.  primes = full coeff_modulus (last one is the special key-switching prime). */
 so_ctx *so_ctx_create(int scheme, uint64_t n, const uint64_t *primes, int count, uint64_t plain_modulus);
 void so_ctx_destroy(so_ctx *c);
 uint64_t so_ntt_root(const so_ctx *c, int prime_index);
@@ -38,6 +38,13 @@ void so_switch_key(const so_ctx *c, int K, uint64_t *ct, const uint64_t *target,
 void so_rescale(const so_ctx *c, int K, const uint64_t *in, int size, uint64_t *out);
 void so_bfv_mod_switch(const so_ctx *c, int K, const uint64_t *in, int size, uint64_t *out);
 void so_drop_last(const so_ctx *c, int K, const uint64_t *in, int size, uint64_t *out);
+/* BGV mod_switch_to_next (rns.cpp:1193-1236) and the correction factor it leaves (evaluator.cpp:1286-1292) */
+void so_bgv_mod_switch(const so_ctx *c, int K, const uint64_t *in, int size, uint64_t *out);
+uint64_t so_bgv_mod_switch_correction(const so_ctx *c, int K, uint64_t correction_factor);
+/* plaintext operands: centred lift of `count` coefficients mod t into [K][N] residues (times scale_by mod t);
+ * BFV add_plain / sub_plain on c0 = [K][N] (util/scalingvariant.cpp:70-175) */
+void so_plain_lift(const so_ctx *c, int K, const uint64_t *m, uint64_t count, uint64_t scale_by, uint64_t *out);
+void so_bfv_addsub_plain(const so_ctx *c, int K, uint64_t *c0, const uint64_t *m, uint64_t count, int sub);
 /* one polynomial [K][N] */
 void so_apply_galois(const so_ctx *c, int K, int ntt_form, uint32_t elt, const uint64_t *in, uint64_t *out);
 uint32_t so_galois_elt_from_step(const so_ctx *c, int step);

@@ -50,7 +50,7 @@ class PortContext:
         self.scheme, self.n, self.primes, self.t = scheme, n, list(primes), plain_modulus
         self.L = len(primes)
         arr = np.array(primes, dtype=np.uint64)
-        self.h = C.c_void_p(lib().so_ctx_create(C.c_int({"bfv": 1, "ckks": 2}[scheme]), C.c_uint64(n), _p(arr),
+        self.h = C.c_void_p(lib().so_ctx_create(C.c_int({"bfv": 1, "ckks": 2, "bgv": 3}[scheme]), C.c_uint64(n), _p(arr),
                                                 C.c_int(len(primes)), C.c_uint64(plain_modulus)))
         assert self.h.value
 
@@ -95,7 +95,7 @@ class PortContext:
         y = np.ascontiguousarray(y, dtype=np.uint64)
         K = x.shape[1]
         out = np.zeros((x.shape[0] + y.shape[0] - 1, K, self.n), dtype=np.uint64)
-        if self.scheme == "ckks":
+        if self.scheme != "bfv":   # CKKS and BGV share the NTT-domain tensor product (evaluator.cpp:569-841)
             lib().so_ckks_multiply(self.h, C.c_int(K), _p(x), C.c_int(x.shape[0]), _p(y), C.c_int(y.shape[0]), _p(out))
         else:
             assert lib().so_bfv_multiply(self.h, C.c_int(K), _p(x), C.c_int(x.shape[0]), _p(y), C.c_int(y.shape[0]), _p(out)) == 0
@@ -120,7 +120,7 @@ class PortContext:
 
     def apply_galois(self, ct2, elt, key):
         """Evaluator::apply_galois_inplace (evaluator.cpp:2384-2502)."""
-        ntt_form = self.scheme == "ckks"
+        ntt_form = self.scheme != "bfv"
         c0 = self.apply_galois_poly(ct2[0], ntt_form, elt)
         c1 = self.apply_galois_poly(ct2[1], ntt_form, elt)
         return self.switch_key(np.stack([c0, np.zeros_like(c0)]), c1, key)
@@ -138,6 +138,50 @@ class PortContext:
         ct = np.ascontiguousarray(ct, dtype=np.uint64)
         out = np.zeros((ct.shape[0], ct.shape[1] - 1, self.n), dtype=np.uint64)
         lib().so_bfv_mod_switch(self.h, C.c_int(ct.shape[1]), _p(ct), C.c_int(ct.shape[0]), _p(out))
+        return out
+
+    def bgv_mod_switch(self, ct, correction_factor=1):
+        """-> (ct at the next level, its correction factor)"""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        out = np.zeros((ct.shape[0], ct.shape[1] - 1, self.n), dtype=np.uint64)
+        lib().so_bgv_mod_switch(self.h, C.c_int(ct.shape[1]), _p(ct), C.c_int(ct.shape[0]), _p(out))
+        lib().so_bgv_mod_switch_correction.restype = C.c_uint64
+        cf = lib().so_bgv_mod_switch_correction(self.h, C.c_int(ct.shape[1]), C.c_uint64(correction_factor))
+        return out, int(cf)
+
+    def plain_lift(self, K, m, scale_by=1):
+        m = np.ascontiguousarray(m, dtype=np.uint64)
+        out = np.zeros((K, self.n), dtype=np.uint64)
+        lib().so_plain_lift(self.h, C.c_int(K), _p(m), C.c_uint64(m.size), C.c_uint64(scale_by), _p(out))
+        return out
+
+    def plain_to_ntt(self, K, m, scale_by=1):
+        """transform_to_ntt_inplace(Plaintext, parms_id of the level with K primes) (evaluator.cpp:2196-2287)"""
+        return self.ntt(0, self.plain_lift(K, m, scale_by), "fwd")
+
+    def addsub_plain(self, ct, m, sub=False, correction_factor=1):
+        """add_plain_inplace / sub_plain_inplace (evaluator.cpp:1760-1985), coefficient-form plaintext (BFV, BGV)"""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64).copy()
+        m = np.ascontiguousarray(m, dtype=np.uint64)
+        K = ct.shape[1]
+        if self.scheme == "bfv":
+            lib().so_bfv_addsub_plain(self.h, C.c_int(K), _p(ct[0]), _p(m), C.c_uint64(m.size), C.c_int(int(sub)))
+            return ct
+        p = self.plain_to_ntt(K, m, correction_factor)
+        q = np.array(self.primes[:K], dtype=np.uint64)[:, None]
+        ct[0] = (ct[0] + (q - p) % q) % q if sub else (ct[0] + p) % q
+        return ct
+
+    def multiply_plain(self, ct, m):
+        """multiply_plain_inplace with a coefficient-form plaintext, generic (non-monomial) path (evaluator.cpp:2096-2155)"""
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        K = ct.shape[1]
+        p = self.plain_to_ntt(K, m)
+        out = np.zeros_like(ct)
+        for i in range(ct.shape[0]):
+            x = ct[i] if self.scheme != "bfv" else self.ntt(0, ct[i], "fwd")
+            y = np.stack([self.dyadic(k, x[k], p[k]) for k in range(K)])
+            out[i] = y if self.scheme != "bfv" else self.ntt(0, y, "inv")
         return out
 
     def drop_last(self, ct):

@@ -175,3 +175,58 @@ def test_port_vs_reference_bfv(n, bits, tb):
     assert np.array_equal(r, x.data())
     ref.mod_switch_to_next_inplace(x)
     assert np.array_equal(c.bfv_mod_switch(r), x.data())
+
+
+@needs_ref
+@pytest.mark.parametrize("n,bits,tb", [(16, [36, 36, 37, 38], 10), (128, [40, 50, 40, 45], 14)])
+def test_port_vs_reference_bgv(n, bits, tb):
+    """BGV restatements of the port: tensor product, key switch with the BGV mod-down (evaluator.cpp:2762-2805),
+    mod_t_and_divide_q_last_ntt (rns.cpp:1193-1236), rotate."""
+    primes = R.coeff_modulus_create(n, bits)
+    t = R.plain_modulus_batching(n, tb)
+    ref = R.RefContext("bgv", n, primes, t)
+    ref.keygen_relin()
+    elt = ref.galois_elt_from_step(1)
+    ref.keygen_galois_elts([elt])
+    c = O.PortContext("bgv", n, primes, t)
+    K, fc = len(primes) - 1, ref.first_chain_index
+    rng = np.random.default_rng(n + 13)
+    a, b = rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)
+    x, y = ref.ct(fc, a, True, 1.0, 3), ref.ct(fc, b, True, 1.0, 5)
+    ref.multiply_inplace(x, y)
+    m = c.multiply(a, b)
+    assert np.array_equal(m, x.data())
+    ref.relinearize_inplace(x)
+    r = c.relinearize(m, ref.key("relin", 0))
+    assert np.array_equal(r, x.data())
+    ref.apply_galois_inplace(x, elt)
+    g = c.apply_galois(r, elt, ref.key("galois", (elt - 1) >> 1))
+    assert np.array_equal(g, x.data())
+    cf = x.info()["correction_factor"]
+    ref.mod_switch_to_next_inplace(x)
+    s, cf2 = c.bgv_mod_switch(g, cf)
+    assert np.array_equal(s, x.data()) and cf2 == x.info()["correction_factor"]
+
+
+@needs_ref
+@pytest.mark.parametrize("scheme,n,bits,tb", [("bfv", 64, [40, 40, 41], 13), ("bfv", 128, [30, 30, 30], 40), ("bgv", 64, [40, 40, 41], 13)])
+def test_port_vs_reference_plain_operands(scheme, n, bits, tb):
+    """plaintext lift / transform_to_ntt(Plaintext), add_plain, sub_plain, multiply_plain (generic path) of the port"""
+    primes = R.coeff_modulus_create(n, bits)
+    t = R.plain_modulus_batching(n, tb)
+    ref = R.RefContext(scheme, n, primes, t)
+    c = O.PortContext(scheme, n, primes, t)
+    K, fc = len(primes) - 1, ref.first_chain_index
+    ntt = scheme == "bgv"
+    rng = np.random.default_rng(n + 17)
+    a = rand_ct(rng, primes, K, n)
+    for m in (rng.integers(0, t, n, dtype=np.uint64), rng.integers(0, t, n // 3, dtype=np.uint64)):
+        p = ref.pt_transform_to_ntt_inplace(ref.pt(m), fc)
+        assert np.array_equal(c.plain_to_ntt(K, m).reshape(-1), p.data())
+        for sub in (False, True):
+            x = ref.ct(fc, a, ntt, 1.0, 3 if scheme == "bgv" else 1)
+            (ref.sub_plain_inplace if sub else ref.add_plain_inplace)(x, ref.pt(m))
+            assert np.array_equal(c.addsub_plain(a, m, sub, 3 if scheme == "bgv" else 1), x.data())
+        x = ref.ct(fc, a, ntt, 1.0, 1)
+        ref.multiply_plain_inplace(x, ref.pt(m))
+        assert np.array_equal(c.multiply_plain(a, m), x.data())
