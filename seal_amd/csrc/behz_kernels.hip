@@ -38,6 +38,56 @@ namespace sealhip
             return barrett128(lo, hi, m);
         }
 
+        typedef shl_uconst_ptr uconst_ptr;
+        // wave-uniform per-prime constants through the scalar cache
+        __device__ __forceinline__ ShoupOp ld_shoup(const ShoupOp *p)
+        {
+            uconst_ptr u = SHL_UCONST(reinterpret_cast<const uint64_t *>(p));
+            return ShoupOp{ u[0], u[1] };
+        }
+        __device__ __forceinline__ ModDesc ld_mod(const ModDesc *p)
+        {
+            uconst_ptr u = SHL_UCONST(reinterpret_cast<const uint64_t *>(p));
+            return ModDesc{ u[0], u[1], u[2], u[3] };
+        }
+        __device__ __forceinline__ uint64_t ld_u64(const uint64_t *p)
+        {
+            return SHL_UCONST(p)[0];
+        }
+        __device__ __forceinline__ uint32_t ld_u32(const uint32_t *p)
+        {
+            return SHL_UCONST32(p)[0];
+        }
+
+        // 64x64 -> 128 product with the four 32x32 partial products computed once (v_mad_u64_u32 chain)
+        __device__ __forceinline__ void mul_wide4(uint64_t a, uint64_t b, uint64_t &lo, uint64_t &hi)
+        {
+            const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+            const uint64_t p00 = (uint64_t)a0 * b0;
+            const uint64_t t = (uint64_t)a0 * b1 + (p00 >> 32);          // < 2^64
+            const uint64_t u = (uint64_t)a1 * b0 + (uint32_t)t;          // < 2^64
+            hi = (uint64_t)a1 * b1 + (t >> 32) + (u >> 32);
+            lo = (u << 32) | (uint32_t)p00;
+        }
+        // Exact dot product modulo m of a vector held in REGISTERS with a matrix row read through the scalar cache
+        // (dot_product_mod, util/uintarithsmallmod.cpp:110-175): the loop is unrolled to the compile-time bound KM and
+        // predicated on the wave-uniform length, so the LDS round trip and the loop-carried latency of dot_lds are gone.
+        template <unsigned KM>
+        __device__ __forceinline__ uint64_t dot_reg(const uint64_t (&y)[KM], uconst_ptr row, unsigned count, const ModDesc &m)
+        {
+            uint64_t lo = 0, hi = 0;
+#pragma unroll
+            for (unsigned i = 0; i < KM; i++)
+                if (i < count)
+                {
+                    uint64_t pl, ph;
+                    mul_wide4(y[i], row[i], pl, ph);
+                    lo += pl;
+                    hi += ph + (lo < pl);
+                }
+            return barrett128(lo, hi, m);
+        }
+
         // ---- stage 0: q -> Bsk U {m~}   (fastbconv_m_tilde)
         __device__ __forceinline__ void stage_fastbconv_m_tilde(
             const ModDesc *mods, const LevelDev &lv, const uint64_t *in, uint64_t *out, size_t N, size_t j, uint64_t *y)
@@ -152,11 +202,12 @@ namespace sealhip
             }
         }
 
-        // fused lift: fastbconv_m_tilde + sm_mrq without the Bsk U {m~} round trip through HBM
+        // fused lift: fastbconv_m_tilde + sm_mrq without the Bsk U {m~} round trip through HBM.
+        // KM >= K: the per-coefficient input vector lives in registers (dot_reg).
+        template <unsigned KM>
         __global__ void __launch_bounds__(kBlock) behz_lift_kernel(
             const ModDesc *mods, LevelDev lv, const uint64_t *in, uint64_t *out, unsigned n_log, size_t items)
         {
-            HIP_DYNAMIC_SHARED(uint64_t, y)
             const size_t N = size_t(1) << n_log;
             const size_t total = items << n_log;
             const unsigned K = lv.K;
@@ -166,85 +217,102 @@ namespace sealhip
                 const size_t item = t >> n_log, j = t & (N - 1);
                 const uint64_t *ip = in + item * K * N;
                 uint64_t *op = out + item * lv.nBsk * N;
+                uint64_t y[KM];
                 uint64_t s = 0;
-                for (unsigned i = 0; i < K; i++)
+#pragma unroll
+                for (unsigned i = 0; i < KM; i++)
                 {
-                    const uint64_t q = mods[i].q;
-                    const ShoupOp m = lv.m_tilde_mod_q[i], pq = lv.inv_punct_q[i];
-                    uint64_t v = mul_shoup(mul_shoup(ip[i * N + j], m.w, m.wq, q), pq.w, pq.wq, q);
-                    y[i * kBlock + threadIdx.x] = v;
-                    s += v * lv.q_to_mtilde[i];
+                    y[i] = 0;
+                    if (i < K)
+                    {
+                        const uint64_t q = ld_u64(&mods[i].q);
+                        const ShoupOp m = ld_shoup(&lv.m_tilde_mod_q[i]), pq = ld_shoup(&lv.inv_punct_q[i]);
+                        y[i] = mul_shoup(mul_shoup(ip[i * N + j], m.w, m.wq, q), pq.w, pq.wq, q);
+                        s += y[i] * ld_u64(&lv.q_to_mtilde[i]);
+                    }
                 }
                 uint64_t r = (((s & (mt - 1)) * lv.neg_inv_prod_q_mod_mtilde)) & (mt - 1);
                 for (unsigned jj = 0; jj < lv.nBsk; jj++)
                 {
-                    const ModDesc md = mods[lv.bsk_prime[jj]];
-                    uint64_t c = dot_lds(y, lv.q_to_bsk + jj * K, K, md);
+                    const ModDesc md = ld_mod(&mods[ld_u32(&lv.bsk_prime[jj])]);
+                    uint64_t c = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk + jj * K), K, md);
                     uint64_t tmp = r;
                     if (tmp >= (mt >> 1))
                         tmp += md.q - mt;
                     uint64_t lo, hi;
-                    mul_wide(tmp, lv.prod_q_mod_bsk[jj], lo, hi);
+                    mul_wide4(tmp, ld_u64(&lv.prod_q_mod_bsk[jj]), lo, hi);
                     lo += c;
                     hi += lo < c;
-                    const ShoupOp im = lv.inv_mtilde_mod_bsk[jj];
+                    const ShoupOp im = ld_shoup(&lv.inv_mtilde_mod_bsk[jj]);
                     op[jj * N + j] = mul_shoup(barrett128(lo, hi, md), im.w, im.wq, md.q);
                 }
             }
         }
 
-        // fused tail: (x t) -> fast_floor -> fastbconv_sk   (evaluator.cpp:549-566)
+        // fused tail: (x t) -> fast_floor -> fastbconv_sk   (evaluator.cpp:549-566).  KM >= nB = K or K + 1.
+        // The q-side vector and the B-side vector live in registers; only the |Bsk| floor values, which are written
+        // under a run-time index, pass through LDS once.
+        template <unsigned KM>
         __global__ void __launch_bounds__(kBlock) behz_floor_sk_kernel(
             const ModDesc *mods, LevelDev lv, const uint64_t *dq, const uint64_t *dbsk, uint64_t *out, unsigned n_log,
             size_t items)
         {
-            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            HIP_DYNAMIC_SHARED(uint64_t, f) // [nBsk][kBlock]
             const size_t N = size_t(1) << n_log;
             const size_t total = items << n_log;
             const unsigned K = lv.K, nB = lv.nB, nBsk = lv.nBsk;
-            uint64_t *y = lds;                      // [max(K, nB)][kBlock]
-            uint64_t *f = lds + (K > nB ? K : nB) * kBlock; // [nBsk][kBlock]
             for (size_t t = blockIdx.x * (size_t)kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock)
             {
                 const size_t item = t >> n_log, j = t & (N - 1);
                 const uint64_t *qp = dq + item * K * N;
                 const uint64_t *bp = dbsk + item * nBsk * N;
                 uint64_t *op = out + item * K * N;
-                for (unsigned i = 0; i < K; i++)
+                uint64_t y[KM];
+#pragma unroll
+                for (unsigned i = 0; i < KM; i++)
                 {
-                    const uint64_t q = mods[i].q;
-                    const ShoupOp tm = lv.t_mod_q[i], pq = lv.inv_punct_q[i];
-                    uint64_t z = mul_shoup(qp[i * N + j], tm.w, tm.wq, q); // step (6), evaluator.cpp:554
-                    y[i * kBlock + threadIdx.x] = mul_shoup(z, pq.w, pq.wq, q);
+                    y[i] = 0;
+                    if (i < K)
+                    {
+                        const uint64_t q = ld_u64(&mods[i].q);
+                        const ShoupOp tm = ld_shoup(&lv.t_mod_q[i]), pq = ld_shoup(&lv.inv_punct_q[i]);
+                        uint64_t z = mul_shoup(qp[i * N + j], tm.w, tm.wq, q); // step (6), evaluator.cpp:554
+                        y[i] = mul_shoup(z, pq.w, pq.wq, q);
+                    }
                 }
                 for (unsigned jj = 0; jj < nBsk; jj++)
                 {
-                    const ModDesc md = mods[lv.bsk_prime[jj]];
-                    uint64_t conv = dot_lds(y, lv.q_to_bsk + jj * K, K, md);
-                    const ShoupOp tm = lv.t_mod_bsk[jj], iq = lv.inv_prod_q_mod_bsk[jj];
+                    const ModDesc md = ld_mod(&mods[ld_u32(&lv.bsk_prime[jj])]);
+                    uint64_t conv = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk + jj * K), K, md);
+                    const ShoupOp tm = ld_shoup(&lv.t_mod_bsk[jj]), iq = ld_shoup(&lv.inv_prod_q_mod_bsk[jj]);
                     uint64_t zb = mul_shoup(bp[jj * N + j], tm.w, tm.wq, md.q);
                     f[jj * kBlock + threadIdx.x] = mul_shoup(zb + (md.q - conv), iq.w, iq.wq, md.q); // step (7)
                 }
-                // step (8): Shenoy-Kumaresan
-                for (unsigned i = 0; i < nB; i++)
+                // step (8): Shenoy-Kumaresan (each thread reads back only what it wrote: no barrier)
+#pragma unroll
+                for (unsigned i = 0; i < KM; i++)
                 {
-                    const ShoupOp ib = lv.inv_punct_b[i];
-                    y[i * kBlock + threadIdx.x] = mul_shoup(f[i * kBlock + threadIdx.x], ib.w, ib.wq, mods[lv.bsk_prime[i]].q);
+                    y[i] = 0;
+                    if (i < nB)
+                    {
+                        const ShoupOp ib = ld_shoup(&lv.inv_punct_b[i]);
+                        y[i] = mul_shoup(f[i * kBlock + threadIdx.x], ib.w, ib.wq, ld_u64(&mods[ld_u32(&lv.bsk_prime[i])].q));
+                    }
                 }
-                const ModDesc msk = mods[lv.msk_prime];
-                uint64_t conv_sk = dot_lds(y, lv.b_to_msk, nB, msk);
+                const ModDesc msk = ld_mod(&mods[lv.msk_prime]);
+                uint64_t conv_sk = dot_reg<KM>(y, SHL_UCONST(lv.b_to_msk), nB, msk);
                 uint64_t alpha = mul_shoup(
                     conv_sk + (msk.q - f[nB * kBlock + threadIdx.x]), lv.inv_prod_b_mod_msk.w, lv.inv_prod_b_mod_msk.wq, msk.q);
                 const bool negative = alpha > (msk.q >> 1);
                 const uint64_t mag = negative ? msk.q - alpha : alpha;
                 for (unsigned i = 0; i < K; i++)
                 {
-                    const ModDesc md = mods[i];
-                    uint64_t g = dot_lds(y, lv.b_to_q + i * nB, nB, md);
-                    uint64_t pb = lv.prod_b_mod_q[i];
+                    const ModDesc md = ld_mod(&mods[i]);
+                    uint64_t g = dot_reg<KM>(y, SHL_UCONST(lv.b_to_q + i * nB), nB, md);
+                    uint64_t pb = ld_u64(&lv.prod_b_mod_q[i]);
                     uint64_t factor = negative ? pb : md.q - pb;
                     uint64_t lo, hi;
-                    mul_wide(mag, factor, lo, hi);
+                    mul_wide4(mag, factor, lo, hi);
                     lo += g;
                     hi += lo < g;
                     op[i * N + j] = barrett128(lo, hi, md);
@@ -269,8 +337,17 @@ namespace sealhip
         size_t work = items << n_log;
         if (!work)
             return hipSuccess;
-        size_t shmem = (size_t)lv.K * kBlock * sizeof(uint64_t);
-        hipLaunchKernelGGL(behz_lift_kernel, dim3(grid_for(work)), dim3(kBlock), shmem, s, mods, lv, in, out, n_log, items);
+        const dim3 g(grid_for(work)), b(kBlock);
+        if (lv.K <= 4)
+            hipLaunchKernelGGL(behz_lift_kernel<4>, g, b, 0, s, mods, lv, in, out, n_log, items);
+        else if (lv.K <= 8)
+            hipLaunchKernelGGL(behz_lift_kernel<8>, g, b, 0, s, mods, lv, in, out, n_log, items);
+        else if (lv.K <= 16)
+            hipLaunchKernelGGL(behz_lift_kernel<16>, g, b, 0, s, mods, lv, in, out, n_log, items);
+        else if (lv.K <= 32)
+            hipLaunchKernelGGL(behz_lift_kernel<32>, g, b, 0, s, mods, lv, in, out, n_log, items);
+        else
+            hipLaunchKernelGGL(behz_lift_kernel<kMaxComps>, g, b, 0, s, mods, lv, in, out, n_log, items);
         return hipGetLastError();
     }
 
@@ -281,9 +358,19 @@ namespace sealhip
         size_t work = items << n_log;
         if (!work)
             return hipSuccess;
-        size_t shmem = ((size_t)(lv.K > lv.nB ? lv.K : lv.nB) + lv.nBsk) * kBlock * sizeof(uint64_t);
-        hipLaunchKernelGGL(
-            behz_floor_sk_kernel, dim3(grid_for(work)), dim3(kBlock), shmem, s, mods, lv, dq, dbsk, out, n_log, items);
+        const size_t shmem = (size_t)lv.nBsk * kBlock * sizeof(uint64_t);
+        const dim3 g(grid_for(work)), b(kBlock);
+        const unsigned need = lv.nB > lv.K ? lv.nB : lv.K;
+        if (need <= 4)
+            hipLaunchKernelGGL(behz_floor_sk_kernel<4>, g, b, shmem, s, mods, lv, dq, dbsk, out, n_log, items);
+        else if (need <= 8)
+            hipLaunchKernelGGL(behz_floor_sk_kernel<8>, g, b, shmem, s, mods, lv, dq, dbsk, out, n_log, items);
+        else if (need <= 16)
+            hipLaunchKernelGGL(behz_floor_sk_kernel<16>, g, b, shmem, s, mods, lv, dq, dbsk, out, n_log, items);
+        else if (need <= 32)
+            hipLaunchKernelGGL(behz_floor_sk_kernel<32>, g, b, shmem, s, mods, lv, dq, dbsk, out, n_log, items);
+        else
+            hipLaunchKernelGGL(behz_floor_sk_kernel<kMaxComps + 1>, g, b, shmem, s, mods, lv, dq, dbsk, out, n_log, items);
         return hipGetLastError();
     }
 

@@ -87,6 +87,17 @@ namespace sealhip
     template <bool FP>
     struct Field;
 
+    // wave-uniform twiddle (the index is the same in every lane): scalar load
+    __device__ __forceinline__ ShoupOp ld_uniform(const ShoupOp *tab, unsigned idx)
+    {
+        shl_uconst_ptr u = SHL_UCONST(reinterpret_cast<const uint64_t *>(tab));
+        return ShoupOp{ u[2 * (size_t)idx], u[2 * (size_t)idx + 1] };
+    }
+    __device__ __forceinline__ double ld_uniform(const double *tab, unsigned idx)
+    {
+        return __builtin_bit_cast(double, SHL_UCONST(reinterpret_cast<const uint64_t *>(tab))[idx]);
+    }
+
     // ---- 64-bit integer back end (Shoup multiplication, Harvey lazy butterflies)
     template <>
     struct Field<false>

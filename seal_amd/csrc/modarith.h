@@ -16,6 +16,21 @@
 
 #define SHL_HD __host__ __device__ __forceinline__
 
+// Wave-uniform, read-only tables (conversion matrices, per-prime constants, the twiddles of the first stages): read
+// through the constant address space the compiler may treat them as invariant and use scalar loads (s_load_dwordx2..16
+// into SGPRs) instead of one vector load per lane-uniform element, which also frees the VGPRs that held them.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const uint64_t __attribute__((address_space(4))) *shl_uconst_ptr;
+typedef const uint32_t __attribute__((address_space(4))) *shl_uconst32_ptr;
+#define SHL_UCONST(p) ((shl_uconst_ptr)(uintptr_t)(p))
+#define SHL_UCONST32(p) ((shl_uconst32_ptr)(uintptr_t)(p))
+#else
+typedef const uint64_t *shl_uconst_ptr;
+typedef const uint32_t *shl_uconst32_ptr;
+#define SHL_UCONST(p) (p)
+#define SHL_UCONST32(p) (p)
+#endif
+
 namespace sealhip
 {
     // One precomputed multiplicand: w and floor(w * 2^64 / q)  ("Shoup pair").

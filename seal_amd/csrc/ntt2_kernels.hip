@@ -213,7 +213,7 @@ namespace sealhip
             if constexpr (G::rA > 0)
             {
                 // phase A: register a = ra*2^(4-rA) + rbh; stage s pairs register bit 3-s; twiddle 2^s + group: uniform
-                phase_fwd<FP, G::rA>(x, m, [&](int t, int g) { return tab[(1u << t) + g]; });
+                phase_fwd<FP, G::rA>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
                 if constexpr (FP)
                 {
 #pragma unroll
