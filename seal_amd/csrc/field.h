@@ -87,6 +87,17 @@ namespace sealhip
     template <bool FP>
     struct Field;
 
+    // per-prime constants of a wave-uniform prime through the scalar cache
+    __device__ __forceinline__ ModDesc ld_uniform_mod(const ModDesc *p)
+    {
+        shl_uconst_ptr u = SHL_UCONST(reinterpret_cast<const uint64_t *>(p));
+        return ModDesc{ u[0], u[1], u[2], u[3] };
+    }
+    __device__ __forceinline__ FpDesc ld_uniform_fpd(const FpDesc *p)
+    {
+        shl_uconst_ptr u = SHL_UCONST(reinterpret_cast<const uint64_t *>(p));
+        return FpDesc{ __builtin_bit_cast(double, u[0]), __builtin_bit_cast(double, u[1]), __builtin_bit_cast(double, u[2]), u[3] };
+    }
     // wave-uniform twiddle (the index is the same in every lane): scalar load
     __device__ __forceinline__ ShoupOp ld_uniform(const ShoupOp *tab, unsigned idx)
     {

@@ -24,11 +24,15 @@ typedef const uint64_t __attribute__((address_space(4))) *shl_uconst_ptr;
 typedef const uint32_t __attribute__((address_space(4))) *shl_uconst32_ptr;
 #define SHL_UCONST(p) ((shl_uconst_ptr)(uintptr_t)(p))
 #define SHL_UCONST32(p) ((shl_uconst32_ptr)(uintptr_t)(p))
+// a value that is the same in every lane of the workgroup (block-level index): move it to an SGPR so that
+// everything derived from it (table base addresses, per-prime constants) is provably uniform
+#define SHL_UNIFORM(x) ((unsigned)__builtin_amdgcn_readfirstlane((int)(x)))
 #else
 typedef const uint64_t *shl_uconst_ptr;
 typedef const uint32_t *shl_uconst32_ptr;
 #define SHL_UCONST(p) (p)
 #define SHL_UCONST32(p) (p)
+#define SHL_UNIFORM(x) (x)
 #endif
 
 namespace sealhip

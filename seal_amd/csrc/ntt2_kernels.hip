@@ -443,7 +443,7 @@ namespace sealhip
             typedef Field<FP> F;
             typedef Geo<D1> G;
             const unsigned tid = threadIdx.x, cg = blockIdx.x;
-            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
             SrcMap sm{ 0, 0, 0, 0 };
             const uint64_t *in0;
@@ -499,7 +499,7 @@ namespace sealhip
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
-            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             if constexpr (CLS == 1)
                 fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
@@ -520,7 +520,7 @@ namespace sealhip
             typedef Field<FP> F;
             typedef Geo<D1> G;
             const unsigned tid = threadIdx.x, hg = blockIdx.x;
-            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
             const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + tid;
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
@@ -587,7 +587,7 @@ namespace sealhip
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
-            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             if constexpr (CLS == 3) // double-precision back end, plain transform, twiddles hoisted
                 fwd_p2_body<true, D1, true>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 1)
@@ -620,7 +620,7 @@ namespace sealhip
             constexpr int D1 = kFusedD1;
             typedef Geo<D1> G;
             const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
-            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
             uint64_t *mid = lds;
             uint64_t *scratch = lds + kFusedMidWords + team * kFusedTeamWords;
@@ -673,7 +673,7 @@ namespace sealhip
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
-            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             fwd_fused_body<true>(a, prime, comp, outer, lds);
         }
 
@@ -704,7 +704,7 @@ namespace sealhip
             const unsigned tid = threadIdx.x, hg = blockIdx.x;
             const unsigned v = tid & 15, u = tid >> 4, ul = u & 3;
             const unsigned h = hg * 16 + u;
-            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, true, prime);
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             uint64_t raw[16];
@@ -751,7 +751,7 @@ namespace sealhip
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
-            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             if constexpr (CLS == 1)
                 inv_pa_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
@@ -770,7 +770,7 @@ namespace sealhip
             static_assert(G::rA >= 1, "the N^-1 stage is handled in phase A");
             const unsigned tid = threadIdx.x, cg = blockIdx.x;
             const unsigned c = tid & (G::C - 1), hi = tid >> G::LC;
-            const typename F::Mod m = F::make_mod(a.t.mods[prime], a.t.fpd[prime]);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, true, prime);
             const unsigned col = cg * G::C + c;
             const uint64_t *i = a.mid + (((size_t)outer * a.ncomp + comp) << G::n) + ((size_t)(hi * 16 + (col >> 4)) << 8) + (col & 15);
@@ -831,7 +831,7 @@ namespace sealhip
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
-            const unsigned prime = a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp;
+            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             if constexpr (CLS == 1)
                 inv_pb_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
@@ -865,7 +865,7 @@ namespace sealhip
             typedef Field<FP> F;
             typedef Geo<D1> G;
             const unsigned tid = threadIdx.x;
-            const typename F::Mod m = F::make_mod(a.tb.mods[prime], a.tb.fpd[prime]);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.tb.mods[prime]), ld_uniform_fpd(&a.tb.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
             TwRegs<FP> tw;
             p1_load_tw<FP, D1>(tw, tab, tid);
@@ -953,7 +953,7 @@ namespace sealhip
             if (grp >= a.batch * G::TILES)
                 return;
             const unsigned b = grp / G::TILES, cg = grp % G::TILES;
-            const unsigned I = a.targets[2 * it], prime = a.targets[2 * it + 1];
+            const unsigned I = SHL_UNIFORM(a.targets[2 * it]), prime = SHL_UNIFORM(a.targets[2 * it + 1]);
             ks1_body<FP, D1>(a, lds, I, prime, b, cg);
         }
 
@@ -985,7 +985,7 @@ namespace sealhip
             typedef Field<FP> F;
             typedef Geo<D1> G;
             const unsigned tid = threadIdx.x;
-            const typename F::Mod m = F::make_mod(a.tb.mods[prime], a.tb.fpd[prime]);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.tb.mods[prime]), ld_uniform_fpd(&a.tb.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
 
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
@@ -1150,7 +1150,7 @@ namespace sealhip
             if (tile >= ntile)
                 return;
             const unsigned it = tile / G::TILES, hg = tile % G::TILES;
-            const unsigned I = a.targets[3 * it], prime = a.targets[3 * it + 1], kc = a.targets[3 * it + 2];
+            const unsigned I = SHL_UNIFORM(a.targets[3 * it]), prime = SHL_UNIFORM(a.targets[3 * it + 1]), kc = SHL_UNIFORM(a.targets[3 * it + 2]);
             if constexpr (CLS == 1)
                 ks2_body<true, D1>(a, lds, I, prime, kc, b, hg);
             else
