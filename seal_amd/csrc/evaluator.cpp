@@ -1753,11 +1753,23 @@ namespace sealhip
 
         PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e.batch() };
         const int ntt_form = scheme == Scheme::bfv ? 0 : 1;
-        Scratch perm(2 * g.words()); // [pi(c0), pi(c1)]
-        ck(k_apply_galois(context_.dev_mods(), e.data(), perm.p, galois_elt, ntt_form, g, 2, stream_), "apply_galois");
-        ck(hipMemcpyAsync(e.plane(0), perm.p, g.words() * 8, hipMemcpyDeviceToDevice, stream_), "galois copy c0");
-        ck(hipMemsetAsync(e.plane(1), 0, g.words() * 8, stream_), "galois zero c1");
-        switch_key_inplace(e, perm.p + g.words(), galois_keys, galois_index(galois_elt));
+        // pi(c0) goes straight into the result slab, pi(c1) into scratch as the key-switch target, c1 starts at zero
+        Scratch perm(g.words());
+        const size_t words = 2 * g.words();
+        uint64_t *out = DevicePool::global().alloc_words(words);
+        try
+        {
+            ck(k_apply_galois(context_.dev_mods(), e.plane(0), out, galois_elt, ntt_form, g, 1, stream_), "apply_galois c0");
+            ck(k_apply_galois(context_.dev_mods(), e.plane(1), perm.p, galois_elt, ntt_form, g, 1, stream_), "apply_galois c1");
+            ck(hipMemsetAsync(out + g.words(), 0, g.words() * 8, stream_), "galois zero c1");
+        }
+        catch (...)
+        {
+            DevicePool::global().free_words(out);
+            throw;
+        }
+        e.adopt(&lvl, 2, out, words);
+        switch_key_inplace(e, perm.p, galois_keys, galois_index(galois_elt));
         throw_if_transparent(e);
     }
 
