@@ -99,3 +99,51 @@ def test_dropin_gpu(gpu, scheme, n, bits, tb):
     if not (R.available() and os.path.exists(path)):
         pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
     _run(_bind(path), scheme, n, bits, tb, seed=4)
+
+
+def _end_to_end(D, n_ckks, n_bfv):
+    """A program against the reference's classes - KeyGenerator, CKKSEncoder / BatchEncoder, Encryptor, Evaluator,
+    Decryptor - with the Evaluator being the drop-in: decrypted results must be the products of the inputs."""
+    primes = R.coeff_modulus_create(n_ckks, [60, 40, 40, 60])
+    ctx = D.RefContext("ckks", n_ckks, primes)
+    ctx.keygen_relin()
+    ctx.keygen_galois_steps([1])
+    rng = np.random.default_rng(9)
+    slots = n_ckks // 2
+    u, v = rng.uniform(-1, 1, slots), rng.uniform(-1, 1, slots)
+    x, y = ctx.ckks_encrypt(u, 2.0 ** 40), ctx.ckks_encrypt(v, 2.0 ** 40)
+    ctx.multiply_inplace(x, y)
+    ctx.relinearize_inplace(x)
+    ctx.rescale_to_next_inplace(x)
+    got = ctx.ckks_decrypt(x, slots)
+    assert np.max(np.abs(got - u * v)) < 1e-6
+    ctx.rotate_vector_inplace(x, 1)
+    got = ctx.ckks_decrypt(x, slots)
+    assert np.max(np.abs(got - np.roll(u * v, -1))) < 1e-6
+    # BFV: batched integers modulo t
+    primes = R.coeff_modulus_create(n_bfv, [40, 40, 41])
+    t = R.plain_modulus_batching(n_bfv, 20)
+    ctx = D.RefContext("bfv", n_bfv, primes, t)
+    ctx.keygen_relin()
+    a, b = rng.integers(0, t, n_bfv, dtype=np.uint64), rng.integers(0, t, n_bfv, dtype=np.uint64)
+    x, y = ctx.batch_encrypt(a), ctx.batch_encrypt(b)
+    ctx.multiply_inplace(x, y)
+    ctx.relinearize_inplace(x)
+    got = ctx.batch_decrypt(x, n_bfv)
+    want = np.array([(int(p) * int(q)) % t for p, q in zip(a, b)], dtype=np.uint64)
+    assert np.array_equal(got, want)
+
+
+def test_dropin_end_to_end_emulated(emu):
+    path = os.path.join(BUILD, "libsealdropin_emu.so")
+    if not (R.available() and os.path.exists(path)):
+        pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
+    _end_to_end(_bind(path), 1024, 1024)
+
+
+@pytest.mark.gpu
+def test_dropin_end_to_end_gpu(gpu):
+    path = os.path.join(BUILD, "libsealdropin.so")
+    if not (R.available() and os.path.exists(path)):
+        pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
+    _end_to_end(_bind(path), 8192, 4096)
