@@ -419,6 +419,7 @@ namespace sealhip
 
     const uint32_t *Evaluator::ks_comp_prime(unsigned K) const
     {
+        std::lock_guard<std::mutex> g(cache_mu_);
         auto it = ks_maps_.find(K);
         if (it != ks_maps_.end())
             return it->second;
@@ -439,6 +440,7 @@ namespace sealhip
 
     const Evaluator::KsTargets &Evaluator::ks_targets(unsigned K) const
     {
+        std::lock_guard<std::mutex> g(cache_mu_);
         auto it = ks_targets_.find(K);
         if (it != ks_targets_.end())
             return it->second;
@@ -523,11 +525,13 @@ namespace sealhip
         // Ciphertext::is_transparent (ciphertext.h:451-456)
         if (!ct.word_count() || ct.size() < 2)
             return true;
+        Scratch word(1); // per call: concurrent checks on different ciphertexts must not share the flag
+        unsigned *d_flag = reinterpret_cast<unsigned *>(word.p);
         unsigned zero = 0;
-        ck(hipMemcpyAsync(d_flag_, &zero, sizeof(zero), hipMemcpyHostToDevice, stream_), "flag reset");
-        ck(k_any_nonzero(ct.plane(1), (ct.size() - 1) * ct.plane_words(), d_flag_, stream_), "any_nonzero");
+        ck(hipMemcpyAsync(d_flag, &zero, sizeof(zero), hipMemcpyHostToDevice, stream_), "flag reset");
+        ck(k_any_nonzero(ct.plane(1), (ct.size() - 1) * ct.plane_words(), d_flag, stream_), "any_nonzero");
         unsigned flag = 0;
-        ck(hipMemcpyAsync(&flag, d_flag_, sizeof(flag), hipMemcpyDeviceToHost, stream_), "flag read");
+        ck(hipMemcpyAsync(&flag, d_flag, sizeof(flag), hipMemcpyDeviceToHost, stream_), "flag read");
         ck(hipStreamSynchronize(stream_), "flag sync");
         return flag == 0;
     }

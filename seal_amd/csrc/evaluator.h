@@ -228,6 +228,9 @@ namespace sealhip
         const Context &context_;
         hipStream_t stream_ = nullptr;
         bool transparent_check_ = false;
+        // lazily built per-level tables; guarded so that concurrent calls on different ciphertexts stay safe, as with the
+        // reference's Evaluator (evaluator.h:79-87: the class holds only immutable state)
+        mutable std::mutex cache_mu_;
         mutable std::map<unsigned, uint32_t *> ks_maps_;
         mutable std::map<unsigned, KsTargets> ks_targets_;
         mutable unsigned *d_flag_ = nullptr;

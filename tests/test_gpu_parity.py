@@ -321,3 +321,49 @@ def test_semantic_bfv_multiply_rotate(gpu):
 
 def test_oracle_kind_is_reported(gpu):
     print("oracle kind used for GPU parity:", kind_available())
+
+
+def test_concurrent_calls_on_different_ciphertexts(gpu):
+    """seal::Evaluator may be called concurrently on different ciphertexts (evaluator.h:79-87; ciphertext.h:48-51 only
+    forbids sharing one object): four host threads run multiply + relinearize + rescale + rotate on their own
+    ciphertexts through ONE evaluator and must get the results of the sequential run."""
+    import threading
+    S = gpu
+    n, bits = 8192, [60, 40, 40, 50, 60]
+    primes = coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    o = Oracle("ckks", n, primes, galois_elts=[3])
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(77)
+    inputs = [(rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)) for _ in range(4)]
+
+    def pipeline(a, b):
+        x, y = d.ct(a, scale=2.0 ** 10), d.ct(b, scale=2.0 ** 10)
+        d.ev.multiply_inplace(x, y)
+        d.ev.relinearize_inplace(x, d.rlk)
+        x.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+        d.ev.rescale_to_next_inplace(x)
+        d.ev.rotate_vector_inplace(x, 1, d.glk)
+        return d.out(x)[0]
+
+    want = [pipeline(a, b) for a, b in inputs]
+    got = [[None] * 6 for _ in inputs]
+    errors = []
+
+    def worker(i):
+        try:
+            for r in range(6):
+                got[i][r] = pipeline(*inputs[i])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(len(inputs)):
+        for r in range(6):
+            assert np.array_equal(got[i][r], want[i]), "thread %d repetition %d differs from the sequential result" % (i, r)
