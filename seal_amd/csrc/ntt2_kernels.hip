@@ -798,18 +798,18 @@ namespace sealhip
                 x[e] = F::unraw(lds[R * G::CP + c]);
             }
             // phase A undone: stages rA-1 .. 1 with uniform twiddles, then stage 0 with N^-1 folded in
-            phase_inv<FP, G::rA, 1>(x, m, [&](int t, int g) { return tab[(1u << t) + g]; });
+            phase_inv<FP, G::rA, 1>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
             {
                 typename F::tw_t ni, nw;
                 if constexpr (FP)
                 {
-                    ni = a.t.ninv_d[2 * prime];
-                    nw = a.t.ninv_d[2 * prime + 1];
+                    ni = ld_uniform(a.t.ninv_d, 2 * prime);
+                    nw = ld_uniform(a.t.ninv_d, 2 * prime + 1);
                 }
                 else
                 {
-                    ni = a.t.ninv[2 * prime];
-                    nw = a.t.ninv[2 * prime + 1];
+                    ni = ld_uniform(a.t.ninv, 2 * prime);
+                    nw = ld_uniform(a.t.ninv, 2 * prime + 1);
                 }
 #pragma unroll
                 for (int k = 0; k < 8; k++)
