@@ -163,6 +163,8 @@ def main():
             config=dict(workload="CKKS N=65536, coeff_modulus {60,14x50,60} (L=16, K=15): multiply_inplace + "
                                  "relinearize_inplace + rescale_to_next_inplace, device-resident batches",
                         batch_per_gpu=B, parallelism="batch-sharded x%d, no data-path collective" % world,
+                        arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for the 14 primes below "
+                                   "2^50, 64-bit Shoup/Barrett integer arithmetic for the two 60-bit primes; results canonical u64",
                         key_bytes=2 * K * L * n * 8, algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n),
             roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
