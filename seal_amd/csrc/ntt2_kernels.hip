@@ -268,7 +268,8 @@ namespace sealhip
             load_tw<FP, 4>(tb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
         }
 
-        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false>
+        // TWA_LDS: only phase A's row-shared twiddles come from LDS (twa), phase B's per-thread ones from global memory
+        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false>
         __device__ __forceinline__ void p2_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const typename Field<FP>::tw_t *twa, const typename Field<FP>::tw_t *twb, uint64_t *lds_wave, unsigned hg, unsigned tid,
@@ -282,7 +283,7 @@ namespace sealhip
             {
                 phase_fwd<FP, 4>(x, m, [&](int t, int g) { return pre_a->get((1 << t) + g); });
             }
-            else if constexpr (LOWREG && TW_LDS)
+            else if constexpr (LOWREG && (TW_LDS || TWA_LDS))
             {
                 phase_fwd<FP, 4>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
             }
@@ -990,6 +991,19 @@ namespace sealhip
 
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             const typename F::tw_t *twa = nullptr, *twb = nullptr;
+            if constexpr (!FP)
+            {
+                // integer back end: phase A's 240 row-shared Shoup pairs (3.8 KiB) in LDS; phase B's stay in L2
+                typename F::tw_t *la = reinterpret_cast<typename F::tw_t *>(lds + kLds2Words);
+                if (tid < 240)
+                {
+                    const unsigned t = 31 - __builtin_clz(tid / 16 + 1);
+                    const unsigned r = tid - ((16u << t) - 16u);
+                    la[tid] = tab[(1u << (D1 + t)) + ((hg * 16) << t) + r];
+                }
+                twa = la;
+                __syncthreads();
+            }
             if constexpr (FP)
             {
                 // stage this tile's twiddles in LDS once: reused by all K digits
@@ -1086,7 +1100,7 @@ namespace sealhip
                 }
                 if (!is_diag)
                 {
-                    p2_tile<FP, D1, FP, true>(x, m, tab, twa, twb, lds_wave, hg, tid);
+                    p2_tile<FP, D1, FP, true, false, !FP>(x, m, tab, twa, twb, lds_wave, hg, tid);
                     if constexpr (!FP)
                     {
 #pragma unroll
@@ -1397,7 +1411,7 @@ namespace sealhip
                 if (fp)
                     hipLaunchKernelGGL((ks2_kernel<D1, 1>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), l2_fp, st, c2);
                 else
-                    hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), kLds2Words * 8, st, c2);
+                    hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), kLds2Words * 8 + 240 * sizeof(ShoupOp), st, c2);
                 return hipGetLastError();
             };
             // The integer-back-end targets (60-bit moduli) are latency-bound at two waves per SIMD, the
