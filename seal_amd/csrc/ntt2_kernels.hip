@@ -269,6 +269,7 @@ namespace sealhip
         }
 
         // TWA_LDS: only phase A's row-shared twiddles come from LDS (twa), phase B's per-thread ones from global memory
+        // (LOWREG) or from the caller's registers (HOIST && TWA_LDS: pre_b only)
         template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false>
         __device__ __forceinline__ void p2_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
@@ -279,11 +280,11 @@ namespace sealhip
             const unsigned v = tid & 15, u = tid >> 4;
             const unsigned h = hg * 16 + u;
             const unsigned ul = u & 3; // row inside this wave's buffer
-            if constexpr (HOIST)
+            if constexpr (HOIST && !TWA_LDS)
             {
                 phase_fwd<FP, 4>(x, m, [&](int t, int g) { return pre_a->get((1 << t) + g); });
             }
-            else if constexpr (LOWREG && (TW_LDS || TWA_LDS))
+            else if constexpr ((LOWREG || HOIST) && (TW_LDS || TWA_LDS))
             {
                 phase_fwd<FP, 4>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
             }
@@ -693,6 +694,7 @@ namespace sealhip
             unsigned prime_first;
             unsigned ncomp;
             unsigned comp0; // as FwdArgs
+            unsigned nouter; // used by the single-launch kernels, whose workgroups loop over outer items
             int lazy;
             NttTables t;
         };
@@ -841,6 +843,276 @@ namespace sealhip
                 inv_pb_body<true, D1>(a, prime, comp, outer, lds);
             else
                 inv_pb_body<false, D1>(a, prime, comp, outer, lds);
+        }
+
+        // ---------------------------------------------------------------------------------------
+        // Single-launch transforms, second generation: N = 2^13 (two teams of 256 threads) and N = 2^14
+        // (four teams), double-precision back end.  Every coefficient crosses HBM once in each direction.
+        // Against ntt2_fwd_fused:
+        //  * the tile-order intermediate, pass 1's exchange buffer and pass 2's wave-local exchange buffers
+        //    are the SAME LDS area used one after the other (one more barrier per transform): 76 KiB per
+        //    workgroup at N = 2^13, so two workgroups share a CU (four waves per SIMD) instead of one;
+        //    152 KiB at N = 2^14 (one 1024-thread workgroup per CU, also four waves per SIMD);
+        //  * for D1 <= 6 the row index of pass 1's phase B is wave-uniform (tid >> LC with LC >= 6), so ALL
+        //    twiddles of pass 1 are scalar loads; pass 2's row-shared phase-A twiddles are staged once in LDS
+        //    and its per-thread phase-B twiddles stay in registers for the whole loop: no twiddle is re-read
+        //    per transform and the kernel fits 128 VGPRs;
+        //  * the inverse transform gets the same treatment (ntt2_inv_fused2).
+        // ---------------------------------------------------------------------------------------
+        template <int D1>
+        struct FusedGeo
+        {
+            typedef Geo<D1> G;
+            static_assert(G::LC >= 6, "pass 1's phase-B row index must be wave-uniform");
+            static_assert(G::lds1_words <= kLds2Words, "pass 1's exchange buffer lives in the team's pass-2 area");
+            static constexpr int TEAMS = G::TILES;
+            static constexpr int BS = 272; // padded 256-word block of the intermediate (as kFusedBS)
+            static constexpr size_t mid_words = (size_t)TEAMS * 16 * BS;
+            static constexpr size_t xch_words = (size_t)TEAMS * kLds2Words;
+            static constexpr size_t main_words = mid_words > xch_words ? mid_words : xch_words;
+            static constexpr size_t lds_bytes = (main_words + (size_t)TEAMS * 240) * 8;
+        };
+
+        // stage the 240 row-shared twiddles of pass 2's phase A (row tile hg) at twa[(16 << t) - 16 + (u << t) + g]
+        template <int D1>
+        __device__ __forceinline__ void stage_twa(double *twa, const double *tab, unsigned hg, unsigned tid)
+        {
+            if (tid < 240)
+            {
+                const unsigned t = 31 - __builtin_clz(tid / 16 + 1);
+                const unsigned r = tid - ((16u << t) - 16u);
+                twa[tid] = tab[(1u << (D1 + t)) + ((hg * 16) << t) + r];
+            }
+        }
+
+        template <int D1>
+        __device__ __forceinline__ void fwd_fused2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<true> F;
+            typedef Geo<D1> G;
+            typedef FusedGeo<D1> FG;
+            const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
+            const F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
+            const double *tab = tw_table<true>(a.t, false, prime);
+            uint64_t *mid = lds;
+            uint64_t *xch = lds + team * kLds2Words;
+            uint64_t *lds_wave = xch + (tid >> 6) * (4 * kRowWords);
+            double *twa = reinterpret_cast<double *>(lds + FG::main_words) + team * 240;
+            stage_twa<D1>(twa, tab, team, tid); // read after several workgroup barriers
+            const unsigned c = tid & (G::C - 1);
+            const unsigned hi = SHL_UNIFORM(tid >> G::LC); // rbl in phase A, ra in phase B: the same in every lane of a wave
+            TwRegs<true> twb, unused;
+            {
+                const unsigned h = team * 16 + (tid >> 4), v = tid & 15;
+                load_tw<true, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
+            }
+            uint64_t *base = a.data + ((size_t)comp << G::n);
+            uint64_t nxt[16];
+            auto fetch = [&](unsigned z) {
+                const uint64_t *in = base + (size_t)z * a.outer_stride + team * G::C + c;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + hi;
+                    nxt[e] = in[(size_t)R * 256];
+                }
+            };
+            const unsigned ostride = gridDim.z;
+            fetch(outer);
+            for (; outer < a.nouter; outer += ostride)
+            {
+                F::elem x[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    x[e] = F::from_canon(nxt[e], m);
+                if (outer + ostride < a.nouter)
+                    fetch(outer + ostride);
+                // ---- pass 1 on column tile `team`
+                phase_fwd<true, G::rA>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    F::fix(x[e], m);
+                __syncthreads(); // the previous transform's wave-local buffers are free
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + hi;
+                    xch[R * G::CP + c] = F::raw(x[e]);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int rb = 0; rb < 16; rb++)
+                    x[rb] = F::unraw(xch[(hi * 16 + rb) * G::CP + c]);
+                phase_fwd<true, 4>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << (G::rA + t)) + (hi << t) + g); });
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    F::fix(x[e], m);
+                __syncthreads(); // every team has read its exchange data: the area becomes the intermediate
+                {
+                    const unsigned col = team * G::C + c;
+                    uint64_t *o = mid + (size_t)(hi * 16 + (col >> 4)) * FG::BS + (col & 15);
+#pragma unroll
+                    for (int rb = 0; rb < 16; rb++)
+                        o[rb * 16] = F::raw(x[rb]);
+                }
+                __syncthreads();
+                // ---- pass 2 on row tile `team`
+                {
+                    const uint64_t *mp = mid + (size_t)(team * 16) * FG::BS + tid;
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = F::unraw(mp[e * FG::BS]);
+                }
+                __syncthreads(); // the intermediate is consumed: the area becomes the wave-local exchange buffers
+                p2_tile<true, D1, false, false, true, true>(x, m, tab, twa, nullptr, lds_wave, team, tid, &unused, &twb);
+                uint64_t val[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    val[e] = a.lazy ? F::fwd_to_lazy(x[e], m) : F::fwd_to_canon(x[e], m);
+                store_rows(val, lds_wave, base + (size_t)outer * a.outer_stride + ((size_t)(team * 16 + (tid >> 6) * 4) << 8), tid);
+            }
+        }
+
+        template <int D1>
+        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, 4) ntt2_fwd_fused2(FwdArgs a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
+            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
+            fwd_fused2_body<D1>(a, prime, comp, outer, lds);
+        }
+
+        // Inverse: team k undoes pass 2 on row tile k (rows -> intermediate in LDS), the teams meet, team k undoes
+        // pass 1 on column tile k (N^-1 folded into the last stage) and stores natural order.
+        template <int D1>
+        __device__ __forceinline__ void inv_fused2_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<true> F;
+            typedef Geo<D1> G;
+            typedef FusedGeo<D1> FG;
+            static_assert(G::rA >= 1, "the N^-1 stage is handled in phase A");
+            const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
+            const unsigned v = tid & 15, u = tid >> 4, ul = u & 3, lane = tid & 63;
+            const unsigned h = team * 16 + u;
+            const F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
+            const double *tab = tw_table<true>(a.t, true, prime);
+            uint64_t *mid = lds;
+            uint64_t *xch = lds + team * kLds2Words;
+            uint64_t *lds_wave = xch + (tid >> 6) * (4 * kRowWords);
+            double *twa = reinterpret_cast<double *>(lds + FG::main_words) + team * 240;
+            stage_twa<D1>(twa, tab, team, tid);
+            const unsigned c = tid & (G::C - 1);
+            const unsigned hi = SHL_UNIFORM(tid >> G::LC);
+            const unsigned col = team * G::C + c;
+            const double ni = ld_uniform(a.t.ninv_d, 2 * prime), nw = ld_uniform(a.t.ninv_d, 2 * prime + 1);
+            const size_t comp_off = (size_t)comp << G::n;
+            const size_t row_off = comp_off + ((size_t)(team * 16 + (tid >> 6) * 4) << 8);
+            uint64_t nxt[16];
+            auto fetch = [&](unsigned z) {
+                const uint64_t *rows = a.src + (size_t)z * a.src_outer_stride + row_off;
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    nxt[k] = rows[(k >> 2) * 256 + (k & 3) * 64 + lane];
+            };
+            const unsigned ostride = gridDim.z;
+            fetch(outer);
+            __syncthreads(); // twa staged
+            for (; outer < a.nouter; outer += ostride)
+            {
+                // ---- rows of tile `team`: coalesced words -> wave-local transposition -> (row u, cols 16 v + e)
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                {
+                    const unsigned row = k >> 2, cc = (k & 3) * 64 + lane;
+                    lds_wave[row * kRowWords + cc + 2 * (cc >> 4)] = nxt[k];
+                }
+                __builtin_amdgcn_wave_barrier();
+                F::elem x[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    x[e] = F::from_canon(lds_wave[ul * kRowWords + v * 18 + e], m);
+                    F::fix(x[e], m);
+                }
+                __builtin_amdgcn_wave_barrier();
+                {
+                    // the 15 per-thread twiddles of this phase are re-read (L2) per transform: holding them next to the
+                    // prefetched rows does not fit 128 VGPRs (measured: 40 spilled registers)
+                    TwRegs<true> twb;
+                    load_tw<true, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
+                    phase_inv<true, 4, 0>(x, m, [&](int t, int g) { return twb.get((1 << t) + g); });
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    F::fix(x[e], m);
+                if (outer + ostride < a.nouter)
+                    fetch(outer + ostride);
+                // wave-local exchange: (v', e') -> (e, v)
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    lds_wave[ul * kRowWords + v * 18 + e] = F::raw(x[e]);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    x[e] = F::unraw(lds_wave[ul * kRowWords + e * 18 + v]);
+                phase_inv<true, 4, 0>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    F::fix(x[e], m);
+                __syncthreads(); // every wave is done with its exchange buffer: the area becomes the intermediate
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    mid[(size_t)(team * 16 + e) * FG::BS + tid] = F::raw(x[e]);
+                __syncthreads();
+                // ---- columns of tile `team`
+                {
+                    const uint64_t *i = mid + (size_t)(hi * 16 + (col >> 4)) * FG::BS + (col & 15);
+#pragma unroll
+                    for (int rb = 0; rb < 16; rb++)
+                        x[rb] = F::unraw(i[rb * 16]);
+                }
+                phase_inv<true, 4, 0>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << (G::rA + t)) + (hi << t) + g); });
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    F::fix(x[e], m);
+                __syncthreads(); // the intermediate is consumed: the area becomes pass 1's exchange buffer
+#pragma unroll
+                for (int rb = 0; rb < 16; rb++)
+                    xch[(hi * 16 + rb) * G::CP + c] = F::raw(x[rb]);
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + hi;
+                    x[e] = F::unraw(xch[R * G::CP + c]);
+                }
+                __syncthreads(); // (the next transform's row loads reuse the area)
+                phase_inv<true, G::rA, 1>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    F::bfly_inv_last(x[k], x[k | 8], ni, nw, m);
+                uint64_t *o = a.data + (size_t)outer * a.outer_stride + comp_off;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    F::fix(x[e], m);
+                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + hi;
+                    o[(size_t)R * 256 + col] = a.lazy ? F::inv_to_lazy(x[e], m) : F::inv_to_canon(x[e], m);
+                }
+            }
+        }
+
+        template <int D1>
+        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, 4) ntt2_inv_fused2(InvArgs a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
+            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
+            inv_fused2_body<D1>(a, prime, comp, outer, lds);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1286,24 +1558,35 @@ namespace sealhip
             if (chunks > 65535)
                 chunks = 65535;
             size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
-            bool fused = false;
+            // single-launch kernels (plain in-place transforms, double-precision components):
+            //   2 = second generation (N = 2^13, 2^14), 1 = ntt2_fwd_fused (N = 2^13; SEALHIP_NTT_FUSED_V1=1 for A/B runs)
+            int fused = 0;
             unsigned fchunks = 1;
-            if constexpr (D1 == kFusedD1)
+            if constexpr (D1 == 5 || D1 == 6)
             {
                 static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED");
-                if (fused_ok && !a.src && a.epi == 0)
+                static const bool v1 = std::getenv("SEALHIP_NTT_FUSED_V1") != nullptr;
+                static const bool no14 = std::getenv("SEALHIP_NTT_NOFUSED14") != nullptr;
+                if (fused_ok && !a.src && a.epi == 0 && (D1 == 5 || !(v1 || no14)))
                 {
                     static bool raised = false;
                     if (!raised)
                     {
                         // above the default 64 KiB of dynamic LDS
-                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsBytes) != hipSuccess)
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused2<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedGeo<D1>::lds_bytes) != hipSuccess)
                             return hipErrorInvalidValue;
+                        if constexpr (D1 == kFusedD1)
+                            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsBytes) != hipSuccess)
+                                return hipErrorInvalidValue;
                         raised = true;
                     }
-                    fused = true;
-                    // one 512-thread workgroup per CU fits (142 KiB of LDS): a few loop iterations per workgroup
-                    fchunks = (1024 + a.ncomp - 1) / a.ncomp;
+                    fused = (v1 && D1 == kFusedD1) ? 1 : 2;
+                    // v1: one 512-thread workgroup per CU; v2: two (N = 2^13) or one 1024-thread workgroup (N = 2^14);
+                    // a few loop iterations per workgroup so that the prefetch and the hoisted twiddles pay
+                    const unsigned want = fused == 2 && D1 == 5 ? 2048 : 1024;
+                    fchunks = (want + a.ncomp - 1) / a.ncomp;
+                    if (const char *f = std::getenv("SEALHIP_NTT_FCHUNKS")) // tests: force the per-workgroup loop at small batches
+                        fchunks = (unsigned)std::atoi(f) ? (unsigned)std::atoi(f) : 1;
                     if (fchunks > nouter)
                         fchunks = nouter;
                     if (fchunks > 65535)
@@ -1313,7 +1596,15 @@ namespace sealhip
             return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp), s, [&](const CompRun &r, hipStream_t st) {
                 FwdArgs g = a;
                 g.comp0 = r.c0;
-                if (fused && r.cls == 1)
+                if constexpr (D1 == 5 || D1 == 6)
+                {
+                    if (fused == 2 && r.cls == 1)
+                    {
+                        hipLaunchKernelGGL((ntt2_fwd_fused2<D1>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), FusedGeo<D1>::lds_bytes, st, g);
+                        return hipGetLastError();
+                    }
+                }
+                if (fused == 1 && r.cls == 1)
                 {
                     hipLaunchKernelGGL(ntt2_fwd_fused, dim3(1, r.nc, fchunks), dim3(2 * kThreads), kFusedLdsBytes, st, g);
                     return hipGetLastError();
@@ -1344,9 +1635,42 @@ namespace sealhip
         hipError_t launch_inv(const InvArgs &a, unsigned nouter, hipStream_t s)
         {
             typedef Geo<D1> G;
+            bool fused = false;
+            unsigned fchunks = 1;
+            if constexpr (D1 == 5 || D1 == 6)
+            {
+                static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED") && !std::getenv("SEALHIP_NTT_FUSED_V1");
+                static const bool no14 = std::getenv("SEALHIP_NTT_NOFUSED14") != nullptr;
+                if (fused_ok && (D1 == 5 || !no14))
+                {
+                    static bool raised = false;
+                    if (!raised)
+                    {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_inv_fused2<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedGeo<D1>::lds_bytes) != hipSuccess)
+                            return hipErrorInvalidValue;
+                        raised = true;
+                    }
+                    fused = true;
+                    const unsigned want = D1 == 5 ? 2048 : 1024;
+                    fchunks = (want + a.ncomp - 1) / a.ncomp;
+                    if (const char *f = std::getenv("SEALHIP_NTT_FCHUNKS"))
+                        fchunks = (unsigned)std::atoi(f) ? (unsigned)std::atoi(f) : 1;
+                    if (fchunks > nouter)
+                        fchunks = nouter;
+                }
+            }
             return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp), s, [&](const CompRun &r, hipStream_t st) {
                 InvArgs g = a;
                 g.comp0 = r.c0;
+                g.nouter = nouter;
+                if constexpr (D1 == 5 || D1 == 6)
+                {
+                    if (fused && r.cls == 1)
+                    {
+                        hipLaunchKernelGGL((ntt2_inv_fused2<D1>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), FusedGeo<D1>::lds_bytes, st, g);
+                        return hipGetLastError();
+                    }
+                }
                 dim3 grid(G::TILES, r.nc, nouter);
                 if (r.cls == 1)
                     hipLaunchKernelGGL((ntt2_inv_pa<D1, 1>), grid, dim3(kThreads), kLds2Words * 8, st, g);
@@ -1498,6 +1822,7 @@ namespace sealhip
         a.prime_first = b.prime_first;
         a.ncomp = b.ncomp;
         a.comp0 = 0;
+        a.nouter = 0; // set per launch
         a.lazy = out_lazy;
         a.t = t;
         const unsigned zmax = 65535;

@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 
@@ -77,8 +78,10 @@ namespace hipemu
     int lane_id();
 } // namespace hipemu
 
+// HIPEMU_TRACE=1 prints the name of every launched kernel to stderr (to check WHICH kernel a test exercised)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kernel(__VA_ARGS__); })
+    (std::getenv("HIPEMU_TRACE") ? (void)std::fprintf(stderr, "hipemu launch %s\n", #kernel) : (void)0, \
+     hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kernel(__VA_ARGS__); }))
 
 static inline void __syncthreads()
 {

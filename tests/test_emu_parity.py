@@ -28,6 +28,13 @@ def test_ntt_two_pass_engine_mixed_primes(emu, n, bits):
     P.case_ntt(n, bits, polys=2)
 
 
+# single-launch kernels (ntt2_fwd_fused2 / ntt2_inv_fused2): the per-workgroup loop with the next transform in flight
+@pytest.mark.parametrize("n,bits,polys,chunks", [(8192, [50, 36, 60], 5, 2), (8192, [40], 3, 1), (16384, [50, 45], 3, 1), (16384, [60, 50], 4, 3)])
+def test_ntt_single_launch_loop(emu, monkeypatch, n, bits, polys, chunks):
+    monkeypatch.setenv("SEALHIP_NTT_FCHUNKS", str(chunks))
+    P.case_ntt(n, bits, polys=polys)
+
+
 def test_ntt_two_pass_engine_integer_only(emu, monkeypatch):
     """SEALHIP_NO_FP=1: the same primes on the 64-bit integer back end give the same words."""
     monkeypatch.setenv("SEALHIP_NO_FP", "1")

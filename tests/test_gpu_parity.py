@@ -37,6 +37,17 @@ def test_ntt(gpu, n, bits, polys):
     P.case_ntt(n, bits, polys=polys)
 
 
+# single-launch transforms (N = 2^13, 2^14): batches large enough that every workgroup loops with the next
+# transform in flight, and a forced one-workgroup-per-component loop
+@pytest.mark.parametrize("n,bits,polys,chunks", [
+    (8192, [50, 36, 60], 5, 2), (8192, [50, 40, 40], 1100, 0), (16384, [50, 45, 60], 3, 1), (16384, [50, 50], 600, 0),
+])
+def test_ntt_single_launch_loop(gpu, monkeypatch, n, bits, polys, chunks):
+    if chunks:
+        monkeypatch.setenv("SEALHIP_NTT_FCHUNKS", str(chunks))
+    P.case_ntt(n, bits, polys=polys)
+
+
 def test_dyadic(gpu):
     P.case_dyadic(4096, [60, 40, 30])
 
