@@ -12,6 +12,8 @@ One JSON line is printed by rank 0 with, besides the contract fields:
   roofline     the NTT (dominant kernel family: one batched ntt_forward = column-pass + row-pass kernel)
                measured live with HIP events on the stream it runs on; achieved = algorithmic bytes
                (16*N per RNS-component transform) / time; peak = 8 TB/s HBM (guide).
+  roofline_configs1  the same measurement at BASELINE configs[1] (CKKS N=8192, L=4: forward and inverse NTT over all
+               RNS components), where the transform fits the LDS and the single-launch kernels move algorithmic bytes only.
   cpu_baseline the reference's own Evaluator (oracle/_ref = Microsoft SEAL 4.4.3, HEXL off) timed on this
                host's cores on a bounded sample, rank 0, N=1 only ("port": the plain-C restatement, 1 core,
                when oracle/_ref did not travel).  Checker/baseline only — never the thing measured.
@@ -149,6 +151,14 @@ def main():
                         traffic=traffic, ms_per_launch=round(ms, 4), algorithmic_bytes_per_launch=alg_bytes)
         assert buf_words == 2 * B * K * n
 
+    # ---- BASELINE configs[1]: CKKS N=8192, L=4, forward + inverse NTT over all RNS components (single-launch kernels,
+    # the transform is 64 KiB and stays in LDS between the passes: HBM traffic = algorithmic bytes).  Two chains: the
+    # config's own {60,40,40,60} (its two 60-bit primes run on the slower 64-bit integer back end, two launches) and a
+    # chain whose primes are all below 2^50 (every component on the double-precision back end).
+    ntt_c1 = None
+    if rank == 0 and world == 1:
+        ntt_c1 = ntt_configs1(S, torch, device)
+
     # ---- CPU baseline (rank 0, N=1 only): the reference's Evaluator on this host's cores
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.ntt_only:
@@ -166,10 +176,43 @@ def main():
                         arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for the 14 primes below "
                                    "2^50, 64-bit Shoup/Barrett integer arithmetic for the two 60-bit primes; results canonical u64",
                         key_bytes=2 * K * L * n * 8, algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n),
-            roofline=roofline, cpu_baseline=cpu)
+            roofline=roofline, roofline_configs1=ntt_c1, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def ntt_configs1(S, torch, device, polys=4096, reps=10):
+    """forward / inverse NTT rate at BASELINE configs[1] (N = 8192, L = 4), batch of `polys` polynomials resident in HBM
+    (1 GiB: four times the Infinity Cache), HIP events on the launch stream, algorithmic bytes = 16*N per component."""
+    n = 8192
+    out = []
+    for label, bits in (("configs[1] {60,40,40,60}", [60, 40, 40, 60]), ("all primes < 2^50 {50,40,40,50}", [50, 40, 40, 50])):
+        pr = S.CoeffModulus.Create(n, bits)
+        p = S.EncryptionParameters("ckks")
+        p.set_poly_modulus_degree(n)
+        p.set_coeff_modulus(pr)
+        ctx = S.SEALContext(p, True, 0)
+        comps = len(pr)
+        data = device_uniform(torch, pr, (polys,), n, device)
+
+        class _Buf:
+            ptr = data.data_ptr()
+        timer = S.HipTimer()
+        rates = {}
+        for name, fn in (("forward", S.ntt_forward), ("inverse", S.ntt_inverse)):
+            for _ in range(3):
+                fn(ctx, _Buf, polys, comps)
+            timer.start()
+            for _ in range(reps):
+                fn(ctx, _Buf, polys, comps)
+            ms = timer.stop() / reps
+            alg = 16.0 * n * comps * polys
+            rates[name] = dict(achieved=round(alg / (ms * 1e-3) / 1e9, 1), frac=round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               ms_per_launch=round(ms, 4), algorithmic_bytes_per_launch=alg)
+        out.append(dict(chain=label, transforms_per_launch=comps * polys, **rates))
+        del data
+    return dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, workload="CKKS N=8192, L=4: batched NTT / INTT over all RNS components", chains=out)
 
 
 def cpu_baseline(primes, args):
