@@ -92,7 +92,8 @@ SHL_FUNC SEALContext_ChainIndex(void *thisptr, uint64_t *parms_id, uint64_t *cha
 SHL_FUNC SEALContext_ParmsIdAt(void *thisptr, uint64_t chain_index, uint64_t *parms_id);
 SHL_FUNC SEALContext_CoeffModulusAt(void *thisptr, uint64_t chain_index, uint64_t *length, uint64_t *coeffs);
 SHL_FUNC SEALContext_TotalCoeffModulusBitCount(void *thisptr, uint64_t chain_index, int *bit_count);
-/* Register the reference's BLAKE2b parms_id for a level so both sides name levels identically. */
+/* parms_ids are computed as the reference does (BLAKE2b-256 of scheme, N, primes, t: encryptionparams.cpp:117-147), so both
+ * sides name levels identically; SetParmsId overrides one (kept for bindings that registered them by hand). */
 SHL_FUNC SEALContext_SetParmsId(void *thisptr, uint64_t chain_index, uint64_t *parms_id);
 /* introspection used by the parity tests: minimal primitive 2N-th root of a pool prime, BEHZ base */
 SHL_FUNC SEALContext_NTTRoot(void *thisptr, uint64_t prime_index, uint64_t *root);
@@ -122,6 +123,19 @@ SHL_FUNC Ciphertext_DevicePtr(void *thisptr, uint64_t **data, uint64_t *word_cou
 SHL_FUNC Ciphertext_CopyFromHost(void *thisptr, const uint64_t *src, uint64_t word_count);
 SHL_FUNC Ciphertext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count);
 SHL_FUNC Ciphertext_CopyFromDevice(void *thisptr, const uint64_t *src, uint64_t word_count, void *hip_stream);
+
+/* Wire format (native/src/seal/c/ciphertext.h:80-86; Ciphertext::save / load / unsafe_load, native/src/seal/ciphertext.cpp:153-403):
+ * the reference's own byte streams - SEALHeader-framed, compr_mode none (0), seeded ciphertexts expanded on load with the
+ * reference's Blake2xb / SHAKE256 PRNG - are parsed straight into the device slab and written back from it.  Same argument order
+ * as sealc.  Load = UnsafeLoad + is_valid_for (every coefficient reduced, data level).  A handle that is a batch of one behaves
+ * exactly like seal::Ciphertext; LoadItem / SaveItem address slot `item` of a larger batch (the first item loaded into an empty
+ * batch defines its metadata, later ones must agree).  BGV streams in coefficient form are transformed on load as the reference does. */
+SHL_FUNC Ciphertext_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+SHL_FUNC Ciphertext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+SHL_FUNC Ciphertext_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+SHL_FUNC Ciphertext_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+SHL_FUNC Ciphertext_LoadItem(void *thisptr, void *context, uint64_t item, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+SHL_FUNC Ciphertext_SaveItem(void *thisptr, uint64_t item, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
 
 /* KSwitchKeys / RelinKeys / GaloisKeys (native/src/seal/c/kswitchkeys.h, relinkeys.h, galoiskeys.h).
  * A key set lives in HBM; one key (index) is uploaded as the concatenation of its decomposition
@@ -154,6 +168,10 @@ SHL_FUNC KSwitchKeys_SetKeyFromDevice(void *thisptr, void *context, uint64_t ind
 SHL_FUNC KSwitchKeys_SetKeyDigits(void *thisptr, void *context, uint64_t index, uint64_t digit_first, uint64_t digits,
                                   const uint64_t *host_words);
 SHL_FUNC KSwitchKeys_HasKey(void *thisptr, uint64_t index, bool *has_key);
+/* KSwitchKeys::load / unsafe_load (native/src/seal/c/kswitchkeys.h:45-47; kswitchkeys.cpp:92-180): a serialized RelinKeys /
+ * GaloisKeys stream (seeded or full, compr_mode none) goes straight into the device key slabs, every key index it holds. */
+SHL_FUNC KSwitchKeys_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+SHL_FUNC KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 SHL_FUNC RelinKeys_GetIndex(uint64_t key_power, uint64_t *index);
 SHL_FUNC GaloisKeys_GetIndex(uint32_t galois_elt, uint64_t *index);
 /* GaloisTool::get_elt_from_step (native/src/seal/util/galois.cpp:53-95) */

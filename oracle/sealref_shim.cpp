@@ -708,6 +708,127 @@ extern "C"
         REF_CATCH
     }
 
+    // ---- wire format (Ciphertext::save / load, KSwitchKeys::save / load, Serializable<> seeded forms) ----
+    // parms_id of a level (EncryptionParameters::parms_id, encryptionparams.cpp:117-147)
+    int ref_ctx_parms_id(void *ctx, uint64_t chain_index, uint64_t *out)
+    {
+        REF_TRY
+        auto l = static_cast<RefCtx *>(ctx)->level(chain_index);
+        if (!l)
+            return 3;
+        std::memcpy(out, l->parms_id().data(), 32);
+        REF_CATCH
+    }
+    int ref_ct_save(void *ct, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        *bytes = static_cast<uint64_t>(CT(ct).save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        REF_CATCH
+    }
+    int ref_ct_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, void **out, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto h = std::make_unique<RefCt>();
+        if (unsafe)
+            *bytes = static_cast<uint64_t>(h->ct.unsafe_load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
+        else
+            *bytes = static_cast<uint64_t>(h->ct.load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
+        *out = h.release();
+        REF_CATCH
+    }
+    // Encryptor::encrypt_zero_symmetric(parms_id) as a Serializable<Ciphertext>: the SEEDED stream (c_1 replaced by its seed,
+    // ciphertext.cpp:153-228) when seeded != 0, the full one otherwise
+    int ref_encrypt_zero_symmetric_save(void *ctx, uint64_t chain_index, int seeded, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 3;
+        Encryptor e(*c->context, c->keygen->secret_key());
+        if (seeded)
+            *bytes = static_cast<uint64_t>(
+                e.encrypt_zero_symmetric(l->parms_id()).save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        else
+        {
+            Ciphertext ct;
+            e.encrypt_zero_symmetric(l->parms_id(), ct);
+            *bytes = static_cast<uint64_t>(ct.save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        }
+        REF_CATCH
+    }
+    // kind 0: RelinKeys, 1: GaloisKeys for `elts`.  seeded != 0: a fresh Serializable<> key set is generated and saved in its
+    // seeded form; either way the saved stream is loaded back into the context's key object, so that ref_key_copy and the
+    // Evaluator calls of this context use exactly the keys the stream describes.
+    int ref_keys_save(void *ctx, int kind, int seeded, const uint32_t *elts, uint64_t nelts, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto o = reinterpret_cast<seal_byte *>(out);
+        std::vector<uint32_t> v(elts, elts + nelts);
+        if (kind == 0)
+        {
+            if (seeded)
+                *bytes = static_cast<uint64_t>(c->keygen->create_relin_keys().save(o, cap, compr_mode_type::none));
+            else
+            {
+                if (!c->have_rlk)
+                    c->keygen->create_relin_keys(c->rlk);
+                *bytes = static_cast<uint64_t>(c->rlk.save(o, cap, compr_mode_type::none));
+            }
+            c->rlk.load(*c->context, o, *bytes);
+            c->have_rlk = true;
+        }
+        else
+        {
+            if (seeded)
+                *bytes = static_cast<uint64_t>(c->keygen->create_galois_keys(v).save(o, cap, compr_mode_type::none));
+            else
+            {
+                c->keygen->create_galois_keys(v, c->glk);
+                *bytes = static_cast<uint64_t>(c->glk.save(o, cap, compr_mode_type::none));
+            }
+            c->glk.load(*c->context, o, *bytes);
+            c->have_glk = true;
+        }
+        REF_CATCH
+    }
+    // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)
+    int ref_keys_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        KSwitchKeys k;
+        if (unsafe)
+            *bytes = static_cast<uint64_t>(k.unsafe_load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
+        else
+            *bytes = static_cast<uint64_t>(k.load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
+        REF_CATCH
+    }
+    // PublicKey::save: a key-level ciphertext in the Ciphertext wire format
+    int ref_public_key_save(void *ctx, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        if (!c->have_pk)
+        {
+            c->keygen->create_public_key(c->pk);
+            c->have_pk = true;
+        }
+        *bytes = static_cast<uint64_t>(c->pk.save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        REF_CATCH
+    }
+    // number of key slots (KSwitchKeys::data().size()) and which are populated
+    int ref_key_slots(void *ctx, int kind, uint64_t *slots)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        const KSwitchKeys &k = kind == 0 ? static_cast<const KSwitchKeys &>(c->rlk) : static_cast<const KSwitchKeys &>(c->glk);
+        *slots = k.data().size();
+        REF_CATCH
+    }
+
     // ---- CPU baseline: time the reference Evaluator on the host cores ---------------------
     // Synthetic size-2 ciphertexts at the first data level, every RNS component uniform in
     // [0, q_i) from mt19937_64(0x5EA1 + index) (restating BMEnv::randomize_ct_*, native/bench/bench.h:195-270).

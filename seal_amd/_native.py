@@ -62,6 +62,8 @@ Ciphertext_Size Ciphertext_BatchCount Ciphertext_PolyModulusDegree Ciphertext_Co
 Ciphertext_IsNTTForm Ciphertext_SetIsNTTForm Ciphertext_Scale Ciphertext_SetScale Ciphertext_CorrectionFactor
 Ciphertext_SetCorrectionFactor Ciphertext_IsTransparent Ciphertext_DevicePtr Ciphertext_CopyFromHost
 Ciphertext_CopyToHost Ciphertext_CopyFromDevice
+Ciphertext_SaveSize Ciphertext_Save Ciphertext_UnsafeLoad Ciphertext_Load Ciphertext_LoadItem Ciphertext_SaveItem
+KSwitchKeys_UnsafeLoad KSwitchKeys_Load
 Plaintext_Create1 Plaintext_Create5 Plaintext_Destroy Plaintext_Set4 Plaintext_SetFromDevice Plaintext_CoeffCount
 Plaintext_IsNTTForm Plaintext_GetParmsId Plaintext_SetParmsId Plaintext_Scale Plaintext_SetScale Plaintext_CopyToHost
 Evaluator_AddMany Evaluator_AddPlain Evaluator_SubPlain Evaluator_MultiplyMany Evaluator_MultiplyPlain Evaluator_Exponentiate

@@ -242,6 +242,37 @@ class Ciphertext:
             N.check(N.lib().Ciphertext_CopyToHost(self._h, _p(out), C.c_uint64(out.size)))
         return out
 
+    # -- the reference's wire format (Ciphertext::save / load / unsafe_load, ciphertext.cpp:153-403)
+    def load_bytes(self, data, unsafe=False, item=None):
+        """seal::Ciphertext::load (unsafe=True: unsafe_load) of a serialized stream; item = slot of a batch.  Returns bytes read."""
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
+        n = C.c_int64()
+        if item is not None:
+            N.check(N.lib().Ciphertext_LoadItem(self._h, self.context._h, C.c_uint64(item), buf, C.c_uint64(len(data)), C.byref(n)))
+        else:
+            fn = N.lib().Ciphertext_UnsafeLoad if unsafe else N.lib().Ciphertext_Load
+            N.check(fn(self._h, self.context._h, buf, C.c_uint64(len(data)), C.byref(n)))
+        return n.value
+
+    def save_size(self, compr_mode=0):
+        return self._get2("Ciphertext_SaveSize", C.c_uint8(compr_mode), C.c_int64)
+
+    def _get2(self, fn, arg, ctype):
+        v = ctype()
+        N.check(getattr(N.lib(), fn)(self._h, arg, C.byref(v)))
+        return v.value
+
+    def save_bytes(self, item=None, compr_mode=0):
+        """seal::Ciphertext::save(compr_mode_type::none) of the ciphertext (or of slot `item` of a batch)"""
+        cap = self.save_size(compr_mode)
+        buf = (C.c_uint8 * cap)()
+        n = C.c_int64()
+        if item is not None:
+            N.check(N.lib().Ciphertext_SaveItem(self._h, C.c_uint64(item), buf, C.c_uint64(cap), C.c_uint8(compr_mode), C.byref(n)))
+        else:
+            N.check(N.lib().Ciphertext_Save(self._h, buf, C.c_uint64(cap), C.c_uint8(compr_mode), C.byref(n)))
+        return bytes(buf[:n.value])
+
     @staticmethod
     def from_numpy(context, array, parms_id, is_ntt_form, scale=1.0, correction_factor=1):
         a = np.ascontiguousarray(array, dtype=np.uint64)
@@ -345,6 +376,14 @@ class KSwitchKeys:
     def set_key_device(self, index, digits, device_ptr):
         N.check(N.lib().KSwitchKeys_SetKeyFromDevice(self._h, self.context._h, C.c_uint64(index), C.c_uint64(digits),
                                                      C.c_void_p(device_ptr)))
+
+    def load_bytes(self, data, unsafe=False):
+        """KSwitchKeys::load / unsafe_load of a serialized RelinKeys / GaloisKeys stream (seeded or full).  Returns bytes read."""
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
+        n = C.c_int64()
+        fn = N.lib().KSwitchKeys_UnsafeLoad if unsafe else N.lib().KSwitchKeys_Load
+        N.check(fn(self._h, self.context._h, buf, C.c_uint64(len(data)), C.byref(n)))
+        return n.value
 
     def has_index(self, index):
         b = C.c_bool()

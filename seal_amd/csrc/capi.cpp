@@ -4,6 +4,7 @@
 // (native/src/seal/c/utilities.h).
 #include "../../include/sealhip.h"
 #include "evaluator.h"
+#include "serial.h"
 #include <cstring>
 #include <new>
 #include <string>
@@ -514,6 +515,163 @@ extern "C"
             throw std::invalid_argument("word_count does not match the ciphertext slab");
         hip_ok(hipMemcpyAsync(ct->data(), src, word_count * 8, hipMemcpyDeviceToDevice, (hipStream_t)hip_stream), "D2D");
         SHL_CATCH
+    }
+
+    // ---- wire format (native/src/seal/c/ciphertext.h:80-86; seal_amd/csrc/serial.h)
+    namespace
+    {
+        // one host image -> batch slot `item` of a device-resident batch.  set_meta: the image defines the batch's metadata
+        // (first item / batch of one); otherwise it has to agree with the items already there.
+        void upload_image(Ciphertext &ct, const Context &c, serial::CiphertextImage &img, size_t item, bool set_meta)
+        {
+            if (&ct.context() != &c)
+                throw std::invalid_argument("ciphertext belongs to another context");
+            if (item >= ct.batch())
+                throw std::out_of_range("batch item");
+            // BGV ciphertexts are serialized in coefficient form and transformed on load (ciphertext.cpp:384-403)
+            const bool to_ntt = c.scheme() == Scheme::bgv && !img.is_ntt_form && !img.data.empty();
+            const bool ntt_form = img.is_ntt_form || to_ntt;
+            hip_ok(hipDeviceSynchronize(), "sync");
+            if (set_meta)
+            {
+                ct.resize(img.level, (size_t)img.size, nullptr);
+                ct.is_ntt_form() = ntt_form;
+                ct.scale() = img.scale;
+                ct.correction_factor() = img.correction_factor;
+            }
+            else if (ct.level() != img.level || ct.size() != img.size || ct.is_ntt_form() != ntt_form || ct.scale() != img.scale ||
+                     ct.correction_factor() != img.correction_factor)
+                throw std::invalid_argument("serialized ciphertext does not match the metadata of the batch");
+            if (img.data.empty())
+                return;
+            const size_t n = c.n(), K = img.level->K, poly_words = K * n;
+            uint64_t *tmp = nullptr;
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&tmp), img.data.size() * 8), "hipMalloc");
+            hipError_t e = hipMemcpy(tmp, img.data.data(), img.data.size() * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess && to_ntt)
+            {
+                NttBatch b{};
+                b.data = tmp;
+                b.outer_stride = poly_words;
+                b.ncomp = (unsigned)K;
+                b.nouter = (unsigned)img.size;
+                b.prime_first = 0;
+                e = ntt_forward(c.ntt_tables(), b, 0, nullptr);
+            }
+            for (size_t p = 0; e == hipSuccess && p < img.size; p++)
+                e = hipMemcpyAsync(ct.plane(p) + item * poly_words, tmp + p * poly_words, poly_words * 8, hipMemcpyDeviceToDevice, nullptr);
+            if (e == hipSuccess)
+                e = hipDeviceSynchronize();
+            hipFree(tmp);
+            hip_ok(e, "ciphertext upload");
+        }
+        SHL_HRESULT ct_load(void *thisptr, void *context, uint64_t item, bool whole, uint8_t *inptr, uint64_t size, int64_t *in_bytes, bool check)
+        {
+            IfNullRet(thisptr, SHL_E_POINTER);
+            IfNullRet(context, SHL_E_POINTER);
+            IfNullRet(inptr, SHL_E_POINTER);
+            IfNullRet(in_bytes, SHL_E_POINTER);
+            SHL_TRY
+            auto ct = as<Ciphertext>(thisptr);
+            auto c = as<Context>(context);
+            if (whole && ct->batch() != 1)
+                throw std::invalid_argument("Ciphertext_Load needs a batch of one: use Ciphertext_LoadItem for a slot of a batch");
+            serial::CiphertextImage img;
+            *in_bytes = (int64_t)serial::load_ciphertext(*c, inptr, (size_t)size, check, img);
+            // the first item loaded into an empty batch defines its metadata
+            upload_image(*ct, *c, img, (size_t)item, whole || ct->size() == 0);
+            SHL_CATCH
+        }
+        SHL_HRESULT ks_load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes, bool check)
+        {
+            IfNullRet(thisptr, SHL_E_POINTER);
+            IfNullRet(context, SHL_E_POINTER);
+            IfNullRet(inptr, SHL_E_POINTER);
+            IfNullRet(in_bytes, SHL_E_POINTER);
+            SHL_TRY
+            auto c = as<Context>(context);
+            serial::KSwitchKeysImage img;
+            *in_bytes = (int64_t)serial::load_kswitchkeys(*c, inptr, (size_t)size, check, img);
+            auto keys = as<KSwitchKeys>(thisptr);
+            std::vector<uint64_t> words;
+            for (size_t index = 0; index < img.keys.size(); index++)
+            {
+                auto &digits = img.keys[index];
+                if (digits.empty())
+                    continue;
+                // [digit][2][L][N], the layout of KSwitchKeys::keys_[index][digit].data() (kswitchkeys.h:340)
+                words.clear();
+                for (auto &d : digits)
+                    words.insert(words.end(), d.data.begin(), d.data.end());
+                keys->set_key(*c, index, digits.size(), words.data(), false);
+                for (auto &d : digits)
+                    std::vector<uint64_t>().swap(d.data);
+            }
+            SHL_CATCH
+        }
+    } // namespace
+    SHL_FUNC Ciphertext_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return ct_load(thisptr, context, 0, true, inptr, size, in_bytes, true);
+    }
+    SHL_FUNC Ciphertext_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return ct_load(thisptr, context, 0, true, inptr, size, in_bytes, false);
+    }
+    SHL_FUNC Ciphertext_LoadItem(void *thisptr, void *context, uint64_t item, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return ct_load(thisptr, context, item, false, inptr, size, in_bytes, true);
+    }
+    SHL_FUNC Ciphertext_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(result, SHL_E_POINTER);
+        SHL_TRY
+        if (compr_mode != 0)
+            throw std::invalid_argument("unsupported compression mode");
+        auto ct = as<Ciphertext>(thisptr);
+        *result = (int64_t)serial::ciphertext_save_size(ct->size(), ct->poly_modulus_degree(), ct->coeff_modulus_size());
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_SaveItem(void *thisptr, uint64_t item, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(outptr, SHL_E_POINTER);
+        IfNullRet(out_bytes, SHL_E_POINTER);
+        SHL_TRY
+        if (compr_mode != 0)
+            throw std::invalid_argument("unsupported compression mode");
+        auto ct = as<Ciphertext>(thisptr);
+        if (item >= ct->batch())
+            throw std::out_of_range("batch item");
+        const size_t poly_words = ct->coeff_modulus_size() * ct->poly_modulus_degree();
+        std::vector<uint64_t> words(ct->size() * poly_words);
+        hip_ok(hipDeviceSynchronize(), "sync");
+        for (size_t p = 0; p < ct->size(); p++)
+            hip_ok(hipMemcpy(words.data() + p * poly_words, ct->plane(p) + item * poly_words, poly_words * 8, hipMemcpyDeviceToHost), "D2H");
+        static const uint64_t zero_id[4] = { 0, 0, 0, 0 };
+        *out_bytes = (int64_t)serial::save_ciphertext(
+            ct->level() ? ct->level()->parms_id : zero_id, ct->is_ntt_form(), ct->size(), ct->poly_modulus_degree(),
+            ct->coeff_modulus_size(), ct->scale(), ct->correction_factor(), words.data(), outptr, (size_t)size);
+        SHL_CATCH
+    }
+    SHL_FUNC Ciphertext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        if (as<Ciphertext>(thisptr)->batch() != 1)
+        {
+            g_last_error = "Ciphertext_Save needs a batch of one: use Ciphertext_SaveItem for a slot of a batch";
+            return SHL_E_INVALIDARG;
+        }
+        return Ciphertext_SaveItem(thisptr, 0, outptr, size, compr_mode, out_bytes);
+    }
+    SHL_FUNC KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return ks_load(thisptr, context, inptr, size, in_bytes, true);
+    }
+    SHL_FUNC KSwitchKeys_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return ks_load(thisptr, context, inptr, size, in_bytes, false);
     }
 
     // ------------------------------------------------------------------ KSwitchKeys

@@ -1,4 +1,5 @@
 #include "context.h"
+#include "blake2.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -204,13 +205,17 @@ namespace sealhip
             pool_.insert(pool_.end(), aux.begin(), aux.end());
         }
 
-        // deterministic per-level ids until a caller registers the reference's hashes
+        // parms_id of a level = BLAKE2b-256 over (scheme, N, q_0 .. q_{K-1}, t) as 64-bit words
+        // (EncryptionParameters::compute_parms_id, encryptionparams.cpp:117-147; HashFunction::hash, util/hash.h:30-37):
+        // the same 256 bits the reference computes, so serialized ciphertexts and keys name their level identically
         for (auto &l : levels_)
         {
-            l.parms_id[0] = 0x5EA1A3D000000000ull | (uint64_t)l.chain_index;
-            l.parms_id[1] = n_;
-            l.parms_id[2] = l.K;
-            l.parms_id[3] = ((uint64_t)scheme_ << 56) ^ primes_[0] ^ plain_modulus_;
+            std::vector<uint64_t> words;
+            words.push_back((uint64_t)scheme_);
+            words.push_back((uint64_t)n_);
+            words.insert(words.end(), primes_.begin(), primes_.begin() + l.K);
+            words.push_back(plain_modulus_);
+            blake2::blake2b(l.parms_id, sizeof(parms_id_type), words.data(), words.size() * sizeof(uint64_t));
         }
 
         size_t np = pool_.size();

@@ -1,0 +1,380 @@
+// Parser / writer of the reference's wire format for Ciphertext and KSwitchKeys: see serial.h for the layout and the
+// reference lines each step follows.
+#include "serial.h"
+#include "blake2.h"
+#include "shake256.h"
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+namespace sealhip
+{
+    namespace serial
+    {
+        namespace
+        {
+            struct Header
+            {
+                uint16_t magic;
+                uint8_t header_size, version_major, version_minor, compr_mode;
+                uint16_t reserved;
+                uint64_t size;
+            };
+            static_assert(sizeof(Header) == 16, "SEALHeader is 16 bytes");
+
+            // an istream over a memory buffer, reduced to what Serialization::Load needs: a failed read is the
+            // reference's ios_base::failure -> runtime_error("I/O error")
+            struct Reader
+            {
+                const uint8_t *base;
+                size_t size, pos = 0;
+                void read(void *dst, size_t n)
+                {
+                    if (n > size - pos)
+                        throw std::runtime_error("I/O error");
+                    std::memcpy(dst, base + pos, n);
+                    pos += n;
+                }
+                template <typename T>
+                T get()
+                {
+                    T v;
+                    read(&v, sizeof(T));
+                    return v;
+                }
+            };
+
+            struct Version
+            {
+                uint8_t major, minor;
+            };
+
+            // Serialization::IsCompatibleVersion (serialization.h:144-165)
+            bool compatible_version(const Header &h)
+            {
+                if (h.version_major == kVersionMajor && h.version_minor <= kVersionMinor)
+                    return true;
+                return h.version_major == 3 && h.version_minor >= 4;
+            }
+            // Serialization::IsValidHeader (serialization.h:172-191) for a build without zlib / zstd
+            bool valid_header(const Header &h)
+            {
+                return h.magic == kMagic && h.header_size == kHeaderSize && compatible_version(h) && h.compr_mode == 0;
+            }
+
+            // Serialization::Load (serialization.cpp:341-553) around `members(reader, version)`
+            template <class Fn>
+            size_t framed(Reader &r, Fn members)
+            {
+                const size_t start = r.pos;
+                Header h;
+                r.read(&h, sizeof(h));
+                if (!compatible_version(h))
+                    throw std::logic_error("incompatible version");
+                if (!valid_header(h) || h.size < sizeof(Header))
+                    throw std::logic_error("loaded SEALHeader is invalid");
+                if (h.size > r.size - start)
+                    throw std::invalid_argument("SEALHeader.size exceeds available input");
+                members(r, Version{ h.version_major, h.version_minor });
+                if (h.size != r.pos - start)
+                    throw std::logic_error("invalid data size");
+                return (size_t)h.size;
+            }
+
+            // is_metadata_valid_for(const Ciphertext &, context, allow_pure_key_levels) (valcheck.cpp:20-78)
+            bool metadata_valid(const Context &ctx, const Level *lvl, uint64_t n, uint64_t K, uint64_t size, double scale,
+                                uint64_t correction_factor, bool allow_pure_key_levels)
+            {
+                if (!lvl)
+                    return false;
+                if (!allow_pure_key_levels && lvl->chain_index > ctx.first_level().chain_index)
+                    return false;
+                if (K != lvl->K || n != ctx.n())
+                    return false;
+                if ((size < 2 && size != 0) || size > 6) // SEAL_CIPHERTEXT_SIZE_MIN / _MAX (util/defines.h)
+                    return false;
+                const Scheme s = ctx.scheme();
+                const bool positive_normal = std::isnormal(scale) && scale > 0;
+                if ((scale != 1.0 && (s == Scheme::bfv || s == Scheme::bgv)) || (!positive_normal && s == Scheme::ckks))
+                    return false;
+                if ((correction_factor != 1 && (s == Scheme::bfv || s == Scheme::ckks)) ||
+                    ((correction_factor == 0 || correction_factor >= ctx.plain_modulus()) && s == Scheme::bgv))
+                    return false;
+                return true;
+            }
+            // the coefficient range part of is_data_valid_for (valcheck.cpp:310-346)
+            bool data_in_range(const Context &ctx, const CiphertextImage &c)
+            {
+                const size_t n = ctx.n();
+                const uint64_t *p = c.data.data();
+                for (uint64_t i = 0; i < c.size; i++)
+                    for (unsigned j = 0; j < c.level->K; j++)
+                    {
+                        const uint64_t q = ctx.coeff_modulus()[j];
+                        for (size_t k = 0; k < n; k++, p++)
+                            if (*p >= q)
+                                return false;
+                    }
+                return true;
+            }
+
+            // UniformRandomGenerator::generate over refill_buffer (randomgen.cpp:179-227): 4096-byte buffers,
+            // buffer i = XOF(seed, counter = i)
+            struct SeededStream
+            {
+                uint8_t type;
+                uint64_t seed[8];
+                uint64_t counter = 0;
+                uint8_t buf[4096];
+                size_t head = 4096;
+                void refill()
+                {
+                    if (type == 1)
+                        blake2::blake2xb(buf, sizeof(buf), &counter, sizeof(counter), seed, sizeof(seed));
+                    else
+                    {
+                        uint64_t ext[9];
+                        std::memcpy(ext, seed, sizeof(seed));
+                        ext[8] = counter;
+                        keccak::shake256(buf, sizeof(buf), reinterpret_cast<const uint8_t *>(ext), sizeof(ext));
+                    }
+                    counter++;
+                    head = 0;
+                }
+                void generate(size_t bytes, uint8_t *dst)
+                {
+                    while (bytes)
+                    {
+                        if (head == sizeof(buf))
+                            refill();
+                        size_t take = sizeof(buf) - head;
+                        if (take > bytes)
+                            take = bytes;
+                        std::memcpy(dst, buf + head, take);
+                        head += take;
+                        dst += take;
+                        bytes -= take;
+                    }
+                }
+            };
+            // sample_poly_uniform (util/rlwe.cpp): bulk fill, then per component reject rand >= max_multiple (drawing the
+            // replacement from the same stream, in coefficient order) and reduce
+            void sample_poly_uniform(SeededStream &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+            {
+                prng.generate(K * N * sizeof(uint64_t), reinterpret_cast<uint8_t *>(dst));
+                for (size_t j = 0; j < K; j++)
+                {
+                    const uint64_t q = primes[j];
+                    const uint64_t max_random = ~0ull;
+                    const uint64_t max_multiple = max_random - (max_random % q) - 1;
+                    for (size_t k = 0; k < N; k++)
+                    {
+                        uint64_t rand = dst[k];
+                        while (rand >= max_multiple)
+                            prng.generate(sizeof(uint64_t), reinterpret_cast<uint8_t *>(&rand));
+                        dst[k] = rand % q;
+                    }
+                    dst += N;
+                }
+            }
+
+            // Ciphertext::load_members (ciphertext.cpp:230-403)
+            void ciphertext_members(const Context &ctx, Reader &r, Version v, CiphertextImage &out)
+            {
+                uint64_t parms_id[4];
+                r.read(parms_id, sizeof(parms_id));
+                const uint8_t ntt_byte = r.get<uint8_t>();
+                const uint64_t size64 = r.get<uint64_t>(), n64 = r.get<uint64_t>(), K64 = r.get<uint64_t>();
+                const double scale = r.get<double>();
+                uint64_t correction_factor = 1;
+                if (v.major == 4)
+                    correction_factor = r.get<uint64_t>();
+                const Level *lvl = ctx.level_by_parms_id(parms_id);
+                // pure key levels are allowed here: the same members serialize a PublicKey
+                if (!metadata_valid(ctx, lvl, n64, K64, size64, scale, correction_factor, true))
+                    throw std::logic_error("ciphertext data is invalid");
+                out.level = lvl;
+                out.is_ntt_form = ntt_byte != 0;
+                out.size = size64;
+                out.scale = scale;
+                out.correction_factor = correction_factor;
+                out.was_seeded = false;
+                const uint64_t total = size64 * n64 * K64;
+                // DynArray::load with in_size_bound = total, strict (dynarray.h:692-735)
+                framed(r, [&](Reader &rr, Version) {
+                    const uint64_t count = rr.get<uint64_t>();
+                    if (count > total)
+                        throw std::logic_error("unexpected size");
+                    out.data.resize((size_t)count);
+                    if (count)
+                        rr.read(out.data.data(), (size_t)count * sizeof(uint64_t));
+                });
+                const uint64_t seeded_count = n64 * K64;
+                if (out.data.size() == seeded_count)
+                {
+                    // only c_0 was stored: c_1 is expanded from the seed that follows (ciphertext.cpp:118-151)
+                    if (size64 != 2)
+                        throw std::logic_error("ciphertext data is invalid");
+                    if (!(v.major == 4 || (v.major == 3 && v.minor >= 6)))
+                        throw std::logic_error("incompatible version"); // the 3.4 / 3.5 samplers are not restated here
+                    SeededStream prng;
+                    framed(r, [&](Reader &rr, Version) {
+                        prng.type = rr.get<uint8_t>();
+                        if (prng.type != 1 && prng.type != 2)
+                            throw std::logic_error("prng_type is invalid");
+                        rr.read(prng.seed, sizeof(prng.seed));
+                    });
+                    out.data.resize((size_t)total);
+                    sample_poly_uniform(prng, ctx.coeff_modulus().data(), (size_t)K64, (size_t)n64, out.data.data() + seeded_count);
+                    out.was_seeded = true;
+                }
+                // is_buffer_valid (valcheck.cpp:180-196)
+                if (out.data.size() != total)
+                    throw std::logic_error("ciphertext data is invalid");
+                // BGV stores coefficient form and transforms on load; the coefficients are range-checked first
+                // (ciphertext.cpp:384-396), for unsafe_load as well
+                if (ctx.scheme() == Scheme::bgv && !out.is_ntt_form && !out.data.empty())
+                {
+                    if (!metadata_valid(ctx, lvl, n64, K64, size64, scale, correction_factor, false) || !data_in_range(ctx, out))
+                        throw std::logic_error("ciphertext data is invalid");
+                }
+            }
+
+            void check_input(const uint8_t *in, size_t size)
+            {
+                // Serialization::Load(load_members, in, size) (serialization.cpp:559-575)
+                if (!in)
+                    throw std::invalid_argument("in cannot be null");
+                if (size < sizeof(Header))
+                    throw std::invalid_argument("insufficient size");
+                if (size > (size_t)std::numeric_limits<std::streamsize>::max())
+                    throw std::invalid_argument("size is too large");
+            }
+        } // namespace
+
+        void expand_seed_blake2xb(const uint64_t *seed, const uint64_t *primes, size_t K, size_t N, uint64_t *destination)
+        {
+            SeededStream prng;
+            prng.type = 1;
+            std::memcpy(prng.seed, seed, sizeof(prng.seed));
+            sample_poly_uniform(prng, primes, K, N, destination);
+        }
+
+        size_t load_ciphertext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, CiphertextImage &out)
+        {
+            check_input(in, size);
+            Reader r{ in, size };
+            CiphertextImage img;
+            const size_t bytes = framed(r, [&](Reader &rr, Version v) { ciphertext_members(ctx, rr, v, img); });
+            if (check_data)
+            {
+                // Ciphertext::load = unsafe_load + is_valid_for (ciphertext.h:533-545; valcheck.cpp): data levels only,
+                // every coefficient reduced
+                if (!metadata_valid(ctx, img.level, ctx.n(), img.level->K, img.size, img.scale, img.correction_factor, false) ||
+                    !data_in_range(ctx, img))
+                    throw std::logic_error("ciphertext data is invalid");
+            }
+            out = std::move(img);
+            return bytes;
+        }
+
+        size_t load_kswitchkeys(const Context &ctx, const uint8_t *in, size_t size, bool check_data, KSwitchKeysImage &out)
+        {
+            check_input(in, size);
+            Reader r{ in, size };
+            KSwitchKeysImage img;
+            uint64_t parms_id[4] = { 0, 0, 0, 0 };
+            const size_t bytes = framed(r, [&](Reader &rr, Version) {
+                // KSwitchKeys::load_members (kswitchkeys.cpp:92-180)
+                rr.read(parms_id, sizeof(parms_id));
+                const uint64_t dim1 = rr.get<uint64_t>();
+                if (dim1 > ctx.n())
+                    throw std::logic_error("KSwitchKeys outer dimension is invalid");
+                const uint64_t max_dim2 = ctx.first_level().K;
+                img.keys.reserve((size_t)dim1);
+                for (uint64_t i = 0; i < dim1; i++)
+                {
+                    const uint64_t dim2 = rr.get<uint64_t>();
+                    if (dim2 > max_dim2)
+                        throw std::logic_error("KSwitchKeys inner dimension is invalid");
+                    img.keys.emplace_back();
+                    img.keys.back().reserve((size_t)dim2);
+                    for (uint64_t j = 0; j < dim2; j++)
+                    {
+                        CiphertextImage key;
+                        framed(rr, [&](Reader &r3, Version v) { ciphertext_members(ctx, r3, v, key); });
+                        img.keys.back().emplace_back(std::move(key));
+                    }
+                }
+            });
+            // What the device representation needs regardless of `check_data` (the reference's unsafe_load defers these to
+            // the first use, where they surface as invalid_argument / logic_error): key-level, NTT-form, size-2 digits
+            const Level *key_level = &ctx.key_level();
+            bool structure_ok = ctx.level_by_parms_id(parms_id) == key_level;
+            for (auto &a : img.keys)
+            {
+                if (!a.empty() && a.size() != ctx.first_level().K)
+                    structure_ok = false;
+                for (auto &b : a)
+                    if (b.level != key_level || !b.is_ntt_form || b.size != 2)
+                        structure_ok = false;
+            }
+            if (!structure_ok)
+                throw std::logic_error("KSwitchKeys data is invalid");
+            if (check_data)
+            {
+                // KSwitchKeys::load = unsafe_load + is_valid_for (kswitchkeys.h:236-246; valcheck.cpp)
+                for (auto &a : img.keys)
+                    for (auto &b : a)
+                        if (!data_in_range(ctx, b))
+                            throw std::logic_error("KSwitchKeys data is invalid");
+            }
+            out = std::move(img);
+            return bytes;
+        }
+
+        size_t ciphertext_save_size(uint64_t size, uint64_t n, uint64_t K)
+        {
+            // Ciphertext::save_size(compr_mode_type::none) (ciphertext.cpp:153-186): members + the DynArray's own frame
+            const size_t members = 4 * 8 + 1 + 3 * 8 + 8 + 8;
+            const size_t dyn = sizeof(Header) + 8 + (size_t)(size * n * K) * 8;
+            return sizeof(Header) + members + dyn;
+        }
+
+        size_t save_ciphertext(const uint64_t *parms_id, bool is_ntt_form, uint64_t size, uint64_t n, uint64_t K, double scale,
+                               uint64_t correction_factor, const uint64_t *words, uint8_t *out, size_t capacity)
+        {
+            // Serialization::Save(save_members, raw_size, out, size, compr_mode) (serialization.cpp:232-340, 541-557)
+            if (!out)
+                throw std::invalid_argument("out cannot be null");
+            if (capacity < sizeof(Header))
+                throw std::invalid_argument("insufficient size");
+            const size_t total = ciphertext_save_size(size, n, K);
+            if (capacity < total)
+                throw std::runtime_error("I/O error"); // the reference's ArrayPutBuffer overflows: ios failure
+            uint8_t *p = out;
+            auto put = [&](const void *src, size_t bytes) {
+                std::memcpy(p, src, bytes);
+                p += bytes;
+            };
+            Header h{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, (uint64_t)total };
+            put(&h, sizeof(h));
+            put(parms_id, 32);
+            const uint8_t ntt = is_ntt_form ? 1 : 0;
+            put(&ntt, 1);
+            put(&size, 8);
+            put(&n, 8);
+            put(&K, 8);
+            put(&scale, 8);
+            put(&correction_factor, 8);
+            const uint64_t count = size * n * K;
+            Header hd{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, (uint64_t)(sizeof(Header) + 8 + count * 8) };
+            put(&hd, sizeof(hd));
+            put(&count, 8);
+            if (count)
+                put(words, (size_t)count * 8);
+            return total;
+        }
+    } // namespace serial
+} // namespace sealhip

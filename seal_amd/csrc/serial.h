@@ -1,0 +1,69 @@
+// The reference's wire format for the two objects that enter and leave the hot path — seal::Ciphertext and
+// seal::KSwitchKeys (RelinKeys / GaloisKeys) — parsed straight into the word layout the device slabs use
+// (SURVEY 8(f) N4).  Host side only; the C ABI (capi.cpp: Ciphertext_Load / _UnsafeLoad / _Save / _SaveSize,
+// KSwitchKeys_Load / _UnsafeLoad) uploads the images.
+//
+// Format (all little-endian; every object is framed by a 16-byte SEALHeader whose `size` counts the header):
+//   SEALHeader  { u16 magic = 0xA15E; u8 header_size = 16; u8 version_major, version_minor; u8 compr_mode; u16 reserved; u64 size }
+//                                                   native/src/seal/serialization.h (struct SEALHeader)
+//   Ciphertext  = SEALHeader, parms_id (4 x u64), is_ntt_form (u8), size, poly_modulus_degree, coeff_modulus_size (u64 each),
+//                 scale (f64), correction_factor (u64), DynArray, [UniformRandomGeneratorInfo when seeded]
+//                                                   native/src/seal/ciphertext.cpp:153-403
+//   DynArray    = SEALHeader, count (u64), count x u64                       native/src/seal/dynarray.h:662-735
+//   seeded      : the DynArray holds c_0 only (N*K words) and is followed by
+//                 SEALHeader, prng_type (u8: 1 = blake2xb, 2 = shake256), seed (64 bytes); c_1 = sample_poly_uniform(prng(seed))
+//                                                   native/src/seal/ciphertext.cpp:118-151, randomgen.cpp:87-110, util/rlwe.cpp
+//   KSwitchKeys = SEALHeader, parms_id, keys_dim1 (u64), keys_dim1 x { keys_dim2 (u64), keys_dim2 x PublicKey }, a PublicKey
+//                 being serialized as its Ciphertext              native/src/seal/kswitchkeys.cpp:47-180, publickey.h:106-131
+// compr_mode: none only — the same set a reference built without zlib / zstd accepts (IsSupportedComprMode,
+// serialization.h:100-116); anything else is "loaded SEALHeader is invalid", as there.
+// Exceptions are the reference's: std::invalid_argument / std::logic_error / std::runtime_error("I/O error") at the same
+// conditions (Serialization::Load, serialization.cpp:341-553; Ciphertext::load_members; valcheck.cpp).
+#pragma once
+#include "context.h"
+#include <cstdint>
+#include <vector>
+
+namespace sealhip
+{
+    namespace serial
+    {
+        constexpr uint16_t kMagic = 0xA15E;
+        constexpr uint8_t kHeaderSize = 0x10;
+        constexpr uint8_t kVersionMajor = 4, kVersionMinor = 4; // the reference release this format follows (4.4.x)
+
+        // host image of one seal::Ciphertext: metadata + [size][K][N] words (seed already expanded)
+        struct CiphertextImage
+        {
+            const Level *level = nullptr;
+            bool is_ntt_form = false;
+            uint64_t size = 0;
+            double scale = 1.0;
+            uint64_t correction_factor = 1;
+            bool was_seeded = false;
+            std::vector<uint64_t> data;
+        };
+        struct KSwitchKeysImage
+        {
+            // keys[index] = decomposition digits of key `index`, each a size-2 key-level ciphertext in NTT form; empty = no key
+            std::vector<std::vector<CiphertextImage>> keys;
+        };
+
+        // Ciphertext::unsafe_load (check_data = false) / Ciphertext::load (true: is_valid_for, valcheck.cpp).  Returns the
+        // bytes consumed.  A BGV ciphertext stored in coefficient form is returned as stored (is_ntt_form false): the caller
+        // transforms it on the device, as the end of Ciphertext::load_members does on the host.
+        size_t load_ciphertext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, CiphertextImage &out);
+        // KSwitchKeys::unsafe_load / load
+        size_t load_kswitchkeys(const Context &ctx, const uint8_t *in, size_t size, bool check_data, KSwitchKeysImage &out);
+
+        // Ciphertext::save_size(compr_mode_type::none) / Ciphertext::save for a full (unseeded) ciphertext
+        size_t ciphertext_save_size(uint64_t size, uint64_t poly_modulus_degree, uint64_t coeff_modulus_size);
+        size_t save_ciphertext(const uint64_t *parms_id, bool is_ntt_form, uint64_t size, uint64_t poly_modulus_degree,
+                               uint64_t coeff_modulus_size, double scale, uint64_t correction_factor, const uint64_t *words,
+                               uint8_t *out, size_t capacity);
+
+        // sample_poly_uniform (util/rlwe.cpp) with the Blake2xb PRNG of randomgen.cpp seeded by `seed` (8 words):
+        // K*N words, component r uniform in [0, primes[r])
+        void expand_seed_blake2xb(const uint64_t *seed, const uint64_t *primes, size_t K, size_t N, uint64_t *destination);
+    } // namespace serial
+} // namespace sealhip

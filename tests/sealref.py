@@ -195,6 +195,66 @@ class RefContext:
         w = np.ascontiguousarray(words, dtype=np.uint64)
         _ck(lib().ref_key_set(self.h, C.c_int(k), C.c_uint64(index), _p(w)))
 
+    # -- wire format
+    def parms_id(self, chain_index):
+        out = (C.c_uint64 * 4)()
+        _ck(lib().ref_ctx_parms_id(self.h, C.c_uint64(chain_index), out))
+        return tuple(out)
+
+    def ct_save(self, ct):
+        """Ciphertext::save(compr_mode_type::none) -> bytes"""
+        i = ct.info()
+        cap = 4096 + 8 * i["size"] * i["coeff_modulus_size"] * self.n
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_ct_save(ct.h, buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def ct_load(self, data, unsafe=False):
+        """Ciphertext::load / unsafe_load -> (RefCiphertext, bytes consumed)"""
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
+        h, n = C.c_void_p(), C.c_uint64()
+        _ck(lib().ref_ct_load(self.h, buf, C.c_uint64(len(data)), C.c_int(1 if unsafe else 0), C.byref(h), C.byref(n)))
+        return RefCiphertext(self, h), n.value
+
+    def encrypt_zero_symmetric_save(self, chain_index, seeded=True):
+        """Encryptor::encrypt_zero_symmetric(parms_id) saved (seeded: the Serializable<> form with c_1 as a seed)"""
+        cap = 4096 + 8 * 2 * len(self.primes) * self.n
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_encrypt_zero_symmetric_save(self.h, C.c_uint64(chain_index), C.c_int(1 if seeded else 0), buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def keys_save(self, kind, seeded=True, elts=()):
+        """RelinKeys / GaloisKeys saved (seeded: Serializable<> form); the context's key object is reloaded from the stream"""
+        k = 0 if kind == "relin" else 1
+        L = len(self.primes)
+        nkeys = 1 if k == 0 else max(1, len(elts))
+        cap = 65536 + 16 * self.n + nkeys * (L - 1) * (4096 + 8 * 2 * L * self.n)  # 8 bytes per (mostly empty) key slot
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        a = (C.c_uint32 * max(1, len(elts)))(*elts)
+        _ck(lib().ref_keys_save(self.h, C.c_int(k), C.c_int(1 if seeded else 0), a, C.c_uint64(len(elts)), buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def keys_load(self, data, unsafe=False):
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
+        n = C.c_uint64()
+        _ck(lib().ref_keys_load(self.h, buf if len(data) else None, C.c_uint64(len(data)), C.c_int(1 if unsafe else 0), C.byref(n)))
+        return n.value
+
+    def public_key_save(self):
+        cap = 4096 + 8 * 2 * len(self.primes) * self.n
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_public_key_save(self.h, buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def key_slots(self, kind):
+        v = C.c_uint64()
+        _ck(lib().ref_key_slots(self.h, C.c_int(0 if kind == "relin" else 1), C.byref(v)))
+        return v.value
+
     def galois_elt_from_step(self, step):
         return int(lib().ref_galois_elt_from_step(self.h, C.c_int(step)))
 

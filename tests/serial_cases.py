@@ -1,0 +1,273 @@
+"""Wire-format cases shared by the CPU (emulated kernels) and `-m gpu` suites: the reference's own byte
+streams — Ciphertext::save / Serializable<Ciphertext> (seeded), RelinKeys / GaloisKeys (seeded or full) — produced by the
+REAL reference (oracle/_ref) are loaded through the C ABI (Ciphertext_Load, KSwitchKeys_Load, ...) and must give the same
+words, metadata, bytes back (Ciphertext_Save) and the same exception classes on malformed input.
+TEST INFRASTRUCTURE: the reference is the checker here, never the thing tested."""
+import struct
+
+import numpy as np
+
+import seal_amd as S
+import sealref
+from harness import DeviceSide
+from oracle import coeff_modulus_create, plain_modulus_batching, rand_ct
+
+# reference error code (oracle/sealref_shim.cpp) -> the exception class the C ABI's HRESULT maps to
+CLASS_OF_CODE = {1: S.InvalidArgument, 2: S.LogicError, 3: S.OutOfRange, 4: S.DeviceError}
+
+
+def setup(scheme, n, bits, tbits=20):
+    primes = coeff_modulus_create(n, bits)
+    t = plain_modulus_batching(n, tbits) if scheme != "ckks" else 0
+    return primes, t, sealref.RefContext(scheme, n, primes, t), DeviceSide(scheme, n, primes, t)
+
+
+def _same_ct(ct, rct, what):
+    ri = rct.info()
+    assert (ct.size(), ct.is_ntt_form(), ct.scale(), ct.correction_factor(), ct.coeff_modulus_size()) == \
+        (ri["size"], ri["is_ntt_form"], ri["scale"], ri["correction_factor"], ri["coeff_modulus_size"]), what
+    assert np.array_equal(ct.to_numpy()[:, 0], rct.data()), what
+
+
+def case_parms_ids(scheme, n, bits):
+    """every level's parms_id is the reference's BLAKE2b hash (encryptionparams.cpp:117-147)"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    for ci in range(ref.key_chain_index + 1):
+        assert d.ctx.parms_id_at(ci) == ref.parms_id(ci), (scheme, ci)
+
+
+def case_ciphertext_streams(scheme, n, bits):
+    """seeded and full streams at every data level: load == the reference's load, save == the reference's bytes"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    for seeded in (True, False):
+        for ci in range(ref.first_chain_index, -1, -1):
+            data = ref.encrypt_zero_symmetric_save(ci, seeded)
+            rct, nbytes = ref.ct_load(data)
+            ct = S.Ciphertext(d.ctx)
+            assert ct.load_bytes(data) == nbytes == len(data)
+            _same_ct(ct, rct, (scheme, seeded, ci))
+            assert ct.save_size() == len(ref.ct_save(rct))
+            assert ct.save_bytes() == ref.ct_save(rct), "Ciphertext::save bytes"
+            # trailing bytes after the object are left alone (concatenated objects)
+            ct2 = S.Ciphertext(d.ctx)
+            assert ct2.load_bytes(data + b"\x00" * 24, unsafe=True) == len(data)
+            _same_ct(ct2, rct, "unsafe_load with trailing bytes")
+
+
+def case_evaluated_ciphertext_roundtrip(scheme, n, bits):
+    """a size-3 product computed on the device is saved, loaded by the REFERENCE, and equals the reference's own product;
+    the reference's saved product loads back into the device slab"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    ref.keygen_relin()
+    K = len(primes) - 1
+    rng = np.random.default_rng(11)
+    x, y = rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)
+    is_ntt = scheme != "bfv"
+    scale = 2.0 ** 10 if scheme == "ckks" else 1.0
+    cx, cy = d.ct(x, scale=scale, is_ntt=is_ntt), d.ct(y, scale=scale, is_ntt=is_ntt)
+    d.ev.multiply_inplace(cx, cy)
+    stream = cx.save_bytes()
+    rct, nbytes = ref.ct_load(stream)
+    assert nbytes == len(stream)
+    rx = ref.ct(ref.first_chain_index, x, is_ntt, scale)
+    ry = ref.ct(ref.first_chain_index, y, is_ntt, scale)
+    ref.multiply_inplace(rx, ry)
+    assert np.array_equal(rct.data(), rx.data()) and rct.info() == rx.info()
+    back = S.Ciphertext(d.ctx)
+    back.load_bytes(ref.ct_save(rx))
+    _same_ct(back, rx, "reference product loaded to the device")
+
+
+def case_bgv_coefficient_form_stream(n, bits):
+    """a BGV ciphertext serialized in coefficient form is transformed on load (ciphertext.cpp:384-403)"""
+    primes, t, ref, d = setup("bgv", n, bits)
+    data = ref.encrypt_zero_symmetric_save(ref.first_chain_index, False)
+    rct, _ = ref.ct_load(data)
+    ref.transform_from_ntt_inplace(rct)
+    stream = ref.ct_save(rct)
+    assert stream[16 + 32] == 0  # is_ntt_form byte
+    loaded, _ = ref.ct_load(stream)
+    assert loaded.info()["is_ntt_form"]
+    ct = S.Ciphertext(d.ctx)
+    ct.load_bytes(stream)
+    _same_ct(ct, loaded, "bgv coefficient-form stream")
+    # out-of-range coefficients are rejected before the transform, for unsafe_load as well
+    bad = bytearray(stream)
+    off = 16 + 32 + 1 + 40 + 16 + 8  # first data word
+    bad[off:off + 8] = struct.pack("<Q", primes[0])
+    for unsafe in (False, True):
+        _same_failure(ref, d, bytes(bad), unsafe)
+
+
+def case_batch_items(scheme, n, bits):
+    """LoadItem / SaveItem: slots of a device-resident batch"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    streams = [ref.encrypt_zero_symmetric_save(ref.first_chain_index, s) for s in (True, False, True)]
+    refs = [ref.ct_load(s)[0] for s in streams]
+    ct = S.Ciphertext(d.ctx, batch=3)
+    for i, s in enumerate(streams):
+        assert ct.load_bytes(s, item=i) == len(s)
+    arr = ct.to_numpy()
+    for i, r in enumerate(refs):
+        assert np.array_equal(arr[:, i], r.data())
+        assert ct.save_bytes(item=i) == ref.ct_save(r)
+    # an item at another level does not fit the batch
+    if ref.first_chain_index > 0:
+        other = ref.encrypt_zero_symmetric_save(ref.first_chain_index - 1, False)
+        try:
+            ct.load_bytes(other, item=1)
+            raise AssertionError("expected InvalidArgument")
+        except S.InvalidArgument:
+            pass
+    try:
+        ct.load_bytes(streams[0], item=3)
+        raise AssertionError("expected OutOfRange")
+    except S.OutOfRange:
+        pass
+
+
+def case_key_streams(scheme, n, bits, seeded, steps=(1,)):
+    """serialized RelinKeys / GaloisKeys (seeded = the Serializable<> form) loaded straight into the device key slabs:
+    relinearize / apply_galois with them give the reference's words"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    K = len(primes) - 1
+    rng = np.random.default_rng(5)
+    is_ntt = scheme != "bfv"
+    scale = 2.0 ** 10 if scheme == "ckks" else 1.0
+    stream = ref.keys_save("relin", seeded)
+    rlk = S.RelinKeys(d.ctx)
+    assert rlk.load_bytes(stream) == len(stream)
+    assert rlk.has_key(2) and rlk.size() == 1
+    x3 = rand_ct(rng, primes, K, n, size=3)
+    cx = d.ct(x3, scale=scale, is_ntt=is_ntt)
+    d.ev.relinearize_inplace(cx, rlk)
+    rx = ref.ct(ref.first_chain_index, x3, is_ntt, scale)
+    ref.relinearize_inplace(rx)
+    assert np.array_equal(cx.to_numpy()[:, 0], rx.data()), "relinearize with keys loaded from the stream"
+
+    elts = [ref.galois_elt_from_step(s) for s in steps] + [2 * n - 1]
+    stream = ref.keys_save("galois", seeded, elts)
+    glk = S.GaloisKeys(d.ctx)
+    assert glk.load_bytes(stream, unsafe=not seeded) == len(stream)
+    assert glk.size() == len(set(elts))
+    for e in elts:
+        assert glk.has_key(e)
+        x2 = rand_ct(rng, primes, K, n)
+        cx = d.ct(x2, scale=scale, is_ntt=is_ntt)
+        d.ev.apply_galois_inplace(cx, e, glk)
+        rx = ref.ct(ref.first_chain_index, x2, is_ntt, scale)
+        ref.apply_galois_inplace(rx, e)
+        assert np.array_equal(cx.to_numpy()[:, 0], rx.data()), "apply_galois(%d) with keys loaded from the stream" % e
+
+
+def _outcome(fn):
+    try:
+        fn()
+        return None
+    except sealref.RefError as e:
+        return CLASS_OF_CODE[e.code]
+    except S.SealHipError as e:
+        return type(e)
+
+
+def _same_failure(ref, d, data, unsafe, keys=False):
+    if keys:
+        want = _outcome(lambda: ref.keys_load(data, unsafe))
+        got = _outcome(lambda: S.KSwitchKeys(d.ctx).load_bytes(data, unsafe=unsafe))
+    else:
+        want = _outcome(lambda: ref.ct_load(data, unsafe))
+        got = _outcome(lambda: S.Ciphertext(d.ctx).load_bytes(data, unsafe=unsafe))
+    assert got == want, "exception class differs from the reference's: got %r, reference %r" % (got, want)
+    return want
+
+
+def case_malformed_streams(scheme, n, bits):
+    """every mutation fails (or not) with the reference's exception class (Serialization::Load, serialization.cpp:341-553;
+    Ciphertext::load_members; valcheck.cpp)"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    full = ref.encrypt_zero_symmetric_save(ref.first_chain_index, False)
+    seeded = ref.encrypt_zero_symmetric_save(ref.first_chain_index, True)
+    pure_key = None
+    members = 16  # offset of parms_id
+    dyn = members + 32 + 1 + 40  # offset of the DynArray's SEALHeader
+    K, nn = len(primes) - 1, n
+
+    def mutate(base, off, fmt, value):
+        b = bytearray(base)
+        b[off:off + struct.calcsize(fmt)] = struct.pack(fmt, value)
+        return bytes(b)
+
+    cases = {
+        "ok_full": full, "ok_seeded": seeded,
+        "empty": b"", "short_header": full[:10], "truncated_members": full[:60], "truncated_data": full[:-8],
+        "truncated_seed": seeded[:-4],
+        "bad_magic": mutate(full, 0, "<H", 0x1234), "bad_header_size": mutate(full, 2, "<B", 0x20),
+        "future_major": mutate(full, 3, "<B", 5), "future_minor": mutate(full, 4, "<B", 200), "old_3_3": mutate(mutate(full, 3, "<B", 3), 4, "<B", 3),
+        "zlib_mode": mutate(full, 5, "<B", 1), "zstd_mode": mutate(full, 5, "<B", 2), "unknown_mode": mutate(full, 5, "<B", 9),
+        "size_too_big": mutate(full, 8, "<Q", len(full) + 1), "size_too_small": mutate(full, 8, "<Q", len(full) - 8),
+        "size_below_header": mutate(full, 8, "<Q", 8),
+        "unknown_parms_id": mutate(full, members, "<Q", 12345),
+        "size_1": mutate(full, members + 33, "<Q", 1), "size_7": mutate(full, members + 33, "<Q", 7), "size_3_short_data": mutate(full, members + 33, "<Q", 3),
+        "wrong_degree": mutate(full, members + 41, "<Q", nn * 2), "wrong_K": mutate(full, members + 49, "<Q", K + 1),
+        "scale_nan": mutate(full, members + 57, "<d", float("nan")), "scale_zero": mutate(full, members + 57, "<d", 0.0),
+        "scale_two": mutate(full, members + 57, "<d", 2.0), "scale_negative": mutate(full, members + 57, "<d", -4.0),
+        "correction_zero": mutate(full, members + 65, "<Q", 0), "correction_two": mutate(full, members + 65, "<Q", 2),
+        "dyn_bad_magic": mutate(full, dyn, "<H", 0), "dyn_count_big": mutate(full, dyn + 16, "<Q", 2 * K * nn + 1),
+        "dyn_count_small": mutate(full, dyn + 16, "<Q", 2 * K * nn - 1), "dyn_size_field": mutate(full, dyn + 8, "<Q", 24),
+        "coefficient_out_of_range": mutate(full, dyn + 24, "<Q", primes[0]),
+        "coefficient_max": mutate(full, dyn + 24 + 8 * (nn * K + 3), "<Q", 2 ** 64 - 1),
+        "seed_prng_unknown": mutate(seeded, len(seeded) - 65, "<B", 0), "seed_prng_shake256": mutate(seeded, len(seeded) - 65, "<B", 2),
+        "seed_prng_9": mutate(seeded, len(seeded) - 65, "<B", 9), "seed_header_bad": mutate(seeded, len(seeded) - 65 - 16, "<H", 1),
+        "seeded_size_3": mutate(seeded, members + 33, "<Q", 3),
+    }
+    seen = set()
+    for name, data in cases.items():
+        for unsafe in (False, True):
+            try:
+                seen.add(_same_failure(ref, d, data, unsafe))
+            except AssertionError as e:
+                raise AssertionError("%s (unsafe=%s): %s" % (name, unsafe, e))
+    # the SHAKE256 variant is not only accepted but expanded identically
+    data = cases["seed_prng_shake256"]
+    rct, _ = ref.ct_load(data)
+    ct = S.Ciphertext(d.ctx)
+    ct.load_bytes(data)
+    _same_ct(ct, rct, "shake256-seeded stream")
+    assert {None, S.InvalidArgument, S.LogicError} <= seen, seen
+    # a key-level ciphertext (a PublicKey's members) is loadable only unsafely
+    if pure_key is None and ref.key_chain_index > ref.first_chain_index:
+        pk = ref.public_key_save()
+        _same_failure(ref, d, pk, True)
+        _same_failure(ref, d, pk, False)
+
+
+def case_malformed_key_streams(scheme, n, bits):
+    primes, t, ref, d = setup(scheme, n, bits)
+    stream = ref.keys_save("relin", True)
+
+    def mutate(base, off, fmt, value):
+        b = bytearray(base)
+        b[off:off + struct.calcsize(fmt)] = struct.pack(fmt, value)
+        return bytes(b)
+
+    first_key = 16 + 32 + 8 + 8  # SEALHeader of the first PublicKey
+    cases = {
+        "ok": stream, "truncated": stream[:-1], "bad_magic": mutate(stream, 0, "<H", 7),
+        "wrong_parms_id": mutate(stream, 16, "<Q", 99),
+        "dim1_huge": mutate(stream, 16 + 32, "<Q", n + 1), "dim2_huge": mutate(stream, 16 + 32 + 8, "<Q", len(primes)),
+        "dim2_short": mutate(stream, 16 + 32 + 8, "<Q", len(primes) - 2),
+        "key_not_ntt": mutate(stream, first_key + 16 + 32, "<B", 0),
+        "key_size_3": mutate(stream, first_key + 16 + 33, "<Q", 3),
+        "key_coefficient_out_of_range": mutate(stream, first_key + 16 + 73 + 24, "<Q", primes[0]),
+    }
+    for name, data in cases.items():
+        for unsafe in (False, True):
+            try:
+                want = _same_failure(ref, d, data, unsafe, keys=True)
+            except AssertionError as e:
+                # documented difference: unsafe_load of structurally unusable keys fails at load time here, at first use in
+                # the reference (the device layout needs key-level, NTT-form, size-2 digits)
+                if unsafe and name in ("wrong_parms_id", "dim2_short", "key_not_ntt", "key_size_3"):
+                    assert _outcome(lambda: S.KSwitchKeys(d.ctx).load_bytes(data, unsafe=True)) == S.LogicError
+                    continue
+                raise AssertionError("%s (unsafe=%s): %s" % (name, unsafe, e))

@@ -1,0 +1,45 @@
+"""`-m gpu`: the reference's wire format on the real device path — streams written by the REAL reference
+(oracle/_ref) are parsed into the HBM slabs through the C ABI; loaded words, re-saved bytes, key-switching results with keys
+loaded from (seeded) streams and exception classes must equal the reference's.  Includes the headline size (N = 2^16, L = 16:
+a 126 MB seeded relinearization key expanded with the Blake2xb PRNG restated in seal_amd/csrc/blake2.h)."""
+import pytest
+
+import sealref
+import serial_cases as SC
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not sealref.available(), reason="oracle/_ref (the real reference) did not travel")]
+
+SIZES = [("ckks", 8192, [60, 40, 40, 60]), ("bfv", 4096, [36, 36, 37]), ("bgv", 8192, [50, 40, 56])]
+
+
+@pytest.mark.parametrize("scheme,n,bits", SIZES)
+def test_parms_ids_and_ciphertext_streams(gpu, scheme, n, bits):
+    SC.case_parms_ids(scheme, n, bits)
+    SC.case_ciphertext_streams(scheme, n, bits)
+    SC.case_evaluated_ciphertext_roundtrip(scheme, n, bits)
+
+
+def test_bgv_coefficient_form_stream(gpu):
+    SC.case_bgv_coefficient_form_stream(8192, [50, 40, 56])
+
+
+def test_batch_items(gpu):
+    SC.case_batch_items("ckks", 8192, [60, 40, 40, 60])
+
+
+@pytest.mark.parametrize("scheme,n,bits,seeded", [
+    ("ckks", 8192, [60, 40, 40, 60], True), ("ckks", 16384, [60, 50, 50, 60], False), ("bfv", 8192, [50, 55, 56], True),
+    ("bgv", 4096, [36, 36, 37], True),
+])
+def test_key_streams(gpu, scheme, n, bits, seeded):
+    SC.case_key_streams(scheme, n, bits, seeded)
+
+
+def test_key_stream_headline_size(gpu):
+    """BASELINE's headline parameters: CKKS N = 65536, {60, 14 x 50, 60}; seeded RelinKeys + GaloisKeys streams"""
+    SC.case_key_streams("ckks", 65536, [60] + [50] * 14 + [60], True)
+
+
+def test_malformed_streams(gpu):
+    SC.case_malformed_streams("ckks", 4096, [40, 30, 40])
+    SC.case_malformed_key_streams("ckks", 4096, [40, 30, 40])
