@@ -245,7 +245,8 @@ class Ciphertext:
     # -- the reference's wire format (Ciphertext::save / load / unsafe_load, ciphertext.cpp:153-403)
     def load_bytes(self, data, unsafe=False, item=None):
         """seal::Ciphertext::load (unsafe=True: unsafe_load) of a serialized stream; item = slot of a batch.  Returns bytes read."""
-        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
+        data = bytes(data)
+        buf = C.cast(C.c_char_p(data), C.c_void_p)  # the stream is parsed in place
         n = C.c_int64()
         if item is not None:
             N.check(N.lib().Ciphertext_LoadItem(self._h, self.context._h, C.c_uint64(item), buf, C.c_uint64(len(data)), C.byref(n)))
@@ -271,7 +272,7 @@ class Ciphertext:
             N.check(N.lib().Ciphertext_SaveItem(self._h, C.c_uint64(item), buf, C.c_uint64(cap), C.c_uint8(compr_mode), C.byref(n)))
         else:
             N.check(N.lib().Ciphertext_Save(self._h, buf, C.c_uint64(cap), C.c_uint8(compr_mode), C.byref(n)))
-        return bytes(buf[:n.value])
+        return C.string_at(buf, n.value)
 
     @staticmethod
     def from_numpy(context, array, parms_id, is_ntt_form, scale=1.0, correction_factor=1):
@@ -379,7 +380,8 @@ class KSwitchKeys:
 
     def load_bytes(self, data, unsafe=False):
         """KSwitchKeys::load / unsafe_load of a serialized RelinKeys / GaloisKeys stream (seeded or full).  Returns bytes read."""
-        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
+        data = bytes(data)
+        buf = C.cast(C.c_char_p(data), C.c_void_p)  # the stream is parsed in place
         n = C.c_int64()
         fn = N.lib().KSwitchKeys_UnsafeLoad if unsafe else N.lib().KSwitchKeys_Load
         N.check(fn(self._h, self.context._h, buf, C.c_uint64(len(data)), C.byref(n)))

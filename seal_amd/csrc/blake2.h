@@ -44,7 +44,7 @@ namespace sealhip
         {
             static const uint64_t IV[8] = { 0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
                                             0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull };
-            static const uint8_t SIGMA[12][16] = {
+            static constexpr uint8_t SIGMA[12][16] = {
                 { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15 }, { 14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3 },
                 { 11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4 }, { 7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8 },
                 { 9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13 }, { 2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9 },
@@ -74,6 +74,7 @@ namespace sealhip
                 v[c] = v[c] + v[d];
                 v[b] = rotr(v[b] ^ v[c], 63);
             };
+#pragma GCC unroll 12
             for (int r = 0; r < 12; r++)
             {
                 G(r, 0, 0, 4, 8, 12);

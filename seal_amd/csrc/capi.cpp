@@ -529,7 +529,7 @@ extern "C"
             if (item >= ct.batch())
                 throw std::out_of_range("batch item");
             // BGV ciphertexts are serialized in coefficient form and transformed on load (ciphertext.cpp:384-403)
-            const bool to_ntt = c.scheme() == Scheme::bgv && !img.is_ntt_form && !img.data.empty();
+            const bool to_ntt = c.scheme() == Scheme::bgv && !img.is_ntt_form && img.word_count() != 0;
             const bool ntt_form = img.is_ntt_form || to_ntt;
             hip_ok(hipDeviceSynchronize(), "sync");
             if (set_meta)
@@ -542,12 +542,15 @@ extern "C"
             else if (ct.level() != img.level || ct.size() != img.size || ct.is_ntt_form() != ntt_form || ct.scale() != img.scale ||
                      ct.correction_factor() != img.correction_factor)
                 throw std::invalid_argument("serialized ciphertext does not match the metadata of the batch");
-            if (img.data.empty())
+            if (img.word_count() == 0)
                 return;
             const size_t n = c.n(), K = img.level->K, poly_words = K * n;
             uint64_t *tmp = nullptr;
-            hip_ok(hipMalloc(reinterpret_cast<void **>(&tmp), img.data.size() * 8), "hipMalloc");
-            hipError_t e = hipMemcpy(tmp, img.data.data(), img.data.size() * 8, hipMemcpyHostToDevice);
+            hip_ok(hipMalloc(reinterpret_cast<void **>(&tmp), img.word_count() * 8), "hipMalloc");
+            // the stored piece goes to the device straight from the caller's stream buffer
+            hipError_t e = img.stored_words ? hipMemcpy(tmp, img.stored, img.stored_words * 8, hipMemcpyHostToDevice) : hipSuccess;
+            if (e == hipSuccess && !img.expanded.empty())
+                e = hipMemcpy(tmp + img.stored_words, img.expanded.data(), img.expanded.size() * 8, hipMemcpyHostToDevice);
             if (e == hipSuccess && to_ntt)
             {
                 NttBatch b{};
@@ -562,7 +565,7 @@ extern "C"
                 e = hipMemcpyAsync(ct.plane(p) + item * poly_words, tmp + p * poly_words, poly_words * 8, hipMemcpyDeviceToDevice, nullptr);
             if (e == hipSuccess)
                 e = hipDeviceSynchronize();
-            hipFree(tmp);
+            (void)hipFree(tmp);
             hip_ok(e, "ciphertext upload");
         }
         SHL_HRESULT ct_load(void *thisptr, void *context, uint64_t item, bool whole, uint8_t *inptr, uint64_t size, int64_t *in_bytes, bool check)
@@ -593,19 +596,25 @@ extern "C"
             serial::KSwitchKeysImage img;
             *in_bytes = (int64_t)serial::load_kswitchkeys(*c, inptr, (size_t)size, check, img);
             auto keys = as<KSwitchKeys>(thisptr);
-            std::vector<uint64_t> words;
             for (size_t index = 0; index < img.keys.size(); index++)
             {
                 auto &digits = img.keys[index];
                 if (digits.empty())
                     continue;
-                // [digit][2][L][N], the layout of KSwitchKeys::keys_[index][digit].data() (kswitchkeys.h:340)
-                words.clear();
+                // [digit][2][L][N], the layout of KSwitchKeys::keys_[index][digit].data() (kswitchkeys.h:340); every piece is
+                // copied to the device from where it lies (the stream buffer / the expanded c_1): no host staging copy
+                keys->set_key_with(*c, index, digits.size(), [&](uint64_t *dst) {
+                    for (auto &d : digits)
+                    {
+                        if (d.stored_words)
+                            hip_ok(hipMemcpy(dst, d.stored, d.stored_words * 8, hipMemcpyHostToDevice), "upload key");
+                        if (!d.expanded.empty())
+                            hip_ok(hipMemcpy(dst + d.stored_words, d.expanded.data(), d.expanded.size() * 8, hipMemcpyHostToDevice), "upload key");
+                        dst += d.word_count();
+                    }
+                });
                 for (auto &d : digits)
-                    words.insert(words.end(), d.data.begin(), d.data.end());
-                keys->set_key(*c, index, digits.size(), words.data(), false);
-                for (auto &d : digits)
-                    std::vector<uint64_t>().swap(d.data);
+                    std::vector<uint64_t>().swap(d.expanded);
             }
             SHL_CATCH
         }
@@ -645,14 +654,15 @@ extern "C"
         if (item >= ct->batch())
             throw std::out_of_range("batch item");
         const size_t poly_words = ct->coeff_modulus_size() * ct->poly_modulus_degree();
-        std::vector<uint64_t> words(ct->size() * poly_words);
-        hip_ok(hipDeviceSynchronize(), "sync");
-        for (size_t p = 0; p < ct->size(); p++)
-            hip_ok(hipMemcpy(words.data() + p * poly_words, ct->plane(p) + item * poly_words, poly_words * 8, hipMemcpyDeviceToHost), "D2H");
         static const uint64_t zero_id[4] = { 0, 0, 0, 0 };
+        size_t data_offset = 0;
         *out_bytes = (int64_t)serial::save_ciphertext(
             ct->level() ? ct->level()->parms_id : zero_id, ct->is_ntt_form(), ct->size(), ct->poly_modulus_degree(),
-            ct->coeff_modulus_size(), ct->scale(), ct->correction_factor(), words.data(), outptr, (size_t)size);
+            ct->coeff_modulus_size(), ct->scale(), ct->correction_factor(), nullptr, outptr, (size_t)size, &data_offset);
+        // the coefficient words go from the device slab straight into the stream
+        hip_ok(hipDeviceSynchronize(), "sync");
+        for (size_t p = 0; p < ct->size(); p++)
+            hip_ok(hipMemcpy(outptr + data_offset + p * poly_words * 8, ct->plane(p) + item * poly_words, poly_words * 8, hipMemcpyDeviceToHost), "D2H");
         SHL_CATCH
     }
     SHL_FUNC Ciphertext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes)

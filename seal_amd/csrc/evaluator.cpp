@@ -329,11 +329,21 @@ namespace sealhip
     }
     void KSwitchKeys::set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device, size_t digit0)
     {
+        if (!words)
+            throw std::invalid_argument("empty key");
+        const size_t bytes = digits * 2 * ctx.key_level().K * ctx.n() * 8;
+        set_key_with(
+            ctx, index, digits,
+            [&](uint64_t *dst) { ck(hipMemcpy(dst, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key"); },
+            digit0);
+    }
+    void KSwitchKeys::set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0)
+    {
         if (!ctx.using_keyswitching())
             throw std::logic_error("keyswitching is not supported by the context");
         if (ctx_ && ctx_ != &ctx)
             throw std::invalid_argument("kswitch_keys belongs to another context");
-        if (!words || digits == 0)
+        if (digits == 0)
             throw std::invalid_argument("empty key");
         ctx_ = &ctx;
         if (index >= keys_.size())
@@ -349,12 +359,12 @@ namespace sealhip
         {
             // upload to a staging block, then lay the key out for the fused kernel
             Scratch stage(bytes / 8);
-            ck(hipMemcpy(stage.p, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key");
+            upload(stage.p);
             ck(key_to_register_order(ctx.ntt_tables(), stage.p, (uint64_t *)p, (unsigned)L, digits * 2, nullptr), "key layout");
             ck(hipDeviceSynchronize(), "key layout sync");
         }
         else
-            ck(hipMemcpy(p, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key");
+            upload((uint64_t *)p);
         keys_[index].dev = (uint64_t *)p;
         keys_[index].digits = digits;
         keys_[index].digit0 = digit0;

@@ -8,6 +8,7 @@
 #include "poly_kernels.h"
 #include "pool.h"
 #include "ntt2_kernels.h"
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -119,6 +120,8 @@ namespace sealhip
         ~KSwitchKeys();
         // words: `digits` digits starting at digit `digit0` of key `index`, each 2 x L x N words
         void set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device, size_t digit0 = 0);
+        // the same with the words delivered by `upload(device_destination)` (e.g. piecewise from a serialized stream)
+        void set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0 = 0);
         bool has_key(size_t index) const { return index < keys_.size() && keys_[index].dev != nullptr; }
         const Key &key(size_t index) const { return keys_[index]; }
         size_t slots() const { return keys_.size(); }

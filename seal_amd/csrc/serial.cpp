@@ -6,7 +6,9 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <stdexcept>
+#include <thread>
 
 namespace sealhip
 {
@@ -29,6 +31,12 @@ namespace sealhip
             {
                 const uint8_t *base;
                 size_t size, pos = 0;
+                void skip(size_t n)
+                {
+                    if (n > size - pos)
+                        throw std::runtime_error("I/O error");
+                    pos += n;
+                }
                 void read(void *dst, size_t n)
                 {
                     if (n > size - pos)
@@ -104,17 +112,28 @@ namespace sealhip
                 return true;
             }
             // the coefficient range part of is_data_valid_for (valcheck.cpp:310-346)
+            typedef uint64_t unaligned_u64 __attribute__((aligned(1)));
             bool data_in_range(const Context &ctx, const CiphertextImage &c)
             {
                 const size_t n = ctx.n();
-                const uint64_t *p = c.data.data();
+                const unaligned_u64 *p = reinterpret_cast<const unaligned_u64 *>(c.stored);
+                size_t left = c.stored_words; // words still to come from the stored piece; then the expanded one
                 for (uint64_t i = 0; i < c.size; i++)
                     for (unsigned j = 0; j < c.level->K; j++)
                     {
+                        if (left == 0)
+                        {
+                            p = reinterpret_cast<const unaligned_u64 *>(c.expanded.data());
+                            left = c.expanded.size();
+                        }
                         const uint64_t q = ctx.coeff_modulus()[j];
-                        for (size_t k = 0; k < n; k++, p++)
-                            if (*p >= q)
-                                return false;
+                        uint64_t over = 0;
+                        for (size_t k = 0; k < n; k++)
+                            over |= (uint64_t)(p[k] >= q);
+                        if (over)
+                            return false;
+                        p += n;
+                        left -= n;
                     }
                 return true;
             }
@@ -179,8 +198,16 @@ namespace sealhip
                 }
             }
 
+            // a seed expansion postponed by the caller (KSwitchKeys: one independent PRNG per digit, expanded on several threads)
+            struct ExpandJob
+            {
+                SeededStream prng;
+                size_t K, N;
+                uint64_t *dst;
+            };
+
             // Ciphertext::load_members (ciphertext.cpp:230-403)
-            void ciphertext_members(const Context &ctx, Reader &r, Version v, CiphertextImage &out)
+            void ciphertext_members(const Context &ctx, Reader &r, Version v, CiphertextImage &out, std::vector<ExpandJob> *deferred = nullptr)
             {
                 uint64_t parms_id[4];
                 r.read(parms_id, sizeof(parms_id));
@@ -202,16 +229,17 @@ namespace sealhip
                 out.was_seeded = false;
                 const uint64_t total = size64 * n64 * K64;
                 // DynArray::load with in_size_bound = total, strict (dynarray.h:692-735)
+                out.expanded.clear();
                 framed(r, [&](Reader &rr, Version) {
                     const uint64_t count = rr.get<uint64_t>();
                     if (count > total)
                         throw std::logic_error("unexpected size");
-                    out.data.resize((size_t)count);
-                    if (count)
-                        rr.read(out.data.data(), (size_t)count * sizeof(uint64_t));
+                    out.stored = rr.base + rr.pos;
+                    out.stored_words = (size_t)count;
+                    rr.skip((size_t)count * sizeof(uint64_t));
                 });
                 const uint64_t seeded_count = n64 * K64;
-                if (out.data.size() == seeded_count)
+                if (out.stored_words == seeded_count)
                 {
                     // only c_0 was stored: c_1 is expanded from the seed that follows (ciphertext.cpp:118-151)
                     if (size64 != 2)
@@ -225,16 +253,19 @@ namespace sealhip
                             throw std::logic_error("prng_type is invalid");
                         rr.read(prng.seed, sizeof(prng.seed));
                     });
-                    out.data.resize((size_t)total);
-                    sample_poly_uniform(prng, ctx.coeff_modulus().data(), (size_t)K64, (size_t)n64, out.data.data() + seeded_count);
+                    out.expanded.resize((size_t)seeded_count);
+                    if (deferred)
+                        deferred->push_back(ExpandJob{ prng, (size_t)K64, (size_t)n64, out.expanded.data() });
+                    else
+                        sample_poly_uniform(prng, ctx.coeff_modulus().data(), (size_t)K64, (size_t)n64, out.expanded.data());
                     out.was_seeded = true;
                 }
                 // is_buffer_valid (valcheck.cpp:180-196)
-                if (out.data.size() != total)
+                if (out.word_count() != total)
                     throw std::logic_error("ciphertext data is invalid");
                 // BGV stores coefficient form and transforms on load; the coefficients are range-checked first
                 // (ciphertext.cpp:384-396), for unsafe_load as well
-                if (ctx.scheme() == Scheme::bgv && !out.is_ntt_form && !out.data.empty())
+                if (ctx.scheme() == Scheme::bgv && !out.is_ntt_form && out.word_count() != 0)
                 {
                     if (!metadata_valid(ctx, lvl, n64, K64, size64, scale, correction_factor, false) || !data_in_range(ctx, out))
                         throw std::logic_error("ciphertext data is invalid");
@@ -252,6 +283,14 @@ namespace sealhip
                     throw std::invalid_argument("size is too large");
             }
         } // namespace
+
+        void CiphertextImage::copy_words(uint64_t *dst) const
+        {
+            if (stored_words)
+                std::memcpy(dst, stored, stored_words * 8);
+            if (!expanded.empty())
+                std::memcpy(dst + stored_words, expanded.data(), expanded.size() * 8);
+        }
 
         void expand_seed_blake2xb(const uint64_t *seed, const uint64_t *primes, size_t K, size_t N, uint64_t *destination)
         {
@@ -285,6 +324,7 @@ namespace sealhip
             Reader r{ in, size };
             KSwitchKeysImage img;
             uint64_t parms_id[4] = { 0, 0, 0, 0 };
+            std::vector<ExpandJob> jobs; // the heap buffers they point into do not move when the images are moved
             const size_t bytes = framed(r, [&](Reader &rr, Version) {
                 // KSwitchKeys::load_members (kswitchkeys.cpp:92-180)
                 rr.read(parms_id, sizeof(parms_id));
@@ -303,11 +343,34 @@ namespace sealhip
                     for (uint64_t j = 0; j < dim2; j++)
                     {
                         CiphertextImage key;
-                        framed(rr, [&](Reader &r3, Version v) { ciphertext_members(ctx, r3, v, key); });
+                        framed(rr, [&](Reader &r3, Version v) { ciphertext_members(ctx, r3, v, key, &jobs); });
                         img.keys.back().emplace_back(std::move(key));
                     }
                 }
             });
+            // seeded keys: every digit has its own seed, so the expansions (BLAKE2Xb runs at ~0.3 GB/s per host core; a C5 key is
+            // 126 MB of it) are independent and spread over the host cores
+            if (!jobs.empty())
+            {
+                unsigned nthreads = std::thread::hardware_concurrency();
+                if (nthreads > 16)
+                    nthreads = 16;
+                if (nthreads > jobs.size())
+                    nthreads = (unsigned)jobs.size();
+                if (nthreads < 1)
+                    nthreads = 1;
+                std::atomic<size_t> next{ 0 };
+                auto work = [&]() {
+                    for (size_t i = next++; i < jobs.size(); i = next++)
+                        sample_poly_uniform(jobs[i].prng, ctx.coeff_modulus().data(), jobs[i].K, jobs[i].N, jobs[i].dst);
+                };
+                std::vector<std::thread> pool;
+                for (unsigned t = 1; t < nthreads; t++)
+                    pool.emplace_back(work);
+                work();
+                for (auto &t : pool)
+                    t.join();
+            }
             // What the device representation needs regardless of `check_data` (the reference's unsafe_load defers these to
             // the first use, where they surface as invalid_argument / logic_error): key-level, NTT-form, size-2 digits
             const Level *key_level = &ctx.key_level();
@@ -343,7 +406,7 @@ namespace sealhip
         }
 
         size_t save_ciphertext(const uint64_t *parms_id, bool is_ntt_form, uint64_t size, uint64_t n, uint64_t K, double scale,
-                               uint64_t correction_factor, const uint64_t *words, uint8_t *out, size_t capacity)
+                               uint64_t correction_factor, const uint64_t *words, uint8_t *out, size_t capacity, size_t *data_offset)
         {
             // Serialization::Save(save_members, raw_size, out, size, compr_mode) (serialization.cpp:232-340, 541-557)
             if (!out)
@@ -372,7 +435,9 @@ namespace sealhip
             Header hd{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, (uint64_t)(sizeof(Header) + 8 + count * 8) };
             put(&hd, sizeof(hd));
             put(&count, 8);
-            if (count)
+            if (data_offset)
+                *data_offset = (size_t)(p - out);
+            if (count && words)
                 put(words, (size_t)count * 8);
             return total;
         }

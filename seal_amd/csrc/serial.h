@@ -41,7 +41,14 @@ namespace sealhip
             double scale = 1.0;
             uint64_t correction_factor = 1;
             bool was_seeded = false;
-            std::vector<uint64_t> data;
+            // The words [size][K][N] in two pieces so that a stream is never copied on the host: `stored` points INTO the
+            // input buffer (unaligned; valid while the caller keeps that buffer) and covers everything for a full object,
+            // c_0 for a seeded one, whose c_1 is expanded into `expanded`.
+            const uint8_t *stored = nullptr;
+            size_t stored_words = 0;
+            std::vector<uint64_t> expanded;
+            size_t word_count() const { return stored_words + expanded.size(); }
+            void copy_words(uint64_t *dst) const; // gather both pieces into one host array
         };
         struct KSwitchKeysImage
         {
@@ -60,7 +67,9 @@ namespace sealhip
         size_t ciphertext_save_size(uint64_t size, uint64_t poly_modulus_degree, uint64_t coeff_modulus_size);
         size_t save_ciphertext(const uint64_t *parms_id, bool is_ntt_form, uint64_t size, uint64_t poly_modulus_degree,
                                uint64_t coeff_modulus_size, double scale, uint64_t correction_factor, const uint64_t *words,
-                               uint8_t *out, size_t capacity);
+                               uint8_t *out, size_t capacity, size_t *data_offset = nullptr);
+        // (words == nullptr: everything but the coefficient words is written and *data_offset tells the caller where they go,
+        //  so that a device slab can be copied straight into the stream)
 
         // sample_poly_uniform (util/rlwe.cpp) with the Blake2xb PRNG of randomgen.cpp seeded by `seed` (8 words):
         // K*N words, component r uniform in [0, primes[r])
