@@ -185,6 +185,15 @@ SHL_FUNC Evaluator_Synchronize(void *thisptr);
 /* SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (evaluator.cpp:386-392) costs a device->host round trip per
  * operation: off by default for device-resident batches, switch on for drop-in error parity. */
 SHL_FUNC Evaluator_SetTransparentCheck(void *thisptr, bool enabled);
+/* hipGraph capture of a fixed operation sequence (the reference has no counterpart - its operations are host
+ * calls).  Between BeginCapture and EndCapture the Evaluator_* operations issued on this evaluator are recorded instead of
+ * executed; Evaluator_LaunchGraph replays them with ONE launch, stream-ordered on the evaluator's stream, on the same device
+ * buffers: refresh the operand ciphertexts' contents in place (Ciphertext_CopyFromHost/Device, Ciphertext_Load), replay, read the
+ * destinations.  Run the sequence once eagerly before capturing; keep the captured objects alive and un-resized. */
+SHL_FUNC Evaluator_BeginCapture(void *thisptr);
+SHL_FUNC Evaluator_EndCapture(void *thisptr, void **graph);
+SHL_FUNC Evaluator_LaunchGraph(void *thisptr, void *graph);
+SHL_FUNC Graph_Destroy(void *graph);
 SHL_FUNC Evaluator_Negate(void *thisptr, void *encrypted, void *destination);
 SHL_FUNC Evaluator_Add(void *thisptr, void *encrypted1, void *encrypted2, void *destination);
 SHL_FUNC Evaluator_Sub(void *thisptr, void *encrypted1, void *encrypted2, void *destination);

@@ -71,6 +71,7 @@ Evaluator_TransformToNTT1 Evaluator_ModSwitchToNext2 Evaluator_ModSwitchTo2
 KSwitchKeys_Create1 KSwitchKeys_Destroy KSwitchKeys_Size KSwitchKeys_SetKey KSwitchKeys_SetKeyFromDevice
 KSwitchKeys_SetKeyDigits KSwitchKeys_HasKey RelinKeys_GetIndex GaloisKeys_GetIndex GaloisTool_GetEltFromStep
 Evaluator_Create Evaluator_Destroy Evaluator_SetStream Evaluator_Synchronize Evaluator_SetTransparentCheck
+Evaluator_BeginCapture Evaluator_EndCapture Evaluator_LaunchGraph Graph_Destroy
 Evaluator_Negate Evaluator_Add Evaluator_Sub Evaluator_Multiply Evaluator_Square Evaluator_Relinearize
 Evaluator_ModSwitchToNext1 Evaluator_ModSwitchTo1 Evaluator_RescaleToNext Evaluator_RescaleTo
 Evaluator_ModReduceToNext Evaluator_TransformToNTT2 Evaluator_TransformFromNTT Evaluator_ApplyGalois

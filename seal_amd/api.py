@@ -420,6 +420,21 @@ class GaloisKeys(KSwitchKeys):
         return self.has_index(self.get_index(galois_elt))
 
 
+class Graph:
+    """an executable hipGraph recorded by Evaluator.capture(); launch() is stream-ordered on the evaluator's stream"""
+
+    def __init__(self, evaluator, handle):
+        self.evaluator, self._h = evaluator, handle
+
+    def launch(self):
+        N.check(N.lib().Evaluator_LaunchGraph(self.evaluator._h, self._h))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().Graph_Destroy(self._h)
+            self._h = None
+
+
 class Evaluator:
     """seal::Evaluator's hot-path surface (evaluator.h:79-1387), in-place and destination forms."""
 
@@ -441,6 +456,18 @@ class Evaluator:
 
     def synchronize(self):
         N.check(N.lib().Evaluator_Synchronize(self._h))
+
+    # -- hipGraph capture of a fixed operation sequence (sealhip.h: Evaluator_BeginCapture ...)
+    def capture(self, fn):
+        """record the evaluator operations issued by fn() into a graph; returns a Graph whose launch() replays them"""
+        N.check(N.lib().Evaluator_BeginCapture(self._h))
+        try:
+            fn()
+        finally:
+            g = C.c_void_p()
+            hr = N.lib().Evaluator_EndCapture(self._h, C.byref(g))
+        N.check(hr)
+        return Graph(self, g)
 
     def _u(self, fn, a, dest, *extra, pool=False):
         d = a if dest is None else dest

@@ -785,6 +785,35 @@ extern "C"
         as<Evaluator>(thisptr)->set_stream((hipStream_t)hip_stream);
         return SHL_S_OK;
     }
+    SHL_FUNC Evaluator_BeginCapture(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->begin_capture();
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_EndCapture(void *thisptr, void **graph)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(graph, SHL_E_POINTER);
+        SHL_TRY
+        *graph = as<Evaluator>(thisptr)->end_capture();
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_LaunchGraph(void *thisptr, void *graph)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(graph, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->launch_graph(static_cast<hipGraphExec_t>(graph));
+        SHL_CATCH
+    }
+    SHL_FUNC Graph_Destroy(void *graph)
+    {
+        IfNullRet(graph, SHL_E_POINTER);
+        (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph));
+        return SHL_S_OK;
+    }
     SHL_FUNC Evaluator_SetTransparentCheck(void *thisptr, bool enabled)
     {
         IfNullRet(thisptr, SHL_E_POINTER);

@@ -386,7 +386,51 @@ namespace sealhip
             (void)hipFree(kv.second.dev);
         if (d_flag_)
             (void)hipFree(d_flag_);
+        if (capture_stream_)
+            (void)hipStreamDestroy(capture_stream_);
     }
+    void Evaluator::begin_capture()
+    {
+        if (capturing_)
+            throw std::logic_error("a capture is already in progress");
+        if (transparent_check_)
+            throw std::logic_error("the transparent-ciphertext check reads device memory back and cannot be captured");
+        if (!capture_stream_)
+            ck(hipStreamCreateWithFlags(&capture_stream_, hipStreamNonBlocking), "capture stream");
+        ck(hipStreamSynchronize(stream_), "stream synchronize");
+        saved_stream_ = stream_;
+        stream_ = capture_stream_;
+        // relaxed: a pool miss may still hipMalloc while recording (it touches no stream)
+        hipError_t e = hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed);
+        if (e != hipSuccess)
+        {
+            stream_ = saved_stream_;
+            ck(e, "hipStreamBeginCapture");
+        }
+        capturing_ = true;
+    }
+    hipGraphExec_t Evaluator::end_capture()
+    {
+        if (!capturing_)
+            throw std::logic_error("no capture in progress");
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(stream_, &graph);
+        stream_ = saved_stream_;
+        capturing_ = false;
+        ck(e, "hipStreamEndCapture");
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        ck(e, "hipGraphInstantiate");
+        return exec;
+    }
+    void Evaluator::launch_graph(hipGraphExec_t graph) const
+    {
+        if (capturing_)
+            throw std::logic_error("a capture is in progress");
+        ck(hipGraphLaunch(graph, stream_), "hipGraphLaunch");
+    }
+
     void Evaluator::synchronize() const
     {
         ck(hipStreamSynchronize(stream_), "stream synchronize");
@@ -1285,7 +1329,7 @@ namespace sealhip
 
     void Evaluator::switch_key_partial(
         const Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, unsigned j0, unsigned j1,
-        uint64_t *acc_out) const
+        uint64_t *acc_out, unsigned split) const
     {
         check_valid(e, "encrypted");
         if (!target)
@@ -1365,8 +1409,11 @@ namespace sealhip
             ka.j0 = j0;
             ka.j1 = j1;
             ka.key_digit0 = (unsigned)key.digit0;
+            ka.parts = split ? split : 1;
             ck(ks_fused(tb, ka, stream_), "ks fused");
         }
+        else if (split > 1)
+            throw std::invalid_argument("in-launch digit groups need the fused key-switch path");
         else
         {
             // u[b][I][J] = NTT_I(t_J mod q_I), I over the K data primes and the special prime
@@ -1488,8 +1535,31 @@ namespace sealhip
     {
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
-        Scratch acc(switch_key_acc_words(e));
-        switch_key_partial(e, target, keys, key_index, 0, e.level()->K, acc.p);
+        // Small batches do not fill the chip: one workgroup per (target modulus, tile, batch item) is 16 (K+1) workgroups per
+        // ciphertext at N = 2^16, each looping over all K digits, and only 2 x 16 of them for the two 60-bit moduli.  Cut the
+        // digit loop into `split` in-launch groups (their partial sums are added by the reduce pass below): single-ciphertext
+        // latency of multiply+relinearize+rescale at C5 0.63 -> 0.40 ms.  SEALHIP_KS_SPLIT overrides (tests, A/B).
+        const unsigned K = e.level()->K;
+        unsigned split = 1;
+        if (keys.context() == &context_ && key_index < keys.slots() && keys.has_key(key_index) && keys.key(key_index).register_order)
+        {
+            const size_t wgs = e.batch() * (size_t)(K + 1) * (context_.n() >> 12);
+            split = (unsigned)(2048 / (wgs ? wgs : 1)); // measured at C5: best split 8 / 4 / 2 / 1 at batch 1 / 2 / 4 / >= 8
+            if (const char *f = std::getenv("SEALHIP_KS_SPLIT"))
+                split = (unsigned)std::atoi(f);
+            if (split > 8)
+                split = 8; // eight canonical residues below 2^61 still fit a 64-bit word
+            if (split > K)
+                split = K;
+            if (split < 1)
+                split = 1;
+        }
+        Scratch acc(switch_key_acc_words(e) * split);
+        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split);
+        if (split > 1)
+            ck(k_keyswitch_reduce(context_.dev_mods(), acc.p, (unsigned)context_.log_n(), K, context_.key_level().K, (unsigned)e.batch(),
+                                  stream_, split),
+               "ks add digit groups");
         switch_key_finish(e, acc.p, 1);
     }
 

@@ -179,6 +179,17 @@ namespace sealhip
 
         bool is_transparent(const Ciphertext &ct) const; // synchronises
 
+        // hipGraph capture of a fixed operation sequence.  Between begin_capture() and end_capture() the
+        // operations issued on this evaluator are RECORDED (stream capture, side streams included), not executed; the returned
+        // executable graph replays them with one launch on the same device buffers - operands, destinations and scratch keep
+        // the addresses they had during capture, so the caller refreshes the operands' contents in place and reads the
+        // destinations after each replay.  Run the sequence once eagerly first (lazily built tables, pool warm-up), keep the
+        // captured objects alive and do not resize them between replays.  At small batches the step is launch-bound on the
+        // host (about 25 kernel launches + stream fork/join per multiply+relinearize+rescale): see DESIGN.md section 5.
+        void begin_capture();
+        hipGraphExec_t end_capture();
+        void launch_graph(hipGraphExec_t graph) const;
+
         static size_t relin_index(size_t key_power);       // RelinKeys::get_index  (relinkeys.h:58)
         static size_t galois_index(uint32_t galois_elt);   // GaloisKeys::get_index (galoiskeys.h:48)
         uint32_t galois_elt_from_step(int step) const;      // GaloisTool::get_elt_from_step (galois.cpp:53)
@@ -190,8 +201,10 @@ namespace sealhip
         // acc = [batch][2][K+1][N] words (switch_key_acc_words); partial fills it with the canonical partial sums of
         // the digits [j0, j1); finish reduces the sum of `parts` such buffers and applies the mod-down to encrypted.
         size_t switch_key_acc_words(const Ciphertext &encrypted) const;
+        // split > 1 (fused path only): the digit range is cut into `split` in-launch groups and acc holds `split` buffers
+        // (ntt2_kernels.h: KsFusedArgs::parts); the caller adds them with k_keyswitch_reduce(..., local_parts = split)
         void switch_key_partial(const Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index,
-                                unsigned j0, unsigned j1, uint64_t *acc) const;
+                                unsigned j0, unsigned j1, uint64_t *acc, unsigned split = 1) const;
         void switch_key_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts) const;
         // relinearize (size 3 -> 2) and apply_galois (size 2) split the same way: *_partial leaves `encrypted` ready for
         // the finish call (for apply_galois: c0 <- pi(c0), c1 <- 0) and writes this rank's partial sums to acc
@@ -230,6 +243,8 @@ namespace sealhip
 
         const Context &context_;
         hipStream_t stream_ = nullptr;
+        hipStream_t capture_stream_ = nullptr, saved_stream_ = nullptr;
+        bool capturing_ = false;
         bool transparent_check_ = false;
         // lazily built per-level tables; guarded so that concurrent calls on different ciphertexts stay safe, as with the
         // reference's Evaluator (evaluator.h:79-87: the class holds only immutable state)

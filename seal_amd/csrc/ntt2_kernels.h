@@ -36,6 +36,10 @@ namespace sealhip
         // digit-parallel key switching: only the digits [j0, j1) contribute to acc;
         // `key` holds digits [key_digit0, key_digit0 + resident) of the full key
         unsigned j0, j1, key_digit0;
+        // in-launch digit groups (0 or 1 = none): with `parts` > 1 the digits [j0, j1) are cut into `parts` slices handled by
+        // separate workgroups, slice g writing its partial sums to acc + g * batch*2*(K+1)*N (acc holds `parts` such buffers,
+        // added by k_keyswitch_reduce).  Multiplies the number of workgroups when batch * targets * tiles does not fill the chip.
+        unsigned parts;
     };
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);
 

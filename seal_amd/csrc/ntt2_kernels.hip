@@ -257,6 +257,18 @@ namespace sealhip
         //   twa[t][u][g] (t<4, g<2^t) at twa[(16 << t) - 16 + (u << t) + g]
         //   twb[t][g][tid]            at twb[((256 << t) - 256) + g*256 + tid]
         // ---------------------------------------------------------------------------------------
+        // stage the 240 row-shared twiddles of pass 2's phase A (row tile hg) at twa[(16 << t) - 16 + (u << t) + g]
+        template <int D1>
+        __device__ __forceinline__ void stage_twa(double *twa, const double *tab, unsigned hg, unsigned tid)
+        {
+            if (tid < 240)
+            {
+                const unsigned t = 31 - __builtin_clz(tid / 16 + 1);
+                const unsigned r = tid - ((16u << t) - 16u);
+                twa[tid] = tab[(1u << (D1 + t)) + ((hg * 16) << t) + r];
+            }
+        }
+
         // twiddles of the two phases of pass 2 for tile hg: they depend on (prime, hg, thread) only, so a
         // workgroup that transforms the same tile of many polynomials can load them once
         template <bool FP, int D1>
@@ -516,7 +528,9 @@ namespace sealhip
         // registers for every outer item of the workgroup's loop - a tile's twiddles are as many bytes as its
         // coefficients.  Costs ~60 VGPRs: measured +4 % on the batched NTT, -3 % on the epilogue variants, hence
         // only here.
-        template <bool FP, int D1, bool HOIST = false>
+        // HOIST_LDS (CLS 4): the row-shared phase-A twiddles are staged once in LDS and only the 15 per-thread phase-B twiddles
+        // stay in registers: the same "no twiddle is re-read per transform" at 128 VGPRs (four waves per SIMD) instead of 214 (two)
+        template <bool FP, int D1, bool HOIST = false, bool HOIST_LDS = false>
         __device__ __forceinline__ void fwd_p2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -535,7 +549,18 @@ namespace sealhip
             };
             const unsigned ostride = gridDim.z;
             TwRegs<FP> pre_a, pre_b;
-            if constexpr (HOIST)
+            const typename F::tw_t *twa = nullptr;
+            if constexpr (HOIST_LDS)
+            {
+                static_assert(FP, "double-precision back end only");
+                double *la = reinterpret_cast<double *>(lds + kLds2Words);
+                stage_twa<D1>(la, tab, hg, tid);
+                twa = la;
+                const unsigned h = hg * 16 + (tid >> 4), v = tid & 15;
+                load_tw<FP, 4>(pre_b, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
+                __syncthreads();
+            }
+            else if constexpr (HOIST)
                 p2_load_tw<FP, D1>(pre_a, pre_b, tab, hg, tid);
             fetch(outer);
             for (; outer < a.nouter; outer += ostride)
@@ -546,13 +571,15 @@ namespace sealhip
                 x[e] = F::unraw(nxt[e]);
             if (outer + ostride < a.nouter)
                 fetch(outer + ostride);
-            if constexpr (HOIST)
+            if constexpr (HOIST_LDS)
+                p2_tile<FP, D1, false, false, true, true>(x, m, tab, twa, nullptr, lds_wave, hg, tid, &pre_a, &pre_b);
+            else if constexpr (HOIST)
                 p2_tile<FP, D1, false, false, true>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid, &pre_a, &pre_b);
             else
                 p2_tile<FP, D1, false>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
             uint64_t val[16];
             const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
-            if (a.epi == 0)
+            if ((HOIST || HOIST_LDS) || a.epi == 0) // the hoisted variants are launched for plain transforms only
             {
 #pragma unroll
                 for (int e = 0; e < 16; e++)
@@ -585,12 +612,14 @@ namespace sealhip
         }
 
         template <int D1, int CLS>
-        __global__ void __launch_bounds__(kThreads, CLS == 1 ? SEALHIP_FP_WAVES_P2 : 2) ntt2_fwd_p2(FwdArgs a)
+        __global__ void __launch_bounds__(kThreads, (CLS == 1 || CLS == 4) ? SEALHIP_FP_WAVES_P2 : 2) ntt2_fwd_p2(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
-            if constexpr (CLS == 3) // double-precision back end, plain transform, twiddles hoisted
+            if constexpr (CLS == 4) // as 3 with the row-shared half of the twiddles in LDS: four waves per SIMD
+                fwd_p2_body<true, D1, false, true>(a, prime, comp, outer, lds);
+            else if constexpr (CLS == 3) // double-precision back end, plain transform, twiddles hoisted
                 fwd_p2_body<true, D1, true>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 1)
                 fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
@@ -873,18 +902,6 @@ namespace sealhip
             static constexpr size_t lds_bytes = (main_words + (size_t)TEAMS * 240) * 8;
         };
 
-        // stage the 240 row-shared twiddles of pass 2's phase A (row tile hg) at twa[(16 << t) - 16 + (u << t) + g]
-        template <int D1>
-        __device__ __forceinline__ void stage_twa(double *twa, const double *tab, unsigned hg, unsigned tid)
-        {
-            if (tid < 240)
-            {
-                const unsigned t = 31 - __builtin_clz(tid / 16 + 1);
-                const unsigned r = tid - ((16u << t) - 16u);
-                twa[tid] = tab[(1u << (D1 + t)) + ((hg * 16) << t) + r];
-            }
-        }
-
         template <int D1>
         __device__ __forceinline__ void fwd_fused2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
@@ -1128,12 +1145,13 @@ namespace sealhip
             unsigned K;
             unsigned batch;
             unsigned j0, j1;     // digits handled by this call (digit-parallel key switching)
+            unsigned parts;      // in-launch digit groups: workgroup group g handles the g-th slice of [j0, j1) (small batches)
             int skip_diag;       // CKKS: (I == J) is the input itself, not transformed
             NttTables tb;
         };
 
         template <bool FP, int D1>
-        __device__ __forceinline__ void ks1_body(const Ks1Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned b, unsigned cg)
+        __device__ __forceinline__ void ks1_body(const Ks1Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned b, unsigned cg, unsigned j0, unsigned j1)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
@@ -1157,10 +1175,10 @@ namespace sealhip
                 }
             };
             const unsigned Jskip = a.skip_diag ? I : ~0u;
-            unsigned J = Jskip == a.j0 ? a.j0 + 1 : a.j0;
-            if (J < a.j1)
+            unsigned J = Jskip == j0 ? j0 + 1 : j0;
+            if (J < j1)
                 fetch(J);
-            while (J < a.j1)
+            while (J < j1)
             {
                 const uint64_t src_q = a.tb.mods[J].q; // digit J is a residue modulo data prime J
                 typename F::elem x[16];
@@ -1202,7 +1220,7 @@ namespace sealhip
                 unsigned Jn = J + 1;
                 if (Jn == Jskip)
                     Jn++;
-                if (Jn < a.j1)
+                if (Jn < j1)
                     fetch(Jn);
                 uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
                 p1_tile<FP, D1>(x, m, tab, tw, lds, mid_tr, cg, tid);
@@ -1223,11 +1241,14 @@ namespace sealhip
             const unsigned bid = blockIdx.x;
             const unsigned low = bid & 7, rest = bid >> 3;
             const unsigned it = rest % a.ntargets, grp = (rest / a.ntargets) * 8 + low; // grp = b*TILES + cg
-            if (grp >= a.batch * G::TILES)
+            if (grp >= a.batch * a.parts * G::TILES)
                 return;
-            const unsigned b = grp / G::TILES, cg = grp % G::TILES;
+            const unsigned vb = grp / G::TILES, cg = grp % G::TILES; // virtual batch item = (digit group, batch item)
+            const unsigned b = vb % a.batch, dg = vb / a.batch;
+            const unsigned jlen = (a.j1 - a.j0 + a.parts - 1) / a.parts;
+            const unsigned j0 = a.j0 + dg * jlen, j1 = j0 + jlen < a.j1 ? j0 + jlen : a.j1;
             const unsigned I = SHL_UNIFORM(a.targets[2 * it]), prime = SHL_UNIFORM(a.targets[2 * it + 1]);
-            ks1_body<FP, D1>(a, lds, I, prime, b, cg);
+            ks1_body<FP, D1>(a, lds, I, prime, b, cg, j0, j1);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1249,11 +1270,13 @@ namespace sealhip
             unsigned K, L;
             unsigned batch;
             unsigned j0, j1, key_digit0; // digits handled by this call; first digit resident in `key`
+            unsigned parts;              // in-launch digit groups (as Ks1Args); group g writes acc + g * batch*2*(K+1)*N
             NttTables tb;
         };
 
         template <bool FP, int D1>
-        __device__ __forceinline__ void ks2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg)
+        __device__ __forceinline__ void ks2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg,
+                                                 unsigned j0, unsigned j1, uint64_t *acc_part)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
@@ -1334,10 +1357,10 @@ namespace sealhip
             constexpr bool PF = FP;
             if constexpr (PF)
             {
-                if (a.j0 < a.j1)
-                    fetch(a.j0);
+                if (j0 < j1)
+                    fetch(j0);
             }
-            for (unsigned J = a.j0; J < a.j1; J++)
+            for (unsigned J = j0; J < j1; J++)
             {
                 typename F::elem x[16];
                 const bool is_diag = diag && J == I;
@@ -1367,7 +1390,7 @@ namespace sealhip
                         kr0[e] = k0[e * 256];
                         kr1[e] = k1[e * 256];
                     }
-                    if (J + 1 < a.j1)
+                    if (J + 1 < j1)
                         fetch(J + 1);
                 }
                 if (!is_diag)
@@ -1398,7 +1421,7 @@ namespace sealhip
                         F::mac(acc1[e], x[e], k1[e * 256], m);
                     }
                 }
-                if (((J - a.j0) & 7) == 7)
+                if (((J - j0) & 7) == 7)
                 {
 #pragma unroll
                     for (int e = 0; e < 16; e++)
@@ -1409,7 +1432,7 @@ namespace sealhip
                 }
             }
             uint64_t val[16];
-            uint64_t *out = a.acc + ((((size_t)b * 2 + 0) * (a.K + 1) + I) << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+            uint64_t *out = acc_part + ((((size_t)b * 2 + 0) * (a.K + 1) + I) << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
 #pragma unroll
             for (int e = 0; e < 16; e++)
                 val[e] = F::acc_to_canon(acc0[e], m);
@@ -1431,16 +1454,21 @@ namespace sealhip
             const unsigned ntile = a.ntargets * G::TILES;
             const unsigned bid = blockIdx.x;
             const unsigned xcd = bid & 7, rest = bid >> 3;
-            const unsigned b = rest % a.batch, tile_hi = rest / a.batch;
+            const unsigned vbatch = a.batch * a.parts;
+            const unsigned vb = rest % vbatch, tile_hi = rest / vbatch;
+            const unsigned b = vb % a.batch, dg = vb / a.batch; // virtual batch item = (digit group, batch item)
+            const unsigned jlen = (a.j1 - a.j0 + a.parts - 1) / a.parts;
+            const unsigned j0 = a.j0 + dg * jlen, j1 = j0 + jlen < a.j1 ? j0 + jlen : a.j1;
+            uint64_t *acc_part = a.acc + (((size_t)dg * a.batch * 2 * (a.K + 1)) << G::n);
             const unsigned tile = tile_hi * 8 + xcd;
             if (tile >= ntile)
                 return;
             const unsigned it = tile / G::TILES, hg = tile % G::TILES;
             const unsigned I = SHL_UNIFORM(a.targets[3 * it]), prime = SHL_UNIFORM(a.targets[3 * it + 1]), kc = SHL_UNIFORM(a.targets[3 * it + 2]);
             if constexpr (CLS == 1)
-                ks2_body<true, D1>(a, lds, I, prime, kc, b, hg);
+                ks2_body<true, D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
             else
-                ks2_body<false, D1>(a, lds, I, prime, kc, b, hg);
+                ks2_body<false, D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
         }
 
         // natural order (u64) -> register order, optionally converted to double
@@ -1619,7 +1647,10 @@ namespace sealhip
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess)
                     return e;
-                if (r.cls == 1 && a.epi == 0 && chunks < nouter)
+                static const int p2_hoist = std::getenv("SEALHIP_P2_HOIST") ? std::atoi(std::getenv("SEALHIP_P2_HOIST")) : 4;
+                if (r.cls == 1 && a.epi == 0 && chunks < nouter && p2_hoist == 4)
+                    hipLaunchKernelGGL((ntt2_fwd_p2<D1, 4>), grid, dim3(kThreads), (kLds2Words + 240) * 8, st, g);
+                else if (r.cls == 1 && a.epi == 0 && chunks < nouter && p2_hoist == 3)
                     hipLaunchKernelGGL((ntt2_fwd_p2<D1, 3>), grid, dim3(kThreads), kLds2Words * 8, st, g);
                 else if (r.cls == 1)
                     hipLaunchKernelGGL((ntt2_fwd_p2<D1, 1>), grid, dim3(kThreads), kLds2Words * 8, st, g);
@@ -1698,7 +1729,8 @@ namespace sealhip
             if (a1.ntargets == 0)
                 return hipSuccess;
             const size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
-            const unsigned groups = batch * G::TILES;
+            const unsigned vbatch = batch * a1.parts; // (digit group, batch item) pairs
+            const unsigned groups = vbatch * G::TILES;
             const unsigned n_fp = a1.ntargets - n_int;
             const size_t l2_fp = kLds2Words * 8 + (240 + 3840) * sizeof(double); // the tile's twiddles staged in LDS
             if (n_fp && l2_fp > 65536)
@@ -1733,9 +1765,9 @@ namespace sealhip
                 c2.ntargets = nt;
                 const unsigned ntile = nt * G::TILES;
                 if (fp)
-                    hipLaunchKernelGGL((ks2_kernel<D1, 1>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), l2_fp, st, c2);
+                    hipLaunchKernelGGL((ks2_kernel<D1, 1>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), l2_fp, st, c2);
                 else
-                    hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * batch * 8), dim3(kThreads), kLds2Words * 8 + 240 * sizeof(ShoupOp), st, c2);
+                    hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), kLds2Words * 8 + 240 * sizeof(ShoupOp), st, c2);
                 return hipGetLastError();
             };
             // The integer-back-end targets (60-bit moduli) are latency-bound at two waves per SIMD, the
@@ -1869,6 +1901,7 @@ namespace sealhip
         a1.skip_diag = k.target_ntt != nullptr;
         a1.j0 = k.j0;
         a1.j1 = k.j1;
+        a1.parts = k.parts ? k.parts : 1;
         a1.tb = t;
         Ks2Args a2;
         a2.mid = k.mid;
@@ -1883,6 +1916,7 @@ namespace sealhip
         a2.j0 = k.j0;
         a2.j1 = k.j1;
         a2.key_digit0 = k.key_digit0;
+        a2.parts = a1.parts;
         a2.tb = t;
         switch (t.log_n)
         {

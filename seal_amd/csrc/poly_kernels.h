@@ -100,7 +100,7 @@ namespace sealhip
         const ModDesc *mods, const uint64_t *u, const uint64_t *key, uint64_t *acc, unsigned n_log, unsigned K,
         unsigned L, unsigned batch, unsigned j0, unsigned j1, unsigned key_digit0, hipStream_t s);
     // acc <- acc mod q_I in place after partial sums of several ranks were added (each canonical, at most 8 of them)
-    hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s);
+    hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts = 1);
     // Key-switch tail (CKKS): ct_k[b][i] += (acc[b][k][i] - t[b][k][i]) * P^-1 mod q_i.
     // ct planes: ct0 and ct1, each [batch][K][N]; acc [batch][2][K+1][N]; t [batch][2][K][N] lazy.
     hipError_t k_keyswitch_tail_ckks(

@@ -402,13 +402,18 @@ namespace sealhip
         }
 
         // acc[item][I][j] <- acc mod q_I: the sum of `parts` canonical partial sums (digit-parallel key switching)
+        // `local_parts` > 1: the summands are still separate buffers of `words` words each (in-launch digit groups of the
+        // fused key switch at small batches); they are added here
         __global__ void __launch_bounds__(kBlock) keyswitch_reduce_kernel(
-            const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, size_t words)
+            const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, size_t words, unsigned local_parts)
         {
             for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
             {
                 const unsigned I = (unsigned)((i >> n_log) % (K + 1));
-                acc[i] = barrett64(acc[i], mods[I == K ? L - 1 : I]);
+                uint64_t v = acc[i];
+                for (unsigned g = 1; g < local_parts; g++)
+                    v += acc[i + g * words];
+                acc[i] = barrett64(v, mods[I == K ? L - 1 : I]);
             }
         }
 
@@ -632,12 +637,12 @@ namespace sealhip
         hipLaunchKernelGGL(keyswitch_mac_kernel, grid, dim3(kBlock), 0, s, mods, u, key, acc, n_log, K, L, batch, j0, j1, key_digit0);
         return hipGetLastError();
     }
-    hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s)
+    hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts)
     {
         size_t w = ((size_t)batch * 2 * (K + 1)) << n_log;
         if (!w)
             return hipSuccess;
-        hipLaunchKernelGGL(keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w);
+        hipLaunchKernelGGL(keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w, local_parts);
         return hipGetLastError();
     }
     hipError_t k_keyswitch_tail_ckks(

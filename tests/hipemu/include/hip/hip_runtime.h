@@ -243,6 +243,40 @@ static inline hipError_t hipEventSynchronize(hipEvent_t)
 {
     return hipSuccess;
 }
+// stream capture / graphs: the emulator executes eagerly, so "capturing" runs the work once and a graph cannot be replayed
+typedef struct hipGraph_emu *hipGraph_t;
+typedef struct hipGraphExec_emu *hipGraphExec_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode)
+{
+    return hipSuccess;
+}
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g)
+{
+    *g = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t, void *, void *, size_t)
+{
+    *e = nullptr;
+    return hipSuccess;
+}
+static inline hipError_t hipGraphDestroy(hipGraph_t)
+{
+    return hipSuccess;
+}
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t)
+{
+    return hipSuccess;
+}
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t)
+{
+    return hipErrorInvalidValue; // nothing was recorded
+}
+static inline hipError_t hipStreamDestroy(hipStream_t)
+{
+    return hipSuccess;
+}
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t)
 {
     *ms = 0.f;

@@ -378,3 +378,59 @@ def test_concurrent_calls_on_different_ciphertexts(gpu):
     for i in range(len(inputs)):
         for r in range(6):
             assert np.array_equal(got[i][r], want[i]), "thread %d repetition %d differs from the sequential result" % (i, r)
+
+
+# hipGraph capture: a recorded multiply + relinearize + rescale (+ rotate) replays bit-exactly on refreshed operands
+@pytest.mark.parametrize("n,bits,batch", [(8192, [60, 40, 40, 60], 2), (65536, [60] + [50] * 14 + [60], 1)])
+def test_graph_capture_replay(gpu, n, bits, batch):
+    import numpy as np
+    import seal_amd as S
+    from harness import DeviceSide
+    from oracle import Oracle, coeff_modulus_create, rand_ct
+    primes = coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    probe = Oracle("ckks", n, primes)
+    elt = probe.galois_elt_from_step(1)
+    o = Oracle("ckks", n, primes, galois_elts=[elt])
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(21)
+    scale = 2.0 ** 20
+
+    def expected(x, y):
+        r = o.rescale(o.relinearize(o.multiply(x, y)))
+        return o.apply_galois(r, elt)
+
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    cx, cy = d.ct(xs, scale=scale), d.ct(ys, scale=scale)
+    work = S.Ciphertext(d.ctx, batch=batch)
+
+    def step():
+        d.ev.multiply(cx, cy, work)
+        d.ev.relinearize_inplace(work, d.rlk)
+        work.set_scale(float(primes[K - 1]) * scale)
+        d.ev.rescale_to_next_inplace(work)
+        d.ev.rotate_vector_inplace(work, 1, d.glk)
+
+    step()  # eager once
+    eager = d.out(work)
+    for b in range(batch):
+        assert np.array_equal(eager[b], expected(xs[b], ys[b]))
+    graph = d.ev.capture(step)
+    for trial in range(3):
+        if trial:
+            xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+            ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+            cx.load(np.stack(xs, axis=1))
+            cy.load(np.stack(ys, axis=1))
+        graph.launch()
+        got = d.out(work)
+        assert work.size() == 2 and work.coeff_modulus_size() == K - 1
+        for b in range(batch):
+            assert np.array_equal(got[b], expected(xs[b], ys[b])), "graph replay %d item %d" % (trial, b)
+    # capturing with the read-back check on is refused, and nesting too
+    d.ev.set_transparent_check(True)
+    with pytest.raises(S.LogicError):
+        d.ev.capture(step)
+    d.ev.set_transparent_check(False)
