@@ -157,6 +157,12 @@ SHL_FUNC Plaintext_SetParmsId(void *thisptr, uint64_t *parms_id);
 SHL_FUNC Plaintext_Scale(void *thisptr, double *scale);
 SHL_FUNC Plaintext_SetScale(void *thisptr, double scale);
 SHL_FUNC Plaintext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count); /* synchronises */
+/* wire format (native/src/seal/c/plaintext.h:83-89; Plaintext::save / load / unsafe_load, native/src/seal/plaintext.cpp): e.g. the
+ * output of CKKSEncoder::encode / BatchEncoder::encode serialized by the client, as Ciphertext_Load above */
+SHL_FUNC Plaintext_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+SHL_FUNC Plaintext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+SHL_FUNC Plaintext_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+SHL_FUNC Plaintext_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 
 SHL_FUNC KSwitchKeys_Create1(void **kswitch_keys);
 SHL_FUNC KSwitchKeys_Destroy(void *thisptr);

@@ -794,6 +794,52 @@ extern "C"
         }
         REF_CATCH
     }
+    // Plaintext::save / load / unsafe_load
+    int ref_pt_save(void *pt, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        *bytes = static_cast<uint64_t>(static_cast<RefPt *>(pt)->pt.save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        REF_CATCH
+    }
+    int ref_pt_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, void **out, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto h = std::make_unique<RefPt>();
+        if (unsafe)
+            *bytes = static_cast<uint64_t>(h->pt.unsafe_load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
+        else
+            *bytes = static_cast<uint64_t>(h->pt.load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
+        *out = h.release();
+        REF_CATCH
+    }
+    // CKKSEncoder::encode(values, parms_id(chain_index), scale) / BatchEncoder::encode(values): the plaintexts a client serializes
+    int ref_ckks_encode(void *ctx, const double *values, uint64_t count, uint64_t chain_index, double scale, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 3;
+        CKKSEncoder enc(*c->context);
+        auto h = std::make_unique<RefPt>();
+        std::vector<double> v(values, values + count);
+        enc.encode(v, l->parms_id(), scale, h->pt);
+        *out = h.release();
+        REF_CATCH
+    }
+    int ref_batch_encode(void *ctx, const uint64_t *values, uint64_t count, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        BatchEncoder enc(*c->context);
+        auto h = std::make_unique<RefPt>();
+        std::vector<uint64_t> v(values, values + count);
+        v.resize(enc.slot_count());
+        enc.encode(v, h->pt);
+        *out = h.release();
+        REF_CATCH
+    }
     // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)
     int ref_keys_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, uint64_t *bytes)
     {

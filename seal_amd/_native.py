@@ -66,6 +66,7 @@ Ciphertext_SaveSize Ciphertext_Save Ciphertext_UnsafeLoad Ciphertext_Load Cipher
 KSwitchKeys_UnsafeLoad KSwitchKeys_Load
 Plaintext_Create1 Plaintext_Create5 Plaintext_Destroy Plaintext_Set4 Plaintext_SetFromDevice Plaintext_CoeffCount
 Plaintext_IsNTTForm Plaintext_GetParmsId Plaintext_SetParmsId Plaintext_Scale Plaintext_SetScale Plaintext_CopyToHost
+Plaintext_SaveSize Plaintext_Save Plaintext_UnsafeLoad Plaintext_Load
 Evaluator_AddMany Evaluator_AddPlain Evaluator_SubPlain Evaluator_MultiplyMany Evaluator_MultiplyPlain Evaluator_Exponentiate
 Evaluator_TransformToNTT1 Evaluator_ModSwitchToNext2 Evaluator_ModSwitchTo2
 KSwitchKeys_Create1 KSwitchKeys_Destroy KSwitchKeys_Size KSwitchKeys_SetKey KSwitchKeys_SetKeyFromDevice

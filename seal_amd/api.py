@@ -350,6 +350,23 @@ class Plaintext:
         N.check(N.lib().Plaintext_CopyToHost(self._h, _p(out), C.c_uint64(out.size)))
         return out
 
+    # -- the reference's wire format (Plaintext::save / load / unsafe_load)
+    def load_bytes(self, data, unsafe=False):
+        data = bytes(data)
+        buf = C.cast(C.c_char_p(data), C.c_void_p)
+        n = C.c_int64()
+        fn = N.lib().Plaintext_UnsafeLoad if unsafe else N.lib().Plaintext_Load
+        N.check(fn(self._h, self.context._h, buf, C.c_uint64(len(data)), C.byref(n)))
+        return n.value
+
+    def save_bytes(self, compr_mode=0):
+        cap = C.c_int64()
+        N.check(N.lib().Plaintext_SaveSize(self._h, C.c_uint8(compr_mode), C.byref(cap)))
+        buf = (C.c_uint8 * cap.value)()
+        n = C.c_int64()
+        N.check(N.lib().Plaintext_Save(self._h, buf, C.c_uint64(cap.value), C.c_uint8(compr_mode), C.byref(n)))
+        return C.string_at(buf, n.value)
+
 
 class KSwitchKeys:
     """Device-resident key-switching keys; slab per index: [digits][2][L][N] (kswitchkeys.h:340)."""

@@ -675,6 +675,64 @@ extern "C"
         }
         return Ciphertext_SaveItem(thisptr, 0, outptr, size, compr_mode, out_bytes);
     }
+    namespace
+    {
+        SHL_HRESULT pt_load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes, bool check)
+        {
+            IfNullRet(thisptr, SHL_E_POINTER);
+            IfNullRet(context, SHL_E_POINTER);
+            IfNullRet(inptr, SHL_E_POINTER);
+            IfNullRet(in_bytes, SHL_E_POINTER);
+            SHL_TRY
+            auto pt = as<Plaintext>(thisptr);
+            auto c = as<Context>(context);
+            if (&pt->context() != c)
+                throw std::invalid_argument("plaintext belongs to another context");
+            serial::PlaintextImage img;
+            *in_bytes = (int64_t)serial::load_plaintext(*c, inptr, (size_t)size, check, img);
+            hip_ok(hipDeviceSynchronize(), "sync");
+            pt->set(reinterpret_cast<const uint64_t *>(img.stored), (size_t)img.coeff_count, false); // H2D straight from the stream
+            pt->set_level(img.level);
+            pt->scale() = img.scale;
+            SHL_CATCH
+        }
+    } // namespace
+    SHL_FUNC Plaintext_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return pt_load(thisptr, context, inptr, size, in_bytes, true);
+    }
+    SHL_FUNC Plaintext_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return pt_load(thisptr, context, inptr, size, in_bytes, false);
+    }
+    SHL_FUNC Plaintext_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(result, SHL_E_POINTER);
+        SHL_TRY
+        if (compr_mode != 0)
+            throw std::invalid_argument("unsupported compression mode");
+        *result = (int64_t)serial::plaintext_save_size(as<Plaintext>(thisptr)->coeff_count());
+        SHL_CATCH
+    }
+    SHL_FUNC Plaintext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(outptr, SHL_E_POINTER);
+        IfNullRet(out_bytes, SHL_E_POINTER);
+        SHL_TRY
+        if (compr_mode != 0)
+            throw std::invalid_argument("unsupported compression mode");
+        auto pt = as<Plaintext>(thisptr);
+        static const uint64_t zero_id[4] = { 0, 0, 0, 0 };
+        size_t data_offset = 0;
+        *out_bytes = (int64_t)serial::save_plaintext(pt->level() ? pt->level()->parms_id : zero_id, pt->coeff_count(), pt->scale(), nullptr,
+                                                     outptr, (size_t)size, &data_offset);
+        hip_ok(hipDeviceSynchronize(), "sync");
+        if (pt->coeff_count())
+            hip_ok(hipMemcpy(outptr + data_offset, pt->data(), pt->coeff_count() * 8, hipMemcpyDeviceToHost), "D2H");
+        SHL_CATCH
+    }
     SHL_FUNC KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
     {
         return ks_load(thisptr, context, inptr, size, in_bytes, true);

@@ -397,6 +397,112 @@ namespace sealhip
             return bytes;
         }
 
+        size_t load_plaintext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, PlaintextImage &out)
+        {
+            check_input(in, size);
+            Reader r{ in, size };
+            PlaintextImage img;
+            // is_metadata_valid_for(const Plaintext &, context, allow_pure_key_levels) (valcheck.cpp:80-133)
+            auto metadata_ok = [&](bool allow_pure_key_levels) {
+                if (img.level)
+                {
+                    if (!allow_pure_key_levels && img.level->chain_index > ctx.first_level().chain_index)
+                        return false;
+                    if ((uint64_t)img.level->K * ctx.n() != img.coeff_count)
+                        return false;
+                }
+                else if (img.coeff_count > ctx.n())
+                    return false;
+                if (ctx.scheme() == Scheme::ckks && !(std::isnormal(img.scale) && img.scale > 0))
+                    return false;
+                return true;
+            };
+            const size_t bytes = framed(r, [&](Reader &rr, Version) {
+                // Plaintext::load_members (plaintext.cpp)
+                uint64_t parms_id[4];
+                rr.read(parms_id, sizeof(parms_id));
+                img.coeff_count = rr.get<uint64_t>();
+                img.scale = rr.get<double>();
+                const bool ntt_form = parms_id[0] || parms_id[1] || parms_id[2] || parms_id[3];
+                img.level = ntt_form ? ctx.level_by_parms_id(parms_id) : nullptr;
+                if ((ntt_form && !img.level) || !metadata_ok(true))
+                    throw std::logic_error("plaintext data is invalid");
+                uint64_t count = 0;
+                framed(rr, [&](Reader &r3, Version) {
+                    count = r3.get<uint64_t>();
+                    if (count > img.coeff_count)
+                        throw std::logic_error("unexpected size");
+                    img.stored = r3.base + r3.pos;
+                    r3.skip((size_t)count * sizeof(uint64_t));
+                });
+                if (count != img.coeff_count) // is_buffer_valid
+                    throw std::logic_error("plaintext data is invalid");
+            });
+            if (check_data)
+            {
+                // Plaintext::load = unsafe_load + is_valid_for (is_data_valid_for, valcheck.cpp:348-396)
+                bool ok = metadata_ok(false);
+                const unaligned_u64 *p = reinterpret_cast<const unaligned_u64 *>(img.stored);
+                if (ok && img.level)
+                {
+                    for (unsigned j = 0; j < img.level->K && ok; j++)
+                    {
+                        const uint64_t q = ctx.coeff_modulus()[j];
+                        uint64_t over = 0;
+                        for (size_t k = 0; k < ctx.n(); k++)
+                            over |= (uint64_t)(p[k] >= q);
+                        ok = !over;
+                        p += ctx.n();
+                    }
+                }
+                else if (ok)
+                {
+                    const uint64_t t = ctx.plain_modulus();
+                    for (uint64_t k = 0; k < img.coeff_count && ok; k++)
+                        ok = p[k] < t;
+                }
+                if (!ok)
+                    throw std::logic_error("plaintext data is invalid");
+            }
+            out = img;
+            return bytes;
+        }
+
+        size_t plaintext_save_size(uint64_t coeff_count)
+        {
+            return sizeof(Header) + 32 + 8 + 8 + sizeof(Header) + 8 + (size_t)coeff_count * 8;
+        }
+
+        size_t save_plaintext(const uint64_t *parms_id, uint64_t coeff_count, double scale, const uint64_t *words, uint8_t *out,
+                              size_t capacity, size_t *data_offset)
+        {
+            if (!out)
+                throw std::invalid_argument("out cannot be null");
+            if (capacity < sizeof(Header))
+                throw std::invalid_argument("insufficient size");
+            const size_t total = plaintext_save_size(coeff_count);
+            if (capacity < total)
+                throw std::runtime_error("I/O error");
+            uint8_t *p = out;
+            auto put = [&](const void *src, size_t bytes) {
+                std::memcpy(p, src, bytes);
+                p += bytes;
+            };
+            Header h{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, (uint64_t)total };
+            put(&h, sizeof(h));
+            put(parms_id, 32);
+            put(&coeff_count, 8);
+            put(&scale, 8);
+            Header hd{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, (uint64_t)(sizeof(Header) + 8 + coeff_count * 8) };
+            put(&hd, sizeof(hd));
+            put(&coeff_count, 8);
+            if (data_offset)
+                *data_offset = (size_t)(p - out);
+            if (coeff_count && words)
+                put(words, (size_t)coeff_count * 8);
+            return total;
+        }
+
         size_t ciphertext_save_size(uint64_t size, uint64_t n, uint64_t K)
         {
             // Ciphertext::save_size(compr_mode_type::none) (ciphertext.cpp:153-186): members + the DynArray's own frame

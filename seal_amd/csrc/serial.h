@@ -71,6 +71,22 @@ namespace sealhip
         // (words == nullptr: everything but the coefficient words is written and *data_offset tells the caller where they go,
         //  so that a device slab can be copied straight into the stream)
 
+        // seal::Plaintext (plaintext.cpp:save_members / load_members): SEALHeader, parms_id (zero = coefficient form), coeff_count (u64),
+        // scale (f64), DynArray.  level == nullptr: coefficient form.  `stored` points into the input buffer (unaligned).
+        struct PlaintextImage
+        {
+            const Level *level = nullptr;
+            uint64_t coeff_count = 0;
+            double scale = 1.0;
+            const uint8_t *stored = nullptr;
+        };
+        // Plaintext::unsafe_load (check_data = false) / Plaintext::load (true: data level, every coefficient below its modulus)
+        size_t load_plaintext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, PlaintextImage &out);
+        size_t plaintext_save_size(uint64_t coeff_count);
+        // as save_ciphertext: words == nullptr leaves the coefficient words to the caller (*data_offset)
+        size_t save_plaintext(const uint64_t *parms_id, uint64_t coeff_count, double scale, const uint64_t *words, uint8_t *out,
+                              size_t capacity, size_t *data_offset = nullptr);
+
         // sample_poly_uniform (util/rlwe.cpp) with the Blake2xb PRNG of randomgen.cpp seeded by `seed` (8 words):
         // K*N words, component r uniform in [0, primes[r])
         void expand_seed_blake2xb(const uint64_t *seed, const uint64_t *primes, size_t K, size_t N, uint64_t *destination);

@@ -237,6 +237,31 @@ class RefContext:
         _ck(lib().ref_keys_save(self.h, C.c_int(k), C.c_int(1 if seeded else 0), a, C.c_uint64(len(elts)), buf, C.c_uint64(cap), C.byref(n)))
         return bytes(buf[:n.value])
 
+    def pt_save(self, pt):
+        cap = 4096 + 8 * pt.info()["coeff_count"]
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_pt_save(pt.h, buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def pt_load(self, data, unsafe=False):
+        buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
+        h, n = C.c_void_p(), C.c_uint64()
+        _ck(lib().ref_pt_load(self.h, buf, C.c_uint64(len(data)), C.c_int(1 if unsafe else 0), C.byref(h), C.byref(n)))
+        return RefPlaintext(self, h), n.value
+
+    def ckks_encode(self, values, chain_index, scale):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        h = C.c_void_p()
+        _ck(lib().ref_ckks_encode(self.h, _p(v), C.c_uint64(v.size), C.c_uint64(chain_index), C.c_double(scale), C.byref(h)))
+        return RefPlaintext(self, h)
+
+    def batch_encode(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        h = C.c_void_p()
+        _ck(lib().ref_batch_encode(self.h, _p(v), C.c_uint64(v.size), C.byref(h)))
+        return RefPlaintext(self, h)
+
     def keys_load(self, data, unsafe=False):
         buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
         n = C.c_uint64()

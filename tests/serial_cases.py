@@ -160,6 +160,58 @@ def case_key_streams(scheme, n, bits, seeded, steps=(1,)):
         assert np.array_equal(cx.to_numpy()[:, 0], rx.data()), "apply_galois(%d) with keys loaded from the stream" % e
 
 
+def case_plaintext_streams(scheme, n, bits):
+    """encoded plaintexts as a client serializes them (CKKSEncoder / BatchEncoder output): load == the reference's load,
+    save == its bytes, multiply_plain with the loaded plaintext == the reference's, malformed streams fail alike"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    K = len(primes) - 1
+    rng = np.random.default_rng(9)
+    if scheme == "ckks":
+        rpt = ref.ckks_encode(rng.standard_normal(n // 2), ref.first_chain_index, 2.0 ** 30)
+    else:
+        rpt = ref.batch_encode(rng.integers(0, t, n, dtype=np.uint64))
+    stream = ref.pt_save(rpt)
+    back, nbytes = ref.pt_load(stream)
+    pt = S.Plaintext(d.ctx)
+    assert pt.load_bytes(stream) == nbytes == len(stream)
+    bi = back.info()
+    assert (pt.coeff_count(), pt.is_ntt_form(), pt.scale()) == (bi["coeff_count"], bi["is_ntt_form"], bi["scale"])
+    if bi["is_ntt_form"]:
+        assert pt.parms_id() == ref.parms_id(bi["chain_index"])
+    assert np.array_equal(pt.to_numpy(), back.data())
+    assert pt.save_bytes() == stream
+    # used as an operand
+    x = rand_ct(rng, primes, K, n)
+    is_ntt = scheme != "bfv"
+    scale = 2.0 ** 20 if scheme == "ckks" else 1.0
+    cx = d.ct(x, scale=scale, is_ntt=is_ntt)
+    d.ev.multiply_plain_inplace(cx, pt)
+    rx = ref.ct(ref.first_chain_index, x, is_ntt, scale)
+    ref.multiply_plain_inplace(rx, back)
+    assert np.array_equal(cx.to_numpy()[:, 0], rx.data()) and cx.scale() == rx.info()["scale"]
+
+    def mutate(base, off, fmt, value):
+        b = bytearray(base)
+        b[off:off + struct.calcsize(fmt)] = struct.pack(fmt, value)
+        return bytes(b)
+
+    data0 = 16 + 32 + 8 + 8 + 16 + 8
+    cases = {
+        "ok": stream, "truncated": stream[:-8], "bad_magic": mutate(stream, 0, "<H", 3), "zstd": mutate(stream, 5, "<B", 2),
+        "unknown_parms_id": mutate(stream, 16, "<Q", 77), "zero_parms_id": stream[:16] + b"\x00" * 32 + stream[48:],
+        "count_plus_1": mutate(stream, 48, "<Q", bi["coeff_count"] + 1), "count_huge": mutate(stream, 48, "<Q", 2 ** 40),
+        "scale_nan": mutate(stream, 56, "<d", float("nan")), "scale_negative": mutate(stream, 56, "<d", -1.0),
+        "dyn_count_small": mutate(stream, data0 - 8, "<Q", bi["coeff_count"] - 1),
+        "coefficient_max": mutate(stream, data0 + 8 * 5, "<Q", 2 ** 64 - 1),
+        "coefficient_eq_modulus": mutate(stream, data0, "<Q", primes[0] if bi["is_ntt_form"] else t),
+    }
+    for name, data in cases.items():
+        for unsafe in (False, True):
+            want = _outcome(lambda: ref.pt_load(data, unsafe))
+            got = _outcome(lambda: S.Plaintext(d.ctx).load_bytes(data, unsafe=unsafe))
+            assert got == want, "%s (unsafe=%s): got %r, reference %r" % (name, unsafe, got, want)
+
+
 def _outcome(fn):
     try:
         fn()

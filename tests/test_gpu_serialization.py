@@ -43,3 +43,8 @@ def test_key_stream_headline_size(gpu):
 def test_malformed_streams(gpu):
     SC.case_malformed_streams("ckks", 4096, [40, 30, 40])
     SC.case_malformed_key_streams("ckks", 4096, [40, 30, 40])
+
+
+@pytest.mark.parametrize("scheme,n,bits", SIZES)
+def test_plaintext_streams(gpu, scheme, n, bits):
+    SC.case_plaintext_streams(scheme, n, bits)

@@ -68,6 +68,13 @@ def test_malformed_streams_fail_like_the_reference(emu, scheme, n, bits):
 
 
 @needs_ref
+@pytest.mark.parametrize("scheme,n,bits", SMALL)
+def test_plaintext_streams(emu, scheme, n, bits):
+    import serial_cases as SC
+    SC.case_plaintext_streams(scheme, n, bits)
+
+
+@needs_ref
 def test_malformed_key_streams(emu):
     import serial_cases as SC
     SC.case_malformed_key_streams("ckks", 1024, [40, 30, 40])
