@@ -137,6 +137,23 @@ SHL_FUNC Ciphertext_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t 
 SHL_FUNC Ciphertext_LoadItem(void *thisptr, void *context, uint64_t item, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 SHL_FUNC Ciphertext_SaveItem(void *thisptr, uint64_t item, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
 
+/* SecretKey / Decryptor (native/src/seal/c/secretkey.h, native/src/seal/c/decryptor.h:16-24; seal::Decryptor::decrypt,
+ * native/src/seal/decryptor.cpp:79-233): the phase c_0 + c_1 s + ... on the NTT engine, then RNSTool::decrypt_scale_and_round (BFV),
+ * decrypt_modt (BGV) or nothing (CKKS: the NTT-form plaintext a CKKSEncoder::decode expects).  SecretKey_Set takes
+ * SecretKey::data().data() (L*N words, key level, NTT form); SecretKey_Load the serialized key.  Decryptor_Decrypt is
+ * seal::Decryptor::decrypt for a batch of one; Decryptor_DecryptBatch decrypts every item of a batch into caller-owned device
+ * memory, untrimmed: [batch][K][N] words (CKKS) or [batch][N] (BFV / BGV). */
+SHL_FUNC SecretKey_Create(void *context, void **secret_key);
+SHL_FUNC SecretKey_Destroy(void *thisptr);
+SHL_FUNC SecretKey_Set(void *thisptr, const uint64_t *host_words, uint64_t word_count);
+SHL_FUNC SecretKey_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+SHL_FUNC SecretKey_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+SHL_FUNC Decryptor_Create(void *context, void *secret_key, void **decryptor);
+SHL_FUNC Decryptor_Destroy(void *thisptr);
+SHL_FUNC Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
+SHL_FUNC Decryptor_DecryptBatchWords(void *thisptr, void *encrypted, uint64_t *word_count);
+SHL_FUNC Decryptor_DecryptBatch(void *thisptr, void *encrypted, uint64_t *device_out, uint64_t word_count);
+
 /* KSwitchKeys / RelinKeys / GaloisKeys (native/src/seal/c/kswitchkeys.h, relinkeys.h, galoiskeys.h).
  * A key set lives in HBM; one key (index) is uploaded as the concatenation of its decomposition
  * digits, each a size-2 key-level ciphertext in NTT form: [digit][2][L][N] words

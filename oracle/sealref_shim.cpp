@@ -840,6 +840,32 @@ extern "C"
         *out = h.release();
         REF_CATCH
     }
+    // ---- decryption: the secret key's words / stream and Decryptor::decrypt as a Plaintext handle ----
+    int ref_secret_key_copy(void *ctx, uint64_t *out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        const Plaintext &sk = c->keygen->secret_key().data();
+        std::memcpy(out, sk.data(), sk.coeff_count() * sizeof(uint64_t));
+        REF_CATCH
+    }
+    int ref_secret_key_save(void *ctx, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        *bytes = static_cast<uint64_t>(c->keygen->secret_key().save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        REF_CATCH
+    }
+    int ref_decrypt(void *ctx, void *ct, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        Decryptor d(*c->context, c->keygen->secret_key());
+        auto h = std::make_unique<RefPt>();
+        d.decrypt(CT(ct), h->pt);
+        *out = h.release();
+        REF_CATCH
+    }
     // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)
     int ref_keys_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, uint64_t *bytes)
     {

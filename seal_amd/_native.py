@@ -64,6 +64,8 @@ Ciphertext_SetCorrectionFactor Ciphertext_IsTransparent Ciphertext_DevicePtr Cip
 Ciphertext_CopyToHost Ciphertext_CopyFromDevice
 Ciphertext_SaveSize Ciphertext_Save Ciphertext_UnsafeLoad Ciphertext_Load Ciphertext_LoadItem Ciphertext_SaveItem
 KSwitchKeys_UnsafeLoad KSwitchKeys_Load
+SecretKey_Create SecretKey_Destroy SecretKey_Set SecretKey_UnsafeLoad SecretKey_Load Decryptor_Create Decryptor_Destroy
+Decryptor_Decrypt Decryptor_DecryptBatchWords Decryptor_DecryptBatch
 Plaintext_Create1 Plaintext_Create5 Plaintext_Destroy Plaintext_Set4 Plaintext_SetFromDevice Plaintext_CoeffCount
 Plaintext_IsNTTForm Plaintext_GetParmsId Plaintext_SetParmsId Plaintext_Scale Plaintext_SetScale Plaintext_CopyToHost
 Plaintext_SaveSize Plaintext_Save Plaintext_UnsafeLoad Plaintext_Load

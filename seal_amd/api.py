@@ -437,6 +437,60 @@ class GaloisKeys(KSwitchKeys):
         return self.has_index(self.get_index(galois_elt))
 
 
+class SecretKey:
+    """seal::SecretKey resident in HBM: [L][N] words, key level, NTT form"""
+
+    def __init__(self, context, words=None):
+        self.context = context
+        self._h = C.c_void_p()
+        N.check(N.lib().SecretKey_Create(context._h, C.byref(self._h)))
+        if words is not None:
+            self.set(words)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().SecretKey_Destroy(self._h)
+            self._h = None
+
+    def set(self, words):
+        a = np.ascontiguousarray(words, dtype=np.uint64)
+        N.check(N.lib().SecretKey_Set(self._h, _p(a), C.c_uint64(a.size)))
+
+    def load_bytes(self, data, unsafe=False):
+        data = bytes(data)
+        n = C.c_int64()
+        fn = N.lib().SecretKey_UnsafeLoad if unsafe else N.lib().SecretKey_Load
+        N.check(fn(self._h, self.context._h, C.cast(C.c_char_p(data), C.c_void_p), C.c_uint64(len(data)), C.byref(n)))
+        return n.value
+
+
+class Decryptor:
+    """seal::Decryptor on the device (sealhip.h): decrypt (batch of one -> Plaintext) and decrypt_batch (raw device words)"""
+
+    def __init__(self, context, secret_key):
+        self.context = context
+        self._h = C.c_void_p()
+        N.check(N.lib().Decryptor_Create(context._h, secret_key._h, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().Decryptor_Destroy(self._h)
+            self._h = None
+
+    def decrypt(self, encrypted, destination=None):
+        destination = destination if destination is not None else Plaintext(self.context)
+        N.check(N.lib().Decryptor_Decrypt(self._h, encrypted._h, destination._h))
+        return destination
+
+    def decrypt_batch(self, encrypted):
+        """-> DeviceBuffer of [batch][K][N] (CKKS) or [batch][N] (BFV / BGV) words and its word count"""
+        w = C.c_uint64()
+        N.check(N.lib().Decryptor_DecryptBatchWords(self._h, encrypted._h, C.byref(w)))
+        buf = DeviceBuffer(w.value)
+        N.check(N.lib().Decryptor_DecryptBatch(self._h, encrypted._h, C.c_void_p(buf.ptr), w))
+        return buf, w.value
+
+
 class Graph:
     """an executable hipGraph recorded by Evaluator.capture(); launch() is stream-ordered on the evaluator's stream"""
 

@@ -4,6 +4,7 @@
 // (native/src/seal/c/utilities.h).
 #include "../../include/sealhip.h"
 #include "evaluator.h"
+#include "decryptor.h"
 #include "serial.h"
 #include <cstring>
 #include <new>
@@ -740,6 +741,109 @@ extern "C"
     SHL_FUNC KSwitchKeys_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
     {
         return ks_load(thisptr, context, inptr, size, in_bytes, false);
+    }
+
+    // ------------------------------------------------------------------ SecretKey / Decryptor (native/src/seal/c/secretkey.h, decryptor.h)
+    SHL_FUNC SecretKey_Create(void *context, void **secret_key)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(secret_key, SHL_E_POINTER);
+        SHL_TRY
+        *secret_key = new SecretKey(*as<Context>(context));
+        SHL_CATCH
+    }
+    SHL_FUNC SecretKey_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<SecretKey>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC SecretKey_Set(void *thisptr, const uint64_t *host_words, uint64_t word_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(host_words, SHL_E_POINTER);
+        SHL_TRY
+        as<SecretKey>(thisptr)->set(host_words, (size_t)word_count);
+        SHL_CATCH
+    }
+    namespace
+    {
+        SHL_HRESULT sk_load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes, bool check)
+        {
+            IfNullRet(thisptr, SHL_E_POINTER);
+            IfNullRet(context, SHL_E_POINTER);
+            IfNullRet(inptr, SHL_E_POINTER);
+            IfNullRet(in_bytes, SHL_E_POINTER);
+            SHL_TRY
+            auto sk = as<SecretKey>(thisptr);
+            auto c = as<Context>(context);
+            if (&sk->context() != c)
+                throw std::invalid_argument("secret key belongs to another context");
+            // SecretKey::load = Plaintext::unsafe_load + is_valid_for(SecretKey) (secretkey.h:134-170; valcheck.cpp: key-level
+            // parms_id, every coefficient reduced); the device object needs the key-level layout for unsafe_load as well
+            serial::PlaintextImage img;
+            const size_t n = serial::load_plaintext(*c, inptr, (size_t)size, false, img);
+            if (img.level != &c->key_level() || (check && !serial::plaintext_in_range(*c, img)))
+                throw std::logic_error("SecretKey data is invalid");
+            sk->set(img.stored, (size_t)img.coeff_count);
+            *in_bytes = (int64_t)n;
+            SHL_CATCH
+        }
+    } // namespace
+    SHL_FUNC SecretKey_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return sk_load(thisptr, context, inptr, size, in_bytes, true);
+    }
+    SHL_FUNC SecretKey_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return sk_load(thisptr, context, inptr, size, in_bytes, false);
+    }
+    SHL_FUNC Decryptor_Create(void *context, void *secret_key, void **decryptor)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(secret_key, SHL_E_POINTER);
+        IfNullRet(decryptor, SHL_E_POINTER);
+        SHL_TRY
+        *decryptor = new Decryptor(*as<Context>(context), *as<SecretKey>(secret_key));
+        SHL_CATCH
+    }
+    SHL_FUNC Decryptor_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<Decryptor>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        hip_ok(hipDeviceSynchronize(), "sync");
+        as<Decryptor>(thisptr)->decrypt(*as<Ciphertext>(encrypted), *as<Plaintext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC Decryptor_DecryptBatchWords(void *thisptr, void *encrypted, uint64_t *word_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(word_count, SHL_E_POINTER);
+        SHL_TRY
+        *word_count = as<Decryptor>(thisptr)->decrypt_batch_words(*as<Ciphertext>(encrypted));
+        SHL_CATCH
+    }
+    SHL_FUNC Decryptor_DecryptBatch(void *thisptr, void *encrypted, uint64_t *device_out, uint64_t word_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(device_out, SHL_E_POINTER);
+        SHL_TRY
+        auto d = as<Decryptor>(thisptr);
+        if (word_count != d->decrypt_batch_words(*as<Ciphertext>(encrypted)))
+            throw std::invalid_argument("word_count does not match Decryptor_DecryptBatchWords");
+        hip_ok(hipDeviceSynchronize(), "sync");
+        d->decrypt_batch(*as<Ciphertext>(encrypted), device_out);
+        SHL_CATCH
     }
 
     // ------------------------------------------------------------------ KSwitchKeys

@@ -312,7 +312,8 @@ namespace sealhip
         {
             size_t inv_q_last = 0, round_fix = 0, half_mod_q = 0, q_last_mod_q = 0, delta_mod_q = 0, upper_half_inc = 0, bsk_prime = 0, inv_punct_q = 0, m_tilde_mod_q = 0, q_to_bsk = 0, q_to_mtilde = 0,
                    prod_q_mod_bsk = 0, inv_mtilde_mod_bsk = 0, inv_prod_q_mod_bsk = 0, inv_punct_b = 0, b_to_q = 0,
-                   b_to_msk = 0, prod_b_mod_q = 0, t_mod_q = 0, t_mod_bsk = 0;
+                   b_to_msk = 0, prod_b_mod_q = 0, t_mod_q = 0, t_mod_bsk = 0, dec_inv_punct_q = 0, dec_q_to_t = 0, dec_prod_t_gamma = 0,
+                   dec_q_to_gamma = 0;
         } off;
 
         // q_last^-1 mod q_i  (rns.cpp:769-776)
@@ -357,6 +358,41 @@ namespace sealhip
             lvl.dev.half_q_last = half;
         }
         lvl.dev.K = K;
+
+        if (scheme_ != Scheme::ckks)
+        {
+            // decryption constants (rns.cpp:617-650, 680-690, 738-765): base conversion q -> {t} (BGV, exact) and
+            // q -> {t, gamma} (BFV)
+            const uint64_t t = plain_modulus_;
+            std::vector<ShoupOp> ipq;
+            std::vector<uint64_t> q2t;
+            for (unsigned i = 0; i < K; i++)
+            {
+                ipq.push_back(make_shoup(invmod(punctured_prod_mod(q, i, q[i]), q[i]), q[i]));
+                q2t.push_back(punctured_prod_mod(q, i, t));
+            }
+            off.dec_inv_punct_q = blk.put(ipq);
+            off.dec_q_to_t = blk.put(q2t);
+            if (scheme_ == Scheme::bfv)
+            {
+                const unsigned gp = aux_first() + 1;
+                const uint64_t gamma = pool_[gp];
+                std::vector<ShoupOp> ptg;
+                std::vector<uint64_t> q2g;
+                for (unsigned i = 0; i < K; i++)
+                {
+                    ptg.push_back(make_shoup(mulmod(t % q[i], gamma % q[i], q[i]), q[i]));
+                    q2g.push_back(punctured_prod_mod(q, i, gamma));
+                }
+                off.dec_prod_t_gamma = blk.put(ptg);
+                off.dec_q_to_gamma = blk.put(q2g);
+                lvl.dev.gamma_prime = gp;
+                const uint64_t qt = prod_mod(q, t), qg = prod_mod(q, gamma);
+                lvl.dev.dec_neg_inv_q_mod_t = (t - invmod(qt, t)) % t;
+                lvl.dev.dec_neg_inv_q_mod_gamma = (gamma - invmod(qg, gamma)) % gamma;
+                lvl.dev.dec_inv_gamma_mod_t = invmod(gamma % t, t);
+            }
+        }
 
         const bool behz = scheme_ == Scheme::bfv;
         if (behz)
@@ -443,6 +479,13 @@ namespace sealhip
         {
             lvl.dev.delta_mod_q = d + off.delta_mod_q;
             lvl.dev.upper_half_inc = d + off.upper_half_inc;
+            lvl.dev.dec_inv_punct_q = reinterpret_cast<const ShoupOp *>(d + off.dec_inv_punct_q);
+            lvl.dev.dec_q_to_t = d + off.dec_q_to_t;
+            if (scheme_ == Scheme::bfv)
+            {
+                lvl.dev.dec_prod_t_gamma_mod_q = reinterpret_cast<const ShoupOp *>(d + off.dec_prod_t_gamma);
+                lvl.dev.dec_q_to_gamma = d + off.dec_q_to_gamma;
+            }
         }
         if (behz)
         {

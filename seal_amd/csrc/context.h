@@ -56,6 +56,14 @@ namespace sealhip
         const uint64_t *upper_half_inc = nullptr;  // [K]
         uint64_t q_mod_t = 0;
         uint64_t plain_upper_half_threshold = 0;
+        // decryption (RNSTool::decrypt_scale_and_round, rns.cpp:1133-1191: BFV; RNSTool::decrypt_modt = BaseConverter::
+        // exact_convert_array, rns.cpp:1193-1198 / 465-540: BGV); null for CKKS
+        const ShoupOp *dec_inv_punct_q = nullptr;     // [K] (Q/q_i)^-1 mod q_i
+        const uint64_t *dec_q_to_t = nullptr;         // [K] (Q/q_i) mod t
+        const ShoupOp *dec_prod_t_gamma_mod_q = nullptr; // [K] t*gamma mod q_i                      (BFV)
+        const uint64_t *dec_q_to_gamma = nullptr;     // [K] (Q/q_i) mod gamma                       (BFV)
+        uint64_t dec_neg_inv_q_mod_t = 0, dec_neg_inv_q_mod_gamma = 0, dec_inv_gamma_mod_t = 0; // (BFV)
+        uint32_t gamma_prime = 0;                     // pool index of gamma                           (BFV)
         // BEHZ (BFV multiply); all null when the scheme is CKKS
         const uint32_t *bsk_prime = nullptr;       // [nBsk] pool index of each Bsk prime (B..., m_sk)
         const ShoupOp *inv_punct_q = nullptr;      // [K]     (Q/q_i)^-1 mod q_i

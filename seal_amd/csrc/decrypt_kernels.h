@@ -1,0 +1,26 @@
+// Kernels of the decryption path: the phase c_0 + c_1 s + ... + c_{k-1} s^{k-1} (Decryptor::
+// dot_product_ct_sk_array, native/src/seal/decryptor.cpp) and the two RNS read-outs of the plaintext
+// (RNSTool::decrypt_scale_and_round, rns.cpp:1133-1191: BFV; RNSTool::decrypt_modt = BaseConverter::exact_convert_array,
+// rns.cpp:465-540: BGV).  Element-wise, HBM-streaming, one pass each; batch = independent ciphertexts.
+#pragma once
+#include "context.h"
+
+namespace sealhip
+{
+    struct SkPowers
+    {
+        const uint64_t *p[5]; // s^1 .. s^5 in NTT form at the key level, [L][N] each (SEAL_CIPHERTEXT_SIZE_MAX = 6)
+    };
+    // out[b][r][j] = (with_c0 ? ct_0 : 0) + sum_{p=1..size-1} ct_p[b][r][j] * s^p[r][j]  mod q_r;  ct planes are [batch][K][N]
+    // (src may hold only the planes 1.. when with_c0 == 0: pass plane0 = nullptr)
+    hipError_t k_decrypt_dot(const ModDesc *mods, const uint64_t *plane0, const uint64_t *planes1, size_t plane_words, unsigned size,
+                             SkPowers sk, uint64_t *out, unsigned n_log, unsigned K, hipStream_t s);
+    // out = out + a mod q_r over [batch][K][N]
+    hipError_t k_add_inplace(const ModDesc *mods, uint64_t *out, const uint64_t *a, size_t words, unsigned n_log, unsigned K, hipStream_t s);
+    // BFV: phase [batch][K][N] (coefficient form) -> plaintext coefficients mod t, [batch][N]
+    hipError_t k_decrypt_scale_and_round(const ModDesc *mods, const LevelDev &lvl, ModDesc t, const uint64_t *phase, uint64_t *out,
+                                         unsigned n_log, unsigned batch, hipStream_t s);
+    // BGV: phase [batch][K][N] (coefficient form) -> (phase mod t) * fix mod t, [batch][N]; fix = correction_factor^-1 mod t
+    hipError_t k_decrypt_modt(const ModDesc *mods, const LevelDev &lvl, ModDesc t, uint64_t fix, const uint64_t *phase, uint64_t *out,
+                              unsigned n_log, unsigned batch, hipStream_t s);
+} // namespace sealhip

@@ -438,34 +438,35 @@ namespace sealhip
                 if (count != img.coeff_count) // is_buffer_valid
                     throw std::logic_error("plaintext data is invalid");
             });
-            if (check_data)
-            {
-                // Plaintext::load = unsafe_load + is_valid_for (is_data_valid_for, valcheck.cpp:348-396)
-                bool ok = metadata_ok(false);
-                const unaligned_u64 *p = reinterpret_cast<const unaligned_u64 *>(img.stored);
-                if (ok && img.level)
-                {
-                    for (unsigned j = 0; j < img.level->K && ok; j++)
-                    {
-                        const uint64_t q = ctx.coeff_modulus()[j];
-                        uint64_t over = 0;
-                        for (size_t k = 0; k < ctx.n(); k++)
-                            over |= (uint64_t)(p[k] >= q);
-                        ok = !over;
-                        p += ctx.n();
-                    }
-                }
-                else if (ok)
-                {
-                    const uint64_t t = ctx.plain_modulus();
-                    for (uint64_t k = 0; k < img.coeff_count && ok; k++)
-                        ok = p[k] < t;
-                }
-                if (!ok)
-                    throw std::logic_error("plaintext data is invalid");
-            }
+            // Plaintext::load = unsafe_load + is_valid_for (is_data_valid_for, valcheck.cpp:348-396)
+            if (check_data && !(metadata_ok(false) && plaintext_in_range(ctx, img)))
+                throw std::logic_error("plaintext data is invalid");
             out = img;
             return bytes;
+        }
+
+        bool plaintext_in_range(const Context &ctx, const PlaintextImage &img)
+        {
+            const unaligned_u64 *p = reinterpret_cast<const unaligned_u64 *>(img.stored);
+            if (img.level)
+            {
+                for (unsigned j = 0; j < img.level->K; j++)
+                {
+                    const uint64_t q = ctx.coeff_modulus()[j];
+                    uint64_t over = 0;
+                    for (size_t k = 0; k < ctx.n(); k++)
+                        over |= (uint64_t)(p[k] >= q);
+                    if (over)
+                        return false;
+                    p += ctx.n();
+                }
+                return true;
+            }
+            const uint64_t t = ctx.plain_modulus();
+            for (uint64_t k = 0; k < img.coeff_count; k++)
+                if (p[k] >= t)
+                    return false;
+            return true;
         }
 
         size_t plaintext_save_size(uint64_t coeff_count)

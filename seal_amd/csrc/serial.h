@@ -82,6 +82,8 @@ namespace sealhip
         };
         // Plaintext::unsafe_load (check_data = false) / Plaintext::load (true: data level, every coefficient below its modulus)
         size_t load_plaintext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, PlaintextImage &out);
+        // the coefficient range part of is_data_valid_for(const Plaintext &) (valcheck.cpp:348-396)
+        bool plaintext_in_range(const Context &ctx, const PlaintextImage &img);
         size_t plaintext_save_size(uint64_t coeff_count);
         // as save_ciphertext: words == nullptr leaves the coefficient words to the caller (*data_offset)
         size_t save_plaintext(const uint64_t *parms_id, uint64_t coeff_count, double scale, const uint64_t *words, uint8_t *out,

@@ -1,0 +1,136 @@
+"""Decryption cases shared by the CPU (emulated kernels) and `-m gpu` suites: ciphertexts encrypted by the REAL
+reference (oracle/_ref), evaluated on either side, are decrypted through the C ABI (Decryptor_Decrypt / Decryptor_DecryptBatch)
+and must give the plaintext words, coefficient count, parms_id and scale of the reference's own Decryptor::decrypt.
+TEST INFRASTRUCTURE: the reference is the checker."""
+import numpy as np
+
+import seal_amd as S
+import sealref
+from harness import DeviceSide
+from oracle import coeff_modulus_create, plain_modulus_batching
+
+
+def _setup(scheme, n, bits, tbits=20):
+    primes = coeff_modulus_create(n, bits)
+    t = plain_modulus_batching(n, tbits) if scheme != "ckks" else 0
+    ref = sealref.RefContext(scheme, n, primes, t)
+    d = DeviceSide(scheme, n, primes, t)
+    sk = S.SecretKey(d.ctx)
+    assert sk.load_bytes(ref.secret_key_save()) > 0            # the serialized SecretKey ...
+    sk2 = S.SecretKey(d.ctx, ref.secret_key())                  # ... and its raw words give the same decryptor
+    return primes, t, ref, d, S.Decryptor(d.ctx, sk), S.Decryptor(d.ctx, sk2)
+
+
+def _to_device(d, rct):
+    i = rct.info()
+    return S.Ciphertext.from_numpy(d.ctx, rct.data(), d.ctx.parms_id_at(i["chain_index"]), i["is_ntt_form"], i["scale"], i["correction_factor"])
+
+
+def _same_plain(pt, rpt, what):
+    ri = rpt.info()
+    assert pt.coeff_count() == ri["coeff_count"], (what, pt.coeff_count(), ri["coeff_count"])
+    assert pt.is_ntt_form() == ri["is_ntt_form"], what
+    if ri["is_ntt_form"]:
+        assert pt.scale() == ri["scale"], what
+    assert np.array_equal(pt.to_numpy(), rpt.data()), what
+
+
+def case_decrypt(scheme, n, bits, batch=3):
+    primes, t, ref, d, dec, dec2 = _setup(scheme, n, bits)
+    ref.keygen_relin()
+    rng = np.random.default_rng(17)
+
+    def fresh():
+        if scheme == "ckks":
+            return ref.ckks_encrypt(rng.standard_normal(n // 2), 2.0 ** 30)
+        return ref.batch_encrypt(rng.integers(0, t, n, dtype=np.uint64))
+
+    # fresh ciphertext (size 2, first data level)
+    a, b = fresh(), fresh()
+    for dcr in (dec, dec2):
+        _same_plain(dcr.decrypt(_to_device(d, a)), ref.decrypt(a), "fresh")
+    # product (size 3: needs s^2), relinearized, at the next level, squared again (size 3 at a lower level)
+    prod = ref.multiply_inplace(a.copy(), b)
+    _same_plain(dec.decrypt(_to_device(d, prod)), ref.decrypt(prod), "size 3")
+    ref.relinearize_inplace(prod)
+    _same_plain(dec.decrypt(_to_device(d, prod)), ref.decrypt(prod), "relinearized")
+    if len(primes) > 2:
+        nxt = ref.rescale_to_next_inplace(prod.copy()) if scheme == "ckks" else ref.mod_switch_to_next_inplace(prod.copy())
+        _same_plain(dec.decrypt(_to_device(d, nxt)), ref.decrypt(nxt), "next level")
+        if scheme == "bgv":
+            assert nxt.info()["correction_factor"] != 1  # exercises the correction-factor fix of bgv_decrypt
+    # a product of products without relinearization: size 5 (s^4)
+    if scheme != "ckks":
+        big = ref.multiply_inplace(ref.multiply_inplace(a.copy(), b), ref.multiply_inplace(a.copy(), a))
+        assert big.info()["size"] == 5
+        _same_plain(dec.decrypt(_to_device(d, big)), ref.decrypt(big), "size 5")
+    # the device's own evaluation decrypts to what the reference's evaluation decrypts to
+    ca, cb = _to_device(d, a), _to_device(d, b)
+    d.ev.multiply_inplace(ca, cb)
+    _same_plain(dec.decrypt(ca), ref.decrypt(ref.multiply_inplace(a.copy(), b)), "device product")
+    # batches: every item, untrimmed
+    items = [fresh() for _ in range(batch)]
+    arr = np.stack([c.data() for c in items], axis=1)
+    i0 = items[0].info()
+    cts = S.Ciphertext.from_numpy(d.ctx, arr, d.ctx.parms_id_at(i0["chain_index"]), i0["is_ntt_form"], i0["scale"], i0["correction_factor"])
+    buf, words = dec.decrypt_batch(cts)
+    out = buf.to_numpy((words,)).reshape(batch, -1)
+    for k, c in enumerate(items):
+        want = ref.decrypt(c).data()
+        assert np.array_equal(out[k][: want.size], want) and not out[k][want.size:].any(), "batch item %d" % k
+    # argument checks (decryptor.cpp:82-92, 119-122, 157-160)
+    try:
+        dec.decrypt(cts)
+        raise AssertionError("expected InvalidArgument for a batch")
+    except S.InvalidArgument:
+        pass
+    wrong = _to_device(d, a)
+    wrong.set_is_ntt_form(not wrong.is_ntt_form())
+    try:
+        dec.decrypt(wrong)
+        raise AssertionError("expected InvalidArgument for the wrong form")
+    except S.InvalidArgument:
+        pass
+    empty = S.Ciphertext(d.ctx)
+    try:
+        dec.decrypt(empty)
+        raise AssertionError("expected InvalidArgument for an empty ciphertext")
+    except S.InvalidArgument:
+        pass
+
+
+def case_end_to_end_streams(scheme, n, bits):
+    """the server flow on the device with nothing but the reference's byte streams on either side: keys + ciphertexts in,
+    multiply / relinearize / (rescale | mod switch) / rotate, result stream out, and the client-side check: the REFERENCE
+    decrypts our stream to the same plaintext as its own evaluation"""
+    primes, t, ref, d, dec, _ = _setup(scheme, n, bits)
+    rng = np.random.default_rng(23)
+    if scheme == "ckks":
+        a, b = (ref.ckks_encrypt(rng.standard_normal(n // 2), 2.0 ** 30) for _ in range(2))
+    else:
+        a, b = (ref.batch_encrypt(rng.integers(0, t, n, dtype=np.uint64)) for _ in range(2))
+    rlk = S.RelinKeys(d.ctx)
+    rlk.load_bytes(ref.keys_save("relin", True))
+    elt = ref.galois_elt_from_step(1)
+    glk = S.GaloisKeys(d.ctx)
+    glk.load_bytes(ref.keys_save("galois", True, [elt]))
+    ca, cb = S.Ciphertext(d.ctx), S.Ciphertext(d.ctx)
+    ca.load_bytes(ref.ct_save(a))
+    cb.load_bytes(ref.ct_save(b))
+    d.ev.multiply_inplace(ca, cb)
+    d.ev.relinearize_inplace(ca, rlk)
+    if scheme == "ckks":
+        d.ev.rescale_to_next_inplace(ca)
+    else:
+        d.ev.mod_switch_to_next_inplace(ca)
+    d.ev.apply_galois_inplace(ca, elt, glk)
+    stream = ca.save_bytes()
+    # reference side
+    r = ref.multiply_inplace(a.copy(), b)
+    ref.relinearize_inplace(r)
+    r = ref.rescale_to_next_inplace(r) if scheme == "ckks" else ref.mod_switch_to_next_inplace(r)
+    ref.apply_galois_inplace(r, elt)
+    assert stream == ref.ct_save(r), "result stream"
+    back, _ = ref.ct_load(stream)
+    assert np.array_equal(ref.decrypt(back).data(), ref.decrypt(r).data())
+    _same_plain(dec.decrypt(ca), ref.decrypt(r), "device decrypt of the device result")

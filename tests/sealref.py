@@ -262,6 +262,25 @@ class RefContext:
         _ck(lib().ref_batch_encode(self.h, _p(v), C.c_uint64(v.size), C.byref(h)))
         return RefPlaintext(self, h)
 
+    def secret_key(self):
+        """SecretKey::data(): [L][N] words, key level, NTT form"""
+        out = np.zeros((len(self.primes), self.n), dtype=np.uint64)
+        _ck(lib().ref_secret_key_copy(self.h, _p(out)))
+        return out
+
+    def secret_key_save(self):
+        cap = 4096 + 8 * len(self.primes) * self.n
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_secret_key_save(self.h, buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def decrypt(self, ct):
+        """Decryptor::decrypt -> RefPlaintext"""
+        h = C.c_void_p()
+        _ck(lib().ref_decrypt(self.h, ct.h, C.byref(h)))
+        return RefPlaintext(self, h)
+
     def keys_load(self, data, unsafe=False):
         buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
         n = C.c_uint64()

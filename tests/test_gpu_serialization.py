@@ -48,3 +48,16 @@ def test_malformed_streams(gpu):
 @pytest.mark.parametrize("scheme,n,bits", SIZES)
 def test_plaintext_streams(gpu, scheme, n, bits):
     SC.case_plaintext_streams(scheme, n, bits)
+
+
+# ---- decryption on the device
+@pytest.mark.parametrize("scheme,n,bits", SIZES + [("ckks", 32768, [60, 50, 50, 50, 60])])
+def test_decrypt(gpu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_decrypt(scheme, n, bits)
+
+
+@pytest.mark.parametrize("scheme,n,bits", SIZES)
+def test_end_to_end_streams(gpu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_end_to_end_streams(scheme, n, bits)

@@ -107,3 +107,18 @@ def test_golden_streams(emu):
         cx = d.ct(x3, scale=2.0 ** 10)
         d.ev.relinearize_inplace(cx, rlk)
         assert hashlib.sha256(np.ascontiguousarray(cx.to_numpy()[:, 0]).tobytes()).hexdigest() == g["sha256_relinearized"], g["file"]
+
+
+# ---- decryption on the device and the whole server flow on byte streams
+@needs_ref
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45]), ("ckks", 8192, [50, 40, 60])])
+def test_decrypt(emu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_decrypt(scheme, n, bits)
+
+
+@needs_ref
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 2048, [36, 36, 37]), ("bgv", 2048, [40, 40, 45])])
+def test_end_to_end_streams(emu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_end_to_end_streams(scheme, n, bits)
