@@ -482,11 +482,11 @@ class Decryptor:
         N.check(N.lib().Decryptor_Decrypt(self._h, encrypted._h, destination._h))
         return destination
 
-    def decrypt_batch(self, encrypted):
-        """-> DeviceBuffer of [batch][K][N] (CKKS) or [batch][N] (BFV / BGV) words and its word count"""
+    def decrypt_batch(self, encrypted, out=None):
+        """-> DeviceBuffer of [batch][K][N] (CKKS) or [batch][N] (BFV / BGV) words and its word count; `out` reuses a buffer"""
         w = C.c_uint64()
         N.check(N.lib().Decryptor_DecryptBatchWords(self._h, encrypted._h, C.byref(w)))
-        buf = DeviceBuffer(w.value)
+        buf = out if out is not None else DeviceBuffer(w.value)
         N.check(N.lib().Decryptor_DecryptBatch(self._h, encrypted._h, C.c_void_p(buf.ptr), w))
         return buf, w.value
 
