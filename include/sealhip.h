@@ -240,6 +240,7 @@ SHL_FUNC Evaluator_ModSwitchTo1(void *thisptr, void *encrypted, uint64_t *parms_
 SHL_FUNC Evaluator_RescaleToNext(void *thisptr, void *encrypted, void *destination, void *pool);
 SHL_FUNC Evaluator_RescaleTo(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool);
 SHL_FUNC Evaluator_ModReduceToNext(void *thisptr, void *encrypted, void *destination, void *pool);
+SHL_FUNC Evaluator_ModReduceTo(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool);
 SHL_FUNC Evaluator_TransformToNTT2(void *thisptr, void *encrypted, void *destination_ntt);
 SHL_FUNC Evaluator_TransformFromNTT(void *thisptr, void *encrypted_ntt, void *destination);
 SHL_FUNC Evaluator_ApplyGalois(void *thisptr, void *encrypted, uint32_t galois_elt, void *galoisKeys, void *destination, void *pool);

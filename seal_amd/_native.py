@@ -77,7 +77,7 @@ Evaluator_Create Evaluator_Destroy Evaluator_SetStream Evaluator_Synchronize Eva
 Evaluator_BeginCapture Evaluator_EndCapture Evaluator_LaunchGraph Graph_Destroy
 Evaluator_Negate Evaluator_Add Evaluator_Sub Evaluator_Multiply Evaluator_Square Evaluator_Relinearize
 Evaluator_ModSwitchToNext1 Evaluator_ModSwitchTo1 Evaluator_RescaleToNext Evaluator_RescaleTo
-Evaluator_ModReduceToNext Evaluator_TransformToNTT2 Evaluator_TransformFromNTT Evaluator_ApplyGalois
+Evaluator_ModReduceToNext Evaluator_ModReduceTo Evaluator_TransformToNTT2 Evaluator_TransformFromNTT Evaluator_ApplyGalois
 Evaluator_RotateRows Evaluator_RotateColumns Evaluator_RotateVector Evaluator_ComplexConjugate
 Evaluator_ContextUsingKeyswitching
 Evaluator_SwitchKeyAccWords Evaluator_RelinearizePartial Evaluator_RelinearizeFinish Evaluator_ApplyGaloisPartial

@@ -617,6 +617,11 @@ class Evaluator:
     def mod_reduce_to_next_inplace(self, a):
         return self._u("Evaluator_ModReduceToNext", a, None, pool=True)
 
+    def mod_reduce_to_inplace(self, a, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Evaluator_ModReduceTo(self._h, a._h, pid, a._h, None))
+        return a
+
     def transform_to_ntt_inplace(self, a):
         return self._u("Evaluator_TransformToNTT2", a, None)
 

@@ -1367,6 +1367,17 @@ extern "C"
         as<Evaluator>(thisptr)->rescale_to_inplace(prepare_dest(encrypted, destination), parms_id);
         SHL_CATCH
     }
+    SHL_FUNC Evaluator_ModReduceTo(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Evaluator>(thisptr)->mod_reduce_to_inplace(prepare_dest(encrypted, destination), parms_id);
+        SHL_CATCH
+    }
     SHL_FUNC Evaluator_ApplyGalois(void *thisptr, void *encrypted, uint32_t galois_elt, void *galoisKeys, void *destination, void *pool)
     {
         (void)pool;

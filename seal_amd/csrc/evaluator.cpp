@@ -1808,6 +1808,20 @@ namespace sealhip
         throw_if_transparent(e);
     }
 
+    // evaluator.cpp:1625-1647
+    void Evaluator::mod_reduce_to_inplace(Ciphertext &e, const uint64_t *parms_id) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        const Level *target = context_.level_by_parms_id(parms_id);
+        if (!target)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (e.level()->chain_index < target->chain_index)
+            throw std::invalid_argument("cannot switch to higher level modulus");
+        while (e.level() != target)
+            mod_reduce_to_next_inplace(e);
+    }
+
     // ---- Galois automorphisms and rotations (evaluator.cpp:2384-2559, evaluator.h:1072-1375)
     void Evaluator::apply_galois_inplace(Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys) const
     {

@@ -159,6 +159,7 @@ namespace sealhip
         void rescale_to_next_inplace(Ciphertext &encrypted) const;
         void rescale_to_inplace(Ciphertext &encrypted, const uint64_t *parms_id) const;
         void mod_reduce_to_next_inplace(Ciphertext &encrypted) const;
+        void mod_reduce_to_inplace(Ciphertext &encrypted, const uint64_t *parms_id) const;
         void transform_to_ntt_inplace(Ciphertext &encrypted) const;
         // plaintext operands and the many-operand forms (evaluator.cpp:242-261, 1649-2287, 1369-1402)
         void add_plain_inplace(Ciphertext &encrypted, const Plaintext &plain) const;

@@ -519,3 +519,37 @@ def case_golden_engine(name):
     assert dg(d.out(x)[0]) == want["rescale"], "rescale_to_next"
     d.ev.rotate_vector_inplace(x, 1, d.glk)
     assert dg(d.out(x)[0]) == want["rotate1"], "rotate_vector(1)"
+
+
+# ---- mod_reduce_to_next / mod_reduce_to (evaluator.cpp:1597-1647): CKKS drops the last prime without scaling
+def case_mod_reduce(n, bits, batch=2, seed=31):
+    import sealref
+    primes = coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    ref = sealref.RefContext("ckks", n, primes, 0)
+    d = DeviceSide("ckks", n, primes)
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    cx = d.ct(xs, scale=2.0 ** 30)
+    rs = [ref.ct(ref.first_chain_index, x, True, 2.0 ** 30) for x in xs]
+    d.ev.mod_reduce_to_next_inplace(cx)
+    for b in range(batch):
+        ref.mod_reduce_to_next_inplace(rs[b])
+        _eq(d.out(cx)[b], rs[b].data(), "mod_reduce_to_next item %d" % b)
+    assert cx.scale() == rs[0].info()["scale"] and cx.coeff_modulus_size() == K - 1
+    # all the way down with mod_reduce_to
+    d.ev.mod_reduce_to_inplace(cx, d.ctx.parms_id_at(0))
+    for b in range(batch):
+        while rs[b].info()["chain_index"] > 0:
+            ref.mod_reduce_to_next_inplace(rs[b])
+        _eq(d.out(cx)[b], rs[b].data(), "mod_reduce_to item %d" % b)
+    assert cx.coeff_modulus_size() == 1
+    import seal_amd as S
+    for bad in (lambda: d.ev.mod_reduce_to_next_inplace(cx),                       # end of chain
+                lambda: d.ev.mod_reduce_to_inplace(cx, d.ctx.parms_id_at(1)),      # higher level
+                lambda: d.ev.mod_reduce_to_inplace(cx, (1, 2, 3, 4))):             # unknown parms_id
+        try:
+            bad()
+            raise AssertionError("expected InvalidArgument")
+        except S.InvalidArgument:
+            pass

@@ -176,3 +176,11 @@ def test_context_constants_match_oracle(emu):
     n = 1024
     assert S.CoeffModulus.Create(n, [60, 40, 40, 60]) == coeff_modulus_create(n, [60, 40, 40, 60])
     assert S.PlainModulus.Batching(n, 20) == plain_modulus_batching(n, 20)
+
+
+def test_mod_reduce(emu):
+    import sealref
+    if not sealref.available():
+        pytest.skip("oracle/_ref (the real reference) is not built")
+    P.case_mod_reduce(1024, [40, 30, 30, 40])
+    P.case_mod_reduce(8192, [50, 40, 60, 50], batch=1)

@@ -434,3 +434,10 @@ def test_graph_capture_replay(gpu, n, bits, batch):
     with pytest.raises(S.LogicError):
         d.ev.capture(step)
     d.ev.set_transparent_check(False)
+
+
+def test_mod_reduce(gpu):
+    import sealref
+    if not sealref.available():
+        pytest.skip("oracle/_ref did not travel")
+    P.case_mod_reduce(16384, [60, 50, 50, 50, 60])
