@@ -154,6 +154,22 @@ SHL_FUNC Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
 SHL_FUNC Decryptor_DecryptBatchWords(void *thisptr, void *encrypted, uint64_t *word_count);
 SHL_FUNC Decryptor_DecryptBatch(void *thisptr, void *encrypted, uint64_t *device_out, uint64_t word_count);
 
+/* Encryptor, the secret-key half (native/src/seal/c/encryptor.h; seal::Encryptor::encrypt_symmetric / encrypt_zero_symmetric and
+ * their Serializable<> forms, native/src/seal/encryptor.cpp:116-330, util/rlwe.cpp:270-395).  The randomness follows the
+ * reference: a bootstrap Blake2xb PRNG gives the public seed of c_1 (sample_poly_uniform) and the centred-binomial noise
+ * (sample_poly_cbd); c_0 = -(c_1 s + e) [+ plaintext] is computed on the device.  Encryptor_SetSeed installs the reference's seeded
+ * factory (every encryption restarts from that 8-word seed: reproducible runs, parity tests); NULL returns to operating-system
+ * entropy.  The *Save forms write the SEEDED stream (c_0 + the 64-byte seed of c_1: half the size) a client uploads.  public_key
+ * must be NULL: public-key encryption is not built. */
+SHL_FUNC Encryptor_Create(void *context, void *public_key, void *secret_key, void **encryptor);
+SHL_FUNC Encryptor_Destroy(void *thisptr);
+SHL_FUNC Encryptor_SetSeed(void *thisptr, const uint64_t *seed);
+SHL_FUNC Encryptor_EncryptZeroSymmetric1(void *thisptr, uint64_t *parms_id, bool save_seed, void *destination, void *pool);
+SHL_FUNC Encryptor_EncryptSymmetric(void *thisptr, void *plaintext, bool save_seed, void *destination, void *pool);
+SHL_FUNC Encryptor_SymmetricSaveSize(void *thisptr, uint64_t *parms_id, int64_t *result);
+SHL_FUNC Encryptor_EncryptZeroSymmetricSave(void *thisptr, uint64_t *parms_id, uint8_t *outptr, uint64_t size, int64_t *out_bytes);
+SHL_FUNC Encryptor_EncryptSymmetricSave(void *thisptr, void *plaintext, uint8_t *outptr, uint64_t size, int64_t *out_bytes);
+
 /* KSwitchKeys / RelinKeys / GaloisKeys (native/src/seal/c/kswitchkeys.h, relinkeys.h, galoiskeys.h).
  * A key set lives in HBM; one key (index) is uploaded as the concatenation of its decomposition
  * digits, each a size-2 key-level ciphertext in NTT form: [digit][2][L][N] words

@@ -866,6 +866,23 @@ extern "C"
         *out = h.release();
         REF_CATCH
     }
+    // Encryptor::encrypt_symmetric(plain) saved: seeded != 0 -> the Serializable<Ciphertext> form, else the full ciphertext
+    int ref_encrypt_symmetric_save(void *ctx, void *pt, int seeded, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        Encryptor e(*c->context, c->keygen->secret_key());
+        const Plaintext &p = static_cast<RefPt *>(pt)->pt;
+        if (seeded)
+            *bytes = static_cast<uint64_t>(e.encrypt_symmetric(p).save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        else
+        {
+            Ciphertext ct;
+            e.encrypt_symmetric(p, ct);
+            *bytes = static_cast<uint64_t>(ct.save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        }
+        REF_CATCH
+    }
     // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)
     int ref_keys_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, uint64_t *bytes)
     {

@@ -491,6 +491,56 @@ class Decryptor:
         return buf, w.value
 
 
+class Encryptor:
+    """seal::Encryptor, secret-key half (sealhip.h): encrypt_symmetric / encrypt_zero_symmetric and their seeded streams"""
+
+    def __init__(self, context, secret_key, seed=None):
+        self.context = context
+        self._h = C.c_void_p()
+        N.check(N.lib().Encryptor_Create(context._h, None, secret_key._h, C.byref(self._h)))
+        if seed is not None:
+            self.set_seed(seed)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().Encryptor_Destroy(self._h)
+            self._h = None
+
+    def set_seed(self, seed):
+        """the reference's seeded Blake2xbPRNGFactory: 8 words (or one int = first word); None -> operating-system entropy"""
+        if seed is None:
+            N.check(N.lib().Encryptor_SetSeed(self._h, None))
+            return
+        words = [seed] + [0] * 7 if isinstance(seed, int) else list(seed)
+        N.check(N.lib().Encryptor_SetSeed(self._h, (C.c_uint64 * 8)(*words)))
+
+    def encrypt_zero_symmetric(self, parms_id, destination=None):
+        destination = destination if destination is not None else Ciphertext(self.context)
+        N.check(N.lib().Encryptor_EncryptZeroSymmetric1(self._h, (C.c_uint64 * 4)(*parms_id), C.c_bool(False), destination._h, None))
+        return destination
+
+    def encrypt_symmetric(self, plain, destination=None):
+        destination = destination if destination is not None else Ciphertext(self.context)
+        N.check(N.lib().Encryptor_EncryptSymmetric(self._h, plain._h, C.c_bool(False), destination._h, None))
+        return destination
+
+    def _save(self, parms_id, call):
+        cap = C.c_int64()
+        N.check(N.lib().Encryptor_SymmetricSaveSize(self._h, (C.c_uint64 * 4)(*parms_id), C.byref(cap)))
+        buf = (C.c_uint8 * cap.value)()
+        n = C.c_int64()
+        N.check(call(buf, C.c_uint64(cap.value), C.byref(n)))
+        return C.string_at(buf, n.value)
+
+    def encrypt_zero_symmetric_save(self, parms_id):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        return self._save(parms_id, lambda b, c, n: N.lib().Encryptor_EncryptZeroSymmetricSave(self._h, pid, b, c, n))
+
+    def encrypt_symmetric_save(self, plain):
+        pid = plain.parms_id() if plain.is_ntt_form() else self.context.first_parms_id()
+        return self._save(pid, lambda b, c, n: N.lib().Encryptor_EncryptSymmetricSave(self._h, plain._h, b, c, n))
+
+
 class Graph:
     """an executable hipGraph recorded by Evaluator.capture(); launch() is stream-ordered on the evaluator's stream"""
 

@@ -846,6 +846,89 @@ extern "C"
         SHL_CATCH
     }
 
+    // ------------------------------------------------------------------ Encryptor, secret-key half (native/src/seal/c/encryptor.h)
+    SHL_FUNC Encryptor_Create(void *context, void *public_key, void *secret_key, void **encryptor)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(encryptor, SHL_E_POINTER);
+        SHL_TRY
+        if (public_key)
+            throw std::invalid_argument("public-key encryption is not built: pass NULL for public_key");
+        if (!secret_key)
+            throw std::invalid_argument("secret key is not set");
+        *encryptor = new Encryptor(*as<Context>(context), *as<SecretKey>(secret_key));
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<Encryptor>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC Encryptor_SetSeed(void *thisptr, const uint64_t *seed)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        SHL_TRY
+        if (seed)
+            as<Encryptor>(thisptr)->set_seed(seed);
+        else
+            as<Encryptor>(thisptr)->clear_seed();
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_EncryptZeroSymmetric1(void *thisptr, uint64_t *parms_id, bool save_seed, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        if (save_seed)
+            throw std::invalid_argument("a device ciphertext holds both polynomials: use Encryptor_EncryptZeroSymmetricSave for the seeded stream");
+        as<Encryptor>(thisptr)->encrypt_zero_symmetric(parms_id, *as<Ciphertext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_EncryptSymmetric(void *thisptr, void *plaintext, bool save_seed, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plaintext, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        if (save_seed)
+            throw std::invalid_argument("a device ciphertext holds both polynomials: use Encryptor_EncryptSymmetricSave for the seeded stream");
+        as<Encryptor>(thisptr)->encrypt_symmetric(*as<Plaintext>(plaintext), *as<Ciphertext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_SymmetricSaveSize(void *thisptr, uint64_t *parms_id, int64_t *result)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(result, SHL_E_POINTER);
+        SHL_TRY
+        *result = (int64_t)as<Encryptor>(thisptr)->symmetric_save_size(parms_id);
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_EncryptZeroSymmetricSave(void *thisptr, uint64_t *parms_id, uint8_t *outptr, uint64_t size, int64_t *out_bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(outptr, SHL_E_POINTER);
+        IfNullRet(out_bytes, SHL_E_POINTER);
+        SHL_TRY
+        *out_bytes = (int64_t)as<Encryptor>(thisptr)->encrypt_zero_symmetric_save(parms_id, outptr, (size_t)size);
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_EncryptSymmetricSave(void *thisptr, void *plaintext, uint8_t *outptr, uint64_t size, int64_t *out_bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plaintext, SHL_E_POINTER);
+        IfNullRet(outptr, SHL_E_POINTER);
+        IfNullRet(out_bytes, SHL_E_POINTER);
+        SHL_TRY
+        *out_bytes = (int64_t)as<Encryptor>(thisptr)->encrypt_symmetric_save(*as<Plaintext>(plaintext), outptr, (size_t)size);
+        SHL_CATCH
+    }
+
     // ------------------------------------------------------------------ KSwitchKeys
     SHL_FUNC KSwitchKeys_Create1(void **kswitch_keys)
     {

@@ -17,6 +17,10 @@ namespace sealhip
                              SkPowers sk, uint64_t *out, unsigned n_log, unsigned K, hipStream_t s);
     // out = out + a mod q_r over [batch][K][N]
     hipError_t k_add_inplace(const ModDesc *mods, uint64_t *out, const uint64_t *a, size_t words, unsigned n_log, unsigned K, hipStream_t s);
+    // symmetric encryption tail (encrypt_zero_symmetric, util/rlwe.cpp:357-381): c0 <- -(c0 + e * m) mod q_r over [K][N] words,
+    // m = t (BGV: the noise is p*e) or 1
+    hipError_t k_neg_add_noise(const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K,
+                               hipStream_t s);
     // BFV: phase [batch][K][N] (coefficient form) -> plaintext coefficients mod t, [batch][N]
     hipError_t k_decrypt_scale_and_round(const ModDesc *mods, const LevelDev &lvl, ModDesc t, const uint64_t *phase, uint64_t *out,
                                          unsigned n_log, unsigned batch, hipStream_t s);

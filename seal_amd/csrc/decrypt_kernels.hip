@@ -52,6 +52,19 @@ namespace sealhip
             }
         }
 
+        __global__ void __launch_bounds__(kBlock) neg_add_noise_kernel(
+            const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K)
+        {
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const ModDesc md = mods[(unsigned)((i >> n_log) % K)];
+                uint64_t noise = e[i];
+                if (m != 1)
+                    noise = mul_mod(noise, barrett64(m, md), md);
+                c0[i] = neg_mod(add_mod(c0[i], noise, md.q), md.q);
+            }
+        }
+
         // rns.cpp:1133-1191
         __global__ void __launch_bounds__(kBlock) decrypt_scale_and_round_kernel(
             const ModDesc *mods, LevelDev lvl, ModDesc t, const uint64_t *phase, uint64_t *out, unsigned n_log, size_t coeffs)
@@ -131,6 +144,14 @@ namespace sealhip
         if (!words)
             return hipSuccess;
         hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, out, a, words, n_log, K);
+        return hipGetLastError();
+    }
+    hipError_t k_neg_add_noise(const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K,
+                               hipStream_t s)
+    {
+        if (!words)
+            return hipSuccess;
+        hipLaunchKernelGGL(neg_add_noise_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, c0, e, m, words, n_log, K);
         return hipGetLastError();
     }
     hipError_t k_decrypt_scale_and_round(const ModDesc *mods, const LevelDev &lvl, ModDesc t, const uint64_t *phase, uint64_t *out,

@@ -208,4 +208,186 @@ namespace sealhip
         destination.adopt(slab, count, words);
         destination.set_level(nullptr);
     }
+    // ---------------------------------------------------------------- Encryptor (secret-key encryption)
+    Encryptor::Encryptor(const Context &context, const SecretKey &secret_key) : context_(context), evaluator_(context)
+    {
+        if (&secret_key.context() != &context || !secret_key.data())
+            throw std::invalid_argument("secret key is not valid for encryption parameters");
+        const size_t words = context.key_level().K * context.n();
+        ck(hipMalloc(reinterpret_cast<void **>(&sk_), words * 8), "hipMalloc secret key");
+        ck(hipMemcpy(sk_, secret_key.data(), words * 8, hipMemcpyDeviceToDevice), "copy secret key");
+    }
+    Encryptor::~Encryptor()
+    {
+        if (sk_)
+        {
+            (void)hipMemset(sk_, 0, context_.key_level().K * context_.n() * 8);
+            (void)hipFree(sk_);
+        }
+    }
+    void Encryptor::set_seed(const uint64_t *seed8)
+    {
+        if (!seed8)
+            throw std::invalid_argument("seed");
+        std::memcpy(seed_, seed8, sizeof(seed_));
+        seeded_ = true;
+    }
+
+    const Level *Encryptor::level_for(const uint64_t *parms_id) const
+    {
+        const Level *l = parms_id ? context_.level_by_parms_id(parms_id) : nullptr;
+        if (!l)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters"); // encryptor.cpp:130-134
+        return l;
+    }
+    const Level *Encryptor::level_for(const Plaintext &plain) const
+    {
+        // Encryptor::encrypt_internal (encryptor.cpp:213-330): where each scheme encrypts and what it accepts
+        if (&plain.context() != &context_)
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+        const Scheme s = context_.scheme();
+        if (s == Scheme::ckks)
+        {
+            if (!plain.is_ntt_form())
+                throw std::invalid_argument("plain must be in NTT form");
+            if (plain.level()->chain_index > context_.first_level().chain_index ||
+                plain.coeff_count() != plain.level()->K * context_.n())
+                throw std::invalid_argument("plain is not valid for encryption parameters");
+            return plain.level();
+        }
+        if (plain.is_ntt_form())
+            throw std::invalid_argument("plain cannot be in NTT form");
+        if (plain.coeff_count() > context_.n())
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+        return &context_.first_level();
+    }
+
+    // util::encrypt_zero_symmetric (util/rlwe.cpp:270-395)
+    void Encryptor::zero(const Level &lvl, bool save_seed, Ciphertext &d, uint64_t *public_seed)
+    {
+        if (&d.context() != &context_)
+            throw std::invalid_argument("destination belongs to another context");
+        if (d.batch() != 1)
+            throw std::invalid_argument("Encryptor encrypts one ciphertext at a time: destination must be a batch of one");
+        const size_t n = context_.n(), K = lvl.K, words = K * n;
+        const unsigned n_log = (unsigned)context_.log_n();
+        const Scheme scheme = context_.scheme();
+        const bool ntt_form = scheme != Scheme::bfv;
+        // a polynomial too small to hold the seed is saved in full (rlwe.cpp:298-306): 16 + 1 + 64 bytes -> 11 words, plus a marker
+        if (save_seed && words < 12)
+            save_seed = false;
+
+        // host: the reference's randomness, in the reference's order
+        uint64_t boot_seed[8];
+        if (seeded_)
+            std::memcpy(boot_seed, seed_, sizeof(boot_seed));
+        else
+            host::random_bytes(boot_seed, sizeof(boot_seed));
+        serial::Prng bootstrap(1, boot_seed);
+        uint64_t pub[8];
+        bootstrap.generate(sizeof(pub), reinterpret_cast<uint8_t *>(pub));
+        serial::Prng cprng(1, pub);
+        std::vector<uint64_t> a(words), noise(words);
+        serial::sample_poly_uniform(cprng, context_.coeff_modulus().data(), K, n, a.data());
+        serial::sample_poly_cbd(bootstrap, context_.coeff_modulus().data(), K, n, noise.data());
+        if (public_seed)
+            std::memcpy(public_seed, pub, sizeof(pub));
+
+        // device: c1 = a, c0 = -(a s + e) (BGV: e -> t e)
+        ck(hipStreamSynchronize(nullptr), "encrypt sync");
+        d.resize(&lvl, 2, nullptr);
+        d.is_ntt_form() = ntt_form;
+        d.scale() = 1.0;
+        d.correction_factor() = 1;
+        uint64_t *c0 = d.plane(0), *c1 = d.plane(1);
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        Scratch e(words);
+        ck(hipMemcpy(c1, a.data(), words * 8, hipMemcpyHostToDevice), "upload a");
+        ck(hipMemcpy(e.p, noise.data(), words * 8, hipMemcpyHostToDevice), "upload noise");
+        if (ntt_form)
+        {
+            ck(k_dyadic(mods, sk_, c1, c0, n_log, (unsigned)K, 0, 1, nullptr), "a s");
+            ck(ntt_forward(tb, polys(e.p, K, n, 1), 0, nullptr), "ntt noise");
+            ck(k_neg_add_noise(mods, c0, e.p, scheme == Scheme::bgv ? context_.plain_modulus() : 1, words, n_log, (unsigned)K, nullptr), "c0");
+        }
+        else if (save_seed)
+        {
+            // a was sampled in coefficient form (it is what the seed re-expands to): transform a copy for the product
+            Scratch an(words);
+            ck(hipMemcpyAsync(an.p, c1, words * 8, hipMemcpyDeviceToDevice, nullptr), "copy a");
+            ck(ntt_forward(tb, polys(an.p, K, n, 1), 0, nullptr), "ntt a");
+            ck(k_dyadic(mods, sk_, an.p, c0, n_log, (unsigned)K, 0, 1, nullptr), "a s");
+            ck(ntt_inverse(tb, polys(c0, K, n, 1), 0, nullptr), "intt a s");
+            ck(k_neg_add_noise(mods, c0, e.p, 1, words, n_log, (unsigned)K, nullptr), "c0");
+            ck(hipStreamSynchronize(nullptr), "encrypt sync");
+        }
+        else
+        {
+            // a was sampled in NTT form; the ciphertext is returned in coefficient form
+            ck(k_dyadic(mods, sk_, c1, c0, n_log, (unsigned)K, 0, 1, nullptr), "a s");
+            ck(ntt_inverse(tb, polys(c0, K, n, 1), 0, nullptr), "intt a s");
+            ck(k_neg_add_noise(mods, c0, e.p, 1, words, n_log, (unsigned)K, nullptr), "c0");
+            ck(ntt_inverse(tb, polys(c1, K, n, 1), 0, nullptr), "intt a");
+        }
+        ck(hipStreamSynchronize(nullptr), "encrypt sync"); // e goes back to the pool
+    }
+
+    void Encryptor::add_plain(const Plaintext &plain, Ciphertext &d)
+    {
+        // the three branches of Encryptor::encrypt_internal add the plaintext to c_0 exactly as Evaluator::add_plain does on a
+        // fresh ciphertext (BFV: multiply_add_plain_with_scaling_variant; CKKS: add_poly_coeffmod, scale taken from the
+        // plaintext; BGV: lift, transform, add - the correction factor of a fresh ciphertext is 1)
+        if (context_.scheme() == Scheme::ckks)
+            d.scale() = plain.scale();
+        evaluator_.add_plain_inplace(d, plain);
+        evaluator_.synchronize();
+    }
+
+    void Encryptor::encrypt_zero_symmetric(const uint64_t *parms_id, Ciphertext &destination)
+    {
+        zero(*level_for(parms_id), false, destination, nullptr);
+    }
+    void Encryptor::encrypt_symmetric(const Plaintext &plain, Ciphertext &destination)
+    {
+        zero(*level_for(plain), false, destination, nullptr);
+        add_plain(plain, destination);
+    }
+
+    size_t Encryptor::symmetric_save_size(const uint64_t *parms_id) const
+    {
+        const Level *l = level_for(parms_id);
+        const size_t n = context_.n(), K = l->K;
+        return K * n < 12 ? serial::ciphertext_save_size(2, n, K) : serial::seeded_ciphertext_save_size(n, K);
+    }
+    size_t Encryptor::save(const Ciphertext &ct, const uint64_t *public_seed, uint8_t *out, size_t capacity) const
+    {
+        const size_t n = context_.n(), K = ct.level()->K, words = K * n;
+        size_t off = 0, total;
+        const bool seeded = words >= 12;
+        if (seeded)
+            total = serial::save_seeded_ciphertext(ct.level()->parms_id, ct.is_ntt_form(), n, K, ct.scale(), ct.correction_factor(), nullptr,
+                                                   1, public_seed, out, capacity, &off);
+        else
+            total = serial::save_ciphertext(ct.level()->parms_id, ct.is_ntt_form(), 2, n, K, ct.scale(), ct.correction_factor(), nullptr, out,
+                                            capacity, &off);
+        ck(hipDeviceSynchronize(), "encrypt sync");
+        ck(hipMemcpy(out + off, ct.data(), (seeded ? 1 : 2) * words * 8, hipMemcpyDeviceToHost), "download ciphertext");
+        return total;
+    }
+    size_t Encryptor::encrypt_zero_symmetric_save(const uint64_t *parms_id, uint8_t *out, size_t capacity)
+    {
+        Ciphertext ct(context_, 1);
+        uint64_t pub[8];
+        zero(*level_for(parms_id), true, ct, pub);
+        return save(ct, pub, out, capacity);
+    }
+    size_t Encryptor::encrypt_symmetric_save(const Plaintext &plain, uint8_t *out, size_t capacity)
+    {
+        Ciphertext ct(context_, 1);
+        uint64_t pub[8];
+        zero(*level_for(plain), true, ct, pub);
+        add_plain(plain, ct);
+        return save(ct, pub, out, capacity);
+    }
 } // namespace sealhip

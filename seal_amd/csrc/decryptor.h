@@ -4,6 +4,7 @@
 #pragma once
 #include "decrypt_kernels.h"
 #include "evaluator.h"
+#include "serial.h"
 #include <mutex>
 #include <vector>
 
@@ -51,5 +52,44 @@ namespace sealhip
         const Context &context_;
         std::mutex mu_;
         std::vector<uint64_t *> powers_; // s^1, s^2, ... at the key level, NTT form
+    };
+    // seal::Encryptor, the secret-key half (native/src/seal/encryptor.h: encrypt_symmetric / encrypt_zero_symmetric and their
+    // Serializable<> forms; encryptor.cpp:116-330, util/rlwe.cpp:270-395).  The randomness is the reference's: a bootstrap
+    // Blake2xb PRNG yields the public seed of c_1 = a (expanded by sample_poly_uniform) and the centred-binomial noise e
+    // (sample_poly_cbd); both are sampled on the host and c_0 = -(a s + e) [+ the plaintext] is computed on the device.
+    // Public-key encryption is not built: its ternary sampler goes through std::uniform_int_distribution, whose algorithm is
+    // the C++ library's, so bit-exactness with a given reference build cannot be promised.
+    class Encryptor
+    {
+    public:
+        Encryptor(const Context &context, const SecretKey &secret_key);
+        ~Encryptor();
+        Encryptor(const Encryptor &) = delete;
+        Encryptor &operator=(const Encryptor &) = delete;
+
+        // the reference's seeded factory (Blake2xbPRNGFactory(seed): every encryption restarts from this seed) for reproducible
+        // runs and parity tests; without it every encryption draws a fresh 64-byte seed from the operating system
+        void set_seed(const uint64_t *seed8);
+        void clear_seed() { seeded_ = false; }
+
+        // Encryptor::encrypt_zero_symmetric(parms_id, destination) / encrypt_symmetric(plain, destination): batch of one
+        void encrypt_zero_symmetric(const uint64_t *parms_id, Ciphertext &destination);
+        void encrypt_symmetric(const Plaintext &plain, Ciphertext &destination);
+        // the Serializable<Ciphertext> forms, saved: a SEEDED stream (c_0 and the seed of c_1); returns the bytes written
+        size_t symmetric_save_size(const uint64_t *parms_id) const;
+        size_t encrypt_zero_symmetric_save(const uint64_t *parms_id, uint8_t *out, size_t capacity);
+        size_t encrypt_symmetric_save(const Plaintext &plain, uint8_t *out, size_t capacity);
+
+    private:
+        const Level *level_for(const uint64_t *parms_id) const;
+        const Level *level_for(const Plaintext &plain) const; // + the checks of Encryptor::encrypt_internal
+        void zero(const Level &lvl, bool save_seed, Ciphertext &destination, uint64_t *public_seed);
+        void add_plain(const Plaintext &plain, Ciphertext &destination);
+        size_t save(const Ciphertext &ct, const uint64_t *public_seed, uint8_t *out, size_t capacity) const;
+        const Context &context_;
+        Evaluator evaluator_;
+        uint64_t *sk_ = nullptr; // [L][N], NTT form
+        bool seeded_ = false;
+        uint64_t seed_[8];
     };
 } // namespace sealhip

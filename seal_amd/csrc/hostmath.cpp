@@ -1,4 +1,5 @@
 #include "hostmath.h"
+#include <cstdio>
 #include <map>
 
 namespace sealhip
@@ -39,6 +40,16 @@ namespace sealhip
             if (t < 0)
                 t += m;
             return (uint64_t)t;
+        }
+
+        void random_bytes(void *dst, size_t count)
+        {
+            FILE *f = std::fopen("/dev/urandom", "rb");
+            const size_t got = f ? std::fread(dst, 1, count, f) : 0;
+            if (f)
+                std::fclose(f);
+            if (got != count)
+                throw std::runtime_error("no entropy source (/dev/urandom)");
         }
 
         int bit_count(uint64_t v)

@@ -25,6 +25,8 @@ namespace sealhip
         uint64_t powmod(uint64_t a, uint64_t e, uint64_t m);
         // a^-1 mod m (m need not be prime, e.g. 2^32 or 2N); throws if not invertible.
         uint64_t invmod(uint64_t a, uint64_t m);
+        // cryptographically secure random bytes from the operating system (the role of seal::random_bytes, randomgen.cpp:24-60)
+        void random_bytes(void *dst, size_t count);
         bool is_prime(uint64_t n);
         int bit_count(uint64_t v);
 

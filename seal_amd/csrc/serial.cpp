@@ -14,6 +14,73 @@ namespace sealhip
 {
     namespace serial
     {
+        // UniformRandomGenerator::generate over refill_buffer (randomgen.cpp:179-227): 4096-byte buffers, buffer i = XOF(seed, counter = i)
+        void Prng::refill()
+        {
+            if (type == 1)
+                blake2::blake2xb(buf, sizeof(buf), &counter, sizeof(counter), seed, sizeof(seed));
+            else
+            {
+                uint64_t ext[9];
+                std::memcpy(ext, seed, sizeof(seed));
+                ext[8] = counter;
+                keccak::shake256(buf, sizeof(buf), reinterpret_cast<const uint8_t *>(ext), sizeof(ext));
+            }
+            counter++;
+            head = 0;
+        }
+        void Prng::generate(size_t bytes, uint8_t *dst)
+        {
+            while (bytes)
+            {
+                if (head == sizeof(buf))
+                    refill();
+                size_t take = sizeof(buf) - head;
+                if (take > bytes)
+                    take = bytes;
+                std::memcpy(dst, buf + head, take);
+                head += take;
+                dst += take;
+                bytes -= take;
+            }
+        }
+        // sample_poly_uniform (util/rlwe.cpp): bulk fill, then per component reject rand >= max_multiple (drawing the replacement
+        // from the same stream, in coefficient order) and reduce
+        void sample_poly_uniform(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+        {
+            prng.generate(K * N * sizeof(uint64_t), reinterpret_cast<uint8_t *>(dst));
+            for (size_t j = 0; j < K; j++)
+            {
+                const uint64_t q = primes[j];
+                const uint64_t max_random = ~0ull;
+                const uint64_t max_multiple = max_random - (max_random % q) - 1;
+                for (size_t k = 0; k < N; k++)
+                {
+                    uint64_t rand = dst[k];
+                    while (rand >= max_multiple)
+                        prng.generate(sizeof(uint64_t), reinterpret_cast<uint8_t *>(&rand));
+                    dst[k] = rand % q;
+                }
+                dst += N;
+            }
+        }
+        // sample_poly_cbd (util/rlwe.cpp): centred binomial noise of standard deviation 3.2 - 6 bytes per coefficient, the
+        // difference of two 21-bit Hamming weights - replicated into every RNS component (negative values as q_i + noise)
+        void sample_poly_cbd(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+        {
+            for (size_t k = 0; k < N; k++)
+            {
+                unsigned char x[6];
+                prng.generate(6, x);
+                x[2] &= 0x1F;
+                x[5] &= 0x1F;
+                const int noise = __builtin_popcount(x[0]) + __builtin_popcount(x[1]) + __builtin_popcount(x[2]) - __builtin_popcount(x[3]) -
+                                  __builtin_popcount(x[4]) - __builtin_popcount(x[5]);
+                for (size_t j = 0; j < K; j++)
+                    dst[j * N + k] = noise < 0 ? primes[j] - (uint64_t)(-noise) : (uint64_t)noise;
+            }
+        }
+
         namespace
         {
             struct Header
@@ -138,70 +205,10 @@ namespace sealhip
                 return true;
             }
 
-            // UniformRandomGenerator::generate over refill_buffer (randomgen.cpp:179-227): 4096-byte buffers,
-            // buffer i = XOF(seed, counter = i)
-            struct SeededStream
-            {
-                uint8_t type;
-                uint64_t seed[8];
-                uint64_t counter = 0;
-                uint8_t buf[4096];
-                size_t head = 4096;
-                void refill()
-                {
-                    if (type == 1)
-                        blake2::blake2xb(buf, sizeof(buf), &counter, sizeof(counter), seed, sizeof(seed));
-                    else
-                    {
-                        uint64_t ext[9];
-                        std::memcpy(ext, seed, sizeof(seed));
-                        ext[8] = counter;
-                        keccak::shake256(buf, sizeof(buf), reinterpret_cast<const uint8_t *>(ext), sizeof(ext));
-                    }
-                    counter++;
-                    head = 0;
-                }
-                void generate(size_t bytes, uint8_t *dst)
-                {
-                    while (bytes)
-                    {
-                        if (head == sizeof(buf))
-                            refill();
-                        size_t take = sizeof(buf) - head;
-                        if (take > bytes)
-                            take = bytes;
-                        std::memcpy(dst, buf + head, take);
-                        head += take;
-                        dst += take;
-                        bytes -= take;
-                    }
-                }
-            };
-            // sample_poly_uniform (util/rlwe.cpp): bulk fill, then per component reject rand >= max_multiple (drawing the
-            // replacement from the same stream, in coefficient order) and reduce
-            void sample_poly_uniform(SeededStream &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
-            {
-                prng.generate(K * N * sizeof(uint64_t), reinterpret_cast<uint8_t *>(dst));
-                for (size_t j = 0; j < K; j++)
-                {
-                    const uint64_t q = primes[j];
-                    const uint64_t max_random = ~0ull;
-                    const uint64_t max_multiple = max_random - (max_random % q) - 1;
-                    for (size_t k = 0; k < N; k++)
-                    {
-                        uint64_t rand = dst[k];
-                        while (rand >= max_multiple)
-                            prng.generate(sizeof(uint64_t), reinterpret_cast<uint8_t *>(&rand));
-                        dst[k] = rand % q;
-                    }
-                    dst += N;
-                }
-            }
-
             // a seed expansion postponed by the caller (KSwitchKeys: one independent PRNG per digit, expanded on several threads)
             struct ExpandJob
             {
-                SeededStream prng;
+                Prng prng;
                 size_t K, N;
                 uint64_t *dst;
             };
@@ -246,7 +253,7 @@ namespace sealhip
                         throw std::logic_error("ciphertext data is invalid");
                     if (!(v.major == 4 || (v.major == 3 && v.minor >= 6)))
                         throw std::logic_error("incompatible version"); // the 3.4 / 3.5 samplers are not restated here
-                    SeededStream prng;
+                    Prng prng;
                     framed(r, [&](Reader &rr, Version) {
                         prng.type = rr.get<uint8_t>();
                         if (prng.type != 1 && prng.type != 2)
@@ -294,9 +301,7 @@ namespace sealhip
 
         void expand_seed_blake2xb(const uint64_t *seed, const uint64_t *primes, size_t K, size_t N, uint64_t *destination)
         {
-            SeededStream prng;
-            prng.type = 1;
-            std::memcpy(prng.seed, seed, sizeof(prng.seed));
+            Prng prng(1, seed);
             sample_poly_uniform(prng, primes, K, N, destination);
         }
 
@@ -501,6 +506,57 @@ namespace sealhip
                 *data_offset = (size_t)(p - out);
             if (coeff_count && words)
                 put(words, (size_t)coeff_count * 8);
+            return total;
+        }
+
+        size_t seeded_ciphertext_save_size(uint64_t n, uint64_t K)
+        {
+            const size_t members = 4 * 8 + 1 + 3 * 8 + 8 + 8;
+            const size_t dyn = sizeof(Header) + 8 + (size_t)(n * K) * 8;
+            const size_t info = sizeof(Header) + 1 + 64;
+            return sizeof(Header) + members + dyn + info;
+        }
+
+        size_t save_seeded_ciphertext(const uint64_t *parms_id, bool is_ntt_form, uint64_t n, uint64_t K, double scale,
+                                      uint64_t correction_factor, const uint64_t *c0_words, uint8_t prng_type, const uint64_t *seed,
+                                      uint8_t *out, size_t capacity, size_t *data_offset)
+        {
+            if (!out)
+                throw std::invalid_argument("out cannot be null");
+            if (capacity < sizeof(Header))
+                throw std::invalid_argument("insufficient size");
+            const size_t total = seeded_ciphertext_save_size(n, K);
+            if (capacity < total)
+                throw std::runtime_error("I/O error");
+            uint8_t *p = out;
+            auto put = [&](const void *src, size_t bytes) {
+                std::memcpy(p, src, bytes);
+                p += bytes;
+            };
+            Header h{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, (uint64_t)total };
+            put(&h, sizeof(h));
+            put(parms_id, 32);
+            const uint8_t ntt = is_ntt_form ? 1 : 0;
+            put(&ntt, 1);
+            const uint64_t size = 2;
+            put(&size, 8);
+            put(&n, 8);
+            put(&K, 8);
+            put(&scale, 8);
+            put(&correction_factor, 8);
+            const uint64_t count = n * K;
+            Header hd{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, (uint64_t)(sizeof(Header) + 8 + count * 8) };
+            put(&hd, sizeof(hd));
+            put(&count, 8);
+            if (data_offset)
+                *data_offset = (size_t)(p - out);
+            if (c0_words)
+                std::memcpy(p, c0_words, (size_t)count * 8);
+            p += (size_t)count * 8;
+            Header hi{ kMagic, kHeaderSize, kVersionMajor, kVersionMinor, 0, 0, (uint64_t)(sizeof(Header) + 1 + 64) };
+            put(&hi, sizeof(hi));
+            put(&prng_type, 1);
+            put(seed, 64);
             return total;
         }
 

@@ -89,6 +89,32 @@ namespace sealhip
         size_t save_plaintext(const uint64_t *parms_id, uint64_t coeff_count, double scale, const uint64_t *words, uint8_t *out,
                               size_t capacity, size_t *data_offset = nullptr);
 
+        // The reference's buffered PRNG (UniformRandomGenerator, randomgen.cpp:179-227): type 1 = Blake2xbPRNG, 2 = Shake256PRNG
+        struct Prng
+        {
+            uint8_t type = 1;
+            uint64_t seed[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            uint64_t counter = 0;
+            uint8_t buf[4096];
+            size_t head = 4096;
+            Prng() = default;
+            Prng(uint8_t t, const uint64_t *s) : type(t)
+            {
+                for (int i = 0; i < 8; i++)
+                    seed[i] = s[i];
+            }
+            void refill();
+            void generate(size_t bytes, uint8_t *dst);
+        };
+        void sample_poly_uniform(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst);
+        void sample_poly_cbd(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst);
+        // Serializable<Ciphertext>::save of a seeded ciphertext (ciphertext.cpp:171-196): members, DynArray with c_0 only, then
+        // the UniformRandomGeneratorInfo (type, seed) c_1 is re-expanded from.  words == nullptr: as save_ciphertext.
+        size_t seeded_ciphertext_save_size(uint64_t poly_modulus_degree, uint64_t coeff_modulus_size);
+        size_t save_seeded_ciphertext(const uint64_t *parms_id, bool is_ntt_form, uint64_t poly_modulus_degree, uint64_t coeff_modulus_size,
+                                      double scale, uint64_t correction_factor, const uint64_t *c0_words, uint8_t prng_type,
+                                      const uint64_t *seed, uint8_t *out, size_t capacity, size_t *data_offset = nullptr);
+
         // sample_poly_uniform (util/rlwe.cpp) with the Blake2xb PRNG of randomgen.cpp seeded by `seed` (8 words):
         // K*N words, component r uniform in [0, primes[r])
         void expand_seed_blake2xb(const uint64_t *seed, const uint64_t *primes, size_t K, size_t N, uint64_t *destination);

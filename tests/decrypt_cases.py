@@ -134,3 +134,41 @@ def case_end_to_end_streams(scheme, n, bits):
     back, _ = ref.ct_load(stream)
     assert np.array_equal(ref.decrypt(back).data(), ref.decrypt(r).data())
     _same_plain(dec.decrypt(ca), ref.decrypt(r), "device decrypt of the device result")
+
+
+def case_encrypt_symmetric(scheme, n, bits, seed=0x5EA1):
+    """secret-key encryption with the reference's randomness (same seeded Blake2xb factory on both sides): the zero encryption
+    and the encryption of an encoded plaintext give the reference's bytes, as a full ciphertext and as the seeded stream, at every
+    level; with operating-system entropy the ciphertext still decrypts to the plaintext on the reference side"""
+    primes, t, ref, d, dec, _ = _setup(scheme, n, bits)   # RefContext's factory is Blake2xbPRNGFactory({seed, 0, ...})
+    enc = S.Encryptor(d.ctx, S.SecretKey(d.ctx, ref.secret_key()), seed=seed)
+    for ci in range(ref.first_chain_index, -1, -1):
+        pid = d.ctx.parms_id_at(ci)
+        assert enc.encrypt_zero_symmetric_save(pid) == ref.encrypt_zero_symmetric_save(ci, True), ("seeded zero", ci)
+        ct = enc.encrypt_zero_symmetric(pid)
+        assert ct.save_bytes() == ref.encrypt_zero_symmetric_save(ci, False), ("full zero", ci)
+    rng = np.random.default_rng(29)
+    if scheme == "ckks":
+        rpt = ref.ckks_encode(rng.standard_normal(n // 2), max(ref.first_chain_index - 1, 0), 2.0 ** 25)
+    else:
+        rpt = ref.batch_encode(rng.integers(0, t, n, dtype=np.uint64))
+    pt = S.Plaintext(d.ctx)
+    pt.load_bytes(ref.pt_save(rpt))
+    assert enc.encrypt_symmetric_save(pt) == ref.encrypt_symmetric_save(rpt, True), "seeded encryption of a plaintext"
+    ct = enc.encrypt_symmetric(pt)
+    assert ct.save_bytes() == ref.encrypt_symmetric_save(rpt, False), "encryption of a plaintext"
+    _same_plain(dec.decrypt(ct), ref.decrypt(ref.ct_load(ct.save_bytes())[0]), "decrypt(encrypt(plain))")
+    # fresh entropy: different bytes every time, same plaintext after the reference decrypts the stream
+    enc.set_seed(None)
+    s1, s2 = enc.encrypt_symmetric_save(pt), enc.encrypt_symmetric_save(pt)
+    assert s1 != s2
+    want = ref.decrypt(ref.ct_load(ref.encrypt_symmetric_save(rpt, True))[0]).data()
+    if scheme != "ckks":
+        for s in (s1, s2):
+            assert np.array_equal(ref.decrypt(ref.ct_load(s)[0]).data(), want)
+    # argument checks of Encryptor::encrypt_internal
+    try:
+        enc.encrypt_zero_symmetric((1, 2, 3, 4))
+        raise AssertionError("expected InvalidArgument for an unknown parms_id")
+    except S.InvalidArgument:
+        pass

@@ -281,6 +281,13 @@ class RefContext:
         _ck(lib().ref_decrypt(self.h, ct.h, C.byref(h)))
         return RefPlaintext(self, h)
 
+    def encrypt_symmetric_save(self, pt, seeded=True):
+        cap = 4096 + 8 * 2 * len(self.primes) * self.n
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_encrypt_symmetric_save(self.h, pt.h, C.c_int(1 if seeded else 0), buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
     def keys_load(self, data, unsafe=False):
         buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
         n = C.c_uint64()

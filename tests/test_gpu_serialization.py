@@ -61,3 +61,9 @@ def test_decrypt(gpu, scheme, n, bits):
 def test_end_to_end_streams(gpu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_end_to_end_streams(scheme, n, bits)
+
+
+@pytest.mark.parametrize("scheme,n,bits", SIZES + [("ckks", 65536, [60] + [50] * 14 + [60])])
+def test_encrypt_symmetric(gpu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_encrypt_symmetric(scheme, n, bits)

@@ -122,3 +122,10 @@ def test_decrypt(emu, scheme, n, bits):
 def test_end_to_end_streams(emu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_end_to_end_streams(scheme, n, bits)
+
+
+@needs_ref
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45])])
+def test_encrypt_symmetric(emu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_encrypt_symmetric(scheme, n, bits)
