@@ -218,6 +218,16 @@ def ntt_configs1(S, torch, device, polys=4096, reps=10):
             alg = 16.0 * n * comps * polys
             rates[name] = dict(achieved=round(alg / (ms * 1e-3) / 1e9, 1), frac=round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                ms_per_launch=round(ms, 4), algorithmic_bytes_per_launch=alg)
+        # HBM bytes per launch of the single-launch kernels from the committed PMC passes (all-double-precision chain only:
+        # the passes were taken on it), scaled by the number of transforms as for the main roofline leg
+        if "2^50" in label:
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "r01_ntt_pmc.json")))["single_launch_n8192"]
+                per = float(pj["algorithmic_kib"]) * 1024 / (16.0 * n)  # transforms in the recorded launch
+                for name in ("forward", "inverse"):
+                    rates[name]["traffic"] = int(round(pj[name]["hbm_bytes_per_launch"] * (comps * polys) / per))
+            except Exception:
+                pass
         out.append(dict(chain=label, transforms_per_launch=comps * polys, **rates))
         del data
     return dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, workload="CKKS N=8192, L=4: batched NTT / INTT over all RNS components", chains=out)
