@@ -154,6 +154,20 @@ SHL_FUNC Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
 SHL_FUNC Decryptor_DecryptBatchWords(void *thisptr, void *encrypted, uint64_t *word_count);
 SHL_FUNC Decryptor_DecryptBatch(void *thisptr, void *encrypted, uint64_t *device_out, uint64_t word_count);
 
+/* BatchEncoder (native/src/seal/c/batchencoder.h:16-30; seal::BatchEncoder::encode / decode, native/src/seal/batchencoder.cpp:97-447):
+ * N integers modulo t <-> one plaintext polynomial through the NTT modulo t and the matrix index map.  Encode1 / Decode1 take
+ * unsigned values, Encode2 / Decode2 signed ones, host vectors as in sealc (Decode writes N values).  The *Device forms convert
+ * `batch` vectors [batch][N] that are already in HBM - e.g. the output of Decryptor_DecryptBatch - without leaving it. */
+SHL_FUNC BatchEncoder_Create(void *context, void **batch_encoder);
+SHL_FUNC BatchEncoder_Destroy(void *thisptr);
+SHL_FUNC BatchEncoder_GetSlotCount(void *thisptr, uint64_t *slot_count);
+SHL_FUNC BatchEncoder_Encode1(void *thisptr, uint64_t count, uint64_t *values, void *destination);
+SHL_FUNC BatchEncoder_Encode2(void *thisptr, uint64_t count, int64_t *values, void *destination);
+SHL_FUNC BatchEncoder_Decode1(void *thisptr, void *plain, uint64_t *count, uint64_t *destination, void *pool);
+SHL_FUNC BatchEncoder_Decode2(void *thisptr, void *plain, uint64_t *count, int64_t *destination, void *pool);
+SHL_FUNC BatchEncoder_EncodeDevice(void *thisptr, const uint64_t *device_values, uint64_t batch, bool is_signed, uint64_t *device_coefficients);
+SHL_FUNC BatchEncoder_DecodeDevice(void *thisptr, const uint64_t *device_coefficients, uint64_t batch, bool is_signed, uint64_t *device_values);
+
 /* Encryptor, the secret-key half (native/src/seal/c/encryptor.h; seal::Encryptor::encrypt_symmetric / encrypt_zero_symmetric and
  * their Serializable<> forms, native/src/seal/encryptor.cpp:116-330, util/rlwe.cpp:270-395).  The randomness follows the
  * reference: a bootstrap Blake2xb PRNG gives the public seed of c_1 (sample_poly_uniform) and the centred-binomial noise

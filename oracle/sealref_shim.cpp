@@ -883,6 +883,38 @@ extern "C"
         }
         REF_CATCH
     }
+    // BatchEncoder::decode of a plaintext handle (unsigned / signed)
+    int ref_batch_decode(void *ctx, void *pt, int is_signed, uint64_t *out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        BatchEncoder enc(*c->context);
+        const Plaintext &p = static_cast<RefPt *>(pt)->pt;
+        if (is_signed)
+        {
+            std::vector<int64_t> v;
+            enc.decode(p, v);
+            std::memcpy(out, v.data(), v.size() * 8);
+        }
+        else
+        {
+            std::vector<uint64_t> v;
+            enc.decode(p, v);
+            std::memcpy(out, v.data(), v.size() * 8);
+        }
+        REF_CATCH
+    }
+    int ref_batch_encode_signed(void *ctx, const int64_t *values, uint64_t count, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        BatchEncoder enc(*c->context);
+        auto h = std::make_unique<RefPt>();
+        std::vector<int64_t> v(values, values + count);
+        enc.encode(v, h->pt);
+        *out = h.release();
+        REF_CATCH
+    }
     // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)
     int ref_keys_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, uint64_t *bytes)
     {

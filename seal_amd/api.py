@@ -491,6 +491,50 @@ class Decryptor:
         return buf, w.value
 
 
+class BatchEncoder:
+    """seal::BatchEncoder on the device (sealhip.h): N integers modulo t <-> one plaintext polynomial"""
+
+    def __init__(self, context):
+        self.context = context
+        self._h = C.c_void_p()
+        N.check(N.lib().BatchEncoder_Create(context._h, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().BatchEncoder_Destroy(self._h)
+            self._h = None
+
+    def slot_count(self):
+        v = C.c_uint64()
+        N.check(N.lib().BatchEncoder_GetSlotCount(self._h, C.byref(v)))
+        return v.value
+
+    def encode(self, values, destination=None, signed=False):
+        destination = destination if destination is not None else Plaintext(self.context)
+        a = np.ascontiguousarray(values, dtype=np.int64 if signed else np.uint64)
+        fn = N.lib().BatchEncoder_Encode2 if signed else N.lib().BatchEncoder_Encode1
+        N.check(fn(self._h, C.c_uint64(a.size), _p(a), destination._h))
+        return destination
+
+    def decode(self, plain, signed=False):
+        out = np.zeros(self.slot_count(), dtype=np.int64 if signed else np.uint64)
+        n = C.c_uint64()
+        fn = N.lib().BatchEncoder_Decode2 if signed else N.lib().BatchEncoder_Decode1
+        N.check(fn(self._h, plain._h, C.byref(n), _p(out), None))
+        return out
+
+    def decode_device(self, coefficients, batch, signed=False, out=None):
+        """coefficients: DeviceBuffer [batch][N] (e.g. from Decryptor.decrypt_batch) -> DeviceBuffer of slot values"""
+        out = out if out is not None else DeviceBuffer(batch * self.slot_count())
+        N.check(N.lib().BatchEncoder_DecodeDevice(self._h, C.c_void_p(coefficients.ptr), C.c_uint64(batch), C.c_bool(signed), C.c_void_p(out.ptr)))
+        return out
+
+    def encode_device(self, values, batch, signed=False, out=None):
+        out = out if out is not None else DeviceBuffer(batch * self.slot_count())
+        N.check(N.lib().BatchEncoder_EncodeDevice(self._h, C.c_void_p(values.ptr), C.c_uint64(batch), C.c_bool(signed), C.c_void_p(out.ptr)))
+        return out
+
+
 class Encryptor:
     """seal::Encryptor, secret-key half (sealhip.h): encrypt_symmetric / encrypt_zero_symmetric and their seeded streams"""
 

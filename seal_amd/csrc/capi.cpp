@@ -846,6 +846,83 @@ extern "C"
         SHL_CATCH
     }
 
+    // ------------------------------------------------------------------ BatchEncoder (native/src/seal/c/batchencoder.h)
+    SHL_FUNC BatchEncoder_Create(void *context, void **batch_encoder)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(batch_encoder, SHL_E_POINTER);
+        SHL_TRY
+        *batch_encoder = new BatchEncoder(*as<Context>(context));
+        SHL_CATCH
+    }
+    SHL_FUNC BatchEncoder_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<BatchEncoder>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC BatchEncoder_GetSlotCount(void *thisptr, uint64_t *slot_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(slot_count, SHL_E_POINTER);
+        *slot_count = as<BatchEncoder>(thisptr)->slot_count();
+        return SHL_S_OK;
+    }
+    SHL_FUNC BatchEncoder_Encode1(void *thisptr, uint64_t count, uint64_t *values, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<BatchEncoder>(thisptr)->encode(values, (size_t)count, false, *as<Plaintext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC BatchEncoder_Encode2(void *thisptr, uint64_t count, int64_t *values, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<BatchEncoder>(thisptr)->encode(reinterpret_cast<const uint64_t *>(values), (size_t)count, true, *as<Plaintext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC BatchEncoder_Decode1(void *thisptr, void *plain, uint64_t *count, uint64_t *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plain, SHL_E_POINTER);
+        IfNullRet(count, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<BatchEncoder>(thisptr)->decode(*as<Plaintext>(plain), destination, false);
+        *count = as<BatchEncoder>(thisptr)->slot_count();
+        SHL_CATCH
+    }
+    SHL_FUNC BatchEncoder_Decode2(void *thisptr, void *plain, uint64_t *count, int64_t *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plain, SHL_E_POINTER);
+        IfNullRet(count, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<BatchEncoder>(thisptr)->decode(*as<Plaintext>(plain), reinterpret_cast<uint64_t *>(destination), true);
+        *count = as<BatchEncoder>(thisptr)->slot_count();
+        SHL_CATCH
+    }
+    SHL_FUNC BatchEncoder_EncodeDevice(void *thisptr, const uint64_t *device_values, uint64_t batch, bool is_signed, uint64_t *device_coefficients)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        SHL_TRY
+        as<BatchEncoder>(thisptr)->encode_device(device_values, (unsigned)batch, is_signed, device_coefficients);
+        SHL_CATCH
+    }
+    SHL_FUNC BatchEncoder_DecodeDevice(void *thisptr, const uint64_t *device_coefficients, uint64_t batch, bool is_signed, uint64_t *device_values)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        SHL_TRY
+        as<BatchEncoder>(thisptr)->decode_device(device_coefficients, (unsigned)batch, is_signed, device_values);
+        SHL_CATCH
+    }
+
     // ------------------------------------------------------------------ Encryptor, secret-key half (native/src/seal/c/encryptor.h)
     SHL_FUNC Encryptor_Create(void *context, void *public_key, void *secret_key, void **encryptor)
     {

@@ -204,6 +204,12 @@ namespace sealhip
             auto aux = get_primes(2 * (uint64_t)n_, 61, max_bsk_mtilde);
             pool_.insert(pool_.end(), aux.begin(), aux.end());
         }
+        if (scheme_ != Scheme::ckks && using_batching_)
+        {
+            // the plain modulus gets NTT tables of its own (BatchEncoder): last entry of the pool
+            plain_prime_ = (int)pool_.size();
+            pool_.push_back(plain_modulus_);
+        }
 
         // parms_id of a level = BLAKE2b-256 over (scheme, N, q_0 .. q_{K-1}, t) as 64-bit words
         // (EncryptionParameters::compute_parms_id, encryptionparams.cpp:117-147; HashFunction::hash, util/hash.h:30-37):
@@ -226,8 +232,8 @@ namespace sealhip
         {
             uint64_t q = pool_[p];
             h_mods_[p] = make_mod(q);
-            if (p == primes_.size() + 1)
-                continue; // gamma: never transformed (decryption only, out of scope)
+            if (p == primes_.size() + 1 && (int)p != plain_prime_)
+                continue; // gamma: never transformed
             uint64_t root;
             if (!minimal_primitive_root(2 * (uint64_t)n_, q, root))
                 throw std::invalid_argument("invalid_coeff_modulus_no_ntt");

@@ -128,6 +128,9 @@ namespace sealhip
         // prime pool
         const std::vector<uint64_t> &pool_primes() const { return pool_; }
         unsigned aux_first() const { return (unsigned)primes_.size(); } // pool index of m_sk
+        // pool index of the plain modulus t when it supports batching (BFV / BGV, t prime, t = 1 mod 2N): its NTT tables are
+        // SEALContext::ContextData::plain_ntt_tables() (context.cpp:415-425 of the reference); -1 otherwise
+        int plain_prime_index() const { return plain_prime_; }
         const NttTables &ntt_tables() const { return tables_; }
         const ModDesc *dev_mods() const { return d_mods_; }
         // host copies (tests / introspection)
@@ -154,6 +157,7 @@ namespace sealhip
         std::vector<Level> levels_;
         bool using_keyswitching_ = false;
         bool using_batching_ = false;
+        int plain_prime_ = -1;
 
         ModDesc *d_mods_ = nullptr;
         ShoupOp *d_fwd_ = nullptr;

@@ -21,6 +21,13 @@ namespace sealhip
     // m = t (BGV: the noise is p*e) or 1
     hipError_t k_neg_add_noise(const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K,
                                hipStream_t s);
+    // BatchEncoder index map (batchencoder.cpp:97-123): scatter out[b][map[i]] = in[b][i] (encode), gather out[b][i] = in[b][map[i]]
+    // (decode) over `batch` vectors of N words; signed_mod != 0 converts between the balanced signed representation and [0, t):
+    // encode: negative int64 v -> t + v; decode: value > t/2 -> value - t (as int64)
+    hipError_t k_slot_scatter(const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, unsigned batch, uint64_t signed_mod,
+                              hipStream_t s);
+    hipError_t k_slot_gather(const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, unsigned batch, uint64_t signed_mod,
+                             hipStream_t s);
     // BFV: phase [batch][K][N] (coefficient form) -> plaintext coefficients mod t, [batch][N]
     hipError_t k_decrypt_scale_and_round(const ModDesc *mods, const LevelDev &lvl, ModDesc t, const uint64_t *phase, uint64_t *out,
                                          unsigned n_log, unsigned batch, hipStream_t s);

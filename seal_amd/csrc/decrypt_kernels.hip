@@ -65,6 +65,31 @@ namespace sealhip
             }
         }
 
+        __global__ void __launch_bounds__(kBlock) slot_scatter_kernel(
+            const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, size_t words, uint64_t signed_mod)
+        {
+            const size_t nmask = (size_t(1) << n_log) - 1;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                uint64_t v = in[i];
+                if (signed_mod && (int64_t)v < 0)
+                    v += signed_mod;
+                out[(i & ~nmask) + map[i & nmask]] = v;
+            }
+        }
+        __global__ void __launch_bounds__(kBlock) slot_gather_kernel(
+            const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, size_t words, uint64_t signed_mod)
+        {
+            const size_t nmask = (size_t(1) << n_log) - 1;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                uint64_t v = in[(i & ~nmask) + map[i & nmask]];
+                if (signed_mod && v > (signed_mod >> 1))
+                    v -= signed_mod;
+                out[i] = v;
+            }
+        }
+
         // rns.cpp:1133-1191
         __global__ void __launch_bounds__(kBlock) decrypt_scale_and_round_kernel(
             const ModDesc *mods, LevelDev lvl, ModDesc t, const uint64_t *phase, uint64_t *out, unsigned n_log, size_t coeffs)
@@ -152,6 +177,24 @@ namespace sealhip
         if (!words)
             return hipSuccess;
         hipLaunchKernelGGL(neg_add_noise_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, c0, e, m, words, n_log, K);
+        return hipGetLastError();
+    }
+    hipError_t k_slot_scatter(const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, unsigned batch, uint64_t signed_mod,
+                              hipStream_t s)
+    {
+        const size_t words = (size_t)batch << n_log;
+        if (!words)
+            return hipSuccess;
+        hipLaunchKernelGGL(slot_scatter_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, map, in, out, n_log, words, signed_mod);
+        return hipGetLastError();
+    }
+    hipError_t k_slot_gather(const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, unsigned batch, uint64_t signed_mod,
+                             hipStream_t s)
+    {
+        const size_t words = (size_t)batch << n_log;
+        if (!words)
+            return hipSuccess;
+        hipLaunchKernelGGL(slot_gather_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, map, in, out, n_log, words, signed_mod);
         return hipGetLastError();
     }
     hipError_t k_decrypt_scale_and_round(const ModDesc *mods, const LevelDev &lvl, ModDesc t, const uint64_t *phase, uint64_t *out,

@@ -208,6 +208,132 @@ namespace sealhip
         destination.adopt(slab, count, words);
         destination.set_level(nullptr);
     }
+    // ---------------------------------------------------------------- BatchEncoder
+    BatchEncoder::BatchEncoder(const Context &context) : context_(context)
+    {
+        // batchencoder.cpp:17-48
+        if (context.scheme() != Scheme::bfv && context.scheme() != Scheme::bgv)
+            throw std::invalid_argument("unsupported scheme");
+        if (context.plain_prime_index() < 0)
+            throw std::invalid_argument("encryption parameters are not valid for batching");
+        // populate_matrix_reps_index_map (batchencoder.cpp:97-123)
+        const size_t n = context.n(), row = n >> 1, m = n << 1;
+        const int logn = context.log_n();
+        std::vector<uint32_t> map(n);
+        uint64_t pos = 1;
+        auto rev = [&](uint64_t v) {
+            uint64_t r = 0;
+            for (int b = 0; b < logn; b++)
+                r |= ((v >> b) & 1) << (logn - 1 - b);
+            return (uint32_t)r;
+        };
+        for (size_t i = 0; i < row; i++)
+        {
+            map[i] = rev((pos - 1) >> 1);
+            map[row | i] = rev((m - pos - 1) >> 1);
+            pos = (pos * 3) & (m - 1);
+        }
+        ck(hipMalloc(reinterpret_cast<void **>(&map_), n * 4), "hipMalloc index map");
+        ck(hipMemcpy(map_, map.data(), n * 4, hipMemcpyHostToDevice), "upload index map");
+    }
+    BatchEncoder::~BatchEncoder()
+    {
+        if (map_)
+            (void)hipFree(map_);
+    }
+    void BatchEncoder::encode_device(const uint64_t *values, unsigned batch, bool is_signed, uint64_t *coefficients) const
+    {
+        if (!values || !coefficients || values == coefficients)
+            throw std::invalid_argument("values / coefficients");
+        const unsigned n_log = (unsigned)context_.log_n();
+        ck(k_slot_scatter(map_, values, coefficients, n_log, batch, is_signed ? context_.plain_modulus() : 0, nullptr), "slot scatter");
+        NttBatch b{};
+        b.data = coefficients;
+        b.outer_stride = context_.n();
+        b.ncomp = 1;
+        b.nouter = batch;
+        b.prime_first = (unsigned)context_.plain_prime_index();
+        ck(ntt_inverse(context_.ntt_tables(), b, 0, nullptr), "intt mod t");
+    }
+    void BatchEncoder::decode_device(const uint64_t *coefficients, unsigned batch, bool is_signed, uint64_t *values) const
+    {
+        if (!values || !coefficients || values == coefficients)
+            throw std::invalid_argument("values / coefficients");
+        const size_t words = (size_t)batch * context_.n();
+        Scratch tmp(words);
+        ck(hipMemcpyAsync(tmp.p, coefficients, words * 8, hipMemcpyDeviceToDevice, nullptr), "copy coefficients");
+        NttBatch b{};
+        b.data = tmp.p;
+        b.outer_stride = context_.n();
+        b.ncomp = 1;
+        b.nouter = batch;
+        b.prime_first = (unsigned)context_.plain_prime_index();
+        ck(ntt_forward(context_.ntt_tables(), b, 0, nullptr), "ntt mod t");
+        ck(k_slot_gather(map_, tmp.p, values, (unsigned)context_.log_n(), batch, is_signed ? context_.plain_modulus() : 0, nullptr), "slot gather");
+        ck(hipStreamSynchronize(nullptr), "decode sync"); // tmp goes back to the pool
+    }
+    void BatchEncoder::encode(const uint64_t *values, size_t count, bool is_signed, Plaintext &destination) const
+    {
+        // batchencoder.cpp:125-165 (unsigned) / 167-215 (signed)
+        const size_t n = context_.n();
+        const uint64_t t = context_.plain_modulus();
+        if (&destination.context() != &context_)
+            throw std::invalid_argument("destination belongs to another context");
+        if (count > n)
+            throw std::invalid_argument("values_matrix size is too large");
+        if (count && !values)
+            throw std::invalid_argument("values_matrix");
+        std::vector<uint64_t> padded(n, 0);
+        for (size_t i = 0; i < count; i++)
+        {
+            const uint64_t v = values[i];
+            if (is_signed)
+            {
+                const int64_t sv = (int64_t)v;
+                const uint64_t mag = sv < 0 ? (uint64_t)0 - v : v;
+                if (mag > (t >> 1))
+                    throw std::invalid_argument("input value is larger than plain_modulus");
+            }
+            else if (v >= t)
+                throw std::invalid_argument("input value is larger than plain_modulus");
+            padded[i] = v;
+        }
+        Scratch in(n);
+        uint64_t *slab = DevicePool::global().alloc_words(n);
+        try
+        {
+            ck(hipStreamSynchronize(nullptr), "encode sync");
+            ck(hipMemcpy(in.p, padded.data(), n * 8, hipMemcpyHostToDevice), "upload values");
+            encode_device(in.p, 1, is_signed, slab);
+            ck(hipStreamSynchronize(nullptr), "encode sync");
+        }
+        catch (...)
+        {
+            DevicePool::global().free_words(slab);
+            throw;
+        }
+        destination.adopt(slab, n, n);
+        destination.set_level(nullptr);
+    }
+    void BatchEncoder::decode(const Plaintext &plain, uint64_t *values, bool is_signed) const
+    {
+        // batchencoder.cpp:357-397 / 399-447
+        const size_t n = context_.n();
+        if (&plain.context() != &context_ || plain.coeff_count() > n)
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+        if (plain.is_ntt_form())
+            throw std::invalid_argument("plain cannot be in NTT form");
+        if (!values)
+            throw std::invalid_argument("destination");
+        Scratch in(n), out(n);
+        ck(hipStreamSynchronize(nullptr), "decode sync");
+        ck(hipMemsetAsync(in.p, 0, n * 8, nullptr), "zero pad");
+        if (plain.coeff_count())
+            ck(hipMemcpyAsync(in.p, plain.data(), plain.coeff_count() * 8, hipMemcpyDeviceToDevice, nullptr), "copy plain");
+        decode_device(in.p, 1, is_signed, out.p);
+        ck(hipMemcpy(values, out.p, n * 8, hipMemcpyDeviceToHost), "download values");
+    }
+
     // ---------------------------------------------------------------- Encryptor (secret-key encryption)
     Encryptor::Encryptor(const Context &context, const SecretKey &secret_key) : context_(context), evaluator_(context)
     {

@@ -53,6 +53,31 @@ namespace sealhip
         std::mutex mu_;
         std::vector<uint64_t *> powers_; // s^1, s^2, ... at the key level, NTT form
     };
+    // seal::BatchEncoder (native/src/seal/batchencoder.h, batchencoder.cpp): N integers modulo t <-> one plaintext polynomial, through
+    // the negacyclic NTT modulo t (the plain modulus has its own tables in the context's prime pool) and the 2 x N/2 matrix index
+    // map.  encode / decode move host vectors like the reference; the *_device forms work on `batch` vectors already in HBM
+    // (e.g. the output of Decryptor::decrypt_batch) without leaving it.
+    class BatchEncoder
+    {
+    public:
+        explicit BatchEncoder(const Context &context);
+        ~BatchEncoder();
+        BatchEncoder(const BatchEncoder &) = delete;
+        BatchEncoder &operator=(const BatchEncoder &) = delete;
+        size_t slot_count() const { return context_.n(); }
+        // values: count <= N unsigned values below t, or signed values of magnitude <= t/2 (is_signed)
+        void encode(const uint64_t *values, size_t count, bool is_signed, Plaintext &destination) const;
+        // N values out (signed: the balanced representatives as int64 bit patterns)
+        void decode(const Plaintext &plain, uint64_t *values, bool is_signed) const;
+        // device vectors [batch][N]; in and out may not alias
+        void encode_device(const uint64_t *values, unsigned batch, bool is_signed, uint64_t *coefficients) const;
+        void decode_device(const uint64_t *coefficients, unsigned batch, bool is_signed, uint64_t *values) const;
+
+    private:
+        const Context &context_;
+        uint32_t *map_ = nullptr; // matrix_reps_index_map_, device
+    };
+
     // seal::Encryptor, the secret-key half (native/src/seal/encryptor.h: encrypt_symmetric / encrypt_zero_symmetric and their
     // Serializable<> forms; encryptor.cpp:116-330, util/rlwe.cpp:270-395).  The randomness is the reference's: a bootstrap
     // Blake2xb PRNG yields the public seed of c_1 = a (expanded by sample_poly_uniform) and the centred-binomial noise e

@@ -172,3 +172,58 @@ def case_encrypt_symmetric(scheme, n, bits, seed=0x5EA1):
         raise AssertionError("expected InvalidArgument for an unknown parms_id")
     except S.InvalidArgument:
         pass
+
+
+def case_batch_encoder(scheme, n, bits, batch=3):
+    """BatchEncoder on the device: encode == the reference's plaintext words (unsigned and signed, short and full vectors),
+    decode == its slot values; the whole client loop encode -> encrypt -> evaluate -> decrypt_batch -> decode_device stays on
+    the device and gives (a * b + rot) modulo t slot by slot, as the reference's own pipeline does"""
+    primes, t, ref, d, dec, _ = _setup(scheme, n, bits)
+    be = S.BatchEncoder(d.ctx)
+    assert be.slot_count() == n
+    rng = np.random.default_rng(41)
+    for count in (n, n // 2 + 3, 1, 0):
+        vals = rng.integers(0, t, count, dtype=np.uint64)
+        rpt = ref.batch_encode(vals) if count else ref.batch_encode(np.zeros(1, dtype=np.uint64))
+        pt = be.encode(vals if count else np.zeros(0, dtype=np.uint64))
+        assert pt.coeff_count() == n and not pt.is_ntt_form()
+        assert np.array_equal(pt.to_numpy(), rpt.data()), ("encode", count)
+        assert np.array_equal(be.decode(pt), ref.batch_decode(rpt)), ("decode", count)
+    svals = rng.integers(-(t // 2), t // 2 + 1, n, dtype=np.int64)
+    rpt = ref.batch_encode_signed(svals)
+    pt = be.encode(svals, signed=True)
+    assert np.array_equal(pt.to_numpy(), rpt.data()), "signed encode"
+    assert np.array_equal(be.decode(pt, signed=True), ref.batch_decode(rpt, signed=True)), "signed decode"
+    assert np.array_equal(be.decode(pt, signed=True), svals)
+    # a trimmed plaintext (as Decryptor returns it) decodes like the reference's
+    short = ref.pt(np.array([5, 0, 7], dtype=np.uint64))
+    mine = S.Plaintext.from_numpy(d.ctx, np.array([5, 0, 7], dtype=np.uint64))
+    assert np.array_equal(be.decode(mine), ref.batch_decode(short))
+    # argument checks (batchencoder.cpp:131-145, 175-190, 363-371)
+    for bad in (lambda: be.encode(np.full(3, t, dtype=np.uint64)), lambda: be.encode(np.zeros(n + 1, dtype=np.uint64)),
+                lambda: be.encode(np.array([t // 2 + 1], dtype=np.int64), signed=True)):
+        try:
+            bad()
+            raise AssertionError("expected InvalidArgument")
+        except S.InvalidArgument:
+            pass
+
+    # the client loop on the device
+    ref.keygen_relin()
+    enc = S.Encryptor(d.ctx, S.SecretKey(d.ctx, ref.secret_key()))
+    rlk = S.RelinKeys(d.ctx)
+    rlk.load_bytes(ref.keys_save("relin", True))
+    a = rng.integers(0, t, (batch, n), dtype=np.uint64)
+    b = rng.integers(0, t, (batch, n), dtype=np.uint64)
+    prods = S.Ciphertext(d.ctx, batch=batch)
+    for k in range(batch):
+        ca, cb = enc.encrypt_symmetric(be.encode(a[k])), enc.encrypt_symmetric(be.encode(b[k]))
+        d.ev.multiply_inplace(ca, cb)
+        d.ev.relinearize_inplace(ca, rlk)
+        prods.load_bytes(ca.save_bytes(), item=k)
+    coeffs, words = dec.decrypt_batch(prods)
+    vals = be.decode_device(coeffs, batch).to_numpy((batch, n))
+    want = (a.astype(object) * b.astype(object)) % t
+    assert np.array_equal(vals, want.astype(np.uint64)), "slot-wise products modulo t"
+    again = be.encode_device(S.DeviceBuffer.from_numpy(vals), batch).to_numpy((batch, n))
+    assert np.array_equal(again, coeffs.to_numpy((batch, n))), "encode_device(decode_device(x)) == x"

@@ -288,6 +288,17 @@ class RefContext:
         _ck(lib().ref_encrypt_symmetric_save(self.h, pt.h, C.c_int(1 if seeded else 0), buf, C.c_uint64(cap), C.byref(n)))
         return bytes(buf[:n.value])
 
+    def batch_decode(self, pt, signed=False):
+        out = np.zeros(self.n, dtype=np.int64 if signed else np.uint64)
+        _ck(lib().ref_batch_decode(self.h, pt.h, C.c_int(1 if signed else 0), _p(out)))
+        return out
+
+    def batch_encode_signed(self, values):
+        v = np.ascontiguousarray(values, dtype=np.int64)
+        h = C.c_void_p()
+        _ck(lib().ref_batch_encode_signed(self.h, _p(v), C.c_uint64(v.size), C.byref(h)))
+        return RefPlaintext(self, h)
+
     def keys_load(self, data, unsafe=False):
         buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
         n = C.c_uint64()

@@ -67,3 +67,9 @@ def test_end_to_end_streams(gpu, scheme, n, bits):
 def test_encrypt_symmetric(gpu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_encrypt_symmetric(scheme, n, bits)
+
+
+@pytest.mark.parametrize("scheme,n,bits", [("bfv", 4096, [36, 36, 37]), ("bgv", 8192, [50, 40, 56]), ("bfv", 32768, [55, 55, 55, 55])])
+def test_batch_encoder(gpu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_batch_encoder(scheme, n, bits)

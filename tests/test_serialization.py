@@ -129,3 +129,20 @@ def test_end_to_end_streams(emu, scheme, n, bits):
 def test_encrypt_symmetric(emu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_encrypt_symmetric(scheme, n, bits)
+
+
+@needs_ref
+@pytest.mark.parametrize("scheme,n,bits", [("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45]), ("bfv", 8192, [50, 55, 56])])
+def test_batch_encoder(emu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_batch_encoder(scheme, n, bits)
+
+
+def test_batch_encoder_needs_batching(emu):
+    import seal_amd as S
+    from harness import DeviceSide
+    from oracle import coeff_modulus_create
+    with pytest.raises(S.InvalidArgument):
+        S.BatchEncoder(DeviceSide("ckks", 1024, coeff_modulus_create(1024, [40, 40])).ctx)
+    with pytest.raises(S.InvalidArgument):
+        S.BatchEncoder(DeviceSide("bfv", 1024, coeff_modulus_create(1024, [40, 40]), 1 << 10).ctx)   # t not prime
