@@ -227,3 +227,41 @@ def case_batch_encoder(scheme, n, bits, batch=3):
     assert np.array_equal(vals, want.astype(np.uint64)), "slot-wise products modulo t"
     again = be.encode_device(S.DeviceBuffer.from_numpy(vals), batch).to_numpy((batch, n))
     assert np.array_equal(again, coeffs.to_numpy((batch, n))), "encode_device(decode_device(x)) == x"
+
+
+def case_slot_semantics(scheme, n, bits):
+    """an application-level check with a mathematical oracle (numpy on the slot vectors, no reference arithmetic involved):
+    BatchEncoder -> secret-key encryption -> add / sub / multiply / relinearize / multiply_plain / add_plain / rotate_rows /
+    rotate_columns / mod_switch_to_next on the device -> decrypt -> decode gives ((a*b + c) * p - a + q) rotated, modulo t,
+    slot by slot.  Only the keys come from the reference's KeyGenerator (as serialized streams)."""
+    primes, t, ref, d, dec, _ = _setup(scheme, n, bits)
+    be = S.BatchEncoder(d.ctx)
+    enc = S.Encryptor(d.ctx, S.SecretKey(d.ctx, ref.secret_key()))
+    rlk = S.RelinKeys(d.ctx)
+    rlk.load_bytes(ref.keys_save("relin", True))
+    steps = (1, -2)
+    elts = [ref.galois_elt_from_step(s) for s in steps] + [2 * n - 1]
+    glk = S.GaloisKeys(d.ctx)
+    glk.load_bytes(ref.keys_save("galois", True, elts))
+    rng = np.random.default_rng(53)
+    a, b, c, p, q = (rng.integers(0, t, n, dtype=np.uint64) for _ in range(5))
+    ca, cb, cc = (enc.encrypt_symmetric(be.encode(v)) for v in (a, b, c))
+    d.ev.multiply_inplace(ca, cb)                    # a*b
+    d.ev.relinearize_inplace(ca, rlk)
+    d.ev.add_inplace(ca, cc)                         # + c
+    d.ev.multiply_plain_inplace(ca, be.encode(p))    # * p
+    d.ev.sub_inplace(ca, enc.encrypt_symmetric(be.encode(a)))   # - a
+    d.ev.add_plain_inplace(ca, be.encode(q))         # + q
+    if len(primes) > 2:
+        d.ev.mod_switch_to_next_inplace(ca)
+    d.ev.rotate_rows_inplace(ca, 1, glk)
+    d.ev.rotate_rows_inplace(ca, -2, glk)
+    d.ev.rotate_columns_inplace(ca, glk)
+    got = be.decode(dec.decrypt(ca))
+    O = lambda v: v.astype(object)
+    want = (((O(a) * O(b) + O(c)) * O(p) - O(a) + O(q)) % t).astype(np.uint64)
+    m = want.reshape(2, n // 2)
+    m = np.roll(m, -1, axis=1)       # rotate_rows(1): every row one slot to the left
+    m = np.roll(m, 2, axis=1)        # rotate_rows(-2)
+    m = m[::-1]                      # rotate_columns: swap the two rows
+    assert np.array_equal(got, m.reshape(-1)), "slot semantics"

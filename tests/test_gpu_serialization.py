@@ -73,3 +73,9 @@ def test_encrypt_symmetric(gpu, scheme, n, bits):
 def test_batch_encoder(gpu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_batch_encoder(scheme, n, bits)
+
+
+@pytest.mark.parametrize("scheme,n,bits", [("bfv", 8192, [50, 50, 50, 58]), ("bgv", 16384, [50, 50, 50, 50, 60])])
+def test_slot_semantics(gpu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_slot_semantics(scheme, n, bits)

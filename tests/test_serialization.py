@@ -146,3 +146,10 @@ def test_batch_encoder_needs_batching(emu):
         S.BatchEncoder(DeviceSide("ckks", 1024, coeff_modulus_create(1024, [40, 40])).ctx)
     with pytest.raises(S.InvalidArgument):
         S.BatchEncoder(DeviceSide("bfv", 1024, coeff_modulus_create(1024, [40, 40]), 1 << 10).ctx)   # t not prime
+
+
+@needs_ref
+@pytest.mark.parametrize("scheme,n,bits", [("bfv", 4096, [50, 50, 50, 58]), ("bgv", 4096, [50, 50, 50, 58])])
+def test_slot_semantics(emu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_slot_semantics(scheme, n, bits)
