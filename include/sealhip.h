@@ -125,7 +125,8 @@ SHL_FUNC Ciphertext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count
 SHL_FUNC Ciphertext_CopyFromDevice(void *thisptr, const uint64_t *src, uint64_t word_count, void *hip_stream);
 
 /* Wire format (native/src/seal/c/ciphertext.h:80-86; Ciphertext::save / load / unsafe_load, native/src/seal/ciphertext.cpp:153-403):
- * the reference's own byte streams - SEALHeader-framed, compr_mode none (0), seeded ciphertexts expanded on load with the
+ * the reference's own byte streams - SEALHeader-framed, compr_mode none (0), zlib (1) or zstd (2: libzstd.so.1 at run time;
+ * stock reference builds write zstd by default), seeded ciphertexts expanded on load with the
  * reference's Blake2xb / SHAKE256 PRNG - are parsed straight into the device slab and written back from it.  Same argument order
  * as sealc.  Load = UnsafeLoad + is_valid_for (every coefficient reduced, data level).  A handle that is a batch of one behaves
  * exactly like seal::Ciphertext; LoadItem / SaveItem address slot `item` of a larger batch (the first item loaded into an empty

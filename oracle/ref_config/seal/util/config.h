@@ -1,7 +1,7 @@
 // Hand-written stand-in for the one generated header the reference needs
 // (native/src/seal/util/config.h.in is normally filled in by CMake). It selects the
 // same options the survey's oracle build used: Release, HEXL OFF,
-// no MSGSL/ZLIB/ZSTD, __int128 intrinsics, Blake2xb default PRNG.
+// no MSGSL/ZSTD, system zlib, __int128 intrinsics, Blake2xb default PRNG.
 // TEST INFRASTRUCTURE ONLY: used by oracle/Makefile to compile the read-only reference
 // tree into oracle/_ref/. Nothing under seal_amd/ includes it.
 #pragma once
@@ -35,4 +35,6 @@
 // Zero memory functions
 #define SEAL_USE_EXPLICIT_BZERO
 
-// Third-party dependencies: none (HEXL OFF, no MSGSL/ZLIB/ZSTD)
+// Third-party dependencies: zlib only (the system's <zlib.h>: lets the wire-format tests check compr_mode_type::zlib streams
+// against the reference); HEXL OFF, no MSGSL, no ZSTD (its header is not in the image)
+#define SEAL_USE_ZLIB

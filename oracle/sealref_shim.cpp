@@ -725,6 +725,21 @@ extern "C"
         *bytes = static_cast<uint64_t>(CT(ct).save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
         REF_CATCH
     }
+    // the same with a compression mode (0 none, 1 zlib; this build has no zstd), for ciphertexts, plaintexts and key sets
+    int ref_ct_save_mode(void *ct, int mode, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        *bytes = static_cast<uint64_t>(CT(ct).save(reinterpret_cast<seal_byte *>(out), cap, static_cast<compr_mode_type>(mode)));
+        REF_CATCH
+    }
+    int ref_keys_save_mode(void *ctx, int kind, int mode, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        const KSwitchKeys &k = kind == 0 ? static_cast<const KSwitchKeys &>(c->rlk) : static_cast<const KSwitchKeys &>(c->glk);
+        *bytes = static_cast<uint64_t>(k.save(reinterpret_cast<seal_byte *>(out), cap, static_cast<compr_mode_type>(mode)));
+        REF_CATCH
+    }
     int ref_ct_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, void **out, uint64_t *bytes)
     {
         REF_TRY
@@ -795,6 +810,13 @@ extern "C"
         REF_CATCH
     }
     // Plaintext::save / load / unsafe_load
+    int ref_pt_save_mode(void *pt, int mode, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        *bytes = static_cast<uint64_t>(
+            static_cast<RefPt *>(pt)->pt.save(reinterpret_cast<seal_byte *>(out), cap, static_cast<compr_mode_type>(mode)));
+        REF_CATCH
+    }
     int ref_pt_save(void *pt, uint8_t *out, uint64_t cap, uint64_t *bytes)
     {
         REF_TRY

@@ -360,6 +360,7 @@ class Plaintext:
         return n.value
 
     def save_bytes(self, compr_mode=0):
+        """Plaintext::save; compr_mode 0 none, 1 zlib, 2 zstd"""
         cap = C.c_int64()
         N.check(N.lib().Plaintext_SaveSize(self._h, C.c_uint8(compr_mode), C.byref(cap)))
         buf = (C.c_uint8 * cap.value)()

@@ -637,10 +637,9 @@ extern "C"
         IfNullRet(thisptr, SHL_E_POINTER);
         IfNullRet(result, SHL_E_POINTER);
         SHL_TRY
-        if (compr_mode != 0)
-            throw std::invalid_argument("unsupported compression mode");
         auto ct = as<Ciphertext>(thisptr);
-        *result = (int64_t)serial::ciphertext_save_size(ct->size(), ct->poly_modulus_degree(), ct->coeff_modulus_size());
+        *result = (int64_t)serial::compress_bound(
+            serial::ciphertext_save_size(ct->size(), ct->poly_modulus_degree(), ct->coeff_modulus_size()), compr_mode);
         SHL_CATCH
     }
     SHL_FUNC Ciphertext_SaveItem(void *thisptr, uint64_t item, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes)
@@ -649,21 +648,33 @@ extern "C"
         IfNullRet(outptr, SHL_E_POINTER);
         IfNullRet(out_bytes, SHL_E_POINTER);
         SHL_TRY
-        if (compr_mode != 0)
+        if (!serial::compr_mode_supported(compr_mode))
             throw std::invalid_argument("unsupported compression mode");
         auto ct = as<Ciphertext>(thisptr);
         if (item >= ct->batch())
             throw std::out_of_range("batch item");
         const size_t poly_words = ct->coeff_modulus_size() * ct->poly_modulus_degree();
         static const uint64_t zero_id[4] = { 0, 0, 0, 0 };
+        // uncompressed: straight into the caller's buffer; compressed: through a host image of the raw stream
+        std::vector<uint8_t> raw;
+        uint8_t *dst = outptr;
+        size_t cap = (size_t)size;
+        if (compr_mode != 0)
+        {
+            raw.resize(serial::ciphertext_save_size(ct->size(), ct->poly_modulus_degree(), ct->coeff_modulus_size()));
+            dst = raw.data();
+            cap = raw.size();
+        }
         size_t data_offset = 0;
         *out_bytes = (int64_t)serial::save_ciphertext(
             ct->level() ? ct->level()->parms_id : zero_id, ct->is_ntt_form(), ct->size(), ct->poly_modulus_degree(),
-            ct->coeff_modulus_size(), ct->scale(), ct->correction_factor(), nullptr, outptr, (size_t)size, &data_offset);
+            ct->coeff_modulus_size(), ct->scale(), ct->correction_factor(), nullptr, dst, cap, &data_offset);
         // the coefficient words go from the device slab straight into the stream
         hip_ok(hipDeviceSynchronize(), "sync");
         for (size_t p = 0; p < ct->size(); p++)
-            hip_ok(hipMemcpy(outptr + data_offset + p * poly_words * 8, ct->plane(p) + item * poly_words, poly_words * 8, hipMemcpyDeviceToHost), "D2H");
+            hip_ok(hipMemcpy(dst + data_offset + p * poly_words * 8, ct->plane(p) + item * poly_words, poly_words * 8, hipMemcpyDeviceToHost), "D2H");
+        if (compr_mode != 0)
+            *out_bytes = (int64_t)serial::compress_stream(raw.data(), raw.size(), compr_mode, outptr, (size_t)size);
         SHL_CATCH
     }
     SHL_FUNC Ciphertext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes)
@@ -711,9 +722,7 @@ extern "C"
         IfNullRet(thisptr, SHL_E_POINTER);
         IfNullRet(result, SHL_E_POINTER);
         SHL_TRY
-        if (compr_mode != 0)
-            throw std::invalid_argument("unsupported compression mode");
-        *result = (int64_t)serial::plaintext_save_size(as<Plaintext>(thisptr)->coeff_count());
+        *result = (int64_t)serial::compress_bound(serial::plaintext_save_size(as<Plaintext>(thisptr)->coeff_count()), compr_mode);
         SHL_CATCH
     }
     SHL_FUNC Plaintext_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes)
@@ -722,16 +731,27 @@ extern "C"
         IfNullRet(outptr, SHL_E_POINTER);
         IfNullRet(out_bytes, SHL_E_POINTER);
         SHL_TRY
-        if (compr_mode != 0)
+        if (!serial::compr_mode_supported(compr_mode))
             throw std::invalid_argument("unsupported compression mode");
         auto pt = as<Plaintext>(thisptr);
         static const uint64_t zero_id[4] = { 0, 0, 0, 0 };
+        std::vector<uint8_t> raw;
+        uint8_t *dst = outptr;
+        size_t cap = (size_t)size;
+        if (compr_mode != 0)
+        {
+            raw.resize(serial::plaintext_save_size(pt->coeff_count()));
+            dst = raw.data();
+            cap = raw.size();
+        }
         size_t data_offset = 0;
         *out_bytes = (int64_t)serial::save_plaintext(pt->level() ? pt->level()->parms_id : zero_id, pt->coeff_count(), pt->scale(), nullptr,
-                                                     outptr, (size_t)size, &data_offset);
+                                                     dst, cap, &data_offset);
         hip_ok(hipDeviceSynchronize(), "sync");
         if (pt->coeff_count())
-            hip_ok(hipMemcpy(outptr + data_offset, pt->data(), pt->coeff_count() * 8, hipMemcpyDeviceToHost), "D2H");
+            hip_ok(hipMemcpy(dst + data_offset, pt->data(), pt->coeff_count() * 8, hipMemcpyDeviceToHost), "D2H");
+        if (compr_mode != 0)
+            *out_bytes = (int64_t)serial::compress_stream(raw.data(), raw.size(), compr_mode, outptr, (size_t)size);
         SHL_CATCH
     }
     SHL_FUNC KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)

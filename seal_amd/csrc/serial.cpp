@@ -6,7 +6,11 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <list>
+#include <algorithm>
 #include <atomic>
+#include <dlfcn.h>
+#include <zlib.h>
 #include <stdexcept>
 #include <thread>
 
@@ -98,6 +102,9 @@ namespace sealhip
             {
                 const uint8_t *base;
                 size_t size, pos = 0;
+                bool seekable = true;                            // false inside an inflated payload (see framed)
+                size_t inflate_limit = size_t(1) << 40;          // bound on one decompressed payload
+                std::list<std::vector<uint8_t>> inflated;        // decompressed payloads (stable addresses)
                 void skip(size_t n)
                 {
                     if (n > size - pos)
@@ -132,10 +139,135 @@ namespace sealhip
                     return true;
                 return h.version_major == 3 && h.version_minor >= 4;
             }
-            // Serialization::IsValidHeader (serialization.h:172-191) for a build without zlib / zstd
+            // Serialization::IsValidHeader (serialization.h:172-191)
             bool valid_header(const Header &h)
             {
-                return h.magic == kMagic && h.header_size == kHeaderSize && compatible_version(h) && h.compr_mode == 0;
+                return h.magic == kMagic && h.header_size == kHeaderSize && compatible_version(h) && compr_mode_supported(h.compr_mode);
+            }
+
+            // libzstd through its stable C ABI, loaded on demand (the image ships libzstd.so.1 without headers)
+            struct Zstd
+            {
+                struct Buf
+                {
+                    void *p;
+                    size_t size, pos;
+                };
+                void *(*createDStream)() = nullptr;
+                size_t (*freeDStream)(void *) = nullptr;
+                size_t (*decompressStream)(void *, Buf *, Buf *) = nullptr;
+                size_t (*compress)(void *, size_t, const void *, size_t, int) = nullptr;
+                size_t (*compressBound)(size_t) = nullptr;
+                unsigned (*isError)(size_t) = nullptr;
+                bool ok = false;
+                Zstd()
+                {
+                    void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+                    if (!h)
+                        return;
+                    createDStream = reinterpret_cast<void *(*)()>(dlsym(h, "ZSTD_createDStream"));
+                    freeDStream = reinterpret_cast<size_t (*)(void *)>(dlsym(h, "ZSTD_freeDStream"));
+                    decompressStream = reinterpret_cast<size_t (*)(void *, Buf *, Buf *)>(dlsym(h, "ZSTD_decompressStream"));
+                    compress = reinterpret_cast<size_t (*)(void *, size_t, const void *, size_t, int)>(dlsym(h, "ZSTD_compress"));
+                    compressBound = reinterpret_cast<size_t (*)(size_t)>(dlsym(h, "ZSTD_compressBound"));
+                    isError = reinterpret_cast<unsigned (*)(size_t)>(dlsym(h, "ZSTD_isError"));
+                    ok = createDStream && freeDStream && decompressStream && compress && compressBound && isError;
+                }
+            };
+            const Zstd &zstd()
+            {
+                static const Zstd z;
+                return z;
+            }
+
+            // the compressed payload of an outermost object -> its member bytes.  `limit` bounds the output (a hostile stream
+            // must not inflate without end: the reference inflates on demand into the parser for the same reason)
+            // A corrupt or truncated stream does not throw here: what could be inflated is returned and *failed is set, so that the
+            // parser behaves like the reference's on-demand inflating stream buffer (ztools.cpp:200-300): it fails where the data
+            // runs out ("I/O error") unless a member check rejects the object earlier.
+            std::vector<uint8_t> decompress(const uint8_t *src, size_t n, uint8_t mode, size_t limit, bool *failed)
+            {
+                *failed = false;
+                std::vector<uint8_t> out(std::min<size_t>(limit, std::max<size_t>(4 * n, 1 << 16)));
+                size_t produced = 0;
+                auto grow = [&]() {
+                    if (out.size() >= limit)
+                        return false;
+                    out.resize(std::min<size_t>(limit, out.size() * 2));
+                    return true;
+                };
+                if (mode == 1)
+                {
+                    z_stream zs;
+                    std::memset(&zs, 0, sizeof(zs));
+                    if (inflateInit(&zs) != Z_OK)
+                    {
+                        *failed = true;
+                        return {};
+                    }
+                    zs.next_in = const_cast<Bytef *>(src);
+                    size_t fed = 0;
+                    int rc = Z_OK;
+                    while (rc != Z_STREAM_END)
+                    {
+                        if (zs.avail_in == 0 && fed < n)
+                        {
+                            const size_t chunk = std::min<size_t>(n - fed, 1u << 30);
+                            zs.next_in = const_cast<Bytef *>(src + fed);
+                            zs.avail_in = (uInt)chunk;
+                            fed += chunk;
+                        }
+                        if (produced == out.size() && !grow())
+                        {
+                            *failed = true;
+                            break;
+                        }
+                        const size_t room = std::min<size_t>(out.size() - produced, 1u << 30);
+                        zs.next_out = out.data() + produced;
+                        zs.avail_out = (uInt)room;
+                        rc = inflate(&zs, Z_NO_FLUSH);
+                        produced += room - zs.avail_out;
+                        if ((rc != Z_OK && rc != Z_STREAM_END && !(rc == Z_BUF_ERROR && (zs.avail_out == 0 || fed < n))) ||
+                            (rc == Z_BUF_ERROR && zs.avail_out != 0 && fed >= n) /* truncated */)
+                        {
+                            *failed = true;
+                            break;
+                        }
+                    }
+                    inflateEnd(&zs);
+                }
+                else
+                {
+                    const Zstd &z = zstd();
+                    void *ds = z.createDStream();
+                    if (!ds)
+                    {
+                        *failed = true;
+                        return {};
+                    }
+                    Zstd::Buf in{ const_cast<uint8_t *>(src), n, 0 };
+                    size_t rc = 1;
+                    while (rc != 0)
+                    {
+                        if (produced == out.size() && !grow())
+                        {
+                            *failed = true;
+                            break;
+                        }
+                        Zstd::Buf ob{ out.data(), out.size(), produced };
+                        rc = z.decompressStream(ds, &ob, &in);
+                        const bool progressed = ob.pos != produced;
+                        produced = ob.pos;
+                        if (z.isError(rc) || (rc != 0 && in.pos == in.size && !progressed && produced < out.size()))
+                        {
+                            *failed = true;
+                            break;
+                        }
+                    }
+                    z.freeDStream(ds);
+                }
+                out.resize(produced);
+                return out;
             }
 
             // Serialization::Load (serialization.cpp:341-553) around `members(reader, version)`
@@ -149,10 +281,30 @@ namespace sealhip
                     throw std::logic_error("incompatible version");
                 if (!valid_header(h) || h.size < sizeof(Header))
                     throw std::logic_error("loaded SEALHeader is invalid");
-                if (h.size > r.size - start)
+                // the two size checks run on seekable streams only (serialization.cpp:383-412, 437): the reference parses a
+                // compressed payload from an inflating, non-seekable stream buffer, where a short payload surfaces as "I/O error"
+                if (r.seekable && h.size > r.size - start)
                     throw std::invalid_argument("SEALHeader.size exceeds available input");
+                if (h.compr_mode != 0)
+                {
+                    // serialization.cpp:430-515: the payload is one compressed stream of the member bytes; the members are parsed
+                    // from the inflated buffer (which the images may point into: it is kept alive by the reader's owner)
+                    const size_t payload = (size_t)h.size - sizeof(Header);
+                    bool failed = false;
+                    r.inflated.emplace_back(decompress(r.base + r.pos, payload, h.compr_mode, r.inflate_limit, &failed));
+                    Reader inner{ r.inflated.back().data(), r.inflated.back().size() };
+                    inner.seekable = false;
+                    inner.inflate_limit = r.inflate_limit;
+                    members(inner, Version{ h.version_major, h.version_minor });
+                    if (failed)
+                        throw std::logic_error("stream decompression failed");
+                    for (auto &b : inner.inflated)
+                        r.inflated.emplace_back(std::move(b));
+                    r.pos += payload;
+                    return (size_t)h.size;
+                }
                 members(r, Version{ h.version_major, h.version_minor });
-                if (h.size != r.pos - start)
+                if (r.seekable && h.size != r.pos - start)
                     throw std::logic_error("invalid data size");
                 return (size_t)h.size;
             }
@@ -309,8 +461,10 @@ namespace sealhip
         {
             check_input(in, size);
             Reader r{ in, size };
+            r.inflate_limit = 6 * ctx.key_level().K * ctx.n() * 8 + 4096; // SEAL_CIPHERTEXT_SIZE_MAX polynomials at the key level
             CiphertextImage img;
             const size_t bytes = framed(r, [&](Reader &rr, Version v) { ciphertext_members(ctx, rr, v, img); });
+            img.inflated = std::move(r.inflated);
             if (check_data)
             {
                 // Ciphertext::load = unsafe_load + is_valid_for (ciphertext.h:533-545; valcheck.cpp): data levels only,
@@ -398,6 +552,7 @@ namespace sealhip
                         if (!data_in_range(ctx, b))
                             throw std::logic_error("KSwitchKeys data is invalid");
             }
+            img.inflated = std::move(r.inflated);
             out = std::move(img);
             return bytes;
         }
@@ -406,6 +561,7 @@ namespace sealhip
         {
             check_input(in, size);
             Reader r{ in, size };
+            r.inflate_limit = ctx.key_level().K * ctx.n() * 8 + 4096;
             PlaintextImage img;
             // is_metadata_valid_for(const Plaintext &, context, allow_pure_key_levels) (valcheck.cpp:80-133)
             auto metadata_ok = [&](bool allow_pure_key_levels) {
@@ -446,7 +602,8 @@ namespace sealhip
             // Plaintext::load = unsafe_load + is_valid_for (is_data_valid_for, valcheck.cpp:348-396)
             if (check_data && !(metadata_ok(false) && plaintext_in_range(ctx, img)))
                 throw std::logic_error("plaintext data is invalid");
-            out = img;
+            img.inflated = std::move(r.inflated);
+            out = std::move(img);
             return bytes;
         }
 
@@ -507,6 +664,90 @@ namespace sealhip
             if (coeff_count && words)
                 put(words, (size_t)coeff_count * 8);
             return total;
+        }
+
+        bool compr_mode_supported(uint8_t compr_mode)
+        {
+            return compr_mode == 0 || compr_mode == 1 || (compr_mode == 2 && zstd().ok);
+        }
+        size_t compress_bound(size_t raw_bytes, uint8_t compr_mode)
+        {
+            if (!compr_mode_supported(compr_mode))
+                throw std::invalid_argument("unsupported compression mode");
+            if (compr_mode == 0)
+                return raw_bytes;
+            const size_t payload = raw_bytes - sizeof(Header);
+            if (compr_mode == 1)
+                return sizeof(Header) + payload + (payload >> 12) + (payload >> 14) + (payload >> 25) + 64; // deflateBound
+            return sizeof(Header) + zstd().compressBound(payload);
+        }
+        size_t compress_stream(const uint8_t *raw, size_t raw_bytes, uint8_t compr_mode, uint8_t *out, size_t capacity)
+        {
+            // Serialization::Save (serialization.cpp:232-340): header in the clear, the member bytes as one compressed stream
+            if (!compr_mode_supported(compr_mode))
+                throw std::invalid_argument("unsupported compression mode");
+            if (!out)
+                throw std::invalid_argument("out cannot be null");
+            if (capacity < sizeof(Header))
+                throw std::invalid_argument("insufficient size");
+            const uint8_t *payload = raw + sizeof(Header);
+            const size_t n = raw_bytes - sizeof(Header), room = capacity - sizeof(Header);
+            size_t produced = 0;
+            if (compr_mode == 0)
+            {
+                if (room < n)
+                    throw std::runtime_error("I/O error");
+                std::memcpy(out + sizeof(Header), payload, n);
+                produced = n;
+            }
+            else if (compr_mode == 1)
+            {
+                z_stream zs;
+                std::memset(&zs, 0, sizeof(zs));
+                if (deflateInit(&zs, Z_DEFAULT_COMPRESSION) != Z_OK)
+                    throw std::logic_error("stream compression failed");
+                size_t fed = 0;
+                int rc = Z_OK;
+                while (rc != Z_STREAM_END)
+                {
+                    if (zs.avail_in == 0 && fed < n)
+                    {
+                        const size_t chunk = std::min<size_t>(n - fed, 1u << 30);
+                        zs.next_in = const_cast<Bytef *>(payload + fed);
+                        zs.avail_in = (uInt)chunk;
+                        fed += chunk;
+                    }
+                    const size_t space = std::min<size_t>(room - produced, 1u << 30);
+                    if (space == 0)
+                    {
+                        deflateEnd(&zs);
+                        throw std::runtime_error("I/O error");
+                    }
+                    zs.next_out = out + sizeof(Header) + produced;
+                    zs.avail_out = (uInt)space;
+                    rc = deflate(&zs, fed < n ? Z_NO_FLUSH : Z_FINISH);
+                    produced += space - zs.avail_out;
+                    if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR)
+                    {
+                        deflateEnd(&zs);
+                        throw std::logic_error("stream compression failed");
+                    }
+                }
+                deflateEnd(&zs);
+            }
+            else
+            {
+                const size_t rc = zstd().compress(out + sizeof(Header), room, payload, n, 3 /* ZSTD_CLEVEL_DEFAULT */);
+                if (zstd().isError(rc))
+                    throw std::runtime_error("I/O error");
+                produced = rc;
+            }
+            Header h;
+            std::memcpy(&h, raw, sizeof(h));
+            h.compr_mode = compr_mode;
+            h.size = sizeof(Header) + produced;
+            std::memcpy(out, &h, sizeof(h));
+            return sizeof(Header) + produced;
         }
 
         size_t seeded_ciphertext_save_size(uint64_t n, uint64_t K)

@@ -15,13 +15,16 @@
 //                                                   native/src/seal/ciphertext.cpp:118-151, randomgen.cpp:87-110, util/rlwe.cpp
 //   KSwitchKeys = SEALHeader, parms_id, keys_dim1 (u64), keys_dim1 x { keys_dim2 (u64), keys_dim2 x PublicKey }, a PublicKey
 //                 being serialized as its Ciphertext              native/src/seal/kswitchkeys.cpp:47-180, publickey.h:106-131
-// compr_mode: none only — the same set a reference built without zlib / zstd accepts (IsSupportedComprMode,
-// serialization.h:100-116); anything else is "loaded SEALHeader is invalid", as there.
+// compr_mode: none (0), zlib (1: the system zlib, the reference's util/ztools.cpp:200-480) and zstd (2: libzstd.so.1 loaded
+// at run time when present, ztools.cpp:560-900) — the reference's default builds write zstd.  Only the OUTERMOST object is
+// compressed: its SEALHeader stays in the clear and the payload after it is one deflate / zstd stream of the member bytes
+// (nested objects are always saved with compr_mode none: ciphertext.cpp:179-193, kswitchkeys.cpp:70-75).
 // Exceptions are the reference's: std::invalid_argument / std::logic_error / std::runtime_error("I/O error") at the same
 // conditions (Serialization::Load, serialization.cpp:341-553; Ciphertext::load_members; valcheck.cpp).
 #pragma once
 #include "context.h"
 #include <cstdint>
+#include <list>
 #include <vector>
 
 namespace sealhip
@@ -47,6 +50,7 @@ namespace sealhip
             const uint8_t *stored = nullptr;
             size_t stored_words = 0;
             std::vector<uint64_t> expanded;
+            std::list<std::vector<uint8_t>> inflated; // decompressed payloads `stored` may point into (compressed streams)
             size_t word_count() const { return stored_words + expanded.size(); }
             void copy_words(uint64_t *dst) const; // gather both pieces into one host array
         };
@@ -54,6 +58,7 @@ namespace sealhip
         {
             // keys[index] = decomposition digits of key `index`, each a size-2 key-level ciphertext in NTT form; empty = no key
             std::vector<std::vector<CiphertextImage>> keys;
+            std::list<std::vector<uint8_t>> inflated; // as CiphertextImage::inflated, for all the digits
         };
 
         // Ciphertext::unsafe_load (check_data = false) / Ciphertext::load (true: is_valid_for, valcheck.cpp).  Returns the
@@ -62,6 +67,13 @@ namespace sealhip
         size_t load_ciphertext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, CiphertextImage &out);
         // KSwitchKeys::unsafe_load / load
         size_t load_kswitchkeys(const Context &ctx, const uint8_t *in, size_t size, bool check_data, KSwitchKeysImage &out);
+
+        // compression of a saved object: `raw` = the uncompressed stream (header + members) as the save_* functions write it;
+        // returns the bytes written to out (header with compr_mode and the compressed size, then the compressed members).
+        // compress_bound = the capacity that always suffices (Serialization::ComprSizeEstimate plays this role).
+        bool compr_mode_supported(uint8_t compr_mode);
+        size_t compress_bound(size_t raw_bytes, uint8_t compr_mode);
+        size_t compress_stream(const uint8_t *raw, size_t raw_bytes, uint8_t compr_mode, uint8_t *out, size_t capacity);
 
         // Ciphertext::save_size(compr_mode_type::none) / Ciphertext::save for a full (unseeded) ciphertext
         size_t ciphertext_save_size(uint64_t size, uint64_t poly_modulus_degree, uint64_t coeff_modulus_size);
@@ -79,6 +91,7 @@ namespace sealhip
             uint64_t coeff_count = 0;
             double scale = 1.0;
             const uint8_t *stored = nullptr;
+            std::list<std::vector<uint8_t>> inflated;
         };
         // Plaintext::unsafe_load (check_data = false) / Plaintext::load (true: data level, every coefficient below its modulus)
         size_t load_plaintext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, PlaintextImage &out);

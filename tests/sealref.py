@@ -210,6 +210,34 @@ class RefContext:
         _ck(lib().ref_ct_save(ct.h, buf, C.c_uint64(cap), C.byref(n)))
         return bytes(buf[:n.value])
 
+    def ct_save_mode(self, ct, mode):
+        """Ciphertext::save with compr_mode `mode` (1 = zlib) -> bytes"""
+        i = ct.info()
+        cap = 65536 + 9 * i["size"] * i["coeff_modulus_size"] * self.n
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_ct_save_mode(ct.h, C.c_int(mode), buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def pt_save_mode(self, pt, mode):
+        cap = 65536 + 9 * pt.info()["coeff_count"]
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_pt_save_mode(pt.h, C.c_int(mode), buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
+    def keys_save_mode(self, kind, mode):
+        """the context's current RelinKeys / GaloisKeys object saved with compr_mode `mode`"""
+        k = 0 if kind == "relin" else 1
+        L = len(self.primes)
+        cap = 1 << 20
+        cap += 9 * self.n * (2 + self.key_slots(kind) ) + 10 * (L - 1) * 2 * L * self.n * max(1, sum(1 for _ in range(1)))
+        cap *= 4
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_keys_save_mode(self.h, C.c_int(k), C.c_int(mode), buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
     def ct_load(self, data, unsafe=False):
         """Ciphertext::load / unsafe_load -> (RefCiphertext, bytes consumed)"""
         buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")

@@ -79,3 +79,8 @@ def test_batch_encoder(gpu, scheme, n, bits):
 def test_slot_semantics(gpu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_slot_semantics(scheme, n, bits)
+
+
+@pytest.mark.parametrize("scheme,n,bits", SIZES[:2] + [("ckks", 32768, [60, 50, 50, 60])])
+def test_compressed_streams(gpu, scheme, n, bits):
+    SC.case_compressed_streams(scheme, n, bits)

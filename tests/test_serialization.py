@@ -153,3 +153,10 @@ def test_batch_encoder_needs_batching(emu):
 def test_slot_semantics(emu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_slot_semantics(scheme, n, bits)
+
+
+@needs_ref
+@pytest.mark.parametrize("scheme,n,bits", SMALL)
+def test_compressed_streams(emu, scheme, n, bits):
+    import serial_cases as SC
+    SC.case_compressed_streams(scheme, n, bits)
