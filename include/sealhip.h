@@ -169,14 +169,24 @@ SHL_FUNC BatchEncoder_Decode2(void *thisptr, void *plain, uint64_t *count, int64
 SHL_FUNC BatchEncoder_EncodeDevice(void *thisptr, const uint64_t *device_values, uint64_t batch, bool is_signed, uint64_t *device_coefficients);
 SHL_FUNC BatchEncoder_DecodeDevice(void *thisptr, const uint64_t *device_coefficients, uint64_t batch, bool is_signed, uint64_t *device_values);
 
-/* Encryptor, the secret-key half (native/src/seal/c/encryptor.h; seal::Encryptor::encrypt_symmetric / encrypt_zero_symmetric and
+/* PublicKey / Encryptor (native/src/seal/c/publickey.h, native/src/seal/c/encryptor.h; seal::Encryptor::encrypt_symmetric / encrypt_zero_symmetric and
  * their Serializable<> forms, native/src/seal/encryptor.cpp:116-330, util/rlwe.cpp:270-395).  The randomness follows the
  * reference: a bootstrap Blake2xb PRNG gives the public seed of c_1 (sample_poly_uniform) and the centred-binomial noise
  * (sample_poly_cbd); c_0 = -(c_1 s + e) [+ plaintext] is computed on the device.  Encryptor_SetSeed installs the reference's seeded
  * factory (every encryption restarts from that 8-word seed: reproducible runs, parity tests); NULL returns to operating-system
- * entropy.  The *Save forms write the SEEDED stream (c_0 + the 64-byte seed of c_1: half the size) a client uploads.  public_key
- * must be NULL: public-key encryption is not built. */
+ * entropy.  The *Save forms write the SEEDED stream (c_0 + the 64-byte seed of c_1: half the size) a client uploads.
+ * Public-key encryption (Encryptor_Encrypt / Encryptor_EncryptZero1; util::encrypt_zero_asymmetric, rlwe.cpp:196-268, then the
+ * modulus switch of encryptor.cpp:139-186) draws u from the ternary distribution the way libstdc++'s uniform_int_distribution does
+ * (GCC >= 11), which is what makes it byte-identical to a reference built with that library.  PublicKey_Set takes
+ * PublicKey::data().data() (2*L*N words); either key of Encryptor_Create may be NULL. */
+SHL_FUNC PublicKey_Create(void *context, void **public_key);
+SHL_FUNC PublicKey_Destroy(void *thisptr);
+SHL_FUNC PublicKey_Set(void *thisptr, const uint64_t *host_words, uint64_t word_count);
+SHL_FUNC PublicKey_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+SHL_FUNC PublicKey_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 SHL_FUNC Encryptor_Create(void *context, void *public_key, void *secret_key, void **encryptor);
+SHL_FUNC Encryptor_Encrypt(void *thisptr, void *plaintext, void *destination, void *pool);
+SHL_FUNC Encryptor_EncryptZero1(void *thisptr, uint64_t *parms_id, void *destination, void *pool);
 SHL_FUNC Encryptor_Destroy(void *thisptr);
 SHL_FUNC Encryptor_SetSeed(void *thisptr, const uint64_t *seed);
 SHL_FUNC Encryptor_EncryptZeroSymmetric1(void *thisptr, uint64_t *parms_id, bool save_seed, void *destination, void *pool);

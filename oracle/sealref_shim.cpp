@@ -937,6 +937,44 @@ extern "C"
         *out = h.release();
         REF_CATCH
     }
+    // public-key encryption: PublicKey words, Encryptor::encrypt_zero(parms_id) / encrypt(plain) saved
+    int ref_public_key_copy(void *ctx, uint64_t *out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        if (!c->have_pk)
+        {
+            c->keygen->create_public_key(c->pk);
+            c->have_pk = true;
+        }
+        const Ciphertext &k = c->pk.data();
+        std::memcpy(out, k.data(), k.size() * k.coeff_modulus_size() * k.poly_modulus_degree() * sizeof(uint64_t));
+        REF_CATCH
+    }
+    int ref_encrypt_asymmetric_save(void *ctx, void *pt /* null: encrypt_zero at chain_index */, uint64_t chain_index, uint8_t *out,
+                                    uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        if (!c->have_pk)
+        {
+            c->keygen->create_public_key(c->pk);
+            c->have_pk = true;
+        }
+        Encryptor e(*c->context, c->pk);
+        Ciphertext ct;
+        if (pt)
+            e.encrypt(static_cast<RefPt *>(pt)->pt, ct);
+        else
+        {
+            auto l = c->level(chain_index);
+            if (!l)
+                return 3;
+            e.encrypt_zero(l->parms_id(), ct);
+        }
+        *bytes = static_cast<uint64_t>(ct.save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        REF_CATCH
+    }
     // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)
     int ref_keys_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, uint64_t *bytes)
     {

@@ -68,6 +68,7 @@ SecretKey_Create SecretKey_Destroy SecretKey_Set SecretKey_UnsafeLoad SecretKey_
 Decryptor_Decrypt Decryptor_DecryptBatchWords Decryptor_DecryptBatch
 BatchEncoder_Create BatchEncoder_Destroy BatchEncoder_GetSlotCount BatchEncoder_Encode1 BatchEncoder_Encode2 BatchEncoder_Decode1
 BatchEncoder_Decode2 BatchEncoder_EncodeDevice BatchEncoder_DecodeDevice
+PublicKey_Create PublicKey_Destroy PublicKey_Set PublicKey_UnsafeLoad PublicKey_Load Encryptor_Encrypt Encryptor_EncryptZero1
 Encryptor_Create Encryptor_Destroy Encryptor_SetSeed Encryptor_EncryptZeroSymmetric1 Encryptor_EncryptSymmetric
 Encryptor_SymmetricSaveSize Encryptor_EncryptZeroSymmetricSave Encryptor_EncryptSymmetricSave
 Plaintext_Create1 Plaintext_Create5 Plaintext_Destroy Plaintext_Set4 Plaintext_SetFromDevice Plaintext_CoeffCount

@@ -492,6 +492,30 @@ class Decryptor:
         return buf, w.value
 
 
+class PublicKey:
+    """seal::PublicKey resident in HBM: [2][L][N] words, key level, NTT form"""
+
+    def __init__(self, context, words=None):
+        self.context = context
+        self._h = C.c_void_p()
+        N.check(N.lib().PublicKey_Create(context._h, C.byref(self._h)))
+        if words is not None:
+            a = np.ascontiguousarray(words, dtype=np.uint64)
+            N.check(N.lib().PublicKey_Set(self._h, _p(a), C.c_uint64(a.size)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().PublicKey_Destroy(self._h)
+            self._h = None
+
+    def load_bytes(self, data, unsafe=False):
+        data = bytes(data)
+        n = C.c_int64()
+        fn = N.lib().PublicKey_UnsafeLoad if unsafe else N.lib().PublicKey_Load
+        N.check(fn(self._h, self.context._h, C.cast(C.c_char_p(data), C.c_void_p), C.c_uint64(len(data)), C.byref(n)))
+        return n.value
+
+
 class BatchEncoder:
     """seal::BatchEncoder on the device (sealhip.h): N integers modulo t <-> one plaintext polynomial"""
 
@@ -539,10 +563,11 @@ class BatchEncoder:
 class Encryptor:
     """seal::Encryptor, secret-key half (sealhip.h): encrypt_symmetric / encrypt_zero_symmetric and their seeded streams"""
 
-    def __init__(self, context, secret_key, seed=None):
+    def __init__(self, context, secret_key=None, seed=None, public_key=None):
         self.context = context
         self._h = C.c_void_p()
-        N.check(N.lib().Encryptor_Create(context._h, None, secret_key._h, C.byref(self._h)))
+        N.check(N.lib().Encryptor_Create(context._h, public_key._h if public_key is not None else None,
+                                         secret_key._h if secret_key is not None else None, C.byref(self._h)))
         if seed is not None:
             self.set_seed(seed)
 
@@ -558,6 +583,17 @@ class Encryptor:
             return
         words = [seed] + [0] * 7 if isinstance(seed, int) else list(seed)
         N.check(N.lib().Encryptor_SetSeed(self._h, (C.c_uint64 * 8)(*words)))
+
+    def encrypt(self, plain, destination=None):
+        """Encryptor::encrypt (public key)"""
+        destination = destination if destination is not None else Ciphertext(self.context)
+        N.check(N.lib().Encryptor_Encrypt(self._h, plain._h, destination._h, None))
+        return destination
+
+    def encrypt_zero(self, parms_id, destination=None):
+        destination = destination if destination is not None else Ciphertext(self.context)
+        N.check(N.lib().Encryptor_EncryptZero1(self._h, (C.c_uint64 * 4)(*parms_id), destination._h, None))
+        return destination
 
     def encrypt_zero_symmetric(self, parms_id, destination=None):
         destination = destination if destination is not None else Ciphertext(self.context)

@@ -944,16 +944,102 @@ extern "C"
     }
 
     // ------------------------------------------------------------------ Encryptor, secret-key half (native/src/seal/c/encryptor.h)
+    SHL_FUNC PublicKey_Create(void *context, void **public_key)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(public_key, SHL_E_POINTER);
+        SHL_TRY
+        *public_key = new PublicKey(*as<Context>(context));
+        SHL_CATCH
+    }
+    SHL_FUNC PublicKey_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<PublicKey>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC PublicKey_Set(void *thisptr, const uint64_t *host_words, uint64_t word_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(host_words, SHL_E_POINTER);
+        SHL_TRY
+        as<PublicKey>(thisptr)->set(host_words, (size_t)word_count);
+        SHL_CATCH
+    }
+    namespace
+    {
+        SHL_HRESULT pk_load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes, bool check)
+        {
+            IfNullRet(thisptr, SHL_E_POINTER);
+            IfNullRet(context, SHL_E_POINTER);
+            IfNullRet(inptr, SHL_E_POINTER);
+            IfNullRet(in_bytes, SHL_E_POINTER);
+            SHL_TRY
+            auto pk = as<PublicKey>(thisptr);
+            auto c = as<Context>(context);
+            if (&pk->context() != c)
+                throw std::invalid_argument("public key belongs to another context");
+            // PublicKey::load = Ciphertext::unsafe_load + is_valid_for(PublicKey) (publickey.h:144-154; valcheck.cpp: key level, NTT
+            // form, size 2, every coefficient reduced - the last part only for the checked load)
+            serial::CiphertextImage img;
+            const size_t n = serial::load_ciphertext(*c, inptr, (size_t)size, false, img);
+            bool ok = img.level == &c->key_level() && img.is_ntt_form && img.size == 2;
+            if (ok && check)
+            {
+                std::vector<uint64_t> words(img.word_count());
+                img.copy_words(words.data());
+                for (size_t p = 0; p < 2 && ok; p++)
+                    for (unsigned r = 0; r < img.level->K && ok; r++)
+                    {
+                        const uint64_t q = c->coeff_modulus()[r];
+                        const uint64_t *w = words.data() + (p * img.level->K + r) * c->n();
+                        for (size_t k = 0; k < c->n(); k++)
+                            ok &= w[k] < q;
+                    }
+            }
+            if (!ok)
+                throw std::logic_error("PublicKey data is invalid");
+            pk->set_parts(img.stored, img.stored_words, img.expanded.data(), img.expanded.size());
+            *in_bytes = (int64_t)n;
+            SHL_CATCH
+        }
+    } // namespace
+    SHL_FUNC PublicKey_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return pk_load(thisptr, context, inptr, size, in_bytes, true);
+    }
+    SHL_FUNC PublicKey_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
+    {
+        return pk_load(thisptr, context, inptr, size, in_bytes, false);
+    }
     SHL_FUNC Encryptor_Create(void *context, void *public_key, void *secret_key, void **encryptor)
     {
         IfNullRet(context, SHL_E_POINTER);
         IfNullRet(encryptor, SHL_E_POINTER);
         SHL_TRY
-        if (public_key)
-            throw std::invalid_argument("public-key encryption is not built: pass NULL for public_key");
-        if (!secret_key)
-            throw std::invalid_argument("secret key is not set");
-        *encryptor = new Encryptor(*as<Context>(context), *as<SecretKey>(secret_key));
+        if (!public_key && !secret_key)
+            throw std::invalid_argument("neither a public key nor a secret key is set");
+        *encryptor = new Encryptor(*as<Context>(context), as<PublicKey>(public_key), as<SecretKey>(secret_key));
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_Encrypt(void *thisptr, void *plaintext, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plaintext, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Encryptor>(thisptr)->encrypt(*as<Plaintext>(plaintext), *as<Ciphertext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_EncryptZero1(void *thisptr, uint64_t *parms_id, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<Encryptor>(thisptr)->encrypt_zero(parms_id, *as<Ciphertext>(destination));
         SHL_CATCH
     }
     SHL_FUNC Encryptor_Destroy(void *thisptr)

@@ -20,7 +20,7 @@ namespace sealhip
     // symmetric encryption tail (encrypt_zero_symmetric, util/rlwe.cpp:357-381): c0 <- -(c0 + e * m) mod q_r over [K][N] words,
     // m = t (BGV: the noise is p*e) or 1
     hipError_t k_neg_add_noise(const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K,
-                               hipStream_t s);
+                               hipStream_t s, bool negate = true); // negate == false: c0 <- c0 + e * m (public-key encryption)
     // BatchEncoder index map (batchencoder.cpp:97-123): scatter out[b][map[i]] = in[b][i] (encode), gather out[b][i] = in[b][map[i]]
     // (decode) over `batch` vectors of N words; signed_mod != 0 converts between the balanced signed representation and [0, t):
     // encode: negative int64 v -> t + v; decode: value > t/2 -> value - t (as int64)

@@ -53,7 +53,7 @@ namespace sealhip
         }
 
         __global__ void __launch_bounds__(kBlock) neg_add_noise_kernel(
-            const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K)
+            const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K, bool negate)
         {
             for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
             {
@@ -61,7 +61,8 @@ namespace sealhip
                 uint64_t noise = e[i];
                 if (m != 1)
                     noise = mul_mod(noise, barrett64(m, md), md);
-                c0[i] = neg_mod(add_mod(c0[i], noise, md.q), md.q);
+                const uint64_t sum = add_mod(c0[i], noise, md.q);
+                c0[i] = negate ? neg_mod(sum, md.q) : sum;
             }
         }
 
@@ -172,11 +173,11 @@ namespace sealhip
         return hipGetLastError();
     }
     hipError_t k_neg_add_noise(const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K,
-                               hipStream_t s)
+                               hipStream_t s, bool negate)
     {
         if (!words)
             return hipSuccess;
-        hipLaunchKernelGGL(neg_add_noise_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, c0, e, m, words, n_log, K);
+        hipLaunchKernelGGL(neg_add_noise_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, c0, e, m, words, n_log, K, negate);
         return hipGetLastError();
     }
     hipError_t k_slot_scatter(const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, unsigned batch, uint64_t signed_mod,

@@ -39,6 +39,28 @@ namespace sealhip
         ck(hipMemcpy(dev_, host_words, want * 8, hipMemcpyHostToDevice), "upload secret key");
     }
 
+    PublicKey::~PublicKey()
+    {
+        if (dev_)
+            (void)hipFree(dev_);
+    }
+    void PublicKey::set_parts(const void *stored, size_t stored_words, const uint64_t *expanded, size_t expanded_words)
+    {
+        const size_t want = 2 * ctx_->key_level().K * ctx_->n();
+        if (stored_words + expanded_words != want || (stored_words && !stored))
+            throw std::invalid_argument("public key is not valid for encryption parameters");
+        if (!dev_)
+            ck(hipMalloc(reinterpret_cast<void **>(&dev_), want * 8), "hipMalloc public key");
+        if (stored_words)
+            ck(hipMemcpy(dev_, stored, stored_words * 8, hipMemcpyHostToDevice), "upload public key");
+        if (expanded_words)
+            ck(hipMemcpy(dev_ + stored_words, expanded, expanded_words * 8, hipMemcpyHostToDevice), "upload public key");
+    }
+    void PublicKey::set(const void *host_words, size_t word_count)
+    {
+        set_parts(host_words, word_count, nullptr, 0);
+    }
+
     Decryptor::Decryptor(const Context &context, const SecretKey &secret_key) : context_(context)
     {
         if (&secret_key.context() != &context || !secret_key.data())
@@ -335,16 +357,108 @@ namespace sealhip
     }
 
     // ---------------------------------------------------------------- Encryptor (secret-key encryption)
-    Encryptor::Encryptor(const Context &context, const SecretKey &secret_key) : context_(context), evaluator_(context)
+    Encryptor::Encryptor(const Context &context, const PublicKey *public_key, const SecretKey *secret_key)
+        : context_(context), evaluator_(context)
     {
-        if (&secret_key.context() != &context || !secret_key.data())
-            throw std::invalid_argument("secret key is not valid for encryption parameters");
         const size_t words = context.key_level().K * context.n();
-        ck(hipMalloc(reinterpret_cast<void **>(&sk_), words * 8), "hipMalloc secret key");
-        ck(hipMemcpy(sk_, secret_key.data(), words * 8, hipMemcpyDeviceToDevice), "copy secret key");
+        if (secret_key)
+        {
+            if (&secret_key->context() != &context || !secret_key->data())
+                throw std::invalid_argument("secret key is not valid for encryption parameters");
+            ck(hipMalloc(reinterpret_cast<void **>(&sk_), words * 8), "hipMalloc secret key");
+            ck(hipMemcpy(sk_, secret_key->data(), words * 8, hipMemcpyDeviceToDevice), "copy secret key");
+        }
+        if (public_key)
+        {
+            if (&public_key->context() != &context || !public_key->data())
+                throw std::invalid_argument("public key is not valid for encryption parameters");
+            ck(hipMalloc(reinterpret_cast<void **>(&pk_), 2 * words * 8), "hipMalloc public key");
+            ck(hipMemcpy(pk_, public_key->data(), 2 * words * 8, hipMemcpyDeviceToDevice), "copy public key");
+        }
     }
+    void Encryptor::bootstrap_seed(uint64_t *seed8) const
+    {
+        if (seeded_)
+            std::memcpy(seed8, seed_, 64);
+        else
+            host::random_bytes(seed8, 64);
+    }
+
+    // util::encrypt_zero_asymmetric (util/rlwe.cpp:196-268) at `lvl`
+    void Encryptor::zero_asymmetric_at(const Level &lvl, Ciphertext &d)
+    {
+        const size_t n = context_.n(), K = lvl.K, L = context_.key_level().K, words = K * n;
+        const unsigned n_log = (unsigned)context_.log_n();
+        const Scheme scheme = context_.scheme();
+        const bool ntt_form = scheme != Scheme::bfv;
+        // host: u <- R_3, then e_0, e_1 <- chi, all from one PRNG, in this order
+        uint64_t boot[8];
+        bootstrap_seed(boot);
+        serial::Prng prng(1, boot);
+        std::vector<uint64_t> u(words), e(2 * words);
+        serial::sample_poly_ternary(prng, context_.coeff_modulus().data(), K, n, u.data());
+        serial::sample_poly_cbd(prng, context_.coeff_modulus().data(), K, n, e.data());
+        serial::sample_poly_cbd(prng, context_.coeff_modulus().data(), K, n, e.data() + words);
+
+        ck(hipStreamSynchronize(nullptr), "encrypt sync");
+        d.resize(&lvl, 2, nullptr);
+        d.is_ntt_form() = ntt_form;
+        d.scale() = 1.0;
+        d.correction_factor() = 1;
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        Scratch du(words), de(2 * words);
+        ck(hipMemcpy(du.p, u.data(), words * 8, hipMemcpyHostToDevice), "upload u");
+        ck(hipMemcpy(de.p, e.data(), 2 * words * 8, hipMemcpyHostToDevice), "upload noise");
+        ck(ntt_forward(tb, polys(du.p, K, n, 1), 0, nullptr), "ntt u");
+        for (size_t j = 0; j < 2; j++)
+            ck(k_dyadic(mods, du.p, pk_ + j * L * n, d.plane(j), n_log, (unsigned)K, 0, 1, nullptr), "pk u");
+        if (ntt_form)
+            ck(ntt_forward(tb, polys(de.p, K, n, 2), 0, nullptr), "ntt noise");
+        else
+            ck(ntt_inverse(tb, polys(d.data(), K, n, 2), 0, nullptr), "intt pk u");
+        ck(k_neg_add_noise(mods, d.data(), de.p, scheme == Scheme::bgv ? context_.plain_modulus() : 1, 2 * words, n_log, (unsigned)K, nullptr,
+                           false),
+           "c + e");
+        ck(hipStreamSynchronize(nullptr), "encrypt sync");
+    }
+    // Encryptor::encrypt_zero_internal, asymmetric branch (encryptor.cpp:139-186): encrypt one level up, switch down
+    void Encryptor::zero_asymmetric(const Level &lvl, Ciphertext &d)
+    {
+        if (!pk_)
+            throw std::logic_error("public key is not set");
+        if (&d.context() != &context_)
+            throw std::invalid_argument("destination belongs to another context");
+        if (d.batch() != 1)
+            throw std::invalid_argument("Encryptor encrypts one ciphertext at a time: destination must be a batch of one");
+        const Level *prev = context_.level_by_chain_index(lvl.chain_index + 1);
+        if (!prev)
+        {
+            zero_asymmetric_at(lvl, d);
+            return;
+        }
+        zero_asymmetric_at(*prev, d);
+        evaluator_.mod_switch_scale_to_next(d);
+        evaluator_.synchronize();
+        d.scale() = 1.0;             // destination.scale() = temp.scale(), .correction_factor() = temp.correction_factor()
+        d.correction_factor() = 1;
+    }
+    void Encryptor::encrypt_zero(const uint64_t *parms_id, Ciphertext &destination)
+    {
+        zero_asymmetric(*level_for(parms_id), destination);
+    }
+    void Encryptor::encrypt(const Plaintext &plain, Ciphertext &destination)
+    {
+        if (!pk_)
+            throw std::logic_error("public key is not set");
+        zero_asymmetric(*level_for(plain), destination);
+        add_plain(plain, destination);
+    }
+
     Encryptor::~Encryptor()
     {
+        if (pk_)
+            (void)hipFree(pk_);
         if (sk_)
         {
             (void)hipMemset(sk_, 0, context_.key_level().K * context_.n() * 8);
@@ -391,6 +505,8 @@ namespace sealhip
     // util::encrypt_zero_symmetric (util/rlwe.cpp:270-395)
     void Encryptor::zero(const Level &lvl, bool save_seed, Ciphertext &d, uint64_t *public_seed)
     {
+        if (!sk_)
+            throw std::logic_error("secret key is not set");
         if (&d.context() != &context_)
             throw std::invalid_argument("destination belongs to another context");
         if (d.batch() != 1)
@@ -405,10 +521,7 @@ namespace sealhip
 
         // host: the reference's randomness, in the reference's order
         uint64_t boot_seed[8];
-        if (seeded_)
-            std::memcpy(boot_seed, seed_, sizeof(boot_seed));
-        else
-            host::random_bytes(boot_seed, sizeof(boot_seed));
+        bootstrap_seed(boot_seed);
         serial::Prng bootstrap(1, boot_seed);
         uint64_t pub[8];
         bootstrap.generate(sizeof(pub), reinterpret_cast<uint8_t *>(pub));

@@ -28,6 +28,24 @@ namespace sealhip
         uint64_t *dev_ = nullptr;
     };
 
+    // seal::PublicKey (publickey.h): a size-2 key-level ciphertext in NTT form, [2][L][N] words, resident in HBM
+    class PublicKey
+    {
+    public:
+        explicit PublicKey(const Context &ctx) : ctx_(&ctx) {}
+        ~PublicKey();
+        PublicKey(const PublicKey &) = delete;
+        PublicKey &operator=(const PublicKey &) = delete;
+        const Context &context() const { return *ctx_; }
+        void set(const void *host_words, size_t word_count); // 2*L*N words: PublicKey::data().data()
+        void set_parts(const void *stored, size_t stored_words, const uint64_t *expanded, size_t expanded_words);
+        const uint64_t *data() const { return dev_; }
+
+    private:
+        const Context *ctx_;
+        uint64_t *dev_ = nullptr;
+    };
+
     class Decryptor
     {
     public:
@@ -82,12 +100,18 @@ namespace sealhip
     // Serializable<> forms; encryptor.cpp:116-330, util/rlwe.cpp:270-395).  The randomness is the reference's: a bootstrap
     // Blake2xb PRNG yields the public seed of c_1 = a (expanded by sample_poly_uniform) and the centred-binomial noise e
     // (sample_poly_cbd); both are sampled on the host and c_0 = -(a s + e) [+ the plaintext] is computed on the device.
-    // Public-key encryption is not built: its ternary sampler goes through std::uniform_int_distribution, whose algorithm is
-    // the C++ library's, so bit-exactness with a given reference build cannot be promised.
+    // Public-key encryption (encrypt / encrypt_zero; util::encrypt_zero_asymmetric, rlwe.cpp:196-268) follows the same pattern with
+    // u <- ternary (serial.h: sample_poly_ternary, tied to libstdc++'s uniform_int_distribution), c_j = pk_j u + e_j at the level
+    // above and one modulus switch down (encryptor.cpp:139-186).
     class Encryptor
     {
     public:
-        Encryptor(const Context &context, const SecretKey &secret_key);
+        // either key may be null (Encryptor(context, public_key) / (context, secret_key) / both)
+        Encryptor(const Context &context, const PublicKey *public_key, const SecretKey *secret_key);
+        Encryptor(const Context &context, const SecretKey &secret_key) : Encryptor(context, nullptr, &secret_key) {}
+        // Encryptor::encrypt_zero(parms_id, destination) / encrypt(plain, destination): public-key encryption, batch of one
+        void encrypt_zero(const uint64_t *parms_id, Ciphertext &destination);
+        void encrypt(const Plaintext &plain, Ciphertext &destination);
         ~Encryptor();
         Encryptor(const Encryptor &) = delete;
         Encryptor &operator=(const Encryptor &) = delete;
@@ -109,6 +133,10 @@ namespace sealhip
         const Level *level_for(const uint64_t *parms_id) const;
         const Level *level_for(const Plaintext &plain) const; // + the checks of Encryptor::encrypt_internal
         void zero(const Level &lvl, bool save_seed, Ciphertext &destination, uint64_t *public_seed);
+        void zero_asymmetric(const Level &lvl, Ciphertext &destination);
+        void zero_asymmetric_at(const Level &lvl, Ciphertext &destination); // util::encrypt_zero_asymmetric
+        void bootstrap_seed(uint64_t *seed8) const;
+        uint64_t *pk_ = nullptr; // [2][L][N], NTT form
         void add_plain(const Plaintext &plain, Ciphertext &destination);
         size_t save(const Ciphertext &ct, const uint64_t *public_seed, uint8_t *out, size_t capacity) const;
         const Context &context_;

@@ -216,6 +216,7 @@ namespace sealhip
         void apply_galois_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts) const;
 
     private:
+        friend class Encryptor; // public-key encryption ends with one modulus switch from the level above (encryptor.cpp:139-186)
         void check_valid(const Ciphertext &ct, const char *what) const;
         bool scale_within_bounds(double scale, const Level &lvl) const;
         void bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const;

@@ -68,6 +68,23 @@ namespace sealhip
                 dst += N;
             }
         }
+        void sample_poly_ternary(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+        {
+            for (size_t k = 0; k < N; k++)
+            {
+                // RandomToStandardAdapter::operator() = 4 bytes of the stream as one uint32_t (randomtostd.h:43-57)
+                uint32_t g;
+                uint64_t product;
+                do
+                {
+                    prng.generate(sizeof(g), reinterpret_cast<uint8_t *>(&g));
+                    product = (uint64_t)g * 3u;
+                } while ((uint32_t)product < 1u /* threshold = (2^32 - 3) mod 3 */);
+                const uint64_t rand = product >> 32; // 0, 1, 2 -> coefficient -1, 0, 1
+                for (size_t j = 0; j < K; j++)
+                    dst[j * N + k] = rand == 0 ? primes[j] - 1 : rand - 1;
+            }
+        }
         // sample_poly_cbd (util/rlwe.cpp): centred binomial noise of standard deviation 3.2 - 6 bytes per coefficient, the
         // difference of two 21-bit Hamming weights - replicated into every RNS component (negative values as q_i + noise)
         void sample_poly_cbd(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)

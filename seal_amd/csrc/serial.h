@@ -121,6 +121,11 @@ namespace sealhip
         };
         void sample_poly_uniform(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst);
         void sample_poly_cbd(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst);
+        // sample_poly_ternary (util/rlwe.cpp:24-43).  The reference draws each coefficient with std::uniform_int_distribution
+        // <uint64_t>(0, 2) over a 32-bit generator, whose algorithm belongs to the C++ library: this restates libstdc++'s
+        // (GCC >= 11: Lemire's multiply-shift, bits/uniform_int_dist.h _S_nd) - value = (g * 3) >> 32 with g = 0 redrawn - which is
+        // what the reference build in this image uses (checked byte for byte in tests/decrypt_cases.py).
+        void sample_poly_ternary(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst);
         // Serializable<Ciphertext>::save of a seeded ciphertext (ciphertext.cpp:171-196): members, DynArray with c_0 only, then
         // the UniformRandomGeneratorInfo (type, seed) c_1 is re-expanded from.  words == nullptr: as save_ciphertext.
         size_t seeded_ciphertext_save_size(uint64_t poly_modulus_degree, uint64_t coeff_modulus_size);

@@ -265,3 +265,36 @@ def case_slot_semantics(scheme, n, bits):
     m = np.roll(m, 2, axis=1)        # rotate_rows(-2)
     m = m[::-1]                      # rotate_columns: swap the two rows
     assert np.array_equal(got, m.reshape(-1)), "slot semantics"
+
+
+def case_encrypt_asymmetric(scheme, n, bits, seed=0x5EA1):
+    """public-key encryption with the reference's randomness: zero encryptions at every data level (they go through the modulus
+    switch from the level above) and the encryption of an encoded plaintext equal Encryptor(context, public_key)'s bytes; the
+    PublicKey comes as raw words and as its serialized stream"""
+    primes, t, ref, d, dec, _ = _setup(scheme, n, bits)
+    pk_words = S.PublicKey(d.ctx, ref.public_key())
+    pk_stream = S.PublicKey(d.ctx)
+    assert pk_stream.load_bytes(ref.public_key_save()) > 0
+    for pk in (pk_words, pk_stream):
+        enc = S.Encryptor(d.ctx, public_key=pk, seed=seed)
+        for ci in range(ref.first_chain_index, -1, -1):
+            ct = enc.encrypt_zero(d.ctx.parms_id_at(ci))
+            assert ct.save_bytes() == ref.encrypt_asymmetric_save(None, ci), ("encrypt_zero", ci)
+    rng = np.random.default_rng(37)
+    if scheme == "ckks":
+        rpt = ref.ckks_encode(rng.standard_normal(n // 2), ref.first_chain_index, 2.0 ** 25)
+    else:
+        rpt = ref.batch_encode(rng.integers(0, t, n, dtype=np.uint64))
+    pt = S.Plaintext(d.ctx)
+    pt.load_bytes(ref.pt_save(rpt))
+    ct = enc.encrypt(pt)
+    assert ct.save_bytes() == ref.encrypt_asymmetric_save(rpt), "encrypt(plain)"
+    _same_plain(dec.decrypt(ct), ref.decrypt(ref.ct_load(ct.save_bytes())[0]), "decrypt(encrypt(plain))")
+    # without a public key / secret key the respective calls are refused like the reference does (logic_error)
+    only_sk = S.Encryptor(d.ctx, S.SecretKey(d.ctx, ref.secret_key()))
+    for bad in (lambda: only_sk.encrypt(pt), lambda: enc.encrypt_symmetric(pt)):
+        try:
+            bad()
+            raise AssertionError("expected LogicError")
+        except S.LogicError:
+            pass

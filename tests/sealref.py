@@ -327,6 +327,19 @@ class RefContext:
         _ck(lib().ref_batch_encode_signed(self.h, _p(v), C.c_uint64(v.size), C.byref(h)))
         return RefPlaintext(self, h)
 
+    def public_key(self):
+        out = np.zeros((2, len(self.primes), self.n), dtype=np.uint64)
+        _ck(lib().ref_public_key_copy(self.h, _p(out)))
+        return out
+
+    def encrypt_asymmetric_save(self, pt=None, chain_index=0):
+        """Encryptor(context, public_key).encrypt(pt) (or encrypt_zero at chain_index) saved in full"""
+        cap = 4096 + 8 * 2 * len(self.primes) * self.n
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_encrypt_asymmetric_save(self.h, pt.h if pt is not None else None, C.c_uint64(chain_index), buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[:n.value])
+
     def keys_load(self, data, unsafe=False):
         buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
         n = C.c_uint64()

@@ -84,3 +84,9 @@ def test_slot_semantics(gpu, scheme, n, bits):
 @pytest.mark.parametrize("scheme,n,bits", SIZES[:2] + [("ckks", 32768, [60, 50, 50, 60])])
 def test_compressed_streams(gpu, scheme, n, bits):
     SC.case_compressed_streams(scheme, n, bits)
+
+
+@pytest.mark.parametrize("scheme,n,bits", SIZES + [("ckks", 32768, [60, 50, 50, 50, 60])])
+def test_encrypt_asymmetric(gpu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_encrypt_asymmetric(scheme, n, bits)

@@ -160,3 +160,10 @@ def test_slot_semantics(emu, scheme, n, bits):
 def test_compressed_streams(emu, scheme, n, bits):
     import serial_cases as SC
     SC.case_compressed_streams(scheme, n, bits)
+
+
+@needs_ref
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45]), ("bfv", 1024, [40])])
+def test_encrypt_asymmetric(emu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_encrypt_asymmetric(scheme, n, bits)
