@@ -155,6 +155,19 @@ SHL_FUNC Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
 SHL_FUNC Decryptor_DecryptBatchWords(void *thisptr, void *encrypted, uint64_t *word_count);
 SHL_FUNC Decryptor_DecryptBatch(void *thisptr, void *encrypted, uint64_t *device_out, uint64_t word_count);
 
+/* CKKSEncoder (native/src/seal/c/ckksencoder.h:16-49; seal::CKKSEncoder::encode / decode, native/src/seal/ckks.h:458-789): vectors of
+ * N/2 real (Encode1 / Decode1) or complex (Encode2 / Decode2: interleaved re, im) numbers <-> NTT-form plaintexts at a level with a
+ * scale.  The double-precision FFT, the rounding and the CRT composition repeat the reference's IEEE operations in its order, so the
+ * plaintext words of Encode and the doubles of Decode are the reference's bit for bit (coefficients up to 128 bits on encode). */
+SHL_FUNC CKKSEncoder_Create(void *context, void **ckks_encoder);
+SHL_FUNC CKKSEncoder_Destroy(void *thisptr);
+SHL_FUNC CKKSEncoder_SlotCount(void *thisptr, uint64_t *slot_count);
+SHL_FUNC CKKSEncoder_Encode1(void *thisptr, uint64_t value_count, double *values, uint64_t *parms_id, double scale, void *destination, void *pool);
+SHL_FUNC CKKSEncoder_Encode2(void *thisptr, uint64_t value_count, double *complex_values, uint64_t *parms_id, double scale, void *destination,
+                             void *pool);
+SHL_FUNC CKKSEncoder_Decode1(void *thisptr, void *plain, uint64_t *value_count, double *values, void *pool);
+SHL_FUNC CKKSEncoder_Decode2(void *thisptr, void *plain, uint64_t *value_count, double *values, void *pool);
+
 /* BatchEncoder (native/src/seal/c/batchencoder.h:16-30; seal::BatchEncoder::encode / decode, native/src/seal/batchencoder.cpp:97-447):
  * N integers modulo t <-> one plaintext polynomial through the NTT modulo t and the matrix index map.  Encode1 / Decode1 take
  * unsigned values, Encode2 / Decode2 signed ones, host vectors as in sealc (Decode writes N values).  The *Device forms convert

@@ -16,6 +16,7 @@
 #include "seal/util/polyarithsmallmod.h"
 #include "seal/util/rns.h"
 #include <chrono>
+#include <complex>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -973,6 +974,43 @@ extern "C"
             e.encrypt_zero(l->parms_id(), ct);
         }
         *bytes = static_cast<uint64_t>(ct.save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        REF_CATCH
+    }
+    // CKKSEncoder::encode of complex values / decode of a plaintext handle (real or complex)
+    int ref_ckks_encode_complex(void *ctx, const double *re_im, uint64_t count, uint64_t chain_index, double scale, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 3;
+        CKKSEncoder enc(*c->context);
+        auto h = std::make_unique<RefPt>();
+        std::vector<std::complex<double>> v(count);
+        for (uint64_t i = 0; i < count; i++)
+            v[i] = { re_im[2 * i], re_im[2 * i + 1] };
+        enc.encode(v, l->parms_id(), scale, h->pt);
+        *out = h.release();
+        REF_CATCH
+    }
+    int ref_ckks_decode(void *ctx, void *pt, int want_complex, double *out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        CKKSEncoder enc(*c->context);
+        const Plaintext &p = static_cast<RefPt *>(pt)->pt;
+        if (want_complex)
+        {
+            std::vector<std::complex<double>> v;
+            enc.decode(p, v);
+            std::memcpy(out, v.data(), v.size() * 16);
+        }
+        else
+        {
+            std::vector<double> v;
+            enc.decode(p, v);
+            std::memcpy(out, v.data(), v.size() * 8);
+        }
         REF_CATCH
     }
     // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)

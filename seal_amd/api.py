@@ -492,6 +492,44 @@ class Decryptor:
         return buf, w.value
 
 
+class CKKSEncoder:
+    """seal::CKKSEncoder on the device (sealhip.h)"""
+
+    def __init__(self, context):
+        self.context = context
+        self._h = C.c_void_p()
+        N.check(N.lib().CKKSEncoder_Create(context._h, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().CKKSEncoder_Destroy(self._h)
+            self._h = None
+
+    def slot_count(self):
+        v = C.c_uint64()
+        N.check(N.lib().CKKSEncoder_SlotCount(self._h, C.byref(v)))
+        return v.value
+
+    def encode(self, values, parms_id, scale, destination=None):
+        destination = destination if destination is not None else Plaintext(self.context)
+        a = np.asarray(values)
+        pid = (C.c_uint64 * 4)(*parms_id)
+        if np.iscomplexobj(a):
+            a = np.ascontiguousarray(a, dtype=np.complex128)
+            N.check(N.lib().CKKSEncoder_Encode2(self._h, C.c_uint64(a.size), _p(a), pid, C.c_double(scale), destination._h, None))
+        else:
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            N.check(N.lib().CKKSEncoder_Encode1(self._h, C.c_uint64(a.size), _p(a), pid, C.c_double(scale), destination._h, None))
+        return destination
+
+    def decode(self, plain, complex_values=False):
+        n = C.c_uint64()
+        out = np.zeros(self.slot_count(), dtype=np.complex128 if complex_values else np.float64)
+        fn = N.lib().CKKSEncoder_Decode2 if complex_values else N.lib().CKKSEncoder_Decode1
+        N.check(fn(self._h, plain._h, C.byref(n), _p(out), None))
+        return out
+
+
 class PublicKey:
     """seal::PublicKey resident in HBM: [2][L][N] words, key level, NTT form"""
 

@@ -4,6 +4,7 @@
 // (native/src/seal/c/utilities.h).
 #include "../../include/sealhip.h"
 #include "evaluator.h"
+#include "ckks_encoder.h"
 #include "decryptor.h"
 #include "serial.h"
 #include <cstring>
@@ -863,6 +864,72 @@ extern "C"
             throw std::invalid_argument("word_count does not match Decryptor_DecryptBatchWords");
         hip_ok(hipDeviceSynchronize(), "sync");
         d->decrypt_batch(*as<Ciphertext>(encrypted), device_out);
+        SHL_CATCH
+    }
+
+    // ------------------------------------------------------------------ CKKSEncoder (native/src/seal/c/ckksencoder.h)
+    SHL_FUNC CKKSEncoder_Create(void *context, void **ckks_encoder)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(ckks_encoder, SHL_E_POINTER);
+        SHL_TRY
+        *ckks_encoder = new CKKSEncoder(*as<Context>(context));
+        SHL_CATCH
+    }
+    SHL_FUNC CKKSEncoder_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<CKKSEncoder>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC CKKSEncoder_SlotCount(void *thisptr, uint64_t *slot_count)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(slot_count, SHL_E_POINTER);
+        *slot_count = as<CKKSEncoder>(thisptr)->slot_count();
+        return SHL_S_OK;
+    }
+    SHL_FUNC CKKSEncoder_Encode1(void *thisptr, uint64_t value_count, double *values, uint64_t *parms_id, double scale, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<CKKSEncoder>(thisptr)->encode(values, (size_t)value_count, false, parms_id, scale, *as<Plaintext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC CKKSEncoder_Encode2(void *thisptr, uint64_t value_count, double *complex_values, uint64_t *parms_id, double scale, void *destination,
+                                 void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<CKKSEncoder>(thisptr)->encode(complex_values, (size_t)value_count, true, parms_id, scale, *as<Plaintext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC CKKSEncoder_Decode1(void *thisptr, void *plain, uint64_t *value_count, double *values, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plain, SHL_E_POINTER);
+        IfNullRet(value_count, SHL_E_POINTER);
+        SHL_TRY
+        as<CKKSEncoder>(thisptr)->decode(*as<Plaintext>(plain), values, false);
+        *value_count = as<CKKSEncoder>(thisptr)->slot_count();
+        SHL_CATCH
+    }
+    SHL_FUNC CKKSEncoder_Decode2(void *thisptr, void *plain, uint64_t *value_count, double *values, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(plain, SHL_E_POINTER);
+        IfNullRet(value_count, SHL_E_POINTER);
+        SHL_TRY
+        as<CKKSEncoder>(thisptr)->decode(*as<Plaintext>(plain), values, true);
+        *value_count = as<CKKSEncoder>(thisptr)->slot_count();
         SHL_CATCH
     }
 

@@ -298,3 +298,70 @@ def case_encrypt_asymmetric(scheme, n, bits, seed=0x5EA1):
             raise AssertionError("expected LogicError")
         except S.LogicError:
             pass
+
+
+def case_ckks_encoder(n, bits, check_bits=True):
+    """CKKSEncoder on the device: the plaintext words of encode (real and complex vectors, short and full, small and > 64-bit
+    scales, every level) and the doubles of decode equal the reference's BIT FOR BIT - the FFT, the rounding and the CRT
+    composition repeat its IEEE operations in its order; the client loop encode -> encrypt -> multiply / relinearize / rescale
+    -> decrypt -> decode returns a*b within the scheme's approximation"""
+    primes, t, ref, d, dec, _ = _setup("ckks", n, bits)
+    enc = S.CKKSEncoder(d.ctx)
+    assert enc.slot_count() == n // 2
+    rng = np.random.default_rng(71)
+    total_bits = sum(bits[:-1])
+    scales = [2.0 ** 30, 2.0 ** 20]
+    if total_bits > 100:
+        scales.append(2.0 ** 80)     # coefficients above 64 bits: the 128-bit decomposition path
+    for ci in range(ref.first_chain_index, -1, -1):
+        pid = d.ctx.parms_id_at(ci)
+        for scale in scales:
+            if np.log2(scale) + 8 >= sum(bits[: ci + 1]):
+                continue
+            for vals in (rng.standard_normal(n // 2) * 10, rng.standard_normal(5), np.zeros(0),
+                         rng.standard_normal(n // 2) + 1j * rng.standard_normal(n // 2), (rng.standard_normal(3) + 2j)):
+                try:
+                    if np.iscomplexobj(vals):
+                        rpt = ref.ckks_encode_complex(vals, ci, scale)
+                    else:
+                        rpt = ref.ckks_encode(vals if vals.size else np.zeros(0), ci, scale)
+                except sealref.RefError as err:
+                    # e.g. "encoded values are too large" at a small level: the same exception class here
+                    want_cls = {1: S.InvalidArgument, 2: S.LogicError}[err.code]
+                    try:
+                        enc.encode(vals, pid, scale)
+                        raise AssertionError("the reference rejected this input (%s)" % err)
+                    except want_cls:
+                        continue
+                pt = enc.encode(vals, pid, scale)
+                assert pt.is_ntt_form() and pt.scale() == scale and pt.parms_id() == pid
+                assert np.array_equal(pt.to_numpy(), rpt.data()), ("encode", ci, scale, vals.size)
+                for cplx in (False, True):
+                    got, want = enc.decode(pt, cplx), ref.ckks_decode(rpt, cplx)
+                    if check_bits:
+                        assert got.tobytes() == want.tobytes(), ("decode bits", ci, scale, vals.size, cplx)
+                    assert np.array_equal(got, want)
+    # argument checks (ckks.h:463-509, 686-716)
+    pid = d.ctx.parms_id_at(ref.first_chain_index)
+    for bad in (lambda: enc.encode(np.zeros(n // 2 + 1), pid, 2.0 ** 20), lambda: enc.encode(np.ones(4), pid, 0.0),
+                lambda: enc.encode(np.ones(4), pid, 2.0 ** 2000 if False else float("inf")), lambda: enc.encode(np.array([np.nan]), pid, 2.0 ** 20),
+                lambda: enc.encode(np.ones(4), (1, 2, 3, 4), 2.0 ** 20), lambda: enc.encode(np.ones(4) * 1e300, pid, 2.0 ** 40)):
+        try:
+            bad()
+            raise AssertionError("expected InvalidArgument")
+        except S.InvalidArgument:
+            pass
+    # the client loop on the device
+    ref.keygen_relin()
+    e = S.Encryptor(d.ctx, S.SecretKey(d.ctx, ref.secret_key()))
+    rlk = S.RelinKeys(d.ctx)
+    rlk.load_bytes(ref.keys_save("relin", True))
+    a, b = rng.standard_normal(n // 2), rng.standard_normal(n // 2)
+    scale = 2.0 ** (bits[-2] if len(bits) > 2 else 12)   # about the prime the rescale divides by
+    ca, cb = e.encrypt_symmetric(enc.encode(a, pid, scale)), e.encrypt_symmetric(enc.encode(b, pid, scale))
+    d.ev.multiply_inplace(ca, cb)
+    d.ev.relinearize_inplace(ca, rlk)
+    if len(primes) > 2:
+        d.ev.rescale_to_next_inplace(ca)
+    got = enc.decode(dec.decrypt(ca))
+    assert np.max(np.abs(got - a * b)) < 1e-2, np.max(np.abs(got - a * b))

@@ -33,6 +33,24 @@ struct dim3
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_)
     {}
 };
+struct alignas(16) double2
+{
+    double x, y;
+};
+// blocks and lanes run one at a time in the emulator: a plain read-modify-write is atomic
+static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v)
+{
+    unsigned long long old = *p;
+    if (v > old)
+        *p = v;
+    return old;
+}
+static inline long long __double_as_longlong(double d)
+{
+    long long r;
+    std::memcpy(&r, &d, 8);
+    return r;
+}
 struct alignas(16) ulonglong2
 {
     unsigned long long x, y;

@@ -340,6 +340,17 @@ class RefContext:
         _ck(lib().ref_encrypt_asymmetric_save(self.h, pt.h if pt is not None else None, C.c_uint64(chain_index), buf, C.c_uint64(cap), C.byref(n)))
         return bytes(buf[:n.value])
 
+    def ckks_encode_complex(self, values, chain_index, scale):
+        v = np.ascontiguousarray(values, dtype=np.complex128)
+        h = C.c_void_p()
+        _ck(lib().ref_ckks_encode_complex(self.h, _p(v), C.c_uint64(v.size), C.c_uint64(chain_index), C.c_double(scale), C.byref(h)))
+        return RefPlaintext(self, h)
+
+    def ckks_decode(self, pt, complex_values=False):
+        out = np.zeros(self.n // 2, dtype=np.complex128 if complex_values else np.float64)
+        _ck(lib().ref_ckks_decode(self.h, pt.h, C.c_int(1 if complex_values else 0), _p(out)))
+        return out
+
     def keys_load(self, data, unsafe=False):
         buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
         n = C.c_uint64()

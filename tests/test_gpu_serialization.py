@@ -90,3 +90,9 @@ def test_compressed_streams(gpu, scheme, n, bits):
 def test_encrypt_asymmetric(gpu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_encrypt_asymmetric(scheme, n, bits)
+
+
+@pytest.mark.parametrize("n,bits", [(8192, [60, 40, 40, 60]), (32768, [60, 50, 50, 50, 60]), (65536, [60] + [50] * 14 + [60])])
+def test_ckks_encoder(gpu, n, bits):
+    import decrypt_cases as DC
+    DC.case_ckks_encoder(n, bits)

@@ -167,3 +167,10 @@ def test_compressed_streams(emu, scheme, n, bits):
 def test_encrypt_asymmetric(emu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_encrypt_asymmetric(scheme, n, bits)
+
+
+@needs_ref
+@pytest.mark.parametrize("n,bits", [(1024, [40, 30, 30, 40]), (4096, [50, 40, 40, 50]), (8, [30, 30])])
+def test_ckks_encoder(emu, n, bits):
+    import decrypt_cases as DC
+    DC.case_ckks_encoder(n, bits)
