@@ -1013,6 +1013,23 @@ extern "C"
         }
         REF_CATCH
     }
+    // CKKSEncoder::encode(double value, ...) / encode(int64_t value, ...): one value in every slot
+    int ref_ckks_encode_value(void *ctx, double value, int is_integer, int64_t ivalue, uint64_t chain_index, double scale, void **out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 3;
+        CKKSEncoder enc(*c->context);
+        auto h = std::make_unique<RefPt>();
+        if (is_integer)
+            enc.encode(ivalue, l->parms_id(), h->pt);
+        else
+            enc.encode(value, l->parms_id(), scale, h->pt);
+        *out = h.release();
+        REF_CATCH
+    }
     // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)
     int ref_keys_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, uint64_t *bytes)
     {

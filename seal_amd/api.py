@@ -512,8 +512,14 @@ class CKKSEncoder:
 
     def encode(self, values, parms_id, scale, destination=None):
         destination = destination if destination is not None else Plaintext(self.context)
-        a = np.asarray(values)
         pid = (C.c_uint64 * 4)(*parms_id)
+        if isinstance(values, (int, np.integer)) and scale is None:
+            N.check(N.lib().CKKSEncoder_Encode5(self._h, C.c_int64(int(values)), pid, destination._h))
+            return destination
+        if isinstance(values, (float, int, np.floating, np.integer)):
+            N.check(N.lib().CKKSEncoder_Encode3(self._h, C.c_double(float(values)), pid, C.c_double(scale), destination._h, None))
+            return destination
+        a = np.asarray(values)
         if np.iscomplexobj(a):
             a = np.ascontiguousarray(a, dtype=np.complex128)
             N.check(N.lib().CKKSEncoder_Encode2(self._h, C.c_uint64(a.size), _p(a), pid, C.c_double(scale), destination._h, None))
@@ -768,6 +774,8 @@ class Evaluator:
         return self._u("Evaluator_ModSwitchToNext1", a, destination, pool=True)
 
     def mod_switch_to_inplace(self, a, parms_id):
+        if isinstance(a, Plaintext):  # the reference overloads the name for plaintexts (evaluator.h:520-560)
+            return self.mod_switch_plain_to_inplace(a, parms_id)
         pid = (C.c_uint64 * 4)(*parms_id)
         N.check(N.lib().Evaluator_ModSwitchTo1(self._h, a._h, pid, a._h, None))
         return a

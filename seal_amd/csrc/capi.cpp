@@ -910,6 +910,25 @@ extern "C"
         as<CKKSEncoder>(thisptr)->encode(complex_values, (size_t)value_count, true, parms_id, scale, *as<Plaintext>(destination));
         SHL_CATCH
     }
+    SHL_FUNC CKKSEncoder_Encode3(void *thisptr, double value, uint64_t *parms_id, double scale, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<CKKSEncoder>(thisptr)->encode_value(value, parms_id, scale, *as<Plaintext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC CKKSEncoder_Encode5(void *thisptr, int64_t value, uint64_t *parms_id, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        as<CKKSEncoder>(thisptr)->encode_integer(value, parms_id, *as<Plaintext>(destination));
+        SHL_CATCH
+    }
     SHL_FUNC CKKSEncoder_Decode1(void *thisptr, void *plain, uint64_t *value_count, double *values, void *pool)
     {
         (void)pool;

@@ -1,6 +1,7 @@
 // See ckks_encoder.h.  Reference: native/src/seal/ckks.h, ckks.cpp, util/croots.cpp, util/rns.cpp (RNSBase).
 #include "ckks_encoder.h"
 #include "hostmath.h"
+#include <algorithm>
 #include <cmath>
 #include <complex>
 #include <cstring>
@@ -230,6 +231,88 @@ namespace sealhip
         dest.adopt(slab, K * n, K * n);
         dest.set_level(lvl);
         dest.scale() = scale;
+    }
+
+    void CKKSEncoder::fill_constant(const Level &lvl, const std::vector<uint64_t> &residues, double scale, Plaintext &dest) const
+    {
+        if (&dest.context() != &context_)
+            throw std::invalid_argument("destination belongs to another context");
+        const size_t n = context_.n(), K = lvl.K;
+        std::vector<uint64_t> words(K * n);
+        for (size_t j = 0; j < K; j++)
+            std::fill_n(words.begin() + j * n, n, residues[j]);
+        uint64_t *slab = DevicePool::global().alloc_words(K * n);
+        hipError_t e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess)
+            e = hipMemcpy(slab, words.data(), K * n * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+        {
+            DevicePool::global().free_words(slab);
+            ck(e, "upload constant plaintext");
+        }
+        dest.adopt(slab, K * n, K * n);
+        dest.set_level(&lvl);
+        dest.scale() = scale;
+    }
+    void CKKSEncoder::encode_value(double value, const uint64_t *parms_id, double scale, Plaintext &dest) const
+    {
+        // ckks.cpp:72-205
+        const Level *lvl = parms_id ? context_.level_by_parms_id(parms_id) : nullptr;
+        if (!lvl)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (!std::isfinite(scale) || scale <= 0 || (static_cast<int>(std::log2(scale)) >= lvl->total_coeff_modulus_bit_count))
+            throw std::invalid_argument("scale out of bounds");
+        if (!std::isfinite(value))
+            throw std::invalid_argument("value must be finite");
+        value *= scale;
+        if (!std::isfinite(value))
+            throw std::invalid_argument("encoded value is too large");
+        const int coeff_bit_count = (std::fabs(value) < 1.0) ? 2 : (static_cast<int>(std::log2(std::fabs(value))) + 2);
+        if (coeff_bit_count >= lvl->total_coeff_modulus_bit_count)
+            throw std::invalid_argument("encoded value is too large");
+        if (coeff_bit_count > 128)
+            throw std::logic_error("coefficients above 128 bits: the multi-precision decomposition of ckks.cpp:165-196 is not built");
+        const double two_pow_64 = std::pow(2.0, 64);
+        double coeffd = std::round(value);
+        const bool is_negative = std::signbit(coeffd);
+        coeffd = std::fabs(coeffd);
+        std::vector<uint64_t> residues(lvl->K);
+        for (unsigned j = 0; j < lvl->K; j++)
+        {
+            const uint64_t q = context_.coeff_modulus()[j];
+            uint64_t r;
+            if (coeff_bit_count <= 64)
+                r = static_cast<uint64_t>(std::fabs(coeffd)) % q;
+            else
+            {
+                const unsigned __int128 v = ((unsigned __int128) static_cast<uint64_t>(coeffd / two_pow_64) << 64) |
+                                            static_cast<uint64_t>(std::fmod(coeffd, two_pow_64));
+                r = (uint64_t)(v % q);
+            }
+            residues[j] = is_negative ? (r ? q - r : 0) : r;
+        }
+        fill_constant(*lvl, residues, scale, dest);
+    }
+    void CKKSEncoder::encode_integer(int64_t value, const uint64_t *parms_id, Plaintext &dest) const
+    {
+        // ckks.cpp:207-250
+        const Level *lvl = parms_id ? context_.level_by_parms_id(parms_id) : nullptr;
+        if (!lvl)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        const uint64_t mag = value < 0 ? (uint64_t)0 - (uint64_t)value : (uint64_t)value;
+        const int coeff_bit_count = (mag ? 64 - __builtin_clzll(mag) : 0) + 2;
+        if (coeff_bit_count >= lvl->total_coeff_modulus_bit_count)
+            throw std::invalid_argument("encoded value is too large");
+        std::vector<uint64_t> residues(lvl->K);
+        for (unsigned j = 0; j < lvl->K; j++)
+        {
+            const uint64_t q = context_.coeff_modulus()[j];
+            uint64_t tmp = static_cast<uint64_t>(value);
+            if (value < 0)
+                tmp += q; // wraps modulo 2^64, as the reference's line does
+            residues[j] = tmp % q;
+        }
+        fill_constant(*lvl, residues, 1.0, dest);
     }
 
     void CKKSEncoder::decode(const Plaintext &plain, double *values, bool want_complex) const

@@ -19,10 +19,15 @@ namespace sealhip
         // CKKSEncoder::encode(values, parms_id, scale, destination) (ckks.h:458-680): values = count <= N/2 complex numbers as
         // (re, im) pairs, or real numbers when is_complex is false
         void encode(const double *values, size_t count, bool is_complex, const uint64_t *parms_id, double scale, Plaintext &destination) const;
+        // CKKSEncoder::encode(double value, ...) / encode(int64_t value, ...) (ckks.cpp:72-250): the value in every slot = a
+        // constant polynomial, whose NTT form is that constant in every position
+        void encode_value(double value, const uint64_t *parms_id, double scale, Plaintext &destination) const;
+        void encode_integer(int64_t value, const uint64_t *parms_id, Plaintext &destination) const;
         // CKKSEncoder::decode (ckks.h:683-789): N/2 complex numbers as (re, im) pairs, or their real parts
         void decode(const Plaintext &plain, double *values, bool want_complex) const;
 
     private:
+        void fill_constant(const Level &lvl, const std::vector<uint64_t> &residues, double scale, Plaintext &destination) const;
         struct LevelConst
         {
             uint64_t *dev = nullptr; // punct [K][K] | q_words [K] | half_words [K] | inv_punct [K] Shoup pairs

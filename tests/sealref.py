@@ -346,6 +346,14 @@ class RefContext:
         _ck(lib().ref_ckks_encode_complex(self.h, _p(v), C.c_uint64(v.size), C.c_uint64(chain_index), C.c_double(scale), C.byref(h)))
         return RefPlaintext(self, h)
 
+    def ckks_encode_value(self, value, chain_index, scale=None):
+        """encode(double value, parms_id, scale) or, with scale None, encode(int64 value, parms_id)"""
+        h = C.c_void_p()
+        integer = scale is None
+        _ck(lib().ref_ckks_encode_value(self.h, C.c_double(0.0 if integer else float(value)), C.c_int(1 if integer else 0),
+                                        C.c_int64(int(value) if integer else 0), C.c_uint64(chain_index), C.c_double(scale or 1.0), C.byref(h)))
+        return RefPlaintext(self, h)
+
     def ckks_decode(self, pt, complex_values=False):
         out = np.zeros(self.n // 2, dtype=np.complex128 if complex_values else np.float64)
         _ck(lib().ref_ckks_decode(self.h, pt.h, C.c_int(1 if complex_values else 0), _p(out)))

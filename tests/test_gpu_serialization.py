@@ -96,3 +96,14 @@ def test_encrypt_asymmetric(gpu, scheme, n, bits):
 def test_ckks_encoder(gpu, n, bits):
     import decrypt_cases as DC
     DC.case_ckks_encoder(n, bits)
+
+
+def test_example_ckks_basics(gpu):
+    """native/examples/5_ckks_basics.cpp with its own parameters (N = 8192, {60, 40, 40, 60}, scale 2^40)"""
+    import example_cases as EC
+    EC.example_ckks_basics()
+
+
+def test_example_batching_rotation(gpu):
+    import example_cases as EC
+    EC.example_batching_rotation()

@@ -174,3 +174,16 @@ def test_encrypt_asymmetric(emu, scheme, n, bits):
 def test_ckks_encoder(emu, n, bits):
     import decrypt_cases as DC
     DC.case_ckks_encoder(n, bits)
+
+
+# ---- the reference's example programs on the device API
+@needs_ref
+def test_example_ckks_basics(emu):
+    import example_cases as EC
+    EC.example_ckks_basics(4096, (60, 40, 40, 60))
+
+
+@needs_ref
+def test_example_batching_rotation(emu):
+    import example_cases as EC
+    EC.example_batching_rotation(4096, (36, 36, 37))
