@@ -152,6 +152,7 @@ SHL_FUNC SecretKey_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t s
 SHL_FUNC Decryptor_Create(void *context, void *secret_key, void **decryptor);
 SHL_FUNC Decryptor_Destroy(void *thisptr);
 SHL_FUNC Decryptor_Decrypt(void *thisptr, void *encrypted, void *destination);
+SHL_FUNC Decryptor_InvariantNoiseBudget(void *thisptr, void *encrypted, int *invariant_noise_budget); /* BFV / BGV, batch of one */
 SHL_FUNC Decryptor_DecryptBatchWords(void *thisptr, void *encrypted, uint64_t *word_count);
 SHL_FUNC Decryptor_DecryptBatch(void *thisptr, void *encrypted, uint64_t *device_out, uint64_t word_count);
 

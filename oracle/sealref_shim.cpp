@@ -1030,6 +1030,14 @@ extern "C"
         *out = h.release();
         REF_CATCH
     }
+    int ref_noise_budget(void *ctx, void *ct, int *bits)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        Decryptor d(*c->context, c->keygen->secret_key());
+        *bits = d.invariant_noise_budget(CT(ct));
+        REF_CATCH
+    }
     // KSwitchKeys::load / unsafe_load into a scratch object (error-class checks)
     int ref_keys_load(void *ctx, const uint8_t *in, uint64_t size, int unsafe, uint64_t *bytes)
     {

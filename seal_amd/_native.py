@@ -65,7 +65,7 @@ Ciphertext_CopyToHost Ciphertext_CopyFromDevice
 Ciphertext_SaveSize Ciphertext_Save Ciphertext_UnsafeLoad Ciphertext_Load Ciphertext_LoadItem Ciphertext_SaveItem
 KSwitchKeys_UnsafeLoad KSwitchKeys_Load
 SecretKey_Create SecretKey_Destroy SecretKey_Set SecretKey_UnsafeLoad SecretKey_Load Decryptor_Create Decryptor_Destroy
-Decryptor_Decrypt Decryptor_DecryptBatchWords Decryptor_DecryptBatch
+Decryptor_Decrypt Decryptor_InvariantNoiseBudget Decryptor_DecryptBatchWords Decryptor_DecryptBatch
 CKKSEncoder_Create CKKSEncoder_Destroy CKKSEncoder_SlotCount CKKSEncoder_Encode1 CKKSEncoder_Encode2 CKKSEncoder_Encode3 CKKSEncoder_Encode5 CKKSEncoder_Decode1 CKKSEncoder_Decode2
 BatchEncoder_Create BatchEncoder_Destroy BatchEncoder_GetSlotCount BatchEncoder_Encode1 BatchEncoder_Encode2 BatchEncoder_Decode1
 BatchEncoder_Decode2 BatchEncoder_EncodeDevice BatchEncoder_DecodeDevice

@@ -483,6 +483,11 @@ class Decryptor:
         N.check(N.lib().Decryptor_Decrypt(self._h, encrypted._h, destination._h))
         return destination
 
+    def invariant_noise_budget(self, encrypted):
+        v = C.c_int()
+        N.check(N.lib().Decryptor_InvariantNoiseBudget(self._h, encrypted._h, C.byref(v)))
+        return v.value
+
     def decrypt_batch(self, encrypted, out=None):
         """-> DeviceBuffer of [batch][K][N] (CKKS) or [batch][N] (BFV / BGV) words and its word count; `out` reuses a buffer"""
         w = C.c_uint64()

@@ -844,6 +844,16 @@ extern "C"
         as<Decryptor>(thisptr)->decrypt(*as<Ciphertext>(encrypted), *as<Plaintext>(destination));
         SHL_CATCH
     }
+    SHL_FUNC Decryptor_InvariantNoiseBudget(void *thisptr, void *encrypted, int *invariant_noise_budget)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(invariant_noise_budget, SHL_E_POINTER);
+        SHL_TRY
+        hip_ok(hipDeviceSynchronize(), "sync");
+        *invariant_noise_budget = as<Decryptor>(thisptr)->invariant_noise_budget(*as<Ciphertext>(encrypted));
+        SHL_CATCH
+    }
     SHL_FUNC Decryptor_DecryptBatchWords(void *thisptr, void *encrypted, uint64_t *word_count)
     {
         IfNullRet(thisptr, SHL_E_POINTER);

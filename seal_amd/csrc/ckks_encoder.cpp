@@ -105,16 +105,10 @@ namespace sealhip
             (void)hipFree(kv.second.dev);
     }
 
-    const CKKSEncoder::LevelConst &CKKSEncoder::level_const(const Level &lvl) const
+    uint64_t *build_crt_constants(const Context &context, const Level &lvl)
     {
-        std::lock_guard<std::mutex> lock(mu_);
-        auto it = consts_.find(lvl.chain_index);
-        if (it != consts_.end())
-            return it->second;
-        // RNSBase::initialize (rns.cpp:212-257): Q / q_j as K words, (Q / q_j)^-1 mod q_j; total_coeff_modulus and
-        // upper_half_threshold = (Q + 1) >> 1 (context.cpp:300-330)
         const unsigned K = lvl.K;
-        std::vector<uint64_t> q(context_.coeff_modulus().begin(), context_.coeff_modulus().begin() + K);
+        std::vector<uint64_t> q(context.coeff_modulus().begin(), context.coeff_modulus().begin() + K);
         std::vector<uint64_t> block((size_t)K * K + 2 * K + 2 * K, 0);
         for (unsigned j = 0; j < K; j++)
         {
@@ -136,9 +130,8 @@ namespace sealhip
         std::vector<uint64_t> Q = host::product(q);
         Q.resize(K, 0);
         // (Q + 1) >> 1
-        std::vector<uint64_t> half(K);
+        std::vector<uint64_t> q1(K), half(K);
         uint64_t carry = 1;
-        std::vector<uint64_t> q1(K);
         for (unsigned w = 0; w < K; w++)
         {
             q1[w] = Q[w] + carry;
@@ -151,9 +144,20 @@ namespace sealhip
             block[(size_t)K * K + w] = Q[w];
             block[(size_t)K * K + K + w] = half[w];
         }
+        uint64_t *dev = nullptr;
+        ck(hipMalloc(reinterpret_cast<void **>(&dev), block.size() * 8), "hipMalloc crt constants");
+        ck(hipMemcpy(dev, block.data(), block.size() * 8, hipMemcpyHostToDevice), "upload crt constants");
+        return dev;
+    }
+
+    const CKKSEncoder::LevelConst &CKKSEncoder::level_const(const Level &lvl) const
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        auto it = consts_.find(lvl.chain_index);
+        if (it != consts_.end())
+            return it->second;
         LevelConst lc;
-        ck(hipMalloc(reinterpret_cast<void **>(&lc.dev), block.size() * 8), "hipMalloc ckks constants");
-        ck(hipMemcpy(lc.dev, block.data(), block.size() * 8, hipMemcpyHostToDevice), "upload ckks constants");
+        lc.dev = build_crt_constants(context_, lvl);
         return consts_.emplace(lvl.chain_index, lc).first->second;
     }
 

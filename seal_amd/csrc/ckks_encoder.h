@@ -8,6 +8,11 @@
 
 namespace sealhip
 {
+    // Multi-precision CRT constants of a level, one device block of K*K + 4K words (RNSBase::initialize, rns.cpp:212-257;
+    // total_coeff_modulus / upper_half_threshold, context.cpp:300-330): punct [K][K] (Q / q_j as K words) | Q [K] | (Q + 1) / 2 [K] |
+    // (Q / q_j)^-1 mod q_j as K Shoup pairs.  The caller owns the block (hipFree).
+    uint64_t *build_crt_constants(const Context &context, const Level &lvl);
+
     class CKKSEncoder
     {
     public:

@@ -26,6 +26,11 @@ namespace sealhip
     hipError_t k_ckks_compose_scale(const ModDesc *mods, const uint64_t *residues, const uint64_t *punct, const ShoupOp *inv_punct,
                                     const uint64_t *q_words, const uint64_t *half_words, double inv_scale, double2 *out, unsigned n_log, unsigned K,
                                     unsigned batch, hipStream_t s);
+    // max over the coefficients of vector b of the bit length of the centred CRT value of (m * residue): out_bits[b] (zeroed
+    // beforehand) - the norm of Decryptor::invariant_noise_budget (decryptor.cpp:222-241; poly_infty_norm_coeffmod)
+    hipError_t k_crt_norm_bits(const ModDesc *mods, const uint64_t *residues, const uint64_t *punct, const ShoupOp *inv_punct,
+                               const uint64_t *q_words, const uint64_t *half_words, uint64_t m, unsigned *out_bits, unsigned n_log, unsigned K,
+                               unsigned batch, hipStream_t s);
     // slot <-> coefficient index map: scatter out[map[i]] = in[i] and out[map[i + slots]] = conj(in[i]) for i < count (rest 0
     // beforehand), gather out[i] = in[map[i]] for i < slots
     hipError_t k_ckks_place(const uint32_t *map, const double2 *in, double2 *out, unsigned n_log, unsigned count, hipStream_t s);

@@ -110,6 +110,63 @@ namespace sealhip
                 }
             }
         }
+        // x = sum_j [x_j m (Q/q_j)^-1 mod q_j] (Q/q_j) mod Q as K little-endian words (RNSBase::compose_array, rns.cpp:300-360);
+        // m = an optional scalar multiplied into every residue first (1 = none)
+        __device__ __forceinline__ void crt_compose(
+            uint64_t (&acc)[kMaxComps], const uint64_t *in, uint64_t m, const ModDesc *mods, const uint64_t *punct, const ShoupOp *inv_punct,
+            const uint64_t *q_words, unsigned n_log, unsigned K)
+        {
+            for (unsigned w = 0; w < K; w++)
+                acc[w] = 0;
+            for (unsigned j = 0; j < K; j++)
+            {
+                const ShoupOp ip = inv_punct[j];
+                uint64_t xj = in[(size_t)j << n_log];
+                if (m != 1)
+                    xj = mul_mod(xj, barrett64(m, mods[j]), mods[j]);
+                const uint64_t y = mul_shoup(xj, ip.w, ip.wq, mods[j].q);
+
+                // acc += y * punct_j  (the product is below Q: K words), then one conditional subtraction of Q
+                uint64_t carry = 0;
+                for (unsigned w = 0; w < K; w++)
+                {
+                    uint64_t lo, hi;
+                    mul_wide(y, punct[(size_t)j * K + w], lo, hi);
+                    const uint64_t s1 = acc[w] + lo;
+                    const uint64_t c1 = s1 < lo;
+                    const uint64_t s2 = s1 + carry;
+                    const uint64_t c2 = s2 < carry;
+                    acc[w] = s2;
+                    carry = hi + c1 + c2; // hi <= 2^64 - 2, so this does not wrap
+                }
+                // the sum of two values below Q is below 2Q < 2^(64 K + 1): `carry` is its top bit
+                bool ge = carry != 0;
+                if (!ge)
+                {
+                    ge = true;
+                    for (int w = (int)K - 1; w >= 0; w--)
+                        if (acc[w] != q_words[w])
+                        {
+                            ge = acc[w] > q_words[w];
+                            break;
+                        }
+                }
+                if (ge)
+                {
+                    uint64_t borrow = 0;
+                    for (unsigned w = 0; w < K; w++)
+                    {
+                        const uint64_t d = acc[w] - q_words[w];
+                        const uint64_t b1 = acc[w] < q_words[w];
+                        const uint64_t d2 = d - borrow;
+                        const uint64_t b2 = d < borrow;
+                        acc[w] = d2;
+                        borrow = b1 | b2;
+                    }
+                }
+            }
+        }
+
         __global__ void __launch_bounds__(kBlock) ckks_compose_scale_kernel(
             const ModDesc *mods, const uint64_t *residues, const uint64_t *punct, const ShoupOp *inv_punct, const uint64_t *q_words,
             const uint64_t *half_words, double inv_scale, double2 *out, unsigned n_log, unsigned K, size_t count)
@@ -120,53 +177,8 @@ namespace sealhip
             {
                 const size_t vec = t >> n_log, i = t & nmask;
                 const uint64_t *in = residues + ((vec * K) << n_log) + i;
-                // x = sum_j [x_j (Q/q_j)^-1 mod q_j] (Q/q_j) mod Q, as K little-endian words
                 uint64_t acc[kMaxComps];
-                for (unsigned w = 0; w < K; w++)
-                    acc[w] = 0;
-                for (unsigned j = 0; j < K; j++)
-                {
-                    const ShoupOp ip = inv_punct[j];
-                    const uint64_t y = mul_shoup(in[(size_t)j << n_log], ip.w, ip.wq, mods[j].q);
-                    // acc += y * punct_j  (the product is below Q: K words), then one conditional subtraction of Q
-                    uint64_t carry = 0;
-                    for (unsigned w = 0; w < K; w++)
-                    {
-                        uint64_t lo, hi;
-                        mul_wide(y, punct[(size_t)j * K + w], lo, hi);
-                        const uint64_t s1 = acc[w] + lo;
-                        const uint64_t c1 = s1 < lo;
-                        const uint64_t s2 = s1 + carry;
-                        const uint64_t c2 = s2 < carry;
-                        acc[w] = s2;
-                        carry = hi + c1 + c2; // hi <= 2^64 - 2, so this does not wrap
-                    }
-                    // the sum of two values below Q is below 2Q < 2^(64 K + 1): `carry` is its top bit
-                    bool ge = carry != 0;
-                    if (!ge)
-                    {
-                        ge = true;
-                        for (int w = (int)K - 1; w >= 0; w--)
-                            if (acc[w] != q_words[w])
-                            {
-                                ge = acc[w] > q_words[w];
-                                break;
-                            }
-                    }
-                    if (ge)
-                    {
-                        uint64_t borrow = 0;
-                        for (unsigned w = 0; w < K; w++)
-                        {
-                            const uint64_t d = acc[w] - q_words[w];
-                            const uint64_t b1 = acc[w] < q_words[w];
-                            const uint64_t d2 = d - borrow;
-                            const uint64_t b2 = d < borrow;
-                            acc[w] = d2;
-                            borrow = b1 | b2;
-                        }
-                    }
-                }
+                crt_compose(acc, in, 1, mods, punct, inv_punct, q_words, n_log, K);
                 // ckks.h:746-775: the centred value times inv_scale, word by word
                 bool upper = true; // acc >= upper_half_threshold
                 for (int w = (int)K - 1; w >= 0; w--)
@@ -199,6 +211,47 @@ namespace sealhip
                     }
                 }
                 out[t] = double2{ res, 0.0 };
+            }
+        }
+        // significant bits of the centred CRT value of every coefficient, maximum per vector (poly_infty_norm_coeffmod)
+        __global__ void __launch_bounds__(kBlock) crt_norm_bits_kernel(
+            const ModDesc *mods, const uint64_t *residues, const uint64_t *punct, const ShoupOp *inv_punct, const uint64_t *q_words,
+            const uint64_t *half_words, uint64_t m, unsigned *out_bits, unsigned n_log, unsigned K, size_t count)
+        {
+            const size_t nmask = (size_t(1) << n_log) - 1;
+            for (size_t t = blockIdx.x * (size_t)kBlock + threadIdx.x; t < count; t += (size_t)gridDim.x * kBlock)
+            {
+                const size_t vec = t >> n_log, i = t & nmask;
+                uint64_t acc[kMaxComps];
+                crt_compose(acc, residues + ((vec * K) << n_log) + i, m, mods, punct, inv_punct, q_words, n_log, K);
+                bool upper = true; // acc >= (Q + 1) / 2: the representative is Q - acc
+                for (int w = (int)K - 1; w >= 0; w--)
+                    if (acc[w] != half_words[w])
+                    {
+                        upper = acc[w] > half_words[w];
+                        break;
+                    }
+                if (upper)
+                {
+                    uint64_t borrow = 0;
+                    for (unsigned w = 0; w < K; w++)
+                    {
+                        const uint64_t d = q_words[w] - acc[w];
+                        const uint64_t b1 = q_words[w] < acc[w];
+                        const uint64_t d2 = d - borrow;
+                        const uint64_t b2 = d < borrow;
+                        acc[w] = d2;
+                        borrow = b1 | b2;
+                    }
+                }
+                unsigned bits = 0;
+                for (int w = (int)K - 1; w >= 0; w--)
+                    if (acc[w])
+                    {
+                        bits = (unsigned)w * 64 + (64 - __builtin_clzll(acc[w]));
+                        break;
+                    }
+                atomicMax(out_bits + vec, bits);
             }
         }
         __global__ void __launch_bounds__(kBlock) ckks_place_kernel(const uint32_t *map, const double2 *in, double2 *out, unsigned n_log, unsigned count)
@@ -252,6 +305,15 @@ namespace sealhip
         const size_t count = (size_t)batch << n_log;
         hipLaunchKernelGGL(ckks_compose_scale_kernel, dim3(grid_for(count)), dim3(kBlock), 0, s, mods, residues, punct, inv_punct, q_words,
                            half_words, inv_scale, out, n_log, K, count);
+        return hipGetLastError();
+    }
+    hipError_t k_crt_norm_bits(const ModDesc *mods, const uint64_t *residues, const uint64_t *punct, const ShoupOp *inv_punct,
+                               const uint64_t *q_words, const uint64_t *half_words, uint64_t m, unsigned *out_bits, unsigned n_log, unsigned K,
+                               unsigned batch, hipStream_t s)
+    {
+        const size_t count = (size_t)batch << n_log;
+        hipLaunchKernelGGL(crt_norm_bits_kernel, dim3(grid_for(count)), dim3(kBlock), 0, s, mods, residues, punct, inv_punct, q_words, half_words,
+                           m, out_bits, n_log, K, count);
         return hipGetLastError();
     }
     hipError_t k_ckks_place(const uint32_t *map, const double2 *in, double2 *out, unsigned n_log, unsigned count, hipStream_t s)

@@ -1,6 +1,7 @@
 // See decryptor.h.  Reference: native/src/seal/decryptor.cpp.
 #include "decryptor.h"
 #include "hostmath.h"
+#include <algorithm>
 #include <cstring>
 
 namespace sealhip
@@ -73,6 +74,8 @@ namespace sealhip
     }
     Decryptor::~Decryptor()
     {
+        for (auto &kv : crt_)
+            (void)hipFree(kv.second);
         for (uint64_t *p : powers_)
         {
             // the reference wipes key material before releasing it (decryptor.cpp: seal_memzero)
@@ -144,6 +147,44 @@ namespace sealhip
             ck(k_add_inplace(context_.dev_mods(), phase, e.plane(0), plane_words, n_log, (unsigned)K, nullptr), "decrypt add c0");
             ck(hipStreamSynchronize(nullptr), "decrypt sync"); // tmp goes back to the pool
         }
+    }
+
+    std::vector<int> Decryptor::invariant_noise_budgets(const Ciphertext &e)
+    {
+        check(e);
+        const Scheme s = context_.scheme();
+        if (s != Scheme::bfv && s != Scheme::bgv)
+            throw std::logic_error("unsupported scheme");
+        const Level &lvl = *e.level();
+        const unsigned n_log = (unsigned)context_.log_n(), K = lvl.K, B = (unsigned)e.batch();
+        uint64_t *crt;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            auto it = crt_.find(lvl.chain_index);
+            if (it == crt_.end())
+                it = crt_.emplace(lvl.chain_index, build_crt_constants(context_, lvl)).first;
+            crt = it->second;
+        }
+        Scratch noise(e.plane_words()), bits((B + 1) / 2 + 1);
+        dot_product_ct_sk_array(e, noise.p, true); // coefficient form (BGV: INTT of the NTT-form phase)
+        unsigned *d_bits = reinterpret_cast<unsigned *>(bits.p);
+        ck(hipMemsetAsync(d_bits, 0, B * sizeof(unsigned), nullptr), "zero norms");
+        // BFV multiplies the phase by t first (the invariant noise is t * phase / Q); BGV takes the phase as it is
+        ck(k_crt_norm_bits(context_.dev_mods(), noise.p, crt, reinterpret_cast<const ShoupOp *>(crt + (size_t)K * K + 2 * K), crt + (size_t)K * K,
+                           crt + (size_t)K * K + K, s == Scheme::bfv ? context_.plain_modulus() : 1, d_bits, n_log, K, B, nullptr),
+           "noise norm");
+        std::vector<unsigned> host(B);
+        ck(hipMemcpy(host.data(), d_bits, B * sizeof(unsigned), hipMemcpyDeviceToHost), "download norms");
+        std::vector<int> out(B);
+        for (unsigned b = 0; b < B; b++)
+            out[b] = std::max(0, lvl.total_coeff_modulus_bit_count - (int)host[b] - 1);
+        return out;
+    }
+    int Decryptor::invariant_noise_budget(const Ciphertext &e)
+    {
+        if (e.batch() != 1)
+            throw std::invalid_argument("Decryptor::invariant_noise_budget takes a batch of one: use invariant_noise_budgets");
+        return invariant_noise_budgets(e)[0];
     }
 
     size_t Decryptor::decrypt_batch_words(const Ciphertext &e) const

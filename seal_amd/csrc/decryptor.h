@@ -2,6 +2,7 @@
 // path).  Same method names, argument checks and exception classes as the reference (native/src/seal/decryptor.h:56-186,
 // decryptor.cpp); the arithmetic reuses the NTT engine and three element-wise kernels (decrypt_kernels.h).
 #pragma once
+#include "ckks_encoder.h"
 #include "decrypt_kernels.h"
 #include "evaluator.h"
 #include "serial.h"
@@ -60,6 +61,9 @@ namespace sealhip
         void decrypt(const Ciphertext &encrypted, Plaintext &destination);
         // the same for every item of a device-resident batch, untrimmed, into caller-owned device memory:
         // [batch][K][N] words (CKKS) or [batch][N] words (BFV / BGV).  Stream-ordered on the null stream.
+        // Decryptor::invariant_noise_budget (decryptor.cpp:188-241), BFV / BGV: bits of noise room left, per batch item
+        int invariant_noise_budget(const Ciphertext &encrypted);
+        std::vector<int> invariant_noise_budgets(const Ciphertext &encrypted);
         size_t decrypt_batch_words(const Ciphertext &encrypted) const;
         void decrypt_batch(const Ciphertext &encrypted, uint64_t *device_out);
 
@@ -70,6 +74,7 @@ namespace sealhip
         const Context &context_;
         std::mutex mu_;
         std::vector<uint64_t *> powers_; // s^1, s^2, ... at the key level, NTT form
+        std::map<size_t, uint64_t *> crt_;  // per level: ckks_encoder.h build_crt_constants
     };
     // seal::BatchEncoder (native/src/seal/batchencoder.h, batchencoder.cpp): N integers modulo t <-> one plaintext polynomial, through
     // the negacyclic NTT modulo t (the plain modulus has its own tables in the context's prime pool) and the 2 x N/2 matrix index

@@ -49,14 +49,27 @@ def case_decrypt(scheme, n, bits, batch=3):
     a, b = fresh(), fresh()
     for dcr in (dec, dec2):
         _same_plain(dcr.decrypt(_to_device(d, a)), ref.decrypt(a), "fresh")
+
+    def budget(c, what):
+        if scheme == "ckks":
+            try:
+                dec.invariant_noise_budget(_to_device(d, c))
+                raise AssertionError("expected LogicError: unsupported scheme")
+            except S.LogicError:
+                return
+        assert dec.invariant_noise_budget(_to_device(d, c)) == ref.noise_budget(c), ("invariant_noise_budget", what)
+    budget(a, "fresh")
     # product (size 3: needs s^2), relinearized, at the next level, squared again (size 3 at a lower level)
     prod = ref.multiply_inplace(a.copy(), b)
     _same_plain(dec.decrypt(_to_device(d, prod)), ref.decrypt(prod), "size 3")
+    budget(prod, "size 3")
     ref.relinearize_inplace(prod)
     _same_plain(dec.decrypt(_to_device(d, prod)), ref.decrypt(prod), "relinearized")
+    budget(prod, "relinearized")
     if len(primes) > 2:
         nxt = ref.rescale_to_next_inplace(prod.copy()) if scheme == "ckks" else ref.mod_switch_to_next_inplace(prod.copy())
         _same_plain(dec.decrypt(_to_device(d, nxt)), ref.decrypt(nxt), "next level")
+        budget(nxt, "next level")
         if scheme == "bgv":
             assert nxt.info()["correction_factor"] != 1  # exercises the correction-factor fix of bgv_decrypt
     # a product of products without relinearization: size 5 (s^4)
@@ -64,6 +77,7 @@ def case_decrypt(scheme, n, bits, batch=3):
         big = ref.multiply_inplace(ref.multiply_inplace(a.copy(), b), ref.multiply_inplace(a.copy(), a))
         assert big.info()["size"] == 5
         _same_plain(dec.decrypt(_to_device(d, big)), ref.decrypt(big), "size 5")
+        budget(big, "size 5 (exhausted or nearly)")
     # the device's own evaluation decrypts to what the reference's evaluation decrypts to
     ca, cb = _to_device(d, a), _to_device(d, b)
     d.ev.multiply_inplace(ca, cb)

@@ -45,6 +45,13 @@ static inline unsigned long long atomicMax(unsigned long long *p, unsigned long 
         *p = v;
     return old;
 }
+static inline unsigned atomicMax(unsigned *p, unsigned v)
+{
+    unsigned old = *p;
+    if (v > old)
+        *p = v;
+    return old;
+}
 static inline long long __double_as_longlong(double d)
 {
     long long r;

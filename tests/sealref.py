@@ -359,6 +359,11 @@ class RefContext:
         _ck(lib().ref_ckks_decode(self.h, pt.h, C.c_int(1 if complex_values else 0), _p(out)))
         return out
 
+    def noise_budget(self, ct):
+        v = C.c_int()
+        _ck(lib().ref_noise_budget(self.h, ct.h, C.byref(v)))
+        return v.value
+
     def keys_load(self, data, unsafe=False):
         buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(bytes(data) or b"\x00")
         n = C.c_uint64()
