@@ -59,6 +59,17 @@ namespace sealhip
         constexpr int kRowWords = 16 * 18;
         constexpr size_t kLds2Words = 16 * kRowWords;
 
+        // ks2 geometry of the double-precision targets: 256 threads x 16 coefficients (default) or lane order / 512 threads x 8
+        // coefficients (SEALHIP_KS2_V2=1).  Measured on MI355X at C5, batch 256 (profiles/r01_ks2_geometries.txt): the second
+        // geometry runs at four waves per SIMD instead of two and is 15 % SLOWER (11.2 vs 9.7 ms per step; 6.90 k vs 7.16 k ct/s):
+        // its second wave-local exchange and the per-stage LDS twiddle reads cost more than the occupancy returns.  Kept for
+        // further work; the switch decides the layout keys are uploaded in, hence process-wide and fixed.
+        inline bool ks2_lane_order()
+        {
+            static const bool v2 = std::getenv("SEALHIP_KS2_V2") != nullptr;
+            return v2;
+        }
+
         template <bool FP>
         __device__ __forceinline__ const typename Field<FP>::tw_t *tw_table(const NttTables &t, bool inverse, unsigned prime)
         {
@@ -201,7 +212,9 @@ namespace sealhip
         // ---------------------------------------------------------------------------------------
         // BS = words between consecutive 256-word blocks of the tile-order intermediate (256 in HBM; 272 when the
         // intermediate lives in LDS, so that the 16-lane runs of one wave instruction fall on different banks)
-        template <bool FP, int D1, int BS = 256>
+        // ORDER 1 ("lane order", for ks2_v2): coefficient (row h = 16 hg + u, column c) at hg*4096 + (c >> 5)*512 + u*32 + (c & 31),
+        // so that the 512 threads (u, l = c & 31) of the 8-coefficients-per-thread pass 2 read eight fully coalesced 4 KiB rows
+        template <bool FP, int D1, int BS = 256, int ORDER = 0>
         __device__ __forceinline__ void p1_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const TwRegs<FP> &tw, uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
@@ -244,10 +257,20 @@ namespace sealhip
             }
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
             const unsigned col = cg * G::C + c;
-            uint64_t *o = mid_tr + (size_t)(hi * 16 + (col >> 4)) * BS + (col & 15);
+            if constexpr (ORDER == 1)
+            {
+                uint64_t *o = mid_tr + ((size_t)hi << 12) + (size_t)(col >> 5) * 512 + (col & 31);
 #pragma unroll
-            for (int rb = 0; rb < 16; rb++)
-                o[rb * 16] = F::raw(x[rb]);
+                for (int rb = 0; rb < 16; rb++)
+                    o[rb * 32] = F::raw(x[rb]);
+            }
+            else
+            {
+                uint64_t *o = mid_tr + (size_t)(hi * 16 + (col >> 4)) * BS + (col & 15);
+#pragma unroll
+                for (int rb = 0; rb < 16; rb++)
+                    o[rb * 16] = F::raw(x[rb]);
+            }
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1150,7 +1173,7 @@ namespace sealhip
             NttTables tb;
         };
 
-        template <bool FP, int D1>
+        template <bool FP, int D1, int ORDER>
         __device__ __forceinline__ void ks1_body(const Ks1Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned b, unsigned cg, unsigned j0, unsigned j1)
         {
             typedef Field<FP> F;
@@ -1223,14 +1246,15 @@ namespace sealhip
                 if (Jn < j1)
                     fetch(Jn);
                 uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
-                p1_tile<FP, D1>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1, 256, ORDER>(x, m, tab, tw, lds, mid_tr, cg, tid);
                 J = Jn;
             }
         }
 
         // One launch per arithmetic back end: the double-precision body needs ~127 VGPRs (4 waves per
         // SIMD), the integer body ~214 (2 waves); a merged kernel would run both at the lower occupancy.
-        template <bool FP, int D1>
+        // ORDER: layout of the intermediate (p1_tile): 0 tile order (ks2_kernel), 1 lane order (ks2v2_kernel)
+        template <bool FP, int D1, int ORDER = 0>
         __global__ void __launch_bounds__(kThreads) ks1_kernel(Ks1Args a)
         {
             typedef Geo<D1> G;
@@ -1248,7 +1272,7 @@ namespace sealhip
             const unsigned jlen = (a.j1 - a.j0 + a.parts - 1) / a.parts;
             const unsigned j0 = a.j0 + dg * jlen, j1 = j0 + jlen < a.j1 ? j0 + jlen : a.j1;
             const unsigned I = SHL_UNIFORM(a.targets[2 * it]), prime = SHL_UNIFORM(a.targets[2 * it + 1]);
-            ks1_body<FP, D1>(a, lds, I, prime, b, cg, j0, j1);
+            ks1_body<FP, D1, ORDER>(a, lds, I, prime, b, cg, j0, j1);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1471,9 +1495,213 @@ namespace sealhip
                 ks2_body<false, D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
         }
 
+        // ---------------------------------------------------------------------------------------
+        // ks2, second geometry (double-precision targets): the same tile of 16 rows x 256 columns, but 512 threads with EIGHT
+        // coefficients each, so that x, the two running sums, the prefetched digit and the key words of a thread are 96 registers
+        // instead of 192 and a SIMD holds four waves instead of two.  Eight stages = three register phases (3 + 3 + 2 stages) with
+        // two wave-local exchanges (the 32 lanes that own a row sit in one wavefront: no s_barrier):
+        //   phase A: thread (u, l) holds columns c = l + 32 k      (register bits = column bits 5,6,7)   stages D1+0..2
+        //   phase B: thread (u, l) holds c = (l & 3) + 4 j + 32 (l >> 2)   (bits 2,3,4)                 stages D1+3..5
+        //   phase C: thread (u, l) holds c = 8 l + m               (bits 0,1,2)                          stages D1+6..7
+        // and ends with 8 contiguous coefficients per thread, which is also the order of the key words ("lane register order":
+        // position hg*4096 + m*512 + tid <-> natural hg*4096 + tid*8 + m).  The intermediate comes in p1_tile's ORDER 1.
+        // LDS: per wave two rows of 256 words (padded) for the exchanges, per workgroup the tile's 16 x 255 twiddles.
+        // ---------------------------------------------------------------------------------------
+        constexpr int kV2Threads = 512;
+        constexpr int kV2RowWords = 256 + 32;                      // 4 pad words per 32 columns
+        constexpr size_t kV2XchWords = (size_t)16 * kV2RowWords;   // 16 rows
+        constexpr int kV2TwPerRow = 7 + 56 + 192;                  // stages 0-2 | 3-5 | 6-7
+        constexpr size_t kV2LdsBytes = (kV2XchWords + (size_t)16 * kV2TwPerRow) * 8;
+        __device__ __forceinline__ unsigned v2_pad(unsigned c)
+        {
+            return c + ((c >> 5) << 2);
+        }
+        // one radix-2 stage over the 8 registers of a thread, pairing register bit BIT; tw(g) = twiddle of group g = e >> (BIT+1)
+        template <int BIT, class TwFn>
+        __device__ __forceinline__ void stage8_fwd(double (&x)[8], const FpDesc &m, TwFn tw)
+        {
+#pragma unroll
+            for (int g = 0; g < (4 >> BIT); g++)
+            {
+                const double w = tw(g);
+#pragma unroll
+                for (int k = 0; k < (1 << BIT); k++)
+                {
+                    const int e0 = (g << (BIT + 1)) | k;
+                    Field<true>::bfly_fwd(x[e0], x[e0 | (1 << BIT)], w, m);
+                }
+            }
+        }
+
+        template <int D1>
+        __device__ __forceinline__ void ks2v2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg,
+                                                   unsigned j0, unsigned j1, uint64_t *acc_part)
+        {
+            typedef Field<true> F;
+            typedef Geo<D1> G;
+            const unsigned tid = threadIdx.x, u = tid >> 5, l = tid & 31;
+            const unsigned h = hg * 16 + u;
+            const F::Mod m = F::make_mod(ld_uniform_mod(&a.tb.mods[prime]), ld_uniform_fpd(&a.tb.fpd[prime]));
+            const double *tab = tw_table<true>(a.tb, false, prime);
+            // this row's exchange buffer (the two rows of a wave are touched by that wave only) and twiddles
+            uint64_t *row = lds + (size_t)u * kV2RowWords;
+            double *twl = reinterpret_cast<double *>(lds + kV2XchWords);
+            // stage the tile's twiddles: row r, stage t (0..7), group g < 2^t at twl[r*255 + (2^t - 1) + g]
+            for (unsigned i = tid; i < 16 * kV2TwPerRow; i += kV2Threads)
+            {
+                const unsigned r = i / kV2TwPerRow, e = i % kV2TwPerRow;
+                const unsigned t = 31 - __builtin_clz(e + 1), g = e + 1 - (1u << t);
+                twl[i] = tab[(1u << (D1 + t)) + (((hg * 16 + r)) << t) + g];
+            }
+            __syncthreads();
+            const double *twr = twl + (size_t)u * kV2TwPerRow;
+
+            double acc0[8], acc1[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                acc0[e] = acc1[e] = 0.0;
+            const double *key = reinterpret_cast<const double *>(a.key);
+            const size_t N = (size_t)1 << G::n;
+            const uint64_t *mid0 = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K) << G::n) + ((size_t)hg << 12) + tid;
+            const uint64_t *diag = a.target && I < a.K ? a.target + (((size_t)b * a.K + I) << G::n) + ((size_t)hg << 12) + (size_t)tid * 8 : nullptr;
+            uint64_t nxt[8];
+            auto fetch = [&](unsigned J) {
+                if (diag && J == I)
+                {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        nxt[e] = diag[e];
+                }
+                else
+                {
+                    const uint64_t *mp = mid0 + ((size_t)J << G::n);
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        nxt[e] = mp[e * 512];
+                }
+            };
+            if (j0 < j1)
+                fetch(j0);
+            for (unsigned J = j0; J < j1; J++)
+            {
+                double x[8];
+                const bool is_diag = diag && J == I;
+                if (is_diag)
+                {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        x[e] = F::from_canon(nxt[e], m);
+                }
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        x[e] = F::unraw(nxt[e]);
+                }
+                const double *k0 = key + (((size_t)(J - a.key_digit0) * 2 + 0) * a.L + kc) * N + ((size_t)hg << 12) + tid;
+                const double *k1 = k0 + (size_t)a.L * N;
+                double kr0[8], kr1[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                {
+                    kr0[e] = k0[e * 512];
+                    kr1[e] = k1[e * 512];
+                }
+                if (J + 1 < j1)
+                    fetch(J + 1);
+                if (!is_diag)
+                {
+                    // phase A: stages 0..2, register k <-> column l + 32 k
+                    stage8_fwd<2>(x, m, [&](int) { return twr[0]; });
+                    stage8_fwd<1>(x, m, [&](int g) { return twr[1 + g]; });
+                    stage8_fwd<0>(x, m, [&](int g) { return twr[3 + g]; });
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        F::fix(x[e], m);
+                    // exchange 1: (l + 32 k) -> ((l & 3) + 4 j + 32 (l >> 2))
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        row[v2_pad(l + 32 * k)] = F::raw(x[k]);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        x[j] = F::unraw(row[v2_pad((l & 3) + 4 * j + 32 * (l >> 2))]);
+                    __builtin_amdgcn_wave_barrier();
+                    // phase B: stages 3..5; group of stage t = column >> (8 - t)
+                    const unsigned G3 = l >> 2;
+                    stage8_fwd<2>(x, m, [&](int) { return twr[7 + G3]; });
+                    stage8_fwd<1>(x, m, [&](int g) { return twr[15 + 2 * G3 + g]; });
+                    stage8_fwd<0>(x, m, [&](int g) { return twr[31 + 4 * G3 + g]; });
+                    // exchange 2: -> (8 l + mm)
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        row[v2_pad((l & 3) + 4 * j + 32 * (l >> 2))] = F::raw(x[j]);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int mm = 0; mm < 8; mm++)
+                        x[mm] = F::unraw(row[v2_pad(8 * l + mm)]);
+                    __builtin_amdgcn_wave_barrier();
+                    // phase C: stages 6..7 on register bits 1, 0
+                    stage8_fwd<1>(x, m, [&](int g) { return twr[63 + 2 * l + g]; });
+                    stage8_fwd<0>(x, m, [&](int g) { return twr[127 + 4 * l + g]; });
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        F::fix(x[e], m);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                {
+                    F::mac(acc0[e], x[e], kr0[e], m);
+                    F::mac(acc1[e], x[e], kr1[e], m);
+                }
+                if (((J - j0) & 7) == 7)
+                {
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                    {
+                        F::acc_fix(acc0[e], m);
+                        F::acc_fix(acc1[e], m);
+                    }
+                }
+            }
+            // thread (u, l) holds columns 8 l .. 8 l + 7 of row h: 64 contiguous bytes
+            uint64_t *out = acc_part + ((((size_t)b * 2 + 0) * (a.K + 1) + I) << G::n) + ((size_t)h << 8) + 8 * l;
+            ulonglong2 *o0 = reinterpret_cast<ulonglong2 *>(out), *o1 = reinterpret_cast<ulonglong2 *>(out + ((size_t)(a.K + 1) << G::n));
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+            {
+                o0[e] = ulonglong2{ F::acc_to_canon(acc0[2 * e], m), F::acc_to_canon(acc0[2 * e + 1], m) };
+                o1[e] = ulonglong2{ F::acc_to_canon(acc1[2 * e], m), F::acc_to_canon(acc1[2 * e + 1], m) };
+            }
+        }
+
+        template <int D1>
+        __global__ void __launch_bounds__(kV2Threads, 4) ks2v2_kernel(Ks2Args a)
+        {
+            typedef Geo<D1> G;
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned ntile = a.ntargets * G::TILES;
+            const unsigned bid = blockIdx.x;
+            const unsigned xcd = bid & 7, rest = bid >> 3;
+            const unsigned vbatch = a.batch * a.parts;
+            const unsigned vb = rest % vbatch, tile_hi = rest / vbatch;
+            const unsigned b = vb % a.batch, dg = vb / a.batch;
+            const unsigned jlen = (a.j1 - a.j0 + a.parts - 1) / a.parts;
+            const unsigned j0 = a.j0 + dg * jlen, j1 = j0 + jlen < a.j1 ? j0 + jlen : a.j1;
+            uint64_t *acc_part = a.acc + (((size_t)dg * a.batch * 2 * (a.K + 1)) << G::n);
+            const unsigned tile = tile_hi * 8 + xcd;
+            if (tile >= ntile)
+                return;
+            const unsigned it = tile / G::TILES, hg = tile % G::TILES;
+            const unsigned I = SHL_UNIFORM(a.targets[3 * it]), prime = SHL_UNIFORM(a.targets[3 * it + 1]), kc = SHL_UNIFORM(a.targets[3 * it + 2]);
+            ks2v2_body<D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
+        }
+
         // natural order (u64) -> register order, optionally converted to double
+        // lane_order != 0: double-precision components go to the order of ks2v2 (position hg*4096 + m*512 + tid <- natural
+        // hg*4096 + tid*8 + m); integer components always keep the order of ks2_kernel
         __global__ void __launch_bounds__(kThreads) key_layout_kernel(
-            const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys)
+            const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys, int lane_order)
         {
             const size_t N = (size_t)1 << n_log;
             const size_t total = polys * L * N;
@@ -1484,7 +1712,12 @@ namespace sealhip
                 // destination position p = hg*4096 + e*256 + tid  <-  natural hg*4096 + (tid>>4)*256 + (tid&15)*16 + e
                 const size_t hg = p >> 12;
                 const unsigned e = (unsigned)(p >> 8) & 15, tid = (unsigned)p & 255;
-                const size_t nat = (hg << 12) + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 4) + e;
+                size_t nat = (hg << 12) + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 4) + e;
+                if (lane_order && fpd[comp].qi)
+                {
+                    const unsigned pp = (unsigned)p & 4095, mm = pp >> 9, t9 = pp & 511;
+                    nat = (hg << 12) + (size_t)t9 * 8 + mm;
+                }
                 const uint64_t v = in[(slab << n_log) + nat];
                 out[i] = fpd[comp].qi ? fp_to_bits(fp_from_u52(v)) : v;
             }
@@ -1741,6 +1974,8 @@ namespace sealhip
                 {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<D1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2_fp) != hipSuccess)
                         return hipErrorInvalidValue;
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2v2_kernel<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kV2LdsBytes) != hipSuccess)
+                        return hipErrorInvalidValue;
                     raised = true;
                 }
             }
@@ -1753,7 +1988,9 @@ namespace sealhip
                 c1.targets = a1.targets + 2 * t0;
                 c1.ntargets = nt;
                 const dim3 g1(((groups + 7) / 8) * nt * 8);
-                if (fp)
+                if (fp && ks2_lane_order())
+                    hipLaunchKernelGGL((ks1_kernel<true, D1, 1>), g1, dim3(kThreads), l1, st, c1);
+                else if (fp)
                     hipLaunchKernelGGL((ks1_kernel<true, D1>), g1, dim3(kThreads), l1, st, c1);
                 else
                     hipLaunchKernelGGL((ks1_kernel<false, D1>), g1, dim3(kThreads), l1, st, c1);
@@ -1764,7 +2001,9 @@ namespace sealhip
                 c2.targets = a2.targets + 3 * t0;
                 c2.ntargets = nt;
                 const unsigned ntile = nt * G::TILES;
-                if (fp)
+                if (fp && ks2_lane_order())
+                    hipLaunchKernelGGL((ks2v2_kernel<D1>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kV2Threads), kV2LdsBytes, st, c2);
+                else if (fp)
                     hipLaunchKernelGGL((ks2_kernel<D1, 1>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), l2_fp, st, c2);
                 else
                     hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), kLds2Words * 8 + 240 * sizeof(ShoupOp), st, c2);
@@ -1940,7 +2179,8 @@ namespace sealhip
         size_t blocks = (total + kThreads - 1) / kThreads;
         if (blocks > 4096)
             blocks = 4096;
-        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, L, (unsigned)t.log_n, polys);
+        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, L, (unsigned)t.log_n, polys,
+                           ks2_lane_order() ? 1 : 0);
         return hipGetLastError();
     }
 } // namespace sealhip
