@@ -21,6 +21,9 @@ namespace sealhip
     // m = t (BGV: the noise is p*e) or 1
     hipError_t k_neg_add_noise(const ModDesc *mods, uint64_t *c0, const uint64_t *e, uint64_t m, size_t words, unsigned n_log, unsigned K,
                                hipStream_t s, bool negate = true); // negate == false: c0 <- c0 + e * m (public-key encryption)
+    // the Encryptor's small polynomials (u, e_0, e_1: N signed bytes each, sampled on the host) replicated into the RNS components:
+    // out[p][r][i] = small[p][i] < 0 ? q_r + small[p][i] : small[p][i] over `polys` polynomials (util/rlwe.cpp:24-43, 120-150)
+    hipError_t k_expand_small(const ModDesc *mods, const int8_t *small, uint64_t *out, unsigned n_log, unsigned K, unsigned polys, hipStream_t s);
     // BatchEncoder index map (batchencoder.cpp:97-123): scatter out[b][map[i]] = in[b][i] (encode), gather out[b][i] = in[b][map[i]]
     // (decode) over `batch` vectors of N words; signed_mod != 0 converts between the balanced signed representation and [0, t):
     // encode: negative int64 v -> t + v; decode: value > t/2 -> value - t (as int64)

@@ -66,6 +66,18 @@ namespace sealhip
             }
         }
 
+        __global__ void __launch_bounds__(kBlock) expand_small_kernel(
+            const ModDesc *mods, const int8_t *small, uint64_t *out, size_t words, unsigned n_log, unsigned K)
+        {
+            const size_t nmask = (size_t(1) << n_log) - 1;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t row = i >> n_log; // p * K + r
+                const int v = small[((row / K) << n_log) + (i & nmask)];
+                out[i] = v < 0 ? mods[(unsigned)(row % K)].q - (uint64_t)(-v) : (uint64_t)v;
+            }
+        }
+
         __global__ void __launch_bounds__(kBlock) slot_scatter_kernel(
             const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, size_t words, uint64_t signed_mod)
         {
@@ -178,6 +190,14 @@ namespace sealhip
         if (!words)
             return hipSuccess;
         hipLaunchKernelGGL(neg_add_noise_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, c0, e, m, words, n_log, K, negate);
+        return hipGetLastError();
+    }
+    hipError_t k_expand_small(const ModDesc *mods, const int8_t *small, uint64_t *out, unsigned n_log, unsigned K, unsigned polys, hipStream_t s)
+    {
+        const size_t words = ((size_t)polys * K) << n_log;
+        if (!words)
+            return hipSuccess;
+        hipLaunchKernelGGL(expand_small_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, small, out, words, n_log, K);
         return hipGetLastError();
     }
     hipError_t k_slot_scatter(const uint32_t *map, const uint64_t *in, uint64_t *out, unsigned n_log, unsigned batch, uint64_t signed_mod,

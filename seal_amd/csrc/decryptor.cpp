@@ -436,10 +436,11 @@ namespace sealhip
         uint64_t boot[8];
         bootstrap_seed(boot);
         serial::Prng prng(1, boot);
-        std::vector<uint64_t> u(words), e(2 * words);
-        serial::sample_poly_ternary(prng, context_.coeff_modulus().data(), K, n, u.data());
-        serial::sample_poly_cbd(prng, context_.coeff_modulus().data(), K, n, e.data());
-        serial::sample_poly_cbd(prng, context_.coeff_modulus().data(), K, n, e.data() + words);
+        // (N signed bytes each; the device replicates them into the RNS components)
+        std::vector<int8_t> small(3 * n);
+        serial::sample_small_ternary(prng, n, small.data());
+        serial::sample_small_cbd(prng, n, small.data() + n);
+        serial::sample_small_cbd(prng, n, small.data() + 2 * n);
 
         ck(hipStreamSynchronize(nullptr), "encrypt sync");
         d.resize(&lvl, 2, nullptr);
@@ -448,9 +449,11 @@ namespace sealhip
         d.correction_factor() = 1;
         const NttTables &tb = context_.ntt_tables();
         const ModDesc *mods = context_.dev_mods();
-        Scratch du(words), de(2 * words);
-        ck(hipMemcpy(du.p, u.data(), words * 8, hipMemcpyHostToDevice), "upload u");
-        ck(hipMemcpy(de.p, e.data(), 2 * words * 8, hipMemcpyHostToDevice), "upload noise");
+        Scratch du(words), de(2 * words), ds((3 * n + 7) / 8);
+        ck(hipMemcpy(ds.p, small.data(), 3 * n, hipMemcpyHostToDevice), "upload u, e");
+        const int8_t *dsmall = reinterpret_cast<const int8_t *>(ds.p);
+        ck(k_expand_small(mods, dsmall, du.p, n_log, (unsigned)K, 1, nullptr), "expand u");
+        ck(k_expand_small(mods, dsmall + n, de.p, n_log, (unsigned)K, 2, nullptr), "expand e");
         ck(ntt_forward(tb, polys(du.p, K, n, 1), 0, nullptr), "ntt u");
         for (size_t j = 0; j < 2; j++)
             ck(k_dyadic(mods, du.p, pk_ + j * L * n, d.plane(j), n_log, (unsigned)K, 0, 1, nullptr), "pk u");
@@ -567,9 +570,10 @@ namespace sealhip
         uint64_t pub[8];
         bootstrap.generate(sizeof(pub), reinterpret_cast<uint8_t *>(pub));
         serial::Prng cprng(1, pub);
-        std::vector<uint64_t> a(words), noise(words);
+        std::vector<uint64_t> a(words);
+        std::vector<int8_t> noise(n);
         serial::sample_poly_uniform(cprng, context_.coeff_modulus().data(), K, n, a.data());
-        serial::sample_poly_cbd(bootstrap, context_.coeff_modulus().data(), K, n, noise.data());
+        serial::sample_small_cbd(bootstrap, n, noise.data());
         if (public_seed)
             std::memcpy(public_seed, pub, sizeof(pub));
 
@@ -582,9 +586,10 @@ namespace sealhip
         uint64_t *c0 = d.plane(0), *c1 = d.plane(1);
         const NttTables &tb = context_.ntt_tables();
         const ModDesc *mods = context_.dev_mods();
-        Scratch e(words);
+        Scratch e(words), ds((n + 7) / 8);
         ck(hipMemcpy(c1, a.data(), words * 8, hipMemcpyHostToDevice), "upload a");
-        ck(hipMemcpy(e.p, noise.data(), words * 8, hipMemcpyHostToDevice), "upload noise");
+        ck(hipMemcpy(ds.p, noise.data(), n, hipMemcpyHostToDevice), "upload noise");
+        ck(k_expand_small(mods, reinterpret_cast<const int8_t *>(ds.p), e.p, n_log, (unsigned)K, 1, nullptr), "expand noise");
         if (ntt_form)
         {
             ck(k_dyadic(mods, sk_, c1, c0, n_log, (unsigned)K, 0, 1, nullptr), "a s");

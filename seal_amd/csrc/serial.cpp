@@ -35,6 +35,52 @@ namespace sealhip
         }
         void Prng::generate(size_t bytes, uint8_t *dst)
         {
+            // Bulk requests (sample_poly_uniform's K*N words, the 4 N / 6 N bytes of the small samplers) are mostly whole 4096-byte
+            // blocks, block i = XOF(seed, counter + i): independent, so after what is left in the buffer they are produced straight
+            // into the destination on several host threads (BLAKE2Xb makes ~0.3 GB/s per core; a C5 polynomial is 7.9 MB).  The
+            // stream - and every later draw - is unchanged.
+            constexpr size_t kBlock = sizeof(buf);
+            if (parallel && bytes >= 32 * kBlock)
+            {
+                const size_t left = kBlock - head;
+                std::memcpy(dst, buf + head, left);
+                head = kBlock;
+                dst += left;
+                bytes -= left;
+                const size_t blocks = bytes / kBlock;
+                unsigned nthreads = std::thread::hardware_concurrency();
+                nthreads = nthreads > 16 ? 16 : (nthreads < 1 ? 1 : nthreads);
+                if (nthreads > blocks / 8)
+                    nthreads = (unsigned)(blocks / 8 ? blocks / 8 : 1);
+                const uint64_t counter0 = counter;
+                const uint8_t xof = type;
+                uint64_t sd[8];
+                std::memcpy(sd, seed, sizeof(sd));
+                auto work = [&](unsigned tix) {
+                    uint64_t ext[9];
+                    std::memcpy(ext, sd, sizeof(sd));
+                    for (size_t i = tix; i < blocks; i += nthreads)
+                    {
+                        const uint64_t c = counter0 + i;
+                        if (xof == 1)
+                            blake2::blake2xb(dst + i * kBlock, kBlock, &c, sizeof(c), sd, sizeof(sd));
+                        else
+                        {
+                            ext[8] = c;
+                            keccak::shake256(dst + i * kBlock, kBlock, reinterpret_cast<const uint8_t *>(ext), sizeof(ext));
+                        }
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (unsigned tix = 1; tix < nthreads; tix++)
+                    pool.emplace_back(work, tix);
+                work(0);
+                for (auto &th : pool)
+                    th.join();
+                counter += blocks;
+                dst += blocks * kBlock;
+                bytes -= blocks * kBlock;
+            }
             while (bytes)
             {
                 if (head == sizeof(buf))
@@ -68,38 +114,65 @@ namespace sealhip
                 dst += N;
             }
         }
-        void sample_poly_ternary(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+        void sample_small_ternary(Prng &prng, size_t N, int8_t *dst)
         {
+            // RandomToStandardAdapter::operator() = 4 bytes of the stream as one uint32_t (randomtostd.h:43-57): N of them in one
+            // draw, a rejected one (g * 3 mod 2^32 == 0, i.e. g == 0) replaced by the next 4 bytes of the stream as the reference's
+            // loop does - everything after it shifts by one draw
+            std::vector<uint32_t> g(N);
+            prng.generate(N * sizeof(uint32_t), reinterpret_cast<uint8_t *>(g.data()));
+            size_t next = 0;
+            auto draw = [&]() {
+                uint32_t v;
+                if (next < N)
+                    v = g[next++];
+                else
+                    prng.generate(sizeof(v), reinterpret_cast<uint8_t *>(&v));
+                return v;
+            };
             for (size_t k = 0; k < N; k++)
             {
-                // RandomToStandardAdapter::operator() = 4 bytes of the stream as one uint32_t (randomtostd.h:43-57)
-                uint32_t g;
                 uint64_t product;
                 do
-                {
-                    prng.generate(sizeof(g), reinterpret_cast<uint8_t *>(&g));
-                    product = (uint64_t)g * 3u;
-                } while ((uint32_t)product < 1u /* threshold = (2^32 - 3) mod 3 */);
-                const uint64_t rand = product >> 32; // 0, 1, 2 -> coefficient -1, 0, 1
-                for (size_t j = 0; j < K; j++)
-                    dst[j * N + k] = rand == 0 ? primes[j] - 1 : rand - 1;
+                    product = (uint64_t)draw() * 3u;
+                while ((uint32_t)product < 1u /* threshold = (2^32 - 3) mod 3 */);
+                dst[k] = (int8_t)((int)(product >> 32) - 1); // 0, 1, 2 -> coefficient -1, 0, 1
             }
         }
         // sample_poly_cbd (util/rlwe.cpp): centred binomial noise of standard deviation 3.2 - 6 bytes per coefficient, the
-        // difference of two 21-bit Hamming weights - replicated into every RNS component (negative values as q_i + noise)
-        void sample_poly_cbd(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+        // difference of two 21-bit Hamming weights
+        void sample_small_cbd(Prng &prng, size_t N, int8_t *dst)
         {
+            std::vector<uint8_t> x(6 * N);
+            prng.generate(x.size(), x.data());
             for (size_t k = 0; k < N; k++)
             {
-                unsigned char x[6];
-                prng.generate(6, x);
-                x[2] &= 0x1F;
-                x[5] &= 0x1F;
-                const int noise = __builtin_popcount(x[0]) + __builtin_popcount(x[1]) + __builtin_popcount(x[2]) - __builtin_popcount(x[3]) -
-                                  __builtin_popcount(x[4]) - __builtin_popcount(x[5]);
-                for (size_t j = 0; j < K; j++)
-                    dst[j * N + k] = noise < 0 ? primes[j] - (uint64_t)(-noise) : (uint64_t)noise;
+                const uint8_t *b = x.data() + 6 * k;
+                dst[k] = (int8_t)(__builtin_popcount(b[0]) + __builtin_popcount(b[1]) + __builtin_popcount(b[2] & 0x1F) - __builtin_popcount(b[3]) -
+                                  __builtin_popcount(b[4]) - __builtin_popcount(b[5] & 0x1F));
             }
+        }
+        namespace
+        {
+            // the small value replicated into every RNS component, negative values as q_j + v (what k_expand_small does on the device)
+            void replicate(const int8_t *small, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+            {
+                for (size_t j = 0; j < K; j++)
+                    for (size_t k = 0; k < N; k++)
+                        dst[j * N + k] = small[k] < 0 ? primes[j] - (uint64_t)(-small[k]) : (uint64_t)small[k];
+            }
+        } // namespace
+        void sample_poly_ternary(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+        {
+            std::vector<int8_t> small(N);
+            sample_small_ternary(prng, N, small.data());
+            replicate(small.data(), primes, K, N, dst);
+        }
+        void sample_poly_cbd(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst)
+        {
+            std::vector<int8_t> small(N);
+            sample_small_cbd(prng, N, small.data());
+            replicate(small.data(), primes, K, N, dst);
         }
 
         namespace
@@ -536,6 +609,8 @@ namespace sealhip
                 if (nthreads < 1)
                     nthreads = 1;
                 std::atomic<size_t> next{ 0 };
+                for (auto &j : jobs)
+                    j.prng.parallel = nthreads == 1; // one level of threading: across the digits here, inside a draw otherwise
                 auto work = [&]() {
                     for (size_t i = next++; i < jobs.size(); i = next++)
                         sample_poly_uniform(jobs[i].prng, ctx.coeff_modulus().data(), jobs[i].K, jobs[i].N, jobs[i].dst);

@@ -110,6 +110,7 @@ namespace sealhip
             uint64_t counter = 0;
             uint8_t buf[4096];
             size_t head = 4096;
+            bool parallel = true; // bulk draws may use several host threads (switched off where the caller already does)
             Prng() = default;
             Prng(uint8_t t, const uint64_t *s) : type(t)
             {
@@ -126,6 +127,10 @@ namespace sealhip
         // (GCC >= 11: Lemire's multiply-shift, bits/uniform_int_dist.h _S_nd) - value = (g * 3) >> 32 with g = 0 redrawn - which is
         // what the reference build in this image uses (checked byte for byte in tests/decrypt_cases.py).
         void sample_poly_ternary(Prng &prng, const uint64_t *primes, size_t K, size_t N, uint64_t *dst);
+        // the same two distributions as N signed bytes (ternary: -1, 0, 1; cbd: -21 .. 21) - what the Encryptor uploads; the device
+        // replicates them into the RNS components (decrypt_kernels.h: k_expand_small)
+        void sample_small_ternary(Prng &prng, size_t N, int8_t *dst);
+        void sample_small_cbd(Prng &prng, size_t N, int8_t *dst);
         // Serializable<Ciphertext>::save of a seeded ciphertext (ciphertext.cpp:171-196): members, DynArray with c_0 only, then
         // the UniformRandomGeneratorInfo (type, seed) c_1 is re-expanded from.  words == nullptr: as save_ciphertext.
         size_t seeded_ciphertext_save_size(uint64_t poly_modulus_degree, uint64_t coeff_modulus_size);

@@ -125,7 +125,8 @@ def test_end_to_end_streams(emu, scheme, n, bits):
 
 
 @needs_ref
-@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45])])
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45]),
+                                           ("ckks", 32768, [50, 55])])   # the last: large enough for the threaded bulk PRNG draws
 def test_encrypt_symmetric(emu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_encrypt_symmetric(scheme, n, bits)
@@ -163,7 +164,8 @@ def test_compressed_streams(emu, scheme, n, bits):
 
 
 @needs_ref
-@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45]), ("bfv", 1024, [40])])
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45]), ("bfv", 1024, [40]),
+                                           ("bfv", 32768, [50, 55])])   # the last: large enough for the threaded bulk PRNG draws
 def test_encrypt_asymmetric(emu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_encrypt_asymmetric(scheme, n, bits)
