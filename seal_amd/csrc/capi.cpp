@@ -7,6 +7,7 @@
 #include "ckks_encoder.h"
 #include "decryptor.h"
 #include "serial.h"
+#include "xof.h"
 #include <cstring>
 #include <new>
 #include <string>
@@ -553,6 +554,22 @@ extern "C"
             hipError_t e = img.stored_words ? hipMemcpy(tmp, img.stored, img.stored_words * 8, hipMemcpyHostToDevice) : hipSuccess;
             if (e == hipSuccess && !img.expanded.empty())
                 e = hipMemcpy(tmp + img.stored_words, img.expanded.data(), img.expanded.size() * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess && img.pending_words)
+            {
+                // the seeded c_1: sample_poly_uniform over Blake2xb on the device (xof.h)
+                XofJob job;
+                std::memcpy(job.seed, img.pending_seed, sizeof(job.seed));
+                job.dst = tmp + img.stored_words;
+                try
+                {
+                    sample_uniform_device(c, K, { job });
+                }
+                catch (...)
+                {
+                    (void)hipFree(tmp);
+                    throw;
+                }
+            }
             if (e == hipSuccess && to_ntt)
             {
                 NttBatch b{};
@@ -582,7 +599,7 @@ extern "C"
             if (whole && ct->batch() != 1)
                 throw std::invalid_argument("Ciphertext_Load needs a batch of one: use Ciphertext_LoadItem for a slot of a batch");
             serial::CiphertextImage img;
-            *in_bytes = (int64_t)serial::load_ciphertext(*c, inptr, (size_t)size, check, img);
+            *in_bytes = (int64_t)serial::load_ciphertext(*c, inptr, (size_t)size, check, img, true);
             // the first item loaded into an empty batch defines its metadata
             upload_image(*ct, *c, img, (size_t)item, whole || ct->size() == 0);
             SHL_CATCH
@@ -596,7 +613,7 @@ extern "C"
             SHL_TRY
             auto c = as<Context>(context);
             serial::KSwitchKeysImage img;
-            *in_bytes = (int64_t)serial::load_kswitchkeys(*c, inptr, (size_t)size, check, img);
+            *in_bytes = (int64_t)serial::load_kswitchkeys(*c, inptr, (size_t)size, check, img, true);
             auto keys = as<KSwitchKeys>(thisptr);
             for (size_t index = 0; index < img.keys.size(); index++)
             {
@@ -606,14 +623,23 @@ extern "C"
                 // [digit][2][L][N], the layout of KSwitchKeys::keys_[index][digit].data() (kswitchkeys.h:340); every piece is
                 // copied to the device from where it lies (the stream buffer / the expanded c_1): no host staging copy
                 keys->set_key_with(*c, index, digits.size(), [&](uint64_t *dst) {
+                    std::vector<XofJob> seeded; // the c_1 halves a Blake2xb seed stands for: expanded on the device, all digits at once
                     for (auto &d : digits)
                     {
                         if (d.stored_words)
                             hip_ok(hipMemcpy(dst, d.stored, d.stored_words * 8, hipMemcpyHostToDevice), "upload key");
                         if (!d.expanded.empty())
                             hip_ok(hipMemcpy(dst + d.stored_words, d.expanded.data(), d.expanded.size() * 8, hipMemcpyHostToDevice), "upload key");
+                        if (d.pending_words)
+                        {
+                            XofJob job;
+                            std::memcpy(job.seed, d.pending_seed, sizeof(job.seed));
+                            job.dst = dst + d.stored_words;
+                            seeded.push_back(job);
+                        }
                         dst += d.word_count();
                     }
+                    sample_uniform_device(*c, c->key_level().K, seeded);
                 });
                 for (auto &d : digits)
                     std::vector<uint64_t>().swap(d.expanded);

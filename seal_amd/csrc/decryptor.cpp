@@ -1,5 +1,6 @@
 // See decryptor.h.  Reference: native/src/seal/decryptor.cpp.
 #include "decryptor.h"
+#include "xof.h"
 #include "hostmath.h"
 #include <algorithm>
 #include <cstring>
@@ -570,9 +571,12 @@ namespace sealhip
         uint64_t pub[8];
         bootstrap.generate(sizeof(pub), reinterpret_cast<uint8_t *>(pub));
         serial::Prng cprng(1, pub);
-        std::vector<uint64_t> a(words);
+        // a = sample_poly_uniform(cprng): on the device when the stream is whole PRNG buffers (xof.h), else here
+        const bool device_a = xof_device_ok(1, K, n);
+        std::vector<uint64_t> a(device_a ? 0 : words);
         std::vector<int8_t> noise(n);
-        serial::sample_poly_uniform(cprng, context_.coeff_modulus().data(), K, n, a.data());
+        if (!device_a)
+            serial::sample_poly_uniform(cprng, context_.coeff_modulus().data(), K, n, a.data());
         serial::sample_small_cbd(bootstrap, n, noise.data());
         if (public_seed)
             std::memcpy(public_seed, pub, sizeof(pub));
@@ -587,7 +591,15 @@ namespace sealhip
         const NttTables &tb = context_.ntt_tables();
         const ModDesc *mods = context_.dev_mods();
         Scratch e(words), ds((n + 7) / 8);
-        ck(hipMemcpy(c1, a.data(), words * 8, hipMemcpyHostToDevice), "upload a");
+        if (device_a)
+        {
+            XofJob job;
+            std::memcpy(job.seed, pub, sizeof(job.seed));
+            job.dst = c1;
+            sample_uniform_device(context_, K, { job });
+        }
+        else
+            ck(hipMemcpy(c1, a.data(), words * 8, hipMemcpyHostToDevice), "upload a");
         ck(hipMemcpy(ds.p, noise.data(), n, hipMemcpyHostToDevice), "upload noise");
         ck(k_expand_small(mods, reinterpret_cast<const int8_t *>(ds.p), e.p, n_log, (unsigned)K, 1, nullptr), "expand noise");
         if (ntt_form)

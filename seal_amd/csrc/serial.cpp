@@ -430,6 +430,8 @@ namespace sealhip
                 for (uint64_t i = 0; i < c.size; i++)
                     for (unsigned j = 0; j < c.level->K; j++)
                     {
+                        if (left == 0 && c.pending_words)
+                            return true; // the rest is expanded on the device, reduced by construction
                         if (left == 0)
                         {
                             p = reinterpret_cast<const unaligned_u64 *>(c.expanded.data());
@@ -456,7 +458,8 @@ namespace sealhip
             };
 
             // Ciphertext::load_members (ciphertext.cpp:230-403)
-            void ciphertext_members(const Context &ctx, Reader &r, Version v, CiphertextImage &out, std::vector<ExpandJob> *deferred = nullptr)
+            void ciphertext_members(const Context &ctx, Reader &r, Version v, CiphertextImage &out, std::vector<ExpandJob> *deferred = nullptr,
+                                    bool device_expand = false)
             {
                 uint64_t parms_id[4];
                 r.read(parms_id, sizeof(parms_id));
@@ -502,8 +505,18 @@ namespace sealhip
                             throw std::logic_error("prng_type is invalid");
                         rr.read(prng.seed, sizeof(prng.seed));
                     });
-                    out.expanded.resize((size_t)seeded_count);
-                    if (deferred)
+                    out.pending_words = 0;
+                    // (the device kernel's conditions, xof.h: xof_device_ok)
+                    if (device_expand && prng.type == 1 && n64 >= 8 && seeded_count && (seeded_count * 8) % 4096 == 0)
+                    {
+                        out.pending_words = (size_t)seeded_count;
+                        std::memcpy(out.pending_seed, prng.seed, sizeof(prng.seed));
+                    }
+                    else
+                        out.expanded.resize((size_t)seeded_count);
+                    if (out.pending_words)
+                        ;
+                    else if (deferred)
                         deferred->push_back(ExpandJob{ prng, (size_t)K64, (size_t)n64, out.expanded.data() });
                     else
                         sample_poly_uniform(prng, ctx.coeff_modulus().data(), (size_t)K64, (size_t)n64, out.expanded.data());
@@ -547,13 +560,13 @@ namespace sealhip
             sample_poly_uniform(prng, primes, K, N, destination);
         }
 
-        size_t load_ciphertext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, CiphertextImage &out)
+        size_t load_ciphertext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, CiphertextImage &out, bool device_expand)
         {
             check_input(in, size);
             Reader r{ in, size };
             r.inflate_limit = 6 * ctx.key_level().K * ctx.n() * 8 + 4096; // SEAL_CIPHERTEXT_SIZE_MAX polynomials at the key level
             CiphertextImage img;
-            const size_t bytes = framed(r, [&](Reader &rr, Version v) { ciphertext_members(ctx, rr, v, img); });
+            const size_t bytes = framed(r, [&](Reader &rr, Version v) { ciphertext_members(ctx, rr, v, img, nullptr, device_expand); });
             img.inflated = std::move(r.inflated);
             if (check_data)
             {
@@ -567,7 +580,7 @@ namespace sealhip
             return bytes;
         }
 
-        size_t load_kswitchkeys(const Context &ctx, const uint8_t *in, size_t size, bool check_data, KSwitchKeysImage &out)
+        size_t load_kswitchkeys(const Context &ctx, const uint8_t *in, size_t size, bool check_data, KSwitchKeysImage &out, bool device_expand)
         {
             check_input(in, size);
             Reader r{ in, size };
@@ -592,7 +605,7 @@ namespace sealhip
                     for (uint64_t j = 0; j < dim2; j++)
                     {
                         CiphertextImage key;
-                        framed(rr, [&](Reader &r3, Version v) { ciphertext_members(ctx, r3, v, key, &jobs); });
+                        framed(rr, [&](Reader &r3, Version v) { ciphertext_members(ctx, r3, v, key, &jobs, device_expand); });
                         img.keys.back().emplace_back(std::move(key));
                     }
                 }

@@ -51,7 +51,11 @@ namespace sealhip
             size_t stored_words = 0;
             std::vector<uint64_t> expanded;
             std::list<std::vector<uint8_t>> inflated; // decompressed payloads `stored` may point into (compressed streams)
-            size_t word_count() const { return stored_words + expanded.size(); }
+            // device_expand loads (Blake2xb seed, whole PRNG buffers): c_1 is left to the device (xof.h) - `expanded` stays empty
+            // and the caller expands `pending_seed` into the pending_words words after the stored ones
+            size_t pending_words = 0;
+            uint64_t pending_seed[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            size_t word_count() const { return stored_words + expanded.size() + pending_words; }
             void copy_words(uint64_t *dst) const; // gather both pieces into one host array
         };
         struct KSwitchKeysImage
@@ -64,9 +68,13 @@ namespace sealhip
         // Ciphertext::unsafe_load (check_data = false) / Ciphertext::load (true: is_valid_for, valcheck.cpp).  Returns the
         // bytes consumed.  A BGV ciphertext stored in coefficient form is returned as stored (is_ntt_form false): the caller
         // transforms it on the device, as the end of Ciphertext::load_members does on the host.
-        size_t load_ciphertext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, CiphertextImage &out);
+        // device_expand: leave the expansion of a Blake2xb-seeded c_1 to the caller (CiphertextImage::pending_words) when the
+        // device kernel can do it; other seeded objects are expanded here on the host as before.
+        size_t load_ciphertext(const Context &ctx, const uint8_t *in, size_t size, bool check_data, CiphertextImage &out,
+                               bool device_expand = false);
         // KSwitchKeys::unsafe_load / load
-        size_t load_kswitchkeys(const Context &ctx, const uint8_t *in, size_t size, bool check_data, KSwitchKeysImage &out);
+        size_t load_kswitchkeys(const Context &ctx, const uint8_t *in, size_t size, bool check_data, KSwitchKeysImage &out,
+                                bool device_expand = false);
 
         // compression of a saved object: `raw` = the uncompressed stream (header + members) as the save_* functions write it;
         // returns the bytes written to out (header with compr_mode and the compressed size, then the compressed members).

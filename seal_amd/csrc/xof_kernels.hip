@@ -1,0 +1,162 @@
+// See xof_kernels.h.  BLAKE2b compression written from RFC 7693; 64-bit adds / xors / rotates only, the message schedule
+// resolved at compile time so that the 16 message words stay in registers.
+#include "xof_kernels.h"
+
+namespace sealhip
+{
+    namespace
+    {
+        constexpr unsigned kBlock = 256;
+        __device__ __forceinline__ uint64_t b2_iv(int i)
+        {
+            constexpr uint64_t iv[8] = { 0x6a09e667f3bcc908ull, 0xbb67ae8584caa73bull, 0x3c6ef372fe94f82bull, 0xa54ff53a5f1d36f1ull,
+                                         0x510e527fade682d1ull, 0x9b05688c2b3e6c1full, 0x1f83d9abfb41bd6bull, 0x5be0cd19137e2179ull };
+            return iv[i];
+        }
+
+        __device__ __forceinline__ uint64_t rotr64(uint64_t x, int c)
+        {
+            return (x >> c) | (x << (64 - c));
+        }
+#define SHL_B2_G(a, b, c, d, x, y)   \
+    v[a] = v[a] + v[b] + (x);        \
+    v[d] = rotr64(v[d] ^ v[a], 32);  \
+    v[c] = v[c] + v[d];              \
+    v[b] = rotr64(v[b] ^ v[c], 24);  \
+    v[a] = v[a] + v[b] + (y);        \
+    v[d] = rotr64(v[d] ^ v[a], 16);  \
+    v[c] = v[c] + v[d];              \
+    v[b] = rotr64(v[b] ^ v[c], 63);
+#define SHL_B2_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \
+    SHL_B2_G(0, 4, 8, 12, m[s0], m[s1])                                                   \
+    SHL_B2_G(1, 5, 9, 13, m[s2], m[s3])                                                   \
+    SHL_B2_G(2, 6, 10, 14, m[s4], m[s5])                                                  \
+    SHL_B2_G(3, 7, 11, 15, m[s6], m[s7])                                                  \
+    SHL_B2_G(0, 5, 10, 15, m[s8], m[s9])                                                  \
+    SHL_B2_G(1, 6, 11, 12, m[s10], m[s11])                                                \
+    SHL_B2_G(2, 7, 8, 13, m[s12], m[s13])                                                 \
+    SHL_B2_G(3, 4, 9, 14, m[s14], m[s15])
+
+        // h <- F(h, m, t, last) (RFC 7693 section 3.2); the byte counter fits one word here
+        __device__ __forceinline__ void b2_compress(uint64_t (&h)[8], const uint64_t (&m)[16], uint64_t t, bool last)
+        {
+            uint64_t v[16];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                v[i] = h[i];
+                v[i + 8] = b2_iv(i);
+            }
+            v[12] ^= t;
+            if (last)
+                v[14] = ~v[14];
+            SHL_B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+            SHL_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+            SHL_B2_ROUND(11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4)
+            SHL_B2_ROUND(7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8)
+            SHL_B2_ROUND(9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13)
+            SHL_B2_ROUND(2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9)
+            SHL_B2_ROUND(12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11)
+            SHL_B2_ROUND(13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10)
+            SHL_B2_ROUND(6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5)
+            SHL_B2_ROUND(10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0)
+            SHL_B2_ROUND(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15)
+            SHL_B2_ROUND(14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                h[i] ^= v[i] ^ v[i + 8];
+        }
+#undef SHL_B2_ROUND
+#undef SHL_B2_G
+
+        constexpr uint64_t kXofLength = 4096; // the reference PRNG's buffer (randomgen.h: buffer_size_)
+
+        __global__ void __launch_bounds__(kBlock) blake2xb_uniform_kernel(
+            const ModDesc *mods, const XofJob *jobs, unsigned *reject, unsigned n_log, unsigned K)
+        {
+            const size_t words = (size_t)K << n_log;
+            const size_t piece = blockIdx.x * (size_t)kBlock + threadIdx.x; // 64 bytes of the stream = 8 words
+            if (piece >= words / 8)
+                return;
+            const XofJob &job = jobs[blockIdx.y];
+            const uint64_t buffer = piece >> 6; // the PRNG's counter for this 4096-byte buffer
+            const uint64_t node = piece & 63;
+
+            // root hash h0 = BLAKE2b-512(key = seed, message = counter), parameter block: digest 64, key 64, fanout 1, depth 1,
+            // xof_length 4096.  Keyed: the key padded to one block is the first message block.
+            uint64_t h[8], m[16];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                h[i] = b2_iv(i);
+            h[0] ^= 64ull | (64ull << 8) | (1ull << 16) | (1ull << 24);
+            h[1] ^= kXofLength << 32;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+            {
+                m[i] = job.seed[i];
+                m[i + 8] = 0;
+            }
+            b2_compress(h, m, 128, false);
+#pragma unroll
+            for (int i = 1; i < 8; i++)
+                m[i] = 0;
+            m[0] = buffer;
+            b2_compress(h, m, 128 + 8, true);
+
+            // piece `node` of the buffer = BLAKE2b-512(h0), parameter block: digest 64, key 0, fanout 0, depth 0, leaf_length 64,
+            // node_offset = node, xof_length 4096, node_depth 0, inner_length 64
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                m[i] = h[i];
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                h[i] = b2_iv(i);
+            h[0] ^= 64ull | (64ull << 32);
+            h[1] ^= node | (kXofLength << 32);
+            h[2] ^= 64ull << 8;
+            b2_compress(h, m, 64, true);
+
+            // sample_poly_uniform's acceptance test and reduction; 8 consecutive words lie in one RNS component
+            const size_t w0 = piece * 8;
+            const ModDesc md = mods[(unsigned)(w0 >> n_log)];
+            const uint64_t max_multiple = ~0ull - barrett64(~0ull, md) - 1;
+            unsigned rejected = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+            {
+                if (h[t] >= max_multiple)
+                    rejected |= 1u << t;
+                else
+                    h[t] = barrett64(h[t], md);
+                job.dst[w0 + t] = h[t];
+            }
+            if (rejected)
+                atomicOr(reject + blockIdx.y * (words / 32) + w0 / 32, rejected << (w0 % 32));
+        }
+
+        __global__ void __launch_bounds__(kBlock) apply_patches_kernel(const XofPatch *patches, size_t count)
+        {
+            const size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x;
+            if (i < count)
+                *patches[i].dst = patches[i].value;
+        }
+    } // namespace
+
+    hipError_t k_blake2xb_uniform(const ModDesc *mods, const XofJob *jobs, unsigned njobs, unsigned *reject, unsigned n_log, unsigned K,
+                                  hipStream_t s)
+    {
+        const size_t pieces = ((size_t)K << n_log) / 8;
+        if (!pieces || !njobs)
+            return hipSuccess;
+        hipLaunchKernelGGL(blake2xb_uniform_kernel, dim3((unsigned)((pieces + kBlock - 1) / kBlock), njobs), dim3(kBlock), 0, s, mods, jobs,
+                           reject, n_log, K);
+        return hipGetLastError();
+    }
+    hipError_t k_apply_patches(const XofPatch *patches, size_t count, hipStream_t s)
+    {
+        if (!count)
+            return hipSuccess;
+        hipLaunchKernelGGL(apply_patches_kernel, dim3((unsigned)((count + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, patches, count);
+        return hipGetLastError();
+    }
+} // namespace sealhip

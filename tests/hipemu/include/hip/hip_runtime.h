@@ -52,6 +52,12 @@ static inline unsigned atomicMax(unsigned *p, unsigned v)
         *p = v;
     return old;
 }
+static inline unsigned atomicOr(unsigned *p, unsigned v)
+{
+    unsigned old = *p;
+    *p = old | v;
+    return old;
+}
 static inline long long __double_as_longlong(double d)
 {
     long long r;

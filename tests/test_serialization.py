@@ -54,7 +54,8 @@ def test_batch_items(emu, scheme, n, bits):
 
 @needs_ref
 @pytest.mark.parametrize("scheme,n,bits,seeded", [("ckks", 1024, [40, 30, 40], True), ("bfv", 1024, [36, 36, 37], False),
-                                                  ("bgv", 2048, [40, 40, 45], True), ("ckks", 8192, [50, 40, 60], True)])
+                                                  ("bgv", 2048, [40, 40, 45], True), ("ckks", 8192, [50, 40, 60], True),
+                                                  ("ckks", 8192, [60, 59, 60], True)])
 def test_key_streams(emu, scheme, n, bits, seeded):
     import serial_cases as SC
     SC.case_key_streams(scheme, n, bits, seeded)
@@ -126,7 +127,8 @@ def test_end_to_end_streams(emu, scheme, n, bits):
 
 @needs_ref
 @pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45]),
-                                           ("ckks", 32768, [50, 55])])   # the last: large enough for the threaded bulk PRNG draws
+                                           ("ckks", 32768, [50, 55]),    # large enough for the threaded bulk PRNG draws
+                                           ("ckks", 8192, [60, 60, 60]), ("bfv", 4096, [50, 59])])   # ~3 % of a's words rejected and redrawn
 def test_encrypt_symmetric(emu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_encrypt_symmetric(scheme, n, bits)
