@@ -3,6 +3,7 @@
 #include "xof.h"
 #include "hostmath.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace sealhip
@@ -427,21 +428,19 @@ namespace sealhip
     }
 
     // util::encrypt_zero_asymmetric (util/rlwe.cpp:196-268) at `lvl`
-    void Encryptor::zero_asymmetric_at(const Level &lvl, Ciphertext &d)
+    void Encryptor::zero_asymmetric_at(const Level &lvl, Ciphertext &d, bool host_sampling)
     {
         const size_t n = context_.n(), K = lvl.K, L = context_.key_level().K, words = K * n;
         const unsigned n_log = (unsigned)context_.log_n();
         const Scheme scheme = context_.scheme();
         const bool ntt_form = scheme != Scheme::bfv;
-        // host: u <- R_3, then e_0, e_1 <- chi, all from one PRNG, in this order
+        // u <- R_3, then e_0, e_1 <- chi, all from one PRNG, in this order: bytes [0, 4n), [4n, 10n), [10n, 16n) of its stream, which
+        // the device produces itself (xof_kernels.h) - unless a ternary draw has to be redrawn (probability n / 2^32), which shifts
+        // everything after it: then the sampling is repeated here on the host, as it is for rings too small for whole 64-byte pieces
         uint64_t boot[8];
         bootstrap_seed(boot);
-        serial::Prng prng(1, boot);
-        // (N signed bytes each; the device replicates them into the RNS components)
-        std::vector<int8_t> small(3 * n);
-        serial::sample_small_ternary(prng, n, small.data());
-        serial::sample_small_cbd(prng, n, small.data() + n);
-        serial::sample_small_cbd(prng, n, small.data() + 2 * n);
+        if (n < 4 || std::getenv("SEALHIP_ENCRYPT_HOST_SAMPLING")) // (the switch: tests run the host branch, otherwise one call in 2^16)
+            host_sampling = true;
 
         ck(hipStreamSynchronize(nullptr), "encrypt sync");
         d.resize(&lvl, 2, nullptr);
@@ -450,9 +449,28 @@ namespace sealhip
         d.correction_factor() = 1;
         const NttTables &tb = context_.ntt_tables();
         const ModDesc *mods = context_.dev_mods();
-        Scratch du(words), de(2 * words), ds((3 * n + 7) / 8);
-        ck(hipMemcpy(ds.p, small.data(), 3 * n, hipMemcpyHostToDevice), "upload u, e");
-        const int8_t *dsmall = reinterpret_cast<const int8_t *>(ds.p);
+        const size_t small_words = (3 * n + 7) / 8;
+        Scratch du(words), de(2 * words), ds(small_words + 1), stream(host_sampling ? 1 : 2 * n);
+        int8_t *dsmall = reinterpret_cast<int8_t *>(ds.p);
+        unsigned *redraw = reinterpret_cast<unsigned *>(ds.p + small_words);
+        if (host_sampling)
+        {
+            // (N signed bytes each; the device replicates them into the RNS components)
+            serial::Prng prng(1, boot);
+            std::vector<int8_t> small(3 * n);
+            serial::sample_small_ternary(prng, n, small.data());
+            serial::sample_small_cbd(prng, n, small.data() + n);
+            serial::sample_small_cbd(prng, n, small.data() + 2 * n);
+            ck(hipMemcpy(ds.p, small.data(), 3 * n, hipMemcpyHostToDevice), "upload u, e");
+        }
+        else
+        {
+            XofSeed seed;
+            std::memcpy(seed.w, boot, sizeof(seed.w));
+            ck(hipMemsetAsync(redraw, 0, 8, nullptr), "clear flag");
+            ck(k_blake2xb_stream(seed, 0, 16 * n / 64, stream.p, nullptr), "bootstrap stream");
+            ck(k_small_from_stream(reinterpret_cast<const uint8_t *>(stream.p), n, 4 * n, 2 * n, dsmall, redraw, nullptr), "sample u, e");
+        }
         ck(k_expand_small(mods, dsmall, du.p, n_log, (unsigned)K, 1, nullptr), "expand u");
         ck(k_expand_small(mods, dsmall + n, de.p, n_log, (unsigned)K, 2, nullptr), "expand e");
         ck(ntt_forward(tb, polys(du.p, K, n, 1), 0, nullptr), "ntt u");
@@ -465,7 +483,12 @@ namespace sealhip
         ck(k_neg_add_noise(mods, d.data(), de.p, scheme == Scheme::bgv ? context_.plain_modulus() : 1, 2 * words, n_log, (unsigned)K, nullptr,
                            false),
            "c + e");
+        unsigned flag = 0;
+        if (!host_sampling)
+            ck(hipMemcpy(&flag, redraw, sizeof(flag), hipMemcpyDeviceToHost), "read flag");
         ck(hipStreamSynchronize(nullptr), "encrypt sync");
+        if (flag)
+            zero_asymmetric_at(lvl, d, true);
     }
     // Encryptor::encrypt_zero_internal, asymmetric branch (encryptor.cpp:139-186): encrypt one level up, switch down
     void Encryptor::zero_asymmetric(const Level &lvl, Ciphertext &d)
@@ -548,7 +571,7 @@ namespace sealhip
     }
 
     // util::encrypt_zero_symmetric (util/rlwe.cpp:270-395)
-    void Encryptor::zero(const Level &lvl, bool save_seed, Ciphertext &d, uint64_t *public_seed)
+    void Encryptor::zero(const Level &lvl, bool save_seed, Ciphertext &d, uint64_t *public_seed, bool host_sampling)
     {
         if (!sk_)
             throw std::logic_error("secret key is not set");
@@ -574,10 +597,13 @@ namespace sealhip
         // a = sample_poly_uniform(cprng): on the device when the stream is whole PRNG buffers (xof.h), else here
         const bool device_a = xof_device_ok(1, K, n);
         std::vector<uint64_t> a(device_a ? 0 : words);
-        std::vector<int8_t> noise(n);
+        // the noise: bytes [64, 64 + 6n) of the bootstrap stream, sampled on the device when they are whole 64-byte pieces
+        const bool device_e = !host_sampling && (6 * n) % 64 == 0 && !std::getenv("SEALHIP_ENCRYPT_HOST_SAMPLING");
+        std::vector<int8_t> noise(device_e ? 0 : n);
         if (!device_a)
             serial::sample_poly_uniform(cprng, context_.coeff_modulus().data(), K, n, a.data());
-        serial::sample_small_cbd(bootstrap, n, noise.data());
+        if (!device_e)
+            serial::sample_small_cbd(bootstrap, n, noise.data());
         if (public_seed)
             std::memcpy(public_seed, pub, sizeof(pub));
 
@@ -590,7 +616,7 @@ namespace sealhip
         uint64_t *c0 = d.plane(0), *c1 = d.plane(1);
         const NttTables &tb = context_.ntt_tables();
         const ModDesc *mods = context_.dev_mods();
-        Scratch e(words), ds((n + 7) / 8);
+        Scratch e(words), ds((n + 7) / 8 + 1), stream(device_e ? 6 * n / 8 : 1);
         if (device_a)
         {
             XofJob job;
@@ -600,7 +626,17 @@ namespace sealhip
         }
         else
             ck(hipMemcpy(c1, a.data(), words * 8, hipMemcpyHostToDevice), "upload a");
-        ck(hipMemcpy(ds.p, noise.data(), n, hipMemcpyHostToDevice), "upload noise");
+        if (device_e)
+        {
+            XofSeed seed;
+            std::memcpy(seed.w, boot_seed, sizeof(seed.w));
+            ck(k_blake2xb_stream(seed, 1, 6 * n / 64, stream.p, nullptr), "bootstrap stream");
+            ck(k_small_from_stream(reinterpret_cast<const uint8_t *>(stream.p), 0, 0, n, reinterpret_cast<int8_t *>(ds.p),
+                                   reinterpret_cast<unsigned *>(ds.p + (n + 7) / 8), nullptr),
+               "sample noise");
+        }
+        else
+            ck(hipMemcpy(ds.p, noise.data(), n, hipMemcpyHostToDevice), "upload noise");
         ck(k_expand_small(mods, reinterpret_cast<const int8_t *>(ds.p), e.p, n_log, (unsigned)K, 1, nullptr), "expand noise");
         if (ntt_form)
         {

@@ -137,9 +137,9 @@ namespace sealhip
     private:
         const Level *level_for(const uint64_t *parms_id) const;
         const Level *level_for(const Plaintext &plain) const; // + the checks of Encryptor::encrypt_internal
-        void zero(const Level &lvl, bool save_seed, Ciphertext &destination, uint64_t *public_seed);
+        void zero(const Level &lvl, bool save_seed, Ciphertext &destination, uint64_t *public_seed, bool host_sampling = false);
         void zero_asymmetric(const Level &lvl, Ciphertext &destination);
-        void zero_asymmetric_at(const Level &lvl, Ciphertext &destination); // util::encrypt_zero_asymmetric
+        void zero_asymmetric_at(const Level &lvl, Ciphertext &destination, bool host_sampling = false); // util::encrypt_zero_asymmetric
         void bootstrap_seed(uint64_t *seed8) const;
         uint64_t *pk_ = nullptr; // [2][L][N], NTT form
         void add_plain(const Plaintext &plain, Ciphertext &destination);

@@ -28,5 +28,16 @@ namespace sealhip
     // of the polynomial was rejected (its dst word is left unreduced).  Requires K*N*8 to be a multiple of 4096.
     hipError_t k_blake2xb_uniform(const ModDesc *mods, const XofJob *jobs, unsigned njobs, unsigned *reject, unsigned n_log, unsigned K,
                                   hipStream_t s);
+    // the raw PRNG stream of `seed`: 64-byte pieces first_piece .. first_piece + pieces - 1 (piece p = bytes 64 p .. of the stream)
+    struct XofSeed
+    {
+        uint64_t w[8];
+    };
+    hipError_t k_blake2xb_stream(const XofSeed &seed, uint64_t first_piece, size_t pieces, uint64_t *out, hipStream_t s);
+    // sample_poly_ternary / sample_poly_cbd as signed bytes from a stream in HBM: small[0 .. n_ternary) from the 4-byte draws at
+    // stream + 4 k, small[n_ternary .. n_ternary + n_cbd) from the 6-byte draws at stream + cbd_offset + 6 k; *redraw is set when a
+    // ternary draw would have been redrawn by the reference (the caller then samples on the host)
+    hipError_t k_small_from_stream(const uint8_t *stream, size_t n_ternary, size_t cbd_offset, size_t n_cbd, int8_t *small, unsigned *redraw,
+                                   hipStream_t s);
     hipError_t k_apply_patches(const XofPatch *patches, size_t count, hipStream_t s);
 } // namespace sealhip

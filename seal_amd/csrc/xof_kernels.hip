@@ -14,6 +14,8 @@ namespace sealhip
             return iv[i];
         }
 
+        constexpr uint64_t kXofLength = 4096; // the reference PRNG's buffer (randomgen.h: buffer_size_)
+
         __device__ __forceinline__ uint64_t rotr64(uint64_t x, int c)
         {
             return (x >> c) | (x << (64 - c));
@@ -69,22 +71,15 @@ namespace sealhip
 #undef SHL_B2_ROUND
 #undef SHL_B2_G
 
-        constexpr uint64_t kXofLength = 4096; // the reference PRNG's buffer (randomgen.h: buffer_size_)
-
-        __global__ void __launch_bounds__(kBlock) blake2xb_uniform_kernel(
-            const ModDesc *mods, const XofJob *jobs, unsigned *reject, unsigned n_log, unsigned K)
+        // h <- the 64 bytes (8 words) number `piece` of the PRNG stream of `seed`: buffer = piece / 64 is the PRNG's counter,
+        // node = piece % 64 the position inside the 4096-byte buffer
+        __device__ __forceinline__ void stream_piece(const uint64_t *seed, uint64_t piece, uint64_t (&h)[8])
         {
-            const size_t words = (size_t)K << n_log;
-            const size_t piece = blockIdx.x * (size_t)kBlock + threadIdx.x; // 64 bytes of the stream = 8 words
-            if (piece >= words / 8)
-                return;
-            const XofJob &job = jobs[blockIdx.y];
-            const uint64_t buffer = piece >> 6; // the PRNG's counter for this 4096-byte buffer
+            const uint64_t buffer = piece >> 6;
             const uint64_t node = piece & 63;
-
             // root hash h0 = BLAKE2b-512(key = seed, message = counter), parameter block: digest 64, key 64, fanout 1, depth 1,
             // xof_length 4096.  Keyed: the key padded to one block is the first message block.
-            uint64_t h[8], m[16];
+            uint64_t m[16];
 #pragma unroll
             for (int i = 0; i < 8; i++)
                 h[i] = b2_iv(i);
@@ -93,7 +88,7 @@ namespace sealhip
 #pragma unroll
             for (int i = 0; i < 8; i++)
             {
-                m[i] = job.seed[i];
+                m[i] = seed[i];
                 m[i + 8] = 0;
             }
             b2_compress(h, m, 128, false);
@@ -115,6 +110,18 @@ namespace sealhip
             h[1] ^= node | (kXofLength << 32);
             h[2] ^= 64ull << 8;
             b2_compress(h, m, 64, true);
+        }
+
+        __global__ void __launch_bounds__(kBlock) blake2xb_uniform_kernel(
+            const ModDesc *mods, const XofJob *jobs, unsigned *reject, unsigned n_log, unsigned K)
+        {
+            const size_t words = (size_t)K << n_log;
+            const size_t piece = blockIdx.x * (size_t)kBlock + threadIdx.x; // 64 bytes of the stream = 8 words
+            if (piece >= words / 8)
+                return;
+            const XofJob &job = jobs[blockIdx.y];
+            uint64_t h[8];
+            stream_piece(job.seed, piece, h);
 
             // sample_poly_uniform's acceptance test and reduction; 8 consecutive words lie in one RNS component
             const size_t w0 = piece * 8;
@@ -134,6 +141,44 @@ namespace sealhip
                 atomicOr(reject + blockIdx.y * (words / 32) + w0 / 32, rejected << (w0 % 32));
         }
 
+        // the raw stream: pieces first_piece .. first_piece + pieces - 1 -> out[8 * pieces]
+        __global__ void __launch_bounds__(kBlock) blake2xb_stream_kernel(XofSeed seed, uint64_t first_piece, size_t pieces, uint64_t *out)
+        {
+            const size_t p = blockIdx.x * (size_t)kBlock + threadIdx.x;
+            if (p >= pieces)
+                return;
+            uint64_t h[8];
+            stream_piece(seed.w, first_piece + p, h);
+#pragma unroll
+            for (int t = 0; t < 8; t++)
+                out[p * 8 + t] = h[t];
+        }
+
+        // The Encryptor's small samplers over a stream already in HBM (util/rlwe.cpp:24-43, 120-150; serial.h for the ternary draw):
+        // thread k < n_ternary: coefficient k of a ternary polynomial from the 4 bytes at 4 k; the others: coefficient of a
+        // centred-binomial polynomial from the 6 bytes at cbd_offset + 6 (k - n_ternary).  A ternary draw the reference would
+        // redraw (g * 3 mod 2^32 == 0: probability 2^-32) shifts the rest of the stream: it raises *redraw and the caller
+        // repeats the sampling on the host.
+        __global__ void __launch_bounds__(kBlock) small_from_stream_kernel(
+            const uint8_t *stream, size_t n_ternary, size_t cbd_offset, size_t n_cbd, int8_t *small, unsigned *redraw)
+        {
+            const size_t k = blockIdx.x * (size_t)kBlock + threadIdx.x;
+            if (k < n_ternary)
+            {
+                const uint8_t *b = stream + 4 * k;
+                const uint32_t g = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+                const uint64_t product = (uint64_t)g * 3u;
+                if ((uint32_t)product < 1u)
+                    atomicOr(redraw, 1u);
+                small[k] = (int8_t)((int)(product >> 32) - 1);
+            }
+            else if (k < n_ternary + n_cbd)
+            {
+                const uint8_t *b = stream + cbd_offset + 6 * (k - n_ternary);
+                small[k] = (int8_t)(__popc(b[0]) + __popc(b[1]) + __popc(b[2] & 0x1Fu) - __popc(b[3]) - __popc(b[4]) - __popc(b[5] & 0x1Fu));
+            }
+        }
+
         __global__ void __launch_bounds__(kBlock) apply_patches_kernel(const XofPatch *patches, size_t count)
         {
             const size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x;
@@ -150,6 +195,24 @@ namespace sealhip
             return hipSuccess;
         hipLaunchKernelGGL(blake2xb_uniform_kernel, dim3((unsigned)((pieces + kBlock - 1) / kBlock), njobs), dim3(kBlock), 0, s, mods, jobs,
                            reject, n_log, K);
+        return hipGetLastError();
+    }
+    hipError_t k_blake2xb_stream(const XofSeed &seed, uint64_t first_piece, size_t pieces, uint64_t *out, hipStream_t s)
+    {
+        if (!pieces)
+            return hipSuccess;
+        hipLaunchKernelGGL(blake2xb_stream_kernel, dim3((unsigned)((pieces + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, seed, first_piece,
+                           pieces, out);
+        return hipGetLastError();
+    }
+    hipError_t k_small_from_stream(const uint8_t *stream, size_t n_ternary, size_t cbd_offset, size_t n_cbd, int8_t *small, unsigned *redraw,
+                                   hipStream_t s)
+    {
+        const size_t work = n_ternary + n_cbd;
+        if (!work)
+            return hipSuccess;
+        hipLaunchKernelGGL(small_from_stream_kernel, dim3((unsigned)((work + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, stream, n_ternary,
+                           cbd_offset, n_cbd, small, redraw);
         return hipGetLastError();
     }
     hipError_t k_apply_patches(const XofPatch *patches, size_t count, hipStream_t s)

@@ -58,6 +58,10 @@ static inline unsigned atomicOr(unsigned *p, unsigned v)
     *p = old | v;
     return old;
 }
+static inline int __popc(unsigned x)
+{
+    return __builtin_popcount(x);
+}
 static inline long long __double_as_longlong(double d)
 {
     long long r;

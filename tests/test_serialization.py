@@ -135,6 +135,16 @@ def test_encrypt_symmetric(emu, scheme, n, bits):
 
 
 @needs_ref
+def test_encrypt_with_host_sampling(emu, monkeypatch):
+    """u, e are normally drawn on the device from the bootstrap stream; the host branch (taken when a ternary draw is redrawn) must
+    produce the same bytes."""
+    import decrypt_cases as DC
+    monkeypatch.setenv("SEALHIP_ENCRYPT_HOST_SAMPLING", "1")
+    DC.case_encrypt_symmetric("ckks", 1024, [40, 30, 30, 40])
+    DC.case_encrypt_asymmetric("bgv", 2048, [40, 40, 45])
+
+
+@needs_ref
 @pytest.mark.parametrize("scheme,n,bits", [("bfv", 1024, [36, 36, 37]), ("bgv", 2048, [40, 40, 45]), ("bfv", 8192, [50, 55, 56])])
 def test_batch_encoder(emu, scheme, n, bits):
     import decrypt_cases as DC
