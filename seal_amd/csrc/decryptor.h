@@ -104,7 +104,8 @@ namespace sealhip
     // seal::Encryptor, the secret-key half (native/src/seal/encryptor.h: encrypt_symmetric / encrypt_zero_symmetric and their
     // Serializable<> forms; encryptor.cpp:116-330, util/rlwe.cpp:270-395).  The randomness is the reference's: a bootstrap
     // Blake2xb PRNG yields the public seed of c_1 = a (expanded by sample_poly_uniform) and the centred-binomial noise e
-    // (sample_poly_cbd); both are sampled on the host and c_0 = -(a s + e) [+ the plaintext] is computed on the device.
+    // (sample_poly_cbd); both are sampled on the device from the reference's byte streams (xof_kernels.h; the host keeps the
+    // same samplers, serial.h, for the cases the kernels leave out) and c_0 = -(a s + e) [+ the plaintext] is computed there too.
     // Public-key encryption (encrypt / encrypt_zero; util::encrypt_zero_asymmetric, rlwe.cpp:196-268) follows the same pattern with
     // u <- ternary (serial.h: sample_poly_ternary, tied to libstdc++'s uniform_int_distribution), c_j = pk_j u + e_j at the level
     // above and one modulus switch down (encryptor.cpp:139-186).
