@@ -350,6 +350,24 @@ SHL_FUNC shl_rns_stage(void *context, uint64_t chain_index, int which, const uin
 SHL_FUNC shl_malloc(uint64_t bytes, void **device_ptr);
 SHL_FUNC shl_free(void *device_ptr);
 SHL_FUNC shl_memcpy_h2d(void *device_dst, const void *host_src, uint64_t bytes);
+/* KeyGenerator (native/src/seal/c/keygenerator.h:16-36; seal::KeyGenerator, native/src/seal/keygenerator.cpp): secret key, public
+ * key, RelinKeys and GaloisKeys generated in HBM with the reference's algorithm and randomness (device samplers over the
+ * reference's BLAKE2Xb streams).  seed8 = 8 words for the reference's seeded factory (Blake2xbPRNGFactory(seed): reproducible,
+ * word-for-word the reference's keys) or NULL for operating-system entropy.  Differences from sealc: destinations are objects
+ * the caller created (SecretKey_Create / PublicKey_Create / KSwitchKeys_Create1) rather than returned handles; the save_seed
+ * forms are not provided (keys are produced where they are used).  KeyGenerator_KeyToHost regenerates one key in the
+ * reference's layout [digit][2][L][N] into host memory (galois_elt 0 = the relinearization key); SecretKey_Get / PublicKey_Get
+ * copy SecretKey::data() / PublicKey::data() to the host. */
+SHL_FUNC KeyGenerator_Create1(void *context, const uint64_t *seed8, void **key_generator);
+SHL_FUNC KeyGenerator_Create2(void *context, void *secret_key, const uint64_t *seed8, void **key_generator);
+SHL_FUNC KeyGenerator_Destroy(void *thisptr);
+SHL_FUNC KeyGenerator_SecretKey(void *thisptr, void *secret_key);
+SHL_FUNC KeyGenerator_CreatePublicKey(void *thisptr, void *public_key);
+SHL_FUNC KeyGenerator_CreateRelinKeys(void *thisptr, void *relin_keys);
+SHL_FUNC KeyGenerator_CreateGaloisKeysFromElts(void *thisptr, uint64_t count, const uint32_t *galois_elts, void *galois_keys);
+SHL_FUNC KeyGenerator_KeyToHost(void *thisptr, uint32_t galois_elt, uint64_t *host_words, uint64_t capacity_words);
+SHL_FUNC SecretKey_Get(void *thisptr, uint64_t *host_words);
+SHL_FUNC PublicKey_Get(void *thisptr, uint64_t *host_words);
 SHL_FUNC shl_memcpy_d2h(void *host_dst, const void *device_src, uint64_t bytes);
 SHL_FUNC shl_device_synchronize(void);
 /* HIP-event timing on the library's stream (bench.py measures kernels where they are launched) */

@@ -457,6 +457,11 @@ class SecretKey:
         a = np.ascontiguousarray(words, dtype=np.uint64)
         N.check(N.lib().SecretKey_Set(self._h, _p(a), C.c_uint64(a.size)))
 
+    def words(self, L, n):
+        out = np.empty((L, n), dtype=np.uint64)
+        N.check(N.lib().SecretKey_Get(self._h, _p(out)))
+        return out
+
     def load_bytes(self, data, unsafe=False):
         data = bytes(data)
         n = C.c_int64()
@@ -557,12 +562,63 @@ class PublicKey:
             N.lib().PublicKey_Destroy(self._h)
             self._h = None
 
+    def words(self, L, n):
+        out = np.empty((2, L, n), dtype=np.uint64)
+        N.check(N.lib().PublicKey_Get(self._h, _p(out)))
+        return out
+
     def load_bytes(self, data, unsafe=False):
         data = bytes(data)
         n = C.c_int64()
         fn = N.lib().PublicKey_UnsafeLoad if unsafe else N.lib().PublicKey_Load
         N.check(fn(self._h, self.context._h, C.cast(C.c_char_p(data), C.c_void_p), C.c_uint64(len(data)), C.byref(n)))
         return n.value
+
+
+class KeyGenerator:
+    """seal::KeyGenerator on the device (sealhip.h): seed = 8 words for the reference's seeded factory, None = OS entropy"""
+
+    def __init__(self, context, secret_key=None, seed=None):
+        self.context = context
+        self._h = C.c_void_p()
+        self._seed = None if seed is None else np.ascontiguousarray(seed, dtype=np.uint64)
+        sp = None if self._seed is None else _p(self._seed)
+        if secret_key is None:
+            N.check(N.lib().KeyGenerator_Create1(context._h, sp, C.byref(self._h)))
+        else:
+            N.check(N.lib().KeyGenerator_Create2(context._h, secret_key._h, sp, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().KeyGenerator_Destroy(self._h)
+            self._h = None
+
+    def secret_key(self):
+        sk = SecretKey(self.context)
+        N.check(N.lib().KeyGenerator_SecretKey(self._h, sk._h))
+        return sk
+
+    def create_public_key(self):
+        pk = PublicKey(self.context)
+        N.check(N.lib().KeyGenerator_CreatePublicKey(self._h, pk._h))
+        return pk
+
+    def create_relin_keys(self):
+        rlk = RelinKeys(self.context)
+        N.check(N.lib().KeyGenerator_CreateRelinKeys(self._h, rlk._h))
+        return rlk
+
+    def create_galois_keys(self, galois_elts):
+        glk = GaloisKeys(self.context)
+        e = np.ascontiguousarray(galois_elts, dtype=np.uint32)
+        N.check(N.lib().KeyGenerator_CreateGaloisKeysFromElts(self._h, C.c_uint64(e.size), e.ctypes.data_as(C.c_void_p), glk._h))
+        return glk
+
+    def key_words(self, galois_elt, digits, L, n):
+        """one key as the reference lays it out: [digits][2][L][N] (galois_elt 0 = the relinearization key)"""
+        out = np.empty((digits, 2, L, n), dtype=np.uint64)
+        N.check(N.lib().KeyGenerator_KeyToHost(self._h, C.c_uint32(galois_elt), _p(out), C.c_uint64(out.size)))
+        return out
 
 
 class BatchEncoder:

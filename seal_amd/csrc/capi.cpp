@@ -6,6 +6,7 @@
 #include "evaluator.h"
 #include "ckks_encoder.h"
 #include "decryptor.h"
+#include "keygen.h"
 #include "serial.h"
 #include "xof.h"
 #include <cstring>
@@ -804,6 +805,94 @@ extern "C"
         IfNullRet(thisptr, SHL_E_POINTER);
         delete as<SecretKey>(thisptr);
         return SHL_S_OK;
+    }
+    // ---- KeyGenerator (native/src/seal/c/keygenerator.h; keygen.h)
+    SHL_FUNC KeyGenerator_Create1(void *context, const uint64_t *seed8, void **key_generator)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(key_generator, SHL_E_POINTER);
+        SHL_TRY
+        *key_generator = new KeyGenerator(*as<Context>(context), seed8);
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_Create2(void *context, void *secret_key, const uint64_t *seed8, void **key_generator)
+    {
+        IfNullRet(context, SHL_E_POINTER);
+        IfNullRet(secret_key, SHL_E_POINTER);
+        IfNullRet(key_generator, SHL_E_POINTER);
+        SHL_TRY
+        *key_generator = new KeyGenerator(*as<Context>(context), *as<SecretKey>(secret_key), seed8);
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_Destroy(void *thisptr)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        delete as<KeyGenerator>(thisptr);
+        return SHL_S_OK;
+    }
+    SHL_FUNC KeyGenerator_SecretKey(void *thisptr, void *secret_key)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(secret_key, SHL_E_POINTER);
+        SHL_TRY
+        auto kg = as<KeyGenerator>(thisptr);
+        auto dst = as<SecretKey>(secret_key);
+        if (&dst->context() != &kg->secret_key().context())
+            throw std::invalid_argument("secret key belongs to another context");
+        const Context &c = dst->context();
+        hip_ok(hipMemcpy(dst->allocate(), kg->secret_key().data(), c.key_level().K * c.n() * 8, hipMemcpyDeviceToDevice), "copy secret key");
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_CreatePublicKey(void *thisptr, void *public_key)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(public_key, SHL_E_POINTER);
+        SHL_TRY
+        as<KeyGenerator>(thisptr)->create_public_key(*as<PublicKey>(public_key));
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_CreateRelinKeys(void *thisptr, void *relin_keys)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(relin_keys, SHL_E_POINTER);
+        SHL_TRY
+        as<KeyGenerator>(thisptr)->create_relin_keys(*as<KSwitchKeys>(relin_keys));
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_CreateGaloisKeysFromElts(void *thisptr, uint64_t count, const uint32_t *galois_elts, void *galois_keys)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(galois_keys, SHL_E_POINTER);
+        SHL_TRY
+        as<KeyGenerator>(thisptr)->create_galois_keys(galois_elts, (size_t)count, *as<KSwitchKeys>(galois_keys));
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_KeyToHost(void *thisptr, uint32_t galois_elt, uint64_t *host_words, uint64_t capacity_words)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(host_words, SHL_E_POINTER);
+        SHL_TRY
+        auto kg = as<KeyGenerator>(thisptr);
+        if (capacity_words < kg->key_words())
+            throw std::invalid_argument("capacity");
+        kg->key_to_host(galois_elt, host_words);
+        SHL_CATCH
+    }
+    SHL_FUNC SecretKey_Get(void *thisptr, uint64_t *host_words)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(host_words, SHL_E_POINTER);
+        SHL_TRY
+        as<SecretKey>(thisptr)->get(host_words);
+        SHL_CATCH
+    }
+    SHL_FUNC PublicKey_Get(void *thisptr, uint64_t *host_words)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(host_words, SHL_E_POINTER);
+        SHL_TRY
+        as<PublicKey>(thisptr)->get(host_words);
+        SHL_CATCH
     }
     SHL_FUNC SecretKey_Set(void *thisptr, const uint64_t *host_words, uint64_t word_count)
     {

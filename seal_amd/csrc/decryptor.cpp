@@ -32,6 +32,30 @@ namespace sealhip
         if (dev_)
             (void)hipFree(dev_);
     }
+    uint64_t *SecretKey::allocate()
+    {
+        if (!dev_)
+            ck(hipMalloc(reinterpret_cast<void **>(&dev_), ctx_->key_level().K * ctx_->n() * 8), "hipMalloc secret key");
+        return dev_;
+    }
+    void SecretKey::get(uint64_t *host_words) const
+    {
+        if (!dev_ || !host_words)
+            throw std::invalid_argument("secret key is not set");
+        ck(hipMemcpy(host_words, dev_, ctx_->key_level().K * ctx_->n() * 8, hipMemcpyDeviceToHost), "download secret key");
+    }
+    uint64_t *PublicKey::allocate()
+    {
+        if (!dev_)
+            ck(hipMalloc(reinterpret_cast<void **>(&dev_), 2 * ctx_->key_level().K * ctx_->n() * 8), "hipMalloc public key");
+        return dev_;
+    }
+    void PublicKey::get(uint64_t *host_words) const
+    {
+        if (!dev_ || !host_words)
+            throw std::invalid_argument("public key is not set");
+        ck(hipMemcpy(host_words, dev_, 2 * ctx_->key_level().K * ctx_->n() * 8, hipMemcpyDeviceToHost), "download public key");
+    }
     void SecretKey::set(const void *host_words, size_t word_count)
     {
         const size_t want = ctx_->key_level().K * ctx_->n();
@@ -571,7 +595,7 @@ namespace sealhip
     }
 
     // util::encrypt_zero_symmetric (util/rlwe.cpp:270-395)
-    void Encryptor::zero(const Level &lvl, bool save_seed, Ciphertext &d, uint64_t *public_seed, bool host_sampling)
+    void Encryptor::zero(const Level &lvl, bool save_seed, Ciphertext &d, uint64_t *public_seed, bool host_sampling, bool key_form)
     {
         if (!sk_)
             throw std::logic_error("secret key is not set");
@@ -582,7 +606,7 @@ namespace sealhip
         const size_t n = context_.n(), K = lvl.K, words = K * n;
         const unsigned n_log = (unsigned)context_.log_n();
         const Scheme scheme = context_.scheme();
-        const bool ntt_form = scheme != Scheme::bfv;
+        const bool ntt_form = key_form || scheme != Scheme::bfv;
         // a polynomial too small to hold the seed is saved in full (rlwe.cpp:298-306): 16 + 1 + 64 bytes -> 11 words, plus a marker
         if (save_seed && words < 12)
             save_seed = false;

@@ -23,6 +23,8 @@ namespace sealhip
         // words = SecretKey::data().data(): L*N residues, host memory (unaligned pointers into a stream are fine)
         void set(const void *host_words, size_t word_count);
         const uint64_t *data() const { return dev_; }
+        uint64_t *allocate(); // the [L][N] device words, for a producer on the device (keygen.h)
+        void get(uint64_t *host_words) const; // SecretKey::data() copied to the host
 
     private:
         const Context *ctx_;
@@ -41,6 +43,8 @@ namespace sealhip
         void set(const void *host_words, size_t word_count); // 2*L*N words: PublicKey::data().data()
         void set_parts(const void *stored, size_t stored_words, const uint64_t *expanded, size_t expanded_words);
         const uint64_t *data() const { return dev_; }
+        uint64_t *allocate(); // the [2][L][N] device words, for a producer on the device (keygen.h)
+        void get(uint64_t *host_words) const;
 
     private:
         const Context *ctx_;
@@ -136,9 +140,12 @@ namespace sealhip
         size_t encrypt_symmetric_save(const Plaintext &plain, uint8_t *out, size_t capacity);
 
     private:
+        friend class KeyGenerator; // keys are encryptions of zero under s (keygenerator.cpp:93-121, 322-357)
         const Level *level_for(const uint64_t *parms_id) const;
         const Level *level_for(const Plaintext &plain) const; // + the checks of Encryptor::encrypt_internal
-        void zero(const Level &lvl, bool save_seed, Ciphertext &destination, uint64_t *public_seed, bool host_sampling = false);
+        // key_form: NTT form whatever the scheme - how KeyGenerator calls encrypt_zero_symmetric (is_ntt_form = true)
+        void zero(const Level &lvl, bool save_seed, Ciphertext &destination, uint64_t *public_seed, bool host_sampling = false,
+                  bool key_form = false);
         void zero_asymmetric(const Level &lvl, Ciphertext &destination);
         void zero_asymmetric_at(const Level &lvl, Ciphertext &destination, bool host_sampling = false); // util::encrypt_zero_asymmetric
         void bootstrap_seed(uint64_t *seed8) const;

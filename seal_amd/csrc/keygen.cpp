@@ -1,0 +1,210 @@
+#include "keygen.h"
+#include "hostmath.h"
+#include "poly_kernels.h"
+#include "pool.h"
+#include "xof.h"
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+
+namespace sealhip
+{
+    namespace
+    {
+        void ck(hipError_t e, const char *what)
+        {
+            if (e != hipSuccess)
+                throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+        }
+        NttBatch polys(uint64_t *data, size_t K, size_t n, size_t count)
+        {
+            NttBatch b{};
+            b.data = data;
+            b.outer_stride = K * n;
+            b.ncomp = (unsigned)K;
+            b.nouter = (unsigned)count;
+            b.prime_first = 0;
+            return b;
+        }
+    } // namespace
+
+    KeyGenerator::KeyGenerator(const Context &context, const uint64_t *seed8) : context_(context), sk_(context)
+    {
+        if (seed8)
+        {
+            std::memcpy(seed_, seed8, sizeof(seed_));
+            seeded_ = true;
+        }
+        sample_secret_key();
+        configure(seed8);
+    }
+    KeyGenerator::KeyGenerator(const Context &context, const SecretKey &secret_key, const uint64_t *seed8) : context_(context), sk_(context)
+    {
+        if (&secret_key.context() != &context || !secret_key.data())
+            throw std::invalid_argument("secret key is not valid for encryption parameters"); // keygenerator.cpp:46-49
+        if (seed8)
+        {
+            std::memcpy(seed_, seed8, sizeof(seed_));
+            seeded_ = true;
+        }
+        const size_t words = context.key_level().K * context.n();
+        ck(hipMemcpy(sk_.allocate(), secret_key.data(), words * 8, hipMemcpyDeviceToDevice), "copy secret key");
+        configure(seed8);
+    }
+    void KeyGenerator::configure(const uint64_t *seed8)
+    {
+        encryptor_ = std::make_unique<Encryptor>(context_, sk_);
+        if (seed8)
+            encryptor_->set_seed(seed8);
+    }
+
+    // generate_sk (keygenerator.cpp:56-91): s <- R_3 from a fresh PRNG of the factory, replicated into the L key primes, NTT
+    void KeyGenerator::sample_secret_key()
+    {
+        const size_t n = context_.n(), L = context_.key_level().K;
+        const unsigned n_log = (unsigned)context_.log_n();
+        uint64_t seed[8];
+        if (seeded_)
+            std::memcpy(seed, seed_, sizeof(seed));
+        else
+            host::random_bytes(seed, sizeof(seed));
+        uint64_t *s = sk_.allocate();
+        const size_t small_words = (n + 7) / 8;
+        Scratch ds(small_words + 1), stream(n >= 16 ? n / 2 : 1);
+        int8_t *dsmall = reinterpret_cast<int8_t *>(ds.p);
+        unsigned *redraw = reinterpret_cast<unsigned *>(ds.p + small_words);
+        // the 4 n bytes of the ternary draws come off the device's BLAKE2Xb unless one of them has to be redrawn (see Encryptor)
+        bool host_sampling = n < 16 || std::getenv("SEALHIP_ENCRYPT_HOST_SAMPLING");
+        for (;;)
+        {
+            if (host_sampling)
+            {
+                serial::Prng prng(1, seed);
+                std::vector<int8_t> small(n);
+                serial::sample_small_ternary(prng, n, small.data());
+                ck(hipMemcpy(ds.p, small.data(), n, hipMemcpyHostToDevice), "upload s");
+            }
+            else
+            {
+                XofSeed xs;
+                std::memcpy(xs.w, seed, sizeof(xs.w));
+                ck(hipMemsetAsync(redraw, 0, 8, nullptr), "clear flag");
+                ck(k_blake2xb_stream(xs, 0, 4 * n / 64, stream.p, nullptr), "secret key stream");
+                ck(k_small_from_stream(reinterpret_cast<const uint8_t *>(stream.p), n, 0, 0, dsmall, redraw, nullptr), "sample s");
+            }
+            ck(k_expand_small(context_.dev_mods(), dsmall, s, n_log, (unsigned)L, 1, nullptr), "expand s");
+            unsigned flag = 0;
+            if (!host_sampling)
+                ck(hipMemcpy(&flag, redraw, sizeof(flag), hipMemcpyDeviceToHost), "read flag");
+            if (!flag)
+                break;
+            host_sampling = true;
+        }
+        ck(ntt_forward(context_.ntt_tables(), polys(s, L, n, 1), 0, nullptr), "ntt s");
+        ck(hipStreamSynchronize(nullptr), "keygen sync");
+        std::memset(seed, 0, sizeof(seed));
+    }
+
+    void KeyGenerator::create_public_key(PublicKey &destination)
+    {
+        if (&destination.context() != &context_)
+            throw std::invalid_argument("destination belongs to another context");
+        const Level &kl = context_.key_level();
+        const size_t words = kl.K * context_.n();
+        Ciphertext ct(context_, 1);
+        encryptor_->zero(kl, false, ct, nullptr, false, true);
+        uint64_t *pk = destination.allocate();
+        ck(hipMemcpy(pk, ct.plane(0), words * 8, hipMemcpyDeviceToDevice), "copy c0");
+        ck(hipMemcpy(pk + words, ct.plane(1), words * 8, hipMemcpyDeviceToDevice), "copy c1");
+    }
+
+    size_t KeyGenerator::key_words() const
+    {
+        return context_.first_level().K * 2 * context_.key_level().K * context_.n();
+    }
+
+    void KeyGenerator::one_kswitch_key(const uint64_t *new_key, uint64_t *out)
+    {
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context"); // keygenerator.cpp:324-327
+        const Level &kl = context_.key_level();
+        const size_t n = context_.n(), L = kl.K, digits = context_.first_level().K, words = L * n;
+        const unsigned n_log = (unsigned)context_.log_n();
+        const ModDesc *mods = context_.dev_mods();
+        const uint64_t special = context_.coeff_modulus()[L - 1];
+        Ciphertext ct(context_, 1);
+        Scratch temp(n);
+        const PlaneGeom one{ n_log, 1, 1 };
+        for (size_t j = 0; j < digits; j++)
+        {
+            // digit j = an encryption of zero under s with (special prime mod q_j) * new_key added into component j of c_0
+            encryptor_->zero(kl, false, ct, nullptr, false, true);
+            uint64_t *dj = out + j * 2 * words;
+            ck(hipMemcpyAsync(dj, ct.plane(0), words * 8, hipMemcpyDeviceToDevice, nullptr), "copy c0");
+            ck(hipMemcpyAsync(dj + words, ct.plane(1), words * 8, hipMemcpyDeviceToDevice, nullptr), "copy c1");
+            const uint64_t factor = special % context_.coeff_modulus()[j];
+            ck(k_mul_scalar(mods + j, new_key + j * n, temp.p, factor, one, 1, nullptr), "factor * key");
+            ck(k_addsub(mods + j, dj + j * n, temp.p, dj + j * n, 0, one, 1, nullptr), "c0 + factor * key");
+            ck(hipStreamSynchronize(nullptr), "keygen sync");
+        }
+    }
+    void KeyGenerator::relin_key(uint64_t *out)
+    {
+        // compute_secret_key_array (keygenerator.cpp:220-290): s^2 = s .* s in NTT form
+        const size_t n = context_.n(), L = context_.key_level().K;
+        Scratch s2(L * n);
+        ck(k_dyadic(context_.dev_mods(), sk_.data(), sk_.data(), s2.p, (unsigned)context_.log_n(), (unsigned)L, 0, 1, nullptr), "s^2");
+        one_kswitch_key(s2.p, out);
+        ck(hipMemsetAsync(s2.p, 0, L * n * 8, nullptr), "clear s^2");
+        ck(hipStreamSynchronize(nullptr), "keygen sync");
+    }
+    void KeyGenerator::galois_key(uint32_t galois_elt, uint64_t *out)
+    {
+        const size_t n = context_.n(), L = context_.key_level().K;
+        if (!(galois_elt & 1) || galois_elt >= 2 * n)
+            throw std::invalid_argument("Galois element is not valid"); // keygenerator.cpp:186-189
+        Scratch rotated(L * n);
+        const PlaneGeom g{ (unsigned)context_.log_n(), (unsigned)L, 1 };
+        ck(k_apply_galois(context_.dev_mods(), sk_.data(), rotated.p, galois_elt, 1, g, 1, nullptr), "rotate s");
+        one_kswitch_key(rotated.p, out);
+        ck(hipMemsetAsync(rotated.p, 0, L * n * 8, nullptr), "clear rotated s");
+        ck(hipStreamSynchronize(nullptr), "keygen sync");
+    }
+
+    void KeyGenerator::create_relin_keys(KSwitchKeys &destination)
+    {
+        Scratch key(key_words());
+        relin_key(key.p);
+        destination.set_key(context_, 0, context_.first_level().K, key.p, true); // RelinKeys::get_index(2) = 0
+        ck(hipDeviceSynchronize(), "keygen sync");
+    }
+    void KeyGenerator::create_galois_keys(const uint32_t *galois_elts, size_t count, KSwitchKeys &destination)
+    {
+        if (count && !galois_elts)
+            throw std::invalid_argument("galois_elts");
+        Scratch key(key_words());
+        for (size_t i = 0; i < count; i++)
+        {
+            const uint32_t elt = galois_elts[i];
+            if (!(elt & 1) || elt >= 2 * context_.n())
+                throw std::invalid_argument("Galois element is not valid");
+            const size_t index = (elt - 1) >> 1; // GaloisKeys::get_index (galoiskeys.h:48)
+            if (destination.has_key(index))
+                continue;
+            galois_key(elt, key.p);
+            destination.set_key(context_, index, context_.first_level().K, key.p, true);
+            ck(hipDeviceSynchronize(), "keygen sync");
+        }
+    }
+    void KeyGenerator::key_to_host(uint32_t galois_elt, uint64_t *host_words)
+    {
+        if (!host_words)
+            throw std::invalid_argument("host_words");
+        Scratch key(key_words());
+        if (galois_elt)
+            galois_key(galois_elt, key.p);
+        else
+            relin_key(key.p);
+        ck(hipMemcpy(host_words, key.p, key_words() * 8, hipMemcpyDeviceToHost), "download key");
+    }
+} // namespace sealhip

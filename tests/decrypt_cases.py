@@ -379,3 +379,65 @@ def case_ckks_encoder(n, bits, check_bits=True):
         d.ev.rescale_to_next_inplace(ca)
     got = enc.decode(dec.decrypt(ca))
     assert np.max(np.abs(got - a * b)) < 1e-2, np.max(np.abs(got - a * b))
+
+
+def case_keygen(scheme, n, bits, seed=0x5EA1, elts=(3, 5)):
+    """KeyGenerator on the device with the reference's seeded factory: the secret key, the public key, the relinearization key
+    and Galois keys equal the reference KeyGenerator's word for word; keys installed by create_* act like the reference's
+    (relinearize / apply_galois give the same ciphertext words); a generator built around an existing secret key continues
+    from it; with operating-system entropy the keys differ per generator and still decrypt correctly."""
+    primes = coeff_modulus_create(n, bits)
+    t = plain_modulus_batching(n, 20) if scheme != "ckks" else 0
+    ref = sealref.RefContext(scheme, n, primes, t, seed=seed)
+    d = DeviceSide(scheme, n, primes, t)
+    L, digits = len(primes), len(primes) - 1
+    seed8 = np.array([seed, 0, 0, 0, 0, 0, 0, 0], dtype=np.uint64)
+    kg = S.KeyGenerator(d.ctx, seed=seed8)
+    assert np.array_equal(kg.secret_key().words(L, n), ref.secret_key()), "secret key"
+    assert np.array_equal(kg.create_public_key().words(L, n), ref.public_key()), "public key"
+    ref.keygen_relin()
+    assert np.array_equal(kg.key_words(0, digits, L, n), ref.key("relin", 0)), "relin key"
+    elts = [e for e in elts if e < 2 * n]
+    elts.append(2 * n - 1)
+    ref.keygen_galois_elts(elts)
+    for e in elts:
+        assert np.array_equal(kg.key_words(e, digits, L, n), ref.key("galois", (e - 1) >> 1)), ("galois key", e)
+    # a generator around the existing secret key produces the same keys
+    kg2 = S.KeyGenerator(d.ctx, secret_key=S.SecretKey(d.ctx, ref.secret_key()), seed=seed8)
+    assert np.array_equal(kg2.key_words(0, digits, L, n), ref.key("relin", 0)), "relin key (existing secret key)"
+    # installed keys in use: the same operations with reference-generated keys uploaded as words
+    rlk, glk = kg.create_relin_keys(), kg.create_galois_keys(elts)
+    rlk_ref, glk_ref = S.RelinKeys(d.ctx), S.GaloisKeys(d.ctx)
+    rlk_ref.set_key(0, ref.key("relin", 0))
+    for e in elts:
+        assert glk.has_key(e)
+        glk_ref.set_key((e - 1) >> 1, ref.key("galois", (e - 1) >> 1))
+    enc = S.Encryptor(d.ctx, secret_key=kg.secret_key(), seed=seed8)
+    a = enc.encrypt_zero_symmetric(d.ctx.first_parms_id())
+    b = enc.encrypt_zero_symmetric(d.ctx.first_parms_id())
+    if scheme == "ckks":
+        a.scale = b.scale = 2.0 ** 20
+    prod = a.copy()
+    d.ev.multiply_inplace(prod, b)
+    r1, r2 = prod.copy(), prod.copy()
+    d.ev.relinearize_inplace(r1, rlk)
+    d.ev.relinearize_inplace(r2, rlk_ref)
+    assert np.array_equal(r1.to_numpy(), r2.to_numpy()), "relinearize"
+    for e in elts:
+        r1, r2 = a.copy(), a.copy()
+        d.ev.apply_galois_inplace(r1, e, glk)
+        d.ev.apply_galois_inplace(r2, e, glk_ref)
+        assert np.array_equal(r1.to_numpy(), r2.to_numpy()), ("apply_galois", e)
+    # operating-system entropy: fresh keys each time, and a working set
+    k1, k2 = S.KeyGenerator(d.ctx), S.KeyGenerator(d.ctx)
+    assert not np.array_equal(k1.secret_key().words(L, n), k2.secret_key().words(L, n))
+    if scheme != "ckks":
+        be = S.BatchEncoder(d.ctx)
+        vals = np.random.default_rng(5).integers(0, t, n, dtype=np.uint64)
+        e1 = S.Encryptor(d.ctx, public_key=k1.create_public_key())
+        ct = e1.encrypt(be.encode(vals))
+        sq = ct.copy()
+        d.ev.multiply_inplace(sq, ct)
+        d.ev.relinearize_inplace(sq, k1.create_relin_keys())
+        got = be.decode(S.Decryptor(d.ctx, k1.secret_key()).decrypt(sq))
+        assert np.array_equal(np.asarray(got, dtype=np.uint64), vals * vals % np.uint64(t)), "fresh keys: square"

@@ -107,3 +107,10 @@ def test_example_ckks_basics(gpu):
 def test_example_batching_rotation(gpu):
     import example_cases as EC
     EC.example_batching_rotation()
+
+
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 8192, [60, 40, 40, 60]), ("bfv", 16384, [50, 50, 50, 58]), ("bgv", 4096, [36, 36, 37]),
+                                           ("ckks", 65536, [60] + [50] * 14 + [60])])
+def test_keygen(gpu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_keygen(scheme, n, bits, elts=(3,) if n == 65536 else (3, 5))

@@ -135,6 +135,13 @@ def test_encrypt_symmetric(emu, scheme, n, bits):
 
 
 @needs_ref
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 2048, [36, 36, 37]), ("bgv", 4096, [50, 50, 58])])
+def test_keygen(emu, scheme, n, bits):
+    import decrypt_cases as DC
+    DC.case_keygen(scheme, n, bits)
+
+
+@needs_ref
 def test_encrypt_with_host_sampling(emu, monkeypatch):
     """u, e are normally drawn on the device from the bootstrap stream; the host branch (taken when a ternary draw is redrawn) must
     produce the same bytes."""
