@@ -365,6 +365,8 @@ SHL_FUNC KeyGenerator_SecretKey(void *thisptr, void *secret_key);
 SHL_FUNC KeyGenerator_CreatePublicKey(void *thisptr, void *public_key);
 SHL_FUNC KeyGenerator_CreateRelinKeys(void *thisptr, void *relin_keys);
 SHL_FUNC KeyGenerator_CreateGaloisKeysFromElts(void *thisptr, uint64_t count, const uint32_t *galois_elts, void *galois_keys);
+SHL_FUNC KeyGenerator_CreateGaloisKeysFromSteps(void *thisptr, uint64_t count, const int *steps, void *galois_keys);
+SHL_FUNC KeyGenerator_CreateGaloisKeysAll(void *thisptr, void *galois_keys);
 SHL_FUNC KeyGenerator_KeyToHost(void *thisptr, uint32_t galois_elt, uint64_t *host_words, uint64_t capacity_words);
 SHL_FUNC SecretKey_Get(void *thisptr, uint64_t *host_words);
 SHL_FUNC PublicKey_Get(void *thisptr, uint64_t *host_words);

@@ -810,6 +810,18 @@ extern "C"
         }
         REF_CATCH
     }
+    // GaloisTool::get_elts_all of the key level
+    int ref_galois_elts_all(void *ctx, uint32_t *out, uint64_t cap, uint64_t *count)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto v = c->context->key_context_data()->galois_tool()->get_elts_all();
+        if (v.size() > cap)
+            return 1;
+        std::copy(v.begin(), v.end(), out);
+        *count = v.size();
+        REF_CATCH
+    }
     // Plaintext::save / load / unsafe_load
     int ref_pt_save_mode(void *pt, int mode, uint8_t *out, uint64_t cap, uint64_t *bytes)
     {

@@ -608,10 +608,18 @@ class KeyGenerator:
         N.check(N.lib().KeyGenerator_CreateRelinKeys(self._h, rlk._h))
         return rlk
 
-    def create_galois_keys(self, galois_elts):
+    def create_galois_keys(self, galois_elts=None, steps=None):
+        """keys for the given Galois elements, or for the given rotation steps, or (neither) for all the elements
+        GaloisTool::get_elts_all lists"""
         glk = GaloisKeys(self.context)
-        e = np.ascontiguousarray(galois_elts, dtype=np.uint32)
-        N.check(N.lib().KeyGenerator_CreateGaloisKeysFromElts(self._h, C.c_uint64(e.size), e.ctypes.data_as(C.c_void_p), glk._h))
+        if galois_elts is not None:
+            e = np.ascontiguousarray(galois_elts, dtype=np.uint32)
+            N.check(N.lib().KeyGenerator_CreateGaloisKeysFromElts(self._h, C.c_uint64(e.size), e.ctypes.data_as(C.c_void_p), glk._h))
+        elif steps is not None:
+            st = np.ascontiguousarray(steps, dtype=np.int32)
+            N.check(N.lib().KeyGenerator_CreateGaloisKeysFromSteps(self._h, C.c_uint64(st.size), st.ctypes.data_as(C.c_void_p), glk._h))
+        else:
+            N.check(N.lib().KeyGenerator_CreateGaloisKeysAll(self._h, glk._h))
         return glk
 
     def key_words(self, galois_elt, digits, L, n):

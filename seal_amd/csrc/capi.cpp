@@ -867,6 +867,22 @@ extern "C"
         as<KeyGenerator>(thisptr)->create_galois_keys(galois_elts, (size_t)count, *as<KSwitchKeys>(galois_keys));
         SHL_CATCH
     }
+    SHL_FUNC KeyGenerator_CreateGaloisKeysFromSteps(void *thisptr, uint64_t count, const int *steps, void *galois_keys)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(galois_keys, SHL_E_POINTER);
+        SHL_TRY
+        as<KeyGenerator>(thisptr)->create_galois_keys_from_steps(steps, (size_t)count, *as<KSwitchKeys>(galois_keys));
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_CreateGaloisKeysAll(void *thisptr, void *galois_keys)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(galois_keys, SHL_E_POINTER);
+        SHL_TRY
+        as<KeyGenerator>(thisptr)->create_galois_keys_all(*as<KSwitchKeys>(galois_keys));
+        SHL_CATCH
+    }
     SHL_FUNC KeyGenerator_KeyToHost(void *thisptr, uint32_t galois_elt, uint64_t *host_words, uint64_t capacity_words)
     {
         IfNullRet(thisptr, SHL_E_POINTER);

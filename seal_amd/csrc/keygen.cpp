@@ -196,6 +196,43 @@ namespace sealhip
             ck(hipDeviceSynchronize(), "keygen sync");
         }
     }
+    void KeyGenerator::create_galois_keys_from_steps(const int *steps, size_t count, KSwitchKeys &destination)
+    {
+        if (!context_.using_batching())
+            throw std::logic_error("encryption parameters do not support batching"); // keygenerator.h:221-224
+        if (count && !steps)
+            throw std::invalid_argument("steps");
+        std::vector<uint32_t> elts(count);
+        for (size_t i = 0; i < count; i++)
+            elts[i] = encryptor_->evaluator_.galois_elt_from_step(steps[i]);
+        create_galois_keys(elts.data(), elts.size(), destination);
+    }
+    // GaloisTool::get_elts_all (util/galois.cpp:106-131)
+    std::vector<uint32_t> KeyGenerator::galois_elts_all() const
+    {
+        const uint64_t m = (uint64_t)context_.n() << 1;
+        std::vector<uint32_t> elts{ (uint32_t)(m - 1) };
+        uint64_t pos = 3, neg = 1;
+        // 3^-1 mod m: the unit group of Z / 2^k has exponent m / 4, so 3^(m/2) = 1 and 3^(m/2 - 1) is the inverse
+        for (uint64_t e = m / 2 - 1, b = 3; e; e >>= 1, b = (b * b) & (m - 1))
+            if (e & 1)
+                neg = (neg * b) & (m - 1);
+        for (unsigned i = 0; i + 1 < context_.log_n(); i++)
+        {
+            elts.push_back((uint32_t)pos);
+            pos = (pos * pos) & (m - 1);
+            elts.push_back((uint32_t)neg);
+            neg = (neg * neg) & (m - 1);
+        }
+        return elts;
+    }
+    void KeyGenerator::create_galois_keys_all(KSwitchKeys &destination)
+    {
+        if (!context_.using_batching())
+            throw std::logic_error("encryption parameters do not support batching");
+        const std::vector<uint32_t> elts = galois_elts_all();
+        create_galois_keys(elts.data(), elts.size(), destination);
+    }
     void KeyGenerator::key_to_host(uint32_t galois_elt, uint64_t *host_words)
     {
         if (!host_words)

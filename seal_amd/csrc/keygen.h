@@ -26,6 +26,11 @@ namespace sealhip
         void create_relin_keys(KSwitchKeys &destination);
         // create_galois_keys(galois_elts) (keygenerator.cpp:159-209): one key per element, at GaloisKeys::get_index(elt)
         void create_galois_keys(const uint32_t *galois_elts, size_t count, KSwitchKeys &destination);
+        // create_galois_keys(steps) (keygenerator.h:207-232: needs batching; GaloisTool::get_elts_from_steps) and create_galois_keys()
+        // (all the elements GaloisTool::get_elts_all lists: 3^(2^i), 3^-(2^i), 2N - 1)
+        void create_galois_keys_from_steps(const int *steps, size_t count, KSwitchKeys &destination);
+        void create_galois_keys_all(KSwitchKeys &destination);
+        std::vector<uint32_t> galois_elts_all() const;
         // one key in the reference's layout [digit][2][L][N] (KSwitchKeys::data()[index][digit].data()) copied to host memory:
         // galois_elt == 0 -> the relinearization key.  For parity tests and for saving keys; regenerates the key.
         size_t key_words() const; // words per key

@@ -428,6 +428,22 @@ def case_keygen(scheme, n, bits, seed=0x5EA1, elts=(3, 5)):
         d.ev.apply_galois_inplace(r1, e, glk)
         d.ev.apply_galois_inplace(r2, e, glk_ref)
         assert np.array_equal(r1.to_numpy(), r2.to_numpy()), ("apply_galois", e)
+    # create_galois_keys(steps) and create_galois_keys(): the elements the reference's GaloisTool derives
+    steps = [1, -2, 0]
+    by_steps = kg.create_galois_keys(steps=steps)
+    want = {ref.galois_elt_from_step(s) for s in steps}
+    assert all(by_steps.has_key(e) for e in want) and by_steps.size() == len(want), "keys from steps"
+    e1 = ref.galois_elt_from_step(1)
+    ref.keygen_galois_elts([e1])
+    glk_ref.set_key((e1 - 1) >> 1, ref.key("galois", (e1 - 1) >> 1))
+    r1, r2 = a.copy(), a.copy()
+    d.ev.apply_galois_inplace(r1, e1, by_steps)
+    d.ev.apply_galois_inplace(r2, e1, glk_ref)
+    assert np.array_equal(r1.to_numpy(), r2.to_numpy()), "rotation by one step"
+    if n <= 4096:
+        everything = kg.create_galois_keys()
+        all_elts = ref.galois_elts_all()
+        assert all(everything.has_key(e) for e in all_elts) and everything.size() == len(set(all_elts)), "all keys"
     # operating-system entropy: fresh keys each time, and a working set
     k1, k2 = S.KeyGenerator(d.ctx), S.KeyGenerator(d.ctx)
     assert not np.array_equal(k1.secret_key().words(L, n), k2.secret_key().words(L, n))

@@ -382,6 +382,12 @@ class RefContext:
         _ck(lib().ref_key_slots(self.h, C.c_int(0 if kind == "relin" else 1), C.byref(v)))
         return v.value
 
+    def galois_elts_all(self):
+        out = (C.c_uint32 * 64)()
+        n = C.c_uint64()
+        _ck(lib().ref_galois_elts_all(self.h, out, C.c_uint64(64), C.byref(n)))
+        return [int(out[i]) for i in range(n.value)]
+
     def galois_elt_from_step(self, step):
         return int(lib().ref_galois_elt_from_step(self.h, C.c_int(step)))
 
