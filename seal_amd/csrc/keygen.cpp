@@ -101,6 +101,10 @@ namespace sealhip
             host_sampling = true;
         }
         ck(ntt_forward(context_.ntt_tables(), polys(s, L, n, 1), 0, nullptr), "ntt s");
+        // the draws s was made from go back to the pool cleared (the reference's seal_memzero of its secret-key copies)
+        ck(hipMemsetAsync(ds.p, 0, (small_words + 1) * 8, nullptr), "clear s bytes");
+        if (n >= 16)
+            ck(hipMemsetAsync(stream.p, 0, n / 2 * 8, nullptr), "clear stream");
         ck(hipStreamSynchronize(nullptr), "keygen sync");
         std::memset(seed, 0, sizeof(seed));
     }
