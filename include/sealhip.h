@@ -355,7 +355,7 @@ SHL_FUNC shl_memcpy_h2d(void *device_dst, const void *host_src, uint64_t bytes);
  * reference's BLAKE2Xb streams).  seed8 = 8 words for the reference's seeded factory (Blake2xbPRNGFactory(seed): reproducible,
  * word-for-word the reference's keys) or NULL for operating-system entropy.  Differences from sealc: destinations are objects
  * the caller created (SecretKey_Create / PublicKey_Create / KSwitchKeys_Create1) rather than returned handles; the save_seed
- * forms are not provided (keys are produced where they are used).  KeyGenerator_KeyToHost regenerates one key in the
+ * forms write the stream directly (the *Save functions below).  KeyGenerator_KeyToHost regenerates one key in the
  * reference's layout [digit][2][L][N] into host memory (galois_elt 0 = the relinearization key); SecretKey_Get / PublicKey_Get
  * copy SecretKey::data() / PublicKey::data() to the host. */
 SHL_FUNC KeyGenerator_Create1(void *context, const uint64_t *seed8, void **key_generator);
@@ -367,6 +367,12 @@ SHL_FUNC KeyGenerator_CreateRelinKeys(void *thisptr, void *relin_keys);
 SHL_FUNC KeyGenerator_CreateGaloisKeysFromElts(void *thisptr, uint64_t count, const uint32_t *galois_elts, void *galois_keys);
 SHL_FUNC KeyGenerator_CreateGaloisKeysFromSteps(void *thisptr, uint64_t count, const int *steps, void *galois_keys);
 SHL_FUNC KeyGenerator_CreateGaloisKeysAll(void *thisptr, void *galois_keys);
+/* the save_seed = true forms, saved: Serializable<RelinKeys> / Serializable<GaloisKeys>::save(compr_mode none) - every digit as its seeded
+ * ciphertext (c_0 + the seed of c_1), half the bytes of the full keys; byte for byte the reference's stream under its seeded factory */
+SHL_FUNC KeyGenerator_SeededSaveSize(void *thisptr, bool galois, uint64_t key_count, int64_t *result);
+SHL_FUNC KeyGenerator_CreateRelinKeysSave(void *thisptr, uint8_t *outptr, uint64_t size, int64_t *out_bytes);
+SHL_FUNC KeyGenerator_CreateGaloisKeysFromEltsSave(void *thisptr, uint64_t count, const uint32_t *galois_elts, uint8_t *outptr, uint64_t size,
+                                                   int64_t *out_bytes);
 SHL_FUNC KeyGenerator_KeyToHost(void *thisptr, uint32_t galois_elt, uint64_t *host_words, uint64_t capacity_words);
 SHL_FUNC SecretKey_Get(void *thisptr, uint64_t *host_words);
 SHL_FUNC PublicKey_Get(void *thisptr, uint64_t *host_words);

@@ -65,7 +65,7 @@ Ciphertext_CopyToHost Ciphertext_CopyFromDevice
 Ciphertext_SaveSize Ciphertext_Save Ciphertext_UnsafeLoad Ciphertext_Load Ciphertext_LoadItem Ciphertext_SaveItem
 KSwitchKeys_UnsafeLoad KSwitchKeys_Load
 KeyGenerator_Create1 KeyGenerator_Create2 KeyGenerator_Destroy KeyGenerator_SecretKey KeyGenerator_CreatePublicKey
-KeyGenerator_CreateRelinKeys KeyGenerator_CreateGaloisKeysFromSteps KeyGenerator_CreateGaloisKeysAll KeyGenerator_CreateGaloisKeysFromElts KeyGenerator_KeyToHost SecretKey_Get PublicKey_Get
+KeyGenerator_CreateRelinKeys KeyGenerator_CreateGaloisKeysFromSteps KeyGenerator_CreateGaloisKeysAll KeyGenerator_CreateGaloisKeysFromElts KeyGenerator_KeyToHost KeyGenerator_SeededSaveSize KeyGenerator_CreateRelinKeysSave KeyGenerator_CreateGaloisKeysFromEltsSave SecretKey_Get PublicKey_Get
 SecretKey_Create SecretKey_Destroy SecretKey_Set SecretKey_UnsafeLoad SecretKey_Load Decryptor_Create Decryptor_Destroy
 Decryptor_Decrypt Decryptor_InvariantNoiseBudget Decryptor_DecryptBatchWords Decryptor_DecryptBatch
 CKKSEncoder_Create CKKSEncoder_Destroy CKKSEncoder_SlotCount CKKSEncoder_Encode1 CKKSEncoder_Encode2 CKKSEncoder_Encode3 CKKSEncoder_Encode5 CKKSEncoder_Decode1 CKKSEncoder_Decode2

@@ -622,6 +622,21 @@ class KeyGenerator:
             N.check(N.lib().KeyGenerator_CreateGaloisKeysAll(self._h, glk._h))
         return glk
 
+    def save_seeded(self, galois_elts=None):
+        """the seeded stream of fresh RelinKeys (galois_elts None) or GaloisKeys for the elements: Serializable<...>::save"""
+        galois = galois_elts is not None
+        e = np.ascontiguousarray(galois_elts if galois else [], dtype=np.uint32)
+        cap = C.c_int64()
+        N.check(N.lib().KeyGenerator_SeededSaveSize(self._h, C.c_bool(galois), C.c_uint64(len(set(e.tolist())) if galois else 1), C.byref(cap)))
+        buf = C.create_string_buffer(cap.value)
+        n = C.c_int64()
+        if galois:
+            N.check(N.lib().KeyGenerator_CreateGaloisKeysFromEltsSave(self._h, C.c_uint64(e.size), e.ctypes.data_as(C.c_void_p),
+                                                                      C.cast(buf, C.c_void_p), C.c_uint64(cap.value), C.byref(n)))
+        else:
+            N.check(N.lib().KeyGenerator_CreateRelinKeysSave(self._h, C.cast(buf, C.c_void_p), C.c_uint64(cap.value), C.byref(n)))
+        return C.string_at(buf, n.value)
+
     def key_words(self, galois_elt, digits, L, n):
         """one key as the reference lays it out: [digits][2][L][N] (galois_elt 0 = the relinearization key)"""
         out = np.empty((digits, 2, L, n), dtype=np.uint64)

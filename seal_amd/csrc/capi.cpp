@@ -883,6 +883,33 @@ extern "C"
         as<KeyGenerator>(thisptr)->create_galois_keys_all(*as<KSwitchKeys>(galois_keys));
         SHL_CATCH
     }
+    SHL_FUNC KeyGenerator_SeededSaveSize(void *thisptr, bool galois, uint64_t key_count, int64_t *result)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(result, SHL_E_POINTER);
+        SHL_TRY
+        *result = (int64_t)as<KeyGenerator>(thisptr)->seeded_save_size(galois, (size_t)key_count);
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_CreateRelinKeysSave(void *thisptr, uint8_t *outptr, uint64_t size, int64_t *out_bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(outptr, SHL_E_POINTER);
+        IfNullRet(out_bytes, SHL_E_POINTER);
+        SHL_TRY
+        *out_bytes = (int64_t)as<KeyGenerator>(thisptr)->save_seeded(false, nullptr, 0, outptr, (size_t)size);
+        SHL_CATCH
+    }
+    SHL_FUNC KeyGenerator_CreateGaloisKeysFromEltsSave(void *thisptr, uint64_t count, const uint32_t *galois_elts, uint8_t *outptr,
+                                                       uint64_t size, int64_t *out_bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(outptr, SHL_E_POINTER);
+        IfNullRet(out_bytes, SHL_E_POINTER);
+        SHL_TRY
+        *out_bytes = (int64_t)as<KeyGenerator>(thisptr)->save_seeded(true, galois_elts, (size_t)count, outptr, (size_t)size);
+        SHL_CATCH
+    }
     SHL_FUNC KeyGenerator_KeyToHost(void *thisptr, uint32_t galois_elt, uint64_t *host_words, uint64_t capacity_words)
     {
         IfNullRet(thisptr, SHL_E_POINTER);

@@ -127,7 +127,7 @@ namespace sealhip
         return context_.first_level().K * 2 * context_.key_level().K * context_.n();
     }
 
-    void KeyGenerator::one_kswitch_key(const uint64_t *new_key, uint64_t *out)
+    void KeyGenerator::one_kswitch_key(const uint64_t *new_key, uint64_t *out, uint64_t *public_seeds)
     {
         if (!context_.using_keyswitching())
             throw std::logic_error("keyswitching is not supported by the context"); // keygenerator.cpp:324-327
@@ -142,7 +142,7 @@ namespace sealhip
         for (size_t j = 0; j < digits; j++)
         {
             // digit j = an encryption of zero under s with (special prime mod q_j) * new_key added into component j of c_0
-            encryptor_->zero(kl, false, ct, nullptr, false, true);
+            encryptor_->zero(kl, false, ct, public_seeds ? public_seeds + 8 * j : nullptr, false, true);
             uint64_t *dj = out + j * 2 * words;
             ck(hipMemcpyAsync(dj, ct.plane(0), words * 8, hipMemcpyDeviceToDevice, nullptr), "copy c0");
             ck(hipMemcpyAsync(dj + words, ct.plane(1), words * 8, hipMemcpyDeviceToDevice, nullptr), "copy c1");
@@ -152,17 +152,17 @@ namespace sealhip
             ck(hipStreamSynchronize(nullptr), "keygen sync");
         }
     }
-    void KeyGenerator::relin_key(uint64_t *out)
+    void KeyGenerator::relin_key(uint64_t *out, uint64_t *public_seeds)
     {
         // compute_secret_key_array (keygenerator.cpp:220-290): s^2 = s .* s in NTT form
         const size_t n = context_.n(), L = context_.key_level().K;
         Scratch s2(L * n);
         ck(k_dyadic(context_.dev_mods(), sk_.data(), sk_.data(), s2.p, (unsigned)context_.log_n(), (unsigned)L, 0, 1, nullptr), "s^2");
-        one_kswitch_key(s2.p, out);
+        one_kswitch_key(s2.p, out, public_seeds);
         ck(hipMemsetAsync(s2.p, 0, L * n * 8, nullptr), "clear s^2");
         ck(hipStreamSynchronize(nullptr), "keygen sync");
     }
-    void KeyGenerator::galois_key(uint32_t galois_elt, uint64_t *out)
+    void KeyGenerator::galois_key(uint32_t galois_elt, uint64_t *out, uint64_t *public_seeds)
     {
         const size_t n = context_.n(), L = context_.key_level().K;
         if (!(galois_elt & 1) || galois_elt >= 2 * n)
@@ -170,7 +170,7 @@ namespace sealhip
         Scratch rotated(L * n);
         const PlaneGeom g{ (unsigned)context_.log_n(), (unsigned)L, 1 };
         ck(k_apply_galois(context_.dev_mods(), sk_.data(), rotated.p, galois_elt, 1, g, 1, nullptr), "rotate s");
-        one_kswitch_key(rotated.p, out);
+        one_kswitch_key(rotated.p, out, public_seeds);
         ck(hipMemsetAsync(rotated.p, 0, L * n * 8, nullptr), "clear rotated s");
         ck(hipStreamSynchronize(nullptr), "keygen sync");
     }
@@ -236,6 +236,74 @@ namespace sealhip
             throw std::logic_error("encryption parameters do not support batching");
         const std::vector<uint32_t> elts = galois_elts_all();
         create_galois_keys(elts.data(), elts.size(), destination);
+    }
+    size_t KeyGenerator::seeded_save_size(bool galois, size_t key_count) const
+    {
+        const size_t n = context_.n(), L = context_.key_level().K, digits = context_.first_level().K;
+        const size_t slots = galois ? n : 1;
+        return 16 + 32 + 8 + slots * 8 + key_count * digits * serial::seeded_ciphertext_save_size(n, L);
+    }
+    size_t KeyGenerator::save_seeded(bool galois, const uint32_t *galois_elts, size_t count, uint8_t *out, size_t capacity)
+    {
+        if (!out || (galois && count && !galois_elts))
+            throw std::invalid_argument("out");
+        const Level &kl = context_.key_level();
+        const size_t n = context_.n(), L = kl.K, digits = context_.first_level().K, words = L * n;
+        // the slots of KSwitchKeys::data(): one for RelinKeys (count = 1), N for GaloisKeys with the key of element e at (e - 1) / 2
+        std::vector<uint32_t> slot_elt(galois ? n : 1, 0);
+        size_t keys = 1;
+        if (galois)
+        {
+            keys = 0;
+            for (size_t i = 0; i < count; i++)
+            {
+                const uint32_t e = galois_elts[i];
+                if (!(e & 1) || e >= 2 * n)
+                    throw std::invalid_argument("Galois element is not valid");
+                if (!slot_elt[(e - 1) >> 1])
+                    keys++;
+                slot_elt[(e - 1) >> 1] = e;
+            }
+        }
+        if (capacity < seeded_save_size(galois, keys))
+            throw std::invalid_argument("capacity");
+        size_t pos = 16;
+        auto put64 = [&](uint64_t v) {
+            std::memcpy(out + pos, &v, 8);
+            pos += 8;
+        };
+        std::memcpy(out + pos, kl.parms_id, 32);
+        pos += 32;
+        put64(slot_elt.size());
+        Scratch key(key_words());
+        std::vector<uint64_t> seeds(digits * 8);
+        for (size_t slot = 0; slot < slot_elt.size(); slot++)
+        {
+            if (galois && !slot_elt[slot])
+            {
+                put64(0);
+                continue;
+            }
+            put64(digits);
+            if (galois)
+                galois_key(slot_elt[slot], key.p, seeds.data());
+            else
+                relin_key(key.p, seeds.data());
+            for (size_t j = 0; j < digits; j++)
+            {
+                size_t off = 0;
+                const size_t bytes = serial::save_seeded_ciphertext(kl.parms_id, true, n, L, 1.0, 1, nullptr, 1, seeds.data() + 8 * j, out + pos,
+                                                                    capacity - pos, &off);
+                ck(hipMemcpy(out + pos + off, key.p + j * 2 * words, words * 8, hipMemcpyDeviceToHost), "download c0");
+                pos += bytes;
+            }
+        }
+        // the outer SEALHeader (serialization.h: magic, header size, version, compr_mode none, reserved, size)
+        const uint8_t header[8] = { 0x5E, 0xA1, serial::kHeaderSize, serial::kVersionMajor, serial::kVersionMinor, 0, 0, 0 };
+        std::memcpy(out, header, 8);
+        const uint64_t total = pos;
+        std::memcpy(out + 8, &total, 8);
+        return pos;
     }
     void KeyGenerator::key_to_host(uint32_t galois_elt, uint64_t *host_words)
     {

@@ -31,6 +31,12 @@ namespace sealhip
         void create_galois_keys_from_steps(const int *steps, size_t count, KSwitchKeys &destination);
         void create_galois_keys_all(KSwitchKeys &destination);
         std::vector<uint32_t> galois_elts_all() const;
+        // The Serializable<RelinKeys> / Serializable<GaloisKeys> forms, saved (create_relin_keys() / create_galois_keys(elts) with
+        // save_seed = true, then save(compr_mode none); kswitchkeys.cpp:47-90): every digit as its SEEDED ciphertext - c_0 and the
+        // 64-byte seed c_1 re-expands from - i.e. half the bytes of the full key set.  galois = false: the relinearization key.
+        // Returns the bytes written; seeded_save_size = the capacity that suffices.
+        size_t seeded_save_size(bool galois, size_t key_count) const;
+        size_t save_seeded(bool galois, const uint32_t *galois_elts, size_t count, uint8_t *out, size_t capacity);
         // one key in the reference's layout [digit][2][L][N] (KSwitchKeys::data()[index][digit].data()) copied to host memory:
         // galois_elt == 0 -> the relinearization key.  For parity tests and for saving keys; regenerates the key.
         size_t key_words() const; // words per key
@@ -40,9 +46,9 @@ namespace sealhip
         void sample_secret_key();
         void configure(const uint64_t *seed8);
         // generate_one_kswitch_key (keygenerator.cpp:322-357): out_dev = [digits][2][L][N]
-        void one_kswitch_key(const uint64_t *new_key_dev, uint64_t *out_dev);
-        void relin_key(uint64_t *out_dev);
-        void galois_key(uint32_t galois_elt, uint64_t *out_dev);
+        void one_kswitch_key(const uint64_t *new_key_dev, uint64_t *out_dev, uint64_t *public_seeds = nullptr); // [digits][8]
+        void relin_key(uint64_t *out_dev, uint64_t *public_seeds = nullptr);
+        void galois_key(uint32_t galois_elt, uint64_t *out_dev, uint64_t *public_seeds = nullptr);
         const Context &context_;
         SecretKey sk_;
         std::unique_ptr<Encryptor> encryptor_;

@@ -428,6 +428,12 @@ def case_keygen(scheme, n, bits, seed=0x5EA1, elts=(3, 5)):
         d.ev.apply_galois_inplace(r1, e, glk)
         d.ev.apply_galois_inplace(r2, e, glk_ref)
         assert np.array_equal(r1.to_numpy(), r2.to_numpy()), ("apply_galois", e)
+    # the save_seed forms: the half-size streams equal Serializable<RelinKeys / GaloisKeys>::save byte for byte, and load back
+    assert kg.save_seeded() == ref.keys_save("relin", seeded=True), "seeded RelinKeys stream"
+    stream = kg.save_seeded(elts)
+    assert stream == ref.keys_save("galois", seeded=True, elts=elts), "seeded GaloisKeys stream"
+    back = S.GaloisKeys(d.ctx)
+    assert back.load_bytes(stream) == len(stream) and all(back.has_key(e) for e in elts)
     # create_galois_keys(steps) and create_galois_keys(): the elements the reference's GaloisTool derives
     steps = [1, -2, 0]
     by_steps = kg.create_galois_keys(steps=steps)
