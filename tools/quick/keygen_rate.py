@@ -38,10 +38,12 @@ for scheme, n, bits in (("ckks", 65536, [60] + [50] * 14 + [60]), ("bfv", 32768,
             ("create_relin_keys", t(kg.create_relin_keys)),
             ("create_galois_keys (8 elements)", t(lambda: kg.create_galois_keys(elts), 2)),
             ("create_galois_keys() (all: %d)" % (2 * (n.bit_length() - 2) + 1), t(lambda: kg.create_galois_keys(), 1))]
+    rows.append(("RelinKeys seeded stream (%.0f MB)" % (len(kg.save_seeded()) / 1e6), t(kg.save_seeded, 2)))
     t_ctx = once(lambda: sealref.RefContext(scheme, n, primes, tt))   # includes the reference's KeyGenerator(context)
     ref = sealref.RefContext(scheme, n, primes, tt)
     refs = [t_ctx, once(ref.public_key), once(ref.keygen_relin), once(lambda: ref.keygen_galois_elts(elts[:2])) * 4]
     refs.append(refs[-1] / 8 * (2 * (n.bit_length() - 2) + 1))   # scaled from the two timed elements
+    refs.append(once(lambda: ref.keys_save("relin", seeded=True)))   # create_relin_keys() + save + reload by the shim
     mb = (len(primes) - 1) * 2 * len(primes) * n * 8 / 1e6
     print("%s N=%d L=%d, one key = %.0f MB (ms: C ABI on MI355X | reference on one host thread%s)" %
           (scheme, n, len(primes), mb, "; its first row includes SEALContext creation"))
