@@ -5,23 +5,34 @@ metric (BASELINE.json): CKKS multiply + relinearize + rescale_to_next throughput
 N = 2^16, L = 16 (CoeffModulus::Create(65536, {60, 14x50, 60}), K = 15 data primes), batches of
 synthetic uniform ciphertexts resident in HBM (the distribution sealbench uses, native/bench/bench.h:195-270).
 A "step" = one pass of multiply_inplace + relinearize_inplace + rescale_to_next_inplace over a batch of
-`--batch` ciphertexts per GPU.  N GPUs = N independent processes each owning its own batch, context
-tables and keys (batch sharding, no data-path collective: SURVEY §8(e).1) -> "scaling": "weak".
+`--batch` ciphertexts per GPU.  N GPUs = N processes (one per GPU, torch.distributed over RCCL) each owning its
+own batch, context tables and keys (batch sharding, no data-path collective: SURVEY §8(e).1) -> "scaling": "weak".
+
+  python bench.py --gpus N          N > 1 without a torchrun environment: bench.py starts the N ranks itself
+                                    (python -m torch.distributed.run, rendezvous on 127.0.0.1) and rank 0 prints the line;
+                                    under torchrun (WORLD_SIZE set) it is one rank and checks WORLD_SIZE == --gpus.
+  --workload headline               (default) the metric above
+  --workload bfv_c4                 BASELINE configs[3]: BFV N=32768, 14x55-bit, multiply + relinearize + mod_switch_to_next,
+                                    a TOTAL batch (--total-batch, default 1024) sharded over the ranks ("scaling": "strong")
+  --workload rotate_c5              BASELINE configs[4]: CKKS N=65536 L=16 rotate_vector with the key-switch decomposition
+                                    digits spread over the ranks (one exchange per key switch) + rescale ("strong")
 
 One JSON line is printed by rank 0 with, besides the contract fields:
-  roofline     the NTT (dominant kernel family: one batched ntt_forward = column-pass + row-pass kernel)
-               measured live with HIP events on the stream it runs on; achieved = algorithmic bytes
-               (16*N per RNS-component transform) / time; peak = 8 TB/s HBM (guide).
-  roofline_configs1  the same measurement at BASELINE configs[1] (CKKS N=8192, L=4: forward and inverse NTT over all
-               RNS components), where the transform fits the LDS and the single-launch kernels move algorithmic bytes only.
-  cpu_baseline the reference's own Evaluator (oracle/_ref = Microsoft SEAL 4.4.3, HEXL off) timed on this
-               host's cores on a bounded sample, rank 0, N=1 only ("port": the plain-C restatement, 1 core,
-               when oracle/_ref did not travel).  Checker/baseline only — never the thing measured.
+  verified_items  ciphertexts of the timed batch (first / middle / last of every rank) compared word for word, outside the timed
+               region, with the reference Evaluator (oracle/_ref) run on the same input and key words
+  roofline     the NTT (dominant kernel family) measured live with HIP events on the stream it runs on; achieved = algorithmic
+               bytes (16*N per RNS-component transform) / time; peak = 8 TB/s HBM (guide); traffic = HBM bytes
+               per launch from two rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE) taken by this run (traffic_source says so)
+  roofline_configs1  the same measurement at BASELINE configs[1] (CKKS N=8192, L=4: forward and inverse NTT over all RNS components)
+  cpu_baseline the reference's own Evaluator (oracle/_ref = Microsoft SEAL 4.4.3, HEXL off) timed on this host's cores on a
+               bounded sample, rank 0, N=1 only.  Checker/baseline only — never the thing measured.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,24 +40,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-N_POLY = 65536
-BITS = [60] + [50] * 14 + [60]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+EMU = bool(os.environ.get("SEALHIP_BENCH_EMU"))  # CPU tests only: fiber-emulated kernels + gloo, tiny parameters
+
+WORKLOADS = {
+    # name: (scheme, N, coeff-modulus bit sizes, plain-modulus bits, default batch per GPU)
+    "headline": ("ckks", 65536, [60] + [50] * 14 + [60], 0, 256),
+    "bfv_c4": ("bfv", 32768, [55] * 14, 20, 0),
+    "rotate_c5": ("ckks", 65536, [60] + [50] * 14 + [60], 0, 32),
+}
+if EMU:
+    WORKLOADS = {"headline": ("ckks", 1024, [40, 30, 30, 40], 0, 2), "bfv_c4": ("bfv", 1024, [36, 36, 37], 20, 0),
+                 "rotate_c5": ("ckks", 1024, [40, 30, 30, 40], 0, 2)}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="ciphertexts per GPU per step (SURVEY 8(d): device-resident throughput batches of 64 / 256 / 1024)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="headline")
+    ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU per step (default: 256 for the headline workload; "
+                    "SURVEY 8(d): device-resident throughput batches of 64 / 256 / 1024)")
+    ap.add_argument("--total-batch", type=int, default=1024, help="bfv_c4: ciphertexts per step over ALL ranks (BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores")
-    ap.add_argument("--cpu-reps", type=int, default=4)
+    ap.add_argument("--no-verify", action="store_true", help="skip the reference check of sampled output items")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 PMC passes for roofline.traffic")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all logical host cores")
+    ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--ntt-only", action="store_true", help="only the NTT roofline leg (for rocprofv3 runs)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (Evaluator_BeginCapture/EndCapture): "
                     "for launch-bound small batches; the default (eager) path is what the headline number uses")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args):
+    """--gpus N > 1 outside torchrun: start the N ranks (one process per GPU) and wait; rank 0 prints the JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def device_uniform(torch, primes, shape_prefix, n, device):
@@ -57,77 +101,160 @@ def device_uniform(torch, primes, shape_prefix, n, device):
 
 def main():
     args = parse()
+    if args.pmc_child:
+        return pmc_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
-
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     import seal_amd as S
     from seal_amd import shard
+    if EMU:
+        S.load(os.path.join(ROOT, "tests", "hipemu", "libsealhip_emu.so"))
+        device = torch.device("cpu")
+        dev_sync = lambda: None  # noqa: E731
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a MI355X: no HIP device visible (there is no CPU fallback)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        dev_sync = torch.cuda.synchronize
+        if world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group(backend="nccl", device_id=device)
+    if world > 1:
+        assert dist.get_world_size() == args.gpus, "process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus)
+        # one collective before anything is timed: RCCL (gloo under emulation) really connects all ranks
+        probe = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(probe)
+        assert int(probe.item()) == args.gpus, "all-reduce saw %d ranks, expected %d" % (int(probe.item()), args.gpus)
+    group = dist if world > 1 else None
 
-    n, B = N_POLY, args.batch
-    primes = S.CoeffModulus.Create(n, BITS)
+    scheme, n, bits, tbits, default_batch = WORKLOADS[args.workload]
+    primes = S.CoeffModulus.Create(n, bits)
     L, K = len(primes), len(primes) - 1
-    parms = S.EncryptionParameters("ckks")
+    parms = S.EncryptionParameters(scheme)
     parms.set_poly_modulus_degree(n)
     parms.set_coeff_modulus(primes)
+    t_plain = 0
+    if scheme != "ckks":
+        t_plain = S.PlainModulus.Batching(n, tbits)
+        parms.set_plain_modulus(t_plain)
     ctx = S.SEALContext(parms, True, 0)  # sec_level_type::none, as sealbench (native/bench/bench.h:35-36)
     ev = S.Evaluator(ctx)
-
-    torch.manual_seed(0x5EA1 + rank)
-    # synthetic relinearization key: K digits x 2 polys x L comps, uniform per component (240 MiB)
-    key = device_uniform(torch, primes, (K, 2), n, device)
-    rlk = S.RelinKeys(ctx)
-    rlk.set_key_device(0, K, key.data_ptr())
-    del key
-    # synthetic size-2 ciphertext batches at the first data level, NTT form, scale = safe_scale
-    scale = 2.0 ** (50 // 2 - 1)
-    xs = device_uniform(torch, primes[:K], (2, B), n, device)
-    ys = device_uniform(torch, primes[:K], (2, B), n, device)
     first = ctx.first_parms_id()
+
+    scaling = "weak"
+    if args.workload == "bfv_c4":
+        # BASELINE configs[3]: a fixed total batch sharded over the ranks, no data-path collective
+        start, B = shard.split(args.total_batch if not EMU else 4, world, rank)
+        scaling = "strong"
+    else:
+        B = args.batch or default_batch
+        start = rank * B
+    if args.workload == "rotate_c5":
+        scaling = "strong"  # every rank holds the same batch; the key-switch digits are divided over the ranks
+
+    # ---- synthetic keys: K digits x 2 polys x L comps, uniform per component (C5: 240 MiB)
+    same_on_all_ranks = args.workload == "rotate_c5"
+    torch.manual_seed(0x5EA1 + (0 if same_on_all_ranks else rank))
+    key = device_uniform(torch, primes, (K, 2), n, device)
+    key_host = None
+    want_verify = not args.no_verify and not args.ntt_only and reference_available()
+    if want_verify:
+        key_host = key.cpu().numpy().view("uint64")
+    dp = None
+    if args.workload == "rotate_c5":
+        elt = ctx.galois_elt_from_step(1)
+        keys = S.GaloisKeys(ctx)
+        dp = shard.DigitParallel(ev, torch, group, device)
+        d0, dc = dp.digit_range(K)
+        if world > 1 and dc:
+            keys.set_key_digits(S.GaloisKeys.get_index(elt), d0, key[d0:d0 + dc].cpu().numpy().view("uint64"))
+        else:
+            keys.set_key_device(S.GaloisKeys.get_index(elt), K, key.data_ptr())
+    else:
+        keys = S.RelinKeys(ctx)
+        keys.set_key_device(0, K, key.data_ptr())
+    del key
+
+    # ---- synthetic size-2 ciphertext batches at the first data level (CKKS: NTT form, scale 2^24)
+    ntt_form = scheme != "bfv"
+    scale = 2.0 ** (50 // 2 - 1) if scheme == "ckks" else 1.0
+    xs = device_uniform(torch, primes[:K], (2, B), n, device)
+    ys = device_uniform(torch, primes[:K], (2, B), n, device) if args.workload != "rotate_c5" else None
 
     def make_ct(t):
         ct = S.Ciphertext(ctx, batch=B)
         ct.resize(first, 2)
-        ct.set_is_ntt_form(True)
+        ct.set_is_ntt_form(ntt_form)
         ct.set_scale(scale)
         ct.load_device(t.data_ptr(), t.numel())
         return ct
 
-    x, y = make_ct(xs), make_ct(ys)
+    x = make_ct(xs)
+    y = make_ct(ys) if ys is not None else None
     work = S.Ciphertext(ctx, batch=B)
-    torch.cuda.synchronize()
+    dev_sync()
 
-    def step():
-        ev.multiply(x, y, work)          # work = x * y (size 3); x stays resident as the next step's input
-        ev.relinearize_inplace(work, rlk)
-        ev.rescale_to_next_inplace(work)
+    if args.workload == "headline":
+        def step():
+            ev.multiply(x, y, work)          # work = x * y (size 3); x stays resident as the next step's input
+            ev.relinearize_inplace(work, keys)
+            ev.rescale_to_next_inplace(work)
+    elif args.workload == "bfv_c4":
+        def step():
+            ev.multiply(x, y, work)
+            ev.relinearize_inplace(work, keys)
+            ev.mod_switch_to_next_inplace(work)
+    else:
+        rot_scale = float(primes[K - 1]) * 2.0 ** 10
+        holder = {}
 
-    if args.graph and not args.ntt_only:
+        def step():
+            w = x.copy()                    # device-to-device copy of the resident batch (the rotation works in place)
+            w.set_scale(rot_scale)
+            dp.rotate_vector_inplace(w, 1, keys)
+            ev.rescale_to_next_inplace(w)
+            holder["work"] = w
+
+    if args.graph and not args.ntt_only and args.workload != "rotate_c5":
         step()  # eager once: lazily built tables, pool warm-up
-        torch.cuda.synchronize()
+        dev_sync()
         graph = ev.capture(step)
-        eager_step, step = step, graph.launch
+        step = graph.launch
 
     result = {}
+    verified = None
     if not args.ntt_only:
-        elapsed = shard.timed_steps(step, args.steps, args.warmup, dist if world > 1 else None, torch.cuda.synchronize, torch, device)
-        assert work.size() == 2 and work.coeff_modulus_size() == K - 1
-        rate = shard.whole_job_rate(B, args.steps, elapsed, dist if world > 1 else None, torch, device)
+        elapsed = shard.timed_steps(step, args.steps, args.warmup, group, dev_sync, torch, device)
+        if args.workload == "rotate_c5":
+            work = holder["work"]
+        assert work.size() == 2 and work.coeff_modulus_size() == K - 1 and work.batch() == B
+        per_step = B if args.workload != "rotate_c5" else float(B) / world  # rotate_c5: all ranks worked on the same B items
+        rate = shard.whole_job_rate(per_step, args.steps, elapsed, group, torch, device)
         result = dict(value=rate, ms_per_step=1e3 * elapsed / args.steps)
+        if want_verify and B > 0:
+            verified = verify_items(args.workload, scheme, n, primes, t_plain, key_host, xs, ys, work, B, scale)
+            if group is not None:
+                v = torch.tensor([verified], dtype=torch.int64, device=device)
+                dist.all_reduce(v)
+                verified = int(v.item())
+    del key_host
 
     # ---- roofline leg: the batched forward NTT over the resident batch (2*B polys x K comps)
     roofline = None
-    if rank == 0:
+    if rank == 0 and scheme == "ckks" and not EMU:
         buf_words = xs.numel()
         timer = S.HipTimer()
         polys = 2 * B
@@ -143,51 +270,105 @@ def main():
         ms = timer.stop() / reps
         alg_bytes = 16.0 * n * K * polys
         achieved = alg_bytes / (ms * 1e-3) / 1e9
-        # HBM bytes of one launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, separate passes,
-        # MI355X_MICROARCH.md).  The passes record their own launch shape; traffic per transform does not depend on
-        # the batch, so a different shape is scaled by the number of transforms.
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_ntt_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                traffic = int(round(pj["hbm_bytes_per_launch"] * (K * polys) / float(pj.get("transforms_per_launch", 480))))
-            except Exception:
-                traffic = None
-        roofline = dict(bound="hbm", kernel="ntt_forward = ntt2_fwd_p1 + ntt2_fwd_p2 (two-pass engine), %d transforms of 2^16 per launch" % (K * polys),
+        roofline = dict(bound="hbm", kernel="ntt_forward over %d transforms of 2^%d per launch" % (K * polys, n.bit_length() - 1),
                         achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                        traffic=traffic, ms_per_launch=round(ms, 4), algorithmic_bytes_per_launch=alg_bytes)
+                        traffic=None, ms_per_launch=round(ms, 4), algorithmic_bytes_per_launch=alg_bytes)
         assert buf_words == 2 * B * K * n
 
-    # ---- BASELINE configs[1]: CKKS N=8192, L=4, forward + inverse NTT over all RNS components (single-launch kernels,
-    # the transform is 64 KiB and stays in LDS between the passes: HBM traffic = algorithmic bytes).  Two chains: the
-    # config's own {60,40,40,60} (its two 60-bit primes run on the slower 64-bit integer back end, two launches) and a
-    # chain whose primes are all below 2^50 (every component on the double-precision back end).
     ntt_c1 = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and args.workload == "headline" and not EMU:
         ntt_c1 = ntt_configs1(S, torch, device)
 
-    # ---- CPU baseline (rank 0, N=1 only): the reference's Evaluator on this host's cores
+    # free the device before the PMC child processes and the CPU baseline start
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and roofline is not None and not args.no_pmc:
+        del x, y, work, xs, ys
+        torch.cuda.empty_cache()
+        S.release_pool()
+        roofline.update(pmc_traffic(args, B, K, n))
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.ntt_only:
-        cpu = cpu_baseline(primes, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.ntt_only and not EMU:
+        cpu = cpu_baseline(args.workload, scheme, n, primes, t_plain, args)
 
     if rank == 0:
+        names = {
+            "headline": ("CKKS multiply+relinearize+rescale ciphertexts/sec @ N=2^16, L=16",
+                         "CKKS N=65536, coeff_modulus {60,14x50,60} (L=16, K=15): multiply_inplace + relinearize_inplace + "
+                         "rescale_to_next_inplace, device-resident batches"),
+            "bfv_c4": ("BFV multiply+relinearize+mod_switch ciphertexts/sec @ N=32768, 14 primes",
+                       "BASELINE configs[3]: BFV N=32768, 14x55-bit chain, t=Batching(32768,20): multiply + relinearize + "
+                       "mod_switch_to_next, total batch %d sharded over the ranks" % args.total_batch),
+            "rotate_c5": ("CKKS rotate_vector+rescale ciphertexts/sec @ N=2^16, L=16, digit-parallel key switch",
+                          "BASELINE configs[4]: CKKS N=65536 L=16 rotate_vector (decomposition digits spread over the ranks, one "
+                          "exchange of 2(K+1)N words per ciphertext) + rescale_to_next"),
+        }[args.workload]
+        par = {"headline": "batch-sharded x%d, no data-path collective" % world,
+               "bfv_c4": "total batch sharded x%d, no data-path collective" % world,
+               "rotate_c5": "key-switch digits split x%d, one all-reduce per key switch" % world}[args.workload]
         line = dict(
-            metric="CKKS multiply+relinearize+rescale ciphertexts/sec @ N=2^16, L=16",
-            value=round(result.get("value", 0.0), 2), unit="ciphertexts/s", n_gpus=world, steps=args.steps,
+            metric=names[0], value=round(result.get("value", 0.0), 2), unit="ciphertexts/s", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(result.get("ms_per_step", 0.0), 3), higher_is_better=True,
-            scaling="weak", vs_baseline=None, dtype="u64", data="synthetic",
-            config=dict(workload="CKKS N=65536, coeff_modulus {60,14x50,60} (L=16, K=15): multiply_inplace + "
-                                 "relinearize_inplace + rescale_to_next_inplace, device-resident batches",
-                        batch_per_gpu=B, launch="hipGraph replay" if args.graph else "eager", parallelism="batch-sharded x%d, no data-path collective" % world,
-                        arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for the 14 primes below "
-                                   "2^50, 64-bit Shoup/Barrett integer arithmetic for the two 60-bit primes; results canonical u64",
+            scaling=scaling, vs_baseline=None, dtype="u64", data="synthetic", verified_items=verified,
+            config=dict(workload=names[1] + (" [EMULATED KERNELS, CPU test]" if EMU else ""),
+                        batch_per_gpu=B, launch="hipGraph replay" if args.graph else "eager", parallelism=par,
+                        arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for primes below "
+                                   "2^50, 64-bit Shoup/Barrett integer arithmetic for larger primes; results canonical u64",
                         key_bytes=2 * K * L * n * 8, algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n),
             roofline=roofline, roofline_configs1=ntt_c1, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def reference_available():
+    try:
+        import sealref
+        return sealref.available()
+    except Exception:
+        return False
+
+
+def verify_items(workload, scheme, n, primes, t_plain, key_host, xs, ys, work, B, scale):
+    """first / middle / last item of this rank's timed batch against seal::Evaluator (oracle/_ref) on the same words.
+    Raises on the first differing word; returns the number of items compared.  Outside the timed region."""
+    import numpy as np
+    import sealref
+    K = len(primes) - 1
+    ref = sealref.RefContext(scheme, n, primes, t_plain)
+    items = sorted({0, B // 2, B - 1})
+    if workload == "rotate_c5":
+        ref.keygen_galois_steps([1])
+        elt = ref.galois_elt_from_step(1)
+        ref.set_key("galois", (elt - 1) >> 1, key_host)
+    else:
+        ref.keygen_relin()
+        ref.set_key("relin", 0, key_host)
+    ci = ref.first_chain_index
+    for b in items:
+        xw = xs[:, b].cpu().numpy().view("uint64")
+        if workload == "rotate_c5":
+            a = ref.ct(ci, xw, True, float(primes[K - 1]) * 2.0 ** 10)
+            ref.rotate_vector_inplace(a, 1)
+            ref.rescale_to_next_inplace(a)
+        else:
+            yw = ys[:, b].cpu().numpy().view("uint64")
+            a, c = ref.ct(ci, xw, scheme != "bfv", scale), ref.ct(ci, yw, scheme != "bfv", scale)
+            ref.multiply_inplace(a, c)
+            ref.relinearize_inplace(a)
+            if workload == "headline":
+                ref.rescale_to_next_inplace(a)
+            else:
+                ref.mod_switch_to_next_inplace(a)
+        exp = a.data()
+        got = work.item_to_numpy(b)
+        if got.shape != exp.shape or not np.array_equal(got, exp):
+            raise SystemExit("bench.py: item %d of the timed batch differs from the reference Evaluator" % b)
+        if scheme == "ckks" and work.scale() != a.info()["scale"]:
+            raise SystemExit("bench.py: scale metadata differs from the reference (%r vs %r)" % (work.scale(), a.info()["scale"]))
+    return len(items)
 
 
 def ntt_configs1(S, torch, device, polys=4096, reps=10):
@@ -218,40 +399,117 @@ def ntt_configs1(S, torch, device, polys=4096, reps=10):
             alg = 16.0 * n * comps * polys
             rates[name] = dict(achieved=round(alg / (ms * 1e-3) / 1e9, 1), frac=round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                ms_per_launch=round(ms, 4), algorithmic_bytes_per_launch=alg)
-        # HBM bytes per launch of the single-launch kernels from the committed PMC passes (all-double-precision chain only:
-        # the passes were taken on it), scaled by the number of transforms as for the main roofline leg
-        if "2^50" in label:
-            try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "r01_ntt_pmc.json")))["single_launch_n8192"]
-                per = float(pj["algorithmic_kib"]) * 1024 / (16.0 * n)  # transforms in the recorded launch
-                for name in ("forward", "inverse"):
-                    rates[name]["traffic"] = int(round(pj[name]["hbm_bytes_per_launch"] * (comps * polys) / per))
-            except Exception:
-                pass
         out.append(dict(chain=label, transforms_per_launch=comps * polys, **rates))
         del data
     return dict(bound="hbm", unit="GB/s", peak=HBM_PEAK_GBS, workload="CKKS N=8192, L=4: batched NTT / INTT over all RNS components", chains=out)
 
 
-def cpu_baseline(primes, args):
-    import numpy as np
-    n = N_POLY
+# ---- roofline.traffic: HBM bytes of one ntt_forward launch, measured by this run -----------------------------------
+PMC_CALLS = 3
+
+
+def pmc_child(args):
+    """Run under `rocprofv3 --kernel-trace --pmc <counter>`: the roofline leg's launch (same shape), no torch, PMC_CALLS calls."""
+    import seal_amd as S
+    scheme, n, bits, _, default_batch = WORKLOADS["headline"]
+    primes = S.CoeffModulus.Create(n, bits)
+    K = len(primes) - 1
+    parms = S.EncryptionParameters(scheme)
+    parms.set_poly_modulus_degree(n)
+    parms.set_coeff_modulus(primes)
+    ctx = S.SEALContext(parms, True, 0)
+    polys = 2 * (args.batch or default_batch)
+    buf = S.DeviceBuffer(polys * K * n)  # contents do not matter for the byte counters
+    for _ in range(PMC_CALLS):
+        S.ntt_forward(ctx, buf, polys, K)
+    S.device_synchronize()
+    return 0
+
+
+def pmc_traffic(args, B, K, n):
+    """Two separate rocprofv3 passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass, MI355X_MICROARCH.md §PMC slots) over a
+    child process that issues the roofline leg's launch; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B, same
+    guide §HBM).  Returns {'traffic': bytes per launch or None, 'traffic_source': how it was obtained}."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return dict(traffic=None, traffic_source="rocprofv3 not found on this host")
+    totals = {}
+    per_kernel = {}
+    tmp = tempfile.mkdtemp(prefix="sealhip_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
+                   "--pmc-child", "--batch", str(B)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if p.returncode != 0 or not dbs:
+                return dict(traffic=None, traffic_source="rocprofv3 --pmc %s failed (rc %d): %s" % (counter, p.returncode, (p.stderr or p.stdout)[-300:]))
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
+                               "group by kernel_name", (counter,)).fetchall()
+            tot = 0.0
+            for name, calls, val in rows:
+                if "ntt" not in name:
+                    continue
+                kib = float(val) / PMC_CALLS
+                short = name.replace("sealhip::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                per_kernel.setdefault(short, {})[counter] = round(kib * (2 if counter == "FETCH_SIZE" else 1), 1)
+                tot += kib
+            totals[counter] = tot * 1024.0
+        traffic = int(round(2.0 * totals["FETCH_SIZE"] + totals["WRITE_SIZE"]))
+        return dict(traffic=traffic, traffic_source="live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run "
+                    "(KiB per launch per kernel, FETCH doubled): %s" % json.dumps(per_kernel, sort_keys=True),
+                    traffic_over_algorithmic=round(traffic / (16.0 * n * K * 2 * B), 3))
+    except Exception as e:  # the counters must never take the benchmark down
+        return dict(traffic=None, traffic_source="PMC passes failed: %r" % (e,))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---- CPU baseline --------------------------------------------------------------------------------------------------
+def physical_cores():
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(workload, scheme, n, primes, t_plain, args):
+    pipeline = {"headline": "ckks_mul_relin_rescale", "bfv_c4": "bfv_mul_relin_modswitch", "rotate_c5": "rotate"}[workload]
     try:
         import sealref
         if sealref.available():
-            threads = args.cpu_threads or (os.cpu_count() or 1)
-            ref = sealref.RefContext("ckks", n, primes)
+            logical = args.cpu_threads or (os.cpu_count() or 1)
+            phys = min(physical_cores(), logical)
+            ref = sealref.RefContext(scheme, n, primes, t_plain)
             ref.keygen_relin()
-            secs = ref.time_pipeline("ckks_mul_relin_rescale", threads, args.cpu_reps)
-            cts = threads * args.cpu_reps
-            one = ref.time_pipeline("ckks_mul_relin_rescale", 1, 2)
-            return dict(value=round(cts / secs, 3), unit="ciphertexts/s", cores=threads, kind="reference",
-                        single_thread_value=round(2 / one, 3),
-                        sample="%d threads x %d ciphertexts each (after one untimed warm-up pass per thread), "
-                               "seal::Evaluator multiply+relinearize+rescale, HEXL off, same parameters" % (threads, args.cpu_reps))
+            if pipeline == "rotate":
+                ref.keygen_galois_steps([1])
+            reps = args.cpu_reps
+            secs = ref.time_pipeline(pipeline, logical, reps)
+            out = dict(value=round(logical * reps / secs, 3), unit="ciphertexts/s", cores=logical, kind="reference",
+                       sample="%d threads x %d ciphertexts each; every thread builds its inputs, runs one untimed pass, waits at a "
+                              "start barrier; wall time from the barrier to the last thread's finish; per-thread "
+                              "MemoryPoolHandle::New(); seal::Evaluator, HEXL off, same parameters" % (logical, reps))
+            if phys != logical:
+                secs_p = ref.time_pipeline(pipeline, phys, reps)
+                out["physical_cores_run"] = dict(value=round(phys * reps / secs_p, 3), cores=phys)
+            one = ref.time_pipeline(pipeline, 1, 2)
+            out["single_thread_value"] = round(2 / one, 3)
+            return out
     except Exception as e:  # the baseline must never take the benchmark down
         sys.stderr.write("cpu_baseline(reference) unavailable: %r\n" % (e,))
+    if workload != "headline":
+        return None
     try:
+        import numpy as np
         import sealoracle
         from oracle import rand_ct
         rng = np.random.default_rng(0x5EA1)

@@ -204,6 +204,7 @@ SHL_FUNC Encryptor_Create(void *context, void *public_key, void *secret_key, voi
 SHL_FUNC Encryptor_Encrypt(void *thisptr, void *plaintext, void *destination, void *pool);
 SHL_FUNC Encryptor_EncryptZero1(void *thisptr, uint64_t *parms_id, void *destination, void *pool);
 SHL_FUNC Encryptor_Destroy(void *thisptr);
+/* INSECURE, parity tests only (see KeyGenerator_Create1): every call restarts from this seed.  NULL restores OS entropy. */
 SHL_FUNC Encryptor_SetSeed(void *thisptr, const uint64_t *seed);
 SHL_FUNC Encryptor_EncryptZeroSymmetric1(void *thisptr, uint64_t *parms_id, bool save_seed, void *destination, void *pool);
 SHL_FUNC Encryptor_EncryptSymmetric(void *thisptr, void *plaintext, bool save_seed, void *destination, void *pool);
@@ -260,6 +261,10 @@ SHL_FUNC GaloisTool_GetEltFromStep(void *context, int step, uint32_t *galois_elt
 /* Evaluator (native/src/seal/c/evaluator.h).  `destination` may equal `encrypted` (in place). */
 SHL_FUNC Evaluator_Create(void *context, void **evaluator);
 SHL_FUNC Evaluator_Destroy(void *thisptr);
+/* Work of the evaluator is enqueued on `hip_stream` (NULL = the NULL stream), blocking or hipStreamNonBlocking alike.  Device
+ * memory recycled through the library's pool is ordered across streams (an event wait when a block changes stream), so
+ * several evaluators may run on different streams concurrently.  The destination copy of the out-of-place forms
+ * (destination != encrypted) runs on the same stream as the operation. */
 SHL_FUNC Evaluator_SetStream(void *thisptr, void *hip_stream);
 SHL_FUNC Evaluator_Synchronize(void *thisptr);
 /* SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (evaluator.cpp:386-392) costs a device->host round trip per
@@ -269,7 +274,9 @@ SHL_FUNC Evaluator_SetTransparentCheck(void *thisptr, bool enabled);
  * calls).  Between BeginCapture and EndCapture the Evaluator_* operations issued on this evaluator are recorded instead of
  * executed; Evaluator_LaunchGraph replays them with ONE launch, stream-ordered on the evaluator's stream, on the same device
  * buffers: refresh the operand ciphertexts' contents in place (Ciphertext_CopyFromHost/Device, Ciphertext_Load), replay, read the
- * destinations.  Run the sequence once eagerly before capturing; keep the captured objects alive and un-resized. */
+ * destinations.  Run the sequence once eagerly before capturing; keep the captured objects alive and un-resized; issue the
+ * recorded operations from the thread that called BeginCapture.  The scratch blocks the recording used stay reserved for the
+ * graph (their addresses are part of it) until Graph_Destroy. */
 SHL_FUNC Evaluator_BeginCapture(void *thisptr);
 SHL_FUNC Evaluator_EndCapture(void *thisptr, void **graph);
 SHL_FUNC Evaluator_LaunchGraph(void *thisptr, void *graph);
@@ -346,14 +353,25 @@ SHL_FUNC shl_apply_galois(void *context, uint64_t chain_index, int ntt_form, uin
  *   4 divide_and_round_q_last_inplace         (rns.cpp:789)      in K,              out K-1
  *   5 divide_and_round_q_last_ntt_inplace     (rns.cpp:830)      in K,              out K-1 */
 SHL_FUNC shl_rns_stage(void *context, uint64_t chain_index, int which, const uint64_t *in, uint64_t *out, uint64_t polys, void *stream);
-/* device memory helpers for bindings without their own allocator */
+/* the pool of cached HBM blocks (the role of MemoryManager / MemoryPool, native/src/seal/memorymanager.h:75-265): give the
+ * cached blocks back to the driver; counters for tests */
+SHL_FUNC SealHip_ReleasePool(void);
+SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
+/* stream and device memory helpers for bindings without their own runtime (a PyTorch / HIP caller passes its own streams) */
+SHL_FUNC shl_stream_create(bool non_blocking, void **hip_stream);
+SHL_FUNC shl_stream_destroy(void *hip_stream);
 SHL_FUNC shl_malloc(uint64_t bytes, void **device_ptr);
 SHL_FUNC shl_free(void *device_ptr);
 SHL_FUNC shl_memcpy_h2d(void *device_dst, const void *host_src, uint64_t bytes);
 /* KeyGenerator (native/src/seal/c/keygenerator.h:16-36; seal::KeyGenerator, native/src/seal/keygenerator.cpp): secret key, public
  * key, RelinKeys and GaloisKeys generated in HBM with the reference's algorithm and randomness (device samplers over the
  * reference's BLAKE2Xb streams).  seed8 = 8 words for the reference's seeded factory (Blake2xbPRNGFactory(seed): reproducible,
- * word-for-word the reference's keys) or NULL for operating-system entropy.  Differences from sealc: destinations are objects
+ * word-for-word the reference's keys) or NULL for operating-system entropy.
+ * !! seed8 != NULL IS INSECURE AND FOR PARITY TESTS ONLY.  Like the reference's seeded Blake2xbPRNGFactory (a test device there
+ * too), every sampling call restarts from the same seed: the secret key, every key-switching digit and every encryption draw
+ * the same (a, e), so differences of key components reveal s^2 / the rotated s, and the public seed written into saved streams
+ * is the head of the stream that sampled the secret key.  Production callers pass NULL.  The same holds for Encryptor_SetSeed. !!
+ * Differences from sealc: destinations are objects
  * the caller created (SecretKey_Create / PublicKey_Create / KSwitchKeys_Create1) rather than returned handles; the save_seed
  * forms write the stream directly (the *Save functions below).  KeyGenerator_KeyToHost regenerates one key in the
  * reference's layout [digit][2][L][N] into host memory (galois_elt 0 = the relinearization key); SecretKey_Get / PublicKey_Get

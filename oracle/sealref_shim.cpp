@@ -16,6 +16,8 @@
 #include "seal/util/polyarithsmallmod.h"
 #include "seal/util/rns.h"
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <complex>
 #include <cstring>
 #include <memory>
@@ -1122,34 +1124,44 @@ extern "C"
             ct.scale() = scale;
             return ct;
         };
-        std::vector<double> secs(threads, 0.0);
+        // All workers build their inputs and run one untimed pass, meet at a start barrier, and the wall clock runs from
+        // the barrier's release to the last worker's finish.  Each worker draws from its own MemoryPoolHandle::New()
+        // (thread-local pools are allowed), so the threads do not serialise on the global pool's lock.
         std::vector<int> errs(threads, 0);
+        std::mutex mu;
+        std::condition_variable cv;
+        int ready = 0;
+        bool go = false;
+        std::chrono::steady_clock::time_point t_start, t_end;
+        std::vector<std::chrono::steady_clock::time_point> ends(threads);
         auto worker = [&](int tid) {
             try
             {
-                Ciphertext a = make_ct(0x5EA1 + 2 * tid), b = make_ct(0x5EA1 + 2 * tid + 1), w;
+                MemoryPoolHandle pool = MemoryPoolHandle::New();
+                Ciphertext a0 = make_ct(0x5EA1 + 2 * tid), b0 = make_ct(0x5EA1 + 2 * tid + 1);
+                Ciphertext a(a0, pool), b(b0, pool), w(pool);
                 auto pass = [&]() {
                     w = a;
                     switch (pipeline)
                     {
                     case 0:
-                        c->evaluator->multiply_inplace(w, b);
-                        c->evaluator->relinearize_inplace(w, c->rlk);
-                        c->evaluator->rescale_to_next_inplace(w);
+                        c->evaluator->multiply_inplace(w, b, pool);
+                        c->evaluator->relinearize_inplace(w, c->rlk, pool);
+                        c->evaluator->rescale_to_next_inplace(w, pool);
                         break;
                     case 1:
-                        c->evaluator->multiply_inplace(w, b);
-                        c->evaluator->relinearize_inplace(w, c->rlk);
-                        c->evaluator->mod_switch_to_next_inplace(w);
+                        c->evaluator->multiply_inplace(w, b, pool);
+                        c->evaluator->relinearize_inplace(w, c->rlk, pool);
+                        c->evaluator->mod_switch_to_next_inplace(w, pool);
                         break;
                     case 2:
                         if (ckks)
                         {
-                            c->evaluator->rotate_vector_inplace(w, 1, c->glk);
-                            c->evaluator->rescale_to_next_inplace(w);
+                            c->evaluator->rotate_vector_inplace(w, 1, c->glk, pool);
+                            c->evaluator->rescale_to_next_inplace(w, pool);
                         }
                         else
-                            c->evaluator->rotate_rows_inplace(w, 1, c->glk);
+                            c->evaluator->rotate_rows_inplace(w, 1, c->glk, pool);
                         break;
                     default:
                         if (ckks)
@@ -1164,29 +1176,45 @@ extern "C"
                         }
                     }
                 };
-                pass(); // warm-up
-                auto t0 = std::chrono::steady_clock::now();
+                pass(); // warm-up (fills this worker's pool)
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    if (++ready == threads)
+                    {
+                        t_start = std::chrono::steady_clock::now();
+                        go = true;
+                        cv.notify_all();
+                    }
+                    else
+                        cv.wait(lk, [&] { return go; });
+                }
                 for (int r = 0; r < reps; r++)
                     pass();
-                auto t1 = std::chrono::steady_clock::now();
-                secs[tid] = std::chrono::duration<double>(t1 - t0).count();
+                ends[tid] = std::chrono::steady_clock::now();
             }
             catch (...)
             {
                 errs[tid] = 1;
+                std::unique_lock<std::mutex> lk(mu);
+                if (++ready == threads && !go)
+                {
+                    t_start = std::chrono::steady_clock::now();
+                    go = true;
+                    cv.notify_all();
+                }
             }
         };
-        std::vector<std::thread> pool;
+        std::vector<std::thread> workers;
         for (int t = 0; t < threads; t++)
-            pool.emplace_back(worker, t);
-        for (auto &t : pool)
+            workers.emplace_back(worker, t);
+        for (auto &t : workers)
             t.join();
         double mx = 0;
         for (int t = 0; t < threads; t++)
         {
             if (errs[t])
                 return 4;
-            mx = std::max(mx, secs[t]);
+            mx = std::max(mx, std::chrono::duration<double>(ends[t] - t_start).count());
         }
         *seconds = mx;
         REF_CATCH

@@ -242,6 +242,19 @@ class Ciphertext:
             N.check(N.lib().Ciphertext_CopyToHost(self._h, _p(out), C.c_uint64(out.size)))
         return out
 
+    def item_to_numpy(self, item):
+        """device -> host copy of ONE batch item: uint64 [size][K][N] (the evaluator's stream is drained first)"""
+        size, batch, K, n = self.shape()
+        if not 0 <= item < batch:
+            raise IndexError("batch item")
+        out = np.zeros((size, K, n), dtype=np.uint64)
+        ptr, _ = self.device_ptr()
+        N.check(N.lib().shl_device_synchronize())
+        for p in range(size):
+            src = C.c_void_p(ptr + ((p * batch + item) * K * n) * 8)
+            N.check(N.lib().shl_memcpy_d2h(_p(out[p]), src, C.c_uint64(K * n * 8)))
+        return out
+
     # -- the reference's wire format (Ciphertext::save / load / unsafe_load, ciphertext.cpp:153-403)
     def load_bytes(self, data, unsafe=False, item=None):
         """seal::Ciphertext::load (unsafe=True: unsafe_load) of a serialized stream; item = slot of a batch.  Returns bytes read."""
@@ -576,7 +589,10 @@ class PublicKey:
 
 
 class KeyGenerator:
-    """seal::KeyGenerator on the device (sealhip.h): seed = 8 words for the reference's seeded factory, None = OS entropy"""
+    """seal::KeyGenerator on the device (sealhip.h): seed = None -> operating-system entropy (the only secure choice).
+    seed = 8 words installs the reference's seeded Blake2xbPRNGFactory, INSECURE and for parity tests only: every sampling
+    call restarts from the same seed, so all key digits share (a, e) and the saved public seed is the head of the stream
+    that sampled the secret key."""
 
     def __init__(self, context, secret_key=None, seed=None):
         self.context = context
@@ -705,7 +721,8 @@ class Encryptor:
             self._h = None
 
     def set_seed(self, seed):
-        """the reference's seeded Blake2xbPRNGFactory: 8 words (or one int = first word); None -> operating-system entropy"""
+        """the reference's seeded Blake2xbPRNGFactory: 8 words (or one int = first word); None -> operating-system entropy.
+        INSECURE, parity tests only: every encryption restarts from the same seed (identical (a, e) for every call)."""
         if seed is None:
             N.check(N.lib().Encryptor_SetSeed(self._h, None))
             return
@@ -1036,6 +1053,35 @@ RNS_STAGE = {"fastbconv_m_tilde": 0, "sm_mrq": 1, "fast_floor": 2, "fastbconv_sk
 def rns_stage(context, chain_index, which, src, dst, polys, stream=None):
     N.check(N.lib().shl_rns_stage(context._h, C.c_uint64(chain_index), C.c_int(RNS_STAGE[which]), C.c_void_p(src.ptr),
                                   C.c_void_p(dst.ptr), C.c_uint64(polys), C.c_void_p(stream or 0)))
+
+
+class Stream:
+    """a HIP stream owned by the library's caller (shl_stream_create); .handle goes to Evaluator.set_stream"""
+
+    def __init__(self, non_blocking=True):
+        self._h = C.c_void_p()
+        N.check(N.lib().shl_stream_create(C.c_bool(non_blocking), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h.value
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            N.lib().shl_stream_destroy(self._h)
+            self._h = None
+
+
+def release_pool():
+    """return the library's cached HBM blocks to the driver"""
+    N.check(N.lib().SealHip_ReleasePool())
+
+
+def pool_stats():
+    """(bytes held by the pool, number of cross-stream hand-outs ordered by an event)"""
+    a, b = C.c_uint64(), C.c_uint64()
+    N.check(N.lib().SealHip_PoolStats(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def device_synchronize():

@@ -616,6 +616,7 @@ extern "C"
             serial::KSwitchKeysImage img;
             *in_bytes = (int64_t)serial::load_kswitchkeys(*c, inptr, (size_t)size, check, img, true);
             auto keys = as<KSwitchKeys>(thisptr);
+            keys->clear(); // the loaded object replaces the previous contents, indices absent from the stream included
             for (size_t index = 0; index < img.keys.size(); index++)
             {
                 auto &digits = img.keys[index];
@@ -1464,8 +1465,9 @@ extern "C"
     SHL_FUNC Evaluator_SetStream(void *thisptr, void *hip_stream)
     {
         IfNullRet(thisptr, SHL_E_POINTER);
+        SHL_TRY
         as<Evaluator>(thisptr)->set_stream((hipStream_t)hip_stream);
-        return SHL_S_OK;
+        SHL_CATCH
     }
     SHL_FUNC Evaluator_BeginCapture(void *thisptr)
     {
@@ -1487,13 +1489,14 @@ extern "C"
         IfNullRet(thisptr, SHL_E_POINTER);
         IfNullRet(graph, SHL_E_POINTER);
         SHL_TRY
-        as<Evaluator>(thisptr)->launch_graph(static_cast<hipGraphExec_t>(graph));
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        as<Evaluator>(thisptr)->launch_graph(static_cast<const Evaluator::Graph *>(graph));
         SHL_CATCH
     }
     SHL_FUNC Graph_Destroy(void *graph)
     {
         IfNullRet(graph, SHL_E_POINTER);
-        (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph));
+        delete static_cast<Evaluator::Graph *>(graph); // its scratch blocks return to the pool
         return SHL_S_OK;
     }
     SHL_FUNC Evaluator_SetTransparentCheck(void *thisptr, bool enabled)
@@ -1506,6 +1509,7 @@ extern "C"
     {
         IfNullRet(thisptr, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->synchronize();
         SHL_CATCH
     }
@@ -1678,6 +1682,7 @@ extern "C"
         IfNullRet(plain, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->multiply_plain_inplace(prepare_dest(encrypted, destination), *as<Plaintext>(plain));
         SHL_CATCH
     }
@@ -1696,6 +1701,7 @@ extern "C"
         IfNullRet(parms_id, SHL_E_POINTER);
         IfNullRet(destination_ntt, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->transform_to_ntt_inplace(prepare_plain_dest(plain, destination_ntt), parms_id);
         SHL_CATCH
     }
@@ -1705,6 +1711,7 @@ extern "C"
         IfNullRet(plain, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->mod_switch_to_next_inplace(prepare_plain_dest(plain, destination));
         SHL_CATCH
     }
@@ -1715,6 +1722,7 @@ extern "C"
         IfNullRet(parms_id, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->mod_switch_to_inplace(prepare_plain_dest(plain, destination), parms_id);
         SHL_CATCH
     }
@@ -1724,6 +1732,7 @@ extern "C"
         IfNullRet(encrypteds, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         std::vector<const Ciphertext *> v;
         for (uint64_t i = 0; i < count; i++)
             v.push_back(as<Ciphertext>(encrypteds[i]));
@@ -1738,6 +1747,7 @@ extern "C"
         IfNullRet(relin_keys, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         std::vector<const Ciphertext *> v;
         for (uint64_t i = 0; i < count; i++)
             v.push_back(as<Ciphertext>(encrypteds[i]));
@@ -1752,6 +1762,7 @@ extern "C"
         IfNullRet(relin_keys, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->exponentiate_inplace(prepare_dest(encrypted, destination), exponent, *as<KSwitchKeys>(relin_keys));
         SHL_CATCH
     }
@@ -1763,6 +1774,7 @@ extern "C"
         IfNullRet(encrypted2, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         auto ev = as<Evaluator>(thisptr);
         if (encrypted2 == destination && encrypted1 != destination)
             ev->add_inplace(*as<Ciphertext>(destination), *as<Ciphertext>(encrypted1)); // evaluator.h add(): commutes
@@ -1777,6 +1789,7 @@ extern "C"
         IfNullRet(encrypted2, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         auto ev = as<Evaluator>(thisptr);
         if (encrypted2 == destination && encrypted1 != destination)
         {
@@ -1796,6 +1809,7 @@ extern "C"
         IfNullRet(encrypted2, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         auto ev = as<Evaluator>(thisptr);
         if (encrypted1 == encrypted2 && encrypted1 == destination)
             ev->multiply_inplace(*as<Ciphertext>(destination), *as<Ciphertext>(destination));
@@ -1811,6 +1825,7 @@ extern "C"
         IfNullRet(relinKeys, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->relinearize_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(relinKeys));
         SHL_CATCH
     }
@@ -1820,6 +1835,7 @@ extern "C"
         IfNullRet(encrypted, SHL_E_POINTER);
         IfNullRet(words, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         *words = as<Evaluator>(thisptr)->switch_key_acc_words(*as<Ciphertext>(encrypted));
         SHL_CATCH
     }
@@ -1831,6 +1847,7 @@ extern "C"
         IfNullRet(relinKeys, SHL_E_POINTER);
         IfNullRet(device_acc, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->relinearize_partial(*as<Ciphertext>(encrypted), *as<KSwitchKeys>(relinKeys), (unsigned)digit_first,
                                                     (unsigned)(digit_first + digit_count), device_acc);
         SHL_CATCH
@@ -1841,6 +1858,7 @@ extern "C"
         IfNullRet(encrypted, SHL_E_POINTER);
         IfNullRet(device_acc, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->relinearize_finish(*as<Ciphertext>(encrypted), device_acc, (unsigned)parts);
         SHL_CATCH
     }
@@ -1852,6 +1870,7 @@ extern "C"
         IfNullRet(galoisKeys, SHL_E_POINTER);
         IfNullRet(device_acc, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->apply_galois_partial(*as<Ciphertext>(encrypted), galois_elt, *as<KSwitchKeys>(galoisKeys),
                                                      (unsigned)digit_first, (unsigned)(digit_first + digit_count), device_acc);
         SHL_CATCH
@@ -1862,6 +1881,7 @@ extern "C"
         IfNullRet(encrypted, SHL_E_POINTER);
         IfNullRet(device_acc, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->apply_galois_finish(*as<Ciphertext>(encrypted), device_acc, (unsigned)parts);
         SHL_CATCH
     }
@@ -1873,6 +1893,7 @@ extern "C"
         IfNullRet(parms_id, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->mod_switch_to_inplace(prepare_dest(encrypted, destination), parms_id);
         SHL_CATCH
     }
@@ -1884,6 +1905,7 @@ extern "C"
         IfNullRet(parms_id, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->rescale_to_inplace(prepare_dest(encrypted, destination), parms_id);
         SHL_CATCH
     }
@@ -1895,6 +1917,7 @@ extern "C"
         IfNullRet(parms_id, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->mod_reduce_to_inplace(prepare_dest(encrypted, destination), parms_id);
         SHL_CATCH
     }
@@ -1906,6 +1929,7 @@ extern "C"
         IfNullRet(galoisKeys, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->apply_galois_inplace(prepare_dest(encrypted, destination), galois_elt, *as<KSwitchKeys>(galoisKeys));
         SHL_CATCH
     }
@@ -1917,6 +1941,7 @@ extern "C"
         IfNullRet(galoisKeys, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->rotate_rows_inplace(prepare_dest(encrypted, destination), steps, *as<KSwitchKeys>(galoisKeys));
         SHL_CATCH
     }
@@ -1928,6 +1953,7 @@ extern "C"
         IfNullRet(galois_keys, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->rotate_columns_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(galois_keys));
         SHL_CATCH
     }
@@ -1939,6 +1965,7 @@ extern "C"
         IfNullRet(galoisKeys, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->rotate_vector_inplace(prepare_dest(encrypted, destination), steps, *as<KSwitchKeys>(galoisKeys));
         SHL_CATCH
     }
@@ -1950,6 +1977,7 @@ extern "C"
         IfNullRet(galoisKeys, SHL_E_POINTER);
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->complex_conjugate_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(galoisKeys));
         SHL_CATCH
     }
@@ -2089,6 +2117,37 @@ extern "C"
         }
         else
             throw std::invalid_argument("unknown stage");
+        SHL_CATCH
+    }
+    SHL_FUNC SealHip_ReleasePool(void)
+    {
+        SHL_TRY
+        DevicePool::global().release_all();
+        SHL_CATCH
+    }
+    SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits)
+    {
+        SHL_TRY
+        if (bytes_held)
+            *bytes_held = DevicePool::global().bytes_held();
+        if (cross_stream_waits)
+            *cross_stream_waits = DevicePool::global().cross_stream_waits();
+        SHL_CATCH
+    }
+    SHL_FUNC shl_stream_create(bool non_blocking, void **hip_stream)
+    {
+        IfNullRet(hip_stream, SHL_E_POINTER);
+        SHL_TRY
+        hipStream_t s = nullptr;
+        hip_ok(hipStreamCreateWithFlags(&s, non_blocking ? hipStreamNonBlocking : hipStreamDefault), "hipStreamCreateWithFlags");
+        *hip_stream = s;
+        SHL_CATCH
+    }
+    SHL_FUNC shl_stream_destroy(void *hip_stream)
+    {
+        SHL_TRY
+        hip_ok(hipStreamSynchronize((hipStream_t)hip_stream), "hipStreamSynchronize");
+        hip_ok(hipStreamDestroy((hipStream_t)hip_stream), "hipStreamDestroy");
         SHL_CATCH
     }
     SHL_FUNC shl_malloc(uint64_t bytes, void **device_ptr)

@@ -98,73 +98,6 @@ namespace sealhip
         }
     } // namespace
 
-    // ---------------------------------------------------------------- DevicePool
-    DevicePool &DevicePool::global()
-    {
-        static DevicePool pool;
-        return pool;
-    }
-    uint64_t *DevicePool::alloc_words(size_t words)
-    {
-        size_t bytes = words * 8;
-        const size_t gran = size_t(256) << 10;
-        bytes = (bytes + gran - 1) / gran * gran;
-        if (!bytes)
-            bytes = gran;
-        std::lock_guard<std::mutex> g(mu_);
-        auto it = free_.lower_bound(bytes);
-        if (it != free_.end() && it->first <= bytes + bytes / 4 + gran)
-        {
-            uint64_t *p = it->second;
-            live_[p] = it->first;
-            free_.erase(it);
-            return p;
-        }
-        void *p = nullptr;
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e != hipSuccess)
-        {
-            // drop the cache and retry once
-            for (auto &kv : free_)
-            {
-                (void)hipFree(kv.second);
-                held_ -= kv.first;
-            }
-            free_.clear();
-            e = hipMalloc(&p, bytes);
-            if (e != hipSuccess)
-                throw std::bad_alloc();
-        }
-        held_ += bytes;
-        live_[(uint64_t *)p] = bytes;
-        return (uint64_t *)p;
-    }
-    void DevicePool::free_words(uint64_t *p)
-    {
-        if (!p)
-            return;
-        std::lock_guard<std::mutex> g(mu_);
-        auto it = live_.find(p);
-        if (it == live_.end())
-            return;
-        free_.emplace(it->second, p);
-        live_.erase(it);
-    }
-    void DevicePool::release_all()
-    {
-        std::lock_guard<std::mutex> g(mu_);
-        for (auto &kv : free_)
-        {
-            (void)hipFree(kv.second);
-            held_ -= kv.first;
-        }
-        free_.clear();
-    }
-    DevicePool::~DevicePool()
-    {
-        // process teardown: the HIP runtime may already be gone; leak rather than crash
-    }
-
     // ---------------------------------------------------------------- Ciphertext
     Ciphertext::~Ciphertext()
     {
@@ -205,7 +138,7 @@ namespace sealhip
         scale_ = o.scale_;
         correction_factor_ = o.correction_factor_;
         if (words)
-            ck(hipMemcpyAsync(data_, o.data_, words * 8, hipMemcpyDeviceToDevice, nullptr), "Ciphertext copy");
+            ck(hipMemcpyAsync(data_, o.data_, words * 8, hipMemcpyDeviceToDevice, DevicePool::thread_stream()), "Ciphertext copy");
         return *this;
     }
     void Ciphertext::resize(const Level *level, size_t size, hipStream_t stream)
@@ -277,7 +210,7 @@ namespace sealhip
         level_ = o.level_;
         scale_ = o.scale_;
         if (coeff_count_)
-            ck(hipMemcpyAsync(data_, o.data_, coeff_count_ * 8, hipMemcpyDeviceToDevice, nullptr), "Plaintext copy");
+            ck(hipMemcpyAsync(data_, o.data_, coeff_count_ * 8, hipMemcpyDeviceToDevice, DevicePool::thread_stream()), "Plaintext copy");
         return *this;
     }
     void Plaintext::resize(size_t coeff_count, hipStream_t stream)
@@ -319,6 +252,13 @@ namespace sealhip
         for (auto &k : keys_)
             if (k.dev)
                 (void)hipFree(k.dev);
+    }
+    void KSwitchKeys::clear()
+    {
+        for (auto &k : keys_)
+            if (k.dev)
+                (void)hipFree(k.dev); // synchronises with the device: no queued key switch still reads it
+        keys_.clear();
     }
     size_t KSwitchKeys::size() const
     {
@@ -388,6 +328,23 @@ namespace sealhip
             (void)hipFree(d_flag_);
         if (capture_stream_)
             (void)hipStreamDestroy(capture_stream_);
+        DevicePool::global().unregister_stream(capturing_ ? saved_stream_ : stream_);
+    }
+    void Evaluator::set_stream(hipStream_t s)
+    {
+        if (capturing_)
+            throw std::logic_error("a capture is in progress");
+        if (s == stream_)
+            return;
+        DevicePool::global().unregister_stream(stream_);
+        stream_ = s;
+        DevicePool::global().register_stream(stream_);
+    }
+    Evaluator::Graph::~Graph()
+    {
+        if (exec)
+            (void)hipGraphExecDestroy(exec);
+        DevicePool::global().release_held(scratch);
     }
     void Evaluator::begin_capture()
     {
@@ -397,7 +354,9 @@ namespace sealhip
             throw std::logic_error("the transparent-ciphertext check reads device memory back and cannot be captured");
         if (!capture_stream_)
             ck(hipStreamCreateWithFlags(&capture_stream_, hipStreamNonBlocking), "capture stream");
-        ck(hipStreamSynchronize(stream_), "stream synchronize");
+        // drain the device: every cached pool block is idle from here on, and the recording takes its scratch only from
+        // idle or fresh blocks, which then belong to the graph (pool.h)
+        ck(hipDeviceSynchronize(), "device synchronize");
         saved_stream_ = stream_;
         stream_ = capture_stream_;
         // relaxed: a pool miss may still hipMalloc while recording (it touches no stream)
@@ -407,9 +366,10 @@ namespace sealhip
             stream_ = saved_stream_;
             ck(e, "hipStreamBeginCapture");
         }
+        DevicePool::global().begin_hold();
         capturing_ = true;
     }
-    hipGraphExec_t Evaluator::end_capture()
+    Evaluator::Graph *Evaluator::end_capture()
     {
         if (!capturing_)
             throw std::logic_error("no capture in progress");
@@ -417,18 +377,21 @@ namespace sealhip
         hipError_t e = hipStreamEndCapture(stream_, &graph);
         stream_ = saved_stream_;
         capturing_ = false;
+        std::unique_ptr<Graph> g(new Graph);
+        g->scratch = DevicePool::global().end_hold();
         ck(e, "hipStreamEndCapture");
-        hipGraphExec_t exec = nullptr;
-        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         ck(e, "hipGraphInstantiate");
-        return exec;
+        return g.release();
     }
-    void Evaluator::launch_graph(hipGraphExec_t graph) const
+    void Evaluator::launch_graph(const Graph *graph) const
     {
         if (capturing_)
             throw std::logic_error("a capture is in progress");
-        ck(hipGraphLaunch(graph, stream_), "hipGraphLaunch");
+        if (!graph || !graph->exec)
+            throw std::invalid_argument("graph");
+        ck(hipGraphLaunch(graph->exec, stream_), "hipGraphLaunch");
     }
 
     void Evaluator::synchronize() const

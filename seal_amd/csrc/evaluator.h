@@ -122,6 +122,7 @@ namespace sealhip
         void set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device, size_t digit0 = 0);
         // the same with the words delivered by `upload(device_destination)` (e.g. piecewise from a serialized stream)
         void set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0 = 0);
+        void clear(); // drop every key (KSwitchKeys::load replaces the whole object, kswitchkeys.cpp:92-180)
         bool has_key(size_t index) const { return index < keys_.size() && keys_[index].dev != nullptr; }
         const Key &key(size_t index) const { return keys_[index]; }
         size_t slots() const { return keys_.size(); }
@@ -140,7 +141,9 @@ namespace sealhip
         ~Evaluator();
 
         const Context &context() const { return context_; }
-        void set_stream(hipStream_t s) { stream_ = s; }
+        // work of this evaluator is enqueued on `s` (nullptr = the NULL stream); the stream is registered with the device
+        // pool so that memory recycled between evaluators on different streams is ordered (pool.h)
+        void set_stream(hipStream_t s);
         hipStream_t stream() const { return stream_; }
         void synchronize() const;
         // SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (evaluator.cpp:386-392) needs a device->host round trip
@@ -187,9 +190,17 @@ namespace sealhip
         // destinations after each replay.  Run the sequence once eagerly first (lazily built tables, pool warm-up), keep the
         // captured objects alive and do not resize them between replays.  At small batches the step is launch-bound on the
         // host (about 25 kernel launches + stream fork/join per multiply+relinearize+rescale): see DESIGN.md section 5.
+        // an executable graph together with the scratch blocks whose addresses it replays on (kept out of the pool until
+        // the graph is destroyed)
+        struct Graph
+        {
+            hipGraphExec_t exec = nullptr;
+            std::vector<uint64_t *> scratch;
+            ~Graph();
+        };
         void begin_capture();
-        hipGraphExec_t end_capture();
-        void launch_graph(hipGraphExec_t graph) const;
+        Graph *end_capture();
+        void launch_graph(const Graph *graph) const;
 
         static size_t relin_index(size_t key_power);       // RelinKeys::get_index  (relinkeys.h:58)
         static size_t galois_index(uint32_t galois_elt);   // GaloisKeys::get_index (galoiskeys.h:48)

@@ -1,0 +1,286 @@
+// DevicePool: stream-aware caching allocator for HBM scratch and slabs (see pool.h).
+#include "pool.h"
+#include <new>
+
+namespace sealhip
+{
+    namespace
+    {
+        struct ThreadState
+        {
+            hipStream_t stream = nullptr;
+            bool scoped = false;
+            // graph-capture hold (begin_hold .. end_hold on this thread)
+            bool holding = false;
+            std::multimap<size_t, uint64_t *> hold_free;
+            std::vector<uint64_t *> hold_all;
+        };
+        ThreadState &ts()
+        {
+            static thread_local ThreadState s;
+            return s;
+        }
+        constexpr size_t kGran = size_t(256) << 10;
+        size_t round_bytes(size_t words)
+        {
+            size_t bytes = (words * 8 + kGran - 1) / kGran * kGran;
+            return bytes ? bytes : kGran;
+        }
+        bool fits(size_t have, size_t want)
+        {
+            return have <= want + want / 4 + kGran;
+        }
+    } // namespace
+
+    StreamScope::StreamScope(hipStream_t s) : prev_(ts().stream), prev_set_(ts().scoped)
+    {
+        ts().stream = s;
+        ts().scoped = true;
+    }
+    StreamScope::~StreamScope()
+    {
+        ts().stream = prev_;
+        ts().scoped = prev_set_;
+    }
+
+    DevicePool &DevicePool::global()
+    {
+        static DevicePool pool;
+        return pool;
+    }
+    hipStream_t DevicePool::thread_stream()
+    {
+        return ts().stream;
+    }
+    bool DevicePool::thread_has_scope()
+    {
+        return ts().scoped;
+    }
+
+    void DevicePool::register_stream(hipStream_t s)
+    {
+        if (!s)
+            return;
+        std::lock_guard<std::mutex> g(mu_);
+        streams_.insert(s);
+    }
+    void DevicePool::unregister_stream(hipStream_t s)
+    {
+        if (!s)
+            return;
+        std::lock_guard<std::mutex> g(mu_);
+        // blocks tagged with a stream that leaves the registry: its owner is about to destroy it (or stops using it);
+        // whatever it queued is ordered by one event now, while the handle is still valid
+        for (auto &kv : free_)
+            if (kv.second.tag == Tag::stream && kv.second.stream == s)
+            {
+                (void)hipStreamSynchronize(s);
+                kv.second.tag = Tag::idle;
+            }
+        streams_.erase(s);
+        auto it = events_.find(s);
+        if (it != events_.end())
+        {
+            (void)hipEventDestroy(it->second);
+            events_.erase(it);
+        }
+    }
+
+    // dst waits for everything queued on src so far
+    void DevicePool::order_after(hipStream_t src, hipStream_t dst)
+    {
+        if (src == dst)
+            return;
+        auto it = events_.find(src);
+        if (it == events_.end())
+        {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            {
+                (void)hipStreamSynchronize(src); // no event to be had: fall back to a host wait
+                return;
+            }
+            it = events_.emplace(src, ev).first;
+        }
+        if (hipEventRecord(it->second, src) != hipSuccess || hipStreamWaitEvent(dst, it->second, 0) != hipSuccess)
+        {
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize(); // a stale stream handle: nothing finer is available
+        }
+        waits_++;
+    }
+
+    void DevicePool::make_usable(const Block &b, hipStream_t user)
+    {
+        switch (b.tag)
+        {
+        case Tag::idle:
+            return;
+        case Tag::stream:
+            order_after(b.stream, user);
+            return;
+        case Tag::unknown:
+            order_after(nullptr, user);
+            for (hipStream_t s : streams_)
+                order_after(s, user);
+            return;
+        }
+    }
+
+    uint64_t *DevicePool::alloc_words(size_t words, hipStream_t stream)
+    {
+        const size_t bytes = round_bytes(words);
+        ThreadState &t = ts();
+        if (t.holding)
+        {
+            // recording a graph: recycle among the recorded operations, otherwise idle or fresh blocks only (no event may be
+            // recorded on or waited for by a capturing stream)
+            auto h = t.hold_free.lower_bound(bytes);
+            if (h != t.hold_free.end() && fits(h->first, bytes))
+            {
+                uint64_t *p = h->second;
+                std::lock_guard<std::mutex> g(mu_);
+                live_[p] = Live{ h->first, true };
+                t.hold_free.erase(h);
+                return p;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (auto it = free_.lower_bound(bytes); it != free_.end() && fits(it->first, bytes); ++it)
+            {
+                if (t.holding && it->second.tag != Tag::idle)
+                    continue;
+                Block b = it->second;
+                make_usable(b, stream);
+                live_[b.p] = Live{ it->first, t.holding };
+                free_.erase(it);
+                if (t.holding)
+                    t.hold_all.push_back(b.p);
+                return b.p;
+            }
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess)
+        {
+            (void)hipGetLastError();
+            if (!t.holding)
+            {
+                // drop the cache and retry once (hipFree synchronises the device: no tag needs honouring)
+                release_all();
+                e = hipMalloc(&p, bytes);
+            }
+            if (e != hipSuccess)
+            {
+                (void)hipGetLastError();
+                throw std::bad_alloc();
+            }
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        held_ += bytes;
+        live_[static_cast<uint64_t *>(p)] = Live{ bytes, t.holding };
+        if (t.holding)
+            t.hold_all.push_back(static_cast<uint64_t *>(p));
+        return static_cast<uint64_t *>(p);
+    }
+
+    void DevicePool::free_words(uint64_t *p)
+    {
+        if (!p)
+            return;
+        ThreadState &t = ts();
+        if (t.scoped)
+        {
+            free_words(p, t.stream);
+            return;
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = live_.find(p);
+        if (it == live_.end())
+            return;
+        free_.emplace(it->second.bytes, Block{ p, Tag::unknown, nullptr });
+        live_.erase(it);
+    }
+
+    void DevicePool::free_words(uint64_t *p, hipStream_t stream)
+    {
+        if (!p)
+            return;
+        ThreadState &t = ts();
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = live_.find(p);
+        if (it == live_.end())
+            return;
+        if (t.holding && it->second.held)
+            t.hold_free.emplace(it->second.bytes, p); // stays with the graph being recorded
+        else
+            free_.emplace(it->second.bytes, Block{ p, Tag::stream, stream });
+        live_.erase(it);
+    }
+
+    void DevicePool::begin_hold()
+    {
+        ThreadState &t = ts();
+        t.holding = true;
+        t.hold_free.clear();
+        t.hold_all.clear();
+        // the caller has drained the device: nothing queued anywhere touches a cached block
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto &kv : free_)
+            kv.second.tag = Tag::idle;
+    }
+
+    std::vector<uint64_t *> DevicePool::end_hold()
+    {
+        ThreadState &t = ts();
+        std::vector<uint64_t *> graph_owned;
+        std::lock_guard<std::mutex> g(mu_);
+        // scratch that was recycled inside the recording belongs to the graph from now on; blocks still live are owned by
+        // the objects that hold them (destinations resized during the recording) and go back to normal bookkeeping
+        for (auto &kv : t.hold_free)
+        {
+            graph_owned.push_back(kv.second);
+            graph_sizes_[kv.second] = kv.first;
+        }
+        for (uint64_t *p : t.hold_all)
+        {
+            auto it = live_.find(p);
+            if (it != live_.end())
+                it->second.held = false;
+        }
+        t.hold_free.clear();
+        t.hold_all.clear();
+        t.holding = false;
+        return graph_owned;
+    }
+
+    void DevicePool::release_held(const std::vector<uint64_t *> &blocks)
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        for (uint64_t *p : blocks)
+        {
+            auto it = graph_sizes_.find(p);
+            if (it == graph_sizes_.end())
+                continue;
+            free_.emplace(it->second, Block{ p, Tag::unknown, nullptr }); // replays may have run on any stream
+            graph_sizes_.erase(it);
+        }
+    }
+
+    void DevicePool::release_all()
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        for (auto &kv : free_)
+        {
+            (void)hipFree(kv.second.p); // synchronises with the device
+            held_ -= kv.first;
+        }
+        free_.clear();
+    }
+
+    DevicePool::~DevicePool()
+    {
+        // process teardown: the HIP runtime may already be gone; leak rather than crash
+    }
+} // namespace sealhip

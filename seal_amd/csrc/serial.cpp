@@ -197,13 +197,13 @@ namespace sealhip
                 std::list<std::vector<uint8_t>> inflated;        // decompressed payloads (stable addresses)
                 void skip(size_t n)
                 {
-                    if (n > size - pos)
+                    if (pos > size || n > size - pos)
                         throw std::runtime_error("I/O error");
                     pos += n;
                 }
                 void read(void *dst, size_t n)
                 {
-                    if (n > size - pos)
+                    if (pos > size || n > size - pos)
                         throw std::runtime_error("I/O error");
                     std::memcpy(dst, base + pos, n);
                     pos += n;
@@ -380,6 +380,11 @@ namespace sealhip
                     // serialization.cpp:430-515: the payload is one compressed stream of the member bytes; the members are parsed
                     // from the inflated buffer (which the images may point into: it is kept alive by the reader's owner)
                     const size_t payload = (size_t)h.size - sizeof(Header);
+                    // a nested object inside an inflated payload is not covered by the seekable-only size check above: the
+                    // reference's inflating stream buffer simply runs dry there ("I/O error"); here the payload is a pointer
+                    // range, so the bound has to be explicit whatever the reader is
+                    if (payload > r.size - r.pos)
+                        throw std::runtime_error("I/O error");
                     bool failed = false;
                     r.inflated.emplace_back(decompress(r.base + r.pos, payload, h.compr_mode, r.inflate_limit, &failed));
                     Reader inner{ r.inflated.back().data(), r.inflated.back().size() };
@@ -584,6 +589,19 @@ namespace sealhip
         {
             check_input(in, size);
             Reader r{ in, size };
+            {
+                // bound on one inflated payload: at most n key slots (GaloisKeys) of first_K digits, each a size-2 ciphertext at
+                // the key level with its own headers; a stream that inflates beyond what any valid object holds is refused
+                // before the host allocates for it
+                const size_t n = ctx.n(), first_K = ctx.first_level().K, L = ctx.key_level().K;
+                const size_t one_ct = 2 * L * n * 8 + 256;
+                size_t limit = 64 + n * 8;
+                const size_t keys_max = n * first_K; // cannot overflow: n <= 2^17, first_K <= 64
+                limit += keys_max * one_ct;
+                // and no valid key stream (uniform residues do not compress) inflates by more than deflate's maximum ratio
+                const size_t by_ratio = std::max<size_t>(size_t(1) << 20, size > (size_t(1) << 50) ? ~size_t(0) : size * 1100);
+                r.inflate_limit = std::min(std::min(limit, by_ratio), size_t(1) << 40);
+            }
             KSwitchKeysImage img;
             uint64_t parms_id[4] = { 0, 0, 0, 0 };
             std::vector<ExpandJob> jobs; // the heap buffers they point into do not move when the images are moved

@@ -251,7 +251,7 @@ static inline hipError_t hipEventCreate(hipEvent_t *e)
     return hipSuccess;
 }
 // streams are synchronous in the emulator: creation hands out a dummy handle, waits are no-ops
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned)
 {
     *s = nullptr;

@@ -135,6 +135,59 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
             _eq(back[b], cur[b], "transform_to_ntt(transform_from_ntt(x)) item %d" % b)
 
 
+# ---- large device-resident batches (the shapes bench.py times): inputs are generated on the device, a sample of items is
+#      downloaded and compared with the reference's multiply + relinearize + rescale (+ rotate) on the same words
+def device_uniform_words(primes, prefix, n, seed):
+    """[*prefix][len(primes)][n] uniform residues generated in HBM (torch only as the device RNG) -> int64 torch tensor"""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    comps = [torch.randint(0, int(q), tuple(prefix) + (1, n), dtype=torch.int64, device="cuda", generator=g) for q in primes]
+    return torch.cat(comps, dim=len(prefix)).contiguous()
+
+
+def case_ckks_big_batch(n, bits, batch, check_items, seed=11, rotate=True):
+    import torch
+    primes = coeff_modulus_create(n, bits)
+    L = len(primes)
+    K = L - 1
+    probe = Oracle("ckks", n, primes)
+    elt = probe.galois_elt_from_step(1)
+    o = Oracle("ckks", n, primes, galois_elts=[elt])
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    xs = device_uniform_words(primes[:K], (2, batch), n, seed)
+    ys = device_uniform_words(primes[:K], (2, batch), n, seed + 1)
+    pid = d.parms_id_for_K(K)
+
+    def make(t):
+        ct = S.Ciphertext(d.ctx, batch=batch)
+        ct.resize(pid, 2)
+        ct.set_is_ntt_form(True)
+        ct.set_scale(2.0 ** 10)
+        ct.load_device(t.data_ptr(), t.numel())
+        return ct
+
+    cx, cy = make(xs), make(ys)
+    torch.cuda.synchronize()
+    work = S.Ciphertext(d.ctx, batch=batch)
+    d.ev.multiply(cx, cy, work)
+    d.ev.relinearize_inplace(work, d.rlk)
+    work.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+    d.ev.rescale_to_next_inplace(work)
+    mid = {b: work.item_to_numpy(b) for b in check_items}
+    if rotate:
+        d.ev.rotate_vector_inplace(work, 1, d.glk)
+    assert work.size() == 2 and work.coeff_modulus_size() == K - 1 and work.batch() == batch
+    for b in check_items:
+        x = xs[:, b].cpu().numpy().astype(np.uint64)
+        y = ys[:, b].cpu().numpy().astype(np.uint64)
+        exp = o.rescale(o.relinearize(o.multiply(x, y)))
+        _eq(mid[b], exp, "multiply+relinearize+rescale item %d of %d" % (b, batch))
+        if rotate:
+            _eq(work.item_to_numpy(b), o.apply_galois(exp, elt), "rotate_vector item %d of %d" % (b, batch))
+
+
 # ---- BFV: BFVEncryptMultiplyDecrypt / BFVRelinearize / BFVEncryptModSwitchToNextDecrypt /
 #      BFVEncryptRotateMatrixDecrypt (native/tests/seal/evaluator.cpp:1356, 2430, 5722, 5670)
 def case_bfv_pipeline(n, primes, t, batch=2, seed=4):

@@ -310,6 +310,22 @@ def case_compressed_streams(scheme, n, bits):
                 _same_failure(ref, d, bad, unsafe)
             except AssertionError as e:
                 raise AssertionError("zlib %s (unsafe=%s): %s" % (name, unsafe, e))
+    # nested compressed objects inside a compressed outer object: the DynArray's own SEALHeader claims zlib and a
+    # size far beyond the inflated buffer, followed by a valid inner zlib stream; and the legitimate form of the same nesting
+    members_off, dyn_off = 16, 16 + 32 + 1 + 40
+    inner_raw = data[dyn_off + 16:]
+    inner_z = zlib.compress(inner_raw)
+    def nested(claimed):
+        nested_dyn = data[dyn_off:dyn_off + 5] + b"\x01" + data[dyn_off + 6:dyn_off + 8] + struct.pack("<Q", claimed) + inner_z
+        return _recompress(data[:dyn_off] + nested_dyn, 1, zlib.compress)
+    for unsafe in (False, True):
+        # the legitimate nesting loads on both sides
+        assert _same_failure(ref, d, nested(16 + len(inner_z)), unsafe) is None
+        # a nested size beyond the inflated buffer: "I/O error" here.  (The reference build in this image does not survive
+        # these two streams - an ios failure escapes its loader and std::terminate ends the process - so there is no class
+        # to compare with; what matters is that nothing is read past the inflated buffer.)
+        for claimed in (1 << 44, 16 + len(inner_z) + 4096):
+            assert _outcome(lambda: S.Ciphertext(d.ctx).load_bytes(nested(claimed), unsafe=unsafe)) == S.DeviceError
     # --- zstd (libzstd on both sides of the check; the reference build has no zstd)
     zs = _zstd()
     if zs is None:

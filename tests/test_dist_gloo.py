@@ -47,3 +47,29 @@ def test_world_size_2_gloo(emu):
     # digit-parallel key switching: ranks 0 and 1 served digits [0,2) and [2,3) of K = 3 and both match the oracle
     assert "DIGIT_PARALLEL_OK rank=0 digits=[0,2)" in outs[0], outs[0]
     assert "DIGIT_PARALLEL_OK rank=1 digits=[2,3)" in outs[1], outs[1]
+
+
+@pytest.mark.parametrize("workload", ["headline", "bfv_c4", "rotate_c5"])
+def test_bench_gpus_2_starts_two_ranks(emu, workload):
+    """`python bench.py --gpus 2` with no torchrun environment starts the two ranks itself; here on the
+    emulated kernels with gloo (SEALHIP_BENCH_EMU=1).  The line must say n_gpus 2, both ranks' sampled items must have
+    been checked against the reference, and a WORLD_SIZE that disagrees with --gpus is refused."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SEALHIP_BENCH_EMU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", workload], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 2
+    assert line["scaling"] == ("weak" if workload == "headline" else "strong")
+    import sealref
+    if sealref.available():
+        assert line["verified_items"] == 4  # two items per rank
+    # a launcher that started a different number of ranks than --gpus says is an error, not a silent n_gpus
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stdout + bad.stderr)

@@ -86,6 +86,31 @@ def test_ckks_north_star_config(gpu):
     P.case_ckks_pipeline(65536, [60] + [50] * 14 + [60], batch=2, steps=(1,), check_transforms=False)
 
 
+# ---- parity at the launch configuration bench.py times: un-split key switch, many items per (I, tile)
+def test_ckks_north_star_unsplit_key_switch(gpu, monkeypatch):
+    """C5 with SEALHIP_KS_SPLIT=1: the one-group-per-workgroup ks1/ks2 kernels that batch >= 8 selects (bench.py: batch 256),
+    here forced at batch 2; multiply + relinearize + rescale + rotate item by item vs the reference."""
+    monkeypatch.setenv("SEALHIP_KS_SPLIT", "1")
+    P.case_ckks_pipeline(65536, [60] + [50] * 14 + [60], batch=2, steps=(1,), check_transforms=False)
+
+
+def test_ckks_north_star_batch16(gpu):
+    """C5, batch 16: split = 1 by the launcher's own rule, XCD-ordered grid over several batch items per (I, tile);
+    every item of every stage compared with the reference (evaluator.cpp:2561-2867)."""
+    P.case_ckks_pipeline(65536, [60] + [50] * 14 + [60], batch=16, steps=(1,), check_transforms=False)
+
+
+def test_ckks_batch1024_scratch_beyond_2_pow_32_words(gpu):
+    """batch 1024 at a two-pass size (CKKS N=32768, K=13): the key-switch intermediate is 1024*14*13*32768 = 6.1e9 words,
+    beyond 2^32 — index arithmetic of the batched launches; sampled items vs the reference."""
+    P.case_ckks_big_batch(32768, [60] + [50] * 12 + [60], batch=1024, check_items=(0, 1, 511, 512, 777, 1023))
+
+
+def test_ckks_north_star_batch256_sampled(gpu):
+    """the shape bench.py times (C5, batch 256, intermediate 4.03e9 words): first / middle / last items vs the reference"""
+    P.case_ckks_big_batch(65536, [60] + [50] * 14 + [60], batch=256, check_items=(0, 127, 128, 255))
+
+
 # ---- BFV pipelines: small, BASELINE config 1 (N=4096 BFVDefault sizes) and config 4 (N=32768, 14 primes)
 @pytest.mark.parametrize("n,bits,tb,batch", [
     (16, [30, 30, 30, 30], 12, 3),
@@ -454,3 +479,117 @@ def test_ks2_second_geometry_in_a_subprocess(gpu):
             % (here, os.path.dirname(here)))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SEALHIP_KS2_V2="1"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "v2 ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+# ---- streams: non-blocking streams, out-of-place forms in a captured graph, two evaluators sharing the pool
+def _ckks_setup(n, bits, galois=True):
+    import numpy as np
+    from harness import DeviceSide
+    from oracle import Oracle, coeff_modulus_create
+    primes = coeff_modulus_create(n, bits)
+    probe = Oracle("ckks", n, primes)
+    elt = probe.galois_elt_from_step(1)
+    o = Oracle("ckks", n, primes, galois_elts=[elt] if galois else [])
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    return primes, o, d, elt
+
+
+def test_non_blocking_stream_parity(gpu):
+    """the whole pipeline on a hipStreamNonBlocking stream (what a PyTorch stream is), out-of-place forms included: the
+    destination copy runs on the evaluator's stream, not on the NULL stream"""
+    import numpy as np
+    import seal_amd as S
+    from oracle import rand_ct
+    n, bits = 8192, [60, 40, 40, 60]
+    primes, o, d, elt = _ckks_setup(n, bits)
+    K = len(primes) - 1
+    stream = S.Stream(non_blocking=True)
+    d.ev.set_stream(stream.handle)
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        x, y = rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)
+        cx, cy = d.ct([x], scale=2.0 ** 10), d.ct([y], scale=2.0 ** 10)
+        prod, rel, res = S.Ciphertext(d.ctx), S.Ciphertext(d.ctx), S.Ciphertext(d.ctx)
+        d.ev.multiply(cx, cy, prod)
+        d.ev.relinearize(prod, d.rlk, rel)              # destination != source: copy + operation on `stream`
+        rel.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+        d.ev.rescale_to_next(rel, res)
+        d.ev.rotate_vector_inplace(res, 1, d.glk)
+        exp = o.apply_galois(o.rescale(o.relinearize(o.multiply(x, y))), elt)
+        assert np.array_equal(d.out(res)[0], exp), "trial %d" % trial
+    d.ev.set_stream(None)
+
+
+def test_graph_capture_out_of_place_forms(gpu):
+    """a recorded sequence of destination forms (square -> relinearize -> rescale, each into its own object) replays on
+    refreshed operands: the destination copies are part of the graph"""
+    import numpy as np
+    import seal_amd as S
+    from oracle import rand_ct
+    n, bits = 8192, [60, 40, 40, 60]
+    primes, o, d, elt = _ckks_setup(n, bits, galois=False)
+    K = len(primes) - 1
+    rng = np.random.default_rng(6)
+    x = rand_ct(rng, primes, K, n)
+    cx = d.ct([x], scale=2.0 ** 10)
+    sq, rel, res = S.Ciphertext(d.ctx), S.Ciphertext(d.ctx), S.Ciphertext(d.ctx)
+
+    def step():
+        d.ev.square(cx, sq)
+        d.ev.relinearize(sq, d.rlk, rel)
+        rel.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+        d.ev.rescale_to_next(rel, res)
+
+    def expected(v):
+        return o.rescale(o.relinearize(o.multiply(v, v)))
+
+    step()
+    assert np.array_equal(d.out(res)[0], expected(x))
+    graph = d.ev.capture(step)
+    for trial in range(3):
+        x = rand_ct(rng, primes, K, n)
+        cx.load(x[:, None])
+        graph.launch()
+        assert np.array_equal(d.out(res)[0], expected(x)), "replay %d" % trial
+    # the graph owns the scratch it recorded: eager work in between must not disturb a later replay
+    other = d.ct([rand_ct(rng, primes, K, n)], scale=2.0 ** 10)
+    d.ev.square_inplace(other)
+    d.ev.relinearize_inplace(other, d.rlk)
+    graph.launch()
+    assert np.array_equal(d.out(res)[0], expected(x))
+    del graph
+
+
+def test_two_evaluators_two_streams_share_the_pool(gpu):
+    """two evaluators on two non-blocking streams issue interleaved work from one host thread; the scratch blocks one frees are
+    handed to the other (same sizes), so the pool has to order the streams; every result equals the reference's"""
+    import numpy as np
+    import seal_amd as S
+    from oracle import rand_ct
+    n, bits = 16384, [60, 50, 50, 50, 60]
+    primes, o, d, elt = _ckks_setup(n, bits, galois=False)
+    K = len(primes) - 1
+    ev2 = S.Evaluator(d.ctx)
+    s1, s2 = S.Stream(True), S.Stream(True)
+    d.ev.set_stream(s1.handle)
+    ev2.set_stream(s2.handle)
+    rng = np.random.default_rng(8)
+    batch = 8
+    waits0 = S.pool_stats()[1]
+    xs = [[rand_ct(rng, primes, K, n) for _ in range(batch)] for _ in range(2)]
+    ys = [[rand_ct(rng, primes, K, n) for _ in range(batch)] for _ in range(2)]
+    cts = [(d.ct(xs[i], scale=2.0 ** 10), d.ct(ys[i], scale=2.0 ** 10)) for i in range(2)]
+    outs = [S.Ciphertext(d.ctx, batch=batch) for _ in range(2)]
+    evs = [d.ev, ev2]
+    for rnd in range(4):
+        for i in range(2):          # no host synchronisation between the two evaluators' calls
+            evs[i].multiply(cts[i][0], cts[i][1], outs[i])
+            evs[i].relinearize_inplace(outs[i], d.rlk)
+        for i in range(2):
+            got = d.out(outs[i])
+            for b in range(batch):
+                assert np.array_equal(got[b], o.relinearize(o.multiply(xs[i][b], ys[i][b]))), "round %d evaluator %d item %d" % (rnd, i, b)
+    assert S.pool_stats()[1] > waits0, "scratch never changed stream: the test did not exercise the ordering"
+    d.ev.set_stream(None)
+    ev2.set_stream(None)
