@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="ciphertexts per GPU per step (default: 256 for the headline workload; "
                     "SURVEY 8(d): device-resident throughput batches of 64 / 256 / 1024)")
     ap.add_argument("--total-batch", type=int, default=1024, help="bfv_c4: ciphertexts per step over ALL ranks (BASELINE configs[3])")
+    ap.add_argument("--exchange", choices=["all_reduce", "reduce_scatter"], default="all_reduce",
+                    help="rotate_c5: shape of the key-switch exchange (sealhip.h section 1c), RCCL calls inside the library")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the reference check of sampled output items")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 PMC passes for roofline.traffic")
@@ -177,7 +179,7 @@ def main():
     if args.workload == "rotate_c5":
         elt = ctx.galois_elt_from_step(1)
         keys = S.GaloisKeys(ctx)
-        dp = shard.DigitParallel(ev, torch, group, device)
+        dp = shard.DigitParallel(ev, torch, group, device, exchange=args.exchange)
         d0, dc = dp.digit_range(K)
         if world > 1 and dc:
             keys.set_key_digits(S.GaloisKeys.get_index(elt), d0, key[d0:d0 + dc].cpu().numpy().view("uint64"))
@@ -306,7 +308,8 @@ def main():
         }[args.workload]
         par = {"headline": "batch-sharded x%d, no data-path collective" % world,
                "bfv_c4": "total batch sharded x%d, no data-path collective" % world,
-               "rotate_c5": "key-switch digits split x%d, one all-reduce per key switch" % world}[args.workload]
+               "rotate_c5": "key-switch digits split x%d, exchange %s per key switch (%s)" % (
+                   world, args.exchange, "RCCL inside libsealhip" if dp is not None and dp.comm is not None else "torch.distributed")}[args.workload]
         line = dict(
             metric=names[0], value=round(result.get("value", 0.0), 2), unit="ciphertexts/s", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(result.get("ms_per_step", 0.0), 3), higher_is_better=True,

@@ -333,6 +333,46 @@ SHL_FUNC Evaluator_ApplyGaloisPartial(void *thisptr, void *encrypted /* size 2 *
 SHL_FUNC Evaluator_ApplyGaloisFinish(void *thisptr, void *encrypted, uint64_t *device_acc, uint64_t parts);
 
 /* ------------------------------------------------------------------------------------------------
+ * 1c. The same with the exchange INSIDE the library: RCCL over xGMI, one process per GPU, collectives enqueued on the
+ * evaluator's stream (no host synchronisation between the partial sums, the exchange and the mod-down).  The reference
+ * has no counterpart (it is a single-host library); the loop being distributed is native/src/seal/evaluator.cpp:2663-2755
+ * (digits) and 2806-2864 (target moduli).
+ *   Comm_GetUniqueId     rank 0 draws the 128-byte RCCL id and hands it to the other ranks out of band
+ *   Comm_Create          ncclCommInitRank on the calling thread's current device (collective over all ranks; nranks <= 8);
+ *                        nranks == 1 also works without RCCL (loopback).  librccl.so.1 is loaded at run time.
+ *   Comm_DigitRange      the contiguous share [first, first + count) of `digits` this rank multiplies
+ *   Evaluator_BroadcastKeyDigits  one-time key distribution: `device_staging` (K*2*L*N words on every rank; on `root` the key
+ *                        [digit][2][L][N]) is broadcast, every rank keeps its own digits resident
+ *   Evaluator_*DigitParallel      relinearize / apply_galois / rotate_vector; every rank calls with equal ciphertexts.
+ *     exchange 0: ONE all-reduce of 2 (K+1) N words per ciphertext, every rank runs the whole mod-down;
+ *     exchange 1 (CKKS): reduce-scatter of the K data moduli's sums by owner + all-reduce of the special-prime component +
+ *                 mod-down of the rank's own moduli + all-gather of the increments - the same bytes on the wire, the mod-down
+ *                 divided by the number of ranks (BFV / BGV fall back to exchange 0).
+ *   Results are bit-identical to Evaluator_Relinearize / Evaluator_ApplyGalois / Evaluator_RotateVector on one GPU.
+ *   Evaluator_SwitchKeySlots / PackTargets / FinishOwned / AddGathered are the local phases of exchange 1 (layouts in
+ *   seal_amd/csrc/evaluator.h); with them a caller can run the exchange through its own collective library. */
+SHL_FUNC Comm_GetUniqueId(uint8_t *id128);
+SHL_FUNC Comm_RcclAvailable(bool *available);
+SHL_FUNC Comm_Create(const uint8_t *id128, int nranks, int rank, void **comm);
+SHL_FUNC Comm_Destroy(void *comm);
+SHL_FUNC Comm_Info(void *comm, int *nranks, int *rank, bool *loopback);
+SHL_FUNC Comm_DigitRange(void *comm, uint64_t digits, uint64_t *first, uint64_t *count);
+SHL_FUNC Comm_AllReduceWords(void *comm, uint64_t *device_words, uint64_t count, void *hip_stream);
+SHL_FUNC Comm_BroadcastWords(void *comm, uint64_t *device_words, uint64_t count, int root, void *hip_stream);
+SHL_FUNC Evaluator_RelinearizeDigitParallel(void *thisptr, void *encrypted, void *relinKeys, void *comm, int exchange, void *destination);
+SHL_FUNC Evaluator_ApplyGaloisDigitParallel(void *thisptr, void *encrypted, uint32_t galois_elt, void *galoisKeys, void *comm, int exchange,
+                                            void *destination);
+SHL_FUNC Evaluator_RotateVectorDigitParallel(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *comm, int exchange,
+                                             void *destination);
+SHL_FUNC Evaluator_BroadcastKeyDigits(void *thisptr, void *kswitch_keys, uint64_t index, uint64_t *device_staging, void *comm, int root);
+SHL_FUNC Evaluator_SwitchKeySlots(void *thisptr, void *encrypted, uint64_t nranks, uint64_t *slots);
+SHL_FUNC Evaluator_SwitchKeyPackTargets(void *thisptr, void *encrypted, const uint64_t *device_acc, uint64_t nranks, uint64_t *device_send,
+                                        uint64_t *device_special);
+SHL_FUNC Evaluator_SwitchKeyFinishOwned(void *thisptr, void *encrypted, const uint64_t *device_recv, const uint64_t *device_special,
+                                        uint64_t nranks, uint64_t rank, uint64_t *device_own);
+SHL_FUNC Evaluator_SwitchKeyAddGathered(void *thisptr, void *encrypted, const uint64_t *device_all, uint64_t nranks);
+
+/* ------------------------------------------------------------------------------------------------
  * 2. Per-kernel seam on raw device slabs (device pointers; `stream` is a hipStream_t or NULL)
  * ---------------------------------------------------------------------------------------------- */
 

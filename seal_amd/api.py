@@ -989,12 +989,87 @@ class Evaluator:
     def apply_galois_finish(self, a, acc_ptr, parts):
         N.check(N.lib().Evaluator_ApplyGaloisFinish(self._h, a._h, C.c_void_p(acc_ptr), C.c_uint64(parts)))
 
+    # -- digit-parallel forms with the exchange inside the library (sealhip.h section 1c)
+    def relinearize_inplace_dp(self, a, relin_keys, comm, exchange=0):
+        N.check(N.lib().Evaluator_RelinearizeDigitParallel(self._h, a._h, relin_keys._h, comm._h, C.c_int(exchange), a._h))
+        return a
+
+    def apply_galois_inplace_dp(self, a, galois_elt, galois_keys, comm, exchange=0):
+        N.check(N.lib().Evaluator_ApplyGaloisDigitParallel(self._h, a._h, C.c_uint32(galois_elt), galois_keys._h, comm._h, C.c_int(exchange), a._h))
+        return a
+
+    def rotate_vector_inplace_dp(self, a, steps, galois_keys, comm, exchange=0):
+        N.check(N.lib().Evaluator_RotateVectorDigitParallel(self._h, a._h, C.c_int(steps), galois_keys._h, comm._h, C.c_int(exchange), a._h))
+        return a
+
+    def broadcast_key_digits(self, keys, index, staging_ptr, comm, root=0):
+        N.check(N.lib().Evaluator_BroadcastKeyDigits(self._h, keys._h, C.c_uint64(index), C.c_void_p(staging_ptr), comm._h, C.c_int(root)))
+
+    def switch_key_slots(self, a, nranks):
+        v = C.c_uint64()
+        N.check(N.lib().Evaluator_SwitchKeySlots(self._h, a._h, C.c_uint64(nranks), C.byref(v)))
+        return v.value
+
+    def switch_key_pack_targets(self, a, acc_ptr, nranks, send_ptr, special_ptr):
+        N.check(N.lib().Evaluator_SwitchKeyPackTargets(self._h, a._h, C.c_void_p(acc_ptr), C.c_uint64(nranks), C.c_void_p(send_ptr), C.c_void_p(special_ptr)))
+
+    def switch_key_finish_owned(self, a, recv_ptr, special_ptr, nranks, rank, own_ptr):
+        N.check(N.lib().Evaluator_SwitchKeyFinishOwned(self._h, a._h, C.c_void_p(recv_ptr), C.c_void_p(special_ptr), C.c_uint64(nranks),
+                                                       C.c_uint64(rank), C.c_void_p(own_ptr)))
+
+    def switch_key_add_gathered(self, a, all_ptr, nranks):
+        N.check(N.lib().Evaluator_SwitchKeyAddGathered(self._h, a._h, C.c_void_p(all_ptr), C.c_uint64(nranks)))
+
     def complex_conjugate_inplace(self, a, galois_keys):
         N.check(N.lib().Evaluator_ComplexConjugate(self._h, a._h, galois_keys._h, a._h, None))
         return a
 
 
 # ---- per-kernel seam on raw device slabs -------------------------------------------------------
+class Comm:
+    """One rank of a communicator over the GPUs of a node (sealhip.h section 1c): RCCL, collectives on the evaluator's stream."""
+    ALL_REDUCE, REDUCE_SCATTER = 0, 1
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        N.check(N.lib().Comm_GetUniqueId(buf))
+        return bytes(buf)
+
+    @staticmethod
+    def rccl_available():
+        v = C.c_bool()
+        N.check(N.lib().Comm_RcclAvailable(C.byref(v)))
+        return v.value
+
+    def __init__(self, unique_id, nranks, rank):
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128)(*bytes(unique_id))
+        N.check(N.lib().Comm_Create(buf, C.c_int(nranks), C.c_int(rank), C.byref(self._h)))
+        self.nranks, self.rank = nranks, rank
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            N.lib().Comm_Destroy(self._h)
+            self._h = None
+
+    def loopback(self):
+        v = C.c_bool()
+        N.check(N.lib().Comm_Info(self._h, None, None, C.byref(v)))
+        return v.value
+
+    def digit_range(self, digits):
+        a, b = C.c_uint64(), C.c_uint64()
+        N.check(N.lib().Comm_DigitRange(self._h, C.c_uint64(digits), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def all_reduce(self, device_ptr, words, stream=None):
+        N.check(N.lib().Comm_AllReduceWords(self._h, C.c_void_p(device_ptr), C.c_uint64(words), C.c_void_p(stream or 0)))
+
+    def broadcast(self, device_ptr, words, root=0, stream=None):
+        N.check(N.lib().Comm_BroadcastWords(self._h, C.c_void_p(device_ptr), C.c_uint64(words), C.c_int(root), C.c_void_p(stream or 0)))
+
+
 class DeviceBuffer:
     """A raw uint64 slab in HBM (shl_malloc) for the per-kernel entry points."""
 

@@ -1520,6 +1520,7 @@ extern "C"
         IfNullRet(encrypted, SHL_E_POINTER);                         \
         IfNullRet(destination, SHL_E_POINTER);                       \
         SHL_TRY                                                      \
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());   \
         auto ev = as<Evaluator>(thisptr);                            \
         Ciphertext &d = prepare_dest(encrypted, destination);        \
         ev->call(d);                                                 \
@@ -1533,6 +1534,7 @@ extern "C"
         IfNullRet(encrypted, SHL_E_POINTER);                                     \
         IfNullRet(destination, SHL_E_POINTER);                                   \
         SHL_TRY                                                                  \
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());               \
         auto ev = as<Evaluator>(thisptr);                                        \
         Ciphertext &d = prepare_dest(encrypted, destination);                    \
         ev->call(d);                                                             \
@@ -1669,6 +1671,7 @@ extern "C"
         IfNullRet(plain, SHL_E_POINTER);                                         \
         IfNullRet(destination, SHL_E_POINTER);                                   \
         SHL_TRY                                                                  \
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());               \
         as<Evaluator>(thisptr)->call(prepare_dest(encrypted, destination), *as<Plaintext>(plain)); \
         SHL_CATCH                                                                \
     }
@@ -1883,6 +1886,174 @@ extern "C"
         SHL_TRY
         StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
         as<Evaluator>(thisptr)->apply_galois_finish(*as<Ciphertext>(encrypted), device_acc, (unsigned)parts);
+        SHL_CATCH
+    }
+    // ------------------------------------------------------------------ communicator + digit-parallel forms with the exchange
+    // inside the library (sealhip.h section 1c; comm.h)
+    SHL_FUNC Comm_GetUniqueId(uint8_t *id128)
+    {
+        IfNullRet(id128, SHL_E_POINTER);
+        SHL_TRY
+        Comm::unique_id(id128);
+        SHL_CATCH
+    }
+    SHL_FUNC Comm_RcclAvailable(bool *available)
+    {
+        IfNullRet(available, SHL_E_POINTER);
+        SHL_TRY
+        *available = Comm::rccl_available();
+        SHL_CATCH
+    }
+    SHL_FUNC Comm_Create(const uint8_t *id128, int nranks, int rank, void **comm)
+    {
+        IfNullRet(comm, SHL_E_POINTER);
+        SHL_TRY
+        *comm = new Comm(id128, nranks, rank);
+        SHL_CATCH
+    }
+    SHL_FUNC Comm_Destroy(void *comm)
+    {
+        IfNullRet(comm, SHL_E_POINTER);
+        delete as<Comm>(comm);
+        return SHL_S_OK;
+    }
+    SHL_FUNC Comm_Info(void *comm, int *nranks, int *rank, bool *loopback)
+    {
+        IfNullRet(comm, SHL_E_POINTER);
+        SHL_TRY
+        if (nranks)
+            *nranks = as<Comm>(comm)->size();
+        if (rank)
+            *rank = as<Comm>(comm)->rank();
+        if (loopback)
+            *loopback = as<Comm>(comm)->loopback();
+        SHL_CATCH
+    }
+    SHL_FUNC Comm_DigitRange(void *comm, uint64_t digits, uint64_t *first, uint64_t *count)
+    {
+        IfNullRet(comm, SHL_E_POINTER);
+        IfNullRet(first, SHL_E_POINTER);
+        IfNullRet(count, SHL_E_POINTER);
+        SHL_TRY
+        unsigned f, c;
+        comm_split((unsigned)digits, (unsigned)as<Comm>(comm)->size(), (unsigned)as<Comm>(comm)->rank(), f, c);
+        *first = f;
+        *count = c;
+        SHL_CATCH
+    }
+    SHL_FUNC Comm_AllReduceWords(void *comm, uint64_t *device_words, uint64_t count, void *hip_stream)
+    {
+        IfNullRet(comm, SHL_E_POINTER);
+        IfNullRet(device_words, SHL_E_POINTER);
+        SHL_TRY
+        as<Comm>(comm)->all_reduce_sum(device_words, (size_t)count, (hipStream_t)hip_stream);
+        SHL_CATCH
+    }
+    SHL_FUNC Comm_BroadcastWords(void *comm, uint64_t *device_words, uint64_t count, int root, void *hip_stream)
+    {
+        IfNullRet(comm, SHL_E_POINTER);
+        IfNullRet(device_words, SHL_E_POINTER);
+        SHL_TRY
+        as<Comm>(comm)->broadcast(device_words, (size_t)count, root, (hipStream_t)hip_stream);
+        SHL_CATCH
+    }
+    static Evaluator::KsExchange exchange_of(int how)
+    {
+        if (how != 0 && how != 1)
+            throw std::invalid_argument("exchange: 0 = all-reduce, 1 = reduce-scatter + all-gather");
+        return how ? Evaluator::KsExchange::reduce_scatter : Evaluator::KsExchange::all_reduce;
+    }
+    SHL_FUNC Evaluator_RelinearizeDigitParallel(void *thisptr, void *encrypted, void *relinKeys, void *comm, int exchange, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(relinKeys, SHL_E_POINTER);
+        IfNullRet(comm, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        as<Evaluator>(thisptr)->relinearize_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(relinKeys), *as<Comm>(comm),
+                                                    exchange_of(exchange));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_ApplyGaloisDigitParallel(void *thisptr, void *encrypted, uint32_t galois_elt, void *galoisKeys, void *comm, int exchange,
+                                                void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(galoisKeys, SHL_E_POINTER);
+        IfNullRet(comm, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        as<Evaluator>(thisptr)->apply_galois_inplace(prepare_dest(encrypted, destination), galois_elt, *as<KSwitchKeys>(galoisKeys),
+                                                     *as<Comm>(comm), exchange_of(exchange));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_RotateVectorDigitParallel(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *comm, int exchange,
+                                                 void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(galoisKeys, SHL_E_POINTER);
+        IfNullRet(comm, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        as<Evaluator>(thisptr)->rotate_vector_inplace(prepare_dest(encrypted, destination), steps, *as<KSwitchKeys>(galoisKeys), *as<Comm>(comm),
+                                                      exchange_of(exchange));
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_BroadcastKeyDigits(void *thisptr, void *kswitch_keys, uint64_t index, uint64_t *device_staging, void *comm, int root)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(kswitch_keys, SHL_E_POINTER);
+        IfNullRet(device_staging, SHL_E_POINTER);
+        IfNullRet(comm, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        as<Evaluator>(thisptr)->broadcast_key_digits(*as<KSwitchKeys>(kswitch_keys), (size_t)index, device_staging, *as<Comm>(comm), root);
+        SHL_CATCH
+    }
+    // the local phases of the reduce-scatter exchange (tests emulate the ranks in one process)
+    SHL_FUNC Evaluator_SwitchKeySlots(void *thisptr, void *encrypted, uint64_t nranks, uint64_t *slots)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(slots, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        *slots = as<Evaluator>(thisptr)->switch_key_slots(*as<Ciphertext>(encrypted), (unsigned)nranks);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_SwitchKeyPackTargets(void *thisptr, void *encrypted, const uint64_t *device_acc, uint64_t nranks, uint64_t *device_send,
+                                            uint64_t *device_special)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        as<Evaluator>(thisptr)->switch_key_pack_targets(*as<Ciphertext>(encrypted), device_acc, (unsigned)nranks, device_send, device_special);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_SwitchKeyFinishOwned(void *thisptr, void *encrypted, const uint64_t *device_recv, const uint64_t *device_special,
+                                            uint64_t nranks, uint64_t rank, uint64_t *device_own)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        as<Evaluator>(thisptr)->switch_key_finish_owned(*as<Ciphertext>(encrypted), device_recv, device_special, (unsigned)nranks, (unsigned)rank,
+                                                        device_own);
+        SHL_CATCH
+    }
+    SHL_FUNC Evaluator_SwitchKeyAddGathered(void *thisptr, void *encrypted, const uint64_t *device_all, uint64_t nranks)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        as<Evaluator>(thisptr)->switch_key_add_gathered(*as<Ciphertext>(encrypted), device_all, (unsigned)nranks);
         SHL_CATCH
     }
     SHL_FUNC Evaluator_ModSwitchTo1(void *thisptr, void *encrypted, uint64_t *parms_id, void *destination, void *pool)

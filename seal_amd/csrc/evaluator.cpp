@@ -38,50 +38,52 @@ namespace sealhip
             return res;
         }
 
-        // balance_correction_factors (evaluator.cpp:50-117): (f, e1, e2) with e1*factor1 = e2*factor2 = f mod t,
-        // gcd(e1,t) = gcd(e2,t) = 1 and |e1| + |e2| minimal in balanced representation
+        // balance_correction_factors (evaluator.cpp:50-117).  Two BGV operands carry correction factors c1, c2 (units mod t);
+        // before they can be added both are scaled to a common factor f = e1*c1 = e2*c2 (mod t), and the scalars should be
+        // small as centred residues because they multiply the noise.  With rho = c2 / c1 (mod t) the admissible pairs are
+        // exactly the lattice points e1 = rho * e2 (mod t), and the short ones appear among the remainders of Euclid's
+        // algorithm on (t, rho): every step yields r = s * rho (mod t).  The walk starts from (rho, 1) and a later step
+        // replaces the choice only when its centred 1-norm is STRICTLY smaller and r is a unit - the reference's tie rule,
+        // which decides the result words and is therefore kept.
         void balance_correction_factors(uint64_t factor1, uint64_t factor2, uint64_t t, uint64_t &f, uint64_t &e1, uint64_t &e2)
         {
-            const uint64_t half_t = t / 2;
-            auto sum_abs = [&](uint64_t x, uint64_t y) {
-                int64_t xb = static_cast<int64_t>(x > half_t ? x - t : x);
-                int64_t yb = static_cast<int64_t>(y > half_t ? y - t : y);
-                return std::abs(xb) + std::abs(yb);
-            };
-            if (std::__gcd(factor1 % t, t) != 1 || factor1 % t == 0)
+            const uint64_t c1 = factor1 % t, c2 = factor2 % t;
+            if (c1 == 0 || std::__gcd(c1, t) != 1)
                 throw std::logic_error("invalid correction factor1");
-            uint64_t ratio = host::mulmod(host::invmod(factor1 % t, t), factor2 % t, t);
-            e1 = ratio;
-            e2 = 1;
-            int64_t sum = sum_abs(e1, e2);
-            int64_t prev_a = static_cast<int64_t>(t), prev_b = 0, a = static_cast<int64_t>(ratio), b = 1;
-            while (a != 0)
+            const uint64_t rho = host::mulmod(host::invmod(c1, t), c2, t);
+            const auto residue = [t](int64_t v) { // v mod t in [0, t)
+                const uint64_t m = static_cast<uint64_t>(v < 0 ? -v : v) % t;
+                return (v < 0 && m) ? t - m : m;
+            };
+            const auto centred_abs = [t](uint64_t x) { // |x| as the centred representative of x mod t
+                return static_cast<int64_t>(x > t / 2 ? t - x : x);
+            };
+            struct Row
             {
-                int64_t q = prev_a / a;
-                int64_t temp = prev_a % a;
-                prev_a = a;
-                a = temp;
-                temp = prev_b - b * q;
-                prev_b = b;
-                b = temp;
-                uint64_t a_mod = static_cast<uint64_t>(std::abs(a)) % t;
-                if (a < 0)
-                    a_mod = a_mod ? t - a_mod : 0;
-                uint64_t b_mod = static_cast<uint64_t>(std::abs(b)) % t;
-                if (b < 0)
-                    b_mod = b_mod ? t - b_mod : 0;
-                if (a_mod != 0 && std::__gcd(a_mod, t) == 1)
+                int64_t r, s; // r = s * rho (mod t)
+            };
+            Row above{ static_cast<int64_t>(t), 0 }, here{ static_cast<int64_t>(rho), 1 };
+            e1 = rho;
+            e2 = 1;
+            int64_t best = centred_abs(e1) + centred_abs(e2);
+            while (here.r != 0)
+            {
+                const int64_t quot = above.r / here.r;
+                const Row below{ above.r - quot * here.r, above.s - quot * here.s };
+                above = here;
+                here = below;
+                const uint64_t r = residue(here.r), sc = residue(here.s);
+                if (r == 0 || std::__gcd(r, t) != 1)
+                    continue;
+                const int64_t norm = centred_abs(r) + centred_abs(sc);
+                if (norm < best)
                 {
-                    int64_t new_sum = sum_abs(a_mod, b_mod);
-                    if (new_sum < sum)
-                    {
-                        sum = new_sum;
-                        e1 = a_mod;
-                        e2 = b_mod;
-                    }
+                    best = norm;
+                    e1 = r;
+                    e2 = sc;
                 }
             }
-            f = host::mulmod(e1, factor1 % t, t);
+            f = host::mulmod(e1, c1, t);
         }
 
         NttBatch plain_batch(uint64_t *data, size_t outer_stride, unsigned ncomp, unsigned nouter, unsigned prime_first)
@@ -1233,7 +1235,7 @@ namespace sealhip
     {
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
-        if (relin_keys.context() != &context_)
+        if (relin_keys.context() != &context_ && !(j0 == j1 && !relin_keys.context())) // a rank without digits may hold no key
             throw std::invalid_argument("relin_keys is not valid for encryption parameters");
         if (e.size() != 3)
             throw std::invalid_argument("digit-parallel relinearization takes a size-3 ciphertext");
@@ -1251,12 +1253,12 @@ namespace sealhip
         Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys, unsigned j0, unsigned j1, uint64_t *acc) const
     {
         check_valid(e, "encrypted");
-        if (galois_keys.context() != &context_)
+        if (galois_keys.context() != &context_ && !(j0 == j1 && !galois_keys.context()))
             throw std::invalid_argument("galois_keys is not valid for encryption parameters");
         uint64_t m = 2 * (uint64_t)context_.n();
         if (!(galois_elt & 1) || galois_elt >= m)
             throw std::invalid_argument("Galois element is not valid");
-        if (!galois_keys.has_key(galois_index(galois_elt)))
+        if (j0 < j1 && !galois_keys.has_key(galois_index(galois_elt))) // a rank without digits holds no slice of the key
             throw std::invalid_argument("Galois key not present");
         if (e.size() != 2)
             throw std::invalid_argument("encrypted size must be 2");
@@ -1301,8 +1303,14 @@ namespace sealhip
             throw std::invalid_argument("acc");
         if (!context_.using_keyswitching())
             throw std::logic_error("keyswitching is not supported by the context");
-        if (keys.context() != &context_)
+        if (keys.context() != &context_ && !(j0 == j1 && !keys.context()))
             throw std::invalid_argument("parameter mismatch");
+        if (j0 == j1 && j0 <= e.level()->K)
+        {
+            // a rank without digits (more ranks than digits) needs no key: its partial sums are zero
+            ck(hipMemsetAsync(acc_out, 0, switch_key_acc_words(e) * 8 * (split ? split : 1), stream_), "ks zero partial sums");
+            return;
+        }
         if (key_index >= keys.slots())
             throw std::out_of_range("kswitch_keys_index");
         const Scheme scheme = context_.scheme();
@@ -1331,7 +1339,6 @@ namespace sealhip
         const NttTables &tb = context_.ntt_tables();
         const ModDesc *mods = context_.dev_mods();
         const uint32_t *map = ks_comp_prime(K);
-
         // t_target: coefficient form of every decomposition digit (evaluator.cpp:2651-2658)
         Scratch t((size_t)B * K * N);
         const bool ntt_target = scheme == Scheme::ckks || scheme == Scheme::bgv; // the target is in NTT form
@@ -1524,6 +1531,185 @@ namespace sealhip
                                   stream_, split),
                "ks add digit groups");
         switch_key_finish(e, acc.p, 1);
+    }
+
+    // ---- digit-parallel key switching over the ranks of a communicator (the reference loop being split:
+    // evaluator.cpp:2663-2755 over the digits, 2806-2864 over the target moduli).  Everything is enqueued on stream_.
+    unsigned Evaluator::switch_key_slots(const Ciphertext &e, unsigned nranks) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (nranks < 1 || nranks > 8)
+            throw std::invalid_argument("nranks");
+        return (e.level()->K + nranks - 1) / nranks;
+    }
+
+    void Evaluator::switch_key_pack_targets(const Ciphertext &e, const uint64_t *acc, unsigned nranks, uint64_t *send, uint64_t *sp) const
+    {
+        const unsigned m = switch_key_slots(e, nranks);
+        if (!acc || !send || !sp)
+            throw std::invalid_argument("buffer");
+        ck(k_ks_pack_targets(acc, send, sp, (unsigned)context_.log_n(), e.level()->K, nranks, m, (unsigned)e.batch(), stream_), "ks pack targets");
+    }
+
+    void Evaluator::switch_key_finish_owned(
+        const Ciphertext &e, const uint64_t *recv, const uint64_t *sp, unsigned nranks, unsigned rank, uint64_t *own) const
+    {
+        const unsigned m = switch_key_slots(e, nranks);
+        if (rank >= nranks)
+            throw std::invalid_argument("rank");
+        if (!recv || !sp || !own)
+            throw std::invalid_argument("buffer");
+        if (context_.scheme() != Scheme::ckks)
+            throw std::logic_error("the reduce-scatter exchange is built for CKKS; BFV / BGV use the all-reduce exchange");
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K, B = (unsigned)e.batch(), n_log = (unsigned)context_.log_n();
+        const size_t N = context_.n();
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        unsigned first, count;
+        comm_split(K, nranks, rank, first, count);
+        if (!count)
+        {
+            // more ranks than moduli: nothing to reduce here, the chunk this rank contributes is zero
+            ck(hipMemsetAsync(own, 0, (size_t)m * B * 2 * N * 8, stream_), "ks zero own");
+            return;
+        }
+        // a key switch over this rank's `count` moduli: sums [batch][2][count+1][N], the special prime last
+        Scratch acc3((size_t)B * 2 * (count + 1) * N);
+        ck(k_ks_unpack_owned(mods, recv, sp, acc3.p, n_log, L, first, count, B, stream_), "ks unpack owned");
+        const uint64_t P = context_.coeff_modulus()[L - 1];
+        NttBatch bi = plain_batch(acc3.p + (size_t)count * N, (size_t)(count + 1) * N, 1, 2 * B, L - 1);
+        ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
+        // increments of the owned moduli, compact planes [2][batch][count][N] (the tail adds into them: start from zero)
+        Scratch inc((size_t)2 * B * count * N);
+        ck(hipMemsetAsync(inc.p, 0, (size_t)2 * B * count * N * 8, stream_), "ks zero increments");
+        Scratch tt(ntt2_supports(context_.log_n()) ? 1 : (size_t)B * 2 * count * N);
+        NttBatch b{};
+        b.data = tt.p;
+        b.outer_stride = (size_t)count * N;
+        b.ncomp = count;
+        b.nouter = 2 * B;
+        b.comp_prime = nullptr;
+        b.prime_first = first;
+        b.src = acc3.p + (size_t)count * N;
+        b.src_outer_stride = (size_t)(count + 1) * N;
+        b.src_ncomp = 1;
+        b.src_mode = 2;
+        b.src_half = P >> 1;
+        b.src_q = P;
+        b.src_fix = klvl.dev.round_fix + first;
+        uint64_t *inc0 = inc.p, *inc1 = inc.p + (size_t)B * count * N;
+        if (ntt2_supports(context_.log_n()))
+        {
+            b.data = nullptr;
+            b.epi = 2;
+            b.epi_a = acc3.p;
+            b.epi_a_stride = (size_t)(count + 1) * N;
+            b.epi_mul = klvl.dev.inv_q_last_mod_q + first;
+            b.epi_out0 = inc0;
+            b.epi_out1 = inc1;
+            b.epi_out_stride = (size_t)count * N;
+            ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction + tail (owned moduli)");
+        }
+        else
+        {
+            ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction (owned moduli)");
+            ck(k_keyswitch_tail_ckks(mods + first, klvl.dev.inv_q_last_mod_q + first, inc0, inc1, acc3.p, tt.p, n_log, count, B, stream_),
+               "ks tail (owned moduli)");
+        }
+        ck(k_ks_pack_owned(inc.p, own, n_log, count, m, B, stream_), "ks pack owned");
+    }
+
+    void Evaluator::switch_key_add_gathered(Ciphertext &e, const uint64_t *all, unsigned nranks) const
+    {
+        const unsigned m = switch_key_slots(e, nranks);
+        if (!all)
+            throw std::invalid_argument("buffer");
+        if (e.size() < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+        ck(k_ks_add_gathered(context_.dev_mods(), e.plane(0), e.plane(1), all, (unsigned)context_.log_n(), e.level()->K, nranks, m,
+                             (unsigned)e.batch(), stream_),
+           "ks add gathered");
+    }
+
+    void Evaluator::switch_key_exchange_finish(Ciphertext &e, uint64_t *acc, Comm &comm, KsExchange how) const
+    {
+        const unsigned G = (unsigned)comm.size();
+        const size_t words = switch_key_acc_words(e);
+        if (how == KsExchange::all_reduce || context_.scheme() != Scheme::ckks)
+        {
+            comm.all_reduce_sum(acc, words, stream_);
+            switch_key_finish(e, acc, G);
+            return;
+        }
+        const unsigned m = switch_key_slots(e, G);
+        const size_t N = context_.n(), B = e.batch();
+        const size_t chunk = (size_t)m * B * 2 * N, spw = B * 2 * N;
+        Scratch send((size_t)G * chunk), sp(spw), recv(chunk), own(chunk), all((size_t)G * chunk);
+        switch_key_pack_targets(e, acc, G, send.p, sp.p);
+        comm.reduce_scatter_sum(send.p, recv.p, chunk, stream_);
+        comm.all_reduce_sum(sp.p, spw, stream_);
+        switch_key_finish_owned(e, recv.p, sp.p, G, (unsigned)comm.rank(), own.p);
+        comm.all_gather(own.p, all.p, chunk, stream_);
+        switch_key_add_gathered(e, all.p, G);
+    }
+
+    void Evaluator::relinearize_inplace(Ciphertext &e, const KSwitchKeys &relin_keys, Comm &comm, KsExchange how) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        unsigned first, count;
+        comm_split(e.level()->K, (unsigned)comm.size(), (unsigned)comm.rank(), first, count);
+        Scratch acc(switch_key_acc_words(e));
+        relinearize_partial(e, relin_keys, first, first + count, acc.p);
+        switch_key_exchange_finish(e, acc.p, comm, how);
+        e.resize(e.level(), 2, stream_);
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::apply_galois_inplace(Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys, Comm &comm, KsExchange how) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        unsigned first, count;
+        comm_split(e.level()->K, (unsigned)comm.size(), (unsigned)comm.rank(), first, count);
+        Scratch acc(switch_key_acc_words(e));
+        apply_galois_partial(e, galois_elt, galois_keys, first, first + count, acc.p);
+        switch_key_exchange_finish(e, acc.p, comm, how);
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::rotate_vector_inplace(Ciphertext &e, int steps, const KSwitchKeys &galois_keys, Comm &comm, KsExchange how) const
+    {
+        if (context_.scheme() != Scheme::ckks)
+            throw std::logic_error("unsupported scheme");
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (steps == 0)
+            return;
+        // the digit-parallel form takes the exact key (evaluator.h:1209 with the key present); the NAF fallback of
+        // rotate_internal would need every rank to hold the power-of-two keys' digits as well
+        apply_galois_inplace(e, galois_elt_from_step(steps), galois_keys, comm, how);
+    }
+
+    void Evaluator::broadcast_key_digits(KSwitchKeys &keys, size_t index, uint64_t *staging, Comm &comm, int root) const
+    {
+        if (!staging)
+            throw std::invalid_argument("staging");
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        const size_t N = context_.n(), L = context_.key_level().K, K = context_.first_level().K;
+        const size_t digit_words = 2 * L * N;
+        comm.broadcast(staging, K * digit_words, root, stream_);
+        ck(hipStreamSynchronize(stream_), "broadcast key");
+        unsigned first, count;
+        comm_split((unsigned)K, (unsigned)comm.size(), (unsigned)comm.rank(), first, count);
+        if (count)
+            keys.set_key(context_, index, count, staging + first * digit_words, true, first);
     }
 
     // NTT the BGV correction polynomials `delta` ([items][ncomp][N], coefficient form, canonical) and fold them

@@ -7,6 +7,7 @@
 #include "context.h"
 #include "poly_kernels.h"
 #include "pool.h"
+#include "comm.h"
 #include "ntt2_kernels.h"
 #include <functional>
 #include <map>
@@ -226,6 +227,38 @@ namespace sealhip
                                   uint64_t *acc) const;
         void apply_galois_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts) const;
 
+        // ---- digit-parallel key switching with the exchange INSIDE the library: RCCL calls on this
+        // evaluator's stream, no host synchronisation.  Every rank of `comm` calls the same method with equal ciphertexts and
+        // a key that holds (at least) its own digits comm_split(K, size, rank).  Two exchange shapes:
+        //   all_reduce      one all-reduce of the 2(K+1)N partial sums per ciphertext; every rank runs the whole mod-down
+        //   reduce_scatter  (CKKS) the sums of the K data moduli are reduce-scattered by owner (comm_split(K, size, rank)),
+        //                   the special-prime component is all-reduced, every rank runs the mod-down of ITS moduli only and
+        //                   the increments are all-gathered: same bytes on the wire, 1/size of the mod-down per rank
+        // Results are bit-identical to the single-GPU operations.  BFV / BGV use the all-reduce shape in either mode.
+        enum class KsExchange
+        {
+            all_reduce = 0,
+            reduce_scatter = 1,
+        };
+        void relinearize_inplace(Ciphertext &encrypted, const KSwitchKeys &relin_keys, Comm &comm, KsExchange how) const;
+        void apply_galois_inplace(Ciphertext &encrypted, uint32_t galois_elt, const KSwitchKeys &galois_keys, Comm &comm, KsExchange how) const;
+        void rotate_vector_inplace(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys, Comm &comm, KsExchange how) const;
+        // one-time distribution of a key-switching key: rank `root` holds the full key `index`, every rank ends up with its own
+        // digits resident (the key is broadcast in its natural layout and re-laid out locally)
+        // (staging: a device buffer of K * 2 * L * N words on EVERY rank; on `root` it holds the key [digit][2][L][N])
+        void broadcast_key_digits(KSwitchKeys &keys, size_t index, uint64_t *staging, Comm &comm, int root) const;
+        // the three local phases of the reduce-scatter shape (the parity tests emulate the ranks in one process):
+        //   slots          m = ceil(K / nranks) moduli slots per rank
+        //   pack_targets   acc (this rank's partial sums) -> send [nranks][m][batch][2][N] + sp [batch][2][N] (special prime)
+        //   finish_owned   recv = the summed chunk of `rank` [m][batch][2][N], sp = the summed special component
+        //                  -> own [m][batch][2][N]: the increments of this rank's moduli
+        //   add_gathered   all [nranks][m][batch][2][N] -> encrypted += increments
+        unsigned switch_key_slots(const Ciphertext &encrypted, unsigned nranks) const;
+        void switch_key_pack_targets(const Ciphertext &encrypted, const uint64_t *acc, unsigned nranks, uint64_t *send, uint64_t *sp) const;
+        void switch_key_finish_owned(
+            const Ciphertext &encrypted, const uint64_t *recv, const uint64_t *sp, unsigned nranks, unsigned rank, uint64_t *own) const;
+        void switch_key_add_gathered(Ciphertext &encrypted, const uint64_t *all, unsigned nranks) const;
+
     private:
         friend class Encryptor; // public-key encryption ends with one modulus switch from the level above (encryptor.cpp:139-186)
         void check_valid(const Ciphertext &ct, const char *what) const;
@@ -246,6 +279,7 @@ namespace sealhip
         void rotate_internal(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
         void conjugate_internal(Ciphertext &encrypted, const KSwitchKeys &galois_keys) const;
         void throw_if_transparent(const Ciphertext &ct) const;
+        void switch_key_exchange_finish(Ciphertext &encrypted, uint64_t *acc, Comm &comm, KsExchange how) const;
         const uint32_t *ks_comp_prime(unsigned K) const;
         struct KsTargets
         {

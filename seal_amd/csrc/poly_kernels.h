@@ -101,6 +101,23 @@ namespace sealhip
         unsigned L, unsigned batch, unsigned j0, unsigned j1, unsigned key_digit0, hipStream_t s);
     // acc <- acc mod q_I in place after partial sums of several ranks were added (each canonical, at most 8 of them)
     hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts = 1);
+    // Reduce-scatter exchange of the digit-parallel key switch (evaluator.cpp: switch_key_exchange_*).  The K data
+    // moduli are owned by the G ranks in contiguous ranges whose sizes differ by at most one (rank c: K/G (+1 for c < K%G)
+    // moduli); m = ceil(K / G) slots per rank.
+    //   pack_targets : send[c][s][b][k][N] = acc[b][k][first(c)+s] (zero padding), sp[b][k][N] = acc[b][k][K] (special prime)
+    //   unpack_owned : acc3[b][k][s] = recv[s][b][k] mod q_{first+s},  acc3[b][k][count] = sp[b][k] mod P  (Barrett, sums of <= 8
+    //                  parts): the layout [batch][2][count+1][N] of a key switch over the rank's own `count` moduli
+    //   pack_owned   : own[s][b][k][N] = inc[k][b][s][N]  (inc: this rank's increments, compact [2][batch][count][N])
+    //   add_gathered : ct_k[b][i] += all[owner(i)][slot(i)][b][k]  mod q_i
+    hipError_t k_ks_pack_targets(
+        const uint64_t *acc, uint64_t *send, uint64_t *sp, unsigned n_log, unsigned K, unsigned G, unsigned m, unsigned batch, hipStream_t s);
+    hipError_t k_ks_unpack_owned(
+        const ModDesc *mods, const uint64_t *recv, const uint64_t *sp, uint64_t *acc3, unsigned n_log, unsigned L, unsigned first,
+        unsigned count, unsigned batch, hipStream_t s);
+    hipError_t k_ks_pack_owned(const uint64_t *inc, uint64_t *own, unsigned n_log, unsigned count, unsigned m, unsigned batch, hipStream_t s);
+    hipError_t k_ks_add_gathered(
+        const ModDesc *mods, uint64_t *ct0, uint64_t *ct1, const uint64_t *all, unsigned n_log, unsigned K, unsigned G, unsigned m,
+        unsigned batch, hipStream_t s);
     // Key-switch tail (CKKS): ct_k[b][i] += (acc[b][k][i] - t[b][k][i]) * P^-1 mod q_i.
     // ct planes: ct0 and ct1, each [batch][K][N]; acc [batch][2][K+1][N]; t [batch][2][K][N] lazy.
     hipError_t k_keyswitch_tail_ckks(

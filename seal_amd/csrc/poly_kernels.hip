@@ -417,6 +417,104 @@ namespace sealhip
             }
         }
 
+        // ---- reduce-scatter exchange of the digit-parallel key switch.  The K data moduli are owned by the G
+        // ranks in contiguous ranges (rank c: [c*base + min(c, extra), ...), sizes differ by at most one; m = ceil(K / G) slots).
+        __device__ __forceinline__ unsigned ks_owner_first(unsigned K, unsigned G, unsigned c)
+        {
+            const unsigned base = K / G, extra = K % G;
+            return c * base + (c < extra ? c : extra);
+        }
+        // send[c][s][b][k][j] = acc[b][k][first(c) + s][j] (zero beyond rank c's range);  sp[b][k][j] = acc[b][k][K][j]
+        __global__ void __launch_bounds__(kBlock) ks_pack_targets_kernel(
+            const uint64_t *acc, uint64_t *send, uint64_t *sp, unsigned n_log, unsigned K, unsigned G, unsigned m, unsigned batch,
+            size_t send_words, size_t sp_words)
+        {
+            const size_t N = size_t(1) << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < send_words + sp_words; i += (size_t)gridDim.x * kBlock)
+            {
+                if (i < send_words)
+                {
+                    const size_t j = i & (N - 1);
+                    size_t r = i >> n_log; // ((c*m + s)*batch + b)*2 + k
+                    const unsigned k = (unsigned)(r & 1);
+                    r >>= 1;
+                    const size_t b = r % batch;
+                    r /= batch;
+                    const unsigned s = (unsigned)(r % m), c = (unsigned)(r / m);
+                    const unsigned first = ks_owner_first(K, G, c), count = ks_owner_first(K, G, c + 1) - first;
+                    send[i] = s < count ? acc[(((b * 2 + k) * (K + 1) + first + s) << n_log) + j] : 0;
+                }
+                else
+                {
+                    const size_t t = i - send_words, j = t & (N - 1), r = t >> n_log; // b*2 + k
+                    sp[t] = acc[((r * (K + 1) + K) << n_log) + j];
+                }
+            }
+        }
+        // the sums this rank received, in the layout of a key switch over its `count` moduli:
+        //   acc3[b][k][s][j] = recv[s][b][k][j] mod q_{first+s} (s < count),  acc3[b][k][count][j] = sp[b][k][j] mod P
+        __global__ void __launch_bounds__(kBlock) ks_unpack_owned_kernel(
+            const ModDesc *mods, const uint64_t *recv, const uint64_t *sp, uint64_t *acc3, unsigned n_log, unsigned L, unsigned first,
+            unsigned count, unsigned batch, size_t own_words, size_t sp_words)
+        {
+            const size_t N = size_t(1) << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < own_words + sp_words; i += (size_t)gridDim.x * kBlock)
+            {
+                if (i < own_words)
+                {
+                    const size_t j = i & (N - 1);
+                    size_t r = i >> n_log; // (s*batch + b)*2 + k
+                    const unsigned k = (unsigned)(r & 1);
+                    r >>= 1;
+                    const size_t b = r % batch;
+                    const unsigned s = (unsigned)(r / batch); // < count
+                    acc3[(((b * 2 + k) * (count + 1) + s) << n_log) + j] = barrett64(recv[i], mods[first + s]);
+                }
+                else
+                {
+                    const size_t t = i - own_words, j = t & (N - 1), r = t >> n_log;
+                    acc3[((r * (count + 1) + count) << n_log) + j] = barrett64(sp[t], mods[L - 1]);
+                }
+            }
+        }
+        // own[s][b][k][j] = inc[k][b][s][j] (zero for the padding slots s >= count)
+        __global__ void __launch_bounds__(kBlock) ks_pack_owned_kernel(
+            const uint64_t *inc, uint64_t *own, unsigned n_log, unsigned count, unsigned m, unsigned batch, size_t words)
+        {
+            const size_t N = size_t(1) << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t j = i & (N - 1);
+                size_t r = i >> n_log;
+                const unsigned k = (unsigned)(r & 1);
+                r >>= 1;
+                const size_t b = r % batch;
+                const unsigned s = (unsigned)(r / batch);
+                own[i] = s < count ? inc[(((size_t)k * batch + b) * count + s) * N + j] : 0;
+            }
+        }
+        // ct_k[b][i][j] += all[owner(i)][slot(i)][b][k][j]  (mod q_i)
+        __global__ void __launch_bounds__(kBlock) ks_add_gathered_kernel(
+            const ModDesc *mods, uint64_t *ct0, uint64_t *ct1, const uint64_t *all, unsigned n_log, unsigned K, unsigned G, unsigned m,
+            unsigned batch, size_t words /* batch*K*N */)
+        {
+            const size_t N = size_t(1) << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t j = i & (N - 1), row = i >> n_log; // b*K + comp
+                const unsigned comp = (unsigned)(row % K);
+                const size_t b = row / K;
+                unsigned c = 0;
+                while (ks_owner_first(K, G, c + 1) <= comp)
+                    c++;
+                const unsigned s = comp - ks_owner_first(K, G, c);
+                const uint64_t q = mods[comp].q;
+                const size_t base = ((((size_t)c * m + s) * batch + b) * 2) << n_log;
+                ct0[i] = add_mod(ct0[i], all[base + j], q);
+                ct1[i] = add_mod(ct1[i], all[base + N + j], q);
+            }
+        }
+
         __global__ void __launch_bounds__(kBlock) keyswitch_tail_ckks_kernel(
             const ModDesc *mods, const ShoupOp *inv_p, uint64_t *ct0, uint64_t *ct1, const uint64_t *acc,
             const uint64_t *t, unsigned n_log, unsigned K, size_t words /* batch*K*N */)
@@ -643,6 +741,43 @@ namespace sealhip
         if (!w)
             return hipSuccess;
         hipLaunchKernelGGL(keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w, local_parts);
+        return hipGetLastError();
+    }
+    hipError_t k_ks_pack_targets(
+        const uint64_t *acc, uint64_t *send, uint64_t *sp, unsigned n_log, unsigned K, unsigned G, unsigned m, unsigned batch, hipStream_t s)
+    {
+        const size_t send_words = ((size_t)G * m * batch * 2) << n_log, sp_words = ((size_t)batch * 2) << n_log;
+        hipLaunchKernelGGL(
+            ks_pack_targets_kernel, dim3(grid_for(send_words + sp_words)), dim3(kBlock), 0, s, acc, send, sp, n_log, K, G, m, batch,
+            send_words, sp_words);
+        return hipGetLastError();
+    }
+    hipError_t k_ks_unpack_owned(
+        const ModDesc *mods, const uint64_t *recv, const uint64_t *sp, uint64_t *acc3, unsigned n_log, unsigned L, unsigned first,
+        unsigned count, unsigned batch, hipStream_t s)
+    {
+        const size_t own_words = ((size_t)count * batch * 2) << n_log, sp_words = ((size_t)batch * 2) << n_log;
+        hipLaunchKernelGGL(
+            ks_unpack_owned_kernel, dim3(grid_for(own_words + sp_words)), dim3(kBlock), 0, s, mods, recv, sp, acc3, n_log, L, first,
+            count, batch, own_words, sp_words);
+        return hipGetLastError();
+    }
+    hipError_t k_ks_pack_owned(const uint64_t *inc, uint64_t *own, unsigned n_log, unsigned count, unsigned m, unsigned batch, hipStream_t s)
+    {
+        const size_t words = ((size_t)m * batch * 2) << n_log;
+        if (!words)
+            return hipSuccess;
+        hipLaunchKernelGGL(ks_pack_owned_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, inc, own, n_log, count, m, batch, words);
+        return hipGetLastError();
+    }
+    hipError_t k_ks_add_gathered(
+        const ModDesc *mods, uint64_t *ct0, uint64_t *ct1, const uint64_t *all, unsigned n_log, unsigned K, unsigned G, unsigned m,
+        unsigned batch, hipStream_t s)
+    {
+        const size_t words = ((size_t)batch * K) << n_log;
+        if (!words)
+            return hipSuccess;
+        hipLaunchKernelGGL(ks_add_gathered_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, ct0, ct1, all, n_log, K, G, m, batch, words);
         return hipGetLastError();
     }
     hipError_t k_keyswitch_tail_ckks(

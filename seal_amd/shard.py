@@ -3,10 +3,11 @@
 1. Batch sharding of independent ciphertexts (8(e).1, the throughput mode bench.py measures): no data-path
    collective at all.
 2. Digit-parallel key switching (8(e).2, BASELINE configs[4]: "decomposition parallel across GPUs"): `DigitParallel`
-   below - every rank holds the same ciphertext and a slice of the key-switching key's decomposition digits, computes
-   its partial sums, ONE all-reduce (sum of 2 (K+1) N 64-bit words per ciphertext) joins them, every rank finishes
-   the mod-down locally.  The exchange is torch.distributed.all_reduce: RCCL over xGMI on the GPU box ("nccl"
-   backend), gloo in the CPU tests.
+   below - every rank holds the same ciphertext and a slice of the key-switching key's decomposition digits and computes
+   its partial sums; the exchange and the mod-down run INSIDE the library (sealhip.h section 1c: RCCL calls on the
+   evaluator's stream, no host synchronisation; all-reduce or reduce-scatter + all-gather by target modulus).  Where the
+   library's communicator cannot be used (gloo in the CPU tests, a process group that is not RCCL) the partial sums go
+   through torch.distributed.all_reduce instead and every rank finishes locally.
 
 One process per GPU (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests).
 The hot path has no exchange step between independent ciphertexts, so the only collectives are the
@@ -76,13 +77,27 @@ class DigitParallel:
     apply_galois_inplace on one GPU.  Keys: KSwitchKeys.set_key_digits(index, *digit_range(K), full_key[range])
     keeps only this rank's slice resident (a full key works too)."""
 
-    def __init__(self, ev, torch, dist, device):
+    def __init__(self, ev, torch, dist, device, exchange="all_reduce", native=None):
+        """exchange: "all_reduce" | "reduce_scatter" (the library's two shapes, sealhip.h section 1c).
+        native: None = use the library's RCCL communicator when the tensors live on a GPU and RCCL loads, else
+        torch.distributed; True / False forces either."""
         self.ev, self.torch, self.dist, self.device = ev, torch, dist, device
         self.rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         if self.world > 8:
             raise ValueError("at most 8 partial sums fit a 64-bit word (residues are below 2^60)")
         self._acc = None
+        self.exchange = {"all_reduce": 0, "reduce_scatter": 1}[exchange]
+        self.comm = None
+        if native is None:
+            from . import api
+            native = self.world > 1 and getattr(device, "type", "cpu") == "cuda" and api.Comm.rccl_available()
+        if native:
+            from . import api
+            ids = [api.Comm.unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(ids, src=0)  # the 128-byte RCCL id travels over the existing process group
+            self.comm = api.Comm(ids[0], self.world, self.rank)
 
     def digit_range(self, K):
         """(first, count) of the decomposition digits this rank serves at a level with K data primes"""
@@ -103,6 +118,8 @@ class DigitParallel:
 
     def relinearize_inplace(self, ct, relin_keys):
         """size 3 -> 2 (Evaluator::relinearize_inplace, evaluator.cpp:1144-1199)"""
+        if self.comm is not None:
+            return self.ev.relinearize_inplace_dp(ct, relin_keys, self.comm, self.exchange)
         first, count = self.digit_range(ct.coeff_modulus_size())
         acc = self._buffer(self.ev.switch_key_acc_words(ct))
         self.ev.relinearize_partial(ct, relin_keys, first, count, acc.data_ptr())
@@ -112,6 +129,8 @@ class DigitParallel:
 
     def apply_galois_inplace(self, ct, galois_elt, galois_keys):
         """Evaluator::apply_galois_inplace (evaluator.cpp:2384-2502) on a size-2 ciphertext"""
+        if self.comm is not None:
+            return self.ev.apply_galois_inplace_dp(ct, galois_elt, galois_keys, self.comm, self.exchange)
         first, count = self.digit_range(ct.coeff_modulus_size())
         acc = self._buffer(self.ev.switch_key_acc_words(ct))
         self.ev.apply_galois_partial(ct, galois_elt, galois_keys, first, count, acc.data_ptr())

@@ -36,6 +36,7 @@ def emu():
     import seal_amd
     if not os.path.exists(EMU_LIB):
         _build("emu")
+    os.environ["SEALHIP_COMM_NO_RCCL"] = "1"  # no device here: the library's communicator runs as a one-rank loopback
     seal_amd.load(EMU_LIB)
     yield seal_amd
     seal_amd._native._lib = None

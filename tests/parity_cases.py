@@ -137,17 +137,22 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
 
 # ---- large device-resident batches (the shapes bench.py times): inputs are generated on the device, a sample of items is
 #      downloaded and compared with the reference's multiply + relinearize + rescale (+ rotate) on the same words
-def device_uniform_words(primes, prefix, n, seed):
-    """[*prefix][len(primes)][n] uniform residues generated in HBM (torch only as the device RNG) -> int64 torch tensor"""
-    import torch
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    comps = [torch.randint(0, int(q), tuple(prefix) + (1, n), dtype=torch.int64, device="cuda", generator=g) for q in primes]
-    return torch.cat(comps, dim=len(prefix)).contiguous()
+def host_uniform_words(primes, polys, batch, n, seed):
+    """[polys][batch][len(primes)][n] uniform residues, drawn on several host threads (numpy releases the GIL); torch is not
+    used: its bundled HIP runtime cannot be initialised next to the one libsealhip.so has already loaded"""
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty((polys, batch, len(primes), n), dtype=np.uint64)
+
+    def fill(job):
+        p, k = job
+        rng = np.random.default_rng([seed, p, k])
+        out[p, :, k, :] = rng.integers(0, primes[k], size=(batch, n), dtype=np.uint64)
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        list(ex.map(fill, [(p, k) for p in range(polys) for k in range(len(primes))]))
+    return out
 
 
 def case_ckks_big_batch(n, bits, batch, check_items, seed=11, rotate=True):
-    import torch
     primes = coeff_modulus_create(n, bits)
     L = len(primes)
     K = L - 1
@@ -156,20 +161,11 @@ def case_ckks_big_batch(n, bits, batch, check_items, seed=11, rotate=True):
     o = Oracle("ckks", n, primes, galois_elts=[elt])
     d = DeviceSide("ckks", n, primes)
     d.upload_keys(o)
-    xs = device_uniform_words(primes[:K], (2, batch), n, seed)
-    ys = device_uniform_words(primes[:K], (2, batch), n, seed + 1)
+    xs = host_uniform_words(primes[:K], 2, batch, n, seed)
+    ys = host_uniform_words(primes[:K], 2, batch, n, seed + 1)
     pid = d.parms_id_for_K(K)
-
-    def make(t):
-        ct = S.Ciphertext(d.ctx, batch=batch)
-        ct.resize(pid, 2)
-        ct.set_is_ntt_form(True)
-        ct.set_scale(2.0 ** 10)
-        ct.load_device(t.data_ptr(), t.numel())
-        return ct
-
-    cx, cy = make(xs), make(ys)
-    torch.cuda.synchronize()
+    cx = S.Ciphertext.from_numpy(d.ctx, xs, pid, True, 2.0 ** 10)
+    cy = S.Ciphertext.from_numpy(d.ctx, ys, pid, True, 2.0 ** 10)
     work = S.Ciphertext(d.ctx, batch=batch)
     d.ev.multiply(cx, cy, work)
     d.ev.relinearize_inplace(work, d.rlk)
@@ -180,12 +176,13 @@ def case_ckks_big_batch(n, bits, batch, check_items, seed=11, rotate=True):
         d.ev.rotate_vector_inplace(work, 1, d.glk)
     assert work.size() == 2 and work.coeff_modulus_size() == K - 1 and work.batch() == batch
     for b in check_items:
-        x = xs[:, b].cpu().numpy().astype(np.uint64)
-        y = ys[:, b].cpu().numpy().astype(np.uint64)
+        x, y = np.ascontiguousarray(xs[:, b]), np.ascontiguousarray(ys[:, b])
         exp = o.rescale(o.relinearize(o.multiply(x, y)))
         _eq(mid[b], exp, "multiply+relinearize+rescale item %d of %d" % (b, batch))
         if rotate:
             _eq(work.item_to_numpy(b), o.apply_galois(exp, elt), "rotate_vector item %d of %d" % (b, batch))
+    del cx, cy, work
+    S.release_pool()
 
 
 # ---- BFV: BFVEncryptMultiplyDecrypt / BFVRelinearize / BFVEncryptModSwitchToNextDecrypt /
@@ -391,6 +388,102 @@ def case_digit_parallel(scheme, n, primes, t=0, parts=2, batch=2, seed=7):
     for b in range(batch):
         exp = o.run("apply_galois_inplace", [(x2[b], 1)], elt)[0] if scheme == "bgv" else o.apply_galois(x2[b], elt)
         _eq(want[b], exp, "apply_galois item %d vs oracle" % b)
+
+
+def case_digit_parallel_reduce_scatter(n, primes, parts=2, batch=2, seed=9):
+    """The reduce-scatter shape of the exchange (sealhip.h section 1c, exchange 1; CKKS) with the ranks emulated in one process:
+    partial sums per rank -> pack by owner -> [reduce-scatter + all-reduce of the special component, here numpy sums] ->
+    mod-down of the rank's own moduli -> [all-gather, here a concatenation] -> add.  Every rank's result equals the
+    single-GPU result and the reference; then the same through the library's own driver on a one-rank communicator."""
+    from seal_amd import shard
+    L = len(primes)
+    K = L - 1
+    probe = Oracle("ckks", n, primes)
+    elt = probe.galois_elt_from_step(1)
+    o = Oracle("ckks", n, primes, galois_elts=[elt])
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rlk_words, glk_words = o.relin_key(), o.galois_key(elt)
+    rng = np.random.default_rng(seed)
+    x3 = [rand_ct(rng, primes, K, n, size=3) for _ in range(batch)]
+    x2 = [rand_ct(rng, primes, K, n, size=2) for _ in range(batch)]
+    G = parts
+    ranges = [shard.split(K, G, r) for r in range(G)]
+    rlks, glks = [], []
+    for first, count in ranges:
+        rk, gk = S.RelinKeys(d.ctx), S.GaloisKeys(d.ctx)
+        if count:  # a rank without digits holds no key at all
+            rk.set_key_digits(0, first, rlk_words[first:first + count])
+            gk.set_key_digits(S.GaloisKeys.get_index(elt), first, glk_words[first:first + count])
+        rlks.append(rk)
+        glks.append(gk)
+
+    def run(make_ct, partial, single, planes_kept):
+        ref_ct = make_ct()
+        single(ref_ct)
+        want = d.out(ref_ct)
+        probe_ct = make_ct()
+        words = d.ev.switch_key_acc_words(probe_ct)
+        m = d.ev.switch_key_slots(probe_ct, G)
+        assert m == -(-K // G)
+        chunk = m * batch * 2 * n
+        cts, sends, sps = [], [], []
+        for r, (first, count) in enumerate(ranges):
+            c = make_ct()
+            acc, send, sp = S.DeviceBuffer(words), S.DeviceBuffer(G * chunk), S.DeviceBuffer(batch * 2 * n)
+            partial(c, r, first, count, acc)
+            d.ev.switch_key_pack_targets(c, acc.ptr, G, send.ptr, sp.ptr)
+            sends.append(send.to_numpy((G, chunk)))
+            sps.append(sp.to_numpy((batch * 2 * n,)))
+            cts.append(c)
+        sp_sum = np.sum(np.stack(sps), axis=0, dtype=np.uint64)
+        owns = []
+        for r in range(G):
+            recv = np.sum(np.stack([sends[src][r] for src in range(G)]), axis=0, dtype=np.uint64)  # reduce-scatter
+            own, recv_d, sp_d = S.DeviceBuffer(chunk), S.DeviceBuffer.from_numpy(recv), S.DeviceBuffer.from_numpy(sp_sum)
+            d.ev.switch_key_finish_owned(cts[r], recv_d.ptr, sp_d.ptr, G, r, own.ptr)
+            owns.append(own.to_numpy((chunk,)))  # (synchronises: the inputs may be released now)
+        gathered = S.DeviceBuffer.from_numpy(np.concatenate(owns))  # all-gather
+        for r in range(G):
+            d.ev.switch_key_add_gathered(cts[r], gathered.ptr, G)
+            got = d.out(cts[r])
+            for b in range(batch):
+                _eq(got[b][:planes_kept], want[b][:planes_kept], "reduce-scatter exchange, rank %d of %d, item %d" % (r, G, b))
+        return want
+
+    want = run(lambda: d.ct(x3), lambda c, r, f, cnt, acc: d.ev.relinearize_partial(c, rlks[r], f, cnt, acc.ptr),
+               lambda c: d.ev.relinearize_inplace(c, d.rlk), 2)
+    for b in range(batch):
+        _eq(want[b], o.relinearize(x3[b]), "relinearize item %d vs oracle" % b)
+    want = run(lambda: d.ct(x2), lambda c, r, f, cnt, acc: d.ev.apply_galois_partial(c, elt, glks[r], f, cnt, acc.ptr),
+               lambda c: d.ev.apply_galois_inplace(c, elt, d.glk), 2)
+    for b in range(batch):
+        _eq(want[b], o.apply_galois(x2[b], elt), "apply_galois item %d vs oracle" % b)
+    # the library's own driver on a one-rank communicator (real RCCL on the GPU box, loopback under emulation), both shapes
+    comm = S.Comm(S.Comm.unique_id(), 1, 0)
+    assert comm.digit_range(K) == (0, K)
+    for exchange in (S.Comm.ALL_REDUCE, S.Comm.REDUCE_SCATTER):
+        c3, c2, cr = d.ct(x3), d.ct(x2), d.ct(x2)
+        d.ev.relinearize_inplace_dp(c3, d.rlk, comm, exchange)
+        d.ev.apply_galois_inplace_dp(c2, elt, d.glk, comm, exchange)
+        d.ev.rotate_vector_inplace_dp(cr, 1, d.glk, comm, exchange)
+        assert c3.size() == 2
+        g3, g2, gr = d.out(c3), d.out(c2), d.out(cr)
+        for b in range(batch):
+            _eq(g3[b], o.relinearize(x3[b]), "driver relinearize (exchange %d) item %d" % (exchange, b))
+            _eq(g2[b], o.apply_galois(x2[b], elt), "driver apply_galois (exchange %d) item %d" % (exchange, b))
+            _eq(gr[b], o.apply_galois(x2[b], elt), "driver rotate_vector (exchange %d) item %d" % (exchange, b))
+    # one-time key distribution: the full key is staged on the device, "broadcast" over the one-rank communicator, and the
+    # evaluator keeps this rank's digits (all of them here)
+    stage = S.DeviceBuffer.from_numpy(rlk_words)
+    rk = S.RelinKeys(d.ctx)
+    d.ev.broadcast_key_digits(rk, 0, stage.ptr, comm, 0)
+    c3 = d.ct(x3)
+    d.ev.relinearize_inplace_dp(c3, rk, comm, S.Comm.REDUCE_SCATTER)
+    g3 = d.out(c3)
+    for b in range(batch):
+        _eq(g3[b], o.relinearize(x3[b]), "relinearize with a broadcast key, item %d" % b)
+    return comm.loopback()
 
 
 # ---- plaintext operands and many-operand forms (SURVEY 8(f) N1): add_plain / sub_plain / multiply_plain in every form

@@ -199,3 +199,16 @@ def test_ks2_second_geometry_in_a_subprocess():
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SEALHIP_KS2_V2="1", HIPEMU_TRACE="1"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "v2 ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert "ks2v2_kernel" in out.stderr, "the second geometry did not run"
+
+
+@pytest.mark.parametrize("n,bits,parts,batch", [
+    (64, [40, 30, 30, 40], 2, 2),
+    (1024, [50, 40, 40, 50], 4, 2),          # more ranks than digits: one rank has neither digits nor moduli
+    (128, [40, 30, 30, 30, 30, 40], 3, 1),
+    (8192, [60, 40, 40, 50, 60], 3, 2),      # two-pass engine, fused tail
+])
+def test_digit_parallel_reduce_scatter(emu, n, bits, parts, batch):
+    """the reduce-scatter shape of the key-switch exchange (sealhip.h section 1c) with emulated ranks, partition arithmetic
+    of pack / owned mod-down / add; and the library's driver + key broadcast on a one-rank (loopback) communicator"""
+    primes = coeff_modulus_create(n, bits)
+    assert P.case_digit_parallel_reduce_scatter(n, primes, parts=parts, batch=batch) is True  # loopback: no RCCL on this box

@@ -159,6 +159,22 @@ def test_digit_parallel_key_switch(gpu, scheme, n, bits, tb, parts, batch):
     P.case_digit_parallel(scheme, n, primes, t, parts=parts, batch=batch)
 
 
+@pytest.mark.parametrize("n,bits,parts,batch", [
+    (1024, [50, 40, 40, 50], 4, 2),
+    (8192, [60, 40, 40, 50, 60], 3, 2),
+    (65536, [60] + [50] * 14 + [60], 8, 1),      # north-star parameters: 15 digits / 15 moduli over 8 ranks
+])
+def test_digit_parallel_reduce_scatter(gpu, n, bits, parts, batch):
+    """exchange 1 of sealhip.h section 1c (reduce-scatter by target modulus + all-gather): emulated ranks on one GPU, then the
+    library's own driver and key broadcast through a ONE-RANK RCCL communicator (real ncclReduceScatter / AllGather /
+    AllReduce / Broadcast calls on the evaluator's stream)"""
+    import seal_amd as S
+    primes = coeff_modulus_create(n, bits)
+    loopback = P.case_digit_parallel_reduce_scatter(n, primes, parts=parts, batch=batch)
+    assert S.Comm.rccl_available(), "librccl.so.1 did not load on the GPU box"
+    assert loopback is False, "the communicator fell back to loopback although RCCL is available"
+
+
 # ---- plaintext operands and many-operand forms (SURVEY 8(f) N1), against the real reference
 @pytest.mark.parametrize("scheme,n,bits,tb,batch", [
     ("ckks", 4096, [40, 30, 30, 40], 0, 2),
