@@ -122,6 +122,8 @@ SHL_FUNC Ciphertext_IsTransparent(void *thisptr, bool *result); /* synchronises 
 SHL_FUNC Ciphertext_DevicePtr(void *thisptr, uint64_t **data, uint64_t *word_count);
 SHL_FUNC Ciphertext_CopyFromHost(void *thisptr, const uint64_t *src, uint64_t word_count);
 SHL_FUNC Ciphertext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count);
+/* a word range of the slab (the device-resident drop-in keeps the unaligned head / tail of a host buffer current with it) */
+SHL_FUNC Ciphertext_CopyWordsToHost(void *thisptr, uint64_t word_offset, uint64_t word_count, uint64_t *dst);
 SHL_FUNC Ciphertext_CopyFromDevice(void *thisptr, const uint64_t *src, uint64_t word_count, void *hip_stream);
 
 /* Wire format (native/src/seal/c/ciphertext.h:80-86; Ciphertext::save / load / unsafe_load, native/src/seal/ciphertext.cpp:153-403):

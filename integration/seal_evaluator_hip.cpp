@@ -6,17 +6,35 @@
 // seal::Evaluator / seal::Ciphertext / seal::RelinKeys / seal::GaloisKeys link unchanged.
 //
 // Shape of a call: validate what the reference validates before touching data (so the same exception class is thrown for
-// the same input), upload the operands (Ciphertext::data() has exactly the device layout for batch = 1), run the device
-// operation, download the result and copy the metadata back.  Device state lives in a process-wide registry keyed by
-// SEALContext::key_parms_id() because the class layout is fixed by the header (its only member is the context,
-// evaluator.h:1385).  Key-switching keys are uploaded once per key object and cached.  This flavour pays two PCIe copies
-// per call; device-resident pipelines use the batch handles of sealhip.h directly.
+// the same input), bring the operands to the device, run the device operation, update the host object's bookkeeping.
+// Device state lives in a process-wide registry keyed by SEALContext::key_parms_id() because the class layout is fixed by
+// the header (its only member is the context, evaluator.h:1385).  Key-switching keys are uploaded once per key object.
+//
+// DEVICE-RESIDENT CIPHERTEXTS.  A seal::Ciphertext is a host object whose words are reached through inline
+// accessors, so the only way to keep a chain of operations on the device without touching the headers is to make the HOST
+// BUFFER ITSELF tell us when somebody looks at it.  Every result stays in HBM as the "mirror" of the host buffer it belongs
+// to (registry keyed by Ciphertext::data()); the host object gets its size / parms_id / scale updated, its buffer is resized
+// WITHOUT copy or zero-fill, and the whole pages of that buffer are made inaccessible (mprotect PROT_NONE).  The next
+// Evaluator call on the object finds the mirror and runs without any PCIe traffic.  The first host access - Decryptor,
+// save(), operator=, user code, or the pool handing the buffer to another object - faults, the SIGSEGV handler copies the
+// words down, opens the pages and drops the mirror, and the access proceeds.  Operands uploaded from valid host memory are
+// kept as read-only mirrors (PROT_READ) so that a second use skips the upload; a host write drops them.  With the
+// reference's allocator hook (SEAL_MALLOC / SEAL_FREE, util/defines.h:170-179, pointed at seal_alloc_hook.cpp by
+// integration/config_hip) pool chunks are page-aligned, so a ciphertext buffer is whole pages; without the hook the
+// unaligned head and tail of a buffer are copied down eagerly after every operation.  SEALHIP_DROPIN_EAGER=1 restores the
+// upload / download per call of the first version (A/B runs).
 //
 // Built by integration/Makefile into integration/_build/libsealdropin*.so together with the reference's other objects;
 // tests/test_dropin.py drives it through the same flat C shim as the real reference and compares word for word.
 #include "seal/evaluator.h"
 #include "seal/valcheck.h"
 #include "sealhip.h"
+#include <execinfo.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -121,39 +139,372 @@ namespace
         }
     };
 
-    void upload(Dev &d, const Ciphertext &x, DCt &out)
+    // ------------------------------------------------------------------------------------------------ host mirrors
+    struct Mirror
     {
-        ck(Ciphertext_Create3(d.ctx, nullptr, &out.h));
-        if (x.size())
-        {
-            parms_id_type pid = x.parms_id();
-            ck(Ciphertext_Resize1(out.h, d.ctx, pid.data(), x.size()));
-            ck(Ciphertext_CopyFromHost(out.h, x.data(), x.size() * x.coeff_modulus_size() * x.poly_modulus_degree()));
-        }
-        ck(Ciphertext_SetIsNTTForm(out.h, x.is_ntt_form()));
-        ck(Ciphertext_SetScale(out.h, x.scale()));
-        ck(Ciphertext_SetCorrectionFactor(out.h, x.correction_factor()));
+        std::uintptr_t begin = 0;      // host buffer [begin, begin + bytes)
+        std::size_t bytes = 0;
+        std::uintptr_t pbegin = 0, pend = 0; // the whole pages inside it (what is protected)
+        void *dev = nullptr;           // device Ciphertext handle (owned)
+        Dev *owner = nullptr;
+        parms_id_type parms_id{};
+        bool host_valid = false;       // true: host == device, pages PROT_READ;  false: host stale, pages PROT_NONE
+    };
+    struct Mirrors
+    {
+        std::recursive_mutex mu;
+        std::map<std::uintptr_t, Mirror> by_begin;
+        std::size_t page = 4096;
+        bool eager = false, trace = false;
+        struct sigaction previous{};
+        // statistics (tests, tools): transfers avoided / done
+        std::size_t uploads = 0, downloads = 0, reused = 0, faults = 0;
+    };
+    Mirrors &mirrors();
+    void segv_handler(int sig, siginfo_t *info, void *uctx);
+
+    Mirrors &mirrors()
+    {
+        static Mirrors *m = [] {
+            auto *mm = new Mirrors; // never destroyed: the handler may run during process teardown
+            mm->page = (std::size_t)sysconf(_SC_PAGESIZE);
+            mm->eager = std::getenv("SEALHIP_DROPIN_EAGER") != nullptr;
+            mm->trace = std::getenv("SEALHIP_DROPIN_TRACE") != nullptr;
+            struct sigaction sa{};
+            sa.sa_sigaction = segv_handler;
+            sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+            sigemptyset(&sa.sa_mask);
+            sigaction(SIGSEGV, &sa, &mm->previous);
+            return mm;
+        }();
+        return *m;
     }
-    void download(const SEALContext &c, const DCt &in, Ciphertext &x)
+    void protect(const Mirror &m, int prot)
     {
+        if (m.pend > m.pbegin)
+            mprotect(reinterpret_cast<void *>(m.pbegin), m.pend - m.pbegin, prot);
+    }
+    // host copy of a stale mirror becomes current (pages opened first)
+    void bring_down(Mirrors &mm, Mirror &m)
+    {
+        protect(m, PROT_READ | PROT_WRITE);
+        if (!m.host_valid)
+        {
+            ck(Ciphertext_CopyToHost(m.dev, reinterpret_cast<uint64_t *>(m.begin), m.bytes / 8));
+            mm.downloads++;
+            m.host_valid = true;
+        }
+    }
+    void destroy(Mirror &m)
+    {
+        if (m.dev)
+            Ciphertext_Destroy(m.dev);
+        m.dev = nullptr;
+    }
+    // every mirror overlapping [lo, hi): host made current, pages opened, mirror dropped
+    void resolve_range(std::uintptr_t lo, std::uintptr_t hi, const Mirror *keep = nullptr)
+    {
+        Mirrors &mm = mirrors();
+        std::lock_guard<std::recursive_mutex> g(mm.mu);
+        auto it = mm.by_begin.lower_bound(lo);
+        if (it != mm.by_begin.begin())
+            --it;
+        while (it != mm.by_begin.end() && it->first < hi)
+        {
+            Mirror &m = it->second;
+            if (&m != keep && m.begin < hi && m.begin + m.bytes > lo)
+            {
+                bring_down(mm, m);
+                destroy(m);
+                it = mm.by_begin.erase(it);
+            }
+            else
+                ++it;
+        }
+    }
+    // called by the allocator hook when a pool chunk goes back to the system: nothing may stay protected or registered
+    void forget_range(std::uintptr_t lo, std::uintptr_t hi)
+    {
+        Mirrors &mm = mirrors();
+        std::lock_guard<std::recursive_mutex> g(mm.mu);
+        auto it = mm.by_begin.lower_bound(lo);
+        if (it != mm.by_begin.begin())
+            --it;
+        while (it != mm.by_begin.end() && it->first < hi)
+        {
+            Mirror &m = it->second;
+            if (m.begin < hi && m.begin + m.bytes > lo)
+            {
+                protect(m, PROT_READ | PROT_WRITE); // the contents die with the chunk: no copy
+                destroy(m);
+                it = mm.by_begin.erase(it);
+            }
+            else
+                ++it;
+        }
+    }
+    void segv_handler(int sig, siginfo_t *info, void *uctx)
+    {
+        Mirrors &mm = mirrors();
+        const std::uintptr_t addr = reinterpret_cast<std::uintptr_t>(info->si_addr);
+        bool ours = false;
+        {
+            std::lock_guard<std::recursive_mutex> g(mm.mu);
+            auto it = mm.by_begin.upper_bound(addr);
+            if (it != mm.by_begin.begin())
+            {
+                --it;
+                Mirror &m = it->second;
+                if (addr >= m.pbegin && addr < m.pend)
+                {
+                    ours = true;
+                    mm.faults++;
+                    if (mm.trace)
+                        std::fprintf(stderr, "[dropin] fault at %p in mirror [%p, +%zu) host_valid=%d\n", info->si_addr,
+                                     reinterpret_cast<void *>(m.begin), m.bytes, (int)m.host_valid);
+                    if (mm.trace)
+                    {
+                        void *frames[24];
+                        backtrace_symbols_fd(frames, backtrace(frames, 24), 2);
+                    }
+                    bool write = true; // without the error code every fault is treated as a write (the mirror is dropped)
+#if defined(__x86_64__) && defined(REG_ERR)
+                    write = (static_cast<ucontext_t *>(uctx)->uc_mcontext.gregs[REG_ERR] & 0x2) != 0;
+#endif
+                    try
+                    {
+                        bring_down(mm, m);
+                    }
+                    catch (...)
+                    {
+                        // the device copy is unreachable: nothing sensible can be returned to the faulting access
+                        std::abort();
+                    }
+                    if (write)
+                    {
+                        if (mm.trace)
+                            std::fprintf(stderr, "[dropin]   write: mirror dropped\n");
+                        destroy(m);
+                        mm.by_begin.erase(it);
+                    }
+                    else
+                        protect(m, PROT_READ); // still mirrored: a later write drops it
+                }
+            }
+        }
+        if (ours)
+            return; // the faulting instruction is retried
+        // not ours: hand over to whoever was installed before (or the default action)
+        if (mm.previous.sa_flags & SA_SIGINFO)
+        {
+            if (mm.previous.sa_sigaction)
+            {
+                mm.previous.sa_sigaction(sig, info, uctx);
+                return;
+            }
+        }
+        else if (mm.previous.sa_handler != SIG_DFL && mm.previous.sa_handler != SIG_IGN)
+        {
+            mm.previous.sa_handler(sig);
+            return;
+        }
+        signal(SIGSEGV, SIG_DFL); // re-executing the instruction now terminates the process as it would have
+    }
+
+    std::size_t word_count(const Ciphertext &x)
+    {
+        return x.size() * x.coeff_modulus_size() * x.poly_modulus_degree();
+    }
+    void push_metadata(void *h, const Ciphertext &x)
+    {
+        ck(Ciphertext_SetIsNTTForm(h, x.is_ntt_form()));
+        ck(Ciphertext_SetScale(h, x.scale()));
+        ck(Ciphertext_SetCorrectionFactor(h, x.correction_factor()));
+    }
+    // fresh device handle holding x's words, copied from the host buffer
+    void *upload_new(Dev &d, const Ciphertext &x)
+    {
+        void *h = nullptr;
+        ck(Ciphertext_Create3(d.ctx, nullptr, &h));
+        try
+        {
+            if (x.size())
+            {
+                parms_id_type pid = x.parms_id();
+                ck(Ciphertext_Resize1(h, d.ctx, pid.data(), x.size()));
+                ck(Ciphertext_CopyFromHost(h, x.data(), word_count(x)));
+            }
+            push_metadata(h, x);
+        }
+        catch (...)
+        {
+            Ciphertext_Destroy(h);
+            throw;
+        }
+        return h;
+    }
+    // A device handle for an operand.  owned == true: the caller destroys it (or hands it to publish()).
+    struct Operand
+    {
+        void *h = nullptr;
+        bool owned = false;
+    };
+    // the mirror of x if it is still x's: same buffer, same extent, same level, same context
+    Mirror *find_mirror(Mirrors &mm, Dev &d, const Ciphertext &x)
+    {
+        auto it = mm.by_begin.find(reinterpret_cast<std::uintptr_t>(x.data()));
+        if (it == mm.by_begin.end())
+            return nullptr;
+        Mirror &m = it->second;
+        if (m.owner != &d || m.bytes != word_count(x) * 8 || m.parms_id != x.parms_id())
+            return nullptr;
+        uint64_t dev_size = 0;
+        if (Ciphertext_Size(m.dev, &dev_size) != 0 || dev_size != x.size())
+            return nullptr;
+        return &m;
+    }
+    Operand acquire(Dev &d, const Ciphertext &x)
+    {
+        Mirrors &mm = mirrors();
+        const std::uintptr_t lo = reinterpret_cast<std::uintptr_t>(x.data()), hi = lo + word_count(x) * 8;
+        if (x.size() && !mm.eager)
+        {
+            std::lock_guard<std::recursive_mutex> g(mm.mu);
+            if (Mirror *m = find_mirror(mm, d, x))
+            {
+                push_metadata(m->dev, x); // scale / form flags are host-side fields the caller may have changed
+                mm.reused++;
+                return Operand{ m->dev, false };
+            }
+        }
+        // the host buffer is the source: whatever else claims these addresses is settled first, from ordinary context (a copy
+        // routine of the runtime must never fault on a protected page)
+        if (x.size())
+            resolve_range(lo, hi);
+        Operand op{ upload_new(d, x), true };
+        mm.uploads++;
+        return op;
+    }
+    // x := the result held by device handle h (ownership of h passes to the registry unless the buffer is too small to protect)
+    void publish(const SEALContext &c, Dev &d, void *h, Ciphertext &x)
+    {
+        Mirrors &mm = mirrors();
         uint64_t size = 0, pid_words[4];
-        ck(Ciphertext_Size(in.h, &size));
-        ck(Ciphertext_ParmsId(in.h, pid_words));
+        ck(Ciphertext_Size(h, &size));
+        ck(Ciphertext_ParmsId(h, pid_words));
         parms_id_type pid;
         std::memcpy(pid.data(), pid_words, sizeof(pid_words));
-        x.resize(c, pid, size);
-        if (size)
-            ck(Ciphertext_CopyToHost(in.h, x.data(), size * x.coeff_modulus_size() * x.poly_modulus_degree()));
         bool ntt = false;
         double scale = 1.0;
         uint64_t cf = 1;
-        ck(Ciphertext_IsNTTForm(in.h, &ntt));
-        ck(Ciphertext_Scale(in.h, &scale));
-        ck(Ciphertext_CorrectionFactor(in.h, &cf));
+        ck(Ciphertext_IsNTTForm(h, &ntt));
+        ck(Ciphertext_Scale(h, &scale));
+        ck(Ciphertext_CorrectionFactor(h, &cf));
+        auto cd = c.get_context_data(pid);
+        const std::size_t need = cd ? size * cd->parms().coeff_modulus().size() * cd->parms().poly_modulus_degree() : 0;
+        {
+            // x's present buffer: any mirror on it goes away WITHOUT a copy - its contents are being replaced (the handle
+            // being published may be that mirror's own)
+            std::lock_guard<std::recursive_mutex> g(mm.mu);
+            auto it = mm.by_begin.find(reinterpret_cast<std::uintptr_t>(x.data()));
+            if (it != mm.by_begin.end())
+            {
+                protect(it->second, PROT_READ | PROT_WRITE);
+                if (it->second.dev != h)
+                    destroy(it->second);
+                mm.by_begin.erase(it);
+            }
+        }
+        if (x.data())
+            resolve_range(reinterpret_cast<std::uintptr_t>(x.data()), reinterpret_cast<std::uintptr_t>(x.data()) + word_count(x) * 8);
+        // host bookkeeping without touching the words: the DynArray is resized with fill_zero = false (and emptied first when it
+        // has to grow, so that no old contents are copied), then Ciphertext::resize only records size / degree / parms_id
+        auto &words = const_cast<DynArray<Ciphertext::ct_coeff_type> &>(x.dyn_array());
+        if (words.capacity() < need)
+            words.resize(0, false);
+        words.resize(need, false);
+        x.resize(c, pid, size);
         x.is_ntt_form() = ntt;
         x.scale() = scale;
         x.correction_factor() = cf;
+        if (!need)
+        {
+            Ciphertext_Destroy(h);
+            return;
+        }
+        Mirror m;
+        m.begin = reinterpret_cast<std::uintptr_t>(x.data());
+        m.bytes = need * 8;
+        m.pbegin = (m.begin + mm.page - 1) / mm.page * mm.page;
+        m.pend = (m.begin + m.bytes) / mm.page * mm.page;
+        m.dev = h;
+        m.owner = &d;
+        m.parms_id = pid;
+        m.host_valid = false;
+        if (mm.eager || m.pend <= m.pbegin)
+        {
+            // nothing to protect (a buffer below two pages) or A/B mode: plain download
+            ck(Ciphertext_CopyToHost(h, x.data(), need));
+            mm.downloads++;
+            Ciphertext_Destroy(h);
+            return;
+        }
+        // the new buffer may overlap other mirrors' address ranges (the pool recycled memory): settle them
+        resolve_range(m.begin, m.begin + m.bytes);
+        // unaligned head / tail (absent with the page-aligned allocator hook) are kept current on the host
+        if (m.pbegin > m.begin)
+            ck(Ciphertext_CopyWordsToHost(h, 0, (m.pbegin - m.begin) / 8, x.data()));
+        if (m.begin + m.bytes > m.pend)
+            ck(Ciphertext_CopyWordsToHost(h, (m.pend - m.begin) / 8, (m.begin + m.bytes - m.pend) / 8, x.data() + (m.pend - m.begin) / 8));
+        std::lock_guard<std::recursive_mutex> g(mm.mu);
+        protect(m, PROT_NONE);
+        mm.by_begin[m.begin] = m;
+        if (mm.trace)
+            std::fprintf(stderr, "[dropin] publish [%p, +%zu) protected [%p, %p)\n", reinterpret_cast<void *>(m.begin), m.bytes,
+                         reinterpret_cast<void *>(m.pbegin), reinterpret_cast<void *>(m.pend));
     }
+    // an operand that was uploaded from valid host memory stays on the device as a read-only mirror of that memory
+    void retain_clean(Dev &d, const Ciphertext &x, Operand &op)
+    {
+        Mirrors &mm = mirrors();
+        if (!op.owned)
+            return;
+        if (mm.eager || !x.size())
+        {
+            Ciphertext_Destroy(op.h);
+            op.owned = false;
+            return;
+        }
+        Mirror m;
+        m.begin = reinterpret_cast<std::uintptr_t>(x.data());
+        m.bytes = word_count(x) * 8;
+        m.pbegin = (m.begin + mm.page - 1) / mm.page * mm.page;
+        m.pend = (m.begin + m.bytes) / mm.page * mm.page;
+        // only buffers made of whole pages can be watched for writes (a write to an unprotected head / tail would go unseen)
+        if (m.pbegin != m.begin || m.pend != m.begin + m.bytes)
+        {
+            Ciphertext_Destroy(op.h);
+            op.owned = false;
+            return;
+        }
+        m.dev = op.h;
+        m.owner = &d;
+        m.parms_id = x.parms_id();
+        m.host_valid = true;
+        std::lock_guard<std::recursive_mutex> g(mm.mu);
+        protect(m, PROT_READ);
+        mm.by_begin[m.begin] = m;
+        op.owned = false;
+        if (mm.trace)
+            std::fprintf(stderr, "[dropin] operand kept on the device, host buffer [%p, +%zu) read-only\n", reinterpret_cast<void *>(m.begin), m.bytes);
+    }
+    void release(Operand &op)
+    {
+        if (op.owned && op.h)
+            Ciphertext_Destroy(op.h);
+        op.owned = false;
+    }
+
     void upload(Dev &d, const Plaintext &p, DPt &out)
     {
         ck(Plaintext_Create1(d.ctx, &out.h));
@@ -219,31 +570,90 @@ namespace
         return h;
     }
 
-    // one in-place ciphertext operation: upload, run, download
+    // one in-place ciphertext operation on the device copy of x; x's host buffer becomes the (protected) shadow of the result
     template <class Fn>
     void unary(const SEALContext &c, Ciphertext &x, Fn fn)
     {
         Dev &d = device_for(c);
-        DCt a;
-        upload(d, x, a);
-        ck(fn(d, a.h));
-        download(c, a, x);
+        Operand a = acquire(d, x);
+        try
+        {
+            ck(fn(d, a.h));
+        }
+        catch (...)
+        {
+            release(a); // a borrowed mirror stays what it was: the device operations validate before they write
+            throw;
+        }
+        publish(c, d, a.h, x);
+    }
+    // destination := op(source) without a host copy of the source
+    template <class Fn>
+    void unary_to(const SEALContext &c, const Ciphertext &src, Ciphertext &dst, Fn fn)
+    {
+        if (&src == &dst)
+        {
+            unary(c, dst, fn);
+            return;
+        }
+        Dev &d = device_for(c);
+        Operand a = acquire(d, src);
+        void *h = nullptr;
+        try
+        {
+            ck(Ciphertext_Create2(a.h, &h)); // device-to-device copy
+            ck(fn(d, h));
+        }
+        catch (...)
+        {
+            if (h)
+                Ciphertext_Destroy(h);
+            release(a);
+            throw;
+        }
+        retain_clean(d, src, a);
+        publish(c, d, h, dst);
     }
     template <class Fn>
     void binary(const SEALContext &c, Ciphertext &x, const Ciphertext &y, Fn fn)
     {
         Dev &d = device_for(c);
-        DCt a, b;
-        upload(d, x, a);
+        Operand a = acquire(d, x), b;
+        try
+        {
+            if (&x != &y)
+                b = acquire(d, y);
+            ck(fn(d, a.h, &x == &y ? a.h : b.h));
+        }
+        catch (...)
+        {
+            release(a);
+            release(b);
+            throw;
+        }
         if (&x != &y)
-            upload(d, y, b);
-        ck(fn(d, a.h, &x == &y ? a.h : b.h));
-        download(c, a, x);
+            retain_clean(d, y, b);
+        publish(c, d, a.h, x);
     }
     void need_valid(const Ciphertext &x, const SEALContext &c, const char *what)
     {
-        // is_metadata_valid_for + is_buffer_valid, as every public method of the reference does first
-        if (!is_metadata_valid_for(x, c) || !is_buffer_valid(x))
+        // is_metadata_valid_for + is_buffer_valid, as every public method of the reference does first.  is_buffer_valid
+        // (valcheck.cpp:221-237) is the size check plus contains_seed(), which READS the first word of the second polynomial:
+        // for an object whose words live on the device (a result of this evaluator: never a seeded stream) only the size
+        // check is made, so that validating an operand does not pull it down
+        bool ok = is_metadata_valid_for(x, c);
+        if (ok)
+        {
+            bool on_device = false;
+            {
+                Mirrors &mm = mirrors();
+                std::lock_guard<std::recursive_mutex> g(mm.mu);
+                auto it = mm.by_begin.find(reinterpret_cast<std::uintptr_t>(x.data()));
+                on_device = it != mm.by_begin.end() && !it->second.host_valid && it->second.bytes == word_count(x) * 8;
+            }
+            ok = on_device ? x.dyn_array().size() == word_count(x) : is_buffer_valid(x);
+        }
+        if (!ok)
             throw std::invalid_argument(std::string(what) + " is not valid for encryption parameters");
     }
 } // namespace
@@ -324,9 +734,7 @@ namespace seal
         need_valid(encrypted, context_, "encrypted");
         if (!pool)
             throw std::invalid_argument("pool is uninitialized");
-        Ciphertext work = encrypted;
-        unary(context_, work, [](Dev &d, void *a) { return Evaluator_ModSwitchToNext1(d.ev, a, a, nullptr); });
-        destination = std::move(work);
+        unary_to(context_, encrypted, destination, [](Dev &d, void *a) { return Evaluator_ModSwitchToNext1(d.ev, a, a, nullptr); });
     }
     void Evaluator::mod_switch_to_inplace(Ciphertext &encrypted, parms_id_type parms_id, MemoryPoolHandle pool) const
     {
@@ -359,9 +767,7 @@ namespace seal
         need_valid(encrypted, context_, "encrypted");
         if (!pool)
             throw std::invalid_argument("pool is uninitialized");
-        Ciphertext work = encrypted;
-        unary(context_, work, [](Dev &d, void *a) { return Evaluator_RescaleToNext(d.ev, a, a, nullptr); });
-        destination = std::move(work);
+        unary_to(context_, encrypted, destination, [](Dev &d, void *a) { return Evaluator_RescaleToNext(d.ev, a, a, nullptr); });
     }
     void Evaluator::rescale_to_inplace(Ciphertext &encrypted, parms_id_type parms_id, MemoryPoolHandle pool) const
     {
@@ -404,23 +810,36 @@ namespace seal
                 throw std::invalid_argument("encrypteds must be different from destination");
         Dev &d = device_for(context_);
         void *keys = device_keys(d, context_, relin_keys);
-        std::vector<DCt> handles(encrypteds.size());
+        std::vector<Operand> handles(encrypteds.size());
         std::vector<void *> raw;
-        for (std::size_t i = 0; i < encrypteds.size(); i++)
+        void *out = nullptr;
+        try
         {
-            // identical operands share one device handle, as the reference detects them by data pointer (evaluator.cpp:1700)
-            std::size_t same = i;
-            for (std::size_t j = 0; j < i; j++)
-                if (encrypteds[j].data() == encrypteds[i].data())
-                    same = j;
-            if (same == i)
-                upload(d, encrypteds[i], handles[i]);
-            raw.push_back(handles[same].h);
+            for (std::size_t i = 0; i < encrypteds.size(); i++)
+            {
+                // identical operands share one device handle, as the reference detects them by data pointer (evaluator.cpp:1700)
+                std::size_t same = i;
+                for (std::size_t j = 0; j < i; j++)
+                    if (encrypteds[j].data() == encrypteds[i].data())
+                        same = j;
+                if (same == i)
+                    handles[i] = acquire(d, encrypteds[i]);
+                raw.push_back(handles[same].h);
+            }
+            ck(Ciphertext_Create3(d.ctx, nullptr, &out));
+            ck(Evaluator_MultiplyMany(d.ev, raw.size(), raw.data(), keys, out, nullptr));
         }
-        DCt out;
-        ck(Ciphertext_Create3(d.ctx, nullptr, &out.h));
-        ck(Evaluator_MultiplyMany(d.ev, raw.size(), raw.data(), keys, out.h, nullptr));
-        download(context_, out, destination);
+        catch (...)
+        {
+            if (out)
+                Ciphertext_Destroy(out);
+            for (auto &h : handles)
+                release(h);
+            throw;
+        }
+        for (std::size_t i = 0; i < encrypteds.size(); i++)
+            retain_clean(d, encrypteds[i], handles[i]);
+        publish(context_, d, out, destination);
     }
     void Evaluator::exponentiate_inplace(Ciphertext &encrypted, uint64_t exponent, const RelinKeys &relin_keys, MemoryPoolHandle pool) const
     {
@@ -527,3 +946,68 @@ namespace seal
         });
     }
 } // namespace seal
+
+// ---- the reference's allocator hook (SEAL_MALLOC / SEAL_FREE, native/src/seal/util/defines.h:170-179; used by
+// util/mempool.cpp:43,91 only).  integration/config_hip/seal/util/config.h points the two macros here when mempool.cpp is
+// compiled for the drop-in: pool chunks become page-aligned (every ciphertext buffer is then whole pages: no unaligned head
+// or tail to keep current) and a chunk that goes back to the system takes its mirrors with it.
+namespace
+{
+    struct Chunks
+    {
+        std::mutex mu;
+        std::map<std::uintptr_t, std::size_t> sizes; // page-aligned chunks handed to the pool
+    };
+    Chunks &chunks()
+    {
+        static Chunks *c = new Chunks; // never destroyed: the reference's global pool frees its chunks during static destruction
+        return *c;
+    }
+} // namespace
+extern "C" void *sealhip_host_alloc(std::size_t size)
+{
+    const std::size_t page = (std::size_t)sysconf(_SC_PAGESIZE);
+    if (size < 4 * page)
+        return std::malloc(size ? size : 1);
+    const std::size_t rounded = (size + page - 1) / page * page;
+    void *p = std::aligned_alloc(page, rounded);
+    if (!p)
+        throw std::bad_alloc();
+    Chunks &c = chunks();
+    std::lock_guard<std::mutex> g(c.mu);
+    c.sizes[reinterpret_cast<std::uintptr_t>(p)] = rounded;
+    return p;
+}
+extern "C" void sealhip_host_free(void *ptr)
+{
+    if (!ptr)
+        return;
+    std::size_t bytes = 0;
+    {
+        Chunks &c = chunks();
+        std::lock_guard<std::mutex> g(c.mu);
+        auto it = c.sizes.find(reinterpret_cast<std::uintptr_t>(ptr));
+        if (it != c.sizes.end())
+        {
+            bytes = it->second;
+            c.sizes.erase(it);
+        }
+    }
+    if (bytes)
+        forget_range(reinterpret_cast<std::uintptr_t>(ptr), reinterpret_cast<std::uintptr_t>(ptr) + bytes);
+    std::free(ptr);
+}
+// counters for tests and tools: uploads, downloads, operands found on the device, faults served
+extern "C" void sealhip_dropin_stats(uint64_t *uploads, uint64_t *downloads, uint64_t *reused, uint64_t *faults)
+{
+    Mirrors &mm = mirrors();
+    std::lock_guard<std::recursive_mutex> g(mm.mu);
+    if (uploads)
+        *uploads = mm.uploads;
+    if (downloads)
+        *downloads = mm.downloads;
+    if (reused)
+        *reused = mm.reused;
+    if (faults)
+        *faults = mm.faults;
+}

@@ -354,6 +354,14 @@ extern "C"
         REF_CATCH
     }
 
+    // dst = src through seal::Ciphertext::operator= (a host-side write into dst's buffer)
+    int ref_ct_assign(void *dst, void *src)
+    {
+        REF_TRY
+        static_cast<RefCt *>(dst)->ct = static_cast<RefCt *>(src)->ct;
+        REF_CATCH
+    }
+
     // ---- Evaluator ops (evaluator.h) ----------------------------------------------------
 #define CT(x) (static_cast<RefCt *>(x)->ct)
 #define EV (static_cast<RefCtx *>(ctx)->evaluator)
@@ -1163,6 +1171,24 @@ extern "C"
                         else
                             c->evaluator->rotate_rows_inplace(w, 1, c->glk, pool);
                         break;
+                    case 4:
+                    {
+                        // a chained program (CKKS): multiply, relinearize, rescale, rotate level after level on the same
+                        // object, the second operand following by mod_switch; the result is looked at once at the end
+                        Ciphertext bb = b;
+                        while (w.coeff_modulus_size() > 2)
+                        {
+                            c->evaluator->multiply_inplace(w, bb, pool);
+                            c->evaluator->relinearize_inplace(w, c->rlk, pool);
+                            c->evaluator->rescale_to_next_inplace(w, pool);
+                            c->evaluator->rotate_vector_inplace(w, 1, c->glk, pool);
+                            c->evaluator->mod_switch_to_next_inplace(bb, pool);
+                            bb.scale() = w.scale();
+                        }
+                        volatile std::uint64_t sink = w.data()[0] + w.data(1)[n - 1];
+                        (void)sink;
+                        break;
+                    }
                     default:
                         if (ckks)
                         {

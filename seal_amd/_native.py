@@ -61,7 +61,7 @@ Ciphertext_Create3 Ciphertext_CreateBatch Ciphertext_Create2 Ciphertext_Set Ciph
 Ciphertext_Size Ciphertext_BatchCount Ciphertext_PolyModulusDegree Ciphertext_CoeffModulusSize Ciphertext_ParmsId
 Ciphertext_IsNTTForm Ciphertext_SetIsNTTForm Ciphertext_Scale Ciphertext_SetScale Ciphertext_CorrectionFactor
 Ciphertext_SetCorrectionFactor Ciphertext_IsTransparent Ciphertext_DevicePtr Ciphertext_CopyFromHost
-Ciphertext_CopyToHost Ciphertext_CopyFromDevice
+Ciphertext_CopyToHost Ciphertext_CopyWordsToHost Ciphertext_CopyFromDevice
 Ciphertext_SaveSize Ciphertext_Save Ciphertext_UnsafeLoad Ciphertext_Load Ciphertext_LoadItem Ciphertext_SaveItem
 KSwitchKeys_UnsafeLoad KSwitchKeys_Load
 KeyGenerator_Create1 KeyGenerator_Create2 KeyGenerator_Destroy KeyGenerator_SecretKey KeyGenerator_CreatePublicKey

@@ -509,6 +509,19 @@ extern "C"
         hip_ok(hipMemcpy(dst, ct->data(), word_count * 8, hipMemcpyDeviceToHost), "D2H");
         SHL_CATCH
     }
+    SHL_FUNC Ciphertext_CopyWordsToHost(void *thisptr, uint64_t word_offset, uint64_t word_count, uint64_t *dst)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(dst, SHL_E_POINTER);
+        SHL_TRY
+        auto ct = as<Ciphertext>(thisptr);
+        if (word_offset > ct->word_count() || word_count > ct->word_count() - word_offset)
+            throw std::invalid_argument("word range outside the ciphertext slab");
+        hip_ok(hipDeviceSynchronize(), "sync");
+        if (word_count)
+            hip_ok(hipMemcpy(dst, ct->data() + word_offset, word_count * 8, hipMemcpyDeviceToHost), "D2H");
+        SHL_CATCH
+    }
     SHL_FUNC Ciphertext_CopyFromDevice(void *thisptr, const uint64_t *src, uint64_t word_count, void *hip_stream)
     {
         IfNullRet(thisptr, SHL_E_POINTER);

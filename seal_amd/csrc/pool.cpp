@@ -45,8 +45,10 @@ namespace sealhip
 
     DevicePool &DevicePool::global()
     {
-        static DevicePool pool;
-        return pool;
+        // never destroyed: device objects may be released during static destruction (a host library that owns handles and is
+        // torn down after this one), when the bookkeeping must still be there and the HIP runtime is not asked for anything
+        static DevicePool *pool = new DevicePool;
+        return *pool;
     }
     hipStream_t DevicePool::thread_stream()
     {

@@ -399,6 +399,10 @@ class RefContext:
                                 C.c_double(scale), C.c_uint64(correction_factor), _p(data), C.byref(h)))
         return RefCiphertext(self, h)
 
+    def ct_assign(self, dst, src):
+        """dst = src (seal::Ciphertext::operator=)"""
+        _ck(lib().ref_ct_assign(dst.h, src.h))
+
     def _op1(self, name, ct, *args):
         _ck(getattr(lib(), name)(self.h, ct.h, *args))
         return ct
@@ -552,7 +556,7 @@ class RefContext:
 
     # -- CPU baseline
     def time_pipeline(self, pipeline, threads, reps):
-        p = {"ckks_mul_relin_rescale": 0, "bfv_mul_relin_modswitch": 1, "rotate": 2, "ntt": 3}[pipeline]
+        p = {"ckks_mul_relin_rescale": 0, "bfv_mul_relin_modswitch": 1, "rotate": 2, "ntt": 3, "ckks_chain": 4}[pipeline]
         s = C.c_double()
         _ck(lib().ref_time_pipeline(self.h, C.c_int(p), C.c_int(threads), C.c_int(reps), C.byref(s)))
         return s.value

@@ -147,3 +147,116 @@ def test_dropin_end_to_end_gpu(gpu):
     if not (R.available() and os.path.exists(path)):
         pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
     _end_to_end(_bind(path), 8192, 4096)
+
+
+def _chain_program(lib, n, primes, a, b, b2, probe):
+    ctx = lib.RefContext("ckks", n, primes)
+    ctx.keygen_relin()
+    ctx.keygen_galois_steps([1])
+    fc = ctx.first_chain_index
+    x, y = ctx.ct(fc, a, True, 2.0 ** 10, 1), ctx.ct(fc, b, True, 2.0 ** 10, 1)
+    out = []
+    s0 = probe()
+    ctx.multiply_inplace(x, y)
+    ctx.relinearize_inplace(x)
+    ctx.rescale_to_next_inplace(x)
+    ctx.rotate_vector_inplace(x, 1)
+    s1 = probe()
+    snap_copy = x.copy()                 # host-side copy construction of a device-resident object (read fault)
+    out.append(snap_copy.data().copy())
+    out.append(x.data().copy())
+    s2 = probe()
+    ctx.square_inplace(x)                # x was read on the host, not written
+    ctx.relinearize_inplace(x)
+    s3 = probe()
+    ctx.multiply_inplace(snap_copy, snap_copy.copy())
+    out.append(snap_copy.data().copy())
+    z = ctx.ct(fc, a, True, 2.0 ** 10, 1)
+    ctx.multiply_inplace(z, y)           # y: uploaded once, above
+    s4 = probe()
+    out.append(z.data().copy())
+    # the second operand is overwritten on the host (operator=): its device copy must not be used again
+    y2 = ctx.ct(fc, b2, True, 2.0 ** 10, 1)
+    ctx.ct_assign(y, y2)
+    w = ctx.ct(fc, a, True, 2.0 ** 10, 1)
+    ctx.multiply_inplace(w, y)
+    out.append(w.data().copy())
+    out.append(x.data().copy())
+    return out, (s0, s1, s2, s3, s4)
+
+
+def _chain_inputs(n, bits):
+    primes = R.coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    rng = np.random.default_rng(12)
+    mk = lambda: np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)]) for _ in range(2)])  # noqa: E731
+    return primes, mk(), mk(), mk()
+
+
+def _dropin_stats(D):
+    import ctypes as C
+    v = [C.c_uint64() for _ in range(4)]
+    D.lib().sealhip_dropin_stats(*[C.byref(x) for x in v])
+    return dict(zip(("uploads", "downloads", "reused", "faults"), [x.value for x in v]))
+
+
+def _device_resident_chain(lib_name, n, bits, emulated):
+    """SURVEY 8(f) N2 behind the headers: a chain of in-place operations on seal::Ciphertext objects runs without PCIe traffic
+    (the host buffers are protected shadows of the device copies), host accesses of every kind see the right words, and a
+    host write to an operand invalidates its device copy.  Words: in this process, next to the reference (both libraries
+    loaded: they then share the reference's inline-static memory manager, the reference's pool serves both and the buffers are
+    NOT page-aligned - the unaligned head / tail path).  Transfer counts: in a process that loads only the drop-in (its own
+    pool through the SEAL_MALLOC hook: page-aligned buffers)."""
+    import subprocess
+    import sys
+    import tempfile
+    path = os.path.join(BUILD, lib_name)
+    primes, a, b, b2 = _chain_inputs(n, bits)
+    ref_out, _ = _chain_program(R, n, primes, a, b, b2, lambda: None)
+    D = _bind(path)
+    got_out, _ = _chain_program(D, n, primes, a, b, b2, lambda: _dropin_stats(D))
+    assert len(ref_out) == len(got_out)
+    for i, (r, g) in enumerate(zip(ref_out, got_out)):
+        assert r.shape == g.shape and np.array_equal(r, g), "snapshot %d differs from the reference" % i
+    with tempfile.TemporaryDirectory() as tmp:
+        out_path = os.path.join(tmp, "out.npz")
+        code = ("import sys, os, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "import numpy as np, seal_amd as S\n"
+                "S.load(%r) if %r else S.load()\n"
+                "import test_dropin as T\n"
+                "D = T._bind(%r)\n"
+                "primes, a, b, b2 = T._chain_inputs(%d, %r)\n"
+                "out, st = T._chain_program(D, %d, primes, a, b, b2, lambda: T._dropin_stats(D))\n"
+                "np.savez(%r, *out)\n"
+                "print('STATS ' + json.dumps(st))\n"
+                % (HERE, os.path.dirname(HERE), os.path.join(HERE, "hipemu", "libsealhip_emu.so"), emulated, path, n, bits, n, out_path))
+        run = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, SEALHIP_COMM_NO_RCCL="1") if emulated else dict(os.environ))
+        assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+        import json
+        st = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith("STATS ")][0][6:])
+        alone = np.load(out_path)
+        for i, r in enumerate(ref_out):
+            assert np.array_equal(r, alone["arr_%d" % i]), "snapshot %d (drop-in alone in its process) differs from the reference" % i
+    s0, s1, s2, s3, s4 = st
+    # the four chained operations moved x and y up once and nothing down
+    assert s1["uploads"] - s0["uploads"] == 2 and s1["downloads"] == s0["downloads"] and s1["faults"] == s0["faults"], (s0, s1)
+    assert s1["reused"] - s0["reused"] >= 3
+    # the host copy and the snapshot cost exactly one download (x stays mirrored read-only afterwards)
+    assert s2["downloads"] - s1["downloads"] == 1 and s2["faults"] > s1["faults"], (s1, s2)
+    assert s3["uploads"] == s2["uploads"], "x was read on the host, not written: its device copy is still good"
+    assert s4["reused"] > s3["reused"], "an operand uploaded once is found on the device the second time"
+
+
+def test_dropin_device_resident_chain_emulated(emu):
+    if not (R.available() and os.path.exists(os.path.join(BUILD, "libsealdropin_emu.so"))):
+        pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
+    _device_resident_chain("libsealdropin_emu.so", 4096, [60, 40, 40, 60], True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,bits", [(8192, [60, 40, 40, 60]), (65536, [60] + [50] * 14 + [60])])
+def test_dropin_device_resident_chain_gpu(gpu, n, bits):
+    if not (R.available() and os.path.exists(os.path.join(BUILD, "libsealdropin.so"))):
+        pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
+    _device_resident_chain("libsealdropin.so", n, bits, False)
