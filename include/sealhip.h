@@ -398,6 +398,10 @@ SHL_FUNC shl_rns_stage(void *context, uint64_t chain_index, int which, const uin
 /* the pool of cached HBM blocks (the role of MemoryManager / MemoryPool, native/src/seal/memorymanager.h:75-265): give the
  * cached blocks back to the driver; counters for tests */
 SHL_FUNC SealHip_ReleasePool(void);
+/* Ciphertext_CopyFromHost / CopyToHost / CopyWordsToHost through pinned bounce buffers owned by the library instead of a
+ * direct hipMemcpy on the caller's buffer, so that the caller's pages are never registered with the driver.  For hosts that
+ * change the protection of their own buffers (integration/seal_evaluator_hip.cpp); process-wide, off by default. */
+SHL_FUNC SealHip_SetStagedHostCopies(bool enabled);
 SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
 /* stream and device memory helpers for bindings without their own runtime (a PyTorch / HIP caller passes its own streams) */
 SHL_FUNC shl_stream_create(bool non_blocking, void **hip_stream);

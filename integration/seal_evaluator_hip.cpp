@@ -33,6 +33,7 @@
 #include <signal.h>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -162,6 +163,7 @@ namespace
     };
     Mirrors &mirrors();
     void segv_handler(int sig, siginfo_t *info, void *uctx);
+    void settle_all_at_exit();
 
     Mirrors &mirrors()
     {
@@ -170,6 +172,13 @@ namespace
             mm->page = (std::size_t)sysconf(_SC_PAGESIZE);
             mm->eager = std::getenv("SEALHIP_DROPIN_EAGER") != nullptr;
             mm->trace = std::getenv("SEALHIP_DROPIN_TRACE") != nullptr;
+            // the library must not register our (pageable) buffers with the driver: their protection changes
+            if (!mm->eager)
+                SealHip_SetStagedHostCopies(true);
+            // At process exit every shadow is settled while the HIP runtime is still alive (this handler is registered late, so
+            // it runs before the destructors of the pools and of the runtime): afterwards nothing is protected any more and
+            // later calls, if any, copy eagerly.
+            std::atexit(settle_all_at_exit);
             struct sigaction sa{};
             sa.sa_sigaction = segv_handler;
             sa.sa_flags = SA_SIGINFO | SA_NODEFER;
@@ -200,6 +209,25 @@ namespace
         if (m.dev)
             Ciphertext_Destroy(m.dev);
         m.dev = nullptr;
+    }
+    void settle_all_at_exit()
+    {
+        Mirrors &m = mirrors();
+        std::lock_guard<std::recursive_mutex> g(m.mu);
+        for (auto &kv : m.by_begin)
+        {
+            try
+            {
+                bring_down(m, kv.second);
+            }
+            catch (...)
+            {
+                protect(kv.second, PROT_READ | PROT_WRITE);
+            }
+            destroy(kv.second);
+        }
+        m.by_begin.clear();
+        m.eager = true;
     }
     // every mirror overlapping [lo, hi): host made current, pages opened, mirror dropped
     void resolve_range(std::uintptr_t lo, std::uintptr_t hi, const Mirror *keep = nullptr)
@@ -452,6 +480,8 @@ namespace
         // the new buffer may overlap other mirrors' address ranges (the pool recycled memory): settle them
         resolve_range(m.begin, m.begin + m.bytes);
         // unaligned head / tail (absent with the page-aligned allocator hook) are kept current on the host
+        // (each copy drains the device first: skipped altogether when the buffer is whole pages, so that the call returns
+        // while the operation is still running)
         if (m.pbegin > m.begin)
             ck(Ciphertext_CopyWordsToHost(h, 0, (m.pbegin - m.begin) / 8, x.data()));
         if (m.begin + m.bytes > m.pend)
@@ -570,12 +600,18 @@ namespace
         return h;
     }
 
+    inline double now_s()
+    {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
     // one in-place ciphertext operation on the device copy of x; x's host buffer becomes the (protected) shadow of the result
     template <class Fn>
     void unary(const SEALContext &c, Ciphertext &x, Fn fn)
     {
         Dev &d = device_for(c);
+        const double t0 = mirrors().trace ? now_s() : 0;
         Operand a = acquire(d, x);
+        const double t1 = mirrors().trace ? now_s() : 0;
         try
         {
             ck(fn(d, a.h));
@@ -585,7 +621,11 @@ namespace
             release(a); // a borrowed mirror stays what it was: the device operations validate before they write
             throw;
         }
+        const double t2 = mirrors().trace ? now_s() : 0;
         publish(c, d, a.h, x);
+        if (mirrors().trace)
+            std::fprintf(stderr, "[dropin] unary: acquire %.3f ms, operation %.3f ms, publish %.3f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3,
+                         (now_s() - t2) * 1e3);
     }
     // destination := op(source) without a host copy of the source
     template <class Fn>

@@ -1183,7 +1183,8 @@ extern "C"
                             c->evaluator->rescale_to_next_inplace(w, pool);
                             c->evaluator->rotate_vector_inplace(w, 1, c->glk, pool);
                             c->evaluator->mod_switch_to_next_inplace(bb, pool);
-                            bb.scale() = w.scale();
+                            w.scale() = scale; // synthetic words: keep the bookkeeping value in range level after level
+                            bb.scale() = scale;
                         }
                         volatile std::uint64_t sink = w.data()[0] + w.data(1)[n - 1];
                         (void)sink;

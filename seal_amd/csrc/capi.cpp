@@ -9,6 +9,7 @@
 #include "keygen.h"
 #include "serial.h"
 #include "xof.h"
+#include <atomic>
 #include <cstring>
 #include <new>
 #include <string>
@@ -494,7 +495,7 @@ extern "C"
         if (word_count != ct->word_count())
             throw std::invalid_argument("word_count does not match the ciphertext slab");
         hip_ok(hipDeviceSynchronize(), "sync");
-        hip_ok(hipMemcpy(ct->data(), src, word_count * 8, hipMemcpyHostToDevice), "H2D");
+        copy_h2d(ct->data(), src, word_count * 8);
         SHL_CATCH
     }
     SHL_FUNC Ciphertext_CopyToHost(void *thisptr, uint64_t *dst, uint64_t word_count)
@@ -506,7 +507,7 @@ extern "C"
         if (word_count != ct->word_count())
             throw std::invalid_argument("word_count does not match the ciphertext slab");
         hip_ok(hipDeviceSynchronize(), "sync");
-        hip_ok(hipMemcpy(dst, ct->data(), word_count * 8, hipMemcpyDeviceToHost), "D2H");
+        copy_d2h(dst, ct->data(), word_count * 8);
         SHL_CATCH
     }
     SHL_FUNC Ciphertext_CopyWordsToHost(void *thisptr, uint64_t word_offset, uint64_t word_count, uint64_t *dst)
@@ -519,7 +520,7 @@ extern "C"
             throw std::invalid_argument("word range outside the ciphertext slab");
         hip_ok(hipDeviceSynchronize(), "sync");
         if (word_count)
-            hip_ok(hipMemcpy(dst, ct->data() + word_offset, word_count * 8, hipMemcpyDeviceToHost), "D2H");
+            copy_d2h(dst, ct->data() + word_offset, word_count * 8);
         SHL_CATCH
     }
     SHL_FUNC Ciphertext_CopyFromDevice(void *thisptr, const uint64_t *src, uint64_t word_count, void *hip_stream)
@@ -1669,7 +1670,7 @@ extern "C"
         if (word_count)
         {
             if (hipDeviceSynchronize() != hipSuccess ||
-                hipMemcpy(dst, pt->data(), word_count * 8, hipMemcpyDeviceToHost) != hipSuccess)
+                (copy_d2h(dst, pt->data(), word_count * 8), false))
                 throw std::runtime_error("HIP failure in Plaintext_CopyToHost");
         }
         SHL_CATCH
@@ -2302,6 +2303,11 @@ extern "C"
         else
             throw std::invalid_argument("unknown stage");
         SHL_CATCH
+    }
+    SHL_FUNC SealHip_SetStagedHostCopies(bool enabled)
+    {
+        set_staged_host_copies(enabled);
+        return SHL_S_OK;
     }
     SHL_FUNC SealHip_ReleasePool(void)
     {

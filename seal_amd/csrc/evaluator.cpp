@@ -237,8 +237,13 @@ namespace sealhip
         level_ = nullptr;
         coeff_count_ = 0;
         resize(count, nullptr);
-        if (count)
-            ck(hipMemcpy(data_, words, count * 8, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "Plaintext set");
+        if (count && from_device)
+            ck(hipMemcpy(data_, words, count * 8, hipMemcpyDeviceToDevice), "Plaintext set");
+        else if (count)
+        {
+            ck(hipDeviceSynchronize(), "Plaintext set");
+            copy_h2d(data_, words, count * 8);
+        }
     }
     void Plaintext::adopt(uint64_t *slab, size_t count, size_t capacity_words)
     {
@@ -276,7 +281,12 @@ namespace sealhip
         const size_t bytes = digits * 2 * ctx.key_level().K * ctx.n() * 8;
         set_key_with(
             ctx, index, digits,
-            [&](uint64_t *dst) { ck(hipMemcpy(dst, words, bytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice), "upload key"); },
+            [&](uint64_t *dst) {
+                if (from_device)
+                    ck(hipMemcpy(dst, words, bytes, hipMemcpyDeviceToDevice), "upload key");
+                else
+                    copy_h2d(dst, words, bytes);
+            },
             digit0);
     }
     void KSwitchKeys::set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0)

@@ -1,6 +1,11 @@
 // DevicePool: stream-aware caching allocator for HBM scratch and slabs (see pool.h).
 #include "pool.h"
+#include <algorithm>
+#include <atomic>
+#include <cstring>
 #include <new>
+#include <stdexcept>
+#include <string>
 
 namespace sealhip
 {
@@ -284,5 +289,109 @@ namespace sealhip
     DevicePool::~DevicePool()
     {
         // process teardown: the HIP runtime may already be gone; leak rather than crash
+    }
+
+    // ---------------------------------------------------------------- host copies (see pool.h)
+    namespace
+    {
+        void hip_ok(hipError_t e, const char *what)
+        {
+            if (e != hipSuccess)
+                throw std::runtime_error(std::string("HIP failure in ") + what + ": " + hipGetErrorString(e));
+        }
+        struct Staging
+        {
+            static constexpr size_t kChunk = size_t(4) << 20;
+            std::mutex mu;
+            uint8_t *buf[2] = { nullptr, nullptr };
+            hipEvent_t done[2] = { nullptr, nullptr };
+            hipStream_t stream = nullptr;
+            bool ready()
+            {
+                if (stream)
+                    return true;
+                for (int i = 0; i < 2; i++)
+                    if (hipHostMalloc(reinterpret_cast<void **>(&buf[i]), kChunk, hipHostMallocDefault) != hipSuccess ||
+                        hipEventCreateWithFlags(&done[i], hipEventDisableTiming) != hipSuccess)
+                        return false;
+                return hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+            }
+        };
+        Staging &staging()
+        {
+            static Staging *s = new Staging; // never destroyed (see DevicePool::global)
+            return *s;
+        }
+        std::atomic<bool> g_staged{ false };
+    } // namespace
+
+    void set_staged_host_copies(bool enabled)
+    {
+        g_staged.store(enabled);
+    }
+
+    void copy_h2d(void *dev, const void *host, size_t bytes)
+    {
+        if (!bytes)
+            return;
+        if (!g_staged.load(std::memory_order_relaxed))
+        {
+            hip_ok(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice), "H2D");
+            return;
+        }
+        Staging &st = staging();
+        std::lock_guard<std::mutex> g(st.mu);
+        if (!st.ready())
+            throw std::runtime_error("pinned staging buffers unavailable");
+        hip_ok(hipDeviceSynchronize(), "sync"); // ordered after everything queued, as the blocking hipMemcpy is
+        size_t off = 0;
+        for (int i = 0; off < bytes; i ^= 1)
+        {
+            const size_t n = std::min(Staging::kChunk, bytes - off);
+            hip_ok(hipEventSynchronize(st.done[i]), "staging wait"); // the previous transfer out of this bounce buffer
+            std::memcpy(st.buf[i], static_cast<const uint8_t *>(host) + off, n);
+            hip_ok(hipMemcpyAsync(static_cast<uint8_t *>(dev) + off, st.buf[i], n, hipMemcpyHostToDevice, st.stream), "H2D (staged)");
+            hip_ok(hipEventRecord(st.done[i], st.stream), "staging record");
+            off += n;
+        }
+        hip_ok(hipStreamSynchronize(st.stream), "staging drain");
+    }
+
+    void copy_d2h(void *host, const void *dev, size_t bytes)
+    {
+        if (!bytes)
+            return;
+        if (!g_staged.load(std::memory_order_relaxed))
+        {
+            hip_ok(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost), "D2H");
+            return;
+        }
+        Staging &st = staging();
+        std::lock_guard<std::mutex> g(st.mu);
+        if (!st.ready())
+            throw std::runtime_error("pinned staging buffers unavailable");
+        hip_ok(hipDeviceSynchronize(), "sync");
+        // chunk k+1 travels while chunk k is copied out of its bounce buffer
+        size_t issued = 0, taken = 0;
+        size_t len[2] = { 0, 0 };
+        int wi = 0, ri = 0;
+        auto issue = [&]() {
+            const size_t n = std::min(Staging::kChunk, bytes - issued);
+            hip_ok(hipMemcpyAsync(st.buf[wi], static_cast<const uint8_t *>(dev) + issued, n, hipMemcpyDeviceToHost, st.stream), "D2H (staged)");
+            hip_ok(hipEventRecord(st.done[wi], st.stream), "staging record");
+            len[wi] = n;
+            issued += n;
+            wi ^= 1;
+        };
+        issue();
+        while (taken < bytes)
+        {
+            if (issued < bytes)
+                issue();
+            hip_ok(hipEventSynchronize(st.done[ri]), "staging wait");
+            std::memcpy(static_cast<uint8_t *>(host) + taken, st.buf[ri], len[ri]);
+            taken += len[ri];
+            ri ^= 1;
+        }
     }
 } // namespace sealhip

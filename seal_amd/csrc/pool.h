@@ -94,6 +94,17 @@ namespace sealhip
         bool prev_set_;
     };
 
+    // Host <-> device copies of words that live in the CALLER's pageable memory (ciphertexts, plaintexts, keys of a host
+    // library).  Direct (default): hipMemcpy on the caller's buffer - the runtime pins the buffer's pages for the DMA and keeps
+    // that registration cached.  Staged: through two pinned bounce buffers owned by this library, so that the caller's pages
+    // are NEVER registered with the driver.  A host that changes the protection of its own buffers (the device-resident
+    // drop-in, integration/seal_evaluator_hip.cpp: mprotect shadows) needs the staged form: a registered range that becomes
+    // inaccessible makes the driver re-validate it on every later submission (measured 20 - 40 ms per operation,
+    // profiles/r02_dropin_chain.txt).  Both are synchronous: the copy is complete on return.
+    void set_staged_host_copies(bool enabled);
+    void copy_h2d(void *device_dst, const void *host_src, size_t bytes);
+    void copy_d2h(void *host_dst, const void *device_src, size_t bytes);
+
     struct Scratch
     {
         uint64_t *p = nullptr;

@@ -182,6 +182,17 @@ static inline hipError_t hipMalloc(T **p, size_t bytes)
 {
     return hipMalloc(reinterpret_cast<void **>(p), bytes);
 }
+enum { hipHostMallocDefault = 0 };
+static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned = 0)
+{
+    *p = malloc(bytes);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipHostFree(void *p)
+{
+    free(p);
+    return hipSuccess;
+}
 static inline hipError_t hipFree(void *p)
 {
     std::free(p);

@@ -25,6 +25,8 @@ def shim_variant(libname, reps):
     ctx.keygen_relin()
     ctx.keygen_galois_steps([1])
     ctx.time_pipeline("ckks_chain", 1, 1)  # warm-up: tables, key upload
+    if os.environ.get("SEALHIP_DROPIN_TRACE"):
+        reps = 1
     s = ctx.time_pipeline("ckks_chain", 1, reps)
     out = dict(ms_per_chain=1e3 * s / reps)
     if "dropin" in libname:
@@ -32,7 +34,7 @@ def shim_variant(libname, reps):
     return out
 
 
-def device_variant(reps):
+def device_variant(reps, transparent_check=False):
     sys.path.insert(0, ROOT)
     import numpy as np
     import seal_amd as S
@@ -42,6 +44,7 @@ def device_variant(reps):
     p.set_coeff_modulus(primes)
     ctx = S.SEALContext(p, True, 0)
     ev = S.Evaluator(ctx)
+    ev.set_transparent_check(transparent_check)  # SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT: a device -> host flag read per operation
     kg = S.KeyGenerator(ctx)
     rlk = kg.create_relin_keys()
     glk = kg.create_galois_keys(steps=[1])
@@ -59,7 +62,8 @@ def device_variant(reps):
             ev.rescale_to_next_inplace(w)
             ev.rotate_vector_inplace(w, 1, glk)
             ev.mod_switch_to_next_inplace(bb)
-            bb.set_scale(w.scale())
+            w.set_scale(2.0 ** 24)
+            bb.set_scale(2.0 ** 24)
         return w.item_to_numpy(0)[0, 0, 0]
     chain()
     t0 = time.perf_counter()
@@ -73,27 +77,30 @@ def main():
         kind = sys.argv[1]
         if kind == "device":
             print("RESULT " + json.dumps(device_variant(8)))
+        elif kind == "device_checked":
+            print("RESULT " + json.dumps(device_variant(8, True)))
         elif kind == "reference":
             print("RESULT " + json.dumps(shim_variant("oracle/_ref/libsealref.so", 1)))
         else:
             print("RESULT " + json.dumps(shim_variant("integration/_build/libsealdropin.so", 8)))
         return
     rows = []
-    for name, kind, env in (("device-resident C ABI, batch 1 (Python host)", "device", {}),
+    for name, kind, env in (("device-resident C ABI, batch 1 (Python host), transparent check on as in the drop-in", "device_checked", {}),
+                            ("device-resident C ABI, batch 1 (Python host), no per-operation check", "device", {}),
                             ("drop-in behind seal::Evaluator, device-resident mirrors", "dropin", {}),
                             ("drop-in, upload / download per call (SEALHIP_DROPIN_EAGER=1)", "dropin", {"SEALHIP_DROPIN_EAGER": "1"}),
                             ("reference seal::Evaluator, 1 CPU thread", "reference", {})):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), kind], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
         if r.returncode != 0 or not line:
-            print("%-70s FAILED: %s" % (name, (r.stdout + r.stderr)[-400:]))
+            print("%-92s FAILED: %s" % (name, (r.stdout + r.stderr)[-400:]))
             continue
         res = json.loads(line[0][7:])
         rows.append((name, res))
-        print("%-70s %9.2f ms per chain (13 levels x multiply+relinearize+rescale+rotate)%s" % (
+        print("%-92s %9.2f ms per chain (13 levels x multiply+relinearize+rescale+rotate)%s" % (
             name, res["ms_per_chain"], "  transfers %s" % res["transfers"] if "transfers" in res else ""), flush=True)
-    if len(rows) >= 2:
-        print("drop-in / device-resident = %.2fx" % (rows[1][1]["ms_per_chain"] / rows[0][1]["ms_per_chain"]))
+    if len(rows) >= 3:
+        print("drop-in / device-resident (same per-operation check) = %.2fx" % (rows[2][1]["ms_per_chain"] / rows[0][1]["ms_per_chain"]))
 
 
 if __name__ == "__main__":
