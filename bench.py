@@ -65,6 +65,8 @@ def parse(argv=None):
     ap.add_argument("--total-batch", type=int, default=1024, help="bfv_c4: ciphertexts per step over ALL ranks (BASELINE configs[3])")
     ap.add_argument("--exchange", choices=["all_reduce", "reduce_scatter"], default="all_reduce",
                     help="rotate_c5: shape of the key-switch exchange (sealhip.h section 1c), RCCL calls inside the library")
+    ap.add_argument("--native-comm", action="store_true", help="rotate_c5: use the library's RCCL communicator even with one rank "
+                    "(exercises pack / reduce-scatter / all-gather on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the reference check of sampled output items")
     ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 PMC passes for roofline.traffic")
@@ -179,9 +181,16 @@ def main():
     if args.workload == "rotate_c5":
         elt = ctx.galois_elt_from_step(1)
         keys = S.GaloisKeys(ctx)
-        dp = shard.DigitParallel(ev, torch, group, device, exchange=args.exchange)
+        dp = shard.DigitParallel(ev, torch, group, device, exchange=args.exchange, native=True if args.native_comm else None)
         d0, dc = dp.digit_range(K)
-        if world > 1 and dc:
+        if dp.comm is not None:
+            # one-time key distribution inside the library: rank 0's key is broadcast over RCCL and every rank keeps its own
+            # digits resident (Evaluator_BroadcastKeyDigits); the other ranks' tensors are only the receive buffers
+            if rank != 0:
+                key.zero_()
+            dev_sync()
+            ev.broadcast_key_digits(keys, S.GaloisKeys.get_index(elt), key.data_ptr(), dp.comm, 0)
+        elif world > 1 and dc:
             keys.set_key_digits(S.GaloisKeys.get_index(elt), d0, key[d0:d0 + dc].cpu().numpy().view("uint64"))
         else:
             keys.set_key_device(S.GaloisKeys.get_index(elt), K, key.data_ptr())
@@ -320,9 +329,17 @@ def main():
                                    "2^50, 64-bit Shoup/Barrett integer arithmetic for larger primes; results canonical u64",
                         key_bytes=2 * K * L * n * 8, algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n),
             roofline=roofline, roofline_configs1=ntt_c1, cpu_baseline=cpu)
-        print(json.dumps(line), flush=True)
+    # RCCL prints a version banner through C stdio when a communicator comes up; it sits in the C buffer until exit.  Tear
+    # the process group down and flush the C streams first, so that the JSON line is the LAST thing on stdout.
+    del dp
     if world > 1:
         dist.destroy_process_group()
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 # --------------------------------------------------------------------------------------------------------------------
