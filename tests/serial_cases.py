@@ -158,6 +158,12 @@ def case_key_streams(scheme, n, bits, seeded, steps=(1,)):
         rx = ref.ct(ref.first_chain_index, x2, is_ntt, scale)
         ref.apply_galois_inplace(rx, e)
         assert np.array_equal(cx.to_numpy()[:, 0], rx.data()), "apply_galois(%d) with keys loaded from the stream" % e
+    # a load REPLACES the object (KSwitchKeys::load, kswitchkeys.cpp:92-180): indices absent from the new stream are gone
+    only_first = ref.keys_save("galois", seeded, elts[:1])
+    assert glk.load_bytes(only_first, unsafe=not seeded) == len(only_first)
+    assert glk.size() == 1 and glk.has_key(elts[0])
+    for e in set(elts[1:]) - {elts[0]}:
+        assert not glk.has_key(e), "key %d survived a load that does not contain it" % e
 
 
 def case_plaintext_streams(scheme, n, bits):
