@@ -404,6 +404,10 @@ SHL_FUNC SealHip_ReleasePool(void);
 SHL_FUNC SealHip_SetStagedHostCopies(bool enabled);
 SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
 /* stream and device memory helpers for bindings without their own runtime (a PyTorch / HIP caller passes its own streams) */
+/* one process per GPU: select the calling thread's device before creating a SEALContext (a PyTorch caller uses
+ * torch.cuda.set_device instead) */
+SHL_FUNC shl_device_count(int *count);
+SHL_FUNC shl_set_device(int device);
 SHL_FUNC shl_stream_create(bool non_blocking, void **hip_stream);
 SHL_FUNC shl_stream_destroy(void *hip_stream);
 SHL_FUNC shl_malloc(uint64_t bytes, void **device_ptr);

@@ -1147,6 +1147,17 @@ class Stream:
             self._h = None
 
 
+def device_count():
+    n = C.c_int()
+    N.check(N.lib().shl_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(index):
+    """select this thread's GPU (one process per GPU) before any context is created"""
+    N.check(N.lib().shl_set_device(C.c_int(index)))
+
+
 def release_pool():
     """return the library's cached HBM blocks to the driver"""
     N.check(N.lib().SealHip_ReleasePool())

@@ -2324,6 +2324,21 @@ extern "C"
             *cross_stream_waits = DevicePool::global().cross_stream_waits();
         SHL_CATCH
     }
+    SHL_FUNC shl_device_count(int *count)
+    {
+        IfNullRet(count, SHL_E_POINTER);
+        SHL_TRY
+        *count = 0;
+        if (hipGetDeviceCount(count) != hipSuccess)
+            *count = 0;
+        SHL_CATCH
+    }
+    SHL_FUNC shl_set_device(int device)
+    {
+        SHL_TRY
+        hip_ok(hipSetDevice(device), "hipSetDevice");
+        SHL_CATCH
+    }
     SHL_FUNC shl_stream_create(bool non_blocking, void **hip_stream)
     {
         IfNullRet(hip_stream, SHL_E_POINTER);
