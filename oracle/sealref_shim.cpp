@@ -1072,6 +1072,36 @@ extern "C"
             *bytes = static_cast<uint64_t>(k.load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
         REF_CATCH
     }
+    // the context's relinearization (kind 0) / Galois (kind 1) key object := the stream (RelinKeys::load / GaloisKeys::load)
+    int ref_keys_install(void *ctx, int kind, const uint8_t *in, uint64_t size, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        if (kind == 0)
+            *bytes = static_cast<uint64_t>(c->rlk.load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
+        else
+            *bytes = static_cast<uint64_t>(c->glk.load(*c->context, reinterpret_cast<const seal_byte *>(in), size));
+        REF_CATCH
+    }
+    // Serializable<PublicKey>::save (KeyGenerator::create_public_key() without destination): the seeded form, c_1 as its seed
+    int ref_public_key_save_seeded(void *ctx, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        *bytes = static_cast<uint64_t>(c->keygen->create_public_key().save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
+        REF_CATCH
+    }
+    // PublicKey::load of a stream (seeded or full) -> the key's words [2][L][N]
+    int ref_public_key_load_words(void *ctx, const uint8_t *in, uint64_t size, uint64_t *out_words)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        PublicKey pk;
+        pk.load(*c->context, reinterpret_cast<const seal_byte *>(in), size);
+        const Ciphertext &d = pk.data();
+        std::memcpy(out_words, d.data(), d.size() * d.coeff_modulus_size() * d.poly_modulus_degree() * sizeof(uint64_t));
+        REF_CATCH
+    }
     // PublicKey::save: a key-level ciphertext in the Ciphertext wire format
     int ref_public_key_save(void *ctx, uint8_t *out, uint64_t cap, uint64_t *bytes)
     {

@@ -574,6 +574,7 @@ extern "C"
                 // the seeded c_1: sample_poly_uniform over Blake2xb on the device (xof.h)
                 XofJob job;
                 std::memcpy(job.seed, img.pending_seed, sizeof(job.seed));
+                job.prng_type = img.pending_type;
                 job.dst = tmp + img.stored_words;
                 try
                 {
@@ -650,6 +651,7 @@ extern "C"
                         {
                             XofJob job;
                             std::memcpy(job.seed, d.pending_seed, sizeof(job.seed));
+                            job.prng_type = d.pending_type;
                             job.dst = dst + d.stored_words;
                             seeded.push_back(job);
                         }
@@ -1251,24 +1253,37 @@ extern "C"
             // PublicKey::load = Ciphertext::unsafe_load + is_valid_for(PublicKey) (publickey.h:144-154; valcheck.cpp: key level, NTT
             // form, size 2, every coefficient reduced - the last part only for the checked load)
             serial::CiphertextImage img;
-            const size_t n = serial::load_ciphertext(*c, inptr, (size_t)size, false, img);
+            const size_t n = serial::load_ciphertext(*c, inptr, (size_t)size, false, img, true);
             bool ok = img.level == &c->key_level() && img.is_ntt_form && img.size == 2;
             if (ok && check)
             {
-                std::vector<uint64_t> words(img.word_count());
+                // the words that came with the stream (a seeded half expanded on the device is reduced by construction)
+                const size_t host_words = img.stored_words + img.expanded.size();
+                std::vector<uint64_t> words(host_words);
                 img.copy_words(words.data());
-                for (size_t p = 0; p < 2 && ok; p++)
-                    for (unsigned r = 0; r < img.level->K && ok; r++)
-                    {
-                        const uint64_t q = c->coeff_modulus()[r];
-                        const uint64_t *w = words.data() + (p * img.level->K + r) * c->n();
-                        for (size_t k = 0; k < c->n(); k++)
-                            ok &= w[k] < q;
-                    }
+                const size_t N = c->n();
+                for (size_t w = 0; w < host_words && ok; w += N)
+                {
+                    const uint64_t q = c->coeff_modulus()[(w / N) % img.level->K];
+                    for (size_t k = 0; k < N; k++)
+                        ok &= words[w + k] < q;
+                }
             }
             if (!ok)
                 throw std::logic_error("PublicKey data is invalid");
-            pk->set_parts(img.stored, img.stored_words, img.expanded.data(), img.expanded.size());
+            if (img.pending_words)
+            {
+                // a seeded stream (Serializable<PublicKey>): c_0 is copied, c_1 is expanded from its seed on the device
+                uint64_t *dev = pk->allocate();
+                copy_h2d(dev, img.stored, img.stored_words * 8);
+                XofJob job;
+                std::memcpy(job.seed, img.pending_seed, sizeof(job.seed));
+                job.prng_type = img.pending_type;
+                job.dst = dev + img.stored_words;
+                sample_uniform_device(*c, c->key_level().K, { job });
+            }
+            else
+                pk->set_parts(img.stored, img.stored_words, img.expanded.data(), img.expanded.size());
             *in_bytes = (int64_t)n;
             SHL_CATCH
         }

@@ -212,12 +212,10 @@ namespace sealhip
         const int max_coeff_bit_count = static_cast<int>(std::ceil(std::log2(mc))) + 1; // util::safe_ceil_log2_int
         if (max_coeff_bit_count >= lvl->total_coeff_modulus_bit_count)
             throw std::invalid_argument("encoded values are too large");
-        if (max_coeff_bit_count > 128)
-            throw std::logic_error("coefficients above 128 bits: the multi-precision decomposition of ckks.h:641-678 is not built");
         uint64_t *slab = DevicePool::global().alloc_words(K * n);
         try
         {
-            ck(k_ckks_decompose(context_.dev_mods(), cv, slab, n_log, (unsigned)K, 1, max_coeff_bit_count <= 64 ? 64 : 128, nullptr), "decompose");
+            ck(k_ckks_decompose(context_.dev_mods(), cv, slab, n_log, (unsigned)K, 1, max_coeff_bit_count <= 64 ? 64 : (max_coeff_bit_count <= 128 ? 128 : 0), nullptr), "decompose");
             NttBatch b{};
             b.data = slab;
             b.outer_stride = K * n;
@@ -274,8 +272,6 @@ namespace sealhip
         const int coeff_bit_count = (std::fabs(value) < 1.0) ? 2 : (static_cast<int>(std::log2(std::fabs(value))) + 2);
         if (coeff_bit_count >= lvl->total_coeff_modulus_bit_count)
             throw std::invalid_argument("encoded value is too large");
-        if (coeff_bit_count > 128)
-            throw std::logic_error("coefficients above 128 bits: the multi-precision decomposition of ckks.cpp:165-196 is not built");
         const double two_pow_64 = std::pow(2.0, 64);
         double coeffd = std::round(value);
         const bool is_negative = std::signbit(coeffd);
@@ -287,6 +283,18 @@ namespace sealhip
             uint64_t r;
             if (coeff_bit_count <= 64)
                 r = static_cast<uint64_t>(std::fabs(coeffd)) % q;
+            else if (coeff_bit_count > 128)
+            {
+                // ckks.cpp:165-196: the double cut into 64-bit words (fmod / division by 2^64, exact), reduced modulo q
+                // (RNSBase::decompose); Horner from the top word
+                std::vector<uint64_t> words;
+                for (double c = coeffd; c >= 1 && words.size() < lvl->K; c /= two_pow_64)
+                    words.push_back(static_cast<uint64_t>(std::fmod(c, two_pow_64)));
+                unsigned __int128 acc = 0;
+                for (size_t w = words.size(); w-- > 0;)
+                    acc = ((acc << 64) | words[w]) % q;
+                r = (uint64_t)acc;
+            }
             else
             {
                 const unsigned __int128 v = ((unsigned __int128) static_cast<uint64_t>(coeffd / two_pow_64) << 64) |

@@ -17,7 +17,8 @@ namespace sealhip
     hipError_t k_fft_ct_stage(double2 *values, const double2 *roots, unsigned n_log, unsigned gap_log, unsigned batch, hipStream_t s);
     // max |Re v| over the vectors, as the bit pattern of a non-negative double (a NaN compares largest); *out must be zeroed
     hipError_t k_max_abs_real(const double2 *values, size_t count, unsigned long long *out, hipStream_t s);
-    // encode_internal's rounding and decomposition (ckks.h:559-640): mode 64: |coefficient| < 2^64; mode 128: < 2^128
+    // encode_internal's rounding and decomposition (ckks.h:559-672): mode 64: |coefficient| < 2^64; mode 128: < 2^128; any other
+    // mode: the multi-precision branch (coefficients up to the level's modulus: K 64-bit words)
     hipError_t k_ckks_decompose(const ModDesc *mods, const double2 *values, uint64_t *out, unsigned n_log, unsigned K, unsigned batch, int mode,
                                 hipStream_t s);
     // decode_internal's CRT composition and scaling (ckks.h:741-781; RNSBase::compose_array, rns.cpp:300-360): coefficient-form

@@ -102,6 +102,30 @@ namespace sealhip
                     hi = (uint64_t)(coeffd / two_pow_64);
                 }
                 uint64_t *o = out + ((vec * K) << n_log) + i;
+                if (mode != 64 && mode != 128)
+                {
+                    // the "slow case" of encode_internal (ckks.h:624-672): the rounded double is cut into 64-bit words by
+                    // repeated fmod / division by 2^64 (both exact: the divisor is a power of two), at most K words since the
+                    // coefficient is below the level's modulus, and the K-word integer is reduced modulo every prime
+                    // (RNSBase::decompose -> modulo_uint).  Horner over the words from the top: r <- (r 2^64 + word) mod q.
+                    uint64_t words[kMaxComps];
+                    unsigned nw = 0;
+                    double c = coeffd;
+                    while (c >= 1 && nw < K)
+                    {
+                        words[nw++] = (uint64_t)::fmod(c, two_pow_64);
+                        c /= two_pow_64;
+                    }
+                    for (unsigned j = 0; j < K; j++)
+                    {
+                        const ModDesc md = mods[j];
+                        uint64_t r = 0;
+                        for (unsigned w = nw; w-- > 0;)
+                            r = barrett128(words[w], r, md);
+                        o[(size_t)j << n_log] = is_negative ? neg_mod(r, md.q) : r;
+                    }
+                    continue;
+                }
                 for (unsigned j = 0; j < K; j++)
                 {
                     const ModDesc md = mods[j];

@@ -512,9 +512,10 @@ namespace sealhip
                     });
                     out.pending_words = 0;
                     // (the device kernel's conditions, xof.h: xof_device_ok)
-                    if (device_expand && prng.type == 1 && n64 >= 8 && seeded_count && (seeded_count * 8) % 4096 == 0)
+                    if (device_expand && n64 >= 8 && seeded_count && (seeded_count * 8) % 4096 == 0)
                     {
                         out.pending_words = (size_t)seeded_count;
+                        out.pending_type = prng.type;
                         std::memcpy(out.pending_seed, prng.seed, sizeof(prng.seed));
                     }
                     else

@@ -55,6 +55,7 @@ namespace sealhip
             // and the caller expands `pending_seed` into the pending_words words after the stored ones
             size_t pending_words = 0;
             uint64_t pending_seed[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            uint8_t pending_type = 1; // 1 = blake2xb, 2 = shake256
             size_t word_count() const { return stored_words + expanded.size() + pending_words; }
             void copy_words(uint64_t *dst) const; // gather both pieces into one host array
         };

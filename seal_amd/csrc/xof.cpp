@@ -20,16 +20,27 @@ namespace sealhip
         const size_t n = ctx.n(), words = K * n, njobs = jobs.size();
         if (!njobs)
             return;
-        if (!xof_device_ok(1, K, n))
+        if (!xof_device_ok((uint8_t)jobs[0].prng_type, K, n))
             throw std::logic_error("polynomial is not a whole number of PRNG buffers");
         const size_t map_words = words / 32; // unsigned words of the rejection bitmap per job
         const size_t job_words = (njobs * sizeof(XofJob) + 7) / 8;
         Scratch djobs(job_words), dmap((njobs * map_words * 4 + 7) / 8);
         ck(hipMemcpyAsync(djobs.p, jobs.data(), njobs * sizeof(XofJob), hipMemcpyHostToDevice, nullptr), "upload seeds");
         ck(hipMemsetAsync(dmap.p, 0, njobs * map_words * 4, nullptr), "clear bitmap");
-        ck(k_blake2xb_uniform(ctx.dev_mods(), reinterpret_cast<const XofJob *>(djobs.p), (unsigned)njobs, reinterpret_cast<unsigned *>(dmap.p),
-                              (unsigned)ctx.log_n(), (unsigned)K, nullptr),
-           "blake2xb");
+        // jobs of one kind form runs (in practice all jobs of a call share the PRNG type): one launch per run
+        for (size_t j0 = 0; j0 < njobs;)
+        {
+            size_t j1 = j0 + 1;
+            while (j1 < njobs && jobs[j1].prng_type == jobs[j0].prng_type)
+                j1++;
+            const XofJob *dj = reinterpret_cast<const XofJob *>(djobs.p) + j0;
+            unsigned *dm = reinterpret_cast<unsigned *>(dmap.p) + j0 * map_words;
+            if (jobs[j0].prng_type == 2)
+                ck(k_shake256_uniform(ctx.dev_mods(), dj, (unsigned)(j1 - j0), dm, (unsigned)ctx.log_n(), (unsigned)K, nullptr), "shake256");
+            else
+                ck(k_blake2xb_uniform(ctx.dev_mods(), dj, (unsigned)(j1 - j0), dm, (unsigned)ctx.log_n(), (unsigned)K, nullptr), "blake2xb");
+            j0 = j1;
+        }
         std::vector<uint32_t> map(njobs * map_words);
         ck(hipMemcpy(map.data(), dmap.p, map.size() * 4, hipMemcpyDeviceToHost), "download bitmap");
 
@@ -40,7 +51,7 @@ namespace sealhip
         for (size_t j = 0; j < njobs; j++)
         {
             const uint32_t *bits = map.data() + j * map_words;
-            serial::Prng prng(1, jobs[j].seed);
+            serial::Prng prng((uint8_t)jobs[j].prng_type, jobs[j].seed);
             prng.counter = words * 8 / 4096;
             prng.parallel = false;
             for (size_t g = 0; g < map_words; g++)

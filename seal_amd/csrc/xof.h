@@ -10,9 +10,9 @@ namespace sealhip
     // true when a polynomial of K*N words can be expanded on the device (the stream is consumed in whole PRNG buffers)
     inline bool xof_device_ok(uint8_t prng_type, size_t K, size_t N)
     {
-        return prng_type == 1 && K && N >= 8 && (K * N * 8) % 4096 == 0;
+        return (prng_type == 1 || prng_type == 2) && K && N >= 8 && (K * N * 8) % 4096 == 0;
     }
-    // dst_j = sample_poly_uniform(Blake2xbPRNG(seed_j)) over the first K primes of the context, every job [K][N] words in HBM.
+    // dst_j = sample_poly_uniform(Blake2xbPRNG(seed_j) or Shake256PRNG(seed_j), XofJob::prng_type) over the first K primes of the context, every job [K][N] words in HBM.
     // Synchronous (returns when the words are in place).
     void sample_uniform_device(const Context &ctx, size_t K, const std::vector<XofJob> &jobs);
 } // namespace sealhip

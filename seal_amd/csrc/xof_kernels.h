@@ -18,6 +18,7 @@ namespace sealhip
     {
         uint64_t seed[8];
         uint64_t *dst; // [K][N] words on the device
+        uint64_t prng_type = 1; // 1 = Blake2xbPRNG, 2 = Shake256PRNG (randomgen.h: prng_type)
     };
     struct XofPatch
     {
@@ -27,6 +28,11 @@ namespace sealhip
     // jobs: device array of njobs; reject: device bitmap, njobs * (K*N/32) words, zeroed by the caller: bit w of job j = word w
     // of the polynomial was rejected (its dst word is left unreduced).  Requires K*N*8 to be a multiple of 4096.
     hipError_t k_blake2xb_uniform(const ModDesc *mods, const XofJob *jobs, unsigned njobs, unsigned *reject, unsigned n_log, unsigned K,
+                                  hipStream_t s);
+    // The same for Shake256PRNG seeds (randomgen.cpp:216-227: buffer b = SHAKE256(seed || b as 8 bytes), 4096 bytes).  A buffer is
+    // one sponge: its 31 permutations are sequential, the buffers are independent - one thread per 4096-byte buffer (Keccak-f[1600]
+    // written from FIPS 202, the 25 lanes in registers).
+    hipError_t k_shake256_uniform(const ModDesc *mods, const XofJob *jobs, unsigned njobs, unsigned *reject, unsigned n_log, unsigned K,
                                   hipStream_t s);
     // the raw PRNG stream of `seed`: 64-byte pieces first_piece .. first_piece + pieces - 1 (piece p = bytes 64 p .. of the stream)
     struct XofSeed

@@ -141,6 +141,95 @@ namespace sealhip
                 atomicOr(reject + blockIdx.y * (words / 32) + w0 / 32, rejected << (w0 % 32));
         }
 
+        // ---- SHAKE256 (FIPS 202): Keccak-f[1600], rate 136 bytes, domain suffix 0x1F
+        __device__ __forceinline__ uint64_t rotl64(uint64_t x, int c)
+        {
+            return c ? (x << c) | (x >> (64 - c)) : x;
+        }
+        __device__ __forceinline__ void keccak_f1600(uint64_t (&a)[25])
+        {
+            constexpr uint64_t RC[24] = {
+                0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+                0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+                0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+                0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+                0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull
+            };
+            // rotation offsets of lane x + 5y; pi moves lane (x, y) to (y, 2x + 3y)
+            constexpr int ROT[25] = { 0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14 };
+#pragma unroll 1
+            for (int round = 0; round < 24; round++)
+            {
+                uint64_t c[5], d[5], b[25];
+#pragma unroll
+                for (int x = 0; x < 5; x++)
+                    c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+                for (int x = 0; x < 5; x++)
+                    d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+                for (int x = 0; x < 5; x++)
+#pragma unroll
+                    for (int y = 0; y < 5; y++)
+                        b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(a[x + 5 * y] ^ d[x], ROT[x + 5 * y]);
+#pragma unroll
+                for (int y = 0; y < 5; y++)
+#pragma unroll
+                    for (int x = 0; x < 5; x++)
+                        a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+                a[0] ^= RC[round];
+            }
+        }
+
+        // one thread = one 4096-byte buffer of the PRNG stream = 512 words of the polynomial
+        __global__ void __launch_bounds__(64) shake256_uniform_kernel(
+            const ModDesc *mods, const XofJob *jobs, unsigned *reject, unsigned n_log, unsigned K)
+        {
+            const size_t words = (size_t)K << n_log;
+            const size_t buffer = blockIdx.x * (size_t)64 + threadIdx.x;
+            if (buffer >= words / 512)
+                return;
+            const XofJob &job = jobs[blockIdx.y];
+            uint64_t a[25];
+#pragma unroll
+            for (int i = 0; i < 25; i++)
+                a[i] = 0;
+            // absorb seed (64 bytes) || counter (8 bytes): 72 bytes < rate; pad: 0x1F after the message, 0x80 at byte 135
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                a[i] = job.seed[i];
+            a[8] = buffer;
+            a[9] = 0x1Full;
+            a[16] ^= 0x8000000000000000ull;
+            keccak_f1600(a);
+            size_t w = buffer * 512, left = 512;
+            unsigned *map = reject + blockIdx.y * (words / 32);
+            while (left)
+            {
+                const unsigned take = left < 17 ? (unsigned)left : 17u; // 17 lanes = 136 bytes per squeeze
+#pragma unroll
+                for (unsigned t = 0; t < 17; t++)
+                {
+                    if (t < take)
+                    {
+                        // (a buffer of 512 words may straddle two RNS components only when N < 512: the component is per word)
+                        const ModDesc md = mods[(unsigned)((w + t) >> n_log)];
+                        const uint64_t max_multiple = ~0ull - barrett64(~0ull, md) - 1;
+                        uint64_t v = a[t];
+                        if (v >= max_multiple)
+                            atomicOr(map + (w + t) / 32, 1u << ((w + t) % 32));
+                        else
+                            v = barrett64(v, md);
+                        job.dst[w + t] = v;
+                    }
+                }
+                w += take;
+                left -= take;
+                if (left)
+                    keccak_f1600(a);
+            }
+        }
+
         // the raw stream: pieces first_piece .. first_piece + pieces - 1 -> out[8 * pieces]
         __global__ void __launch_bounds__(kBlock) blake2xb_stream_kernel(XofSeed seed, uint64_t first_piece, size_t pieces, uint64_t *out)
         {
@@ -195,6 +284,15 @@ namespace sealhip
             return hipSuccess;
         hipLaunchKernelGGL(blake2xb_uniform_kernel, dim3((unsigned)((pieces + kBlock - 1) / kBlock), njobs), dim3(kBlock), 0, s, mods, jobs,
                            reject, n_log, K);
+        return hipGetLastError();
+    }
+    hipError_t k_shake256_uniform(const ModDesc *mods, const XofJob *jobs, unsigned njobs, unsigned *reject, unsigned n_log, unsigned K,
+                                  hipStream_t s)
+    {
+        const size_t buffers = ((size_t)K << n_log) / 512;
+        if (!buffers || !njobs)
+            return hipSuccess;
+        hipLaunchKernelGGL(shake256_uniform_kernel, dim3((unsigned)((buffers + 63) / 64), njobs), dim3(64), 0, s, mods, jobs, reject, n_log, K);
         return hipGetLastError();
     }
     hipError_t k_blake2xb_stream(const XofSeed &seed, uint64_t first_piece, size_t pieces, uint64_t *out, hipStream_t s)

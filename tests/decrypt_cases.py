@@ -327,6 +327,9 @@ def case_ckks_encoder(n, bits, check_bits=True):
     scales = [2.0 ** 30, 2.0 ** 20]
     if total_bits > 100:
         scales.append(2.0 ** 80)     # coefficients above 64 bits: the 128-bit decomposition path
+    if total_bits > 180:
+        scales.append(2.0 ** 150)    # above 128 bits: the multi-precision branch (ckks.h:624-672)
+        scales.append(2.0 ** 131.5)
     for ci in range(ref.first_chain_index, -1, -1):
         pid = d.ctx.parms_id_at(ci)
         for scale in scales:
@@ -355,6 +358,22 @@ def case_ckks_encoder(n, bits, check_bits=True):
                     if check_bits:
                         assert got.tobytes() == want.tobytes(), ("decode bits", ci, scale, vals.size, cplx)
                     assert np.array_equal(got, want)
+    # the single-value overloads (ckks.cpp:72-250), incl. coefficients above 64 and above 128 bits
+    pid = d.ctx.parms_id_at(ref.first_chain_index)
+    for scale in scales:
+        if np.log2(scale) + 8 >= total_bits:
+            continue
+        for v in (3.14159265, -0.4, 1234.5):
+            try:
+                want = ref.ckks_encode_value(v, ref.first_chain_index, scale).data()
+            except sealref.RefError as err:
+                want_cls = {1: S.InvalidArgument, 2: S.LogicError}[err.code]
+                try:
+                    enc.encode(v, pid, scale)
+                    raise AssertionError("the reference rejected encode(%r, scale %r): %s" % (v, scale, err))
+                except want_cls:
+                    continue
+            assert np.array_equal(enc.encode(v, pid, scale).to_numpy(), want), (v, scale)
     # argument checks (ckks.h:463-509, 686-716)
     pid = d.ctx.parms_id_at(ref.first_chain_index)
     for bad in (lambda: enc.encode(np.zeros(n // 2 + 1), pid, 2.0 ** 20), lambda: enc.encode(np.ones(4), pid, 0.0),

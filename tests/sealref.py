@@ -370,6 +370,28 @@ class RefContext:
         _ck(lib().ref_keys_load(self.h, buf if len(data) else None, C.c_uint64(len(data)), C.c_int(1 if unsafe else 0), C.byref(n)))
         return n.value
 
+    def public_key_save_seeded(self):
+        """Serializable<PublicKey>::save of a fresh public key (the seeded form)"""
+        cap = 2 * len(self.primes) * self.n * 8 + 4096
+        buf = (C.c_uint8 * cap)()
+        n = C.c_uint64()
+        _ck(lib().ref_public_key_save_seeded(self.h, buf, C.c_uint64(cap), C.byref(n)))
+        return bytes(buf[: n.value])
+
+    def public_key_load_words(self, data):
+        """PublicKey::load(stream).data() as uint64 [2][L][N]"""
+        out = np.zeros((2, len(self.primes), self.n), dtype=np.uint64)
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+        _ck(lib().ref_public_key_load_words(self.h, buf, C.c_uint64(len(data)), _p(out)))
+        return out
+
+    def keys_install(self, kind, data):
+        """the context's RelinKeys ('relin') / GaloisKeys ('galois') object := the serialized stream"""
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+        n = C.c_uint64()
+        _ck(lib().ref_keys_install(self.h, C.c_int(0 if kind == "relin" else 1), buf, C.c_uint64(len(data)), C.byref(n)))
+        return n.value
+
     def public_key_save(self):
         cap = 4096 + 8 * 2 * len(self.primes) * self.n
         buf = (C.c_uint8 * cap)()

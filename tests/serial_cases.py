@@ -166,6 +166,67 @@ def case_key_streams(scheme, n, bits, seeded, steps=(1,)):
         assert not glk.has_key(e), "key %d survived a load that does not contain it" % e
 
 
+def _walk_key_digits(stream):
+    """offsets (start, size) of every digit (a framed seeded or full ciphertext) inside a KSwitchKeys stream"""
+    pos = 16 + 32
+    dim1 = struct.unpack_from("<Q", stream, pos)[0]
+    pos += 8
+    out = []
+    for _ in range(dim1):
+        dim2 = struct.unpack_from("<Q", stream, pos)[0]
+        pos += 8
+        for _ in range(dim2):
+            size = struct.unpack_from("<Q", stream, pos + 8)[0]
+            out.append((pos, size))
+            pos += size
+    assert pos == len(stream)
+    return out
+
+
+def case_shake256_seeded_streams(scheme, n, bits):
+    """seeded objects whose seed names the reference's OTHER generator (prng_type 2 = Shake256PRNG, randomgen.cpp:216-227): the
+    c_1 halves are expanded by the device SHAKE256 kernel when the polynomial is whole PRNG buffers - a ciphertext and every
+    digit of a relinearization key; loaded words and the key-switching result equal the reference's"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    K = len(primes) - 1
+    rng = np.random.default_rng(15)
+    seeded = bytearray(ref.encrypt_zero_symmetric_save(ref.first_chain_index, True))
+    assert seeded[len(seeded) - 65] == 1
+    seeded[len(seeded) - 65] = 2
+    seeded = bytes(seeded)
+    rct, _ = ref.ct_load(seeded)
+    ct = S.Ciphertext(d.ctx)
+    assert ct.load_bytes(seeded) == len(seeded)
+    _same_ct(ct, rct, "shake256-seeded ciphertext")
+    kstream = bytearray(ref.keys_save("relin", True))
+    digits = _walk_key_digits(bytes(kstream))
+    assert len(digits) == K
+    for start, size in digits:
+        assert kstream[start + size - 65] == 1
+        kstream[start + size - 65] = 2
+    kstream = bytes(kstream)
+    assert ref.keys_install("relin", kstream) == len(kstream)   # the context's relinearization key is now the SHAKE256 expansion
+    rlk = S.RelinKeys(d.ctx)
+    assert rlk.load_bytes(kstream) == len(kstream)
+    is_ntt, scale = scheme != "bfv", (2.0 ** 10 if scheme == "ckks" else 1.0)
+    x3 = rand_ct(rng, primes, K, n, size=3)
+    cx = d.ct(x3, scale=scale, is_ntt=is_ntt)
+    d.ev.relinearize_inplace(cx, rlk)
+    rx = ref.ct(ref.first_chain_index, x3, is_ntt, scale)
+    ref.relinearize_inplace(rx)
+    assert np.array_equal(cx.to_numpy()[:, 0], rx.data()), "relinearize with SHAKE256-seeded keys"
+    # a seeded PublicKey stream (Serializable<PublicKey>): c_1 expanded on the device, both generators
+    for prng_type in (1, 2):
+        pstream = bytearray(ref.public_key_save_seeded())
+        assert pstream[len(pstream) - 65] == 1 and len(pstream) < len(primes) * n * 8 + 4096
+        pstream[len(pstream) - 65] = prng_type
+        pstream = bytes(pstream)
+        want = ref.public_key_load_words(pstream)
+        pk = S.PublicKey(d.ctx)
+        assert pk.load_bytes(pstream) == len(pstream)
+        assert np.array_equal(pk.words(len(primes), n), want), "seeded PublicKey stream (prng_type %d)" % prng_type
+
+
 def case_plaintext_streams(scheme, n, bits):
     """encoded plaintexts as a client serializes them (CKKSEncoder / BatchEncoder output): load == the reference's load,
     save == its bytes, multiply_plain with the loaded plaintext == the reference's, malformed streams fail alike"""

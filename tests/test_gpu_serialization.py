@@ -92,7 +92,7 @@ def test_encrypt_asymmetric(gpu, scheme, n, bits):
     DC.case_encrypt_asymmetric(scheme, n, bits)
 
 
-@pytest.mark.parametrize("n,bits", [(8192, [60, 40, 40, 60]), (32768, [60, 50, 50, 50, 60]), (65536, [60] + [50] * 14 + [60])])
+@pytest.mark.parametrize("n,bits", [(8192, [60, 40, 40, 60]), (32768, [60, 50, 50, 50, 60]), (65536, [60] + [50] * 14 + [60])])   # the last two reach the multi-precision branch (scale 2^150)
 def test_ckks_encoder(gpu, n, bits):
     import decrypt_cases as DC
     DC.case_ckks_encoder(n, bits)
@@ -114,3 +114,10 @@ def test_example_batching_rotation(gpu):
 def test_keygen(gpu, scheme, n, bits):
     import decrypt_cases as DC
     DC.case_keygen(scheme, n, bits, elts=(3,) if n == 65536 else (3, 5))
+
+
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 8192, [50, 55, 56]), ("ckks", 8192, [60, 59, 60]),
+                                           ("ckks", 65536, [60] + [50] * 14 + [60])])
+def test_shake256_seeded_streams(gpu, scheme, n, bits):
+    """the device SHAKE256 expansion (one thread per 4096-byte PRNG buffer), incl. primes with hundreds of redrawn words"""
+    SC.case_shake256_seeded_streams(scheme, n, bits)

@@ -191,7 +191,7 @@ def test_encrypt_asymmetric(emu, scheme, n, bits):
 
 
 @needs_ref
-@pytest.mark.parametrize("n,bits", [(1024, [40, 30, 30, 40]), (4096, [50, 40, 40, 50]), (8, [30, 30])])
+@pytest.mark.parametrize("n,bits", [(1024, [40, 30, 30, 40]), (4096, [50, 40, 40, 50]), (8, [30, 30]), (1024, [60, 50, 50, 50, 50, 60])])
 def test_ckks_encoder(emu, n, bits):
     import decrypt_cases as DC
     DC.case_ckks_encoder(n, bits)
@@ -208,3 +208,9 @@ def test_example_ckks_basics(emu):
 def test_example_batching_rotation(emu):
     import example_cases as EC
     EC.example_batching_rotation(4096, (36, 36, 37))
+
+
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 30, 40]), ("bfv", 2048, [36, 36, 37]), ("ckks", 8192, [60, 59, 60])])
+def test_shake256_seeded_streams(emu, scheme, n, bits):
+    import serial_cases as SC
+    SC.case_shake256_seeded_streams(scheme, n, bits)
