@@ -161,7 +161,7 @@ SHL_FUNC Decryptor_DecryptBatch(void *thisptr, void *encrypted, uint64_t *device
 /* CKKSEncoder (native/src/seal/c/ckksencoder.h:16-49; seal::CKKSEncoder::encode / decode, native/src/seal/ckks.h:458-789): vectors of
  * N/2 real (Encode1 / Decode1) or complex (Encode2 / Decode2: interleaved re, im) numbers <-> NTT-form plaintexts at a level with a
  * scale.  The double-precision FFT, the rounding and the CRT composition repeat the reference's IEEE operations in its order, so the
- * plaintext words of Encode and the doubles of Decode are the reference's bit for bit (coefficients up to 128 bits on encode). */
+ * plaintext words of Encode and the doubles of Decode are the reference's bit for bit (incl. the multi-precision branch for coefficients above 128 bits). */
 SHL_FUNC CKKSEncoder_Create(void *context, void **ckks_encoder);
 SHL_FUNC CKKSEncoder_Destroy(void *thisptr);
 SHL_FUNC CKKSEncoder_SlotCount(void *thisptr, uint64_t *slot_count);
