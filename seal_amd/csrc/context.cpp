@@ -270,13 +270,17 @@ namespace sealhip
             h_fpd_[p].qinv = 1.0 / (double)q;
             h_fpd_[p].two32 = (double)((uint64_t(1) << 32) % q);
             h_fpd_[p].qi = q;
+            // BALANCED representatives in (-q/2, q/2]: a multiplier of magnitude <= q/2 halves the quotient-estimate term of the
+            // butterfly bound (field.h: |r| <= q (1/2 + 3/16 B) instead of 3/8 B), which is what lets the key-switch kernels
+            // run seven stages between two fix() calls
+            const auto balanced = [q](uint64_t w) { return w > q / 2 ? -(double)(q - w) : (double)w; };
             for (size_t i = 0; i < n_; i++)
             {
-                fwd_d[p * n_ + i] = (double)fwd[p * n_ + i].w;
-                inv_d[p * n_ + i] = (double)inv[p * n_ + i].w;
+                fwd_d[p * n_ + i] = balanced(fwd[p * n_ + i].w);
+                inv_d[p * n_ + i] = balanced(inv[p * n_ + i].w);
             }
-            ninv_d[2 * p] = (double)ninv[2 * p].w;
-            ninv_d[2 * p + 1] = (double)ninv[2 * p + 1].w;
+            ninv_d[2 * p] = balanced(ninv[2 * p].w);
+            ninv_d[2 * p + 1] = balanced(ninv[2 * p + 1].w);
         }
         check_hip(hipMalloc(&d_fpd_, np * sizeof(FpDesc)), "hipMalloc fpd");
         check_hip(hipMalloc(&d_fwd_d_, fwd_d.size() * 8), "hipMalloc fwd_d");

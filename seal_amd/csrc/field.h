@@ -14,11 +14,15 @@
 //                                               the results are integers of magnitude < 2^53
 //
 // r is congruent to y*w mod q whatever k was; only |r| depends on how good the quotient estimate
-// is: |r| <= q*(1/2 + 3*2^-53*|y*w/q|) (three roundings), i.e. |r| <= q*(0.5 + 0.375*B) when
-// |y| <= B*q and q < 2^50.  Values are kept as signed ("balanced") integers in doubles; sums stay
-// exact while every magnitude is below 2^53 = 8*2^50, which the kernels guarantee by calling
-// fix() (x - rint(x*qinv)*q, |result| <= q/2 + eps) after at most four butterfly stages:
-//     forward (CT):  B -> 1.375*B + 0.5 per stage:  1 -> 1.9 -> 3.1 -> 4.7 -> 7.0   (< 8)
+// is: |r| <= q*(1/2 + 3*2^-53*|y*w/q|) (three roundings: the product, 1/q, their product).  The
+// multipliers - twiddles, N^-1 constants, key words - are stored as BALANCED representatives,
+// |w| <= q/2 (Context, key_layout_kernel), so |y*w/q| <= |y|/2 and, with |y| <= B*q and q < 2^50,
+//     |r| <= q*(0.5 + 0.1875*B)        (0.375*B for a multiplier in [0, q), e.g. 2^32 mod q in fp_from_u64).
+// Values are kept as signed integers in doubles; sums stay exact while every magnitude is below
+// 2^53 = 8*2^50, which the kernels guarantee by calling fix() (x - rint(x*qinv)*q, |result| <= q/2 + eps):
+//     forward (CT):  B -> 1.1875*B + 0.5 per stage: 0.5 -> 1.09 -> 1.80 -> 2.64 -> 3.63 -> 4.81 -> 6.21 -> 7.88  (< 8)
+//                    seven stages between two fix(); the transform kernels fix after every four-stage phase (3.63 q), the
+//                    key-switch kernels of N = 2^16 after stages 7 and 14 only (ntt2_kernels.hip: p1_tile / p2_tile, LEAN)
 //     inverse (GS):  B -> 2*B per stage:            0.5 -> 1 -> 2 -> 4 -> 8 (sum < 8q <= 2^53, exact)
 // Only canonical residues in [0,q) ever leave a kernel, so results are bit-identical to the
 // integer path and to the reference: the representation is internal.
@@ -27,6 +31,10 @@
 // forward values in [0,4q), inverse values in [0,2q).
 #pragma once
 #include "modarith.h"
+#if defined(SEALHIP_CHECK_BOUNDS)
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace sealhip
 {
@@ -42,6 +50,21 @@ namespace sealhip
         uint64_t qi;   // the prime as an integer (0 = prime not eligible)
     };
 
+#if defined(SEALHIP_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
+#define SEALHIP_BOUND(v)                                                                                        \
+    do                                                                                                          \
+    {                                                                                                           \
+        const double sealhip_b_ = (v);                                                                          \
+        if (!(sealhip_b_ < 9007199254740992.0 && sealhip_b_ > -9007199254740992.0))                             \
+        {                                                                                                       \
+            std::fprintf(stderr, "sealhip: magnitude bound 2^53 violated (%g) at %s:%d\n", sealhip_b_, __FILE__, __LINE__); \
+            std::abort();                                                                                       \
+        }                                                                                                       \
+    } while (0)
+#else
+#define SEALHIP_BOUND(v) ((void)0)
+#endif
+
     SHL_HD double fp_from_bits(uint64_t b)
     {
         return __builtin_bit_cast(double, b);
@@ -51,13 +74,17 @@ namespace sealhip
         return __builtin_bit_cast(uint64_t, d);
     }
 
-    // x*w - k*q with k = rint(x*w/q): exact residue of the product, |result| <= q*(0.5 + 0.375*|x|/q)
+    // x*w - k*q with k = rint(x*w/q): exact residue of the product, |result| <= q*(0.5 + 0.375*|x*w|/q^2)
+    // (= 0.5 + 0.1875*|x|/q for a balanced multiplier |w| <= q/2).  SEALHIP_CHECK_BOUNDS (emulated build only): every
+    // operand and result is checked against 2^53.
     SHL_HD double fp_mulmod(double x, double w, double q, double qinv)
     {
+        SEALHIP_BOUND(x);
         double h = x * w;
         double l = __builtin_fma(x, w, -h);
         double k = __builtin_rint(h * qinv);
         double v = __builtin_fma(-k, q, h);
+        SEALHIP_BOUND(v + l);
         return v + l;
     }
     // |x| < 2^53 -> congruent value with |result| <= q/2 (+ a few ulp of q)
@@ -258,6 +285,8 @@ namespace sealhip
             double t = fp_mulmod(Y, w, m.q, m.qinv);
             Y = X - t;
             X = X + t;
+            SEALHIP_BOUND(X);
+            SEALHIP_BOUND(Y);
         }
         static SHL_HD void bfly_inv(elem &X, elem &Y, const tw_t &w, const Mod &m)
         {
@@ -301,8 +330,9 @@ namespace sealhip
             return fp_from_bits(x);
         }
 
-        // key-switch inner product: each product is reduced to |r| <= 0.69q and summed exactly;
-        // acc_fix() is called every 8 terms so the sum stays below 8q <= 2^53.
+        // key-switch inner product: each product is reduced to |r| <= q (0.5 + 0.1875 B) - balanced key words, |x| <= B q with
+        // B <= 1.8 (lean placement) - i.e. <= 0.84 q, and summed exactly; acc_fix() is called every 8 terms so the sum stays
+        // below 0.5 q + 8 * 0.84 q = 7.2 q < 2^53.
         typedef double Acc;
         typedef double key_t; // the key component is stored as doubles for eligible primes
         static SHL_HD Acc acc_zero()
@@ -312,6 +342,7 @@ namespace sealhip
         static SHL_HD void mac(Acc &a, elem x, key_t k, const Mod &m)
         {
             a += fp_mulmod(x, k, m.q, m.qinv);
+            SEALHIP_BOUND(a);
         }
         static SHL_HD void acc_fix(Acc &a, const Mod &m)
         {

@@ -111,6 +111,36 @@ namespace sealhip
                 stage_fwd<FP, 0>(x, m, [&](int g) { return tw(3, g); });
         }
 
+        // the same with one fix() of all 16 values after the first FIXAT stages of the phase (double-precision back end: the
+        // "lean" placement of the key-switch kernels, see p1_tile)
+        template <bool FP, int R, int FIXAT, class TwFn>
+        __device__ __forceinline__ void phase_fwd_fix(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
+        {
+            static_assert(R == 4 && FIXAT >= 1 && FIXAT <= 3, "a four-stage phase with the fix inside it");
+            stage_fwd<FP, 3>(x, m, [&](int g) { return tw(0, g); });
+            if constexpr (FIXAT == 1)
+            {
+#pragma unroll
+                for (int a = 0; a < 16; a++)
+                    Field<FP>::fix(x[a], m);
+            }
+            stage_fwd<FP, 2>(x, m, [&](int g) { return tw(1, g); });
+            if constexpr (FIXAT == 2)
+            {
+#pragma unroll
+                for (int a = 0; a < 16; a++)
+                    Field<FP>::fix(x[a], m);
+            }
+            stage_fwd<FP, 1>(x, m, [&](int g) { return tw(2, g); });
+            if constexpr (FIXAT == 3)
+            {
+#pragma unroll
+                for (int a = 0; a < 16; a++)
+                    Field<FP>::fix(x[a], m);
+            }
+            stage_fwd<FP, 0>(x, m, [&](int g) { return tw(3, g); });
+        }
+
         // Inverse (Gentleman-Sande) counterparts: the stages of a phase are undone last-to-first.
         template <bool FP, int BIT, class TwFn>
         __device__ __forceinline__ void stage_inv(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
@@ -214,7 +244,12 @@ namespace sealhip
         // intermediate lives in LDS, so that the 16-lane runs of one wave instruction fall on different banks)
         // ORDER 1 ("lane order", for ks2_v2): coefficient (row h = 16 hg + u, column c) at hg*4096 + (c >> 5)*512 + u*32 + (c & 31),
         // so that the 512 threads (u, l = c & 31) of the 8-coefficients-per-thread pass 2 read eight fully coalesced 4 KiB rows
-        template <bool FP, int D1, int BS = 256, int ORDER = 0>
+        // LEAN (double-precision back end, N = 2^16, key switching): with balanced twiddles a magnitude B q grows to
+        // (1.1875 B + 0.5) q per stage (field.h), 0.5 -> 1.09 -> 1.80 -> 2.64 -> 3.63 -> 4.81 -> 6.21 -> 7.88 over seven stages
+        // (< 8 q <= 2^53: still exact).  The sixteen stages of a raised digit therefore need a fix() after global stage 7 (here,
+        // inside phase B) and after stage 14 (p2_tile) only: the input must come in with |x| <= q/2, the intermediate leaves
+        // with |x| <= 1.09 q, unfixed.
+        template <bool FP, int D1, int BS = 256, int ORDER = 0, bool LEAN = false>
         __device__ __forceinline__ void p1_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const TwRegs<FP> &tw, uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
@@ -227,7 +262,7 @@ namespace sealhip
             {
                 // phase A: register a = ra*2^(4-rA) + rbh; stage s pairs register bit 3-s; twiddle 2^s + group: uniform
                 phase_fwd<FP, G::rA>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
-                if constexpr (FP)
+                if constexpr (FP && !LEAN)
                 {
 #pragma unroll
                     for (int a = 0; a < 16; a++)
@@ -248,12 +283,20 @@ namespace sealhip
             }
             // phase B: thread (c, ra = hi); register rb; stage rA+t pairs rb bit 3-t; twiddle 2^(rA+t) + ra*2^t + group
             // (tw = p1_load_tw(), loop-invariant for callers that transform many tiles with one prime)
-            phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
-            if constexpr (FP)
+            if constexpr (FP && LEAN)
             {
+                static_assert(!LEAN || G::rA == 4, "the lean placement is worked out for eight stages per pass");
+                phase_fwd_fix<FP, 4, 3>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+            }
+            else
+            {
+                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                if constexpr (FP)
+                {
 #pragma unroll
-                for (int a = 0; a < 16; a++)
-                    F::fix(x[a], m);
+                    for (int a = 0; a < 16; a++)
+                        F::fix(x[a], m);
+                }
             }
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
             const unsigned col = cg * G::C + c;
@@ -305,7 +348,11 @@ namespace sealhip
 
         // TWA_LDS: only phase A's row-shared twiddles come from LDS (twa), phase B's per-thread ones from global memory
         // (LOWREG) or from the caller's registers (HOIST && TWA_LDS: pre_b only)
-        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false>
+        // LEAN (see p1_tile): the input arrives with |x| <= 1.09 q; no fix() after phase A (-> 4.81 q), one after the second stage
+        // of phase B (global stage 14: 7.88 q -> q/2), none at the end: the values leave with |x| <= 1.80 q, which the key
+        // products take (|x k mod q| <= q (1/2 + 3/16 * 1.8) = 0.84 q with balanced key words; eight terms on top of a fixed
+        // accumulator stay below 7.2 q)
+        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false, bool LEAN = false>
         __device__ __forceinline__ void p2_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const typename Field<FP>::tw_t *twa, const typename Field<FP>::tw_t *twb, uint64_t *lds_wave, unsigned hg, unsigned tid,
@@ -337,7 +384,7 @@ namespace sealhip
                     load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + t)) + (h << t); });
                 phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
-            if constexpr (FP)
+            if constexpr (FP && !LEAN)
             {
 #pragma unroll
                 for (int a = 0; a < 16; a++)
@@ -363,6 +410,10 @@ namespace sealhip
             {
                 phase_fwd<FP, 4>(x, m, [&](int t, int g) { return pre_b->get((1 << t) + g); });
             }
+            else if constexpr (LOWREG && TW_LDS && LEAN)
+            {
+                phase_fwd_fix<FP, 4, 2>(x, m, [&](int t, int g) { return twb[((256u << t) - 256u) + g * 256 + tid]; });
+            }
             else if constexpr (LOWREG && TW_LDS)
             {
                 phase_fwd<FP, 4>(x, m, [&](int t, int g) { return twb[((256u << t) - 256u) + g * 256 + tid]; });
@@ -386,7 +437,8 @@ namespace sealhip
                     load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
                 phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
-            if constexpr (FP)
+            static_assert(!LEAN || (FP && LOWREG && TW_LDS), "the lean placement is wired for the double-precision ks2 variant only");
+            if constexpr (FP && !LEAN)
             {
 #pragma unroll
                 for (int a = 0; a < 16; a++)
@@ -1155,6 +1207,16 @@ namespace sealhip
             inv_fused2_body<D1>(a, prime, comp, outer, lds);
         }
 
+        // The key-switch kernels of N = 2^16 (eight stages per pass) use the lean fix() placement of p1_tile / p2_tile (tile-order
+        // intermediate only; the lane-order geometry keeps its own).  SEALHIP_KS_LEAN_OFF at build time restores five fix() per pair.
+#ifdef SEALHIP_KS_LEAN_OFF
+        template <int D1, int ORDER>
+        constexpr bool kLeanKs = false;
+#else
+        template <int D1, int ORDER>
+        constexpr bool kLeanKs = D1 == 8 && ORDER == 0;
+#endif
+
         // ---------------------------------------------------------------------------------------
         // fused key switching, pass 1: one workgroup = (column tile cg, digit J, batch item b);
         // loops over the target moduli in `targets` (entries: slot I in the K+1 x K grid, pool prime).
@@ -1211,7 +1273,11 @@ namespace sealhip
                     {
 #pragma unroll
                         for (int e = 0; e < 16; e++)
-                            x[e] = F::from_any(nxt[e], m);
+                        {
+                            x[e] = F::from_any(nxt[e], m); // magnitude < q + 2^32
+                            if constexpr (kLeanKs<D1, ORDER>)
+                                F::fix(x[e], m); // the lean placement starts from |x| <= q/2
+                        }
                     }
                     else
                     {
@@ -1246,7 +1312,7 @@ namespace sealhip
                 if (Jn < j1)
                     fetch(Jn);
                 uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
-                p1_tile<FP, D1, 256, ORDER>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1, 256, ORDER, FP && kLeanKs<D1, ORDER>>(x, m, tab, tw, lds, mid_tr, cg, tid);
                 J = Jn;
             }
         }
@@ -1419,7 +1485,7 @@ namespace sealhip
                 }
                 if (!is_diag)
                 {
-                    p2_tile<FP, D1, FP, true, false, !FP>(x, m, tab, twa, twb, lds_wave, hg, tid);
+                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1, 0>>(x, m, tab, twa, twb, lds_wave, hg, tid);
                     if constexpr (!FP)
                     {
 #pragma unroll
@@ -1719,7 +1785,16 @@ namespace sealhip
                     nat = (hg << 12) + (size_t)t9 * 8 + mm;
                 }
                 const uint64_t v = in[(slab << n_log) + nat];
-                out[i] = fpd[comp].qi ? fp_to_bits(fp_from_u52(v)) : v;
+                if (fpd[comp].qi)
+                {
+                    // balanced representative in (-q/2, q/2] (see Context: the same halving of the bound for the key products)
+                    double d = fp_from_u52(v);
+                    if (v > fpd[comp].qi / 2)
+                        d -= fpd[comp].q;
+                    out[i] = fp_to_bits(d);
+                }
+                else
+                    out[i] = v;
             }
         }
 

@@ -212,3 +212,11 @@ def test_digit_parallel_reduce_scatter(emu, n, bits, parts, batch):
     of pack / owned mod-down / add; and the library's driver + key broadcast on a one-rank (loopback) communicator"""
     primes = coeff_modulus_create(n, bits)
     assert P.case_digit_parallel_reduce_scatter(n, primes, parts=parts, batch=batch) is True  # loopback: no RCCL on this box
+
+
+def test_ckks_pipeline_n65536_lean_key_switch(emu):
+    """N = 2^16 is the one size whose key-switch kernels use the lean fix() placement (two per sixteen stages, balanced
+    tables; ntt2_kernels.hip p1_tile / p2_tile): multiply + relinearize + rescale + rotate word for word, incl. 60-bit digits
+    feeding double-precision targets and the other way round"""
+    P.case_ckks_pipeline(65536, [60, 50, 50, 60], batch=1, steps=(1,), check_transforms=False)
+    P.case_ckks_pipeline(65536, [60, 50, 40, 50, 45, 60], batch=2, steps=(1,), check_transforms=False)
