@@ -74,6 +74,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--ntt-only", action="store_true", help="only the NTT roofline leg (for rocprofv3 runs)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--streams", type=int, default=1, help="headline / bfv_c4: divide the GPU's batch over this many evaluators, each on its "
+                    "own HIP stream, so that one sub-batch's memory-bound phases overlap another's key switching")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (Evaluator_BeginCapture/EndCapture): "
                     "for launch-bound small batches; the default (eager) path is what the headline number uses")
     return ap.parse_args(argv)
@@ -218,7 +220,38 @@ def main():
     work = S.Ciphertext(ctx, batch=B)
     dev_sync()
 
-    if args.workload == "headline":
+    lanes = None
+    if args.streams > 1 and args.workload != "rotate_c5" and B >= args.streams:
+        # sub-batches [lo, hi) of the resident inputs, one evaluator + stream + output batch each
+        lanes = []
+        for si in range(args.streams):
+            lo, cnt = shard.split(B, args.streams, si)
+            st = S.Stream()
+            e = S.Evaluator(ctx)
+            e.set_stream(st.handle)
+
+            def sub(t, lo=lo, cnt=cnt):
+                ct = S.Ciphertext(ctx, batch=cnt)
+                ct.resize(first, 2)
+                ct.set_is_ntt_form(ntt_form)
+                ct.set_scale(scale)
+                src = t[:, lo:lo + cnt].contiguous()   # [2][cnt][K][n]
+                ct.load_device(src.data_ptr(), src.numel())
+                dev_sync()
+                return ct
+            lanes.append(dict(ev=e, stream=st, lo=lo, cnt=cnt, x=sub(xs), y=sub(ys), work=S.Ciphertext(ctx, batch=cnt)))
+        dev_sync()
+
+    last_op = {"headline": "rescale_to_next_inplace", "bfv_c4": "mod_switch_to_next_inplace"}.get(args.workload)
+    if lanes:
+        def step():
+            for ln in lanes:
+                ln["ev"].multiply(ln["x"], ln["y"], ln["work"])
+            for ln in lanes:
+                ln["ev"].relinearize_inplace(ln["work"], keys)
+            for ln in lanes:
+                getattr(ln["ev"], last_op)(ln["work"])
+    elif args.workload == "headline":
         def step():
             ev.multiply(x, y, work)          # work = x * y (size 3); x stays resident as the next step's input
             ev.relinearize_inplace(work, keys)
@@ -239,6 +272,8 @@ def main():
             ev.rescale_to_next_inplace(w)
             holder["work"] = w
 
+    if args.graph and lanes:
+        raise SystemExit("bench.py: --graph captures one evaluator's stream; not combined with --streams")
     if args.graph and not args.ntt_only and args.workload != "rotate_c5":
         step()  # eager once: lazily built tables, pool warm-up
         dev_sync()
@@ -251,6 +286,8 @@ def main():
         elapsed = shard.timed_steps(step, args.steps, args.warmup, group, dev_sync, torch, device)
         if args.workload == "rotate_c5":
             work = holder["work"]
+        if lanes:
+            work = LaneView(lanes)
         assert work.size() == 2 and work.coeff_modulus_size() == K - 1 and work.batch() == B
         per_step = B if args.workload != "rotate_c5" else float(B) / world  # rotate_c5: all ranks worked on the same B items
         rate = shard.whole_job_rate(per_step, args.steps, elapsed, group, torch, device)
@@ -295,6 +332,7 @@ def main():
         dist.barrier()
     if rank == 0 and world == 1 and roofline is not None and not args.no_pmc:
         del x, y, work, xs, ys
+        lanes = None
         torch.cuda.empty_cache()
         S.release_pool()
         roofline.update(pmc_traffic(args, B, K, n))
@@ -324,7 +362,9 @@ def main():
             warmup=args.warmup, ms_per_step=round(result.get("ms_per_step", 0.0), 3), higher_is_better=True,
             scaling=scaling, vs_baseline=None, dtype="u64", data="synthetic", verified_items=verified,
             config=dict(workload=names[1] + (" [EMULATED KERNELS, CPU test]" if EMU else ""),
-                        batch_per_gpu=B, launch="hipGraph replay" if args.graph else "eager", parallelism=par,
+                        batch_per_gpu=B, launch=("hipGraph replay" if args.graph else "eager") + (
+                            ", %d evaluators x %d-item sub-batches on %d HIP streams" % (len(lanes), lanes[0]["cnt"], len(lanes)) if lanes else ""),
+                        parallelism=par,
                         arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for primes below "
                                    "2^50, 64-bit Shoup/Barrett integer arithmetic for larger primes; results canonical u64",
                         key_bytes=2 * K * L * n * 8, algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n),
@@ -349,6 +389,33 @@ def reference_available():
         return sealref.available()
     except Exception:
         return False
+
+
+class LaneView:
+    """the per-stream output batches of --streams seen as one batch (metadata of lane 0, items by global index)"""
+
+    def __init__(self, lanes):
+        self.lanes = lanes
+
+    def size(self):
+        sizes = {ln["work"].size() for ln in self.lanes}
+        assert len(sizes) == 1
+        return sizes.pop()
+
+    def coeff_modulus_size(self):
+        return self.lanes[0]["work"].coeff_modulus_size()
+
+    def batch(self):
+        return sum(ln["work"].batch() for ln in self.lanes)
+
+    def scale(self):
+        return self.lanes[0]["work"].scale()
+
+    def item_to_numpy(self, b):
+        for ln in self.lanes:
+            if ln["lo"] <= b < ln["lo"] + ln["cnt"]:
+                return ln["work"].item_to_numpy(b - ln["lo"])
+        raise IndexError(b)
 
 
 def verify_items(workload, scheme, n, primes, t_plain, key_host, xs, ys, work, B, scale):

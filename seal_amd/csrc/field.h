@@ -61,8 +61,19 @@ namespace sealhip
             std::abort();                                                                                       \
         }                                                                                                       \
     } while (0)
+// integer back end: a + b must not wrap (the unguarded forward butterflies rely on 16 q fitting a word)
+#define SEALHIP_NOWRAP(a, b)                                                                                    \
+    do                                                                                                          \
+    {                                                                                                           \
+        if ((uint64_t)(a) > ~(uint64_t)(b))                                                                     \
+        {                                                                                                       \
+            std::fprintf(stderr, "sealhip: 64-bit sum wraps at %s:%d\n", __FILE__, __LINE__);                   \
+            std::abort();                                                                                       \
+        }                                                                                                       \
+    } while (0)
 #else
 #define SEALHIP_BOUND(v) ((void)0)
+#define SEALHIP_NOWRAP(a, b) ((void)0)
 #endif
 
     SHL_HD double fp_from_bits(uint64_t b)
@@ -146,12 +157,21 @@ namespace sealhip
         {
             uint64_t q, two_q;
             ModDesc md;
+            // fwd_fix(): rcp = floor(2^(32 + bits) / 2q) in [2^31, 2^32), bits = bit_length(q); sx = max(bits - 28, 0) aligns
+            // a value below 16 q to 32 bits, sh = bits - sx; n0, n1 = the two halves of -2q mod 2^64
+            uint32_t rcp, sx, sh, n0, n1;
         };
         static constexpr int tw_words = 2;
 
         static SHL_HD Mod make_mod(const ModDesc &md, const FpDesc &)
         {
-            return Mod{ md.q, md.two_q, md };
+            // floor(2^(31 + bits) / q) = floor(2^128 / q) >> (97 - bits); wave-uniform: scalar instructions on the device
+            const unsigned bits = 64u - (unsigned)__builtin_clzll(md.q | 1);
+            const unsigned s128 = 97u - bits; // 37 .. 95 for 2 <= bits <= 60
+            const uint32_t rcp = s128 >= 64 ? (uint32_t)(md.ratio_hi >> (s128 - 64)) : (uint32_t)((md.ratio_hi << (64 - s128)) | (md.ratio_lo >> s128));
+            const unsigned sx = bits > 28 ? bits - 28 : 0;
+            const uint64_t nq2 = 0 - md.two_q;
+            return Mod{ md.q, md.two_q, md, rcp, sx, bits - sx, (uint32_t)nq2, (uint32_t)(nq2 >> 32) };
         }
         static SHL_HD elem from_canon(uint64_t x, const Mod &)
         {
@@ -182,13 +202,39 @@ namespace sealhip
             const uint64_t d = x - m.two_q;
             return (int64_t)d < 0 ? x : d;
         }
-        // X,Y in [0,4q) -> [0,4q)   (Arithmetic<>::guard/add/sub/mul_root, ntt.h:30-61)
+        // Forward butterfly WITHOUT the per-butterfly guard of the reference (Arithmetic<>::guard, ntt.h:30-61): with q < 2^60
+        // a 64-bit word holds 16 q, mul_lazy() takes any 64-bit Y, so X, Y in [0, B q) -> [0, (B + 2) q) and a run of stages only
+        // needs B + 2 * stages <= 16; fwd_fix() brings everything back under 4 q once per run (p1_tile / p2_tile: after each
+        // phase of at most four stages, 4 -> 12).  The residues are the same as with the reference's ranges; outputs leave
+        // through fwd_to_canon / fwd_to_lazy from [0, 4q) as before.  Moduli of 2^60 and above (SEAL allows 61 bits: user
+        // primes, the BEHZ auxiliary base) take bfly_fwd_guarded instead (wide_modulus() / phase_fwd_end in ntt2_kernels.hip:
+        // one wave-uniform branch at the top of each kernel).
         static SHL_HD void bfly_fwd(elem &X, elem &Y, const tw_t &w, const Mod &m)
+        {
+            uint64_t t = mul_lazy(Y, w, m);
+            SEALHIP_NOWRAP(X, m.two_q);
+            Y = X + m.two_q - t;
+            X = X + t;
+        }
+        // X,Y in [0,4q) -> [0,4q)   (Arithmetic<>::guard/add/sub/mul_root, ntt.h:30-61): moduli of 2^60 and above
+        static SHL_HD void bfly_fwd_guarded(elem &X, elem &Y, const tw_t &w, const Mod &m)
         {
             uint64_t x = guard(X, m);
             uint64_t t = mul_lazy(Y, w, m);
             X = x + t;
             Y = x + m.two_q - t;
+        }
+        // x < 16 q -> x - k * 2q in [0, 4q) with k = floor((x >> sx) * rcp / 2^(32 + sh)) in {floor(x / 2q) - 1, floor(x / 2q)}:
+        // (x >> sx) * 2^sx <= x and rcp <= 2^(32 + sx + sh) / 2q give k <= x / 2q; the two truncations and the floor lose less
+        // than 2^sx / 2q + (x >> sx) / 2^(32 + sh) + 1 < 2 (x >> sx < 2^32 because x < 2^(bits + 4)).  Six VALU instructions
+        // (v_lshrrev_b64, v_mul_hi_u32, v_lshrrev_b32, v_mad_u64_u32, v_mul_lo_u32, v_add_u32).
+        static SHL_HD void fwd_fix(elem &x, const Mod &m)
+        {
+            const uint32_t xs = (uint32_t)(x >> m.sx);
+            const uint32_t k = (uint32_t)(((uint64_t)xs * m.rcp) >> 32) >> m.sh;
+            const uint64_t lo = (uint64_t)k * m.n0 + x;
+            const uint32_t hi = (uint32_t)(lo >> 32) + k * m.n1;
+            x = ((uint64_t)hi << 32) | (uint32_t)lo;
         }
         // X,Y in [0,2q) -> [0,2q)   (dwthandler.h:202-356)
         static SHL_HD void bfly_inv(elem &X, elem &Y, const tw_t &w, const Mod &m)
@@ -301,6 +347,10 @@ namespace sealhip
             Y = fp_mulmod(d, nw, m.q, m.qinv);
         }
         static SHL_HD void fix(elem &x, const Mod &m)
+        {
+            x = fp_fix(x, m.q, m.qinv);
+        }
+        static SHL_HD void fwd_fix(elem &x, const Mod &m)
         {
             x = fp_fix(x, m.q, m.qinv);
         }

@@ -70,6 +70,11 @@ namespace sealhip
             return v2;
         }
 
+        // moduli of 2^60 and above (SEAL allows 61 bits) keep the reference's guarded forward butterflies (field.h); wave-uniform
+        __device__ __forceinline__ bool wide_modulus(const NttTables &t, unsigned prime)
+        {
+            return (SHL_UCONST(reinterpret_cast<const uint64_t *>(&t.mods[prime]))[0] >> 60) != 0;
+        }
         template <bool FP>
         __device__ __forceinline__ const typename Field<FP>::tw_t *tw_table(const NttTables &t, bool inverse, unsigned prime)
         {
@@ -81,7 +86,8 @@ namespace sealhip
 
         // One radix-2 stage over the 16 registers of a thread, pairing register-index bit BIT.
         // tw(g) supplies the twiddle of group g = e >> (BIT+1).
-        template <bool FP, int BIT, class TwFn>
+        // GUARD (integer back end only): the reference's butterfly with its per-butterfly range guard (moduli of 2^60 and above)
+        template <bool FP, int BIT, bool GUARD = false, class TwFn>
         __device__ __forceinline__ void stage_fwd(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {
 #pragma unroll
@@ -92,23 +98,60 @@ namespace sealhip
                 for (int k = 0; k < (1 << BIT); k++)
                 {
                     const int e0 = (g << (BIT + 1)) | k;
-                    Field<FP>::bfly_fwd(x[e0], x[e0 | (1 << BIT)], w, m);
+                    if constexpr (!FP && GUARD)
+                        Field<FP>::bfly_fwd_guarded(x[e0], x[e0 | (1 << BIT)], w, m);
+                    else
+                        Field<FP>::bfly_fwd(x[e0], x[e0 | (1 << BIT)], w, m);
                 }
             }
         }
 
         // R (<= 4) consecutive stages on register bits 3, 2, ...; twiddle of (stage t, group g) = tw(t, g)
-        template <bool FP, int R, class TwFn>
+        template <bool FP, int R, bool GUARD = false, class TwFn>
         __device__ __forceinline__ void phase_fwd(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {
             if constexpr (R >= 1)
-                stage_fwd<FP, 3>(x, m, [&](int g) { return tw(0, g); });
+                stage_fwd<FP, 3, GUARD>(x, m, [&](int g) { return tw(0, g); });
             if constexpr (R >= 2)
-                stage_fwd<FP, 2>(x, m, [&](int g) { return tw(1, g); });
+                stage_fwd<FP, 2, GUARD>(x, m, [&](int g) { return tw(1, g); });
             if constexpr (R >= 3)
-                stage_fwd<FP, 1>(x, m, [&](int g) { return tw(2, g); });
+                stage_fwd<FP, 1, GUARD>(x, m, [&](int g) { return tw(2, g); });
             if constexpr (R >= 4)
-                stage_fwd<FP, 0>(x, m, [&](int g) { return tw(3, g); });
+                stage_fwd<FP, 0, GUARD>(x, m, [&](int g) { return tw(3, g); });
+        }
+
+        // A phase and the reduction that ends it.  Double precision: fix() of all 16 values when FIX.  Integer back end: for
+        // q < 2^60 the unguarded butterflies of field.h (+ 2 q per stage) and, when FIX, fwd_fix() back under 4 q; for the wider
+        // moduli SEAL allows (up to 61 bits: user primes, the BEHZ auxiliary base) the reference's guarded butterflies, which
+        // keep [0, 4q) by themselves (WIDE).  One modulus per workgroup: the kernels branch once, at the top (int_body()).
+        template <bool FP, int R, bool FIX, bool WIDE, class TwFn>
+        __device__ __forceinline__ void phase_fwd_end(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
+        {
+            if constexpr (FP)
+            {
+                phase_fwd<FP, R>(x, m, tw);
+                if constexpr (FIX)
+                {
+#pragma unroll
+                    for (int a = 0; a < 16; a++)
+                        Field<FP>::fix(x[a], m);
+                }
+            }
+            else
+            {
+                if constexpr (WIDE)
+                    phase_fwd<FP, R, true>(x, m, tw);
+                else
+                {
+                    phase_fwd<FP, R>(x, m, tw);
+                    if constexpr (FIX)
+                    {
+#pragma unroll
+                        for (int a = 0; a < 16; a++)
+                            Field<FP>::fwd_fix(x[a], m);
+                    }
+                }
+            }
         }
 
         // the same with one fix() of all 16 values after the first FIXAT stages of the phase (double-precision back end: the
@@ -249,7 +292,7 @@ namespace sealhip
         // (< 8 q <= 2^53: still exact).  The sixteen stages of a raised digit therefore need a fix() after global stage 7 (here,
         // inside phase B) and after stage 14 (p2_tile) only: the input must come in with |x| <= q/2, the intermediate leaves
         // with |x| <= 1.09 q, unfixed.
-        template <bool FP, int D1, int BS = 256, int ORDER = 0, bool LEAN = false>
+        template <bool FP, int D1, int BS = 256, int ORDER = 0, bool LEAN = false, bool WIDE = false>
         __device__ __forceinline__ void p1_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const TwRegs<FP> &tw, uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
@@ -261,13 +304,9 @@ namespace sealhip
             if constexpr (G::rA > 0)
             {
                 // phase A: register a = ra*2^(4-rA) + rbh; stage s pairs register bit 3-s; twiddle 2^s + group: uniform
-                phase_fwd<FP, G::rA>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
-                if constexpr (FP && !LEAN)
-                {
-#pragma unroll
-                    for (int a = 0; a < 16; a++)
-                        F::fix(x[a], m);
-                }
+                // integer back end (field.h, bfly_fwd): input below 4 q, + 2 q per stage, 16 q fit a word: short first phases
+                // (rA <= 2: 4 + 2 (rA + 4) <= 16) run on into phase B
+                phase_fwd_end<FP, G::rA, FP ? !LEAN : (G::rA > 2), WIDE>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
                 __syncthreads(); // previous users of the exchange buffer are done
 #pragma unroll
                 for (int a = 0; a < 16; a++)
@@ -290,13 +329,8 @@ namespace sealhip
             }
             else
             {
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
-                if constexpr (FP)
-                {
-#pragma unroll
-                    for (int a = 0; a < 16; a++)
-                        F::fix(x[a], m);
-                }
+                // the intermediate is stored with |x| <= q/2 resp. in [0, 4q)
+                phase_fwd_end<FP, 4, true, WIDE>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
             const unsigned col = cg * G::C + c;
@@ -352,7 +386,10 @@ namespace sealhip
         // of phase B (global stage 14: 7.88 q -> q/2), none at the end: the values leave with |x| <= 1.80 q, which the key
         // products take (|x k mod q| <= q (1/2 + 3/16 * 1.8) = 0.84 q with balanced key words; eight terms on top of a fixed
         // accumulator stay below 7.2 q)
-        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false, bool LEAN = false>
+        // TWB_REGS (with LOWREG && TW_LDS): the twiddles of phase B's last TWB_REGS stages are taken from the caller's registers
+        // (pre_b) instead of twb: a smaller LDS table (256 * (2^(4 - TWB_REGS) - 1) words) for 2 * (16 - 2^(4 - TWB_REGS)) VGPRs
+        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false, bool LEAN = false, int TWB_REGS = 0,
+                  bool WIDE = false>
         __device__ __forceinline__ void p2_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const typename Field<FP>::tw_t *twa, const typename Field<FP>::tw_t *twb, uint64_t *lds_wave, unsigned hg, unsigned tid,
@@ -364,16 +401,16 @@ namespace sealhip
             const unsigned ul = u & 3; // row inside this wave's buffer
             if constexpr (HOIST && !TWA_LDS)
             {
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return pre_a->get((1 << t) + g); });
+                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return pre_a->get((1 << t) + g); });
             }
             else if constexpr ((LOWREG || HOIST) && (TW_LDS || TWA_LDS))
             {
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
+                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
             }
             else if constexpr (LOWREG)
             {
                 // register-lean variant: each twiddle is fetched where it is used
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tab[(1u << (D1 + t)) + (h << t) + g]; });
+                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return tab[(1u << (D1 + t)) + (h << t) + g]; });
             }
             else
             {
@@ -382,13 +419,7 @@ namespace sealhip
                     load_tw<FP, 4>(tw, twa, [&](int t) { return (16u << t) - 16u + (u << t); });
                 else
                     load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + t)) + (h << t); });
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
-            }
-            if constexpr (FP && !LEAN)
-            {
-#pragma unroll
-                for (int a = 0; a < 16; a++)
-                    F::fix(x[a], m);
+                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
             // wave-local exchange: (e, v) -> (v', e')
 #pragma unroll
@@ -408,19 +439,23 @@ namespace sealhip
             __builtin_amdgcn_wave_barrier(); // the buffer may be rewritten by the caller's next tile
             if constexpr (HOIST)
             {
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return pre_b->get((1 << t) + g); });
-            }
-            else if constexpr (LOWREG && TW_LDS && LEAN)
-            {
-                phase_fwd_fix<FP, 4, 2>(x, m, [&](int t, int g) { return twb[((256u << t) - 256u) + g * 256 + tid]; });
+                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return pre_b->get((1 << t) + g); });
             }
             else if constexpr (LOWREG && TW_LDS)
             {
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return twb[((256u << t) - 256u) + g * 256 + tid]; });
+                auto twf = [&](int t, int g) {
+                    if (t >= 4 - TWB_REGS)
+                        return pre_b->get((1 << t) + g);
+                    return twb[((256u << t) - 256u) + g * 256 + tid];
+                };
+                if constexpr (LEAN)
+                    phase_fwd_fix<FP, 4, 2>(x, m, twf);
+                else
+                    phase_fwd_end<FP, 4, true, WIDE>(x, m, twf);
             }
             else if constexpr (LOWREG)
             {
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tab[(1u << (D1 + 4 + t)) + ((h * 16 + v) << t) + g]; });
+                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return tab[(1u << (D1 + 4 + t)) + ((h * 16 + v) << t) + g]; });
             }
             else
             {
@@ -435,15 +470,9 @@ namespace sealhip
                 }
                 else
                     load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
-                phase_fwd<FP, 4>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
             static_assert(!LEAN || (FP && LOWREG && TW_LDS), "the lean placement is wired for the double-precision ks2 variant only");
-            if constexpr (FP && !LEAN)
-            {
-#pragma unroll
-                for (int a = 0; a < 16; a++)
-                    F::fix(x[a], m);
-            }
         }
 
         // registers (row u, cols 16 v' + e') -> wave-local transpose -> 16 coalesced 512-byte stores
@@ -526,7 +555,7 @@ namespace sealhip
             NttTables t;
         };
 
-        template <bool FP, int D1>
+        template <bool FP, int D1, bool WIDE = false>
         __device__ __forceinline__ void fwd_p1_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -577,7 +606,7 @@ namespace sealhip
                 if (outer + ostride < a.nouter)
                     fetch(outer + ostride);
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
-                p1_tile<FP, D1>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1, 256, 0, false, WIDE>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
         }
 
@@ -592,11 +621,16 @@ namespace sealhip
             if constexpr (CLS == 1)
                 fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
-                fwd_p1_body<false, D1>(a, prime, comp, outer, lds);
+            {
+                if (wide_modulus(a.t, prime))
+                    fwd_p1_body<false, D1, true>(a, prime, comp, outer, lds);
+                else
+                    fwd_p1_body<false, D1>(a, prime, comp, outer, lds);
+            }
             else if (a.t.fpd[prime].qi)
                 fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
             else
-                fwd_p1_body<false, D1>(a, prime, comp, outer, lds);
+                fwd_p1_body<false, D1, true>(a, prime, comp, outer, lds); // mixed launches keep the guarded butterflies
         }
 
         // HOIST (plain transforms of the double-precision back end, no epilogue): the tile's 30 twiddles stay in
@@ -605,7 +639,7 @@ namespace sealhip
         // only here.
         // HOIST_LDS (CLS 4): the row-shared phase-A twiddles are staged once in LDS and only the 15 per-thread phase-B twiddles
         // stay in registers: the same "no twiddle is re-read per transform" at 128 VGPRs (four waves per SIMD) instead of 214 (two)
-        template <bool FP, int D1, bool HOIST = false, bool HOIST_LDS = false>
+        template <bool FP, int D1, bool HOIST = false, bool HOIST_LDS = false, bool WIDE = false>
         __device__ __forceinline__ void fwd_p2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -651,7 +685,7 @@ namespace sealhip
             else if constexpr (HOIST)
                 p2_tile<FP, D1, false, false, true>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid, &pre_a, &pre_b);
             else
-                p2_tile<FP, D1, false>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
+                p2_tile<FP, D1, false, false, false, false, false, 0, WIDE>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
             uint64_t val[16];
             const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
             if ((HOIST || HOIST_LDS) || a.epi == 0) // the hoisted variants are launched for plain transforms only
@@ -699,11 +733,16 @@ namespace sealhip
             else if constexpr (CLS == 1)
                 fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
-                fwd_p2_body<false, D1>(a, prime, comp, outer, lds);
+            {
+                if (wide_modulus(a.t, prime))
+                    fwd_p2_body<false, D1, false, false, true>(a, prime, comp, outer, lds);
+                else
+                    fwd_p2_body<false, D1>(a, prime, comp, outer, lds);
+            }
             else if (a.t.fpd[prime].qi)
                 fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
             else
-                fwd_p2_body<false, D1>(a, prime, comp, outer, lds);
+                fwd_p2_body<false, D1, false, false, true>(a, prime, comp, outer, lds);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1209,6 +1248,12 @@ namespace sealhip
 
         // The key-switch kernels of N = 2^16 (eight stages per pass) use the lean fix() placement of p1_tile / p2_tile (tile-order
         // intermediate only; the lane-order geometry keeps its own).  SEALHIP_KS_LEAN_OFF at build time restores five fix() per pair.
+        // ks2 (double-precision targets): phase B's twiddles of the last kKs2TwbRegs stages in registers, the rest in LDS
+#ifndef SEALHIP_KS2_TWB_REGS
+#define SEALHIP_KS2_TWB_REGS 0
+#endif
+        constexpr int kKs2TwbRegs = SEALHIP_KS2_TWB_REGS;
+        constexpr size_t kKs2TwbLdsWords = 256u * ((1u << (4 - kKs2TwbRegs)) - 1u);
 #ifdef SEALHIP_KS_LEAN_OFF
         template <int D1, int ORDER>
         constexpr bool kLeanKs = false;
@@ -1235,7 +1280,7 @@ namespace sealhip
             NttTables tb;
         };
 
-        template <bool FP, int D1, int ORDER>
+        template <bool FP, int D1, int ORDER, bool WIDE = false>
         __device__ __forceinline__ void ks1_body(const Ks1Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned b, unsigned cg, unsigned j0, unsigned j1)
         {
             typedef Field<FP> F;
@@ -1312,7 +1357,7 @@ namespace sealhip
                 if (Jn < j1)
                     fetch(Jn);
                 uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
-                p1_tile<FP, D1, 256, ORDER, FP && kLeanKs<D1, ORDER>>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1, 256, ORDER, FP && kLeanKs<D1, ORDER>, WIDE>(x, m, tab, tw, lds, mid_tr, cg, tid);
                 J = Jn;
             }
         }
@@ -1338,7 +1383,12 @@ namespace sealhip
             const unsigned jlen = (a.j1 - a.j0 + a.parts - 1) / a.parts;
             const unsigned j0 = a.j0 + dg * jlen, j1 = j0 + jlen < a.j1 ? j0 + jlen : a.j1;
             const unsigned I = SHL_UNIFORM(a.targets[2 * it]), prime = SHL_UNIFORM(a.targets[2 * it + 1]);
-            ks1_body<FP, D1, ORDER>(a, lds, I, prime, b, cg, j0, j1);
+            if constexpr (FP)
+                ks1_body<FP, D1, ORDER>(a, lds, I, prime, b, cg, j0, j1);
+            else if (wide_modulus(a.tb, prime))
+                ks1_body<FP, D1, ORDER, true>(a, lds, I, prime, b, cg, j0, j1);
+            else
+                ks1_body<FP, D1, ORDER>(a, lds, I, prime, b, cg, j0, j1);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1364,7 +1414,7 @@ namespace sealhip
             NttTables tb;
         };
 
-        template <bool FP, int D1>
+        template <bool FP, int D1, bool WIDE = false>
         __device__ __forceinline__ void ks2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg,
                                                  unsigned j0, unsigned j1, uint64_t *acc_part)
         {
@@ -1376,6 +1426,7 @@ namespace sealhip
 
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             const typename F::tw_t *twa = nullptr, *twb = nullptr;
+            TwRegs<FP> twr;
             if constexpr (!FP)
             {
                 // integer back end: phase A's 240 row-shared Shoup pairs (3.8 KiB) in LDS; phase B's stay in L2
@@ -1402,10 +1453,16 @@ namespace sealhip
                     la[tid] = tab[(1u << (D1 + t)) + ((hg * 16) << t) + r];
                 }
 #pragma unroll
-                for (int t = 0; t < 4; t++)
+                for (int t = 0; t < 4 - kKs2TwbRegs; t++)
 #pragma unroll
                     for (int g = 0; g < (1 << t); g++)
                         lb[((256u << t) - 256u) + g * 256 + tid] = tab[(1u << (D1 + 4 + t)) + ((hg * 256 + tid) << t) + g];
+                // the last kKs2TwbRegs stages' twiddles of this thread stay in registers for the whole digit loop
+#pragma unroll
+                for (int t = 4 - kKs2TwbRegs; t < 4; t++)
+#pragma unroll
+                    for (int g = 0; g < (1 << t); g++)
+                        twr.set((1 << t) + g, tab[(1u << (D1 + 4 + t)) + ((hg * 256 + tid) << t) + g]);
                 twa = la;
                 twb = lb;
                 __syncthreads();
@@ -1485,7 +1542,7 @@ namespace sealhip
                 }
                 if (!is_diag)
                 {
-                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1, 0>>(x, m, tab, twa, twb, lds_wave, hg, tid);
+                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1, 0>, FP ? kKs2TwbRegs : 0, WIDE>(x, m, tab, twa, twb, lds_wave, hg, tid, nullptr, &twr);
                     if constexpr (!FP)
                     {
 #pragma unroll
@@ -1534,8 +1591,11 @@ namespace sealhip
         }
 
         // CLS: 0 integer-back-end targets only, 1 double-precision targets only
+#ifndef SEALHIP_KS2_FP_WAVES
+#define SEALHIP_KS2_FP_WAVES 2
+#endif
         template <int D1, int CLS>
-        __global__ void __launch_bounds__(kThreads, 2) ks2_kernel(Ks2Args a)
+        __global__ void __launch_bounds__(kThreads, CLS == 1 ? SEALHIP_KS2_FP_WAVES : 2) ks2_kernel(Ks2Args a)
         {
             typedef Geo<D1> G;
             HIP_DYNAMIC_SHARED(uint64_t, lds)
@@ -1557,6 +1617,8 @@ namespace sealhip
             const unsigned I = SHL_UNIFORM(a.targets[3 * it]), prime = SHL_UNIFORM(a.targets[3 * it + 1]), kc = SHL_UNIFORM(a.targets[3 * it + 2]);
             if constexpr (CLS == 1)
                 ks2_body<true, D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
+            else if (wide_modulus(a.tb, prime))
+                ks2_body<false, D1, true>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
             else
                 ks2_body<false, D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
         }
@@ -2040,7 +2102,7 @@ namespace sealhip
             const unsigned vbatch = batch * a1.parts; // (digit group, batch item) pairs
             const unsigned groups = vbatch * G::TILES;
             const unsigned n_fp = a1.ntargets - n_int;
-            const size_t l2_fp = kLds2Words * 8 + (240 + 3840) * sizeof(double); // the tile's twiddles staged in LDS
+            const size_t l2_fp = kLds2Words * 8 + (240 + kKs2TwbLdsWords) * sizeof(double); // the tile's twiddles staged in LDS
             if (n_fp && l2_fp > 65536)
             {
                 // more than the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU)
