@@ -386,10 +386,7 @@ namespace sealhip
         // of phase B (global stage 14: 7.88 q -> q/2), none at the end: the values leave with |x| <= 1.80 q, which the key
         // products take (|x k mod q| <= q (1/2 + 3/16 * 1.8) = 0.84 q with balanced key words; eight terms on top of a fixed
         // accumulator stay below 7.2 q)
-        // TWB_REGS (with LOWREG && TW_LDS): the twiddles of phase B's last TWB_REGS stages are taken from the caller's registers
-        // (pre_b) instead of twb: a smaller LDS table (256 * (2^(4 - TWB_REGS) - 1) words) for 2 * (16 - 2^(4 - TWB_REGS)) VGPRs
-        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false, bool LEAN = false, int TWB_REGS = 0,
-                  bool WIDE = false>
+        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false, bool LEAN = false, bool WIDE = false>
         __device__ __forceinline__ void p2_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const typename Field<FP>::tw_t *twa, const typename Field<FP>::tw_t *twb, uint64_t *lds_wave, unsigned hg, unsigned tid,
@@ -443,11 +440,7 @@ namespace sealhip
             }
             else if constexpr (LOWREG && TW_LDS)
             {
-                auto twf = [&](int t, int g) {
-                    if (t >= 4 - TWB_REGS)
-                        return pre_b->get((1 << t) + g);
-                    return twb[((256u << t) - 256u) + g * 256 + tid];
-                };
+                auto twf = [&](int t, int g) { return twb[((256u << t) - 256u) + g * 256 + tid]; };
                 if constexpr (LEAN)
                     phase_fwd_fix<FP, 4, 2>(x, m, twf);
                 else
@@ -685,7 +678,7 @@ namespace sealhip
             else if constexpr (HOIST)
                 p2_tile<FP, D1, false, false, true>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid, &pre_a, &pre_b);
             else
-                p2_tile<FP, D1, false, false, false, false, false, 0, WIDE>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
+                p2_tile<FP, D1, false, false, false, false, false, WIDE>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
             uint64_t val[16];
             const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
             if ((HOIST || HOIST_LDS) || a.epi == 0) // the hoisted variants are launched for plain transforms only
@@ -1248,12 +1241,6 @@ namespace sealhip
 
         // The key-switch kernels of N = 2^16 (eight stages per pass) use the lean fix() placement of p1_tile / p2_tile (tile-order
         // intermediate only; the lane-order geometry keeps its own).  SEALHIP_KS_LEAN_OFF at build time restores five fix() per pair.
-        // ks2 (double-precision targets): phase B's twiddles of the last kKs2TwbRegs stages in registers, the rest in LDS
-#ifndef SEALHIP_KS2_TWB_REGS
-#define SEALHIP_KS2_TWB_REGS 0
-#endif
-        constexpr int kKs2TwbRegs = SEALHIP_KS2_TWB_REGS;
-        constexpr size_t kKs2TwbLdsWords = 256u * ((1u << (4 - kKs2TwbRegs)) - 1u);
 #ifdef SEALHIP_KS_LEAN_OFF
         template <int D1, int ORDER>
         constexpr bool kLeanKs = false;
@@ -1426,7 +1413,6 @@ namespace sealhip
 
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             const typename F::tw_t *twa = nullptr, *twb = nullptr;
-            TwRegs<FP> twr;
             if constexpr (!FP)
             {
                 // integer back end: phase A's 240 row-shared Shoup pairs (3.8 KiB) in LDS; phase B's stay in L2
@@ -1453,16 +1439,10 @@ namespace sealhip
                     la[tid] = tab[(1u << (D1 + t)) + ((hg * 16) << t) + r];
                 }
 #pragma unroll
-                for (int t = 0; t < 4 - kKs2TwbRegs; t++)
+                for (int t = 0; t < 4; t++)
 #pragma unroll
                     for (int g = 0; g < (1 << t); g++)
                         lb[((256u << t) - 256u) + g * 256 + tid] = tab[(1u << (D1 + 4 + t)) + ((hg * 256 + tid) << t) + g];
-                // the last kKs2TwbRegs stages' twiddles of this thread stay in registers for the whole digit loop
-#pragma unroll
-                for (int t = 4 - kKs2TwbRegs; t < 4; t++)
-#pragma unroll
-                    for (int g = 0; g < (1 << t); g++)
-                        twr.set((1 << t) + g, tab[(1u << (D1 + 4 + t)) + ((hg * 256 + tid) << t) + g]);
                 twa = la;
                 twb = lb;
                 __syncthreads();
@@ -1542,7 +1522,7 @@ namespace sealhip
                 }
                 if (!is_diag)
                 {
-                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1, 0>, FP ? kKs2TwbRegs : 0, WIDE>(x, m, tab, twa, twb, lds_wave, hg, tid, nullptr, &twr);
+                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1, 0>, WIDE>(x, m, tab, twa, twb, lds_wave, hg, tid);
                     if constexpr (!FP)
                     {
 #pragma unroll
@@ -1591,11 +1571,8 @@ namespace sealhip
         }
 
         // CLS: 0 integer-back-end targets only, 1 double-precision targets only
-#ifndef SEALHIP_KS2_FP_WAVES
-#define SEALHIP_KS2_FP_WAVES 2
-#endif
         template <int D1, int CLS>
-        __global__ void __launch_bounds__(kThreads, CLS == 1 ? SEALHIP_KS2_FP_WAVES : 2) ks2_kernel(Ks2Args a)
+        __global__ void __launch_bounds__(kThreads, 2) ks2_kernel(Ks2Args a)
         {
             typedef Geo<D1> G;
             HIP_DYNAMIC_SHARED(uint64_t, lds)
@@ -2102,7 +2079,7 @@ namespace sealhip
             const unsigned vbatch = batch * a1.parts; // (digit group, batch item) pairs
             const unsigned groups = vbatch * G::TILES;
             const unsigned n_fp = a1.ntargets - n_int;
-            const size_t l2_fp = kLds2Words * 8 + (240 + kKs2TwbLdsWords) * sizeof(double); // the tile's twiddles staged in LDS
+            const size_t l2_fp = kLds2Words * 8 + (240 + 3840) * sizeof(double); // the tile's twiddles staged in LDS
             if (n_fp && l2_fp > 65536)
             {
                 // more than the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU)
