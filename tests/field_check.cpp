@@ -72,6 +72,77 @@ int main()
         double B = 1.0;
         for (int s = 0; s < 4; s++) B = B + 0.5 + 0.375 * B;
         if (!(B < 8.0)) { printf("forward bound %.3f\n", B); fails++; }
+        // balanced tables (|w| <= q/2): B -> 1.1875 B + 0.5, seven stages from a fixed value stay below 8 q
+        B = 0.5;
+        for (int s = 0; s < 7; s++) B = 1.1875 * B + 0.5;
+        if (!(B < 8.0)) { printf("balanced forward bound %.3f\n", B); fails++; }
+    }
+    // balanced multiplier: |r| <= q (1/2 + 3/16 B) for |x| <= B q, |w| <= q/2 (the bound the lean key-switch placement uses)
+    for (uint64_t q : qs)
+    {
+        const double qd = (double)q, qinv = 1.0 / qd;
+        for (int it = 0; it < 200000; it++)
+        {
+            const double w = (double)(int64_t)(rng() % (q / 2 + 1)) * ((rng() & 1) ? 1.0 : -1.0);
+            const double Bq = (it & 1) ? 7.88 * qd : (double)(rng() % (8 * q));
+            const double x = std::floor(Bq) * ((rng() & 2) ? 1.0 : -1.0);
+            if (std::fabs(x) >= 9007199254740992.0)
+                continue;
+            const double r = fp_mulmod(x, w, qd, qinv);
+            EXPECT(canon((i128)r, q) == canon((i128)x * (i128)w, q), "balanced mulmod residue");
+            EXPECT(std::fabs(r) <= qd * (0.5 + 0.1875 * std::fabs(x) / qd) + 2.0, "balanced mulmod magnitude %.1f (x %.1f q %.1f)", std::fabs(r), x, qd);
+        }
+    }
+    // ---- integer back end: fwd_fix() and the unguarded forward butterflies (field.h, Field<false>)
+    {
+        typedef Field<false> F;
+        const uint64_t iq[] = { (1ull << 60) - (1ull << 18) + 1, (1ull << 59) + (1ull << 17) + 1, 1152921504606830593ull /* SEAL's first 60-bit prime */,
+                                (1ull << 55) - (1ull << 17) * 5 + 1, (1ull << 50) + (1ull << 17) + 1, (1ull << 40) + (1ull << 17) * 7 + 1,
+                                (1ull << 33) + (1ull << 17) + 1, (1ull << 30) - (1ull << 17) + 1, (1ull << 20) + 1, 786433ull, 65537ull };
+        for (uint64_t q : iq)
+        {
+            const u128 ratio = (((u128)1 << 127) / q) * 2 + ((((u128)1 << 127) % q) * 2 >= q ? 1 : 0); // floor(2^128 / q)
+            ModDesc md{ q, 2 * q, (uint64_t)ratio, (uint64_t)(ratio >> 64) };
+            EXPECT((u128)md.ratio_hi * q <= (((u128)1) << 64) - 1 + q, "ratio");
+            const F::Mod m = F::make_mod(md, FpDesc{});
+            const u128 lim = (u128)16 * q < ((u128)1 << 64) ? (u128)16 * q : ((u128)1 << 64);
+            for (int it = 0; it < 300000; it++)
+            {
+                uint64_t x;
+                switch (it % 6)
+                {
+                case 0: x = (uint64_t)(lim - 1 - (rng() & 1023)); break;          // just below 16 q
+                case 1: x = rng() % (4 * q); break;
+                case 2: x = 2 * q * (1 + rng() % 7) - (rng() & 3); break;         // around the multiples of 2q
+                case 3: x = 2 * q * (rng() % 8) + (rng() & 3); break;
+                case 4: x = (uint64_t)(rng() & 0xffffffffull); break;
+                default: x = (uint64_t)((u128)rng() % lim); break;
+                }
+                if ((u128)x >= lim)
+                    continue;
+                uint64_t y = x;
+                F::fwd_fix(y, m);
+                EXPECT(y < 4 * q, "fwd_fix range q=%llu x=%llu -> %llu", (unsigned long long)q, (unsigned long long)x, (unsigned long long)y);
+                EXPECT(y % q == x % q, "fwd_fix residue q=%llu x=%llu", (unsigned long long)q, (unsigned long long)x);
+            }
+            // four unguarded stages from [0, 4q) stay below 12 q and keep the residues of the guarded butterfly
+            for (int it = 0; it < 100000; it++)
+            {
+                uint64_t X = (it & 1) ? 4 * q - 1 - (rng() & 7) : rng() % (4 * q), Y = (it & 2) ? 4 * q - 1 - (rng() & 7) : rng() % (4 * q);
+                uint64_t Xg = X, Yg = Y;
+                for (int sgl = 0; sgl < 4; sgl++)
+                {
+                    const uint64_t w = rng() % q;
+                    const ShoupOp tw{ w, (uint64_t)((((u128)w) << 64) / q) };
+                    F::bfly_fwd(X, Y, tw, m);
+                    F::bfly_fwd_guarded(Xg, Yg, tw, m);
+                    EXPECT((u128)X < (u128)(6 + 2 * sgl) * q && (u128)Y < (u128)(6 + 2 * sgl) * q, "unguarded growth");
+                    EXPECT(X % q == Xg % q && Y % q == Yg % q, "unguarded residue");
+                    std::swap(X, Y); // let both outputs take both roles
+                    std::swap(Xg, Yg);
+                }
+            }
+        }
     }
     if (fails) { printf("%d failures\n", fails); return 1; }
     printf("field_check ok\n");

@@ -73,3 +73,21 @@ def test_bench_gpus_2_starts_two_ranks(emu, workload):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stdout + bad.stderr)
+
+
+@pytest.mark.parametrize("workload", ["headline", "bfv_c4"])
+def test_bench_streams_divides_the_batch(emu, workload):
+    """`bench.py --streams 2`: two evaluators on two streams, each with half of the rank's batch; the sampled items of the
+    joined output are still the reference's (emulated kernels)."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SEALHIP_BENCH_EMU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--streams", "2", "--steps", "1", "--warmup", "1", "--batch", "5",
+                          "--workload", workload, "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "2 evaluators" in line["config"]["launch"] and line["value"] > 0
+    import sealref
+    if sealref.available():
+        assert line["verified_items"] >= 2
