@@ -206,8 +206,8 @@ namespace sealhip
         // a 64-bit word holds 16 q, mul_lazy() takes any 64-bit Y, so X, Y in [0, B q) -> [0, (B + 2) q) and a run of stages only
         // needs B + 2 * stages <= 16; fwd_fix() brings everything back under 4 q once per run (p1_tile / p2_tile: after each
         // phase of at most four stages, 4 -> 12).  The residues are the same as with the reference's ranges; outputs leave
-        // through fwd_to_canon / fwd_to_lazy from [0, 4q) as before.  Moduli of 2^60 and above (SEAL allows 61 bits: user
-        // primes, the BEHZ auxiliary base) take bfly_fwd_guarded instead (wide_modulus() / phase_fwd_end in ntt2_kernels.hip:
+        // through fwd_to_canon / fwd_to_lazy from [0, 4q) as before.  Moduli of 2^60 and above (SEAL's internal moduli have
+        // 61 bits - the BEHZ auxiliary base; user primes have at most 60, defines.h:33-40) take bfly_fwd_guarded instead (wide_modulus() / phase_fwd_end in ntt2_kernels.hip:
         // one wave-uniform branch at the top of each kernel).
         static SHL_HD void bfly_fwd(elem &X, elem &Y, const tw_t &w, const Mod &m)
         {

@@ -70,7 +70,7 @@ namespace sealhip
             return v2;
         }
 
-        // moduli of 2^60 and above (SEAL allows 61 bits) keep the reference's guarded forward butterflies (field.h); wave-uniform
+        // moduli of 2^60 and above (SEAL's 61-bit internal moduli: the BEHZ auxiliary base) keep the reference's guarded forward butterflies (field.h); wave-uniform
         __device__ __forceinline__ bool wide_modulus(const NttTables &t, unsigned prime)
         {
             return (SHL_UCONST(reinterpret_cast<const uint64_t *>(&t.mods[prime]))[0] >> 60) != 0;
@@ -122,8 +122,8 @@ namespace sealhip
 
         // A phase and the reduction that ends it.  Double precision: fix() of all 16 values when FIX.  Integer back end: for
         // q < 2^60 the unguarded butterflies of field.h (+ 2 q per stage) and, when FIX, fwd_fix() back under 4 q; for the wider
-        // moduli SEAL allows (up to 61 bits: user primes, the BEHZ auxiliary base) the reference's guarded butterflies, which
-        // keep [0, 4q) by themselves (WIDE).  One modulus per workgroup: the kernels branch once, at the top (int_body()).
+        // moduli SEAL uses internally (61 bits: the BEHZ auxiliary base) the reference's guarded butterflies, which
+        // keep [0, 4q) by themselves (WIDE).  One modulus per workgroup: the kernels branch once, at the top (wide_modulus()).
         template <bool FP, int R, bool FIX, bool WIDE, class TwFn>
         __device__ __forceinline__ void phase_fwd_end(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {

@@ -23,6 +23,8 @@ def test_ntt_all_plans(emu, n, bits):
 # two-pass engine (ntt2_kernels.hip): every D1 geometry, both arithmetic back ends in one context
 @pytest.mark.parametrize("n,bits", [
     (8192, [50, 30, 60]), (8192, [20, 25]), (16384, [50, 50, 45, 60]), (32768, [40, 50]), (65536, [50, 60, 36]),
+    # integer back end, unguarded butterflies (field.h): 51 .. 60-bit user moduli (the 61-bit BEHZ base of the BFV cases is guarded)
+    (8192, [60, 59, 58]), (16384, [58, 60]), (32768, [60, 55]), (65536, [60, 59, 51]),
 ])
 def test_ntt_two_pass_engine_mixed_primes(emu, n, bits):
     P.case_ntt(n, bits, polys=2)

@@ -32,6 +32,8 @@ def test_native_library_is_the_one_loaded(gpu):
     (1024, [50, 60], 2), (2048, [60], 3), (4096, [36, 36, 37], 4),
     (8192, [60, 40, 40, 60], 6),            # BASELINE configs[1]
     (16384, [60, 50, 50], 3), (32768, [55, 55], 2), (65536, [60, 50, 60], 2), (131072, [60], 1),
+    # integer back end, unguarded butterflies: user moduli of 51 .. 60 bits in the two-pass engine
+    (8192, [60, 59, 58], 5), (16384, [58, 60], 3), (32768, [60, 55, 52], 2), (65536, [60, 59, 51], 2),
 ])
 def test_ntt(gpu, n, bits, polys):
     P.case_ntt(n, bits, polys=polys)
