@@ -31,6 +31,8 @@ GROUPS = [
     ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"],
     ["SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
     ["GRBM_GUI_ACTIVE"],
+    ["SQ_WAVE_CYCLES", "SQ_WAIT_INST_LDS", "SQ_INST_LEVEL_LDS", "SQ_INST_LEVEL_VMEM", "SQ_IFETCH", "SQ_IFETCH_LEVEL", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC"],
+    ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_FLAT", "SQ_LDS_CMD_FIFO_FULL", "SQ_LDS_DATA_FIFO_FULL", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_UNALIGNED_STALL", "SQ_INST_CYCLES_VMEM_RD"],
 ]
 CALLS = 3  # bench.py: PMC_CALLS
 
