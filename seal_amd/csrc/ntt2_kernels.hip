@@ -1523,7 +1523,9 @@ namespace sealhip
                 if (!is_diag)
                 {
                     p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1, 0>, WIDE>(x, m, tab, twa, twb, lds_wave, hg, tid);
-                    if constexpr (!FP)
+                    // integer back end: 128-bit sums of x * key.  q < 2^60: x < 4 q < 2^62 and key < 2^60 give terms below 2^122,
+                    // and SEAL's 64 moduli at most (63 digits) stay below 2^128 - no need to canonicalise x; 61-bit moduli do
+                    if constexpr (!FP && WIDE)
                     {
 #pragma unroll
                         for (int e = 0; e < 16; e++)
