@@ -27,8 +27,9 @@
 // Only canonical residues in [0,q) ever leave a kernel, so results are bit-identical to the
 // integer path and to the reference: the representation is internal.
 //
-// IntField is the general path (any q < 2^61) and follows the reference's lazy ranges:
-// forward values in [0,4q), inverse values in [0,2q).
+// IntField is the general path (any q < 2^61).  Values between kernels and phases are in the reference's lazy
+// ranges - forward [0,4q), inverse [0,2q) -; inside a forward phase moduli below 2^60 run unguarded up to 16 q
+// (bfly_fwd / fwd_fix below), 61-bit moduli keep the reference's guard per butterfly.
 #pragma once
 #include "modarith.h"
 #if defined(SEALHIP_CHECK_BOUNDS)
