@@ -5,7 +5,7 @@ import fuzz_cases as F, test_fuzz as T
 S.load()
 ok = rej = 0
 fails = []
-for seed in range(100, 112):
+for seed in range(int(os.environ.get("FUZZ_SEED0", "100")), int(os.environ.get("FUZZ_SEED0", "100")) + int(os.environ.get("FUZZ_SEEDS", "12"))):
     for cfg in T._configs(seed, 30, [16, 128, 1024, 4096, 8192, 16384, 32768, 65536]):
         if cfg[1] >= 32768 and len(cfg[2]) > 4:
             cfg = cfg[:2] + (cfg[2][:4],) + cfg[3:]
