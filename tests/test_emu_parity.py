@@ -54,6 +54,7 @@ def test_ntt_two_pass_engine_mixed_kernel(emu, monkeypatch):
     (8192, [50, 40, 60, 50], 2, (1,)),
     (8192, [60, 40, 40, 60], 1, (-1,)),
     (16384, [60, 50, 50, 60], 1, (1,)),
+    (8192, [60] + [30, 40, 50, 45, 36] * 4 + [60], 1, (1,)),   # 22 primes of unequal sizes: 21 digits, both classes interleaved
 ])
 def test_ckks_pipeline_engine_sizes(emu, n, bits, batch, steps):
     P.case_ckks_pipeline(n, bits, batch=batch, steps=steps)

@@ -82,6 +82,17 @@ def test_ckks_pipeline(gpu, n, bits, batch, steps):
     P.case_ckks_pipeline(n, bits, batch=batch, steps=steps)
 
 
+@pytest.mark.parametrize("n,bits", [
+    (8192, [60] + [30, 40, 50, 45, 36] * 4 + [60]),           # 22 primes, mixed sizes: 21 digits, both arithmetic classes interleaved
+    (16384, [60] + [50, 40, 48, 36, 44, 58] * 5 + [60]),      # 32 primes incl. 58-bit ones: 31 digits (sums fixed every 8 terms, 4 times)
+    (65536, [55] + [45, 50] * 9 + [59]),                      # N = 2^16 with the lean placement on unequal prime sizes, 20 primes
+])
+def test_ckks_long_mixed_chains(gpu, n, bits):
+    """long coefficient-modulus chains with unequal prime sizes: digits from larger primes raised to smaller target moduli, many
+    terms per key-switch sum, integer and double-precision targets interleaved (evaluator.cpp:2561-2867)"""
+    P.case_ckks_pipeline(n, bits, batch=1, steps=(1,), check_transforms=n <= 16384)
+
+
 def test_ckks_north_star_config(gpu):
     """BASELINE configs[4] / north-star: CKKS N=65536, L=16 ({60, 14x50, 60}): multiply + relinearize +
     rescale_to_next, then rotate_vector(1) + mod_switch, batch of 2, bit-exact."""
