@@ -113,7 +113,7 @@ namespace sealhip
     // any 64-bit x -> value congruent to x mod q with magnitude < q + 2^32
     SHL_HD double fp_from_u64(uint64_t x, const FpDesc &m)
     {
-        double hi = fp_from_u52(x >> 32), lo = fp_from_u52(x & 0xffffffffull);
+        double hi = (double)(uint32_t)(x >> 32), lo = (double)(uint32_t)x; // v_cvt_f64_u32: exact, one instruction each
         return fp_mulmod(hi, m.two32, m.q, m.qinv) + lo;
     }
     // |x| < q (integer-valued) -> canonical residue in [0,q) as an integer
