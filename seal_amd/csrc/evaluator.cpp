@@ -1,5 +1,6 @@
 #include "evaluator.h"
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
@@ -105,8 +106,27 @@ namespace sealhip
     {
         release();
     }
+    void Ciphertext::settle() const
+    {
+        if (!lazy_)
+            return;
+        const LazyTail t = *lazy_;
+        delete lazy_;
+        lazy_ = nullptr;
+        t.owner->complete_tail(const_cast<Ciphertext &>(*this), t);
+    }
+    void Ciphertext::drop_lazy()
+    {
+        if (!lazy_)
+            return;
+        const LazyTail t = *lazy_;
+        delete lazy_;
+        lazy_ = nullptr;
+        t.owner->forget_tail(*this, t);
+    }
     void Ciphertext::release()
     {
+        drop_lazy();
         DevicePool::global().free_words(data_);
         data_ = nullptr;
         capacity_words_ = 0;
@@ -121,6 +141,8 @@ namespace sealhip
     {
         if (this == &o)
             return *this;
+        o.settle();  // the source's words are read below
+        drop_lazy(); // this object's words are replaced
         if (ctx_ != o.ctx_ || batch_ != o.batch_)
         {
             release();
@@ -152,6 +174,10 @@ namespace sealhip
         size_t pw = batch_ * level->K * ctx_->n();
         size_t need = size * pw;
         bool same_level = (level == level_);
+        // a deferred key-switch tail works on the first two polynomials in place: dropping trailing ones at the same level
+        // (relinearize: 3 -> 2) leaves it alone, anything else completes it first
+        if (lazy_ && !(same_level && size >= 2 && size <= size_))
+            settle();
         size_t keep = same_level ? std::min(size_, size) * pw : 0;
         if (need > capacity_words_)
         {
@@ -169,6 +195,7 @@ namespace sealhip
     }
     void Ciphertext::reshape_uninitialized(const Level *level, size_t size)
     {
+        drop_lazy();
         size_t need = size * batch_ * level->K * ctx_->n();
         if (need > capacity_words_)
         {
@@ -181,6 +208,7 @@ namespace sealhip
     }
     void Ciphertext::adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words)
     {
+        drop_lazy();
         DevicePool::global().free_words(data_);
         data_ = slab;
         capacity_words_ = capacity_words;
@@ -330,8 +358,80 @@ namespace sealhip
         ck(hipMalloc(&p, sizeof(unsigned)), "hipMalloc flag");
         d_flag_ = (unsigned *)p;
     }
+    // ---- deferred key-switch tails (LazyTail, evaluator.h)
+    void Evaluator::defer_tail(Ciphertext &e, uint64_t *acc) const
+    {
+        e.lazy_ = new LazyTail{ this, acc };
+        std::lock_guard<std::mutex> lock(lazy_mu_);
+        lazy_cts_.push_back(&e);
+    }
+    LazyTail Evaluator::detach_tail(Ciphertext &e) const
+    {
+        const LazyTail t = *e.lazy_;
+        delete e.lazy_;
+        e.lazy_ = nullptr;
+        std::lock_guard<std::mutex> lock(lazy_mu_);
+        lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &e), lazy_cts_.end());
+        return t;
+    }
+    void Evaluator::forget_tail(const Ciphertext &e, LazyTail t) const
+    {
+        {
+            std::lock_guard<std::mutex> lock(lazy_mu_);
+            lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &e), lazy_cts_.end());
+        }
+        DevicePool::global().free_words(t.acc, stream_);
+    }
+    void Evaluator::complete_tail(Ciphertext &e, LazyTail t) const
+    {
+        {
+            std::lock_guard<std::mutex> lock(lazy_mu_);
+            lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &e), lazy_cts_.end());
+        }
+        // the sums were produced on this evaluator's stream: the tail runs there too; a caller working on another stream
+        // (another evaluator, a host copy) continues only when it is done
+        const hipStream_t caller = DevicePool::thread_stream();
+        static const bool trace = std::getenv("SEALHIP_KS_TRACE") != nullptr; // tests: which tail ran
+        if (trace)
+            std::fprintf(stderr, "[ks] plain tail\n");
+        try
+        {
+            StreamScope scope(stream_);
+            switch_key_finish(e, t.acc, 1);
+        }
+        catch (...)
+        {
+            DevicePool::global().free_words(t.acc, stream_);
+            throw;
+        }
+        DevicePool::global().free_words(t.acc, stream_);
+        if (caller != stream_)
+            ck(hipStreamSynchronize(stream_), "deferred key-switch tail");
+    }
+    void Evaluator::settle_all() const
+    {
+        for (;;)
+        {
+            const Ciphertext *c = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(lazy_mu_);
+                if (lazy_cts_.empty())
+                    return;
+                c = lazy_cts_.back();
+            }
+            c->settle(); // removes it from the list
+        }
+    }
+
     Evaluator::~Evaluator()
     {
+        try
+        {
+            settle_all();
+        }
+        catch (...)
+        {
+        }
         for (auto &kv : ks_maps_)
             (void)hipFree(kv.second);
         for (auto &kv : ks_targets_)
@@ -364,6 +464,7 @@ namespace sealhip
             throw std::logic_error("a capture is already in progress");
         if (transparent_check_)
             throw std::logic_error("the transparent-ciphertext check reads device memory back and cannot be captured");
+        settle_all(); // deferred tails hold pool blocks of their own: complete them before the recording starts
         if (!capture_stream_)
             ck(hipStreamCreateWithFlags(&capture_stream_, hipStreamNonBlocking), "capture stream");
         // drain the device: every cached pool block is idle from here on, and the recording takes its scratch only from
@@ -543,7 +644,7 @@ namespace sealhip
                 ok = ok && !(cf == 0 || cf >= context_.plain_modulus());
             else
                 ok = ok && cf == 1;
-            ok = ok && (ct.word_count() == 0 || ct.data() != nullptr);
+            ok = ok && (ct.word_count() == 0 || ct.has_storage());
         }
         if (!ok)
             throw std::invalid_argument(std::string(what) + " is not valid for encryption parameters");
@@ -1540,7 +1641,111 @@ namespace sealhip
             ck(k_keyswitch_reduce(context_.dev_mods(), acc.p, (unsigned)context_.log_n(), K, context_.key_level().K, (unsigned)e.batch(),
                                   stream_, split),
                "ks add digit groups");
-        switch_key_finish(e, acc.p, 1);
+        // CKKS at the two-pass sizes: leave the mod-down to whoever touches the ciphertext next (LazyTail) - a rescale on this
+        // evaluator then does both rounding divisions with one transform per component.  SEALHIP_KS_EAGER_TAIL=1: always now.
+        static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
+        if (lazy_ok && !capturing_ && context_.scheme() == Scheme::ckks && ntt2_supports(context_.log_n()) && K >= 2)
+            defer_tail(e, acc.release());
+        else
+            switch_key_finish(e, acc.p, 1);
+    }
+
+    // relinearize (or a rotation) followed by rescale_to_next: acc = the key-switch sums, planes 0 and 1 of e = the addends.
+    // Reference steps being folded: evaluator.cpp:2806-2864 (mod-down by the special prime P), then rns.cpp:830-901 on the result
+    // (divide_and_round_q_last_ntt_inplace); see NttTail2 (ntt_kernels.h) for the algebra.
+    void Evaluator::switch_key_finish_rescale(Ciphertext &e, uint64_t *acc_p, const Level *next, double destination_scale) const
+    {
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K;
+        const size_t N = context_.n();
+        const unsigned B = (unsigned)e.batch();
+        const NttTables &tb = context_.ntt_tables();
+        const uint64_t P = context_.coeff_modulus()[L - 1];
+        uint64_t *c0 = e.data_, *c1 = e.data_ + (size_t)B * K * N; // no deferred tail left on e: the caller detached it
+        static const bool trace = std::getenv("SEALHIP_KS_TRACE") != nullptr;
+        if (trace)
+            std::fprintf(stderr, "[ks] folded tail\n");
+
+        // t_P: coefficient form of the special-prime sums, in place (component K of every (item, plane) of acc)
+        NttBatch bi = plain_batch(acc_p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
+        ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
+
+        // the relinearised ciphertext's LAST component (the one rescale divides by), completed alone: c += (S - NTT(v)) P^-1
+        {
+            NttBatch b{};
+            b.data = nullptr;
+            b.outer_stride = N;
+            b.ncomp = 1;
+            b.nouter = 2 * B;
+            b.comp_prime = nullptr;
+            b.prime_first = K - 1;
+            b.src = acc_p + (size_t)K * N;
+            b.src_outer_stride = (size_t)(K + 1) * N;
+            b.src_ncomp = 1;
+            b.src_mode = 2;
+            b.src_half = P >> 1;
+            b.src_q = P;
+            b.src_fix = klvl.dev.round_fix + (K - 1);
+            b.epi = 2;
+            b.epi_a = acc_p + (size_t)(K - 1) * N;
+            b.epi_a_stride = (size_t)(K + 1) * N;
+            b.epi_mul = klvl.dev.inv_q_last_mod_q + (K - 1);
+            b.epi_out0 = c0 + (size_t)(K - 1) * N;
+            b.epi_out1 = c1 + (size_t)(K - 1) * N;
+            b.epi_out_stride = (size_t)K * N;
+            ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction + tail, last component");
+        }
+        // t_last: its coefficient form, in place (that component is dropped by the rescale)
+        ck(ntt_inverse(tb, plain_batch(c0 + (size_t)(K - 1) * N, (size_t)K * N, 1, 2 * B, K - 1), 0, stream_), "rescale intt last");
+
+        // components 0 .. K-2: out = (c + S P^-1 - NTT(v P^-1 + u)) q_last^-1, one transform each
+        const size_t words = (size_t)2 * B * (K - 1) * N;
+        uint64_t *out = DevicePool::global().alloc_words(words);
+        try
+        {
+            NttTail2 t2{};
+            t2.src2_0 = c0 + (size_t)(K - 1) * N;
+            t2.src2_1 = c1 + (size_t)(K - 1) * N;
+            t2.src2_stride = (size_t)K * N;
+            t2.src2_half = lvl.dev.half_q_last;
+            t2.src2_q = lvl.dev.q_last;
+            t2.src2_fix = lvl.dev.round_fix;
+            t2.pmul = klvl.dev.inv_q_last_mod_q;
+            t2.c0 = c0;
+            t2.c1 = c1;
+            t2.c_stride = (size_t)K * N;
+            NttBatch b{};
+            b.data = nullptr;
+            b.outer_stride = (size_t)(K - 1) * N;
+            b.ncomp = K - 1;
+            b.nouter = 2 * B;
+            b.comp_prime = nullptr;
+            b.prime_first = 0;
+            b.src = acc_p + (size_t)K * N;
+            b.src_outer_stride = (size_t)(K + 1) * N;
+            b.src_ncomp = 1;
+            b.src_mode = 2;
+            b.src_half = P >> 1;
+            b.src_q = P;
+            b.src_fix = klvl.dev.round_fix;
+            b.epi = 0;
+            b.epi_a = acc_p;
+            b.epi_a_stride = (size_t)(K + 1) * N;
+            b.epi_mul = lvl.dev.inv_q_last_mod_q;
+            b.epi_out0 = out;
+            b.epi_out1 = out + (size_t)B * (K - 1) * N;
+            b.epi_out_stride = (size_t)(K - 1) * N;
+            b.tail2 = &t2;
+            ck(ntt_forward(tb, b, 1, stream_), "mod-down + rescale in one transform");
+        }
+        catch (...)
+        {
+            DevicePool::global().free_words(out);
+            throw;
+        }
+        e.adopt(next, 2, out, words);
+        e.scale() = destination_scale;
     }
 
     // ---- digit-parallel key switching over the ranks of a communicator (the reference loop being split:
@@ -1789,6 +1994,23 @@ namespace sealhip
         }
         const unsigned K = lvl.K;
         const size_t N = context_.n();
+        if (scheme == Scheme::ckks && e.lazy_ && e.lazy_->owner == this && e.size() == 2 && K >= 2 && !capturing_ &&
+            ntt2_supports(context_.log_n()))
+        {
+            // the key switch that produced e left its mod-down undone (LazyTail): both rounding divisions in one pass
+            const LazyTail t = detach_tail(e);
+            try
+            {
+                switch_key_finish_rescale(e, t.acc, next, destination_scale);
+            }
+            catch (...)
+            {
+                DevicePool::global().free_words(t.acc, stream_);
+                throw;
+            }
+            DevicePool::global().free_words(t.acc, stream_);
+            return;
+        }
         const size_t items = e.size() * e.batch();
         const unsigned n_log = (unsigned)context_.log_n();
         const ModDesc *mods = context_.dev_mods();

@@ -19,6 +19,17 @@
 namespace sealhip
 {
     // A batch of `batch` ciphertexts sharing metadata; slab layout [poly][batch][K][N].
+    class Evaluator;
+    // A key-switch tail that has not run yet (Evaluator::switch_key_inplace, CKKS at the two-pass sizes): the two planes of the
+    // ciphertext still hold the addends, `acc` the key-switch sums [batch][2][K+1][N].  Whoever touches the words next completes
+    // it - except rescale_to_next_inplace on the same evaluator, which folds the mod-down and its own division into one pass
+    // (ntt_kernels.h: NttTail2).  Results are the same words either way.
+    struct LazyTail
+    {
+        const Evaluator *owner;
+        uint64_t *acc;
+    };
+
     class Ciphertext
     {
     public:
@@ -39,12 +50,23 @@ namespace sealhip
         double scale() const { return scale_; }
         uint64_t &correction_factor() { return correction_factor_; }
         uint64_t correction_factor() const { return correction_factor_; }
-        uint64_t *data() { return data_; }
-        const uint64_t *data() const { return data_; }
+        // every access to the words completes a deferred key-switch tail first (LazyTail)
+        uint64_t *data()
+        {
+            settle();
+            return data_;
+        }
+        const uint64_t *data() const
+        {
+            settle();
+            return data_;
+        }
         size_t plane_words() const { return level_ ? batch_ * level_->K * ctx_->n() : 0; }
         size_t word_count() const { return size_ * plane_words(); }
-        uint64_t *plane(size_t p) { return data_ + p * plane_words(); }
-        const uint64_t *plane(size_t p) const { return data_ + p * plane_words(); }
+        uint64_t *plane(size_t p) { return data() + p * plane_words(); }
+        const uint64_t *plane(size_t p) const { return data() + p * plane_words(); }
+        bool has_lazy_tail() const { return lazy_ != nullptr; }
+        bool has_storage() const { return data_ != nullptr; } // a question about the buffer, not about its words
 
         // Ciphertext::resize(context, parms_id, size) (ciphertext.cpp:101-116): keeps the leading
         // polynomials when only `size` changes at the same level; contents are unspecified after a
@@ -66,6 +88,11 @@ namespace sealhip
         uint64_t correction_factor_ = 1;
         uint64_t *data_ = nullptr;
         size_t capacity_words_ = 0;
+        // deferred key-switch tail (owned; see LazyTail)
+        mutable LazyTail *lazy_ = nullptr;
+        void settle() const; // run it now
+        void drop_lazy();    // the words are about to be replaced: discard it
+        friend class Evaluator;
     };
 
     // seal::Plaintext (plaintext.h) resident in HBM: either coeff_count <= N coefficients modulo t (BFV/BGV,
@@ -295,6 +322,18 @@ namespace sealhip
         bool transparent_check_ = false;
         // lazily built per-level tables; guarded so that concurrent calls on different ciphertexts stay safe, as with the
         // reference's Evaluator (evaluator.h:79-87: the class holds only immutable state)
+        // ciphertexts whose key-switch tail this evaluator deferred (LazyTail): completed before the evaluator goes away or starts
+        // recording a graph
+        friend class Ciphertext;
+        void defer_tail(Ciphertext &e, uint64_t *acc) const;
+        void complete_tail(Ciphertext &e, LazyTail t) const;     // the plain mod-down, then the sums go back to the pool
+        void forget_tail(const Ciphertext &e, LazyTail t) const; // discard
+        LazyTail detach_tail(Ciphertext &e) const;
+        void settle_all() const;
+        // mod-down by the special prime and rescale by q_last in one pass (NttTail2); e has two polynomials and a deferred tail
+        void switch_key_finish_rescale(Ciphertext &e, uint64_t *acc, const Level *next, double destination_scale) const;
+        mutable std::mutex lazy_mu_;
+        mutable std::vector<const Ciphertext *> lazy_cts_;
         mutable std::mutex cache_mu_;
         mutable std::map<unsigned, uint32_t *> ks_maps_;
         mutable std::map<unsigned, KsTargets> ks_targets_;

@@ -739,6 +739,154 @@ namespace sealhip
         }
 
         // ---------------------------------------------------------------------------------------
+        // NttTail2 (ntt_kernels.h): two rounding divisions in one transform.  Separate kernels so that the plain passes above
+        // keep their register budgets.  Pass 1 maps two sources into the target modulus, x = v P^-1 + u; pass 2's tail computes
+        // out = (c + S P^-1 - NTT(x)) q_last^-1.
+        // ---------------------------------------------------------------------------------------
+        struct Tail2Args
+        {
+            FwdArgs f;
+            NttTail2 x;
+        };
+
+        template <bool FP, int D1, bool WIDE>
+        __device__ __forceinline__ void tail2_p1_body(const Tail2Args &t2, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            const FwdArgs &a = t2.f;
+            const unsigned tid = threadIdx.x, cg = blockIdx.x;
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
+            const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
+            const SrcMap s1{ 2, a.src_half, a.src_q, a.src_fix[comp] }, s2{ 2, t2.x.src2_half, t2.x.src2_q, t2.x.src2_fix[comp] };
+            const ShoupOp pm = t2.x.pmul[comp];
+            const uint64_t q = a.t.mods[prime].q;
+            const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
+            const size_t col = (size_t)cg * G::C + c;
+            TwRegs<FP> tw;
+            p1_load_tw<FP, D1>(tw, tab, tid);
+            const unsigned ostride = gridDim.z;
+            for (; outer < a.nouter; outer += ostride)
+            {
+                const uint64_t *in1 = a.src + (size_t)outer * a.src_outer_stride + col;
+                const uint64_t *in2 = ((outer & 1) ? t2.x.src2_1 : t2.x.src2_0) + (size_t)(outer >> 1) * t2.x.src2_stride + col;
+                uint64_t n1[16], n2[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                    const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+                    n1[e] = in1[(size_t)R * 256];
+                    n2[e] = in2[(size_t)R * 256];
+                }
+                typename F::elem x[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    const typename F::elem v = map_src<FP>(n1[e], s1, m), u = map_src<FP>(n2[e], s2, m);
+                    if constexpr (FP)
+                    {
+                        const double pinv = pm.w > q / 2 ? -(double)(q - pm.w) : (double)pm.w; // balanced, exact below 2^50
+                        x[e] = fp_mulmod(v, pinv, m.q, m.qinv) + u; // |v|, |u| <= q/2: |x| <= 1.1 q
+                        F::fix(x[e], m);
+                    }
+                    else
+                        x[e] = mul_shoup(v, pm.w, pm.wq, q) + u; // below q + 2q: inside the forward input range [0, 4q)
+                }
+                uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
+                p1_tile<FP, D1, 256, 0, false, WIDE>(x, m, tab, tw, lds, mid_tr, cg, tid);
+            }
+        }
+
+        template <bool FP, int D1, bool WIDE>
+        __device__ __forceinline__ void tail2_p2_body(const Tail2Args &t2, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            const FwdArgs &a = t2.f;
+            const unsigned tid = threadIdx.x, hg = blockIdx.x;
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
+            const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
+            const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + tid;
+            uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
+            const uint64_t q = a.t.mods[prime].q;
+            const ShoupOp mul = a.epi_mul[comp], pm = t2.x.pmul[comp];
+            const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+            uint64_t nxt[16];
+            auto fetch = [&](unsigned z) {
+                const uint64_t *mp = mid0 + (((size_t)z * a.ncomp) << G::n);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    nxt[e] = mp[e * 256];
+            };
+            const unsigned ostride = gridDim.z;
+            fetch(outer);
+            for (; outer < a.nouter; outer += ostride)
+            {
+                typename F::elem x[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    x[e] = F::unraw(nxt[e]);
+                if (outer + ostride < a.nouter)
+                    fetch(outer + ostride);
+                p2_tile<FP, D1, false, false, false, false, false, WIDE>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
+                uint64_t val[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    val[e] = F::fwd_to_lazy(x[e], m); // < 4q
+                const uint64_t *A = a.epi_a + (size_t)outer * a.epi_a_stride + row0;
+                const uint64_t *C = ((outer & 1) ? t2.x.c1 : t2.x.c0) + (size_t)(outer >> 1) * t2.x.c_stride + row0;
+                uint64_t *O = ((outer & 1) ? a.epi_out1 : a.epi_out0) + (size_t)(outer >> 1) * a.epi_out_stride + row0;
+                emit_rows(val, lds_wave, tid, [&](unsigned off, uint64_t tv) {
+                    const uint64_t s = add_mod(mul_shoup(A[off], pm.w, pm.wq, q), C[off], q); // c + S P^-1, canonical
+                    O[off] = mul_shoup(s + 4 * q - tv, mul.w, mul.wq, q);
+                });
+            }
+        }
+
+        // CLS as ntt2_fwd_p1 / ntt2_fwd_p2
+        template <int D1, int CLS>
+        __global__ void __launch_bounds__(kThreads, 2) ntt2_tail2_p1(Tail2Args a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y + a.f.comp0, outer = blockIdx.z;
+            const unsigned prime = SHL_UNIFORM(a.f.prime_first + comp);
+            if constexpr (CLS == 1)
+                tail2_p1_body<true, D1, false>(a, prime, comp, outer, lds);
+            else if constexpr (CLS == 0)
+            {
+                if (wide_modulus(a.f.t, prime))
+                    tail2_p1_body<false, D1, true>(a, prime, comp, outer, lds);
+                else
+                    tail2_p1_body<false, D1, false>(a, prime, comp, outer, lds);
+            }
+            else if (a.f.t.fpd[prime].qi)
+                tail2_p1_body<true, D1, false>(a, prime, comp, outer, lds);
+            else
+                tail2_p1_body<false, D1, true>(a, prime, comp, outer, lds);
+        }
+        template <int D1, int CLS>
+        __global__ void __launch_bounds__(kThreads, 2) ntt2_tail2_p2(Tail2Args a)
+        {
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned comp = blockIdx.y + a.f.comp0, outer = blockIdx.z;
+            const unsigned prime = SHL_UNIFORM(a.f.prime_first + comp);
+            if constexpr (CLS == 1)
+                tail2_p2_body<true, D1, false>(a, prime, comp, outer, lds);
+            else if constexpr (CLS == 0)
+            {
+                if (wide_modulus(a.f.t, prime))
+                    tail2_p2_body<false, D1, true>(a, prime, comp, outer, lds);
+                else
+                    tail2_p2_body<false, D1, false>(a, prime, comp, outer, lds);
+            }
+            else if (a.f.t.fpd[prime].qi)
+                tail2_p2_body<true, D1, false>(a, prime, comp, outer, lds);
+            else
+                tail2_p2_body<false, D1, true>(a, prime, comp, outer, lds);
+        }
+
+        // ---------------------------------------------------------------------------------------
         // N = 2^13: both passes in ONE launch with the intermediate in LDS (the transform is 64 KiB).
         // A workgroup of 512 threads = two teams of 256; team k runs pass 1 on column tile k, the
         // teams meet at a barrier, team k runs pass 2 on row tile k: every coefficient crosses HBM
@@ -2012,6 +2160,40 @@ namespace sealhip
         }
 
         template <int D1>
+        hipError_t launch_tail2(const Tail2Args &a, unsigned nouter, hipStream_t s)
+        {
+            typedef Geo<D1> G;
+            unsigned per = G::TILES * a.f.ncomp;
+            unsigned chunks = (4096 + per - 1) / per;
+            if (chunks > nouter)
+                chunks = nouter;
+            if (chunks > 65535)
+                chunks = 65535;
+            const size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
+            return launch_runs(comp_runs(a.f.t, nullptr, a.f.prime_first, a.f.ncomp), s, [&](const CompRun &r, hipStream_t st) {
+                Tail2Args g = a;
+                g.f.comp0 = r.c0;
+                dim3 grid(G::TILES, r.nc, chunks);
+                if (r.cls == 1)
+                    hipLaunchKernelGGL((ntt2_tail2_p1<D1, 1>), grid, dim3(kThreads), l1, st, g);
+                else if (r.cls == 0)
+                    hipLaunchKernelGGL((ntt2_tail2_p1<D1, 0>), grid, dim3(kThreads), l1, st, g);
+                else
+                    hipLaunchKernelGGL((ntt2_tail2_p1<D1, 2>), grid, dim3(kThreads), l1, st, g);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess)
+                    return e;
+                if (r.cls == 1)
+                    hipLaunchKernelGGL((ntt2_tail2_p2<D1, 1>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                else if (r.cls == 0)
+                    hipLaunchKernelGGL((ntt2_tail2_p2<D1, 0>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                else
+                    hipLaunchKernelGGL((ntt2_tail2_p2<D1, 2>), grid, dim3(kThreads), kLds2Words * 8, st, g);
+                return hipGetLastError();
+            });
+        }
+
+        template <int D1>
         hipError_t launch_inv(const InvArgs &a, unsigned nouter, hipStream_t s)
         {
             typedef Geo<D1> G;
@@ -2180,6 +2362,26 @@ namespace sealhip
         a.epi_out1 = b.epi_out1;
         a.epi_out_stride = b.epi_out_stride;
         a.t = t;
+        if (b.tail2)
+        {
+            // NttTail2: mapped source 2 + the double-division tail; prime of a component = prime_first + comp
+            if (!b.src || b.src_mode != 2 || b.comp_prime || !b.epi_a || !b.epi_mul || !b.epi_out0 || !b.epi_out1)
+                return hipErrorInvalidValue;
+            Tail2Args t2{ a, *b.tail2 };
+            switch (t.log_n)
+            {
+            case 13:
+                return launch_tail2<5>(t2, b.nouter, stream);
+            case 14:
+                return launch_tail2<6>(t2, b.nouter, stream);
+            case 15:
+                return launch_tail2<7>(t2, b.nouter, stream);
+            case 16:
+                return launch_tail2<8>(t2, b.nouter, stream);
+            default:
+                return hipErrorInvalidValue;
+            }
+        }
         switch (t.log_n)
         {
         case 13:

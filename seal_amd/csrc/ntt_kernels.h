@@ -35,6 +35,27 @@ namespace sealhip
         int log_n;
     };
 
+    // Two rounding divisions folded into ONE forward transform (two-pass engine; NttBatch::tail2).  CKKS relinearize followed by
+    // rescale divides by the special prime P (key-switch mod-down, evaluator.cpp:2806-2864) and then by q_last
+    // (divide_and_round_q_last_ntt_inplace, rns.cpp:830-901).  With v_i = the mod-down correction of component i (from t_P, the
+    // coefficient form of the special-prime sums) and u_i = the rescale correction (from t_last, the coefficient form of the
+    // relinearised ciphertext's last component) the two steps give, for i < K - 1,
+    //   out_i = (c_i + (S_i - NTT_i(v_i)) P^-1 - NTT_i(u_i)) q_last^-1 = (c_i + S_i P^-1 - NTT_i(v_i P^-1 + u_i)) q_last^-1   (mod q_i)
+    // because the transform is linear over Z_q_i and every step is exact residue arithmetic: one transform per component
+    // instead of two, and the relinearised ciphertext is never written.  The NttBatch carries the mod-down side in its src_*
+    // fields (src = t_P, src_mode 2 constants of P) and epi_a = S (the key-switch sums), epi_mul = q_last^-1, epi_out0 / epi_out1 =
+    // the two output planes; this struct adds the rest.  outer = 2 * item + plane (the layout of the key-switch sums).
+    struct NttTail2
+    {
+        const uint64_t *src2_0, *src2_1; // t_last of plane 0 / 1: + (outer >> 1) * src2_stride
+        size_t src2_stride;
+        uint64_t src2_half, src2_q;      // q_last / 2, q_last
+        const uint64_t *src2_fix;        // [ncomp] rescale rounding constants (device)
+        const ShoupOp *pmul;             // [ncomp] P^-1 mod q_i (device)
+        const uint64_t *c0, *c1;         // ciphertext planes: + (outer >> 1) * c_stride + comp * N
+        size_t c_stride;
+    };
+
     // One batched launch: transforms live at data + outer*outer_stride + comp*N, comp in
     // [0, ncomp), outer in [0, nouter); prime of a component = comp_prime[comp] (device array) or
     // prime_first + comp when comp_prime == nullptr.
@@ -72,6 +93,7 @@ namespace sealhip
         const ShoupOp *epi_mul; // [ncomp]
         uint64_t *epi_out0, *epi_out1;
         size_t epi_out_stride;
+        const NttTail2 *tail2 = nullptr; // see NttTail2 (host pointer, read during the call only)
     };
 
     // out_range: 0 = canonical [0,q); 1 = lazy ([0,4q) forward / [0,2q) inverse).

@@ -668,7 +668,7 @@ namespace sealhip
 
     hipError_t ntt_forward(const NttTables &t, const NttBatch &b, int out_lazy, hipStream_t stream)
     {
-        if (b.epi && !ntt2_supports(t.log_n))
+        if ((b.epi || b.tail2) && !ntt2_supports(t.log_n))
             return hipErrorInvalidValue;
         if (ntt2_supports(t.log_n))
         {

@@ -110,6 +110,12 @@ namespace sealhip
         uint64_t *p = nullptr;
         explicit Scratch(size_t words) : p(DevicePool::global().alloc_words(words)) {}
         ~Scratch() { DevicePool::global().free_words(p); }
+        uint64_t *release() // hand the block to another owner
+        {
+            uint64_t *r = p;
+            p = nullptr;
+            return r;
+        }
         Scratch(const Scratch &) = delete;
         Scratch &operator=(const Scratch &) = delete;
     };

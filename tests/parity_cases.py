@@ -134,6 +134,40 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
         for b in range(batch):
             _eq(back[b], cur[b], "transform_to_ntt(transform_from_ntt(x)) item %d" % b)
 
+    if K >= 2:
+        # Deferred key-switch tails (evaluator.h: LazyTail): the key switch leaves its mod-down undone, and a rescale that follows
+        # without anything reading the ciphertext in between does both rounding divisions in one pass.  Same words as the
+        # reference's two separate steps (evaluator.cpp:2806-2864, rns.cpp:830-901).
+        sc = float(primes[K - 1]) * 2.0 ** 10
+        cz, cw = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10)
+        d.ev.multiply_inplace(cz, cw)
+        d.ev.relinearize_inplace(cz, d.rlk)
+        cz.set_scale(sc)
+        d.ev.rescale_to_next_inplace(cz)
+        assert cz.size() == 2 and cz.coeff_modulus_size() == K - 1 and cz.scale() == sc / float(primes[K - 1])
+        got = d.out(cz)
+        for b in range(batch):
+            _eq(got[b], o.rescale(o.relinearize(o.multiply(xs[b], ys[b]))), "relinearize + rescale folded, item %d" % b)
+        if steps:
+            cr = d.ct(xs, scale=sc)
+            d.ev.rotate_vector_inplace(cr, steps[0], d.glk)
+            d.ev.rescale_to_next_inplace(cr)
+            got = d.out(cr)
+            for b in range(batch):
+                _eq(got[b], o.rescale(o.apply_galois(xs[b], elts[0])), "rotate + rescale folded, item %d" % b)
+        # a deferred tail is completed by anything else that needs the words: a copy, another operation, a second key switch
+        ca, cb = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10)
+        d.ev.multiply_inplace(ca, cb)
+        d.ev.relinearize_inplace(ca, d.rlk)
+        cc = ca.copy()
+        d.ev.add_inplace(ca, cc)
+        got, one = d.out(ca), d.out(cc)
+        for b in range(batch):
+            r = o.relinearize(o.multiply(xs[b], ys[b]))
+            _eq(one[b], r, "copy of a ciphertext with a deferred tail, item %d" % b)
+            qk = np.array(primes[:K], dtype=np.uint64)[None, :, None]
+            _eq(got[b], (r + r) % qk, "add after a deferred tail, item %d" % b)
+
 
 # ---- large device-resident batches (the shapes bench.py times): inputs are generated on the device, a sample of items is
 #      downloaded and compared with the reference's multiply + relinearize + rescale (+ rotate) on the same words
