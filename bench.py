@@ -341,6 +341,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.ntt_only and not EMU:
         cpu = cpu_baseline(args.workload, scheme, n, primes, t_plain, args)
 
+    tail_note = None
+    if args.workload != "bfv_c4":
+        folded, plain, dropped = S.tail_stats()
+        tail_note = ("deferred: relinearize leaves the mod-down by the special prime to the rescale that follows, which does both "
+                     "rounding divisions with one transform per component (same words; %d folded / %d separate / %d discarded in "
+                     "this process)" % (folded, plain, dropped)) if folded else "separate pass (%d tails completed on their own)" % plain
     if rank == 0:
         names = {
             "headline": ("CKKS multiply+relinearize+rescale ciphertexts/sec @ N=2^16, L=16",
@@ -362,7 +368,7 @@ def main():
             warmup=args.warmup, ms_per_step=round(result.get("ms_per_step", 0.0), 3), higher_is_better=True,
             scaling=scaling, vs_baseline=None, dtype="u64", data="synthetic", verified_items=verified,
             config=dict(workload=names[1] + (" [EMULATED KERNELS, CPU test]" if EMU else ""),
-                        batch_per_gpu=B, launch=("hipGraph replay" if args.graph else "eager") + (
+                        batch_per_gpu=B, key_switch_tail=tail_note, launch=("hipGraph replay" if args.graph else "eager") + (
                             ", %d evaluators x %d-item sub-batches on %d HIP streams" % (len(lanes), lanes[0]["cnt"], len(lanes)) if lanes else ""),
                         parallelism=par,
                         arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for primes below "

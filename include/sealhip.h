@@ -403,6 +403,17 @@ SHL_FUNC SealHip_ReleasePool(void);
  * change the protection of their own buffers (integration/seal_evaluator_hip.cpp); process-wide, off by default. */
 SHL_FUNC SealHip_SetStagedHostCopies(bool enabled);
 SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
+/* Deferred key-switch tails.  For CKKS at 2^13 <= N <= 2^16, Evaluator_Relinearize / ApplyGalois / RotateVector /
+ * ComplexConjugate return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext
+ * object keeps the key-switch sums next to its two polynomials.  Whatever needs the words next completes it first -
+ * every Evaluator_* call on the object, Ciphertext_CopyToHost / Save / copies, Decryptor_Decrypt, destroying the evaluator,
+ * Evaluator_BeginCapture - except Evaluator_RescaleToNext (in place) on the same evaluator, which performs the mod-down and
+ * its own division by q_last with ONE transform per component instead of two (rns.cpp:830-901 folded in by linearity of the
+ * transform; same words as the two separate steps).  Metadata (size, parms_id, scale) is up to date at all times.  A deferred
+ * tail runs on the stream of the evaluator that created it; a caller on another stream is made to wait for it.  Not thread
+ * safe per object, like every other Ciphertext operation.  SEALHIP_KS_EAGER_TAIL=1 in the environment turns deferral off.
+ * Counters for tests: tails folded into a rescale / completed on their own / discarded because the object was overwritten. */
+SHL_FUNC SealHip_TailStats(uint64_t *folded, uint64_t *plain, uint64_t *dropped);
 /* stream and device memory helpers for bindings without their own runtime (a PyTorch / HIP caller passes its own streams) */
 /* one process per GPU: select the calling thread's device before creating a SEALContext (a PyTorch caller uses
  * torch.cuda.set_device instead) */

@@ -1170,6 +1170,13 @@ def pool_stats():
     return a.value, b.value
 
 
+def tail_stats():
+    """deferred key-switch tails (sealhip.h: SealHip_TailStats): (folded into a rescale, completed on their own, discarded)"""
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    N.check(N.lib().SealHip_TailStats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def device_synchronize():
     N.check(N.lib().shl_device_synchronize())
 

@@ -2339,6 +2339,19 @@ extern "C"
             *cross_stream_waits = DevicePool::global().cross_stream_waits();
         SHL_CATCH
     }
+    SHL_FUNC SealHip_TailStats(uint64_t *folded, uint64_t *plain, uint64_t *dropped)
+    {
+        SHL_TRY
+        uint64_t f, p, d;
+        lazy_tail_stats(f, p, d);
+        if (folded)
+            *folded = f;
+        if (plain)
+            *plain = p;
+        if (dropped)
+            *dropped = d;
+        SHL_CATCH
+    }
     SHL_FUNC shl_device_count(int *count)
     {
         IfNullRet(count, SHL_E_POINTER);

@@ -1,4 +1,5 @@
 #include "evaluator.h"
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -359,6 +360,16 @@ namespace sealhip
         d_flag_ = (unsigned *)p;
     }
     // ---- deferred key-switch tails (LazyTail, evaluator.h)
+    namespace
+    {
+        std::atomic<uint64_t> g_tail_folded{ 0 }, g_tail_plain{ 0 }, g_tail_dropped{ 0 };
+    }
+    void lazy_tail_stats(uint64_t &folded, uint64_t &plain, uint64_t &dropped)
+    {
+        folded = g_tail_folded.load();
+        plain = g_tail_plain.load();
+        dropped = g_tail_dropped.load();
+    }
     void Evaluator::defer_tail(Ciphertext &e, uint64_t *acc) const
     {
         e.lazy_ = new LazyTail{ this, acc };
@@ -381,6 +392,7 @@ namespace sealhip
             lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &e), lazy_cts_.end());
         }
         DevicePool::global().free_words(t.acc, stream_);
+        g_tail_dropped++;
     }
     void Evaluator::complete_tail(Ciphertext &e, LazyTail t) const
     {
@@ -394,6 +406,7 @@ namespace sealhip
         static const bool trace = std::getenv("SEALHIP_KS_TRACE") != nullptr; // tests: which tail ran
         if (trace)
             std::fprintf(stderr, "[ks] plain tail\n");
+        g_tail_plain++;
         try
         {
             StreamScope scope(stream_);
@@ -1666,6 +1679,7 @@ namespace sealhip
         static const bool trace = std::getenv("SEALHIP_KS_TRACE") != nullptr;
         if (trace)
             std::fprintf(stderr, "[ks] folded tail\n");
+        g_tail_folded++;
 
         // t_P: coefficient form of the special-prime sums, in place (component K of every (item, plane) of acc)
         NttBatch bi = plain_batch(acc_p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);

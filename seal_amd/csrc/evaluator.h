@@ -29,6 +29,8 @@ namespace sealhip
         const Evaluator *owner;
         uint64_t *acc;
     };
+    // process-wide counters (tests, tools): tails folded into a rescale / completed on their own / discarded unrun
+    void lazy_tail_stats(uint64_t &folded, uint64_t &plain, uint64_t &dropped);
 
     class Ciphertext
     {

@@ -1,6 +1,8 @@
 """Parity cases shared by the CPU (fiber-emulated, index arithmetic only) and GPU (the real thing) test
 files.  Every comparison is bit-exact (np.array_equal on uint64 slabs): the path is integer work.
 Each case mirrors a reference test or bench case (cited)."""
+import os
+
 import numpy as np
 
 import seal_amd as S
@@ -139,11 +141,14 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
         # without anything reading the ciphertext in between does both rounding divisions in one pass.  Same words as the
         # reference's two separate steps (evaluator.cpp:2806-2864, rns.cpp:830-901).
         sc = float(primes[K - 1]) * 2.0 ** 10
+        defers = 13 <= n.bit_length() - 1 <= 16 and not os.environ.get("SEALHIP_KS_EAGER_TAIL")  # the two-pass sizes
+        folded0, plain0, dropped0 = S.tail_stats()
         cz, cw = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10)
         d.ev.multiply_inplace(cz, cw)
         d.ev.relinearize_inplace(cz, d.rlk)
         cz.set_scale(sc)
         d.ev.rescale_to_next_inplace(cz)
+        assert S.tail_stats()[0] - folded0 == (1 if defers else 0), "the folded pass did not run where it should"
         assert cz.size() == 2 and cz.coeff_modulus_size() == K - 1 and cz.scale() == sc / float(primes[K - 1])
         got = d.out(cz)
         for b in range(batch):
@@ -167,6 +172,71 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
             _eq(one[b], r, "copy of a ciphertext with a deferred tail, item %d" % b)
             qk = np.array(primes[:K], dtype=np.uint64)[None, :, None]
             _eq(got[b], (r + r) % qk, "add after a deferred tail, item %d" % b)
+        # ... or never runs when the object is overwritten or destroyed first
+        folded1, plain1, dropped1 = S.tail_stats()
+        cd, ce = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10)
+        d.ev.multiply_inplace(cd, ce)
+        d.ev.relinearize_inplace(cd, d.rlk)
+        d.ev.multiply(d.ct(xs, scale=2.0 ** 10), ce, cd)   # cd is the destination: its pending tail is discarded
+        d.ev.relinearize_inplace(cd, d.rlk)
+        del cd
+        import gc
+        gc.collect()
+        folded2, plain2, dropped2 = S.tail_stats()
+        assert (folded2, plain2) == (folded1, plain1) and dropped2 - dropped1 == (2 if defers else 0)
+
+
+# ---- deferred key-switch tails: who completes them (sealhip.h: SealHip_TailStats)
+def case_deferred_tail_lifecycle(n=8192, bits=(50, 40, 60)):
+    """K = 2 (the folded pass has ONE component to produce); a pending tail completed by a second evaluator, by the owner's
+    destruction, by serialisation; the folded rescale after a rotation of a relinearised ciphertext (tail completed, new one
+    deferred, then folded)."""
+    import gc
+    primes = coeff_modulus_create(n, list(bits))
+    K = len(primes) - 1
+    probe = Oracle("ckks", n, primes)
+    elt = probe.galois_elt_from_step(1)
+    o = Oracle("ckks", n, primes, galois_elts=[elt])
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(11)
+    x, y = rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)
+    ref_relin = o.relinearize(o.multiply(x, y))
+    sc = float(primes[K - 1]) * 2.0 ** 10
+
+    def relinearised(ev):
+        a, b = d.ct([x], scale=2.0 ** 10), d.ct([y], scale=2.0 ** 10)
+        ev.multiply_inplace(a, b)
+        ev.relinearize_inplace(a, d.rlk)
+        return a
+
+    f0, p0, _ = S.tail_stats()
+    # K = 2: relinearize + rescale folded
+    a = relinearised(d.ev)
+    a.set_scale(sc)
+    d.ev.rescale_to_next_inplace(a)
+    _eq(d.out(a)[0], o.rescale(ref_relin), "folded pass with one remaining component")
+    # another evaluator touches the pending ciphertext: the owner completes it, the second evaluator then works on the result
+    ev2 = S.Evaluator(d.ctx)
+    a = relinearised(d.ev)
+    a.set_scale(sc)
+    ev2.rescale_to_next_inplace(a)   # not the owner: plain tail, then an ordinary rescale
+    _eq(d.out(a)[0], o.rescale(ref_relin), "rescale by a second evaluator")
+    # the owner goes away first
+    ev3 = S.Evaluator(d.ctx)
+    a = relinearised(ev3)
+    del ev3
+    gc.collect()
+    _eq(d.out(a)[0], ref_relin, "tail completed when its evaluator was destroyed")
+    # rotate a relinearised ciphertext, then rescale: the first tail runs alone, the rotation's is folded
+    a = relinearised(d.ev)
+    a.set_scale(sc)
+    d.ev.rotate_vector_inplace(a, 1, d.glk)
+    d.ev.rescale_to_next_inplace(a)
+    _eq(d.out(a)[0], o.rescale(o.apply_galois(ref_relin, elt)), "relinearize, rotate, rescale")
+    f1, p1, _ = S.tail_stats()
+    if not os.environ.get("SEALHIP_KS_EAGER_TAIL"):
+        assert (f1 - f0, p1 - p0) == (2, 3), (f1 - f0, p1 - p0)
 
 
 # ---- large device-resident batches (the shapes bench.py times): inputs are generated on the device, a sample of items is

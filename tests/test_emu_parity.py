@@ -223,3 +223,8 @@ def test_ckks_pipeline_n65536_lean_key_switch(emu):
     feeding double-precision targets and the other way round"""
     P.case_ckks_pipeline(65536, [60, 50, 50, 60], batch=1, steps=(1,), check_transforms=False)
     P.case_ckks_pipeline(65536, [60, 50, 40, 50, 45, 60], batch=2, steps=(1,), check_transforms=False)
+
+
+def test_deferred_tail_lifecycle(emu):
+    """deferred key-switch tails (sealhip.h): folded into a rescale by their owner, completed by anyone else who needs the words"""
+    P.case_deferred_tail_lifecycle()

@@ -622,3 +622,10 @@ def test_two_evaluators_two_streams_share_the_pool(gpu):
     assert S.pool_stats()[1] > waits0, "scratch never changed stream: the test did not exercise the ordering"
     d.ev.set_stream(None)
     ev2.set_stream(None)
+
+
+def test_deferred_tail_lifecycle(gpu):
+    """deferred key-switch tails (sealhip.h): folded into a rescale by their owner, completed by anyone else who needs the words;
+    at N = 8192 and at the headline size"""
+    P.case_deferred_tail_lifecycle()
+    P.case_deferred_tail_lifecycle(65536, (60, 50, 50, 50, 60))
