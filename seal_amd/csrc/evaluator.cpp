@@ -1682,7 +1682,9 @@ namespace sealhip
         g_tail_folded++;
 
         // t_P: coefficient form of the special-prime sums, in place (component K of every (item, plane) of acc)
+        // plus P/2: the rounding's addend goes in here, once per coefficient (NttBatch::out_add; the maps below run in mode 3)
         NttBatch bi = plain_batch(acc_p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
+        bi.out_add = P >> 1;
         ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
 
         // the relinearised ciphertext's LAST component (the one rescale divides by), completed alone: c += (S - NTT(v)) P^-1
@@ -1697,7 +1699,7 @@ namespace sealhip
             b.src = acc_p + (size_t)K * N;
             b.src_outer_stride = (size_t)(K + 1) * N;
             b.src_ncomp = 1;
-            b.src_mode = 2;
+            b.src_mode = 3;
             b.src_half = P >> 1;
             b.src_q = P;
             b.src_fix = klvl.dev.round_fix + (K - 1);
@@ -1711,7 +1713,11 @@ namespace sealhip
             ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction + tail, last component");
         }
         // t_last: its coefficient form, in place (that component is dropped by the rescale)
-        ck(ntt_inverse(tb, plain_batch(c0 + (size_t)(K - 1) * N, (size_t)K * N, 1, 2 * B, K - 1), 0, stream_), "rescale intt last");
+        {
+            NttBatch bl = plain_batch(c0 + (size_t)(K - 1) * N, (size_t)K * N, 1, 2 * B, K - 1);
+            bl.out_add = lvl.dev.half_q_last;
+            ck(ntt_inverse(tb, bl, 0, stream_), "rescale intt last");
+        }
 
         // components 0 .. K-2: out = (c + S P^-1 - NTT(v P^-1 + u)) q_last^-1, one transform each
         const size_t words = (size_t)2 * B * (K - 1) * N;
@@ -1729,6 +1735,7 @@ namespace sealhip
             t2.c0 = c0;
             t2.c1 = c1;
             t2.c_stride = (size_t)K * N;
+            t2.halves_added = 1;
             NttBatch b{};
             b.data = nullptr;
             b.outer_stride = (size_t)(K - 1) * N;
@@ -1739,7 +1746,7 @@ namespace sealhip
             b.src = acc_p + (size_t)K * N;
             b.src_outer_stride = (size_t)(K + 1) * N;
             b.src_ncomp = 1;
-            b.src_mode = 2;
+            b.src_mode = 3;
             b.src_half = P >> 1;
             b.src_q = P;
             b.src_fix = klvl.dev.round_fix;

@@ -256,7 +256,7 @@ namespace sealhip
         // ---------------------------------------------------------------------------------------
         struct SrcMap
         {
-            int mode; // 0 own residue, 1 foreign residue (x mod q), 2 ((x + half) mod src_q) mod q + fix
+            int mode; // 0 own residue, 1 foreign residue (x mod q), 2 ((x + half) mod src_q) mod q + fix, 3 x mod q + fix
             uint64_t half, src_q, fix;
         };
         template <bool FP>
@@ -267,7 +267,7 @@ namespace sealhip
                 return F::from_canon(v, m);
             if (s.mode == 1)
                 return F::from_any(v, m);
-            uint64_t r = csub(v + s.half, s.src_q);
+            const uint64_t r = s.mode == 3 ? v : csub(v + s.half, s.src_q); // 3: the producer has added `half` (NttBatch::out_add)
             typename F::elem x = F::from_any(r, m) + F::from_canon(s.fix, m);
             F::fix(x, m); // the sum may reach 1.5q: bring it back before four butterfly stages
             return x;
@@ -566,7 +566,7 @@ namespace sealhip
                 sm.mode = a.src_mode;
                 sm.half = a.src_half;
                 sm.src_q = a.src_q;
-                sm.fix = a.src_mode == 2 ? a.src_fix[comp] : 0;
+                sm.fix = a.src_mode >= 2 ? a.src_fix[comp] : 0;
             }
             else
             {
@@ -758,7 +758,8 @@ namespace sealhip
             const unsigned tid = threadIdx.x, cg = blockIdx.x;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
-            const SrcMap s1{ 2, a.src_half, a.src_q, a.src_fix[comp] }, s2{ 2, t2.x.src2_half, t2.x.src2_q, t2.x.src2_fix[comp] };
+            const int mode = t2.x.halves_added ? 3 : 2;
+            const SrcMap s1{ mode, a.src_half, a.src_q, a.src_fix[comp] }, s2{ mode, t2.x.src2_half, t2.x.src2_q, t2.x.src2_fix[comp] };
             const ShoupOp pm = t2.x.pmul[comp];
             const uint64_t q = a.t.mods[prime].q;
             const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
@@ -794,7 +795,9 @@ namespace sealhip
                         x[e] = mul_shoup(v, pm.w, pm.wq, q) + u; // below q + 2q: inside the forward input range [0, 4q)
                 }
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
-                p1_tile<FP, D1, 256, 0, false, WIDE>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                // double precision, eight stages: x is fixed (|x| <= q/2), so one fix() after stage 7 does (p1_tile, LEAN); the
+                // intermediate leaves at 1.09 q, which pass 2's first phase takes (-> 4.81 q)
+                p1_tile<FP, D1, 256, 0, FP && G::rA == 4, WIDE>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
         }
 
@@ -980,6 +983,7 @@ namespace sealhip
             unsigned comp0; // as FwdArgs
             unsigned nouter; // used by the single-launch kernels, whose workgroups loop over outer items
             int lazy;
+            uint64_t out_add; // NttBatch::out_add
             NttTables t;
         };
 
@@ -1109,7 +1113,10 @@ namespace sealhip
                 F::fix(x[e], m);
                 const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
                 const unsigned R = ra * 16 + (rbh << G::rA) + hi;
-                o[(size_t)R * 256 + col] = a.lazy ? F::inv_to_lazy(x[e], m) : F::inv_to_canon(x[e], m);
+                uint64_t v = a.lazy ? F::inv_to_lazy(x[e], m) : F::inv_to_canon(x[e], m);
+                if (a.out_add)
+                    v = csub(v + a.out_add, a.t.mods[prime].q);
+                o[(size_t)R * 256 + col] = v;
             }
         }
 
@@ -1373,7 +1380,10 @@ namespace sealhip
                     F::fix(x[e], m);
                     const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
                     const unsigned R = ra * 16 + (rbh << G::rA) + hi;
-                    o[(size_t)R * 256 + col] = a.lazy ? F::inv_to_lazy(x[e], m) : F::inv_to_canon(x[e], m);
+                    uint64_t v = a.lazy ? F::inv_to_lazy(x[e], m) : F::inv_to_canon(x[e], m);
+                if (a.out_add)
+                    v = csub(v + a.out_add, a.t.mods[prime].q);
+                o[(size_t)R * 256 + col] = v;
                 }
             }
         }
@@ -2365,7 +2375,7 @@ namespace sealhip
         if (b.tail2)
         {
             // NttTail2: mapped source 2 + the double-division tail; prime of a component = prime_first + comp
-            if (!b.src || b.src_mode != 2 || b.comp_prime || !b.epi_a || !b.epi_mul || !b.epi_out0 || !b.epi_out1)
+            if (!b.src || (b.src_mode != 2 && b.src_mode != 3) || b.comp_prime || !b.epi_a || !b.epi_mul || !b.epi_out0 || !b.epi_out1)
                 return hipErrorInvalidValue;
             Tail2Args t2{ a, *b.tail2 };
             switch (t.log_n)
@@ -2413,6 +2423,9 @@ namespace sealhip
         a.comp0 = 0;
         a.nouter = 0; // set per launch
         a.lazy = out_lazy;
+        if (b.out_add && out_lazy)
+            return hipErrorInvalidValue;
+        a.out_add = b.out_add;
         a.t = t;
         const unsigned zmax = 65535;
         for (unsigned z0 = 0; z0 < b.nouter; z0 += zmax)

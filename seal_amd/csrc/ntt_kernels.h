@@ -54,6 +54,7 @@ namespace sealhip
         const ShoupOp *pmul;             // [ncomp] P^-1 mod q_i (device)
         const uint64_t *c0, *c1;         // ciphertext planes: + (outer >> 1) * c_stride + comp * N
         size_t c_stride;
+        int halves_added;                // both sources were produced with out_add = their half: the maps skip that step
     };
 
     // One batched launch: transforms live at data + outer*outer_stride + comp*N, comp in
@@ -73,6 +74,8 @@ namespace sealhip
         //   src_mode 2: ((x + src_half) mod src_q) mod q + src_fix[comp]
         //               (the "+half, mod q_i, -half" rounding step fused into the load:
         //                rns.cpp:858-881 rescale, evaluator.cpp:2813-2832 key-switch mod-down)
+        //   src_mode 3: x mod q + src_fix[comp]: mode 2 for a source whose producer has already added src_half (out_add below;
+        //               two-pass engine only)
         const uint64_t *src;
         size_t src_outer_stride;
         unsigned src_ncomp;
@@ -94,6 +97,10 @@ namespace sealhip
         uint64_t *epi_out0, *epi_out1;
         size_t epi_out_stride;
         const NttTail2 *tail2 = nullptr; // see NttTail2 (host pointer, read during the call only)
+        // Inverse transforms of the two-pass engine, canonical output only: every output word v is stored as
+        // (v + out_add) mod q.  Used on the single component a rounding division is about to drop, so that the "+ q/2" of the
+        // rounding is added once per coefficient instead of once per target modulus (NttTail2::halves_added).
+        uint64_t out_add = 0;
     };
 
     // out_range: 0 = canonical [0,q); 1 = lazy ([0,4q) forward / [0,2q) inverse).
