@@ -461,6 +461,7 @@ namespace sealhip
             throw std::logic_error("a capture is in progress");
         if (s == stream_)
             return;
+        settle_all(); // deferred tails belong to the stream their sums were produced on
         DevicePool::global().unregister_stream(stream_);
         stream_ = s;
         DevicePool::global().register_stream(stream_);
