@@ -45,3 +45,37 @@ def test_random_sequences_gpu(gpu, cfg):
         F.run_sequence(*cfg)
     except sealref.RefError as e:
         pytest.skip("reference rejected the parameters: %s" % e)
+
+
+def _ckks_configs(seed, count, degrees):
+    """CKKS only, more operations per sequence, a mix that favours key switches followed by rescales"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        n = int(degrees[rng.integers(0, len(degrees))])
+        L = int(rng.integers(4, 8))
+        bits = [int(b) for b in rng.integers(36, 61, L)]
+        out.append(("ckks", n, bits, 20, int(rng.integers(1, 3)), int(rng.integers(8, 14)), 5000 * seed + i))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _ckks_configs(3, 6, [8192, 8192, 16384]), ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+def test_random_sequences_with_deferred_state_emulated(emu, cfg):
+    """the same sequences with the result read back only now and then: deferred key-switch tails reach the next operation"""
+    if not sealref.available():
+        pytest.skip("needs the real reference (oracle/_ref)")
+    try:
+        F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30)
+    except sealref.RefError as e:
+        pytest.skip("reference rejected the parameters: %s" % e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", _ckks_configs(4, 24, [8192, 16384, 32768, 65536]), ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+def test_random_sequences_with_deferred_state_gpu(gpu, cfg):
+    if not sealref.available():
+        pytest.skip("needs the real reference (oracle/_ref)")
+    try:
+        F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30)
+    except sealref.RefError as e:
+        pytest.skip("reference rejected the parameters: %s" % e)
