@@ -407,7 +407,8 @@ SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
  * ComplexConjugate return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext
  * object keeps the key-switch sums next to its two polynomials.  Whatever needs the words next completes it first -
  * every Evaluator_* call on the object, Ciphertext_CopyToHost / Save / copies, Decryptor_Decrypt, destroying the evaluator,
- * Evaluator_BeginCapture - except Evaluator_RescaleToNext (in place) on the same evaluator, which performs the mod-down and
+ * Evaluator_SetStream, Evaluator_BeginCapture (tails from before the recording) and Evaluator_EndCapture (tails deferred inside
+ * it and not consumed there become the recording's last work) - except Evaluator_RescaleToNext (in place) on the same evaluator, which performs the mod-down and
  * its own division by q_last with ONE transform per component instead of two (rns.cpp:830-901 folded in by linearity of the
  * transform; same words as the two separate steps).  Metadata (size, parms_id, scale) is up to date at all times.  A deferred
  * tail runs on the stream of the evaluator that created it; a caller on another stream is made to wait for it.  Not thread

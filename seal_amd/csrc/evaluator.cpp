@@ -418,7 +418,7 @@ namespace sealhip
             throw;
         }
         DevicePool::global().free_words(t.acc, stream_);
-        if (caller != stream_)
+        if (caller != stream_ && !capturing_) // (a stream that is recording cannot be waited for: its work runs when the graph does)
             ck(hipStreamSynchronize(stream_), "deferred key-switch tail");
     }
     void Evaluator::settle_all() const
@@ -500,6 +500,22 @@ namespace sealhip
     {
         if (!capturing_)
             throw std::logic_error("no capture in progress");
+        // a tail deferred inside the recording and not consumed by it runs as the recording's last work (on the capture stream)
+        try
+        {
+            settle_all();
+        }
+        catch (...)
+        {
+            hipGraph_t dead = nullptr;
+            (void)hipStreamEndCapture(stream_, &dead);
+            if (dead)
+                (void)hipGraphDestroy(dead);
+            stream_ = saved_stream_;
+            capturing_ = false;
+            DevicePool::global().release_held(DevicePool::global().end_hold());
+            throw;
+        }
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamEndCapture(stream_, &graph);
         stream_ = saved_stream_;
@@ -1658,7 +1674,7 @@ namespace sealhip
         // CKKS at the two-pass sizes: leave the mod-down to whoever touches the ciphertext next (LazyTail) - a rescale on this
         // evaluator then does both rounding divisions with one transform per component.  SEALHIP_KS_EAGER_TAIL=1: always now.
         static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
-        if (lazy_ok && !capturing_ && context_.scheme() == Scheme::ckks && ntt2_supports(context_.log_n()) && K >= 2)
+        if (lazy_ok && context_.scheme() == Scheme::ckks && ntt2_supports(context_.log_n()) && K >= 2)
             defer_tail(e, acc.release());
         else
             switch_key_finish(e, acc.p, 1);
@@ -2016,7 +2032,7 @@ namespace sealhip
         }
         const unsigned K = lvl.K;
         const size_t N = context_.n();
-        if (scheme == Scheme::ckks && e.lazy_ && e.lazy_->owner == this && e.size() == 2 && K >= 2 && !capturing_ &&
+        if (scheme == Scheme::ckks && e.lazy_ && e.lazy_->owner == this && e.size() == 2 && K >= 2 &&
             ntt2_supports(context_.log_n()))
         {
             // the key switch that produced e left its mod-down undone (LazyTail): both rounding divisions in one pass
