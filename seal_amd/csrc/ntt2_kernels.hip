@@ -502,6 +502,24 @@ namespace sealhip
                 sink(row * 256 + col, lds_wave[row * kRowWords + col + 2 * (col >> 4)]);
             }
         }
+        // emit_rows with the index k of the (offset, value) pair: k-th pair = offset (k >> 2) * 256 + (k & 3) * 64 + lane, so that a
+        // caller can have loaded its other operands of these offsets ahead of time
+        template <class Sink>
+        __device__ __forceinline__ void emit_rows_k(const uint64_t (&val)[16], uint64_t *lds_wave, unsigned tid, Sink sink)
+        {
+            const unsigned v = tid & 15, ul = (tid >> 4) & 3, lane = tid & 63;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                lds_wave[ul * kRowWords + v * 18 + e] = val[e];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+            {
+                const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
+                sink(k, row * 256 + col, lds_wave[row * kRowWords + col + 2 * (col >> 4)]);
+            }
+        }
         __device__ __forceinline__ void load_rows(uint64_t (&val)[16], uint64_t *lds_wave, const uint64_t *rows, unsigned tid)
         {
             const unsigned v = tid & 15, ul = (tid >> 4) & 3, lane = tid & 63;
@@ -832,16 +850,25 @@ namespace sealhip
                     x[e] = F::unraw(nxt[e]);
                 if (outer + ostride < a.nouter)
                     fetch(outer + ostride);
+                // the tail's two operands are requested before the transform, not at the stores that need them
+                const uint64_t *A = a.epi_a + (size_t)outer * a.epi_a_stride + row0;
+                const uint64_t *C = ((outer & 1) ? t2.x.c1 : t2.x.c0) + (size_t)(outer >> 1) * t2.x.c_stride + row0;
+                uint64_t av[16], cv[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                {
+                    const unsigned off = (k >> 2) * 256 + (k & 3) * 64 + (tid & 63);
+                    av[k] = A[off];
+                    cv[k] = C[off];
+                }
                 p2_tile<FP, D1, false, false, false, false, false, WIDE>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
                 uint64_t val[16];
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     val[e] = F::fwd_to_lazy(x[e], m); // < 4q
-                const uint64_t *A = a.epi_a + (size_t)outer * a.epi_a_stride + row0;
-                const uint64_t *C = ((outer & 1) ? t2.x.c1 : t2.x.c0) + (size_t)(outer >> 1) * t2.x.c_stride + row0;
                 uint64_t *O = ((outer & 1) ? a.epi_out1 : a.epi_out0) + (size_t)(outer >> 1) * a.epi_out_stride + row0;
-                emit_rows(val, lds_wave, tid, [&](unsigned off, uint64_t tv) {
-                    const uint64_t s = add_mod(mul_shoup(A[off], pm.w, pm.wq, q), C[off], q); // c + S P^-1, canonical
+                emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t tv) {
+                    const uint64_t s = add_mod(mul_shoup(av[k], pm.w, pm.wq, q), cv[k], q); // c + S P^-1, canonical
                     O[off] = mul_shoup(s + 4 * q - tv, mul.w, mul.wq, q);
                 });
             }
