@@ -148,7 +148,21 @@ namespace sealhip
         return __builtin_bit_cast(double, SHL_UCONST(reinterpret_cast<const uint64_t *>(tab))[idx]);
     }
 
-    // ---- 64-bit integer back end (Shoup multiplication, Harvey lazy butterflies)
+    // ---- 64-bit integer back end (Shoup multiplication, lazy butterflies with compile-time range tracking)
+    //
+    // Round 3.  A butterfly's cost on gfx950 is its instruction count (every VALU instruction is one issue slot), and the
+    // reference's Harvey butterfly (ntt.h:20-67) costs 20 (forward) / 26 (inverse) instructions in 32-bit limbs.  Three changes
+    // bring that to 15 / 16 without changing a single residue:
+    //  * the Shoup quotient h = floor(x * wq / 2^64) is only needed to within a few units - the remainder x*w - h*q is computed
+    //    modulo 2^64 and a 64-bit word holds 16 q (q < 2^60) - so it is taken from three of the four 32 x 32 partial products
+    //    (mul_hi_approx: 4 instructions instead of 8), which leaves the product in [0, 4q) instead of [0, 2q);
+    //  * the sum X + t rides in the 64-bit addend of the first v_mad_u64_u32 of the remainder chain, and the difference is
+    //    2X + 4q - (X + t): one v_lshl_add_u64 and one 64-bit subtraction;
+    //  * no per-butterfly guard: values grow by 4 q per forward stage (they double per inverse stage) and the kernels place
+    //    fix4() - six (generic) or five (q >= 2^40) instructions, result in [0, 4q) - where a COMPILE-TIME bound says the next
+    //    stage could wrap (IntBounds below; ntt2_kernels.hip threads the bound through phases, passes and launches).
+    // Moduli of 2^60 and above (SEAL's 61-bit internal moduli, the BEHZ auxiliary base; user primes have at most 60 bits,
+    // defines.h:33-40) keep the reference's guarded butterflies with the exact quotient.
     template <>
     struct Field<false>
     {
@@ -156,11 +170,14 @@ namespace sealhip
         typedef ShoupOp tw_t;
         struct Mod
         {
-            uint64_t q, two_q;
+            uint64_t q, two_q, four_q;
             ModDesc md;
-            // fwd_fix(): rcp = floor(2^(32 + bits) / 2q) in [2^31, 2^32), bits = bit_length(q); sx = max(bits - 28, 0) aligns
-            // a value below 16 q to 32 bits, sh = bits - sx; n0, n1 = the two halves of -2q mod 2^64
-            uint32_t rcp, sx, sh, n0, n1;
+            // rcp = floor(2^(31 + bits) / q) in (2^31, 2^32], bits = bit_length(q): the 32-bit reciprocal of q and of 2q
+            // sx = max(bits - 26, 0) aligns any value below 64 q to 32 bits; floor(x / 2q) ~ ((x >> sx) * rcp >> 32) >> (bits - sx),
+            // floor(x / q) ~ the same shifted by one less; sh_hi = bits - 32: the same estimates from the high word alone (q >= 2^40)
+            uint32_t rcp, sx, sh, sh_hi;
+            uint32_t n0, n1; // the two halves of -q mod 2^64
+            uint32_t m0, m1; // the two halves of -2q mod 2^64
         };
         static constexpr int tw_words = 2;
 
@@ -168,11 +185,13 @@ namespace sealhip
         {
             // floor(2^(31 + bits) / q) = floor(2^128 / q) >> (97 - bits); wave-uniform: scalar instructions on the device
             const unsigned bits = 64u - (unsigned)__builtin_clzll(md.q | 1);
-            const unsigned s128 = 97u - bits; // 37 .. 95 for 2 <= bits <= 60
+            const unsigned s128 = 97u - bits; // 36 .. 95 for 2 <= bits <= 61
             const uint32_t rcp = s128 >= 64 ? (uint32_t)(md.ratio_hi >> (s128 - 64)) : (uint32_t)((md.ratio_hi << (64 - s128)) | (md.ratio_lo >> s128));
-            const unsigned sx = bits > 28 ? bits - 28 : 0;
-            const uint64_t nq2 = 0 - md.two_q;
-            return Mod{ md.q, md.two_q, md, rcp, sx, bits - sx, (uint32_t)nq2, (uint32_t)(nq2 >> 32) };
+            const unsigned sx = bits > 26 ? bits - 26 : 0;
+            const uint64_t nq = 0 - md.q, nq2 = 0 - md.two_q;
+            return Mod{ md.q,           md.two_q,           md.two_q << 1,  md,
+                        rcp,            sx,                 bits - sx,      bits > 32 ? bits - 32 : 0,
+                        (uint32_t)nq,   (uint32_t)(nq >> 32), (uint32_t)nq2, (uint32_t)(nq2 >> 32) };
         }
         static SHL_HD elem from_canon(uint64_t x, const Mod &)
         {
@@ -188,14 +207,32 @@ namespace sealhip
         // high limb (no carry chain, no separate subtraction).  Result in [0,2q) for any 64-bit x.
         static SHL_HD uint64_t mul_lazy(uint64_t x, const tw_t &w, const Mod &m)
         {
-            const uint64_t h = mul_hi64(x, w.wq);
-            const uint64_t nq = 0 - m.q;
+            return mul_rem(x, w, mul_hi64(x, w.wq), 0, m);
+        }
+        // h in {floor(x * wq / 2^64) - 2, ..., floor(x * wq / 2^64)}: x wq / 2^64 = x1 wq1 + (x1 wq0 + x0 wq1) / 2^32 + x0 wq0 / 2^64; keep
+        // x1 wq1 + hi32(x1 wq0) + hi32(x0 wq1), the dropped (lo32(x1 wq0) + lo32(x0 wq1)) 2^32 + x0 wq0 is below 3 * 2^64.
+        // Two v_mul_hi_u32, one v_mad_u64_u32, one v_lshl_add_u64.
+        static SHL_HD uint64_t mul_hi_approx(uint64_t x, uint64_t wq)
+        {
+            const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)wq, w1 = (uint32_t)(wq >> 32);
+            const uint32_t a = (uint32_t)(((uint64_t)x0 * w1) >> 32), c = (uint32_t)(((uint64_t)x1 * w0) >> 32);
+            return ((uint64_t)x1 * w1 + a) + c;
+        }
+        // low 64 bits of add + x*w + h*(-q): one v_mad_u64_u32 chain carrying `add`, the four cross products into the high word
+        static SHL_HD uint64_t mul_rem(uint64_t x, const tw_t &w, uint64_t h, uint64_t add, const Mod &m)
+        {
             const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w.w, w1 = (uint32_t)(w.w >> 32);
-            const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32), n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
-            uint64_t lo = (uint64_t)x0 * w0;
-            lo += (uint64_t)h0 * n0;
-            const uint32_t hi = (uint32_t)(lo >> 32) + x0 * w1 + x1 * w0 + h0 * n1 + h1 * n0;
+            const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+            uint64_t lo = (uint64_t)x0 * w0 + add;
+            lo += (uint64_t)h0 * m.n0;
+            const uint32_t hi = (uint32_t)(lo >> 32) + x0 * w1 + x1 * w0 + h0 * m.n1 + h1 * m.n0;
             return ((uint64_t)hi << 32) | (uint32_t)lo;
+        }
+        // x * w mod q in [0, 4q) for ANY 64-bit x: with h = floor(x wq / 2^64) - e, e <= 2, the remainder is
+        // x w - h q = (x w - floor(x wq / 2^64) q) + e q < 2q + 2q.  12 instructions.
+        static SHL_HD uint64_t mul_lazy4(uint64_t x, const tw_t &w, const Mod &m)
+        {
+            return mul_rem(x, w, mul_hi_approx(x, w.wq), 0, m);
         }
         // [0,4q) -> [0,2q) without a carry chain: the sign of x - 2q selects
         static SHL_HD uint64_t guard(uint64_t x, const Mod &m)
@@ -203,19 +240,15 @@ namespace sealhip
             const uint64_t d = x - m.two_q;
             return (int64_t)d < 0 ? x : d;
         }
-        // Forward butterfly WITHOUT the per-butterfly guard of the reference (Arithmetic<>::guard, ntt.h:30-61): with q < 2^60
-        // a 64-bit word holds 16 q, mul_lazy() takes any 64-bit Y, so X, Y in [0, B q) -> [0, (B + 2) q) and a run of stages only
-        // needs B + 2 * stages <= 16; fwd_fix() brings everything back under 4 q once per run (p1_tile / p2_tile: after each
-        // phase of at most four stages, 4 -> 12).  The residues are the same as with the reference's ranges; outputs leave
-        // through fwd_to_canon / fwd_to_lazy from [0, 4q) as before.  Moduli of 2^60 and above (SEAL's internal moduli have
-        // 61 bits - the BEHZ auxiliary base; user primes have at most 60, defines.h:33-40) take bfly_fwd_guarded instead (wide_modulus() / phase_fwd_end in ntt2_kernels.hip:
-        // one wave-uniform branch at the top of each kernel).
+        // Forward butterfly, 15 instructions: X, Y below B q -> below (B + 4) q, for any B with (B + 4) q <= 2^64.
+        //   X' = X + t (the sum is the addend of the remainder chain), Y' = X + 4q - t = 2X + 4q - X', t = Y w mod q in [0, 4q)
+        // The callers keep B + 4 <= the limit of the modulus class with fix4() (IntBounds).
         static SHL_HD void bfly_fwd(elem &X, elem &Y, const tw_t &w, const Mod &m)
         {
-            uint64_t t = mul_lazy(Y, w, m);
-            SEALHIP_NOWRAP(X, m.two_q);
-            Y = X + m.two_q - t;
-            X = X + t;
+            SEALHIP_NOWRAP(X, m.four_q);
+            const uint64_t xn = mul_rem(Y, w, mul_hi_approx(Y, w.wq), X, m);
+            Y = (X << 1) + m.four_q - xn;
+            X = xn;
         }
         // X,Y in [0,4q) -> [0,4q)   (Arithmetic<>::guard/add/sub/mul_root, ntt.h:30-61): moduli of 2^60 and above
         static SHL_HD void bfly_fwd_guarded(elem &X, elem &Y, const tw_t &w, const Mod &m)
@@ -225,31 +258,65 @@ namespace sealhip
             X = x + t;
             Y = x + m.two_q - t;
         }
-        // x < 16 q -> x - k * 2q in [0, 4q) with k = floor((x >> sx) * rcp / 2^(32 + sh)) in {floor(x / 2q) - 1, floor(x / 2q)}:
-        // (x >> sx) * 2^sx <= x and rcp <= 2^(32 + sx + sh) / 2q give k <= x / 2q; the two truncations and the floor lose less
-        // than 2^sx / 2q + (x >> sx) / 2^(32 + sh) + 1 < 2 (x >> sx < 2^32 because x < 2^(bits + 4)).  Six VALU instructions
-        // (v_lshrrev_b64, v_mul_hi_u32, v_lshrrev_b32, v_mad_u64_u32, v_mul_lo_u32, v_add_u32).
-        static SHL_HD void fwd_fix(elem &x, const Mod &m)
+        // x < 64 q (and < 2^64) -> x - k * 2q in [0, 4q) with k in {floor(x / 2q) - 1, floor(x / 2q)}:
+        // (x >> sx) 2^sx <= x and rcp <= 2^(31 + bits) / q give k <= x / 2q; the two truncations and the floor lose less than
+        // 2^sx / 2q + (x >> sx) / 2^(32 + sh) + 1 < 1 + 2^(2 - sh), and sh >= 2 (x >> sx < 2^32 because x < 2^(bits + 6)).
+        // HI32 (moduli of 40 bits and more, decided per kernel body): the high word alone is x >> 32 - no 64-bit shift; its
+        // truncation loses 2^32 / 2q <= 2^-8.  Six / five VALU instructions
+        // ([v_lshrrev_b64,] v_mul_hi_u32, v_lshrrev_b32, v_mad_u64_u32, v_mul_lo_u32, v_add_u32).
+        template <bool HI32 = false>
+        static SHL_HD void fix4(elem &x, const Mod &m)
         {
-            const uint32_t xs = (uint32_t)(x >> m.sx);
-            const uint32_t k = (uint32_t)(((uint64_t)xs * m.rcp) >> 32) >> m.sh;
-            const uint64_t lo = (uint64_t)k * m.n0 + x;
-            const uint32_t hi = (uint32_t)(lo >> 32) + k * m.n1;
+            const uint32_t xs = HI32 ? (uint32_t)(x >> 32) : (uint32_t)(x >> m.sx);
+            const uint32_t k = (uint32_t)(((uint64_t)xs * m.rcp) >> 32) >> (HI32 ? m.sh_hi : m.sh);
+            const uint64_t lo = (uint64_t)k * m.m0 + x;
+            const uint32_t hi = (uint32_t)(lo >> 32) + k * m.m1;
             x = ((uint64_t)hi << 32) | (uint32_t)lo;
         }
-        // X,Y in [0,2q) -> [0,2q)   (dwthandler.h:202-356)
+        static SHL_HD void fwd_fix(elem &x, const Mod &m)
+        {
+            fix4<false>(x, m);
+        }
+        // x < 64 q -> [0, q): the same estimate for floor(x / q) (one bit less of shift), then one conditional subtraction
+        template <bool HI32 = false>
+        static SHL_HD uint64_t canon_any(elem x, const Mod &m)
+        {
+            const uint32_t xs = HI32 ? (uint32_t)(x >> 32) : (uint32_t)(x >> m.sx);
+            const uint32_t k = (uint32_t)(((uint64_t)xs * m.rcp) >> 32) >> ((HI32 ? m.sh_hi : m.sh) - 1);
+            const uint64_t lo = (uint64_t)k * m.n0 + x;
+            const uint32_t hi = (uint32_t)(lo >> 32) + k * m.n1;
+            return csub(((uint64_t)hi << 32) | (uint32_t)lo, m.q);
+        }
+        // Inverse butterfly without a guard, 16 instructions: X, Y below 2^E q (c = 2^E q) -> X' = X + Y below 2^(E+1) q,
+        // Y' = (X + c - Y) w mod q in [0, 4q).  Needs 2^(E+1) q <= 2^64 (IntBounds).
+        static SHL_HD void bfly_inv_lazy(elem &X, elem &Y, const tw_t &w, uint64_t c, const Mod &m)
+        {
+            SEALHIP_NOWRAP(X, Y);
+            SEALHIP_NOWRAP(X, c);
+            const uint64_t s = X + Y, d = X + c - Y;
+            X = s;
+            Y = mul_lazy4(d, w, m);
+        }
+        // X,Y in [0,2q) -> [0,2q)   (dwthandler.h:202-356): moduli of 2^60 and above
         static SHL_HD void bfly_inv(elem &X, elem &Y, const tw_t &w, const Mod &m)
         {
             uint64_t s = X + Y, d = X + m.two_q - Y;
             X = guard(s, m);
             Y = mul_lazy(d, w, m);
         }
-        // last inverse stage with N^-1 folded in (dwthandler.h:273-314): ni = N^-1, nw = N^-1 * w
-        static SHL_HD void bfly_inv_last(elem &X, elem &Y, const tw_t &ni, const tw_t &nw, const Mod &m)
+        // last inverse stage with N^-1 folded in (dwthandler.h:273-314): ni = N^-1, nw = N^-1 * w; X, Y below c (a multiple of q,
+        // 2c <= 2^64); exact quotients, so that the results are in [0, 2q)
+        static SHL_HD void bfly_inv_last(elem &X, elem &Y, const tw_t &ni, const tw_t &nw, uint64_t c, const Mod &m)
         {
-            uint64_t s = X + Y, d = X + m.two_q - Y;
+            SEALHIP_NOWRAP(X, Y);
+            SEALHIP_NOWRAP(X, c);
+            uint64_t s = X + Y, d = X + c - Y;
             X = mul_lazy(s, ni, m);
             Y = mul_lazy(d, nw, m);
+        }
+        static SHL_HD void bfly_inv_last(elem &X, elem &Y, const tw_t &ni, const tw_t &nw, const Mod &m)
+        {
+            bfly_inv_last(X, Y, ni, nw, m.two_q, m);
         }
         static SHL_HD void fix(elem &, const Mod &)
         {}
@@ -304,6 +371,53 @@ namespace sealhip
         {
             return barrett128(a.lo, a.hi, m.md);
         }
+    };
+
+    // Compile-time range tracking for the integer back end.  ICLS = modulus class of a kernel body (decided per workgroup from
+    // the prime, one wave-uniform branch at the top of each kernel):
+    //   0 "tight"  2^58 <= q < 2^60: a word holds 16 q;   1 "roomy"  q < 2^58: 64 q (fix4()'s domain);   2 "wide"  q >= 2^60: the
+    //   reference's guarded butterflies, every value in the reference's own ranges.
+    // Forward: every value of a stage has the same bound B (in units of q), a stage adds 4: fix4() of all values before a stage
+    // whenever B + 4 would pass the limit.  Inverse: the sum doubles, the product is back to 4 - tracked per register as an
+    // exponent (the two operands of a butterfly always share their history inside a phase), see ntt2_kernels.hip.
+    template <int ICLS>
+    struct IntBounds
+    {
+        static constexpr bool wide = ICLS == 2;
+        static constexpr bool hi32 = ICLS == 0;           // fix4<true>: the class guarantees q >= 2^40
+        static constexpr int lim = ICLS == 0 ? 16 : 64;    // units of q
+        static constexpr int lim_exp = ICLS == 0 ? 4 : 6;  // log2(lim)
+        static constexpr bool fwd_fix_before(int b)
+        {
+            return !wide && b + 4 > lim;
+        }
+        static constexpr int fwd_after_stage(int b)
+        {
+            return wide ? 4 : (b + 4 > lim ? 4 : b) + 4;
+        }
+        static constexpr int fwd_after(int b, int stages)
+        {
+            for (int s = 0; s < stages; s++)
+                b = fwd_after_stage(b);
+            return b;
+        }
+        // exponent of register r of a phase before its stage number `idx`; the phase's stages pair register bits first_bit,
+        // first_bit + 1, ... (Gentleman-Sande order); every register enters with exponent e_in.  A butterfly whose operands are
+        // at the limit fixes them first (-> 2, i.e. 4 q).
+        static constexpr int inv_exp(int r, int idx, int first_bit, int e_in)
+        {
+            int cur = e_in;
+            for (int i = 0; i < idx; i++)
+            {
+                if (cur + 1 > lim_exp)
+                    cur = 2;
+                cur = ((r >> (first_bit + i)) & 1) ? 2 : cur + 1;
+            }
+            return cur;
+        }
+        // the exponent every register is brought under at the end of a phase, so that the next phase (other registers: the
+        // history is in the lane index there) starts from one known bound
+        static constexpr int inv_phase_out = lim_exp - 1;
     };
 
     // ---- double-precision back end (q < 2^50)

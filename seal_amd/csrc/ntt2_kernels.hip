@@ -26,6 +26,7 @@
 // the K(K+1) transformed digits never reach HBM in NTT form.
 #include "ntt2_kernels.h"
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 // minimum waves per SIMD requested for the double-precision-only forward kernels (register budget
@@ -59,21 +60,24 @@ namespace sealhip
         constexpr int kRowWords = 16 * 18;
         constexpr size_t kLds2Words = 16 * kRowWords;
 
-        // ks2 geometry of the double-precision targets: 256 threads x 16 coefficients (default) or lane order / 512 threads x 8
-        // coefficients (SEALHIP_KS2_V2=1).  Measured on MI355X at C5, batch 256 (profiles/r01_ks2_geometries.txt): the second
-        // geometry runs at four waves per SIMD instead of two and is 15 % SLOWER (11.2 vs 9.7 ms per step; 6.90 k vs 7.16 k ct/s):
-        // its second wave-local exchange and the per-stage LDS twiddle reads cost more than the occupancy returns.  Kept for
-        // further work; the switch decides the layout keys are uploaded in, hence process-wide and fixed.
-        inline bool ks2_lane_order()
+        // modulus class of the integer back end (field.h, IntBounds): 0 tight (2^58 <= q < 2^60), 1 roomy (q < 2^58), 2 wide
+        // (q >= 2^60: SEAL's 61-bit internal moduli, the BEHZ auxiliary base, keep the reference's guarded butterflies); wave-uniform
+        __device__ __forceinline__ int int_class(const NttTables &t, unsigned prime)
         {
-            static const bool v2 = std::getenv("SEALHIP_KS2_V2") != nullptr;
-            return v2;
+            const uint64_t q = SHL_UCONST(reinterpret_cast<const uint64_t *>(&t.mods[prime]))[0];
+            return (q >> 60) ? 2 : (q >> 58) ? 0 : 1;
         }
-
-        // moduli of 2^60 and above (SEAL's 61-bit internal moduli: the BEHZ auxiliary base) keep the reference's guarded forward butterflies (field.h); wave-uniform
-        __device__ __forceinline__ bool wide_modulus(const NttTables &t, unsigned prime)
+        // runs body(std::integral_constant<int, ICLS>) for the class of `prime`: one wave-uniform branch per kernel
+        template <class Body>
+        __device__ __forceinline__ void with_int_class(const NttTables &t, unsigned prime, Body body)
         {
-            return (SHL_UCONST(reinterpret_cast<const uint64_t *>(&t.mods[prime]))[0] >> 60) != 0;
+            const int c = int_class(t, prime);
+            if (c == 0)
+                body(std::integral_constant<int, 0>());
+            else if (c == 1)
+                body(std::integral_constant<int, 1>());
+            else
+                body(std::integral_constant<int, 2>());
         }
         template <bool FP>
         __device__ __forceinline__ const typename Field<FP>::tw_t *tw_table(const NttTables &t, bool inverse, unsigned prime)
@@ -84,12 +88,27 @@ namespace sealhip
                 return (inverse ? t.inv : t.fwd) + ((size_t)prime << t.log_n);
         }
 
+        template <int ICLS>
+        __device__ __forceinline__ void int_fix_all(uint64_t (&x)[16], const Field<false>::Mod &m)
+        {
+#pragma unroll
+            for (int a = 0; a < 16; a++)
+                Field<false>::fix4<IntBounds<ICLS>::hi32>(x[a], m);
+        }
+
         // One radix-2 stage over the 16 registers of a thread, pairing register-index bit BIT.
         // tw(g) supplies the twiddle of group g = e >> (BIT+1).
-        // GUARD (integer back end only): the reference's butterfly with its per-butterfly range guard (moduli of 2^60 and above)
-        template <bool FP, int BIT, bool GUARD = false, class TwFn>
+        // Integer back end: ICLS = modulus class, B = bound of every value before the stage in units of q (compile time); classes
+        // 0 / 1 run the unguarded 15-instruction butterfly (+ 4 q per stage) and bring all sixteen values back under 4 q first when
+        // the stage could pass the class's limit; class 2 runs the reference's butterfly with its per-butterfly range guard.
+        template <bool FP, int BIT, int ICLS = 0, int B = 4, class TwFn>
         __device__ __forceinline__ void stage_fwd(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {
+            if constexpr (!FP)
+            {
+                if constexpr (IntBounds<ICLS>::fwd_fix_before(B))
+                    int_fix_all<ICLS>(x, m);
+            }
 #pragma unroll
             for (int g = 0; g < (8 >> BIT); g++)
             {
@@ -98,7 +117,7 @@ namespace sealhip
                 for (int k = 0; k < (1 << BIT); k++)
                 {
                     const int e0 = (g << (BIT + 1)) | k;
-                    if constexpr (!FP && GUARD)
+                    if constexpr (!FP && ICLS == 2)
                         Field<FP>::bfly_fwd_guarded(x[e0], x[e0 | (1 << BIT)], w, m);
                     else
                         Field<FP>::bfly_fwd(x[e0], x[e0 | (1 << BIT)], w, m);
@@ -106,60 +125,65 @@ namespace sealhip
             }
         }
 
-        // R (<= 4) consecutive stages on register bits 3, 2, ...; twiddle of (stage t, group g) = tw(t, g)
-        template <bool FP, int R, bool GUARD = false, class TwFn>
+        // R (<= 4) consecutive stages on register bits 3, 2, ...; twiddle of (stage t, group g) = tw(t, g).  Integer back end:
+        // values enter below B q and leave below IntBounds<ICLS>::fwd_after(B, R) q.
+        template <bool FP, int R, int ICLS = 0, int B = 4, class TwFn>
         __device__ __forceinline__ void phase_fwd(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {
+            typedef IntBounds<ICLS> IB;
             if constexpr (R >= 1)
-                stage_fwd<FP, 3, GUARD>(x, m, [&](int g) { return tw(0, g); });
+                stage_fwd<FP, 3, ICLS, B>(x, m, [&](int g) { return tw(0, g); });
             if constexpr (R >= 2)
-                stage_fwd<FP, 2, GUARD>(x, m, [&](int g) { return tw(1, g); });
+                stage_fwd<FP, 2, ICLS, IB::fwd_after(B, 1)>(x, m, [&](int g) { return tw(1, g); });
             if constexpr (R >= 3)
-                stage_fwd<FP, 1, GUARD>(x, m, [&](int g) { return tw(2, g); });
+                stage_fwd<FP, 1, ICLS, IB::fwd_after(B, 2)>(x, m, [&](int g) { return tw(2, g); });
             if constexpr (R >= 4)
-                stage_fwd<FP, 0, GUARD>(x, m, [&](int g) { return tw(3, g); });
+                stage_fwd<FP, 0, ICLS, IB::fwd_after(B, 3)>(x, m, [&](int g) { return tw(3, g); });
         }
 
-        // A phase and the reduction that ends it.  Double precision: fix() of all 16 values when FIX.  Integer back end: for
-        // q < 2^60 the unguarded butterflies of field.h (+ 2 q per stage) and, when FIX, fwd_fix() back under 4 q; for the wider
-        // moduli SEAL uses internally (61 bits: the BEHZ auxiliary base) the reference's guarded butterflies, which
-        // keep [0, 4q) by themselves (WIDE).  One modulus per workgroup: the kernels branch once, at the top (wide_modulus()).
-        template <bool FP, int R, bool FIX, bool WIDE, class TwFn>
+        // A phase and the reduction that ends it.  Double precision: fix() of all 16 values when FIX.  Integer back end: FIX is
+        // ignored - the reductions are placed by the compile-time bound (stage_fwd), and the values leave below
+        // IntBounds<ICLS>::fwd_after(B, R) q, which the caller hands to whatever consumes them.
+        template <bool FP, int R, bool FIX, int ICLS = 0, int B = 4, class TwFn>
         __device__ __forceinline__ void phase_fwd_end(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {
-            if constexpr (FP)
+            phase_fwd<FP, R, ICLS, B>(x, m, tw);
+            if constexpr (FP && FIX)
             {
-                phase_fwd<FP, R>(x, m, tw);
-                if constexpr (FIX)
-                {
 #pragma unroll
-                    for (int a = 0; a < 16; a++)
-                        Field<FP>::fix(x[a], m);
-                }
-            }
-            else
-            {
-                if constexpr (WIDE)
-                    phase_fwd<FP, R, true>(x, m, tw);
-                else
-                {
-                    phase_fwd<FP, R>(x, m, tw);
-                    if constexpr (FIX)
-                    {
-#pragma unroll
-                        for (int a = 0; a < 16; a++)
-                            Field<FP>::fwd_fix(x[a], m);
-                    }
-                }
+                for (int a = 0; a < 16; a++)
+                    Field<FP>::fix(x[a], m);
             }
         }
+        // integer back end: a forward result below B q -> [0, 4q) (the reference's lazy output range) / -> [0, q)
+        template <bool FP, int ICLS, int B>
+        __device__ __forceinline__ uint64_t fwd_out_lazy(typename Field<FP>::elem x, const typename Field<FP>::Mod &m)
+        {
+            if constexpr (!FP && B > 4)
+                Field<FP>::template fix4<IntBounds<ICLS>::hi32>(x, m);
+            return Field<FP>::fwd_to_lazy(x, m);
+        }
+        template <bool FP, int ICLS, int B>
+        __device__ __forceinline__ uint64_t fwd_out_canon(typename Field<FP>::elem x, const typename Field<FP>::Mod &m)
+        {
+            if constexpr (!FP && ICLS != 2)
+                return Field<FP>::template canon_any<IntBounds<ICLS>::hi32>(x, m);
+            else
+                return Field<FP>::fwd_to_canon(x, m);
+        }
+        // bound (units of q) of the integer back end's values after pass 1 / after both passes of a forward transform whose
+        // input is below 4 q
+        template <int ICLS, int D1>
+        constexpr int kP1Out = IntBounds<ICLS>::fwd_after(4, D1);
+        template <int ICLS, int D1>
+        constexpr int kP2Out = IntBounds<ICLS>::fwd_after(kP1Out<ICLS, D1>, 8);
 
         // the same with one fix() of all 16 values after the first FIXAT stages of the phase (double-precision back end: the
         // "lean" placement of the key-switch kernels, see p1_tile)
         template <bool FP, int R, int FIXAT, class TwFn>
         __device__ __forceinline__ void phase_fwd_fix(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {
-            static_assert(R == 4 && FIXAT >= 1 && FIXAT <= 3, "a four-stage phase with the fix inside it");
+            static_assert(FP && R == 4 && FIXAT >= 1 && FIXAT <= 3, "a four-stage double-precision phase with the fix inside it");
             stage_fwd<FP, 3>(x, m, [&](int g) { return tw(0, g); });
             if constexpr (FIXAT == 1)
             {
@@ -185,7 +209,11 @@ namespace sealhip
         }
 
         // Inverse (Gentleman-Sande) counterparts: the stages of a phase are undone last-to-first.
-        template <bool FP, int BIT, class TwFn>
+        // Integer back end (classes 0 / 1): IDX = number of stages of this phase already undone, FB = register bit of the
+        // phase's first stage, EIN = exponent every register entered the phase with (values below 2^EIN q); the exponent of a
+        // register before this stage is IntBounds::inv_exp() - the two operands of a butterfly share it -, operands at the limit
+        // are brought under 4 q first, the difference is offset by 2^E q.
+        template <bool FP, int BIT, int ICLS = 2, int IDX = 0, int FB = 0, int EIN = 0, class TwFn>
         __device__ __forceinline__ void stage_inv(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {
 #pragma unroll
@@ -195,23 +223,86 @@ namespace sealhip
 #pragma unroll
                 for (int k = 0; k < (1 << BIT); k++)
                 {
-                    const int e0 = (g << (BIT + 1)) | k;
-                    Field<FP>::bfly_inv(x[e0], x[e0 | (1 << BIT)], w, m);
+                    const int e0 = (g << (BIT + 1)) | k, e1 = e0 | (1 << BIT);
+                    if constexpr (!FP && ICLS != 2)
+                    {
+                        typedef IntBounds<ICLS> IB;
+                        int E = IB::inv_exp(e0, IDX, FB, EIN);
+                        if (E + 1 > IB::lim_exp)
+                        {
+                            Field<FP>::template fix4<IB::hi32>(x[e0], m);
+                            Field<FP>::template fix4<IB::hi32>(x[e1], m);
+                            E = 2;
+                        }
+                        Field<FP>::bfly_inv_lazy(x[e0], x[e1], w, m.q << E, m);
+                    }
+                    else
+                        Field<FP>::bfly_inv(x[e0], x[e1], w, m);
                 }
             }
         }
-        // undo stages t = R-1 .. FIRST of a phase (FIRST = 1 leaves stage 0 to the caller)
-        template <bool FP, int R, int FIRST, class TwFn>
+        // exponent the integer back end's registers leave an inverse phase with: R stages from exponent EIN, first register bit FB,
+        // everything above IntBounds::inv_phase_out fixed at the end of the phase
+        template <int ICLS>
+        constexpr int inv_phase_exp(int ein, int stages, int fb)
+        {
+            if (ICLS == 2)
+                return 1; // the guarded butterflies keep [0, 2q)
+            int mx = 0;
+            for (int r = 0; r < 16; r++)
+            {
+                const int e = IntBounds<ICLS>::inv_exp(r, stages, fb, ein);
+                mx = e > mx ? e : mx;
+            }
+            return mx > IntBounds<ICLS>::inv_phase_out ? IntBounds<ICLS>::inv_phase_out : mx;
+        }
+        // undo stages t = R-1 .. FIRST of a phase (FIRST = 1 leaves stage 0 to the caller, together with the reduction it needs).
+        // Integer back end, FIRST = 0: the registers leave below 2^inv_phase_exp<ICLS>(EIN, R, 4 - R) q.
+        template <bool FP, int R, int FIRST, int ICLS = 2, int EIN = 0, class TwFn>
         __device__ __forceinline__ void phase_inv(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, TwFn tw)
         {
+            constexpr int FB = 4 - R;
             if constexpr (R >= 4 && FIRST <= 3)
-                stage_inv<FP, 0>(x, m, [&](int g) { return tw(3, g); });
+                stage_inv<FP, 0, ICLS, R - 4, FB, EIN>(x, m, [&](int g) { return tw(3, g); });
             if constexpr (R >= 3 && FIRST <= 2)
-                stage_inv<FP, 1>(x, m, [&](int g) { return tw(2, g); });
+                stage_inv<FP, 1, ICLS, R - 3, FB, EIN>(x, m, [&](int g) { return tw(2, g); });
             if constexpr (R >= 2 && FIRST <= 1)
-                stage_inv<FP, 2>(x, m, [&](int g) { return tw(1, g); });
+                stage_inv<FP, 2, ICLS, R - 2, FB, EIN>(x, m, [&](int g) { return tw(1, g); });
             if constexpr (R >= 1 && FIRST <= 0)
-                stage_inv<FP, 3>(x, m, [&](int g) { return tw(0, g); });
+                stage_inv<FP, 3, ICLS, R - 1, FB, EIN>(x, m, [&](int g) { return tw(0, g); });
+            if constexpr (!FP && ICLS != 2 && FIRST == 0)
+            {
+                typedef IntBounds<ICLS> IB;
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (IB::inv_exp(r, R, FB, EIN) > IB::inv_phase_out)
+                        Field<FP>::template fix4<IB::hi32>(x[r], m);
+            }
+        }
+        // the last inverse stage (register bit 3, N^-1 folded in) after a phase_inv<.., R, 1, ICLS, EIN>: operands at the limit are
+        // fixed first; results in [0, 2q) (exact quotients)
+        template <bool FP, int R, int ICLS, int EIN>
+        __device__ __forceinline__ void inv_last_stage(typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m,
+                                                       const typename Field<FP>::tw_t &ni, const typename Field<FP>::tw_t &nw)
+        {
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+            {
+                if constexpr (!FP && ICLS != 2)
+                {
+                    typedef IntBounds<ICLS> IB;
+                    int E = IB::inv_exp(k, R - 1, 4 - R, EIN);
+                    if (E + 1 > IB::lim_exp)
+                    {
+                        Field<FP>::template fix4<IB::hi32>(x[k], m);
+                        Field<FP>::template fix4<IB::hi32>(x[k | 8], m);
+                        E = 2;
+                    }
+                    Field<FP>::bfly_inv_last(x[k], x[k | 8], ni, nw, m.q << E, m);
+                }
+                else
+                    Field<FP>::bfly_inv_last(x[k], x[k | 8], ni, nw, m);
+            }
         }
 
         // The 15 twiddles of a 4-stage phase held in registers: slot (1<<t)+g.
@@ -285,14 +376,13 @@ namespace sealhip
         // ---------------------------------------------------------------------------------------
         // BS = words between consecutive 256-word blocks of the tile-order intermediate (256 in HBM; 272 when the
         // intermediate lives in LDS, so that the 16-lane runs of one wave instruction fall on different banks)
-        // ORDER 1 ("lane order", for ks2_v2): coefficient (row h = 16 hg + u, column c) at hg*4096 + (c >> 5)*512 + u*32 + (c & 31),
-        // so that the 512 threads (u, l = c & 31) of the 8-coefficients-per-thread pass 2 read eight fully coalesced 4 KiB rows
         // LEAN (double-precision back end, N = 2^16, key switching): with balanced twiddles a magnitude B q grows to
         // (1.1875 B + 0.5) q per stage (field.h), 0.5 -> 1.09 -> 1.80 -> 2.64 -> 3.63 -> 4.81 -> 6.21 -> 7.88 over seven stages
         // (< 8 q <= 2^53: still exact).  The sixteen stages of a raised digit therefore need a fix() after global stage 7 (here,
         // inside phase B) and after stage 14 (p2_tile) only: the input must come in with |x| <= q/2, the intermediate leaves
         // with |x| <= 1.09 q, unfixed.
-        template <bool FP, int D1, int BS = 256, int ORDER = 0, bool LEAN = false, bool WIDE = false>
+        // Integer back end: ICLS = modulus class; the sixteen values enter below 4 q and leave below kP1Out<ICLS, D1> q.
+        template <bool FP, int D1, int BS = 256, bool LEAN = false, int ICLS = 0>
         __device__ __forceinline__ void p1_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const TwRegs<FP> &tw, uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
@@ -304,9 +394,7 @@ namespace sealhip
             if constexpr (G::rA > 0)
             {
                 // phase A: register a = ra*2^(4-rA) + rbh; stage s pairs register bit 3-s; twiddle 2^s + group: uniform
-                // integer back end (field.h, bfly_fwd): input below 4 q, + 2 q per stage, 16 q fit a word: short first phases
-                // (rA <= 2: 4 + 2 (rA + 4) <= 16) run on into phase B
-                phase_fwd_end<FP, G::rA, FP ? !LEAN : (G::rA > 2), WIDE>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
+                phase_fwd_end<FP, G::rA, !LEAN, ICLS, 4>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
                 __syncthreads(); // previous users of the exchange buffer are done
 #pragma unroll
                 for (int a = 0; a < 16; a++)
@@ -329,25 +417,15 @@ namespace sealhip
             }
             else
             {
-                // the intermediate is stored with |x| <= q/2 resp. in [0, 4q)
-                phase_fwd_end<FP, 4, true, WIDE>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                // the intermediate is stored with |x| <= q/2 resp. below kP1Out<ICLS, D1> q
+                phase_fwd_end<FP, 4, true, ICLS, IntBounds<ICLS>::fwd_after(4, G::rA)>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
             const unsigned col = cg * G::C + c;
-            if constexpr (ORDER == 1)
-            {
-                uint64_t *o = mid_tr + ((size_t)hi << 12) + (size_t)(col >> 5) * 512 + (col & 31);
+            uint64_t *o = mid_tr + (size_t)(hi * 16 + (col >> 4)) * BS + (col & 15);
 #pragma unroll
-                for (int rb = 0; rb < 16; rb++)
-                    o[rb * 32] = F::raw(x[rb]);
-            }
-            else
-            {
-                uint64_t *o = mid_tr + (size_t)(hi * 16 + (col >> 4)) * BS + (col & 15);
-#pragma unroll
-                for (int rb = 0; rb < 16; rb++)
-                    o[rb * 16] = F::raw(x[rb]);
-            }
+            for (int rb = 0; rb < 16; rb++)
+                o[rb * 16] = F::raw(x[rb]);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -386,7 +464,10 @@ namespace sealhip
         // of phase B (global stage 14: 7.88 q -> q/2), none at the end: the values leave with |x| <= 1.80 q, which the key
         // products take (|x k mod q| <= q (1/2 + 3/16 * 1.8) = 0.84 q with balanced key words; eight terms on top of a fixed
         // accumulator stay below 7.2 q)
-        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false, bool LEAN = false, bool WIDE = false>
+        // Integer back end: ICLS = modulus class, BIN = bound of the loaded values in units of q (kP1Out<ICLS, D1> for an
+        // intermediate written by p1_tile); they leave below IntBounds<ICLS>::fwd_after(BIN, 8) q.
+        template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false, bool LEAN = false, int ICLS = 0,
+                  int BIN = 4>
         __device__ __forceinline__ void p2_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const typename Field<FP>::tw_t *twa, const typename Field<FP>::tw_t *twb, uint64_t *lds_wave, unsigned hg, unsigned tid,
@@ -398,16 +479,16 @@ namespace sealhip
             const unsigned ul = u & 3; // row inside this wave's buffer
             if constexpr (HOIST && !TWA_LDS)
             {
-                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return pre_a->get((1 << t) + g); });
+                phase_fwd_end<FP, 4, !LEAN, ICLS, BIN>(x, m, [&](int t, int g) { return pre_a->get((1 << t) + g); });
             }
             else if constexpr ((LOWREG || HOIST) && (TW_LDS || TWA_LDS))
             {
-                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
+                phase_fwd_end<FP, 4, !LEAN, ICLS, BIN>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
             }
             else if constexpr (LOWREG)
             {
                 // register-lean variant: each twiddle is fetched where it is used
-                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return tab[(1u << (D1 + t)) + (h << t) + g]; });
+                phase_fwd_end<FP, 4, !LEAN, ICLS, BIN>(x, m, [&](int t, int g) { return tab[(1u << (D1 + t)) + (h << t) + g]; });
             }
             else
             {
@@ -416,7 +497,7 @@ namespace sealhip
                     load_tw<FP, 4>(tw, twa, [&](int t) { return (16u << t) - 16u + (u << t); });
                 else
                     load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + t)) + (h << t); });
-                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                phase_fwd_end<FP, 4, !LEAN, ICLS, BIN>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
             // wave-local exchange: (e, v) -> (v', e')
 #pragma unroll
@@ -434,9 +515,10 @@ namespace sealhip
                 }
             }
             __builtin_amdgcn_wave_barrier(); // the buffer may be rewritten by the caller's next tile
+            constexpr int BMID = IntBounds<ICLS>::fwd_after(BIN, 4);
             if constexpr (HOIST)
             {
-                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return pre_b->get((1 << t) + g); });
+                phase_fwd_end<FP, 4, !LEAN, ICLS, BMID>(x, m, [&](int t, int g) { return pre_b->get((1 << t) + g); });
             }
             else if constexpr (LOWREG && TW_LDS)
             {
@@ -444,11 +526,11 @@ namespace sealhip
                 if constexpr (LEAN)
                     phase_fwd_fix<FP, 4, 2>(x, m, twf);
                 else
-                    phase_fwd_end<FP, 4, true, WIDE>(x, m, twf);
+                    phase_fwd_end<FP, 4, true, ICLS, BMID>(x, m, twf);
             }
             else if constexpr (LOWREG)
             {
-                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return tab[(1u << (D1 + 4 + t)) + ((h * 16 + v) << t) + g]; });
+                phase_fwd_end<FP, 4, !LEAN, ICLS, BMID>(x, m, [&](int t, int g) { return tab[(1u << (D1 + 4 + t)) + ((h * 16 + v) << t) + g]; });
             }
             else
             {
@@ -463,7 +545,7 @@ namespace sealhip
                 }
                 else
                     load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
-                phase_fwd_end<FP, 4, !LEAN, WIDE>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                phase_fwd_end<FP, 4, !LEAN, ICLS, BMID>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
             static_assert(!LEAN || (FP && LOWREG && TW_LDS), "the lean placement is wired for the double-precision ks2 variant only");
         }
@@ -566,7 +648,7 @@ namespace sealhip
             NttTables t;
         };
 
-        template <bool FP, int D1, bool WIDE = false>
+        template <bool FP, int D1, int ICLS = 0>
         __device__ __forceinline__ void fwd_p1_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -617,7 +699,7 @@ namespace sealhip
                 if (outer + ostride < a.nouter)
                     fetch(outer + ostride);
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
-                p1_tile<FP, D1, 256, 0, false, WIDE>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1, 256, false, ICLS>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
         }
 
@@ -632,16 +714,11 @@ namespace sealhip
             if constexpr (CLS == 1)
                 fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
-            {
-                if (wide_modulus(a.t, prime))
-                    fwd_p1_body<false, D1, true>(a, prime, comp, outer, lds);
-                else
-                    fwd_p1_body<false, D1>(a, prime, comp, outer, lds);
-            }
+                with_int_class(a.t, prime, [&](auto ic) { fwd_p1_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
             else if (a.t.fpd[prime].qi)
                 fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
             else
-                fwd_p1_body<false, D1, true>(a, prime, comp, outer, lds); // mixed launches keep the guarded butterflies
+                fwd_p1_body<false, D1, 2>(a, prime, comp, outer, lds); // mixed launches keep the guarded butterflies
         }
 
         // HOIST (plain transforms of the double-precision back end, no epilogue): the tile's 30 twiddles stay in
@@ -650,7 +727,7 @@ namespace sealhip
         // only here.
         // HOIST_LDS (CLS 4): the row-shared phase-A twiddles are staged once in LDS and only the 15 per-thread phase-B twiddles
         // stay in registers: the same "no twiddle is re-read per transform" at 128 VGPRs (four waves per SIMD) instead of 214 (two)
-        template <bool FP, int D1, bool HOIST = false, bool HOIST_LDS = false, bool WIDE = false>
+        template <bool FP, int D1, bool HOIST = false, bool HOIST_LDS = false, int ICLS = 0>
         __device__ __forceinline__ void fwd_p2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -696,14 +773,15 @@ namespace sealhip
             else if constexpr (HOIST)
                 p2_tile<FP, D1, false, false, true>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid, &pre_a, &pre_b);
             else
-                p2_tile<FP, D1, false, false, false, false, false, WIDE>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
+                p2_tile<FP, D1, false, false, false, false, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
+            constexpr int BOUT = kP2Out<ICLS, D1>; // integer back end: bound of the results
             uint64_t val[16];
             const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
             if ((HOIST || HOIST_LDS) || a.epi == 0) // the hoisted variants are launched for plain transforms only
             {
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    val[e] = a.lazy ? F::fwd_to_lazy(x[e], m) : F::fwd_to_canon(x[e], m);
+                    val[e] = a.lazy ? fwd_out_lazy<FP, ICLS, BOUT>(x[e], m) : fwd_out_canon<FP, ICLS, BOUT>(x[e], m);
                 store_rows(val, lds_wave, a.data + (size_t)outer * a.outer_stride + row0, tid);
             }
             else
@@ -711,7 +789,7 @@ namespace sealhip
                 // fused tail: the transform is consumed here and never stored
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    val[e] = F::fwd_to_lazy(x[e], m); // < 4q
+                    val[e] = fwd_out_lazy<FP, ICLS, BOUT>(x[e], m); // < 4q
                 const uint64_t q = a.t.mods[prime].q;
                 const ShoupOp mul = a.epi_mul[comp];
                 const uint64_t *A = a.epi_a + (size_t)outer * a.epi_a_stride + row0;
@@ -744,16 +822,11 @@ namespace sealhip
             else if constexpr (CLS == 1)
                 fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
-            {
-                if (wide_modulus(a.t, prime))
-                    fwd_p2_body<false, D1, false, false, true>(a, prime, comp, outer, lds);
-                else
-                    fwd_p2_body<false, D1>(a, prime, comp, outer, lds);
-            }
+                with_int_class(a.t, prime, [&](auto ic) { fwd_p2_body<false, D1, false, false, decltype(ic)::value>(a, prime, comp, outer, lds); });
             else if (a.t.fpd[prime].qi)
                 fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
             else
-                fwd_p2_body<false, D1, false, false, true>(a, prime, comp, outer, lds);
+                fwd_p2_body<false, D1, false, false, 2>(a, prime, comp, outer, lds);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -767,7 +840,7 @@ namespace sealhip
             NttTail2 x;
         };
 
-        template <bool FP, int D1, bool WIDE>
+        template <bool FP, int D1, int ICLS>
         __device__ __forceinline__ void tail2_p1_body(const Tail2Args &t2, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -815,11 +888,11 @@ namespace sealhip
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
                 // double precision, eight stages: x is fixed (|x| <= q/2), so one fix() after stage 7 does (p1_tile, LEAN); the
                 // intermediate leaves at 1.09 q, which pass 2's first phase takes (-> 4.81 q)
-                p1_tile<FP, D1, 256, 0, FP && G::rA == 4, WIDE>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1, 256, FP && G::rA == 4, ICLS>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
         }
 
-        template <bool FP, int D1, bool WIDE>
+        template <bool FP, int D1, int ICLS>
         __device__ __forceinline__ void tail2_p2_body(const Tail2Args &t2, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -861,11 +934,11 @@ namespace sealhip
                     av[k] = A[off];
                     cv[k] = C[off];
                 }
-                p2_tile<FP, D1, false, false, false, false, false, WIDE>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
+                p2_tile<FP, D1, false, false, false, false, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
                 uint64_t val[16];
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    val[e] = F::fwd_to_lazy(x[e], m); // < 4q
+                    val[e] = fwd_out_lazy<FP, ICLS, kP2Out<ICLS, D1>>(x[e], m); // < 4q
                 uint64_t *O = ((outer & 1) ? a.epi_out1 : a.epi_out0) + (size_t)(outer >> 1) * a.epi_out_stride + row0;
                 emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t tv) {
                     const uint64_t s = add_mod(mul_shoup(av[k], pm.w, pm.wq, q), cv[k], q); // c + S P^-1, canonical
@@ -882,18 +955,13 @@ namespace sealhip
             const unsigned comp = blockIdx.y + a.f.comp0, outer = blockIdx.z;
             const unsigned prime = SHL_UNIFORM(a.f.prime_first + comp);
             if constexpr (CLS == 1)
-                tail2_p1_body<true, D1, false>(a, prime, comp, outer, lds);
+                tail2_p1_body<true, D1, 0>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
-            {
-                if (wide_modulus(a.f.t, prime))
-                    tail2_p1_body<false, D1, true>(a, prime, comp, outer, lds);
-                else
-                    tail2_p1_body<false, D1, false>(a, prime, comp, outer, lds);
-            }
+                with_int_class(a.f.t, prime, [&](auto ic) { tail2_p1_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
             else if (a.f.t.fpd[prime].qi)
-                tail2_p1_body<true, D1, false>(a, prime, comp, outer, lds);
+                tail2_p1_body<true, D1, 0>(a, prime, comp, outer, lds);
             else
-                tail2_p1_body<false, D1, true>(a, prime, comp, outer, lds);
+                tail2_p1_body<false, D1, 2>(a, prime, comp, outer, lds);
         }
         template <int D1, int CLS>
         __global__ void __launch_bounds__(kThreads, 2) ntt2_tail2_p2(Tail2Args a)
@@ -902,95 +970,13 @@ namespace sealhip
             const unsigned comp = blockIdx.y + a.f.comp0, outer = blockIdx.z;
             const unsigned prime = SHL_UNIFORM(a.f.prime_first + comp);
             if constexpr (CLS == 1)
-                tail2_p2_body<true, D1, false>(a, prime, comp, outer, lds);
+                tail2_p2_body<true, D1, 0>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
-            {
-                if (wide_modulus(a.f.t, prime))
-                    tail2_p2_body<false, D1, true>(a, prime, comp, outer, lds);
-                else
-                    tail2_p2_body<false, D1, false>(a, prime, comp, outer, lds);
-            }
+                with_int_class(a.f.t, prime, [&](auto ic) { tail2_p2_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
             else if (a.f.t.fpd[prime].qi)
-                tail2_p2_body<true, D1, false>(a, prime, comp, outer, lds);
+                tail2_p2_body<true, D1, 0>(a, prime, comp, outer, lds);
             else
-                tail2_p2_body<false, D1, true>(a, prime, comp, outer, lds);
-        }
-
-        // ---------------------------------------------------------------------------------------
-        // N = 2^13: both passes in ONE launch with the intermediate in LDS (the transform is 64 KiB).
-        // A workgroup of 512 threads = two teams of 256; team k runs pass 1 on column tile k, the
-        // teams meet at a barrier, team k runs pass 2 on row tile k: every coefficient crosses HBM
-        // once in each direction (algorithmic traffic) instead of twice.  Plain in-place transforms
-        // only; the mapped-source and epilogue variants stay on the two-launch engine.
-        // ---------------------------------------------------------------------------------------
-        constexpr int kFusedD1 = 5;
-        constexpr int kFusedBS = 272;                                           // padded block of the LDS intermediate
-        constexpr size_t kFusedMidWords = (size_t)Geo<kFusedD1>::TILES * 16 * kFusedBS;
-        constexpr size_t kFusedTeamWords = kLds2Words > Geo<kFusedD1>::lds1_words ? kLds2Words : Geo<kFusedD1>::lds1_words;
-        constexpr size_t kFusedLdsBytes = (kFusedMidWords + Geo<kFusedD1>::TILES * kFusedTeamWords) * 8;
-
-        template <bool FP>
-        __device__ __forceinline__ void fwd_fused_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
-        {
-            typedef Field<FP> F;
-            constexpr int D1 = kFusedD1;
-            typedef Geo<D1> G;
-            const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
-            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
-            const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
-            uint64_t *mid = lds;
-            uint64_t *scratch = lds + kFusedMidWords + team * kFusedTeamWords;
-            uint64_t *lds_wave = scratch + (tid >> 6) * (4 * kRowWords);
-            const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
-            uint64_t *base = a.data + ((size_t)comp << G::n);
-            TwRegs<FP> tw;
-            p1_load_tw<FP, D1>(tw, tab, tid);
-            uint64_t nxt[16];
-            auto fetch = [&](unsigned z) {
-                const uint64_t *in = base + (size_t)z * a.outer_stride + team * G::C + c;
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                {
-                    const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
-                    const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
-                    nxt[e] = in[(size_t)R * 256];
-                }
-            };
-            const unsigned ostride = gridDim.z;
-            fetch(outer);
-            for (; outer < a.nouter; outer += ostride)
-            {
-                typename F::elem x[16];
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    x[e] = F::from_canon(nxt[e], m);
-                if (outer + ostride < a.nouter)
-                    fetch(outer + ostride);
-                // pass 1 on column tile `team` -> LDS intermediate (p1_tile synchronises the workgroup around its exchange)
-                p1_tile<FP, D1, kFusedBS>(x, m, tab, tw, scratch, mid, team, tid);
-                __syncthreads();
-                // pass 2 on row tile `team`
-                const uint64_t *mp = mid + (size_t)(team * 16) * kFusedBS + tid;
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    x[e] = F::unraw(mp[e * kFusedBS]);
-                p2_tile<FP, D1, false>(x, m, tab, nullptr, nullptr, lds_wave, team, tid);
-                uint64_t val[16];
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    val[e] = a.lazy ? F::fwd_to_lazy(x[e], m) : F::fwd_to_canon(x[e], m);
-                store_rows(val, lds_wave, base + (size_t)outer * a.outer_stride + ((size_t)(team * 16 + (tid >> 6) * 4) << 8), tid);
-                __syncthreads(); // the intermediate and the exchange buffers are free again
-            }
-        }
-
-        // double-precision back end only: the integer butterflies do not fit 256 VGPRs next to the prefetch
-        __global__ void __launch_bounds__(2 * kThreads) ntt2_fwd_fused(FwdArgs a)
-        {
-            HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
-            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
-            fwd_fused_body<true>(a, prime, comp, outer, lds);
+                tail2_p2_body<false, D1, 2>(a, prime, comp, outer, lds);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1014,7 +1000,16 @@ namespace sealhip
             NttTables t;
         };
 
-        template <bool FP, int D1>
+        // exponents (IntBounds) of the integer back end between the phases of an inverse transform with canonical input:
+        // after pass A's two phases, after pass B's first phase
+        template <int ICLS>
+        constexpr int kInvE1 = inv_phase_exp<ICLS>(0, 4, 0);
+        template <int ICLS>
+        constexpr int kInvE2 = inv_phase_exp<ICLS>(kInvE1<ICLS>, 4, 0);
+        template <int ICLS>
+        constexpr int kInvE3 = inv_phase_exp<ICLS>(kInvE2<ICLS>, 4, 0);
+
+        template <bool FP, int D1, int ICLS = 2>
         __device__ __forceinline__ void inv_pa_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -1037,7 +1032,7 @@ namespace sealhip
             {
                 TwRegs<FP> tw;
                 load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
-                phase_inv<FP, 4, 0>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                phase_inv<FP, 4, 0, ICLS, 0>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
 #pragma unroll
             for (int e = 0; e < 16; e++)
@@ -1053,7 +1048,7 @@ namespace sealhip
             {
                 TwRegs<FP> tw;
                 load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (D1 + t)) + (h << t); });
-                phase_inv<FP, 4, 0>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                phase_inv<FP, 4, 0, ICLS, kInvE1<ICLS>>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
 #pragma unroll
             for (int e = 0; e < 16; e++)
@@ -1073,14 +1068,14 @@ namespace sealhip
             if constexpr (CLS == 1)
                 inv_pa_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
-                inv_pa_body<false, D1>(a, prime, comp, outer, lds);
+                with_int_class(a.t, prime, [&](auto ic) { inv_pa_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
             else if (a.t.fpd[prime].qi)
                 inv_pa_body<true, D1>(a, prime, comp, outer, lds);
             else
-                inv_pa_body<false, D1>(a, prime, comp, outer, lds);
+                inv_pa_body<false, D1, 2>(a, prime, comp, outer, lds); // mixed launches keep the guarded butterflies
         }
 
-        template <bool FP, int D1>
+        template <bool FP, int D1, int ICLS = 2>
         __device__ __forceinline__ void inv_pb_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
             typedef Field<FP> F;
@@ -1099,7 +1094,7 @@ namespace sealhip
             {
                 TwRegs<FP> tw;
                 load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (G::rA + t)) + (hi << t); });
-                phase_inv<FP, 4, 0>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                phase_inv<FP, 4, 0, ICLS, kInvE2<ICLS>>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
 #pragma unroll
             for (int e = 0; e < 16; e++)
@@ -1116,7 +1111,7 @@ namespace sealhip
                 x[e] = F::unraw(lds[R * G::CP + c]);
             }
             // phase A undone: stages rA-1 .. 1 with uniform twiddles, then stage 0 with N^-1 folded in
-            phase_inv<FP, G::rA, 1>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
+            phase_inv<FP, G::rA, 1, ICLS, kInvE3<ICLS>>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
             {
                 typename F::tw_t ni, nw;
                 if constexpr (FP)
@@ -1129,9 +1124,7 @@ namespace sealhip
                     ni = ld_uniform(a.t.ninv, 2 * prime);
                     nw = ld_uniform(a.t.ninv, 2 * prime + 1);
                 }
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    F::bfly_inv_last(x[k], x[k | 8], ni, nw, m);
+                inv_last_stage<FP, G::rA, ICLS, kInvE3<ICLS>>(x, m, ni, nw);
             }
             uint64_t *o = a.data + (size_t)outer * a.outer_stride + ((size_t)comp << G::n);
 #pragma unroll
@@ -1156,17 +1149,17 @@ namespace sealhip
             if constexpr (CLS == 1)
                 inv_pb_body<true, D1>(a, prime, comp, outer, lds);
             else if constexpr (CLS == 0)
-                inv_pb_body<false, D1>(a, prime, comp, outer, lds);
+                with_int_class(a.t, prime, [&](auto ic) { inv_pb_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
             else if (a.t.fpd[prime].qi)
                 inv_pb_body<true, D1>(a, prime, comp, outer, lds);
             else
-                inv_pb_body<false, D1>(a, prime, comp, outer, lds);
+                inv_pb_body<false, D1, 2>(a, prime, comp, outer, lds);
         }
 
         // ---------------------------------------------------------------------------------------
         // Single-launch transforms, second generation: N = 2^13 (two teams of 256 threads) and N = 2^14
         // (four teams), double-precision back end.  Every coefficient crosses HBM once in each direction.
-        // Against ntt2_fwd_fused:
+        // Against a first generation that kept the intermediate and the exchange buffers side by side (140 KiB, one workgroup per CU):
         //  * the tile-order intermediate, pass 1's exchange buffer and pass 2's wave-local exchange buffers
         //    are the SAME LDS area used one after the other (one more barrier per transform): 76 KiB per
         //    workgroup at N = 2^13, so two workgroups share a CU (four waves per SIMD) instead of one;
@@ -1184,7 +1177,7 @@ namespace sealhip
             static_assert(G::LC >= 6, "pass 1's phase-B row index must be wave-uniform");
             static_assert(G::lds1_words <= kLds2Words, "pass 1's exchange buffer lives in the team's pass-2 area");
             static constexpr int TEAMS = G::TILES;
-            static constexpr int BS = 272; // padded 256-word block of the intermediate (as kFusedBS)
+            static constexpr int BS = 272; // padded 256-word block of the LDS intermediate: the 16-lane runs of pass 1 fall on different banks
             static constexpr size_t mid_words = (size_t)TEAMS * 16 * BS;
             static constexpr size_t xch_words = (size_t)TEAMS * kLds2Words;
             static constexpr size_t main_words = mid_words > xch_words ? mid_words : xch_words;
@@ -1427,11 +1420,11 @@ namespace sealhip
         // The key-switch kernels of N = 2^16 (eight stages per pass) use the lean fix() placement of p1_tile / p2_tile (tile-order
         // intermediate only; the lane-order geometry keeps its own).  SEALHIP_KS_LEAN_OFF at build time restores five fix() per pair.
 #ifdef SEALHIP_KS_LEAN_OFF
-        template <int D1, int ORDER>
+        template <int D1>
         constexpr bool kLeanKs = false;
 #else
-        template <int D1, int ORDER>
-        constexpr bool kLeanKs = D1 == 8 && ORDER == 0;
+        template <int D1>
+        constexpr bool kLeanKs = D1 == 8;
 #endif
 
         // ---------------------------------------------------------------------------------------
@@ -1452,7 +1445,7 @@ namespace sealhip
             NttTables tb;
         };
 
-        template <bool FP, int D1, int ORDER, bool WIDE = false>
+        template <bool FP, int D1, int ICLS = 0>
         __device__ __forceinline__ void ks1_body(const Ks1Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned b, unsigned cg, unsigned j0, unsigned j1)
         {
             typedef Field<FP> F;
@@ -1492,7 +1485,7 @@ namespace sealhip
                         for (int e = 0; e < 16; e++)
                         {
                             x[e] = F::from_any(nxt[e], m); // magnitude < q + 2^32
-                            if constexpr (kLeanKs<D1, ORDER>)
+                            if constexpr (kLeanKs<D1>)
                                 F::fix(x[e], m); // the lean placement starts from |x| <= q/2
                         }
                     }
@@ -1529,15 +1522,14 @@ namespace sealhip
                 if (Jn < j1)
                     fetch(Jn);
                 uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
-                p1_tile<FP, D1, 256, ORDER, FP && kLeanKs<D1, ORDER>, WIDE>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1, 256, FP && kLeanKs<D1>, ICLS>(x, m, tab, tw, lds, mid_tr, cg, tid);
                 J = Jn;
             }
         }
 
         // One launch per arithmetic back end: the double-precision body needs ~127 VGPRs (4 waves per
         // SIMD), the integer body ~214 (2 waves); a merged kernel would run both at the lower occupancy.
-        // ORDER: layout of the intermediate (p1_tile): 0 tile order (ks2_kernel), 1 lane order (ks2v2_kernel)
-        template <bool FP, int D1, int ORDER = 0>
+        template <bool FP, int D1>
         __global__ void __launch_bounds__(kThreads) ks1_kernel(Ks1Args a)
         {
             typedef Geo<D1> G;
@@ -1556,11 +1548,9 @@ namespace sealhip
             const unsigned j0 = a.j0 + dg * jlen, j1 = j0 + jlen < a.j1 ? j0 + jlen : a.j1;
             const unsigned I = SHL_UNIFORM(a.targets[2 * it]), prime = SHL_UNIFORM(a.targets[2 * it + 1]);
             if constexpr (FP)
-                ks1_body<FP, D1, ORDER>(a, lds, I, prime, b, cg, j0, j1);
-            else if (wide_modulus(a.tb, prime))
-                ks1_body<FP, D1, ORDER, true>(a, lds, I, prime, b, cg, j0, j1);
+                ks1_body<FP, D1>(a, lds, I, prime, b, cg, j0, j1);
             else
-                ks1_body<FP, D1, ORDER>(a, lds, I, prime, b, cg, j0, j1);
+                with_int_class(a.tb, prime, [&](auto ic) { ks1_body<FP, D1, decltype(ic)::value>(a, lds, I, prime, b, cg, j0, j1); });
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1586,7 +1576,7 @@ namespace sealhip
             NttTables tb;
         };
 
-        template <bool FP, int D1, bool WIDE = false>
+        template <bool FP, int D1, int ICLS = 0>
         __device__ __forceinline__ void ks2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg,
                                                  unsigned j0, unsigned j1, uint64_t *acc_part)
         {
@@ -1707,14 +1697,14 @@ namespace sealhip
                 }
                 if (!is_diag)
                 {
-                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1, 0>, WIDE>(x, m, tab, twa, twb, lds_wave, hg, tid);
+                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1>, ICLS, kP1Out<ICLS, D1>>(x, m, tab, twa, twb, lds_wave, hg, tid);
                     // integer back end: 128-bit sums of x * key.  q < 2^60: x < 4 q < 2^62 and key < 2^60 give terms below 2^122,
                     // and SEAL's 64 moduli at most (63 digits) stay below 2^128 - no need to canonicalise x; 61-bit moduli do
-                    if constexpr (!FP && WIDE)
+                    if constexpr (!FP)
                     {
 #pragma unroll
                         for (int e = 0; e < 16; e++)
-                            x[e] = F::fwd_to_canon(x[e], m);
+                            x[e] = ICLS == 2 ? F::fwd_to_canon(x[e], m) : fwd_out_lazy<FP, ICLS, kP2Out<ICLS, D1>>(x[e], m);
                     }
                 }
                 if constexpr (FP)
@@ -1781,219 +1771,13 @@ namespace sealhip
             const unsigned I = SHL_UNIFORM(a.targets[3 * it]), prime = SHL_UNIFORM(a.targets[3 * it + 1]), kc = SHL_UNIFORM(a.targets[3 * it + 2]);
             if constexpr (CLS == 1)
                 ks2_body<true, D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
-            else if (wide_modulus(a.tb, prime))
-                ks2_body<false, D1, true>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
             else
-                ks2_body<false, D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
-        }
-
-        // ---------------------------------------------------------------------------------------
-        // ks2, second geometry (double-precision targets): the same tile of 16 rows x 256 columns, but 512 threads with EIGHT
-        // coefficients each, so that x, the two running sums, the prefetched digit and the key words of a thread are 96 registers
-        // instead of 192 and a SIMD holds four waves instead of two.  Eight stages = three register phases (3 + 3 + 2 stages) with
-        // two wave-local exchanges (the 32 lanes that own a row sit in one wavefront: no s_barrier):
-        //   phase A: thread (u, l) holds columns c = l + 32 k      (register bits = column bits 5,6,7)   stages D1+0..2
-        //   phase B: thread (u, l) holds c = (l & 3) + 4 j + 32 (l >> 2)   (bits 2,3,4)                 stages D1+3..5
-        //   phase C: thread (u, l) holds c = 8 l + m               (bits 0,1,2)                          stages D1+6..7
-        // and ends with 8 contiguous coefficients per thread, which is also the order of the key words ("lane register order":
-        // position hg*4096 + m*512 + tid <-> natural hg*4096 + tid*8 + m).  The intermediate comes in p1_tile's ORDER 1.
-        // LDS: per wave two rows of 256 words (padded) for the exchanges, per workgroup the tile's 16 x 255 twiddles.
-        // ---------------------------------------------------------------------------------------
-        constexpr int kV2Threads = 512;
-        constexpr int kV2RowWords = 256 + 32;                      // 4 pad words per 32 columns
-        constexpr size_t kV2XchWords = (size_t)16 * kV2RowWords;   // 16 rows
-        constexpr int kV2TwPerRow = 7 + 56 + 192;                  // stages 0-2 | 3-5 | 6-7
-        constexpr size_t kV2LdsBytes = (kV2XchWords + (size_t)16 * kV2TwPerRow) * 8;
-        __device__ __forceinline__ unsigned v2_pad(unsigned c)
-        {
-            return c + ((c >> 5) << 2);
-        }
-        // one radix-2 stage over the 8 registers of a thread, pairing register bit BIT; tw(g) = twiddle of group g = e >> (BIT+1)
-        template <int BIT, class TwFn>
-        __device__ __forceinline__ void stage8_fwd(double (&x)[8], const FpDesc &m, TwFn tw)
-        {
-#pragma unroll
-            for (int g = 0; g < (4 >> BIT); g++)
-            {
-                const double w = tw(g);
-#pragma unroll
-                for (int k = 0; k < (1 << BIT); k++)
-                {
-                    const int e0 = (g << (BIT + 1)) | k;
-                    Field<true>::bfly_fwd(x[e0], x[e0 | (1 << BIT)], w, m);
-                }
-            }
-        }
-
-        template <int D1>
-        __device__ __forceinline__ void ks2v2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg,
-                                                   unsigned j0, unsigned j1, uint64_t *acc_part)
-        {
-            typedef Field<true> F;
-            typedef Geo<D1> G;
-            const unsigned tid = threadIdx.x, u = tid >> 5, l = tid & 31;
-            const unsigned h = hg * 16 + u;
-            const F::Mod m = F::make_mod(ld_uniform_mod(&a.tb.mods[prime]), ld_uniform_fpd(&a.tb.fpd[prime]));
-            const double *tab = tw_table<true>(a.tb, false, prime);
-            // this row's exchange buffer (the two rows of a wave are touched by that wave only) and twiddles
-            uint64_t *row = lds + (size_t)u * kV2RowWords;
-            double *twl = reinterpret_cast<double *>(lds + kV2XchWords);
-            // stage the tile's twiddles: row r, stage t (0..7), group g < 2^t at twl[r*255 + (2^t - 1) + g]
-            for (unsigned i = tid; i < 16 * kV2TwPerRow; i += kV2Threads)
-            {
-                const unsigned r = i / kV2TwPerRow, e = i % kV2TwPerRow;
-                const unsigned t = 31 - __builtin_clz(e + 1), g = e + 1 - (1u << t);
-                twl[i] = tab[(1u << (D1 + t)) + (((hg * 16 + r)) << t) + g];
-            }
-            __syncthreads();
-            const double *twr = twl + (size_t)u * kV2TwPerRow;
-
-            double acc0[8], acc1[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-                acc0[e] = acc1[e] = 0.0;
-            const double *key = reinterpret_cast<const double *>(a.key);
-            const size_t N = (size_t)1 << G::n;
-            const uint64_t *mid0 = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K) << G::n) + ((size_t)hg << 12) + tid;
-            const uint64_t *diag = a.target && I < a.K ? a.target + (((size_t)b * a.K + I) << G::n) + ((size_t)hg << 12) + (size_t)tid * 8 : nullptr;
-            uint64_t nxt[8];
-            auto fetch = [&](unsigned J) {
-                if (diag && J == I)
-                {
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        nxt[e] = diag[e];
-                }
-                else
-                {
-                    const uint64_t *mp = mid0 + ((size_t)J << G::n);
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        nxt[e] = mp[e * 512];
-                }
-            };
-            if (j0 < j1)
-                fetch(j0);
-            for (unsigned J = j0; J < j1; J++)
-            {
-                double x[8];
-                const bool is_diag = diag && J == I;
-                if (is_diag)
-                {
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        x[e] = F::from_canon(nxt[e], m);
-                }
-                else
-                {
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        x[e] = F::unraw(nxt[e]);
-                }
-                const double *k0 = key + (((size_t)(J - a.key_digit0) * 2 + 0) * a.L + kc) * N + ((size_t)hg << 12) + tid;
-                const double *k1 = k0 + (size_t)a.L * N;
-                double kr0[8], kr1[8];
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                {
-                    kr0[e] = k0[e * 512];
-                    kr1[e] = k1[e * 512];
-                }
-                if (J + 1 < j1)
-                    fetch(J + 1);
-                if (!is_diag)
-                {
-                    // phase A: stages 0..2, register k <-> column l + 32 k
-                    stage8_fwd<2>(x, m, [&](int) { return twr[0]; });
-                    stage8_fwd<1>(x, m, [&](int g) { return twr[1 + g]; });
-                    stage8_fwd<0>(x, m, [&](int g) { return twr[3 + g]; });
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        F::fix(x[e], m);
-                    // exchange 1: (l + 32 k) -> ((l & 3) + 4 j + 32 (l >> 2))
-#pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        row[v2_pad(l + 32 * k)] = F::raw(x[k]);
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        x[j] = F::unraw(row[v2_pad((l & 3) + 4 * j + 32 * (l >> 2))]);
-                    __builtin_amdgcn_wave_barrier();
-                    // phase B: stages 3..5; group of stage t = column >> (8 - t)
-                    const unsigned G3 = l >> 2;
-                    stage8_fwd<2>(x, m, [&](int) { return twr[7 + G3]; });
-                    stage8_fwd<1>(x, m, [&](int g) { return twr[15 + 2 * G3 + g]; });
-                    stage8_fwd<0>(x, m, [&](int g) { return twr[31 + 4 * G3 + g]; });
-                    // exchange 2: -> (8 l + mm)
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        row[v2_pad((l & 3) + 4 * j + 32 * (l >> 2))] = F::raw(x[j]);
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int mm = 0; mm < 8; mm++)
-                        x[mm] = F::unraw(row[v2_pad(8 * l + mm)]);
-                    __builtin_amdgcn_wave_barrier();
-                    // phase C: stages 6..7 on register bits 1, 0
-                    stage8_fwd<1>(x, m, [&](int g) { return twr[63 + 2 * l + g]; });
-                    stage8_fwd<0>(x, m, [&](int g) { return twr[127 + 4 * l + g]; });
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        F::fix(x[e], m);
-                }
-#pragma unroll
-                for (int e = 0; e < 8; e++)
-                {
-                    F::mac(acc0[e], x[e], kr0[e], m);
-                    F::mac(acc1[e], x[e], kr1[e], m);
-                }
-                if (((J - j0) & 7) == 7)
-                {
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                    {
-                        F::acc_fix(acc0[e], m);
-                        F::acc_fix(acc1[e], m);
-                    }
-                }
-            }
-            // thread (u, l) holds columns 8 l .. 8 l + 7 of row h: 64 contiguous bytes
-            uint64_t *out = acc_part + ((((size_t)b * 2 + 0) * (a.K + 1) + I) << G::n) + ((size_t)h << 8) + 8 * l;
-            ulonglong2 *o0 = reinterpret_cast<ulonglong2 *>(out), *o1 = reinterpret_cast<ulonglong2 *>(out + ((size_t)(a.K + 1) << G::n));
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-            {
-                o0[e] = ulonglong2{ F::acc_to_canon(acc0[2 * e], m), F::acc_to_canon(acc0[2 * e + 1], m) };
-                o1[e] = ulonglong2{ F::acc_to_canon(acc1[2 * e], m), F::acc_to_canon(acc1[2 * e + 1], m) };
-            }
-        }
-
-        template <int D1>
-        __global__ void __launch_bounds__(kV2Threads, 4) ks2v2_kernel(Ks2Args a)
-        {
-            typedef Geo<D1> G;
-            HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned ntile = a.ntargets * G::TILES;
-            const unsigned bid = blockIdx.x;
-            const unsigned xcd = bid & 7, rest = bid >> 3;
-            const unsigned vbatch = a.batch * a.parts;
-            const unsigned vb = rest % vbatch, tile_hi = rest / vbatch;
-            const unsigned b = vb % a.batch, dg = vb / a.batch;
-            const unsigned jlen = (a.j1 - a.j0 + a.parts - 1) / a.parts;
-            const unsigned j0 = a.j0 + dg * jlen, j1 = j0 + jlen < a.j1 ? j0 + jlen : a.j1;
-            uint64_t *acc_part = a.acc + (((size_t)dg * a.batch * 2 * (a.K + 1)) << G::n);
-            const unsigned tile = tile_hi * 8 + xcd;
-            if (tile >= ntile)
-                return;
-            const unsigned it = tile / G::TILES, hg = tile % G::TILES;
-            const unsigned I = SHL_UNIFORM(a.targets[3 * it]), prime = SHL_UNIFORM(a.targets[3 * it + 1]), kc = SHL_UNIFORM(a.targets[3 * it + 2]);
-            ks2v2_body<D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
+                with_int_class(a.tb, prime, [&](auto ic) { ks2_body<false, D1, decltype(ic)::value>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part); });
         }
 
         // natural order (u64) -> register order, optionally converted to double
-        // lane_order != 0: double-precision components go to the order of ks2v2 (position hg*4096 + m*512 + tid <- natural
-        // hg*4096 + tid*8 + m); integer components always keep the order of ks2_kernel
         __global__ void __launch_bounds__(kThreads) key_layout_kernel(
-            const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys, int lane_order)
+            const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys)
         {
             const size_t N = (size_t)1 << n_log;
             const size_t total = polys * L * N;
@@ -2005,11 +1789,6 @@ namespace sealhip
                 const size_t hg = p >> 12;
                 const unsigned e = (unsigned)(p >> 8) & 15, tid = (unsigned)p & 255;
                 size_t nat = (hg << 12) + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 4) + e;
-                if (lane_order && fpd[comp].qi)
-                {
-                    const unsigned pp = (unsigned)p & 4095, mm = pp >> 9, t9 = pp & 511;
-                    nat = (hg << 12) + (size_t)t9 * 8 + mm;
-                }
                 const uint64_t v = in[(slab << n_log) + nat];
                 if (fpd[comp].qi)
                 {
@@ -2120,16 +1899,13 @@ namespace sealhip
             if (chunks > 65535)
                 chunks = 65535;
             size_t l1 = G::rA > 0 ? G::lds1_words * 8 : 8;
-            // single-launch kernels (plain in-place transforms, double-precision components):
-            //   2 = second generation (N = 2^13, 2^14), 1 = ntt2_fwd_fused (N = 2^13; SEALHIP_NTT_FUSED_V1=1 for A/B runs)
-            int fused = 0;
+            // single-launch kernels (plain in-place transforms, N = 2^13, 2^14); SEALHIP_NTT_NOFUSED=1 keeps the two-launch engine
+            bool fused = false;
             unsigned fchunks = 1;
             if constexpr (D1 == 5 || D1 == 6)
             {
                 static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED");
-                static const bool v1 = std::getenv("SEALHIP_NTT_FUSED_V1") != nullptr;
-                static const bool no14 = std::getenv("SEALHIP_NTT_NOFUSED14") != nullptr;
-                if (fused_ok && !a.src && a.epi == 0 && (D1 == 5 || !(v1 || no14)))
+                if (fused_ok && !a.src && a.epi == 0)
                 {
                     static bool raised = false;
                     if (!raised)
@@ -2137,15 +1913,12 @@ namespace sealhip
                         // above the default 64 KiB of dynamic LDS
                         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused2<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedGeo<D1>::lds_bytes) != hipSuccess)
                             return hipErrorInvalidValue;
-                        if constexpr (D1 == kFusedD1)
-                            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsBytes) != hipSuccess)
-                                return hipErrorInvalidValue;
                         raised = true;
                     }
-                    fused = (v1 && D1 == kFusedD1) ? 1 : 2;
-                    // v1: one 512-thread workgroup per CU; v2: two (N = 2^13) or one 1024-thread workgroup (N = 2^14);
+                    fused = true;
+                    // two workgroups per CU (N = 2^13) or one 1024-thread workgroup (N = 2^14);
                     // a few loop iterations per workgroup so that the prefetch and the hoisted twiddles pay
-                    const unsigned want = fused == 2 && D1 == 5 ? 2048 : 1024;
+                    const unsigned want = D1 == 5 ? 2048 : 1024;
                     fchunks = (want + a.ncomp - 1) / a.ncomp;
                     if (const char *f = std::getenv("SEALHIP_NTT_FCHUNKS")) // tests: force the per-workgroup loop at small batches
                         fchunks = (unsigned)std::atoi(f) ? (unsigned)std::atoi(f) : 1;
@@ -2160,16 +1933,11 @@ namespace sealhip
                 g.comp0 = r.c0;
                 if constexpr (D1 == 5 || D1 == 6)
                 {
-                    if (fused == 2 && r.cls == 1)
+                    if (fused && r.cls == 1)
                     {
                         hipLaunchKernelGGL((ntt2_fwd_fused2<D1>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), FusedGeo<D1>::lds_bytes, st, g);
                         return hipGetLastError();
                     }
-                }
-                if (fused == 1 && r.cls == 1)
-                {
-                    hipLaunchKernelGGL(ntt2_fwd_fused, dim3(1, r.nc, fchunks), dim3(2 * kThreads), kFusedLdsBytes, st, g);
-                    return hipGetLastError();
                 }
                 dim3 grid(G::TILES, r.nc, chunks);
                 if (r.cls == 1)
@@ -2238,9 +2006,8 @@ namespace sealhip
             unsigned fchunks = 1;
             if constexpr (D1 == 5 || D1 == 6)
             {
-                static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED") && !std::getenv("SEALHIP_NTT_FUSED_V1");
-                static const bool no14 = std::getenv("SEALHIP_NTT_NOFUSED14") != nullptr;
-                if (fused_ok && (D1 == 5 || !no14))
+                static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED");
+                if (fused_ok)
                 {
                     static bool raised = false;
                     if (!raised)
@@ -2309,8 +2076,6 @@ namespace sealhip
                 {
                     if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<D1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2_fp) != hipSuccess)
                         return hipErrorInvalidValue;
-                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2v2_kernel<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kV2LdsBytes) != hipSuccess)
-                        return hipErrorInvalidValue;
                     raised = true;
                 }
             }
@@ -2323,9 +2088,7 @@ namespace sealhip
                 c1.targets = a1.targets + 2 * t0;
                 c1.ntargets = nt;
                 const dim3 g1(((groups + 7) / 8) * nt * 8);
-                if (fp && ks2_lane_order())
-                    hipLaunchKernelGGL((ks1_kernel<true, D1, 1>), g1, dim3(kThreads), l1, st, c1);
-                else if (fp)
+                if (fp)
                     hipLaunchKernelGGL((ks1_kernel<true, D1>), g1, dim3(kThreads), l1, st, c1);
                 else
                     hipLaunchKernelGGL((ks1_kernel<false, D1>), g1, dim3(kThreads), l1, st, c1);
@@ -2336,9 +2099,7 @@ namespace sealhip
                 c2.targets = a2.targets + 3 * t0;
                 c2.ntargets = nt;
                 const unsigned ntile = nt * G::TILES;
-                if (fp && ks2_lane_order())
-                    hipLaunchKernelGGL((ks2v2_kernel<D1>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kV2Threads), kV2LdsBytes, st, c2);
-                else if (fp)
+                if (fp)
                     hipLaunchKernelGGL((ks2_kernel<D1, 1>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), l2_fp, st, c2);
                 else
                     hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), kLds2Words * 8 + 240 * sizeof(ShoupOp), st, c2);
@@ -2537,8 +2298,7 @@ namespace sealhip
         size_t blocks = (total + kThreads - 1) / kThreads;
         if (blocks > 4096)
             blocks = 4096;
-        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, L, (unsigned)t.log_n, polys,
-                           ks2_lane_order() ? 1 : 0);
+        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, L, (unsigned)t.log_n, polys);
         return hipGetLastError();
     }
 } // namespace sealhip
