@@ -18,7 +18,7 @@ own batch, context tables and keys (batch sharding, no data-path collective: SUR
                                     digits spread over the ranks (one exchange per key switch) + rescale ("strong")
 
 One JSON line is printed by rank 0 with, besides the contract fields:
-  verified_items  ciphertexts of the timed batch (first / middle / last of every rank) compared word for word, outside the timed
+  verified_items  ciphertexts of the timed batch (16 spread evenly over every rank's share) compared word for word, outside the timed
                region, with the reference Evaluator (oracle/_ref) run on the same input and key words
   roofline     the NTT (dominant kernel family) measured live with HIP events on the stream it runs on; achieved = algorithmic
                bytes (16*N per RNS-component transform) / time; peak = 8 TB/s HBM (guide); traffic = HBM bytes
@@ -424,14 +424,17 @@ class LaneView:
         raise IndexError(b)
 
 
-def verify_items(workload, scheme, n, primes, t_plain, key_host, xs, ys, work, B, scale):
-    """first / middle / last item of this rank's timed batch against seal::Evaluator (oracle/_ref) on the same words.
-    Raises on the first differing word; returns the number of items compared.  Outside the timed region."""
+def verify_items(workload, scheme, n, primes, t_plain, key_host, xs, ys, work, B, scale, count=16):
+    """`count` items spread evenly over this rank's timed batch (first and last included) against seal::Evaluator (oracle/_ref)
+    on the same words, the reference running on host threads (ctypes releases the GIL).  Raises on the first differing word;
+    returns the number of items compared.  Outside the timed region."""
     import numpy as np
     import sealref
+    from concurrent.futures import ThreadPoolExecutor
     K = len(primes) - 1
     ref = sealref.RefContext(scheme, n, primes, t_plain)
-    items = sorted({0, B // 2, B - 1})
+    take = min(count, B)
+    items = sorted({int(round(i * (B - 1) / max(1, take - 1))) for i in range(take)})
     if workload == "rotate_c5":
         ref.keygen_galois_steps([1])
         elt = ref.galois_elt_from_step(1)
@@ -440,7 +443,8 @@ def verify_items(workload, scheme, n, primes, t_plain, key_host, xs, ys, work, B
         ref.keygen_relin()
         ref.set_key("relin", 0, key_host)
     ci = ref.first_chain_index
-    for b in items:
+
+    def expected(b):
         xw = xs[:, b].cpu().numpy().view("uint64")
         if workload == "rotate_c5":
             a = ref.ct(ci, xw, True, float(primes[K - 1]) * 2.0 ** 10)
@@ -455,12 +459,16 @@ def verify_items(workload, scheme, n, primes, t_plain, key_host, xs, ys, work, B
                 ref.rescale_to_next_inplace(a)
             else:
                 ref.mod_switch_to_next_inplace(a)
-        exp = a.data()
-        got = work.item_to_numpy(b)
+        return a.data(), a.info()["scale"]
+
+    inputs_ready = [(b, work.item_to_numpy(b)) for b in items]      # device reads on this thread
+    with ThreadPoolExecutor(max_workers=min(len(items), os.cpu_count() or 1)) as pool:
+        results = list(pool.map(expected, items))
+    for (b, got), (exp, ref_scale) in zip(inputs_ready, results):
         if got.shape != exp.shape or not np.array_equal(got, exp):
             raise SystemExit("bench.py: item %d of the timed batch differs from the reference Evaluator" % b)
-        if scheme == "ckks" and work.scale() != a.info()["scale"]:
-            raise SystemExit("bench.py: scale metadata differs from the reference (%r vs %r)" % (work.scale(), a.info()["scale"]))
+        if scheme == "ckks" and work.scale() != ref_scale:
+            raise SystemExit("bench.py: scale metadata differs from the reference (%r vs %r)" % (work.scale(), ref_scale))
     return len(items)
 
 

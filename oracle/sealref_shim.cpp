@@ -395,6 +395,31 @@ extern "C"
         REF_TRY EV->mod_reduce_to_next_inplace(CT(a));
         REF_CATCH
     }
+    // the multi-level forms (evaluator.cpp:1451-1473, 1543-1595, 1625-1647): target = the level with this chain index
+    int ref_rescale_to_inplace(void *ctx, void *a, uint64_t chain_index)
+    {
+        REF_TRY auto l = static_cast<RefCtx *>(ctx)->level(chain_index);
+        if (!l)
+            return 1;
+        EV->rescale_to_inplace(CT(a), l->parms_id());
+        REF_CATCH
+    }
+    int ref_mod_switch_to_inplace(void *ctx, void *a, uint64_t chain_index)
+    {
+        REF_TRY auto l = static_cast<RefCtx *>(ctx)->level(chain_index);
+        if (!l)
+            return 1;
+        EV->mod_switch_to_inplace(CT(a), l->parms_id());
+        REF_CATCH
+    }
+    int ref_mod_reduce_to_inplace(void *ctx, void *a, uint64_t chain_index)
+    {
+        REF_TRY auto l = static_cast<RefCtx *>(ctx)->level(chain_index);
+        if (!l)
+            return 1;
+        EV->mod_reduce_to_inplace(CT(a), l->parms_id());
+        REF_CATCH
+    }
     int ref_rotate_vector_inplace(void *ctx, void *a, int steps)
     {
         REF_TRY EV->rotate_vector_inplace(CT(a), steps, static_cast<RefCtx *>(ctx)->glk);

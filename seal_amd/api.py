@@ -881,6 +881,11 @@ class Evaluator:
         N.check(N.lib().Evaluator_ModSwitchTo1(self._h, a._h, pid, a._h, None))
         return a
 
+    def mod_switch_to(self, a, parms_id, destination):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Evaluator_ModSwitchTo1(self._h, a._h, pid, destination._h, None))
+        return destination
+
     def rescale_to_next_inplace(self, a):
         return self._u("Evaluator_RescaleToNext", a, None, pool=True)
 
@@ -891,6 +896,11 @@ class Evaluator:
         pid = (C.c_uint64 * 4)(*parms_id)
         N.check(N.lib().Evaluator_RescaleTo(self._h, a._h, pid, a._h, None))
         return a
+
+    def rescale_to(self, a, parms_id, destination):
+        pid = (C.c_uint64 * 4)(*parms_id)
+        N.check(N.lib().Evaluator_RescaleTo(self._h, a._h, pid, destination._h, None))
+        return destination
 
     def mod_reduce_to_next_inplace(self, a):
         return self._u("Evaluator_ModReduceToNext", a, None, pool=True)

@@ -24,12 +24,13 @@ def _same(dev_ct, ref_cts, what):
         assert dev_ct.coeff_modulus_size() == info["coeff_modulus_size"] and dev_ct.size() == info["size"], what
 
 
-def run_sequence(scheme, n, bits, tb, batch, nops, seed, check_prob=1.0, scale0=None):
+def run_sequence(scheme, n, bits, tb, batch, nops, seed, check_prob=1.0, scale0=None, wild_prob=0.0):
     """check_prob < 1: the device result is compared with the reference's only after some of the operations (always after the
     last), so that state the library defers between calls - the key-switch tail, sealhip.h: SealHip_TailStats - survives into
     the next operation instead of being completed by the comparison's read"""
     rng = np.random.default_rng(seed)
     check_rng = np.random.default_rng(seed + 77)
+    wild_rng = np.random.default_rng(seed + 78)
     primes = coeff_modulus_create(n, bits)
     t = plain_modulus_batching(n, tb) if scheme != "ckks" else 0
     L, K = len(primes), len(primes) - 1
@@ -76,85 +77,90 @@ def run_sequence(scheme, n, bits, tb, batch, nops, seed, check_prob=1.0, scale0=
             op = "negate"
         if op == "rescale" and x.scale() < float(primes[Kc - 1]) * 2.0:
             op = "mod_switch"   # rescaling would push the scale below 1
-        log.append(op)
-        state = {"rx": rx}
-
-        def apply_both():
-            rx = state["rx"]
-            if op in ("add", "sub"):
-                y, ry = fresh(size=int(rng.integers(2, 4)))
-                # bring the fresh operand to x's level / form / scale
-                while y.coeff_modulus_size() > Kc:
-                    d.ev.mod_switch_to_next_inplace(y)
-                    for r in ry:
-                        o.ref.mod_switch_to_next_inplace(r)
-                if scheme == "ckks":
-                    y.set_scale(x.scale())
-                    ry = [o.ref.ct(o._ci(Kc), r.data(), True, x.scale(), 1) for r in ry]
-                getattr(d.ev, op + "_inplace")(x, y)
-                for r, q in zip(rx, ry):
-                    getattr(o.ref, op + "_inplace")(r, q)
-            elif op == "negate":
-                d.ev.negate_inplace(x)
-                for r in rx:
-                    o.ref.negate_inplace(r)
-            elif op in ("multiply", "multiply32"):
-                y, ry = fresh(size=2)
-                while y.coeff_modulus_size() > Kc:
-                    d.ev.mod_switch_to_next_inplace(y)
-                    for r in ry:
-                        o.ref.mod_switch_to_next_inplace(r)
-                if scheme == "ckks":
-                    y.set_scale(x.scale())
-                    ry = [o.ref.ct(o._ci(Kc), r.data(), True, x.scale(), 1) for r in ry]
-                d.ev.multiply_inplace(x, y)
-                for r, q in zip(rx, ry):
-                    o.ref.multiply_inplace(r, q)
-            elif op == "square":
-                d.ev.square_inplace(x)
-                for r in rx:
-                    o.ref.square_inplace(r)
-            elif op == "relinearize":
-                d.ev.relinearize_inplace(x, d.rlk)
-                for r in rx:
-                    o.ref.relinearize_inplace(r)
-            elif op == "rotate":
-                s = steps[rng.integers(0, len(steps))]
-                if scheme == "ckks":
-                    d.ev.rotate_vector_inplace(x, s, d.glk)
-                    for r in rx:
-                        o.ref.rotate_vector_inplace(r, s)
-                else:
-                    d.ev.rotate_rows_inplace(x, s, d.glk)
-                    for r in rx:
-                        o.ref.rotate_rows_inplace(r, s)
-            elif op == "conj":
-                if scheme == "ckks":
-                    d.ev.complex_conjugate_inplace(x, d.glk)
-                    for r in rx:
-                        o.ref.complex_conjugate_inplace(r)
-                else:
-                    d.ev.rotate_columns_inplace(x, d.glk)
-                    for r in rx:
-                        o.ref.rotate_columns_inplace(r)
-            elif op == "mod_switch":
-                d.ev.mod_switch_to_next_inplace(x)
-                for r in rx:
+        # wild_prob > 0: now and then an operation chosen with none of the guards above (a rotation of a three-part ciphertext,
+        # a rescale at the end of the chain or of a BFV ciphertext, a product whose scale does not fit, operands at different
+        # levels or scales): whatever the device says about it - accept or reject - the reference must say the same
+        wild = wild_prob > 0 and wild_rng.random() < wild_prob
+        mismatch = None
+        if wild:
+            op = ["rotate", "conj", "square", "multiply", "relinearize", "mod_switch", "rescale", "add", "sub", "multiply32"][wild_rng.integers(0, 10)]
+            if op in ("add", "sub", "multiply") and wild_rng.random() < 0.5:
+                mismatch = ["level", "scale"][wild_rng.integers(0, 2)]
+        log.append(op + ("!" if wild else "") + ("~" + mismatch if mismatch else ""))
+        # the operation as two closures - device side, reference side - over operands prepared beforehand, so that a call the
+        # device rejects can be replayed on the reference (which must reject it with the same exception class)
+        def second_operand(size):
+            y, ry = fresh(size=size)
+            while y.coeff_modulus_size() > Kc:     # bring the fresh operand to x's level / form / scale
+                d.ev.mod_switch_to_next_inplace(y)
+                for r in ry:
                     o.ref.mod_switch_to_next_inplace(r)
-            elif op == "rescale":
-                d.ev.rescale_to_next_inplace(x)
+            if mismatch == "level" and Kc >= 2:
+                d.ev.mod_switch_to_next_inplace(y)
+                for r in ry:
+                    o.ref.mod_switch_to_next_inplace(r)
+            if scheme == "ckks":
+                ysc = x.scale() * (2.0 if mismatch == "scale" else 1.0)
+                y.set_scale(ysc)
+                ry = [o.ref.ct(r.info()["chain_index"], r.data(), True, ysc, 1) for r in ry]
+            return y, ry
+
+        def each(name, *args):
+            def run():
                 for r in rx:
-                    o.ref.rescale_to_next_inplace(r)
+                    getattr(o.ref, name)(r, *args)
+            return run
+
+        if op in ("add", "sub"):
+            y, ry = second_operand(int(rng.integers(2, 4)))
+            dev_call = lambda: getattr(d.ev, op + "_inplace")(x, y)
+            ref_call = lambda: [getattr(o.ref, op + "_inplace")(r, q) for r, q in zip(rx, ry)]
+        elif op == "negate":
+            dev_call, ref_call = (lambda: d.ev.negate_inplace(x)), each("negate_inplace")
+        elif op in ("multiply", "multiply32"):
+            y, ry = second_operand(2)
+            dev_call = lambda: d.ev.multiply_inplace(x, y)
+            ref_call = lambda: [o.ref.multiply_inplace(r, q) for r, q in zip(rx, ry)]
+        elif op == "square":
+            dev_call, ref_call = (lambda: d.ev.square_inplace(x)), each("square_inplace")
+        elif op == "relinearize":
+            dev_call, ref_call = (lambda: d.ev.relinearize_inplace(x, d.rlk)), each("relinearize_inplace")
+        elif op == "rotate":
+            s = steps[rng.integers(0, len(steps))]
+            if scheme == "ckks":
+                dev_call, ref_call = (lambda: d.ev.rotate_vector_inplace(x, s, d.glk)), each("rotate_vector_inplace", s)
+            else:
+                dev_call, ref_call = (lambda: d.ev.rotate_rows_inplace(x, s, d.glk)), each("rotate_rows_inplace", s)
+        elif op == "conj":
+            if scheme == "ckks":
+                dev_call, ref_call = (lambda: d.ev.complex_conjugate_inplace(x, d.glk)), each("complex_conjugate_inplace")
+            else:
+                dev_call, ref_call = (lambda: d.ev.rotate_columns_inplace(x, d.glk)), each("rotate_columns_inplace")
+        elif op == "mod_switch":
+            dev_call, ref_call = (lambda: d.ev.mod_switch_to_next_inplace(x)), each("mod_switch_to_next_inplace")
+        elif op == "rescale":
+            dev_call, ref_call = (lambda: d.ev.rescale_to_next_inplace(x)), each("rescale_to_next_inplace")
+        else:
+            raise AssertionError(op)
 
         try:
-            apply_both()
+            dev_call()
         except (S.InvalidArgument, S.LogicError) as dev_exc:
-            # a call the device rejects must be rejected by the reference with the same exception class (run on fresh
-            # copies of the last agreed state is not possible for in-place ops, so the sequence simply ends here)
-            return log + ["device raised %s: %s" % (type(dev_exc).__name__, dev_exc.message)]
+            # replay on the reference: it must reject the same call, with the same exception class (RefError codes: 1
+            # invalid_argument, 2 logic_error); the sequence ends here - the operand may be half-way for in-place forms
+            want = 1 if isinstance(dev_exc, S.InvalidArgument) else 2
+            try:
+                ref_call()
+            except sealref.RefError as ref_exc:
+                assert ref_exc.code == want, "device raised %s (%s), the reference %s, after %s" % (
+                    type(dev_exc).__name__, dev_exc.message, ref_exc, " > ".join(log))
+                return log + ["both raised %s: %s" % (type(dev_exc).__name__, dev_exc.message)]
+            raise AssertionError("the device raised %s (%s) but the reference accepted the call after %s" % (
+                type(dev_exc).__name__, dev_exc.message, " > ".join(log)))
+        try:
+            ref_call()
         except sealref.RefError as ref_exc:
             raise AssertionError("the reference raised %s but the device accepted the call after %s" % (ref_exc, " > ".join(log)))
-        rx = state["rx"]
         if op_index == nops - 1 or check_rng.random() < check_prob:
             _same(x, rx, "%s n=%d bits=%s seed=%d after %s" % (scheme, n, bits, seed, " > ".join(log)))
     return log

@@ -803,3 +803,147 @@ def case_mod_reduce(n, bits, batch=2, seed=31):
             raise AssertionError("expected InvalidArgument")
         except S.InvalidArgument:
             pass
+
+
+# ---- the multi-level forms against the reference's own (evaluator.cpp:1451-1473 mod_switch_to_inplace(Ciphertext),
+#      1543-1595 rescale_to_inplace): three and more levels in one call, directly and right after a key switch (CKKS at the
+#      two-pass sizes: the key switch's mod-down is still pending - LazyTail - when the call arrives)
+def case_multi_level_ckks(n, bits, batch=2, seed=41, step=1):
+    import sealref
+    primes = coeff_modulus_create(n, bits)
+    L = len(primes)
+    K = L - 1
+    assert K >= 4
+    probe = Oracle("ckks", n, primes)
+    elt = probe.galois_elt_from_step(step)
+    o = Oracle("ckks", n, primes, galois_elts=[elt], kind="reference")
+    ref = o.ref
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    defers = 13 <= n.bit_length() - 1 <= 16 and not os.environ.get("SEALHIP_KS_EAGER_TAIL")
+    levels = 3
+    target_K = K - levels
+    dropped = 1.0
+    for i in range(target_K, K):
+        dropped *= float(primes[i])
+    sc = dropped * 2.0 ** 10     # lands on 2^10 (up to rounding) after three divisions
+    pid = d.parms_id_for_K(target_K)
+    tci = o._ci(target_K)
+
+    def same(dev, refs, what):
+        got = d.out(dev)
+        for b in range(batch):
+            _eq(got[b], refs[b].data(), "%s item %d" % (what, b))
+        info = refs[0].info()
+        assert dev.coeff_modulus_size() == info["coeff_modulus_size"] == target_K and dev.size() == info["size"], what
+        assert dev.scale() == info["scale"], "%s: scale %r vs %r" % (what, dev.scale(), info["scale"])
+        assert dev.parms_id() == tuple(ref.parms_id(tci)), what
+
+    # 1. rescale_to over three levels, in place and out of place
+    cx = d.ct(xs, scale=sc)
+    rs = [ref.rescale_to_inplace(o._ct(x, sc), tci) for x in xs]
+    dst = S.Ciphertext(d.ctx)
+    d.ev.rescale_to(cx, pid, dst)
+    same(dst, rs, "rescale_to (out of place)")
+    assert cx.coeff_modulus_size() == K
+    d.ev.rescale_to_inplace(cx, pid)
+    same(cx, rs, "rescale_to_inplace")
+    # 2. mod_switch_to over three levels (CKKS drops components), in place and out of place
+    cm = d.ct(xs, scale=2.0 ** 30)
+    rm = [ref.mod_switch_to_inplace(o._ct(x, 2.0 ** 30), tci) for x in xs]
+    dst = S.Ciphertext(d.ctx)
+    d.ev.mod_switch_to(cm, pid, dst)
+    same(dst, rm, "mod_switch_to (out of place)")
+    d.ev.mod_switch_to_inplace(cm, pid)
+    same(cm, rm, "mod_switch_to_inplace")
+    # 3. right after relinearize / rotate: the first of the three divisions is folded with the pending mod-down
+    f0, p0, x0 = S.tail_stats()
+    ca, cb = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10)
+    d.ev.multiply_inplace(ca, cb)
+    d.ev.relinearize_inplace(ca, d.rlk)
+    ca.set_scale(sc)
+    d.ev.rescale_to_inplace(ca, pid)
+    f1, p1, x1 = S.tail_stats()
+    assert (f1 - f0, p1 - p0, x1 - x0) == ((1, 0, 0) if defers else (0, 0, 0)), (f1 - f0, p1 - p0, x1 - x0)
+    ra = []
+    for b in range(batch):
+        a, bb = o._ct(xs[b], 2.0 ** 10), o._ct(ys[b], 2.0 ** 10)
+        ref.multiply_inplace(a, bb)
+        ref.relinearize_inplace(a)
+        a = o._ct(a.data(), sc)
+        ra.append(ref.rescale_to_inplace(a, tci))
+    same(ca, ra, "relinearize then rescale_to")
+    cr = d.ct(xs, scale=sc)
+    d.ev.rotate_vector_inplace(cr, step, d.glk)
+    d.ev.rescale_to_inplace(cr, pid)
+    f2, p2, x2 = S.tail_stats()
+    assert (f2 - f1, p2 - p1) == ((1, 0) if defers else (0, 0))
+    rr = [ref.rescale_to_inplace(ref.apply_galois_inplace(o._ct(x, sc), elt), tci) for x in xs]
+    same(cr, rr, "rotate then rescale_to")
+    # ... and mod_switch_to after a key switch: the tail is completed on its own, then the components are dropped
+    cs = d.ct(xs, scale=2.0 ** 30)
+    d.ev.rotate_vector_inplace(cs, step, d.glk)
+    d.ev.mod_switch_to_inplace(cs, pid)
+    f3, p3, x3 = S.tail_stats()
+    assert (f3 - f2, p3 - p2) == ((0, 1) if defers else (0, 0))
+    rsw = [ref.mod_switch_to_inplace(ref.apply_galois_inplace(o._ct(x, 2.0 ** 30), elt), tci) for x in xs]
+    same(cs, rsw, "rotate then mod_switch_to")
+    # 4. the calls the reference rejects are rejected the same way
+    for what, dev_call, ref_call in (
+            ("rescale_to a higher level", lambda: d.ev.rescale_to_inplace(cs, d.parms_id_for_K(K)), lambda c: ref.rescale_to_inplace(c, o._ci(K))),
+            ("mod_switch_to a higher level", lambda: d.ev.mod_switch_to_inplace(cs, d.parms_id_for_K(K)), lambda c: ref.mod_switch_to_inplace(c, o._ci(K))),
+            ("mod_switch_to a level the scale does not fit", lambda: d.ev.mod_switch_to_inplace(cs, d.parms_id_for_K(1)), lambda c: ref.mod_switch_to_inplace(c, o._ci(1)))):
+        big = 2.0 ** (sum(bits[:target_K]) - 5)     # fits the current level, not the one below
+        cs.set_scale(big)
+        try:
+            ref_call(o._ct(rsw[0].data(), big))
+            raise AssertionError("the reference accepts: " + what)
+        except sealref.RefError as e:
+            assert e.code == 1, what
+        try:
+            dev_call()
+            raise AssertionError("the device accepts: " + what)
+        except S.InvalidArgument:
+            pass
+    cs.set_scale(2.0 ** 30)
+    same(cs, rsw, "operand unchanged by the rejected calls")
+
+
+def case_multi_level_bfv_bgv(scheme, n, primes, t, batch=2, seed=43):
+    """mod_switch_to_inplace(Ciphertext) over three levels for BFV (coefficient form, divide_and_round_q_last) and BGV (NTT form,
+    correction factor tracked), against the reference's own multi-level call"""
+    import sealref
+    o = Oracle(scheme, n, primes, t, kind="reference")
+    ref = o.ref
+    d = DeviceSide(scheme, n, primes, t)
+    K = len(primes) - 1
+    assert K >= 4
+    target_K = K - 3
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    cx = d.ct(xs, is_ntt=scheme == "bgv")
+    rs = [ref.mod_switch_to_inplace(o._ct(x), o._ci(target_K)) for x in xs]
+    dst = S.Ciphertext(d.ctx)
+    d.ev.mod_switch_to(cx, d.parms_id_for_K(target_K), dst)
+    d.ev.mod_switch_to_inplace(cx, d.parms_id_for_K(target_K))
+    for c, what in ((dst, "out of place"), (cx, "in place")):
+        got = d.out(c)
+        for b in range(batch):
+            _eq(got[b], rs[b].data(), "%s mod_switch_to (%s) item %d" % (scheme, what, b))
+        info = rs[0].info()
+        assert c.coeff_modulus_size() == target_K == info["coeff_modulus_size"]
+        if scheme == "bgv":
+            assert c.correction_factor() == info["correction_factor"]
+    try:
+        d.ev.rescale_to_inplace(cx, d.parms_id_for_K(1))
+        raise AssertionError("rescale_to is CKKS only")
+    except S.InvalidArgument:
+        pass
+    try:
+        ref.rescale_to_inplace(rs[0], o._ci(1))
+        raise AssertionError("rescale_to is CKKS only (reference)")
+    except sealref.RefError as e:
+        assert e.code == 1

@@ -459,6 +459,16 @@ class RefContext:
     def mod_reduce_to_next_inplace(self, a):
         return self._op1("ref_mod_reduce_to_next_inplace", a)
 
+    # the multi-level forms of the reference itself (evaluator.cpp:1451-1473, 1543-1595, 1625-1647)
+    def rescale_to_inplace(self, a, chain_index):
+        return self._op1("ref_rescale_to_inplace", a, C.c_uint64(chain_index))
+
+    def mod_switch_to_inplace(self, a, chain_index):
+        return self._op1("ref_mod_switch_to_inplace", a, C.c_uint64(chain_index))
+
+    def mod_reduce_to_inplace(self, a, chain_index):
+        return self._op1("ref_mod_reduce_to_inplace", a, C.c_uint64(chain_index))
+
     def rotate_vector_inplace(self, a, steps):
         return self._op1("ref_rotate_vector_inplace", a, C.c_int(steps))
 

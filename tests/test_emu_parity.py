@@ -189,6 +189,20 @@ def test_mod_reduce(emu):
     P.case_mod_reduce(8192, [50, 40, 60, 50], batch=1)
 
 
+def test_multi_level_forms(emu):
+    """rescale_to_inplace / mod_switch_to_inplace(Ciphertext) over three levels against the reference's own multi-level calls
+    (evaluator.cpp:1451-1473, 1543-1595), also with a key switch's deferred tail pending (missing #3)"""
+    import sealref
+    if not sealref.available():
+        pytest.skip("oracle/_ref (the real reference) is not built")
+    P.case_multi_level_ckks(1024, [40, 30, 30, 30, 30, 40])
+    P.case_multi_level_ckks(8192, [50, 30, 40, 30, 40, 50], batch=1)       # two-pass size: deferred tails
+    primes = coeff_modulus_create(1024, [36, 36, 36, 36, 36, 37])
+    t = plain_modulus_batching(1024, 20)
+    P.case_multi_level_bfv_bgv("bfv", 1024, primes, t)
+    P.case_multi_level_bfv_bgv("bgv", 1024, primes, t)
+
+
 @pytest.mark.parametrize("n,bits,parts,batch", [
     (64, [40, 30, 30, 40], 2, 2),
     (1024, [50, 40, 40, 50], 4, 2),          # more ranks than digits: one rank has neither digits nor moduli

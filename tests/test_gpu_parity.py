@@ -497,6 +497,26 @@ def test_mod_reduce(gpu):
     P.case_mod_reduce(16384, [60, 50, 50, 50, 60])
 
 
+@pytest.mark.parametrize("n,bits", [(8192, [60, 30, 30, 30, 40, 60]), (16384, [60, 50, 50, 50, 50, 60]), (65536, [60, 50, 40, 50, 60, 50, 60]), (4096, [36, 30, 30, 30, 36])])
+def test_multi_level_forms_ckks(gpu, n, bits):
+    """rescale_to_inplace / mod_switch_to_inplace(Ciphertext) over three levels against the reference's own multi-level calls
+    (evaluator.cpp:1451-1473, 1543-1595), directly and with a key switch's deferred tail pending (tail counters asserted)"""
+    import sealref
+    if not sealref.available():
+        pytest.skip("oracle/_ref did not travel")
+    P.case_multi_level_ckks(n, bits, batch=3 if n <= 16384 else 1)
+
+
+@pytest.mark.parametrize("scheme", ["bfv", "bgv"])
+def test_multi_level_forms_bfv_bgv(gpu, scheme):
+    import sealref
+    from oracle import coeff_modulus_create, plain_modulus_batching
+    if not sealref.available():
+        pytest.skip("oracle/_ref did not travel")
+    n = 16384
+    P.case_multi_level_bfv_bgv(scheme, n, coeff_modulus_create(n, [55, 55, 50, 58, 60, 55]), plain_modulus_batching(n, 20), batch=3)
+
+
 # ---- streams: non-blocking streams, out-of-place forms in a captured graph, two evaluators sharing the pool (ADVICE r1, VERDICT r1 #8)
 def _ckks_setup(n, bits, galois=True):
     import numpy as np
