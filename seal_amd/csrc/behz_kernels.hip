@@ -12,6 +12,7 @@
 // consecutive coefficients so every global access is a coalesced 512-byte row segment; the
 // per-coefficient input vector is parked in LDS as [component][thread] (conflict-free) so the
 // output loop can re-read it with the matrix row held in scalar registers.
+#include "field.h"
 #include "poly_kernels.h"
 
 namespace sealhip
@@ -69,23 +70,47 @@ namespace sealhip
             hi = (uint64_t)a1 * b1 + (t >> 32) + (u >> 32);
             lo = (u << 32) | (uint32_t)p00;
         }
+        // a * s + c with the wave-uniform s in an SGPR: one v_mad_u64_u32 (field.h, gfx::mad64_s: issued through an instruction
+        // wrapper so that the compiler does not rebuild register pairs around it)
+        __device__ __forceinline__ uint64_t mad_uniform(uint32_t a, uint32_t s, uint64_t c)
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            return gfx::mad64_s(a, s, c);
+#else
+            return (uint64_t)a * s + c;
+#endif
+        }
         // Exact dot product modulo m of a vector held in REGISTERS with a matrix row read through the scalar cache
         // (dot_product_mod, util/uintarithsmallmod.cpp:110-175): the loop is unrolled to the compile-time bound KM and
         // predicated on the wave-uniform length, so the LDS round trip and the loop-carried latency of dot_lds are gone.
+        //
+        // Round 3: no carries.  A 64 x 64 -> 128 product accumulated into 128 bits costs four products plus the carry handling
+        // (sixteen instructions a term as compiled).  The matrix entry is wave-uniform, so it is cut into three 21-bit limbs with
+        // scalar instructions (free for the vector unit); y = y1 2^32 + y0 < 2^61 then gives six products below 2^53 that go to
+        // six 64-bit column sums (weights 2^0, 2^21, 2^42 for y0 and 2^32, 2^53, 2^74 for y1) by six v_mad_u64_u32 - no
+        // carry, no register pair to build - and 64 terms stay below 2^59.  The columns are added up once per dot product.
         template <unsigned KM>
         __device__ __forceinline__ uint64_t dot_reg(const uint64_t (&y)[KM], uconst_ptr row, unsigned count, const ModDesc &m)
         {
-            uint64_t lo = 0, hi = 0;
+            static_assert(KM <= 128, "six column sums of terms below 2^53: 128 of them stay below 2^60");
+            uint64_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
 #pragma unroll
             for (unsigned i = 0; i < KM; i++)
                 if (i < count)
                 {
-                    uint64_t pl, ph;
-                    mul_wide4(y[i], row[i], pl, ph);
-                    lo += pl;
-                    hi += ph + (lo < pl);
+                    const uint64_t r = row[i];
+                    const uint32_t ra = (uint32_t)r & 0x1FFFFFu, rb = (uint32_t)(r >> 21) & 0x1FFFFFu, rc = (uint32_t)(r >> 42);
+                    const uint32_t y0 = (uint32_t)y[i], y1 = (uint32_t)(y[i] >> 32);
+                    a0 = mad_uniform(y0, ra, a0);
+                    a1 = mad_uniform(y0, rb, a1);
+                    a2 = mad_uniform(y0, rc, a2);
+                    b0 = mad_uniform(y1, ra, b0);
+                    b1 = mad_uniform(y1, rb, b1);
+                    b2 = mad_uniform(y1, rc, b2);
                 }
-            return barrett128(lo, hi, m);
+            typedef unsigned __int128 u128;
+            const u128 t = (u128)a0 + ((u128)a1 << 21) + ((u128)a2 << 42) + ((u128)b0 << 32) + ((u128)b1 << 53) + ((u128)b2 << 74);
+            return barrett128((uint64_t)t, (uint64_t)(t >> 64), m);
         }
 
         // ---- stage 0: q -> Bsk U {m~}   (fastbconv_m_tilde)

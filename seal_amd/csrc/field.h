@@ -137,16 +137,98 @@ namespace sealhip
         shl_uconst_ptr u = SHL_UCONST(reinterpret_cast<const uint64_t *>(p));
         return FpDesc{ __builtin_bit_cast(double, u[0]), __builtin_bit_cast(double, u[1]), __builtin_bit_cast(double, u[2]), u[3] };
     }
-    // wave-uniform twiddle (the index is the same in every lane): scalar load
-    __device__ __forceinline__ ShoupOp ld_uniform(const ShoupOp *tab, unsigned idx)
+    // wave-uniform twiddle (the index is the same in every lane): scalar load.  The distinct type tells the integer back end
+    // that the four words live in SGPRs (its instruction wrappers below need to know the register class of every operand).
+    struct ShoupOpU : ShoupOp
+    {};
+    __device__ __forceinline__ ShoupOpU ld_uniform(const ShoupOp *tab, unsigned idx)
     {
         shl_uconst_ptr u = SHL_UCONST(reinterpret_cast<const uint64_t *>(tab));
-        return ShoupOp{ u[2 * (size_t)idx], u[2 * (size_t)idx + 1] };
+        ShoupOpU r;
+        r.w = u[2 * (size_t)idx];
+        r.wq = u[2 * (size_t)idx + 1];
+        return r;
     }
     __device__ __forceinline__ double ld_uniform(const double *tab, unsigned idx)
     {
         return __builtin_bit_cast(double, SHL_UCONST(reinterpret_cast<const uint64_t *>(tab))[idx]);
     }
+
+    // ---- single gfx950 instructions for the integer back end
+    //
+    // hipcc's instruction selection works against 32-bit-limb arithmetic here: it rewrites every 32-bit `a * b + c` into
+    // v_mad_u64_u32 with a freshly assembled {c, 0} register pair (two v_mov_b32 per product), and expands the high half of a
+    // 64 x 64 product through the same pairs - a butterfly written as 15 operations came out as 24 instructions, a quarter of them
+    // v_mov_b32 (round 3, llvm-objdump of ntt2_fwd_p2 / ks2_kernel).  The products are therefore issued through these wrappers:
+    // one instruction each, opaque to the combiner, still scheduled and register-allocated by the compiler (not volatile, no
+    // fixed registers).  SRC1 of the `_s` forms is an SGPR (wave-uniform twiddles and per-prime constants; gfx950 reads one SGPR
+    // per VALU instruction).  The carry-out of v_mad_u64_u32 goes to a scratch SGPR pair nobody reads.
+#if defined(__HIP_DEVICE_COMPILE__)
+    namespace gfx
+    {
+#define SHL_GFX_PRODUCTS(SFX, C1)                                                                                          \
+    __device__ __forceinline__ uint32_t mul_hi_##SFX(uint32_t a, uint32_t b)                                              \
+    {                                                                                                                      \
+        uint32_t r;                                                                                                        \
+        asm("v_mul_hi_u32 %0, %1, %2" : "=v"(r) : "v"(a), C1(b));                                                          \
+        return r;                                                                                                          \
+    }                                                                                                                      \
+    __device__ __forceinline__ uint32_t mul_lo_##SFX(uint32_t a, uint32_t b)                                              \
+    {                                                                                                                      \
+        uint32_t r;                                                                                                        \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(r) : "v"(a), C1(b));                                                          \
+        return r;                                                                                                          \
+    }                                                                                                                      \
+    /* a * b + c, all 64 bits */                                                                                           \
+    __device__ __forceinline__ uint64_t mad64_##SFX(uint32_t a, uint32_t b, uint64_t c)                                   \
+    {                                                                                                                      \
+        uint64_t r, cy;                                                                                                    \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(cy) : "v"(a), C1(b), "v"(c));                               \
+        return r;                                                                                                          \
+    }                                                                                                                      \
+    /* a * b, all 64 bits */                                                                                               \
+    __device__ __forceinline__ uint64_t mul64_##SFX(uint32_t a, uint32_t b)                                               \
+    {                                                                                                                      \
+        uint64_t r, cy;                                                                                                    \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(cy) : "v"(a), C1(b));                                        \
+        return r;                                                                                                          \
+    }
+        SHL_GFX_PRODUCTS(v, "v")
+        SHL_GFX_PRODUCTS(s, "s")
+#undef SHL_GFX_PRODUCTS
+        // a + b in 32 bits, kept as one v_add_u32 on the high half of a register pair (the compiler would rather widen it to a
+        // shifted 64-bit addition: a v_mov_b32 to build the pair plus a v_lshl_add_u64)
+        __device__ __forceinline__ uint32_t add32(uint32_t a, uint32_t b)
+        {
+            uint32_t r;
+            asm("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+            return r;
+        }
+        // 2 x + c with c in an SGPR pair: one v_lshl_add_u64 (the compiler factors 2 (x + c / 2) into two instructions when it
+        // knows c is even)
+        __device__ __forceinline__ uint64_t twice_plus(uint64_t x, uint64_t c)
+        {
+            uint64_t r;
+            asm("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(x), "s"(c));
+            return r;
+        }
+        // the register class of a twiddle's words: ShoupOpU -> SGPRs, ShoupOp -> VGPRs
+        template <class TW>
+        struct Tw
+        {
+            static __device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return mul_hi_v(a, b); }
+            static __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return mad64_v(a, b, c); }
+            static __device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b) { return mul64_v(a, b); }
+        };
+        template <>
+        struct Tw<ShoupOpU>
+        {
+            static __device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return mul_hi_s(a, b); }
+            static __device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return mad64_s(a, b, c); }
+            static __device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b) { return mul64_s(a, b); }
+        };
+    } // namespace gfx
+#endif
 
     // ---- 64-bit integer back end (Shoup multiplication, lazy butterflies with compile-time range tracking)
     //
@@ -207,32 +289,71 @@ namespace sealhip
         // high limb (no carry chain, no separate subtraction).  Result in [0,2q) for any 64-bit x.
         static SHL_HD uint64_t mul_lazy(uint64_t x, const tw_t &w, const Mod &m)
         {
-            return mul_rem(x, w, mul_hi64(x, w.wq), 0, m);
+            return mul_rem0(x, w, mul_hi64(x, w.wq), m);
         }
         // h in {floor(x * wq / 2^64) - 2, ..., floor(x * wq / 2^64)}: x wq / 2^64 = x1 wq1 + (x1 wq0 + x0 wq1) / 2^32 + x0 wq0 / 2^64; keep
         // x1 wq1 + hi32(x1 wq0) + hi32(x0 wq1), the dropped (lo32(x1 wq0) + lo32(x0 wq1)) 2^32 + x0 wq0 is below 3 * 2^64.
-        // Two v_mul_hi_u32, one v_mad_u64_u32, one v_lshl_add_u64.
-        static SHL_HD uint64_t mul_hi_approx(uint64_t x, uint64_t wq)
+        // Five instructions: two v_mul_hi_u32, their 33-bit sum (v_add_co_u32 + v_addc_co_u32: a register pair that can be the addend
+        // of) one v_mad_u64_u32.
+        template <class TW>
+        static SHL_HD uint64_t mul_hi_approx(uint64_t x, const TW &w)
         {
-            const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)wq, w1 = (uint32_t)(wq >> 32);
+            const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w.wq, w1 = (uint32_t)(w.wq >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t a = gfx::Tw<TW>::mul_hi(x0, w1), c = gfx::Tw<TW>::mul_hi(x1, w0);
+            return gfx::Tw<TW>::mad64(x1, w1, (uint64_t)a + c);
+#else
             const uint32_t a = (uint32_t)(((uint64_t)x0 * w1) >> 32), c = (uint32_t)(((uint64_t)x1 * w0) >> 32);
             return ((uint64_t)x1 * w1 + a) + c;
+#endif
         }
-        // low 64 bits of add + x*w + h*(-q): one v_mad_u64_u32 chain carrying `add`, the four cross products into the high word
-        static SHL_HD uint64_t mul_rem(uint64_t x, const tw_t &w, uint64_t h, uint64_t add, const Mod &m)
+        // low 64 bits of add + x*w + h*(-q), seven instructions: a v_mad_u64_u32 chain carrying `add` for the low limbs, a second
+        // chain of four whose low word alone is used (the four cross products of the high limb), one 32-bit addition
+        template <class TW>
+        static SHL_HD uint64_t mul_rem(uint64_t x, const TW &w, uint64_t h, uint64_t add, const Mod &m)
         {
             const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w.w, w1 = (uint32_t)(w.w >> 32);
             const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+            uint64_t lo = gfx::Tw<TW>::mad64(x0, w0, add);
+            lo = gfx::mad64_s(h0, m.n0, lo);
+            uint64_t cr = gfx::Tw<TW>::mul64(x0, w1);
+            cr = gfx::Tw<TW>::mad64(x1, w0, cr);
+            cr = gfx::mad64_s(h0, m.n1, cr);
+            cr = gfx::mad64_s(h1, m.n0, cr);
+            const uint32_t hi = gfx::add32((uint32_t)(lo >> 32), (uint32_t)cr);
+#else
             uint64_t lo = (uint64_t)x0 * w0 + add;
             lo += (uint64_t)h0 * m.n0;
             const uint32_t hi = (uint32_t)(lo >> 32) + x0 * w1 + x1 * w0 + h0 * m.n1 + h1 * m.n0;
+#endif
             return ((uint64_t)hi << 32) | (uint32_t)lo;
+        }
+        // the same with add = 0 (the first product has no addend to carry)
+        template <class TW>
+        static SHL_HD uint64_t mul_rem0(uint64_t x, const TW &w, uint64_t h, const Mod &m)
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w.w, w1 = (uint32_t)(w.w >> 32);
+            const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+            uint64_t lo = gfx::Tw<TW>::mul64(x0, w0);
+            lo = gfx::mad64_s(h0, m.n0, lo);
+            uint64_t cr = gfx::Tw<TW>::mul64(x0, w1);
+            cr = gfx::Tw<TW>::mad64(x1, w0, cr);
+            cr = gfx::mad64_s(h0, m.n1, cr);
+            cr = gfx::mad64_s(h1, m.n0, cr);
+            const uint32_t hi = gfx::add32((uint32_t)(lo >> 32), (uint32_t)cr);
+            return ((uint64_t)hi << 32) | (uint32_t)lo;
+#else
+            return mul_rem(x, w, h, 0, m);
+#endif
         }
         // x * w mod q in [0, 4q) for ANY 64-bit x: with h = floor(x wq / 2^64) - e, e <= 2, the remainder is
         // x w - h q = (x w - floor(x wq / 2^64) q) + e q < 2q + 2q.  12 instructions.
-        static SHL_HD uint64_t mul_lazy4(uint64_t x, const tw_t &w, const Mod &m)
+        template <class TW>
+        static SHL_HD uint64_t mul_lazy4(uint64_t x, const TW &w, const Mod &m)
         {
-            return mul_rem(x, w, mul_hi_approx(x, w.wq), 0, m);
+            return mul_rem0(x, w, mul_hi_approx(x, w), m);
         }
         // [0,4q) -> [0,2q) without a carry chain: the sign of x - 2q selects
         static SHL_HD uint64_t guard(uint64_t x, const Mod &m)
@@ -243,11 +364,16 @@ namespace sealhip
         // Forward butterfly, 15 instructions: X, Y below B q -> below (B + 4) q, for any B with (B + 4) q <= 2^64.
         //   X' = X + t (the sum is the addend of the remainder chain), Y' = X + 4q - t = 2X + 4q - X', t = Y w mod q in [0, 4q)
         // The callers keep B + 4 <= the limit of the modulus class with fix4() (IntBounds).
-        static SHL_HD void bfly_fwd(elem &X, elem &Y, const tw_t &w, const Mod &m)
+        template <class TW>
+        static SHL_HD void bfly_fwd(elem &X, elem &Y, const TW &w, const Mod &m)
         {
             SEALHIP_NOWRAP(X, m.four_q);
-            const uint64_t xn = mul_rem(Y, w, mul_hi_approx(Y, w.wq), X, m);
+            const uint64_t xn = mul_rem(Y, w, mul_hi_approx(Y, w), X, m);
+#if defined(__HIP_DEVICE_COMPILE__)
+            Y = gfx::twice_plus(X, m.four_q) - xn;
+#else
             Y = (X << 1) + m.four_q - xn;
+#endif
             X = xn;
         }
         // X,Y in [0,4q) -> [0,4q)   (Arithmetic<>::guard/add/sub/mul_root, ntt.h:30-61): moduli of 2^60 and above
@@ -268,9 +394,15 @@ namespace sealhip
         static SHL_HD void fix4(elem &x, const Mod &m)
         {
             const uint32_t xs = HI32 ? (uint32_t)(x >> 32) : (uint32_t)(x >> m.sx);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t k = gfx::mul_hi_s(xs, m.rcp) >> (HI32 ? m.sh_hi : m.sh);
+            const uint64_t lo = gfx::mad64_s(k, m.m0, x);
+            const uint32_t hi = gfx::add32((uint32_t)(lo >> 32), gfx::mul_lo_s(k, m.m1));
+#else
             const uint32_t k = (uint32_t)(((uint64_t)xs * m.rcp) >> 32) >> (HI32 ? m.sh_hi : m.sh);
             const uint64_t lo = (uint64_t)k * m.m0 + x;
             const uint32_t hi = (uint32_t)(lo >> 32) + k * m.m1;
+#endif
             x = ((uint64_t)hi << 32) | (uint32_t)lo;
         }
         static SHL_HD void fwd_fix(elem &x, const Mod &m)
@@ -282,14 +414,21 @@ namespace sealhip
         static SHL_HD uint64_t canon_any(elem x, const Mod &m)
         {
             const uint32_t xs = HI32 ? (uint32_t)(x >> 32) : (uint32_t)(x >> m.sx);
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t k = gfx::mul_hi_s(xs, m.rcp) >> ((HI32 ? m.sh_hi : m.sh) - 1);
+            const uint64_t lo = gfx::mad64_s(k, m.n0, x);
+            const uint32_t hi = gfx::add32((uint32_t)(lo >> 32), gfx::mul_lo_s(k, m.n1));
+#else
             const uint32_t k = (uint32_t)(((uint64_t)xs * m.rcp) >> 32) >> ((HI32 ? m.sh_hi : m.sh) - 1);
             const uint64_t lo = (uint64_t)k * m.n0 + x;
             const uint32_t hi = (uint32_t)(lo >> 32) + k * m.n1;
+#endif
             return csub(((uint64_t)hi << 32) | (uint32_t)lo, m.q);
         }
         // Inverse butterfly without a guard, 16 instructions: X, Y below 2^E q (c = 2^E q) -> X' = X + Y below 2^(E+1) q,
         // Y' = (X + c - Y) w mod q in [0, 4q).  Needs 2^(E+1) q <= 2^64 (IntBounds).
-        static SHL_HD void bfly_inv_lazy(elem &X, elem &Y, const tw_t &w, uint64_t c, const Mod &m)
+        template <class TW>
+        static SHL_HD void bfly_inv_lazy(elem &X, elem &Y, const TW &w, uint64_t c, const Mod &m)
         {
             SEALHIP_NOWRAP(X, Y);
             SEALHIP_NOWRAP(X, c);

@@ -112,7 +112,7 @@ namespace sealhip
 #pragma unroll
             for (int g = 0; g < (8 >> BIT); g++)
             {
-                const typename Field<FP>::tw_t w = tw(g);
+                const auto w = tw(g);
 #pragma unroll
                 for (int k = 0; k < (1 << BIT); k++)
                 {
@@ -219,7 +219,7 @@ namespace sealhip
 #pragma unroll
             for (int g = 0; g < (8 >> BIT); g++)
             {
-                const typename Field<FP>::tw_t w = tw(g);
+                const auto w = tw(g);
 #pragma unroll
                 for (int k = 0; k < (1 << BIT); k++)
                 {
@@ -436,8 +436,8 @@ namespace sealhip
         //   twb[t][g][tid]            at twb[((256 << t) - 256) + g*256 + tid]
         // ---------------------------------------------------------------------------------------
         // stage the 240 row-shared twiddles of pass 2's phase A (row tile hg) at twa[(16 << t) - 16 + (u << t) + g]
-        template <int D1>
-        __device__ __forceinline__ void stage_twa(double *twa, const double *tab, unsigned hg, unsigned tid)
+        template <int D1, class TW>
+        __device__ __forceinline__ void stage_twa(TW *twa, const TW *tab, unsigned hg, unsigned tid)
         {
             if (tid < 240)
             {
@@ -1170,7 +1170,7 @@ namespace sealhip
         //    per transform and the kernel fits 128 VGPRs;
         //  * the inverse transform gets the same treatment (ntt2_inv_fused2).
         // ---------------------------------------------------------------------------------------
-        template <int D1>
+        template <int D1, int TWW = 1> // TWW = 64-bit words per twiddle: 1 double-precision back end, 2 integer back end (Shoup pairs)
         struct FusedGeo
         {
             typedef Geo<D1> G;
@@ -1181,29 +1181,57 @@ namespace sealhip
             static constexpr size_t mid_words = (size_t)TEAMS * 16 * BS;
             static constexpr size_t xch_words = (size_t)TEAMS * kLds2Words;
             static constexpr size_t main_words = mid_words > xch_words ? mid_words : xch_words;
-            static constexpr size_t lds_bytes = (main_words + (size_t)TEAMS * 240) * 8;
+            static constexpr size_t lds_bytes = (main_words + (size_t)TEAMS * 240 * TWW) * 8;
         };
+        // Integer back end in one launch (round 3): the same structure with Shoup pairs, budgeted for 128 VGPRs like the
+        // double-precision kernels - two workgroups per CU at N = 2^13 (or one of each class, which is what a chain with both
+        // kinds of primes launches side by side: 76 + 77 KiB of LDS, 4 x 128 registers per SIMD lane) and the one 1024-thread
+        // workgroup a CU holds at N = 2^14.  Measured by hipcc's resource remarks (tools/quick/resources.py):
+        //  * TWB_REGS: pass 2's fifteen per-thread twiddles resident for the workgroup's loop are 60 VGPRs of Shoup pairs -> 183
+        //    registers (two waves per SIMD) or 120-230 bytes of scratch at 128; they are re-read per transform instead (L2:
+        //    the table of one prime is 16 N bytes), each where it is used;
+        //  * PF: the next transform's sixteen words in flight during this one (32 VGPRs) fits the forward kernel at 2^14 only
+        //    (124 registers); elsewhere it spills 28-76 bytes, and at 2^13 the second workgroup of the CU covers the load.
+#ifndef SEALHIP_FUSED_INT_TWB_REGS
+#define SEALHIP_FUSED_INT_TWB_REGS 0
+#endif
+#ifndef SEALHIP_FUSED_INT_PF_FWD14
+#define SEALHIP_FUSED_INT_PF_FWD14 1
+#endif
+#ifndef SEALHIP_FUSED_INT_PF_FWD13
+#define SEALHIP_FUSED_INT_PF_FWD13 0
+#endif
+#ifndef SEALHIP_FUSED_INT_PF_INV
+#define SEALHIP_FUSED_INT_PF_INV 0
+#endif
+#ifndef SEALHIP_FUSED_INT_WAVES
+#define SEALHIP_FUSED_INT_WAVES 4
+#endif
 
-        template <int D1>
+        template <bool FP, int D1, int ICLS = 0>
         __device__ __forceinline__ void fwd_fused2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
-            typedef Field<true> F;
+            typedef Field<FP> F;
             typedef Geo<D1> G;
-            typedef FusedGeo<D1> FG;
+            typedef FusedGeo<D1, F::tw_words> FG;
+            typedef typename F::tw_t tw_t;
+            constexpr bool TWB_REGS = FP || SEALHIP_FUSED_INT_TWB_REGS;
+            constexpr bool PF = FP || (D1 == 6 && SEALHIP_FUSED_INT_PF_FWD14) || (D1 == 5 && SEALHIP_FUSED_INT_PF_FWD13);
             const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
-            const F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
-            const double *tab = tw_table<true>(a.t, false, prime);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
+            const tw_t *tab = tw_table<FP>(a.t, false, prime);
             uint64_t *mid = lds;
             uint64_t *xch = lds + team * kLds2Words;
             uint64_t *lds_wave = xch + (tid >> 6) * (4 * kRowWords);
-            double *twa = reinterpret_cast<double *>(lds + FG::main_words) + team * 240;
+            tw_t *twa = reinterpret_cast<tw_t *>(lds + FG::main_words) + team * 240;
             stage_twa<D1>(twa, tab, team, tid); // read after several workgroup barriers
             const unsigned c = tid & (G::C - 1);
             const unsigned hi = SHL_UNIFORM(tid >> G::LC); // rbl in phase A, ra in phase B: the same in every lane of a wave
-            TwRegs<true> twb, unused;
+            TwRegs<FP> twb, unused;
+            if constexpr (TWB_REGS)
             {
                 const unsigned h = team * 16 + (tid >> 4), v = tid & 15;
-                load_tw<true, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
+                load_tw<FP, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
             }
             uint64_t *base = a.data + ((size_t)comp << G::n);
             uint64_t nxt[16];
@@ -1218,20 +1246,23 @@ namespace sealhip
                 }
             };
             const unsigned ostride = gridDim.z;
-            fetch(outer);
+            if constexpr (PF)
+                fetch(outer);
             for (; outer < a.nouter; outer += ostride)
             {
-                F::elem x[16];
+                typename F::elem x[16];
+                if constexpr (!PF)
+                    fetch(outer);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     x[e] = F::from_canon(nxt[e], m);
-                if (outer + ostride < a.nouter)
-                    fetch(outer + ostride);
-                // ---- pass 1 on column tile `team`
-                phase_fwd<true, G::rA>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    F::fix(x[e], m);
+                if constexpr (PF)
+                {
+                    if (outer + ostride < a.nouter)
+                        fetch(outer + ostride);
+                }
+                // ---- pass 1 on column tile `team`: every twiddle is wave-uniform (scalar loads)
+                phase_fwd_end<FP, G::rA, true, ICLS, 4>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
                 __syncthreads(); // the previous transform's wave-local buffers are free
 #pragma unroll
                 for (int e = 0; e < 16; e++)
@@ -1244,10 +1275,8 @@ namespace sealhip
 #pragma unroll
                 for (int rb = 0; rb < 16; rb++)
                     x[rb] = F::unraw(xch[(hi * 16 + rb) * G::CP + c]);
-                phase_fwd<true, 4>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << (G::rA + t)) + (hi << t) + g); });
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    F::fix(x[e], m);
+                phase_fwd_end<FP, 4, true, ICLS, IntBounds<ICLS>::fwd_after(4, G::rA)>(
+                    x, m, [&](int t, int g) { return ld_uniform(tab, (1u << (G::rA + t)) + (hi << t) + g); });
                 __syncthreads(); // every team has read its exchange data: the area becomes the intermediate
                 {
                     const unsigned col = team * G::C + c;
@@ -1265,47 +1294,66 @@ namespace sealhip
                         x[e] = F::unraw(mp[e * FG::BS]);
                 }
                 __syncthreads(); // the intermediate is consumed: the area becomes the wave-local exchange buffers
-                p2_tile<true, D1, false, false, true, true>(x, m, tab, twa, nullptr, lds_wave, team, tid, &unused, &twb);
+                if constexpr (TWB_REGS)
+                    p2_tile<FP, D1, false, false, true, true, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, twa, nullptr, lds_wave, team, tid, &unused, &twb);
+                else
+                    p2_tile<FP, D1, false, true, false, true, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, twa, nullptr, lds_wave, team, tid);
                 uint64_t val[16];
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    val[e] = a.lazy ? F::fwd_to_lazy(x[e], m) : F::fwd_to_canon(x[e], m);
+                    val[e] = a.lazy ? fwd_out_lazy<FP, ICLS, kP2Out<ICLS, D1>>(x[e], m) : fwd_out_canon<FP, ICLS, kP2Out<ICLS, D1>>(x[e], m);
                 store_rows(val, lds_wave, base + (size_t)outer * a.outer_stride + ((size_t)(team * 16 + (tid >> 6) * 4) << 8), tid);
             }
         }
 
-        template <int D1>
-        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, 4) ntt2_fwd_fused2(FwdArgs a)
+        // CLS: 1 double-precision back end, 0 integer back end (one modulus class per workgroup)
+        template <int D1, int CLS>
+        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, CLS == 1 ? 4 : SEALHIP_FUSED_INT_WAVES) ntt2_fwd_fused2(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
-            fwd_fused2_body<D1>(a, prime, comp, outer, lds);
+            if constexpr (CLS == 1)
+                fwd_fused2_body<true, D1>(a, prime, comp, outer, lds);
+            else
+                with_int_class(a.t, prime, [&](auto ic) { fwd_fused2_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
         }
 
         // Inverse: team k undoes pass 2 on row tile k (rows -> intermediate in LDS), the teams meet, team k undoes
         // pass 1 on column tile k (N^-1 folded into the last stage) and stores natural order.
-        template <int D1>
+        template <bool FP, int D1, int ICLS = 2>
         __device__ __forceinline__ void inv_fused2_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
         {
-            typedef Field<true> F;
+            typedef Field<FP> F;
             typedef Geo<D1> G;
-            typedef FusedGeo<D1> FG;
+            typedef FusedGeo<D1, F::tw_words> FG;
+            typedef typename F::tw_t tw_t;
             static_assert(G::rA >= 1, "the N^-1 stage is handled in phase A");
+            constexpr bool PF = FP || SEALHIP_FUSED_INT_PF_INV;
             const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
             const unsigned v = tid & 15, u = tid >> 4, ul = u & 3, lane = tid & 63;
             const unsigned h = team * 16 + u;
-            const F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
-            const double *tab = tw_table<true>(a.t, true, prime);
+            const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
+            const tw_t *tab = tw_table<FP>(a.t, true, prime);
             uint64_t *mid = lds;
             uint64_t *xch = lds + team * kLds2Words;
             uint64_t *lds_wave = xch + (tid >> 6) * (4 * kRowWords);
-            double *twa = reinterpret_cast<double *>(lds + FG::main_words) + team * 240;
+            tw_t *twa = reinterpret_cast<tw_t *>(lds + FG::main_words) + team * 240;
             stage_twa<D1>(twa, tab, team, tid);
             const unsigned c = tid & (G::C - 1);
             const unsigned hi = SHL_UNIFORM(tid >> G::LC);
             const unsigned col = team * G::C + c;
-            const double ni = ld_uniform(a.t.ninv_d, 2 * prime), nw = ld_uniform(a.t.ninv_d, 2 * prime + 1);
+            tw_t ni, nw;
+            if constexpr (FP)
+            {
+                ni = ld_uniform(a.t.ninv_d, 2 * prime);
+                nw = ld_uniform(a.t.ninv_d, 2 * prime + 1);
+            }
+            else
+            {
+                ni = ld_uniform(a.t.ninv, 2 * prime);
+                nw = ld_uniform(a.t.ninv, 2 * prime + 1);
+            }
             const size_t comp_off = (size_t)comp << G::n;
             const size_t row_off = comp_off + ((size_t)(team * 16 + (tid >> 6) * 4) << 8);
             uint64_t nxt[16];
@@ -1316,10 +1364,13 @@ namespace sealhip
                     nxt[k] = rows[(k >> 2) * 256 + (k & 3) * 64 + lane];
             };
             const unsigned ostride = gridDim.z;
-            fetch(outer);
+            if constexpr (PF)
+                fetch(outer);
             __syncthreads(); // twa staged
             for (; outer < a.nouter; outer += ostride)
             {
+                if constexpr (!PF)
+                    fetch(outer);
                 // ---- rows of tile `team`: coalesced words -> wave-local transposition -> (row u, cols 16 v + e)
 #pragma unroll
                 for (int k = 0; k < 16; k++)
@@ -1328,7 +1379,7 @@ namespace sealhip
                     lds_wave[row * kRowWords + cc + 2 * (cc >> 4)] = nxt[k];
                 }
                 __builtin_amdgcn_wave_barrier();
-                F::elem x[16];
+                typename F::elem x[16];
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
@@ -1339,15 +1390,23 @@ namespace sealhip
                 {
                     // the 15 per-thread twiddles of this phase are re-read (L2) per transform: holding them next to the
                     // prefetched rows does not fit 128 VGPRs (measured: 40 spilled registers)
-                    TwRegs<true> twb;
-                    load_tw<true, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
-                    phase_inv<true, 4, 0>(x, m, [&](int t, int g) { return twb.get((1 << t) + g); });
+                    if constexpr (FP)
+                    {
+                        TwRegs<FP> twb;
+                        load_tw<FP, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
+                        phase_inv<FP, 4, 0, ICLS, 0>(x, m, [&](int t, int g) { return twb.get((1 << t) + g); });
+                    }
+                    else // integer back end: sixty registers of Shoup pairs at once do not fit next to the data; each is fetched where it is used
+                        phase_inv<FP, 4, 0, ICLS, 0>(x, m, [&](int t, int g) { return tab[(1u << (D1 + 4 + t)) + ((h * 16 + v) << t) + g]; });
                 }
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     F::fix(x[e], m);
-                if (outer + ostride < a.nouter)
-                    fetch(outer + ostride);
+                if constexpr (PF)
+                {
+                    if (outer + ostride < a.nouter)
+                        fetch(outer + ostride);
+                }
                 // wave-local exchange: (v', e') -> (e, v)
 #pragma unroll
                 for (int e = 0; e < 16; e++)
@@ -1356,7 +1415,7 @@ namespace sealhip
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     x[e] = F::unraw(lds_wave[ul * kRowWords + e * 18 + v]);
-                phase_inv<true, 4, 0>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
+                phase_inv<FP, 4, 0, ICLS, kInvE1<ICLS>>(x, m, [&](int t, int g) { return twa[(16u << t) - 16u + (u << t) + g]; });
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     F::fix(x[e], m);
@@ -1372,7 +1431,7 @@ namespace sealhip
                     for (int rb = 0; rb < 16; rb++)
                         x[rb] = F::unraw(i[rb * 16]);
                 }
-                phase_inv<true, 4, 0>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << (G::rA + t)) + (hi << t) + g); });
+                phase_inv<FP, 4, 0, ICLS, kInvE2<ICLS>>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << (G::rA + t)) + (hi << t) + g); });
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     F::fix(x[e], m);
@@ -1389,10 +1448,8 @@ namespace sealhip
                     x[e] = F::unraw(xch[R * G::CP + c]);
                 }
                 __syncthreads(); // (the next transform's row loads reuse the area)
-                phase_inv<true, G::rA, 1>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    F::bfly_inv_last(x[k], x[k | 8], ni, nw, m);
+                phase_inv<FP, G::rA, 1, ICLS, kInvE3<ICLS>>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
+                inv_last_stage<FP, G::rA, ICLS, kInvE3<ICLS>>(x, m, ni, nw);
                 uint64_t *o = a.data + (size_t)outer * a.outer_stride + comp_off;
 #pragma unroll
                 for (int e = 0; e < 16; e++)
@@ -1401,20 +1458,23 @@ namespace sealhip
                     const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
                     const unsigned R = ra * 16 + (rbh << G::rA) + hi;
                     uint64_t v = a.lazy ? F::inv_to_lazy(x[e], m) : F::inv_to_canon(x[e], m);
-                if (a.out_add)
-                    v = csub(v + a.out_add, a.t.mods[prime].q);
-                o[(size_t)R * 256 + col] = v;
+                    if (a.out_add)
+                        v = csub(v + a.out_add, a.t.mods[prime].q);
+                    o[(size_t)R * 256 + col] = v;
                 }
             }
         }
 
-        template <int D1>
-        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, 4) ntt2_inv_fused2(InvArgs a)
+        template <int D1, int CLS>
+        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, CLS == 1 ? 4 : SEALHIP_FUSED_INT_WAVES) ntt2_inv_fused2(InvArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
-            inv_fused2_body<D1>(a, prime, comp, outer, lds);
+            if constexpr (CLS == 1)
+                inv_fused2_body<true, D1>(a, prime, comp, outer, lds);
+            else
+                with_int_class(a.t, prime, [&](auto ic) { inv_fused2_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
         }
 
         // The key-switch kernels of N = 2^16 (eight stages per pass) use the lean fix() placement of p1_tile / p2_tile (tile-order
@@ -1886,6 +1946,13 @@ namespace sealhip
             return hipSuccess;
         }
 
+        // single-launch kernels for the integer back end (N = 2^13, 2^14); SEALHIP_NTT_NOFUSED_INT=1 keeps its two-launch engine (A/B runs)
+        inline bool fused_int()
+        {
+            static const bool on = !std::getenv("SEALHIP_NTT_NOFUSED_INT");
+            return on;
+        }
+
         template <int D1>
         hipError_t launch_fwd(const FwdArgs &a, unsigned nouter, hipStream_t s)
         {
@@ -1911,7 +1978,8 @@ namespace sealhip
                     if (!raised)
                     {
                         // above the default 64 KiB of dynamic LDS
-                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused2<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedGeo<D1>::lds_bytes) != hipSuccess)
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused2<D1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedGeo<D1>::lds_bytes) != hipSuccess ||
+                            hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_fwd_fused2<D1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FusedGeo<D1, 2>::lds_bytes)) != hipSuccess)
                             return hipErrorInvalidValue;
                         raised = true;
                     }
@@ -1935,7 +2003,13 @@ namespace sealhip
                 {
                     if (fused && r.cls == 1)
                     {
-                        hipLaunchKernelGGL((ntt2_fwd_fused2<D1>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), FusedGeo<D1>::lds_bytes, st, g);
+                        hipLaunchKernelGGL((ntt2_fwd_fused2<D1, 1>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), FusedGeo<D1>::lds_bytes, st, g);
+                        return hipGetLastError();
+                    }
+                    if (fused && r.cls == 0 && fused_int())
+                    {
+                        constexpr size_t lds_int = FusedGeo<D1, 2>::lds_bytes;
+                        hipLaunchKernelGGL((ntt2_fwd_fused2<D1, 0>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), lds_int, st, g);
                         return hipGetLastError();
                     }
                 }
@@ -2012,7 +2086,8 @@ namespace sealhip
                     static bool raised = false;
                     if (!raised)
                     {
-                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_inv_fused2<D1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedGeo<D1>::lds_bytes) != hipSuccess)
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_inv_fused2<D1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FusedGeo<D1>::lds_bytes) != hipSuccess ||
+                            hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt2_inv_fused2<D1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FusedGeo<D1, 2>::lds_bytes)) != hipSuccess)
                             return hipErrorInvalidValue;
                         raised = true;
                     }
@@ -2033,7 +2108,13 @@ namespace sealhip
                 {
                     if (fused && r.cls == 1)
                     {
-                        hipLaunchKernelGGL((ntt2_inv_fused2<D1>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), FusedGeo<D1>::lds_bytes, st, g);
+                        hipLaunchKernelGGL((ntt2_inv_fused2<D1, 1>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), FusedGeo<D1>::lds_bytes, st, g);
+                        return hipGetLastError();
+                    }
+                    if (fused && r.cls == 0 && fused_int())
+                    {
+                        constexpr size_t lds_int = FusedGeo<D1, 2>::lds_bytes;
+                        hipLaunchKernelGGL((ntt2_inv_fused2<D1, 0>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), lds_int, st, g);
                         return hipGetLastError();
                     }
                 }

@@ -141,7 +141,7 @@ int main()
                 const uint64_t w = (it & 8) ? q - 1 - (rng() & 3) : rng() % q;
                 const ShoupOp tw{ w, (uint64_t)((((u128)w) << 64) / q) };
                 const uint64_t xx = (it & 16) ? ~(uint64_t)0 - (rng() & 1023) : (it & 32) ? rng() : x;
-                const uint64_t hq = F::mul_hi_approx(xx, tw.wq), he = (uint64_t)(((u128)xx * tw.wq) >> 64);
+                const uint64_t hq = F::mul_hi_approx(xx, tw), he = (uint64_t)(((u128)xx * tw.wq) >> 64);
                 EXPECT(hq <= he && he - hq <= 2, "mul_hi_approx");
                 const uint64_t r4 = F::mul_lazy4(xx, tw, m), r2 = F::mul_lazy(xx, tw, m);
                 EXPECT(r4 < 4 * q && r4 % q == (uint64_t)(((u128)xx * w) % q), "mul_lazy4 q=%llu", (unsigned long long)q);

@@ -31,7 +31,9 @@ def test_ntt_two_pass_engine_mixed_primes(emu, n, bits):
 
 
 # single-launch kernels (ntt2_fwd_fused2 / ntt2_inv_fused2): the per-workgroup loop with the next transform in flight
-@pytest.mark.parametrize("n,bits,polys,chunks", [(8192, [50, 36, 60], 5, 2), (8192, [40], 3, 1), (16384, [50, 45], 3, 1), (16384, [60, 50], 4, 3)])
+@pytest.mark.parametrize("n,bits,polys,chunks", [(8192, [50, 36, 60], 5, 2), (8192, [40], 3, 1), (16384, [50, 45], 3, 1), (16384, [60, 50], 4, 3),
+                                                 # integer back end in one launch (round 3): the three modulus classes' bodies
+                                                 (8192, [60, 59, 57, 55], 5, 2), (16384, [58, 60, 51], 3, 1), (16384, [59, 40, 57], 4, 3)])
 def test_ntt_single_launch_loop(emu, monkeypatch, n, bits, polys, chunks):
     monkeypatch.setenv("SEALHIP_NTT_FCHUNKS", str(chunks))
     P.case_ntt(n, bits, polys=polys)

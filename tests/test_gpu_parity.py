@@ -43,6 +43,8 @@ def test_ntt(gpu, n, bits, polys):
 # transform in flight, and a forced one-workgroup-per-component loop
 @pytest.mark.parametrize("n,bits,polys,chunks", [
     (8192, [50, 36, 60], 5, 2), (8192, [50, 40, 40], 1100, 0), (16384, [50, 45, 60], 3, 1), (16384, [50, 50], 600, 0),
+    # integer back end in one launch (round 3), the three modulus classes; BASELINE configs[1]'s own chain at a bench-sized batch
+    (8192, [60, 59, 57, 55], 5, 2), (8192, [60, 40, 40, 60], 600, 0), (16384, [58, 60, 51], 3, 1), (16384, [59, 57], 300, 0),
 ])
 def test_ntt_single_launch_loop(gpu, monkeypatch, n, bits, polys, chunks):
     if chunks:
@@ -488,6 +490,17 @@ def test_graph_capture_replay(gpu, n, bits, batch):
     with pytest.raises(S.LogicError):
         d.ev.capture(step)
     d.ev.set_transparent_check(False)
+
+
+def test_device_field_check(gpu):
+    """the integer back end's gfx950 instruction sequences (field.h: products issued through single-instruction wrappers, device
+    only) against 128-bit arithmetic on the device itself: tests/device_field_check.hip, built by seal_amd/csrc/Makefile"""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "seal_amd", "lib", "device_field_check")
+    assert os.path.exists(exe), "seal_amd/lib/device_field_check is not built (make -C seal_amd/csrc gpu)"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "device_field_check ok" in out.stdout, out.stdout + out.stderr
 
 
 def test_mod_reduce(gpu):
