@@ -334,8 +334,10 @@ namespace sealhip
         if (keys_[index].dev)
             (void)hipFree(keys_[index].dev);
         void *p = nullptr;
-        ck(hipMalloc(&p, bytes), "hipMalloc key");
         const bool reorder = ntt2_supports(ctx.log_n()) && !std::getenv("SEALHIP_OLD_KS");
+        // register order carries a second plane: the Shoup quotients of the integer back end's components
+        const size_t plane_words = bytes / 8;
+        ck(hipMalloc(&p, reorder ? key_register_order_words(ctx.log_n(), (unsigned)L, digits * 2) * 8 : bytes), "hipMalloc key");
         if (reorder)
         {
             // upload to a staging block, then lay the key out for the fused kernel
@@ -350,6 +352,7 @@ namespace sealhip
         keys_[index].digits = digits;
         keys_[index].digit0 = digit0;
         keys_[index].register_order = reorder;
+        keys_[index].quot_off = reorder ? plane_words : 0;
     }
 
     // ---------------------------------------------------------------- Evaluator
@@ -1311,8 +1314,13 @@ namespace sealhip
         // steps (1)-(3): lift each input to q U Bsk and transform (evaluator.cpp:456-489)
         auto lift = [&](const Ciphertext &x, Scratch &xq, Scratch &xb) {
             size_t items = x.size() * B;
-            ck(hipMemcpyAsync(xq.p, x.data(), items * K * N * 8, hipMemcpyDeviceToDevice, stream_), "bfv copy");
-            ck(ntt_forward(tb, plain_batch(xq.p, (size_t)K * N, K, (unsigned)items, 0), 0, stream_), "bfv ntt q");
+            // out of place: the first pass reads the ciphertext itself (NttBatch::src, mode 0) - no copy of the input
+            NttBatch qb = plain_batch(xq.p, (size_t)K * N, K, (unsigned)items, 0);
+            qb.src = x.data();
+            qb.src_outer_stride = (size_t)K * N;
+            qb.src_ncomp = K;
+            qb.src_mode = 0;
+            ck(ntt_forward(tb, qb, 0, stream_), "bfv ntt q");
             ck(k_behz_lift(mods, lv, x.data(), xb.p, n_log, items, stream_), "behz lift");
             NttBatch bb = plain_batch(xb.p, (size_t)nBsk * N, nBsk, (unsigned)items, 0);
             bb.comp_prime = lv.bsk_prime;
@@ -1481,9 +1489,14 @@ namespace sealhip
         const ModDesc *mods = context_.dev_mods();
         const uint32_t *map = ks_comp_prime(K);
         // t_target: coefficient form of every decomposition digit (evaluator.cpp:2651-2658)
-        Scratch t((size_t)B * K * N);
         const bool ntt_target = scheme == Scheme::ckks || scheme == Scheme::bgv; // the target is in NTT form
-        if (ntt_target && ntt2_supports(context_.log_n()))
+        // BFV on the fused path: the target is in coefficient form already and the kernels only read it - no copy
+        const bool read_in_place = !ntt_target && key.register_order;
+        Scratch t(read_in_place ? 1 : (size_t)B * K * N);
+        const uint64_t *digits = read_in_place ? target : t.p;
+        if (read_in_place)
+            ;
+        else if (ntt_target && ntt2_supports(context_.log_n()))
         {
             // out-of-place: the two-pass engine reads the target and writes t
             NttBatch bt = plain_batch(t.p, (size_t)K * N, K, B, 0);
@@ -1505,9 +1518,10 @@ namespace sealhip
             const KsTargets &kt = ks_targets(K);
             Scratch mid((size_t)B * (K + 1) * K * N);
             KsFusedArgs ka{};
-            ka.t = t.p;
+            ka.t = digits;
             ka.target_ntt = ntt_target ? target : nullptr; // the I == J shortcut of evaluator.cpp:2682-2685
             ka.key = key.dev;
+            ka.key_quot_off = key.quot_off;
             ka.mid = mid.p;
             ka.acc = acc_out;
             ka.targets1 = kt.dev;
@@ -1538,7 +1552,7 @@ namespace sealhip
             b.nouter = B;
             b.comp_prime = map;
             b.prime_first = 0;
-            b.src = t.p;
+            b.src = digits;
             b.src_outer_stride = (size_t)K * N;
             b.src_ncomp = K;
             b.src_mode = 1;

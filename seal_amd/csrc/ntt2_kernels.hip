@@ -1192,20 +1192,29 @@ namespace sealhip
         //    the table of one prime is 16 N bytes), each where it is used;
         //  * PF: the next transform's sixteen words in flight during this one (32 VGPRs) fits the forward kernel at 2^14 only
         //    (124 registers); elsewhere it spills 28-76 bytes, and at 2^13 the second workgroup of the CU covers the load.
-#ifndef SEALHIP_FUSED_INT_TWB_REGS
-#define SEALHIP_FUSED_INT_TWB_REGS 0
+// forward: where pass 2's fifteen per-thread twiddles come from (0 fetched where used, 1 requested at the start of pass 2 of every
+// transform, 2 resident for the workgroup's loop), prefetch of the next transform at 2^13 / 2^14, waves per SIMD asked of the compiler
+#ifndef SEALHIP_FINT_FWD_TWB
+#define SEALHIP_FINT_FWD_TWB 0
 #endif
-#ifndef SEALHIP_FUSED_INT_PF_FWD14
-#define SEALHIP_FUSED_INT_PF_FWD14 1
+#ifndef SEALHIP_FINT_FWD_PF13
+#define SEALHIP_FINT_FWD_PF13 0
 #endif
-#ifndef SEALHIP_FUSED_INT_PF_FWD13
-#define SEALHIP_FUSED_INT_PF_FWD13 0
+#ifndef SEALHIP_FINT_FWD_PF14
+#define SEALHIP_FINT_FWD_PF14 1
 #endif
-#ifndef SEALHIP_FUSED_INT_PF_INV
-#define SEALHIP_FUSED_INT_PF_INV 0
+#ifndef SEALHIP_FINT_FWD_WAVES
+#define SEALHIP_FINT_FWD_WAVES 4
 #endif
-#ifndef SEALHIP_FUSED_INT_WAVES
-#define SEALHIP_FUSED_INT_WAVES 4
+// inverse: the first phase's per-thread twiddles fetched where used (0) or requested together with the rows (1); prefetch; waves
+#ifndef SEALHIP_FINT_INV_TWB
+#define SEALHIP_FINT_INV_TWB 1
+#endif
+#ifndef SEALHIP_FINT_INV_PF
+#define SEALHIP_FINT_INV_PF 0
+#endif
+#ifndef SEALHIP_FINT_INV_WAVES
+#define SEALHIP_FINT_INV_WAVES 4
 #endif
 
         template <bool FP, int D1, int ICLS = 0>
@@ -1215,8 +1224,9 @@ namespace sealhip
             typedef Geo<D1> G;
             typedef FusedGeo<D1, F::tw_words> FG;
             typedef typename F::tw_t tw_t;
-            constexpr bool TWB_REGS = FP || SEALHIP_FUSED_INT_TWB_REGS;
-            constexpr bool PF = FP || (D1 == 6 && SEALHIP_FUSED_INT_PF_FWD14) || (D1 == 5 && SEALHIP_FUSED_INT_PF_FWD13);
+            constexpr bool TWB_REGS = FP || (D1 == 5 && SEALHIP_FINT_FWD_TWB == 2); // 2^14: one 1024-thread workgroup, 128 registers
+            constexpr bool TWB_EARLY = !FP && D1 == 5 && SEALHIP_FINT_FWD_TWB == 1;
+            constexpr bool PF = FP || (D1 == 6 && SEALHIP_FINT_FWD_PF14) || (D1 == 5 && SEALHIP_FINT_FWD_PF13);
             const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const tw_t *tab = tw_table<FP>(a.t, false, prime);
@@ -1234,9 +1244,12 @@ namespace sealhip
                 load_tw<FP, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
             }
             uint64_t *base = a.data + ((size_t)comp << G::n);
+            // out of place (NttBatch::src with mode 0: the same residues, read from another buffer)
+            const uint64_t *in_base = a.src ? a.src + ((size_t)(comp % a.src_ncomp) << G::n) : base;
+            const size_t in_stride = a.src ? a.src_outer_stride : a.outer_stride;
             uint64_t nxt[16];
             auto fetch = [&](unsigned z) {
-                const uint64_t *in = base + (size_t)z * a.outer_stride + team * G::C + c;
+                const uint64_t *in = in_base + (size_t)z * in_stride + team * G::C + c;
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                 {
@@ -1293,8 +1306,15 @@ namespace sealhip
                     for (int e = 0; e < 16; e++)
                         x[e] = F::unraw(mp[e * FG::BS]);
                 }
+                if constexpr (TWB_EARLY)
+                {
+                    // requested before phase A so that they arrive during it (fetched where they are used, every stage of phase B
+                    // waits for a round trip to L2)
+                    const unsigned h = team * 16 + (tid >> 4), v = tid & 15;
+                    load_tw<FP, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
+                }
                 __syncthreads(); // the intermediate is consumed: the area becomes the wave-local exchange buffers
-                if constexpr (TWB_REGS)
+                if constexpr (TWB_REGS || TWB_EARLY)
                     p2_tile<FP, D1, false, false, true, true, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, twa, nullptr, lds_wave, team, tid, &unused, &twb);
                 else
                     p2_tile<FP, D1, false, true, false, true, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, twa, nullptr, lds_wave, team, tid);
@@ -1308,7 +1328,7 @@ namespace sealhip
 
         // CLS: 1 double-precision back end, 0 integer back end (one modulus class per workgroup)
         template <int D1, int CLS>
-        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, CLS == 1 ? 4 : SEALHIP_FUSED_INT_WAVES) ntt2_fwd_fused2(FwdArgs a)
+        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, CLS == 1 ? 4 : SEALHIP_FINT_FWD_WAVES) ntt2_fwd_fused2(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
@@ -1329,7 +1349,7 @@ namespace sealhip
             typedef FusedGeo<D1, F::tw_words> FG;
             typedef typename F::tw_t tw_t;
             static_assert(G::rA >= 1, "the N^-1 stage is handled in phase A");
-            constexpr bool PF = FP || SEALHIP_FUSED_INT_PF_INV;
+            constexpr bool PF = FP || (D1 == 5 && SEALHIP_FINT_INV_PF);
             const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
             const unsigned v = tid & 15, u = tid >> 4, ul = u & 3, lane = tid & 63;
             const unsigned h = team * 16 + u;
@@ -1371,6 +1391,9 @@ namespace sealhip
             {
                 if constexpr (!PF)
                     fetch(outer);
+                TwRegs<FP> twb_early;
+                if constexpr (!FP && SEALHIP_FINT_INV_TWB == 1) // the first phase's per-thread twiddles travel with the rows
+                    load_tw<FP, 4>(twb_early, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
                 // ---- rows of tile `team`: coalesced words -> wave-local transposition -> (row u, cols 16 v + e)
 #pragma unroll
                 for (int k = 0; k < 16; k++)
@@ -1396,7 +1419,9 @@ namespace sealhip
                         load_tw<FP, 4>(twb, tab, [&](int t) { return (1u << (D1 + 4 + t)) + ((h * 16 + v) << t); });
                         phase_inv<FP, 4, 0, ICLS, 0>(x, m, [&](int t, int g) { return twb.get((1 << t) + g); });
                     }
-                    else // integer back end: sixty registers of Shoup pairs at once do not fit next to the data; each is fetched where it is used
+                    else if constexpr (SEALHIP_FINT_INV_TWB == 1)
+                        phase_inv<FP, 4, 0, ICLS, 0>(x, m, [&](int t, int g) { return twb_early.get((1 << t) + g); });
+                    else // each twiddle fetched where it is used
                         phase_inv<FP, 4, 0, ICLS, 0>(x, m, [&](int t, int g) { return tab[(1u << (D1 + 4 + t)) + ((h * 16 + v) << t) + g]; });
                 }
 #pragma unroll
@@ -1466,7 +1491,7 @@ namespace sealhip
         }
 
         template <int D1, int CLS>
-        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, CLS == 1 ? 4 : SEALHIP_FUSED_INT_WAVES) ntt2_inv_fused2(InvArgs a)
+        __global__ void __launch_bounds__(FusedGeo<D1>::TEAMS *kThreads, CLS == 1 ? 4 : SEALHIP_FINT_INV_WAVES) ntt2_inv_fused2(InvArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
@@ -1626,6 +1651,7 @@ namespace sealhip
             const uint64_t *mid;     // [batch][K+1][K][N]
             const uint64_t *target;  // [batch][K][N] NTT form (CKKS diagonal shortcut) or null
             const uint64_t *key;     // [digits][2][L][N] register order
+            size_t key_quot_off;     // integer back end: the Shoup quotient of key word w is at w + key_quot_off
             uint64_t *acc;           // [batch][2][K+1][N] natural order, canonical
             const uint32_t *targets; // [ntargets] triples (I, prime, key component)
             unsigned ntargets;
@@ -1683,12 +1709,26 @@ namespace sealhip
                 __syncthreads();
             }
 
-            typename F::Acc acc0[16], acc1[16];
+            // double precision: sums of doubles, fixed every eight terms.  Integer back end (round 3): the key is the precomputed
+            // operand of a Shoup product (its quotient plane: key_to_register_order), so a term is x k mod q in [0, 4q) for any
+            // 64-bit x and the sum stays a 64-bit word - 2 VGPRs instead of the 4 of a 128-bit sum, 12 instructions a term with the
+            // addition riding in the remainder chain (field.h: mul_rem) - brought under 4 q every kAccRun terms.
+            typedef typename std::conditional<FP, typename F::Acc, uint64_t>::type acc_t;
+            constexpr unsigned kAccRun = ICLS == 2 ? 1 : IntBounds<ICLS>::lim / 4 - 1; // 4 (n + 1) q <= lim q
+            acc_t acc0[16], acc1[16];
 #pragma unroll
             for (int e = 0; e < 16; e++)
             {
-                acc0[e] = F::acc_zero();
-                acc1[e] = F::acc_zero();
+                if constexpr (FP)
+                {
+                    acc0[e] = F::acc_zero();
+                    acc1[e] = F::acc_zero();
+                }
+                else
+                {
+                    acc0[e] = 0;
+                    acc1[e] = 0;
+                }
             }
             const typename F::key_t *key = reinterpret_cast<const typename F::key_t *>(a.key);
             const size_t N = (size_t)1 << G::n;
@@ -1714,9 +1754,12 @@ namespace sealhip
                         nxt[e] = mp[e * 256];
                 }
             };
-            // The integer back end has no registers to spare for the prefetch: measured on MI355X, prefetching with
-            // the overflow spilled to scratch gains nothing and one wave per SIMD (512 registers) loses 10 %.
-            constexpr bool PF = FP;
+            // Integer back end: with 128-bit sums there were no registers for the prefetch (round 2: the overflow spilled to
+            // scratch gained nothing, one wave per SIMD lost 10 %); with 64-bit sums (round 3) digit J + 1 travels during digit J
+#ifndef SEALHIP_KS2_INT_PF
+#define SEALHIP_KS2_INT_PF 1
+#endif
+            constexpr bool PF = FP || SEALHIP_KS2_INT_PF;
             if constexpr (PF)
             {
                 if (j0 < j1)
@@ -1755,17 +1798,16 @@ namespace sealhip
                     if (J + 1 < j1)
                         fetch(J + 1);
                 }
+                else if constexpr (PF)
+                {
+                    if (J + 1 < j1)
+                        fetch(J + 1);
+                }
                 if (!is_diag)
                 {
                     p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1>, ICLS, kP1Out<ICLS, D1>>(x, m, tab, twa, twb, lds_wave, hg, tid);
-                    // integer back end: 128-bit sums of x * key.  q < 2^60: x < 4 q < 2^62 and key < 2^60 give terms below 2^122,
-                    // and SEAL's 64 moduli at most (63 digits) stay below 2^128 - no need to canonicalise x; 61-bit moduli do
-                    if constexpr (!FP)
-                    {
-#pragma unroll
-                        for (int e = 0; e < 16; e++)
-                            x[e] = ICLS == 2 ? F::fwd_to_canon(x[e], m) : fwd_out_lazy<FP, ICLS, kP2Out<ICLS, D1>>(x[e], m);
-                    }
+                    // integer back end: the Shoup product takes any 64-bit x (the transform's results are below kP2Out q); the
+                    // guarded class (moduli of 2^60 and above: never a key-switch target, kept for completeness) works in [0, 2q)
                 }
                 if constexpr (FP)
                 {
@@ -1778,32 +1820,65 @@ namespace sealhip
                 }
                 else
                 {
+                    const size_t qo = a.key_quot_off;
 #pragma unroll
                     for (int e = 0; e < 16; e++)
                     {
-                        F::mac(acc0[e], x[e], k0[e * 256], m);
-                        F::mac(acc1[e], x[e], k1[e * 256], m);
+                        const ShoupOp w0{ k0[e * 256], k0[e * 256 + qo] }, w1{ k1[e * 256], k1[e * 256 + qo] };
+                        if constexpr (ICLS == 2)
+                        {
+                            acc0[e] = F::guard(acc0[e] + F::mul_lazy(x[e], w0, m), m);
+                            acc1[e] = F::guard(acc1[e] + F::mul_lazy(x[e], w1, m), m);
+                        }
+                        else
+                        {
+                            acc0[e] = F::mul_rem(x[e], w0, F::mul_hi_approx(x[e], w0), acc0[e], m);
+                            acc1[e] = F::mul_rem(x[e], w1, F::mul_hi_approx(x[e], w1), acc1[e], m);
+                        }
                     }
                 }
-                if (((J - j0) & 7) == 7)
+                if constexpr (FP)
                 {
-#pragma unroll
-                    for (int e = 0; e < 16; e++)
+                    if (((J - j0) & 7) == 7)
                     {
-                        F::acc_fix(acc0[e], m);
-                        F::acc_fix(acc1[e], m);
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                        {
+                            F::acc_fix(acc0[e], m);
+                            F::acc_fix(acc1[e], m);
+                        }
+                    }
+                }
+                else if constexpr (ICLS != 2)
+                {
+                    if ((J - j0) % kAccRun == kAccRun - 1)
+                    {
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                        {
+                            F::template fix4<IntBounds<ICLS>::hi32>(acc0[e], m);
+                            F::template fix4<IntBounds<ICLS>::hi32>(acc1[e], m);
+                        }
                     }
                 }
             }
             uint64_t val[16];
             uint64_t *out = acc_part + ((((size_t)b * 2 + 0) * (a.K + 1) + I) << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+            auto sum_to_canon = [&](const acc_t &s) {
+                if constexpr (FP)
+                    return F::acc_to_canon(s, m);
+                else if constexpr (ICLS == 2)
+                    return csub(s, m.q);
+                else
+                    return F::template canon_any<IntBounds<ICLS>::hi32>(s, m);
+            };
 #pragma unroll
             for (int e = 0; e < 16; e++)
-                val[e] = F::acc_to_canon(acc0[e], m);
+                val[e] = sum_to_canon(acc0[e]);
             store_rows(val, lds_wave, out, tid);
 #pragma unroll
             for (int e = 0; e < 16; e++)
-                val[e] = F::acc_to_canon(acc1[e], m);
+                val[e] = sum_to_canon(acc1[e]);
             store_rows(val, lds_wave, out + ((size_t)(a.K + 1) << G::n), tid);
         }
 
@@ -1837,7 +1912,7 @@ namespace sealhip
 
         // natural order (u64) -> register order, optionally converted to double
         __global__ void __launch_bounds__(kThreads) key_layout_kernel(
-            const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys)
+            const uint64_t *in, uint64_t *out, const FpDesc *fpd, const ModDesc *mods, unsigned L, unsigned n_log, size_t polys)
         {
             const size_t N = (size_t)1 << n_log;
             const size_t total = polys * L * N;
@@ -1859,7 +1934,24 @@ namespace sealhip
                     out[i] = fp_to_bits(d);
                 }
                 else
+                {
+                    // integer back end: the word and, one plane further on, floor(v 2^64 / q) (exact: estimate from the
+                    // Barrett ratio floor(2^128 / q), then at most two corrections)
+                    typedef unsigned __int128 u128;
+                    const ModDesc md = mods[comp];
+                    const u128 ratio = ((u128)md.ratio_hi << 64) | md.ratio_lo;
+                    const u128 vr = (u128)v * md.ratio_hi + (((u128)v * md.ratio_lo) >> 64); // floor(v * ratio / 2^64), below 2^64 + 1
+                    (void)ratio;
+                    uint64_t est = vr > (u128)~(uint64_t)0 ? ~(uint64_t)0 : (uint64_t)vr;
+                    u128 rem = ((u128)v << 64) - (u128)est * md.q;
+                    while (rem >= md.q)
+                    {
+                        rem -= md.q;
+                        est++;
+                    }
                     out[i] = v;
+                    out[total + i] = est;
+                }
             }
         }
 
@@ -1919,14 +2011,14 @@ namespace sealhip
         }
         // run(r, stream) launches the kernels of one run; the longest run stays on `s`
         template <class RunFn>
-        hipError_t launch_runs(const std::vector<CompRun> &runs, hipStream_t s, RunFn run)
+        hipError_t launch_runs(const std::vector<CompRun> &runs, hipStream_t s, RunFn run, bool may_fork = true)
         {
             size_t longest = 0;
             for (size_t i = 1; i < runs.size(); i++)
                 if (runs[i].nc > runs[longest].nc)
                     longest = i;
             SideStream &ss = side_stream();
-            const bool fork = runs.size() > 1 && ss.ok;
+            const bool fork = may_fork && runs.size() > 1 && ss.ok;
             hipError_t e;
             if (fork)
             {
@@ -1972,7 +2064,7 @@ namespace sealhip
             if constexpr (D1 == 5 || D1 == 6)
             {
                 static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED");
-                if (fused_ok && !a.src && a.epi == 0)
+                if (fused_ok && (!a.src || a.src_mode == 0) && a.epi == 0)
                 {
                     static bool raised = false;
                     if (!raised)
@@ -2035,7 +2127,10 @@ namespace sealhip
                 else
                     hipLaunchKernelGGL((ntt2_fwd_p2<D1, 2>), grid, dim3(kThreads), kLds2Words * 8, st, g);
                 return hipGetLastError();
-            });
+            }, !(fused && fused_int()));
+            // single-launch kernels of both classes: one after the other.  Side by side a CU holds one workgroup of each (LDS), and
+            // each class loses the partner workgroup that covers its latencies: measured at configs[1]'s chain {60,40,40,60}, 8192
+            // polynomials: 2.83 / 3.02 TB/s forked, 2.97 / 3.12 in sequence (profiles/r03_configs1_chain.txt)
         }
 
         template <int D1>
@@ -2135,7 +2230,7 @@ namespace sealhip
                 else
                     hipLaunchKernelGGL((ntt2_inv_pb<D1, 2>), grid, dim3(kThreads), G::lds1_words * 8, st, g);
                 return hipGetLastError();
-            });
+            }, !(fused && fused_int()));
         }
 
         template <int D1>
@@ -2346,6 +2441,7 @@ namespace sealhip
         a2.mid = k.mid;
         a2.target = k.target_ntt;
         a2.key = k.key;
+        a2.key_quot_off = k.key_quot_off;
         a2.acc = k.acc;
         a2.targets = k.targets2;
         a2.ntargets = k.ntargets;
@@ -2379,7 +2475,7 @@ namespace sealhip
         size_t blocks = (total + kThreads - 1) / kThreads;
         if (blocks > 4096)
             blocks = 4096;
-        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, L, (unsigned)t.log_n, polys);
+        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, t.mods, L, (unsigned)t.log_n, polys);
         return hipGetLastError();
     }
 } // namespace sealhip
