@@ -23,6 +23,9 @@ One JSON line is printed by rank 0 with, besides the contract fields:
   roofline     the NTT (dominant kernel family) measured live with HIP events on the stream it runs on; achieved = algorithmic
                bytes (16*N per RNS-component transform) / time; peak = 8 TB/s HBM (guide); traffic = HBM bytes
                per launch from two rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE) taken by this run (traffic_source says so)
+  roofline_step  the timed step itself: SURVEY 8(d)'s algorithmic bytes per ciphertext x the measured rate against the HBM peak, with
+               the key counted per ciphertext and per batch; and the kernels that bound the step (key switch, BEHZ: vector ALU)
+               from one live rocprofv3 --pmc pass - share of GPU time, VALU wave instructions, issue utilisation
   roofline_configs1  the same measurement at BASELINE configs[1] (CKKS N=8192, L=4: forward and inverse NTT over all RNS components)
   cpu_baseline the reference's own Evaluator (oracle/_ref = Microsoft SEAL 4.4.3, HEXL off) timed on this host's cores on a
                bounded sample, rank 0, N=1 only.  Checker/baseline only — never the thing measured.
@@ -74,6 +77,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-reps", type=int, default=2)
     ap.add_argument("--ntt-only", action="store_true", help="only the NTT roofline leg (for rocprofv3 runs)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--step-child", action="store_true", help=argparse.SUPPRESS)  # the timed step alone, under rocprofv3 --pmc (roofline_step)
     ap.add_argument("--streams", type=int, default=1, help="headline / bfv_c4: divide the GPU's batch over this many evaluators, each on its "
                     "own HIP stream, so that one sub-batch's memory-bound phases overlap another's key switching")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (Evaluator_BeginCapture/EndCapture): "
@@ -109,6 +113,8 @@ def main():
     args = parse()
     if args.pmc_child:
         return pmc_child(args)
+    if args.step_child:
+        args.no_cpu_baseline = args.no_pmc = args.no_verify = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
     import torch
@@ -302,7 +308,7 @@ def main():
 
     # ---- roofline leg: the batched forward NTT over the resident batch (2*B polys x K comps)
     roofline = None
-    if rank == 0 and scheme == "ckks" and not EMU:
+    if rank == 0 and not EMU and not args.step_child:
         buf_words = xs.numel()
         timer = S.HipTimer()
         polys = 2 * B
@@ -324,7 +330,7 @@ def main():
         assert buf_words == 2 * B * K * n
 
     ntt_c1 = None
-    if rank == 0 and world == 1 and args.workload == "headline" and not EMU:
+    if rank == 0 and world == 1 and args.workload == "headline" and not EMU and not args.step_child:
         ntt_c1 = ntt_configs1(S, torch, device)
 
     # free the device before the PMC child processes and the CPU baseline start
@@ -336,6 +342,20 @@ def main():
         torch.cuda.empty_cache()
         S.release_pool()
         roofline.update(pmc_traffic(args, B, K, n))
+
+    roofline_step = None
+    if rank == 0 and result and not EMU and not args.step_child:
+        # the whole step against the memory roofline in both accountings, and the kernels that actually bound it (vector ALU)
+        sb = step_bytes(args.workload, K, L, n)
+        cts_per_s_per_gpu = result["value"] / world
+        roofline_step = dict(
+            bound="valu", note="the step is bound by vector-ALU issue in the key-switch (and BEHZ) kernels, not by HBM: the memory "
+            "fractions below are what the algorithmic bytes amount to, the kernel table says how busy the vector ALU is",
+            algorithmic_bytes_per_ciphertext=sb, peak=HBM_PEAK_GBS, unit="GB/s",
+            achieved={k: round(v * cts_per_s_per_gpu / 1e9, 1) for k, v in sb.items()},
+            frac={k: round(v * cts_per_s_per_gpu / 1e9 / HBM_PEAK_GBS, 4) for k, v in sb.items()})
+        if world == 1 and not args.no_pmc:
+            roofline_step.update(step_counters(args, B))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.ntt_only and not EMU:
@@ -374,7 +394,7 @@ def main():
                         arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for primes below "
                                    "2^50, 64-bit Shoup/Barrett integer arithmetic for larger primes; results canonical u64",
                         key_bytes=2 * K * L * n * 8, algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n),
-            roofline=roofline, roofline_configs1=ntt_c1, cpu_baseline=cpu)
+            roofline=roofline, roofline_step=roofline_step, roofline_configs1=ntt_c1, cpu_baseline=cpu)
     # RCCL prints a version banner through C stdio when a communicator comes up; it sits in the C buffer until exit.  Tear
     # the process group down and flush the C streams first, so that the JSON line is the LAST thing on stdout.
     del dp
@@ -512,12 +532,14 @@ PMC_CALLS = 3
 def pmc_child(args):
     """Run under `rocprofv3 --kernel-trace --pmc <counter>`: the roofline leg's launch (same shape), no torch, PMC_CALLS calls."""
     import seal_amd as S
-    scheme, n, bits, _, default_batch = WORKLOADS["headline"]
+    scheme, n, bits, tbits, default_batch = WORKLOADS[args.workload]
     primes = S.CoeffModulus.Create(n, bits)
     K = len(primes) - 1
     parms = S.EncryptionParameters(scheme)
     parms.set_poly_modulus_degree(n)
     parms.set_coeff_modulus(primes)
+    if scheme != "ckks":
+        parms.set_plain_modulus(S.PlainModulus.Batching(n, tbits))
     ctx = S.SEALContext(parms, True, 0)
     polys = 2 * (args.batch or default_batch)
     buf = S.DeviceBuffer(polys * K * n)  # contents do not matter for the byte counters
@@ -545,7 +567,7 @@ def pmc_traffic(args, B, K, n):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "r", "--", sys.executable, os.path.abspath(__file__),
-                   "--pmc-child", "--batch", str(B)]
+                   "--pmc-child", "--batch", str(B), "--workload", args.workload]
             env = dict(os.environ, TMPDIR="/tmp")
             p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
             dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
@@ -571,6 +593,78 @@ def pmc_traffic(args, B, K, n):
         return dict(traffic=None, traffic_source="PMC passes failed: %r" % (e,))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ---- roofline_step: the kernels that dominate the timed step, by this run's own counters --------------------------------
+VALU_CYCLES_PER_WAVE_INST = 4      # a wave64 VALU instruction occupies a SIMD16 for four cycles (MI355X_MICROARCH.md; measured 4.2-5)
+SIMDS, ENGINE_HZ = 256 * 4, 2.4e9
+
+
+def step_counters(args, B):
+    """One rocprofv3 --kernel-trace --pmc pass over a child that runs the timed step alone (a smaller batch: the per-dispatch
+    figures scale with it, the utilisation does not once the chip is full).  Per kernel: share of the step's GPU time, wave
+    instructions on the vector ALU per dispatch, and issue utilisation = those x 4 cycles / (duration x 1024 SIMDs x 2.4 GHz)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return dict(source="rocprofv3 not found on this host")
+    child_batch = max(1, min(B, 64))
+    tmp = tempfile.mkdtemp(prefix="sealhip_step_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "-d", tmp, "-o", "r", "--",
+               sys.executable, os.path.abspath(__file__), "--step-child", "--workload", args.workload, "--batch", str(child_batch),
+               "--total-batch", str(child_batch), "--steps", "2", "--warmup", "1"]
+        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+        if p.returncode != 0 or not dbs:
+            return dict(source="rocprofv3 --pmc pass failed (rc %d): %s" % (p.returncode, (p.stderr or p.stdout)[-300:]))
+        cur = sqlite3.connect(dbs[0]).cursor()
+        rows = cur.execute("select kernel_name, counter_name, count(*), sum(value), sum(duration) from counters_collection "
+                           "group by kernel_name, counter_name").fetchall()
+        table = {}
+        for name, ctr, cnt, val, dur in rows:
+            if "sealhip" not in name:
+                continue  # torch's input generation, copies
+            short = name.replace("sealhip::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            e = table.setdefault(short, dict(dispatches=cnt, ns=float(dur)))
+            e[ctr] = float(val)
+        total_ns = sum(e["ns"] for e in table.values()) or 1.0
+        out = []
+        for k, e in sorted(table.items(), key=lambda kv: -kv[1]["ns"])[:8]:
+            insts = e.get("SQ_INSTS_VALU", 0.0)
+            util = insts * VALU_CYCLES_PER_WAVE_INST / (e["ns"] * 1e-9 * SIMDS * ENGINE_HZ) if e["ns"] else 0.0
+            row = dict(kernel=k, share_of_gpu_time=round(e["ns"] / total_ns, 3), dispatches=e["dispatches"],
+                       avg_ms=round(e["ns"] / e["dispatches"] / 1e6, 4), valu_wave_insts_per_dispatch=int(insts / e["dispatches"]),
+                       valu_issue_utilisation=round(util, 3))
+            if e.get("SQ_WAVE_CYCLES"):
+                row["waiting_to_issue_frac_of_wave_cycles"] = round(e.get("SQ_WAIT_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3)
+            out.append(row)
+        return dict(source="live: one rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY pass over "
+                           "`bench.py --step-child --batch %d` (3 steps); utilisation = VALU wave instructions x %d cycles / (kernel time "
+                           "x %d SIMDs x %.1f GHz)" % (child_batch, VALU_CYCLES_PER_WAVE_INST, SIMDS, ENGINE_HZ / 1e9),
+                    kernels=out)
+    except Exception as e:  # the counters must never take the benchmark down
+        return dict(source="PMC pass failed: %r" % (e,))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def step_bytes(workload, K, L, n):
+    """algorithmic bytes of one ciphertext through the timed step (words of 8 bytes; twiddles and scratch excluded),
+    with the switching key read once per ciphertext / once per batch (what the kernels do: it stays in L2 for the whole batch)."""
+    key = 2 * K * L * n * 8
+    if workload == "rotate_c5":
+        total = (2 * K * K + 10 * K - 2) * 8 * n          # apply_galois + key switch + rescale
+    else:
+        total = (2 * K * K + 18 * K - 2) * 8 * n          # multiply + relinearize + rescale / mod_switch
+    out = dict(with_key=total, key_amortised=total - key)
+    if workload == "bfv_c4":
+        # BEHZ multiply is transform-heavy: (8K+4) forward + (6K+3) inverse transforms of 16 N bytes each, K(K+1) more in the key switch
+        out["ntt_equivalent"] = ((8 * K + 4) + (6 * K + 3) + K * (K + 1) + 2 * K) * 16 * n
+    return out
 
 
 # ---- CPU baseline --------------------------------------------------------------------------------------------------

@@ -21,8 +21,12 @@
 // kept as read-only mirrors (PROT_READ) so that a second use skips the upload; a host write drops them.  With the
 // reference's allocator hook (SEAL_MALLOC / SEAL_FREE, util/defines.h:170-179, pointed at seal_alloc_hook.cpp by
 // integration/config_hip) pool chunks are page-aligned, so a ciphertext buffer is whole pages; without the hook the
-// unaligned head and tail of a buffer are copied down eagerly after every operation.  SEALHIP_DROPIN_EAGER=1 restores the
-// upload / download per call of the first version (A/B runs).
+// unaligned head and tail of a buffer are copied down eagerly after every operation.
+// This mode is OPT-IN since round 3 (SEALHIP_DROPIN_RESIDENT=1 or sealhip_dropin_set_resident(1)): it asks things of the host
+// that the reference's contract does not (one thread at a time on a shadowed buffer, no system call on it without
+// sealhip_dropin_settle() first, SIGSEGV left to this library) - INTEGRATION.md section 2c.  The DEFAULT uploads the operands
+// and downloads the results of every call: valid for any thread and any kind of access, 40 ms instead of 12 ms for the
+// chained program of section 2b.
 //
 // Built by integration/Makefile into integration/_build/libsealdropin*.so together with the reference's other objects;
 // tests/test_dropin.py drives it through the same flat C shim as the real reference and compares word for word.
@@ -164,17 +168,20 @@ namespace
     Mirrors &mirrors();
     void segv_handler(int sig, siginfo_t *info, void *uctx);
     void settle_all_at_exit();
+    void enable_resident(Mirrors &mm);
 
-    Mirrors &mirrors()
+    // Device-resident shadows are OPT-IN (round 3): SEALHIP_DROPIN_RESIDENT=1 or sealhip_dropin_set_resident(1).
+    // The default copies every result down before the call returns, which is what the reference's contract needs in general -
+    // any thread, any kind of access to Ciphertext::data() (also from system calls, which do not fault on a protected page but
+    // fail with EFAULT), no signal handler in the process.  See INTEGRATION.md section 2c for what resident mode asks of a host.
+    void enable_resident(Mirrors &mm)
     {
-        static Mirrors *m = [] {
-            auto *mm = new Mirrors; // never destroyed: the handler may run during process teardown
-            mm->page = (std::size_t)sysconf(_SC_PAGESIZE);
-            mm->eager = std::getenv("SEALHIP_DROPIN_EAGER") != nullptr;
-            mm->trace = std::getenv("SEALHIP_DROPIN_TRACE") != nullptr;
+        static bool installed = false;
+        if (!installed)
+        {
+            installed = true;
             // the library must not register our (pageable) buffers with the driver: their protection changes
-            if (!mm->eager)
-                SealHip_SetStagedHostCopies(true);
+            SealHip_SetStagedHostCopies(true);
             // At process exit every shadow is settled while the HIP runtime is still alive (this handler is registered late, so
             // it runs before the destructors of the pools and of the runtime): afterwards nothing is protected any more and
             // later calls, if any, copy eagerly.
@@ -183,7 +190,19 @@ namespace
             sa.sa_sigaction = segv_handler;
             sa.sa_flags = SA_SIGINFO | SA_NODEFER;
             sigemptyset(&sa.sa_mask);
-            sigaction(SIGSEGV, &sa, &mm->previous);
+            sigaction(SIGSEGV, &sa, &mm.previous);
+        }
+        mm.eager = false;
+    }
+    Mirrors &mirrors()
+    {
+        static Mirrors *m = [] {
+            auto *mm = new Mirrors; // never destroyed: the handler may run during process teardown
+            mm->page = (std::size_t)sysconf(_SC_PAGESIZE);
+            mm->eager = true;
+            mm->trace = std::getenv("SEALHIP_DROPIN_TRACE") != nullptr;
+            if (std::getenv("SEALHIP_DROPIN_RESIDENT") && !std::getenv("SEALHIP_DROPIN_EAGER"))
+                enable_resident(*mm);
             return mm;
         }();
         return *m;
@@ -1038,6 +1057,31 @@ extern "C" void sealhip_host_free(void *ptr)
     std::free(ptr);
 }
 // counters for tests and tools: uploads, downloads, operands found on the device, faults served
+// resident mode on / off at run time (off: every shadow is settled first).  Returns the previous setting.
+extern "C" int sealhip_dropin_set_resident(int on)
+{
+    Mirrors &mm = mirrors();
+    std::lock_guard<std::recursive_mutex> g(mm.mu);
+    const int was = mm.eager ? 0 : 1;
+    if (on)
+        enable_resident(mm);
+    else if (!mm.eager)
+    {
+        resolve_range(0, ~(std::uintptr_t)0);
+        mm.eager = true;
+    }
+    return was;
+}
+// resident mode: make the host copies of [ptr, ptr + bytes) current and unprotected (bytes == 0: of everything).  What a host
+// calls before it hands Ciphertext::data() to anything that is not an ordinary load or store of its own threads: write(2) /
+// send(2), another device's copy engine, a thread that must not take a signal.
+extern "C" void sealhip_dropin_settle(const void *ptr, std::size_t bytes)
+{
+    if (!bytes)
+        resolve_range(0, ~(std::uintptr_t)0);
+    else
+        resolve_range(reinterpret_cast<std::uintptr_t>(ptr), reinterpret_cast<std::uintptr_t>(ptr) + bytes);
+}
 extern "C" void sealhip_dropin_stats(uint64_t *uploads, uint64_t *downloads, uint64_t *reused, uint64_t *faults)
 {
     Mirrors &mm = mirrors();

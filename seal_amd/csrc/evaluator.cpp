@@ -107,14 +107,46 @@ namespace sealhip
     {
         release();
     }
+    namespace
+    {
+        // settle() runs from const accessors, and the reference lets several threads read one ciphertext at a time (evaluator.h:
+        // "concurrent calls on different destinations are safe"): exactly one of them may take the pending tail, the others wait
+        // until it has been launched.  One mutex per ciphertext would grow every object; a small table keyed by address does.
+        std::mutex g_settle_mu[64];
+        inline std::mutex &settle_mutex(const void *p)
+        {
+            return g_settle_mu[(reinterpret_cast<uintptr_t>(p) >> 6) & 63];
+        }
+        thread_local const Ciphertext *tl_settling = nullptr; // the tail's own kernels read the words through data() / plane()
+    } // namespace
     void Ciphertext::settle() const
     {
-        if (!lazy_)
+        if (!__atomic_load_n(&lazy_, __ATOMIC_ACQUIRE) || tl_settling == this)
             return;
-        const LazyTail t = *lazy_;
-        delete lazy_;
-        lazy_ = nullptr;
-        t.owner->complete_tail(const_cast<Ciphertext &>(*this), t);
+        std::lock_guard<std::mutex> lock(settle_mutex(this));
+        struct Marker
+        {
+            const Ciphertext *saved;
+            explicit Marker(const Ciphertext *c) : saved(tl_settling) { tl_settling = c; }
+            ~Marker() { tl_settling = saved; }
+        } marker(this);
+        LazyTail *pending = lazy_;
+        if (!pending)
+            return; // another thread completed it while this one waited
+        const LazyTail t = *pending;
+        // the words are valid once complete_tail() returns; only then may a reader that skips the lock see "nothing pending"
+        try
+        {
+            t.owner->complete_tail(const_cast<Ciphertext &>(*this), t);
+        }
+        catch (...)
+        {
+            __atomic_store_n(&lazy_, (LazyTail *)nullptr, __ATOMIC_RELEASE);
+            delete pending;
+            throw;
+        }
+        __atomic_store_n(&lazy_, (LazyTail *)nullptr, __ATOMIC_RELEASE);
+        delete pending;
     }
     void Ciphertext::drop_lazy()
     {

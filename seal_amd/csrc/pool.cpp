@@ -206,7 +206,10 @@ namespace sealhip
         auto it = live_.find(p);
         if (it == live_.end())
             return;
-        free_.emplace(it->second.bytes, Block{ p, Tag::unknown, nullptr });
+        if (t.holding)
+            t.hold_free.emplace(it->second.bytes, p); // recorded nodes may reference it: it stays with the graph (see below)
+        else
+            free_.emplace(it->second.bytes, Block{ p, Tag::unknown, nullptr });
         live_.erase(it);
     }
 
@@ -219,8 +222,12 @@ namespace sealhip
         auto it = live_.find(p);
         if (it == live_.end())
             return;
-        if (t.holding && it->second.held)
-            t.hold_free.emplace(it->second.bytes, p); // stays with the graph being recorded
+        // While this thread records a graph EVERY block it frees stays with the recording - also one that was allocated before
+        // the recording began (a destination whose old slab is replaced inside it): recorded nodes hold its address, so it must
+        // not be handed to another object before the graph is destroyed, and no pool block may ever be tagged with the
+        // capturing stream (another thread taking it would record an event on / wait for a stream that is capturing).
+        if (t.holding)
+            t.hold_free.emplace(it->second.bytes, p);
         else
             free_.emplace(it->second.bytes, Block{ p, Tag::stream, stream });
         live_.erase(it);

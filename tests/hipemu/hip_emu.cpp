@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <ucontext.h>
+#include <mutex>
 #include <vector>
 
 uint3_emu threadIdx, blockIdx;
@@ -85,8 +86,13 @@ namespace hipemu
         return g_mail[wave][gen & 1][src_lane];
     }
 
+    // the fibers and their scheduler are process-wide state: launches of several host threads (the threaded tests of the
+    // library's own locking) run one after the other
+    static std::mutex g_launch_mu;
+
     void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body)
     {
+        std::lock_guard<std::mutex> one_at_a_time(g_launch_mu);
         int nthreads = (int)(block.x * block.y * block.z);
         if (nthreads > kMaxThreads || shmem > kLds)
         {

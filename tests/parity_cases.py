@@ -948,3 +948,49 @@ def case_multi_level_bfv_bgv(scheme, n, primes, t, batch=2, seed=43):
         raise AssertionError("rescale_to is CKKS only (reference)")
     except sealref.RefError as e:
         assert e.code == 1
+
+
+# ---- a pending key-switch tail and two threads that read the same ciphertext at once (settle() runs from const accessors)
+def case_deferred_tail_two_readers(n=8192, bits=(50, 40, 40, 60), rounds=6):
+    """The reference lets several threads use one ciphertext as an operand at the same time.  Here the operand carries a
+    deferred key-switch tail: exactly one of the readers may run it (the counters say so), both must see the completed words."""
+    import threading
+    primes = coeff_modulus_create(n, list(bits))
+    K = len(primes) - 1
+    o = Oracle("ckks", n, primes)
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(17)
+    x, y = rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)
+    z1, z2 = rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)
+    ref_relin = o.relinearize(o.multiply(x, y))
+    qk = np.array(primes[:K], dtype=np.uint64)[None, :, None]
+    defers = 13 <= n.bit_length() - 1 <= 16 and not os.environ.get("SEALHIP_KS_EAGER_TAIL")
+    ev2 = S.Evaluator(d.ctx)
+    for r in range(rounds):
+        a, b = d.ct([x], scale=2.0 ** 10), d.ct([y], scale=2.0 ** 10)
+        d.ev.multiply_inplace(a, b)
+        d.ev.relinearize_inplace(a, d.rlk)            # tail pending on d.ev
+        c1, c2 = d.ct([z1], scale=2.0 ** 20), d.ct([z2], scale=2.0 ** 20)
+        out1, out2 = S.Ciphertext(d.ctx), S.Ciphertext(d.ctx)
+        f0, p0, x0 = S.tail_stats()
+        start = threading.Barrier(2)
+        errs = []
+
+        def reader(ev, other, out):
+            try:
+                start.wait()
+                ev.add(a, other, out)
+            except Exception as e:   # noqa: BLE001 - reported below
+                errs.append(e)
+        # odd rounds: the same evaluator from both threads; even rounds: two evaluators (two streams)
+        t1 = threading.Thread(target=reader, args=(d.ev, c1, out1))
+        t2 = threading.Thread(target=reader, args=(d.ev if r & 1 else ev2, c2, out2))
+        t1.start(); t2.start(); t1.join(); t2.join()
+        assert not errs, errs
+        S.device_synchronize()
+        f1, p1, x1 = S.tail_stats()
+        assert (f1 - f0, p1 - p0, x1 - x0) == ((0, 1, 0) if defers else (0, 0, 0)), "the pending tail must run exactly once"
+        _eq(d.out(out1)[0], (ref_relin + z1) % qk, "reader 1, round %d" % r)
+        _eq(d.out(out2)[0], (ref_relin + z2) % qk, "reader 2, round %d" % r)
+        _eq(d.out(a)[0], ref_relin, "the shared operand, round %d" % r)

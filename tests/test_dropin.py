@@ -214,7 +214,11 @@ def _device_resident_chain(lib_name, n, bits, emulated):
     primes, a, b, b2 = _chain_inputs(n, bits)
     ref_out, _ = _chain_program(R, n, primes, a, b, b2, lambda: None)
     D = _bind(path)
-    got_out, _ = _chain_program(D, n, primes, a, b, b2, lambda: _dropin_stats(D))
+    was = D.lib().sealhip_dropin_set_resident(1)   # opt-in since round 3 (the default copies every result down)
+    try:
+        got_out, _ = _chain_program(D, n, primes, a, b, b2, lambda: _dropin_stats(D))
+    finally:
+        D.lib().sealhip_dropin_set_resident(was)
     assert len(ref_out) == len(got_out)
     for i, (r, g) in enumerate(zip(ref_out, got_out)):
         assert r.shape == g.shape and np.array_equal(r, g), "snapshot %d differs from the reference" % i
@@ -225,6 +229,7 @@ def _device_resident_chain(lib_name, n, bits, emulated):
                 "S.load(%r) if %r else S.load()\n"
                 "import test_dropin as T\n"
                 "D = T._bind(%r)\n"
+                "D.lib().sealhip_dropin_set_resident(1)\n"
                 "primes, a, b, b2 = T._chain_inputs(%d, %r)\n"
                 "out, st = T._chain_program(D, %d, primes, a, b, b2, lambda: T._dropin_stats(D))\n"
                 "np.savez(%r, *out)\n"
@@ -260,3 +265,70 @@ def test_dropin_device_resident_chain_gpu(gpu, n, bits):
     if not (R.available() and os.path.exists(os.path.join(BUILD, "libsealdropin.so"))):
         pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
     _device_resident_chain("libsealdropin.so", n, bits, False)
+
+
+# ---- the reference's contract: concurrent calls on different ciphertexts are safe (evaluator.h:79-87, memorymanager.h:26-52)
+def _concurrent(path, n, bits, threads=4, rounds=2):
+    """`threads` host threads, each with its own ciphertexts, run multiply / relinearize / rescale / rotate chains through ONE
+    seal::Evaluator of the drop-in at the same time (default mode: results copied down per call); every result equals the
+    reference's.  Also with a settle + mode switch in between, which must not disturb the others' objects."""
+    import threading
+    primes = R.coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    D = _bind(path)
+    rng = np.random.default_rng(5)
+    mk = lambda: np.stack([np.stack([rng.integers(0, primes[i], n, dtype=np.uint64) for i in range(K)]) for _ in range(2)])  # noqa: E731
+    inputs = [(mk(), mk()) for _ in range(threads)]
+    sides = []
+    for lib in (R, D):
+        ctx = lib.RefContext("ckks", n, primes, 0)
+        ctx.keygen_relin()
+        ctx.keygen_galois_steps([1])
+        sides.append(ctx)
+    ref_ctx, dev_ctx = sides
+    sc = float(primes[K - 1]) * 2.0 ** 10
+
+    def program(ctx, a, b):
+        fc = ctx.first_chain_index
+        x, y = ctx.ct(fc, a, True, 2.0 ** 10, 1), ctx.ct(fc, b, True, 2.0 ** 10, 1)
+        ctx.multiply_inplace(x, y)
+        ctx.relinearize_inplace(x)
+        z = ctx.ct(fc, x.data(), True, sc, 1)
+        ctx.rescale_to_next_inplace(z)
+        ctx.rotate_vector_inplace(z, 1)
+        ctx.add_inplace(z, z.copy())
+        return z.data().copy()
+    expected = [program(ref_ctx, a, b) for a, b in inputs]
+    for _ in range(rounds):
+        got, errs = [None] * threads, []
+        start = threading.Barrier(threads)
+
+        def worker(i):
+            try:
+                start.wait()
+                got[i] = program(dev_ctx, *inputs[i])
+            except Exception as e:   # noqa: BLE001
+                errs.append((i, e))
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(threads)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        for i in range(threads):
+            assert np.array_equal(got[i], expected[i]), "thread %d: words differ from the reference" % i
+        D.lib().sealhip_dropin_settle(None, 0)   # a no-op in the default mode; must be callable at any time
+
+
+def test_dropin_concurrent_emulated(emu):
+    path = os.path.join(BUILD, "libsealdropin_emu.so")
+    if not (R.available() and os.path.exists(path)):
+        pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
+    _concurrent(path, 1024, [40, 30, 30, 40], threads=3, rounds=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,bits", [(8192, [60, 40, 40, 60]), (32768, [60, 50, 50, 50, 60])])
+def test_dropin_concurrent_gpu(gpu, n, bits):
+    path = os.path.join(BUILD, "libsealdropin.so")
+    if not (R.available() and os.path.exists(path)):
+        pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
+    _concurrent(path, n, bits, threads=4, rounds=2)

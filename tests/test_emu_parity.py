@@ -191,6 +191,10 @@ def test_mod_reduce(emu):
     P.case_mod_reduce(8192, [50, 40, 60, 50], batch=1)
 
 
+def test_deferred_tail_two_readers(emu):
+    P.case_deferred_tail_two_readers(8192, (50, 40, 60), rounds=2)
+
+
 def test_multi_level_forms(emu):
     """rescale_to_inplace / mod_switch_to_inplace(Ciphertext) over three levels against the reference's own multi-level calls
     (evaluator.cpp:1451-1473, 1543-1595), also with a key switch's deferred tail pending (missing #3)"""

@@ -492,6 +492,12 @@ def test_graph_capture_replay(gpu, n, bits, batch):
     d.ev.set_transparent_check(False)
 
 
+def test_deferred_tail_two_readers(gpu):
+    """two threads read one ciphertext whose key-switch tail is pending: it runs once, both see the completed words"""
+    P.case_deferred_tail_two_readers(8192, (50, 40, 40, 60), rounds=8)
+    P.case_deferred_tail_two_readers(65536, (60, 50, 50, 60), rounds=3)
+
+
 def test_device_field_check(gpu):
     """the integer back end's gfx950 instruction sequences (field.h: products issued through single-instruction wrappers, device
     only) against 128-bit arithmetic on the device itself: tests/device_field_check.hip, built by seal_amd/csrc/Makefile"""

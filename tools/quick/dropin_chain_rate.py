@@ -87,8 +87,8 @@ def main():
     rows = []
     for name, kind, env in (("device-resident C ABI, batch 1 (Python host), transparent check on as in the drop-in", "device_checked", {}),
                             ("device-resident C ABI, batch 1 (Python host), no per-operation check", "device", {}),
-                            ("drop-in behind seal::Evaluator, device-resident mirrors", "dropin", {}),
-                            ("drop-in, upload / download per call (SEALHIP_DROPIN_EAGER=1)", "dropin", {"SEALHIP_DROPIN_EAGER": "1"}),
+                            ("drop-in behind seal::Evaluator, device-resident mirrors (SEALHIP_DROPIN_RESIDENT=1)", "dropin", {"SEALHIP_DROPIN_RESIDENT": "1"}),
+                            ("drop-in, upload / download per call (the default)", "dropin", {}),
                             ("reference seal::Evaluator, 1 CPU thread", "reference", {})):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), kind], env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
         line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
