@@ -403,6 +403,18 @@ SHL_FUNC SealHip_ReleasePool(void);
  * change the protection of their own buffers (integration/seal_evaluator_hip.cpp); process-wide, off by default. */
 SHL_FUNC SealHip_SetStagedHostCopies(bool enabled);
 SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
+/* Environment.  The product library reads five variables, each exercised by a parity test; everything else that earlier
+ * rounds could switch at run time (superseded kernels, fork / no-fork of the side streams, ...) only exists in development
+ * builds made with -DSEALHIP_AB_SWITCHES (seal_amd/csrc/modarith.h: shl_ab_getenv).
+ *   SEALHIP_NO_FP=1                  every prime on the 64-bit integer back end (no exact double-precision arithmetic for
+ *                                    primes below 2^50); same words, slower.  Read when a SEALContext is created.
+ *   SEALHIP_KS_EAGER_TAIL=1          key switches complete their mod-down before they return (no deferred tails, below)
+ *   SEALHIP_KS_SPLIT=<parts>         cut the digits of a key switch into <parts> in-launch groups (small batches; default:
+ *                                    chosen from the batch size)
+ *   SEALHIP_NTT_FCHUNKS=<n>          workgroups per component of the single-launch transforms (N = 2^13, 2^14): tests force
+ *                                    the per-workgroup loop at small batches with it
+ *   SEALHIP_ENCRYPT_HOST_SAMPLING=1  encryption noise is sampled on the host with the reference's own sampler instead of the
+ *                                    device kernels (same distribution and, for a seeded generator, the same words) */
 /* Deferred key-switch tails.  For CKKS at 2^13 <= N <= 2^16, Evaluator_Relinearize / ApplyGalois / RotateVector /
  * ComplexConjugate return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext
  * object keeps the key-switch sums next to its two polynomials.  Whatever needs the words next completes it first -

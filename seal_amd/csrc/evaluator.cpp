@@ -366,7 +366,7 @@ namespace sealhip
         if (keys_[index].dev)
             (void)hipFree(keys_[index].dev);
         void *p = nullptr;
-        const bool reorder = ntt2_supports(ctx.log_n()) && !std::getenv("SEALHIP_OLD_KS");
+        const bool reorder = ntt2_supports(ctx.log_n()) && !shl_ab_getenv("SEALHIP_OLD_KS");
         // register order carries a second plane: the Shoup quotients of the integer back end's components
         const size_t plane_words = bytes / 8;
         ck(hipMalloc(&p, reorder ? key_register_order_words(ctx.log_n(), (unsigned)L, digits * 2) * 8 : bytes), "hipMalloc key");
@@ -438,7 +438,7 @@ namespace sealhip
         // the sums were produced on this evaluator's stream: the tail runs there too; a caller working on another stream
         // (another evaluator, a host copy) continues only when it is done
         const hipStream_t caller = DevicePool::thread_stream();
-        static const bool trace = std::getenv("SEALHIP_KS_TRACE") != nullptr; // tests: which tail ran
+        static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr; // tests: which tail ran
         if (trace)
             std::fprintf(stderr, "[ks] plain tail\n");
         g_tail_plain++;
@@ -1739,7 +1739,7 @@ namespace sealhip
         const NttTables &tb = context_.ntt_tables();
         const uint64_t P = context_.coeff_modulus()[L - 1];
         uint64_t *c0 = e.data_, *c1 = e.data_ + (size_t)B * K * N; // no deferred tail left on e: the caller detached it
-        static const bool trace = std::getenv("SEALHIP_KS_TRACE") != nullptr;
+        static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr;
         if (trace)
             std::fprintf(stderr, "[ks] folded tail\n");
         g_tail_folded++;

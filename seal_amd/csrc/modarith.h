@@ -16,6 +16,20 @@
 
 #define SHL_HD __host__ __device__ __forceinline__
 
+// A/B switches of the development builds (tools/quick/ab_*.sh): environment variables that select a losing or superseded
+// code path for a measurement.  They exist only in libraries built with -DSEALHIP_AB_SWITCHES; the product library reads the
+// five switches listed in include/sealhip.h ("Environment") and nothing else.
+#include <cstdlib>
+inline const char *shl_ab_getenv(const char *name)
+{
+#ifdef SEALHIP_AB_SWITCHES
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // Wave-uniform, read-only tables (conversion matrices, per-prime constants, the twiddles of the first stages): read
 // through the constant address space the compiler may treat them as invariant and use scalar loads (s_load_dwordx2..16
 // into SGPRs) instead of one vector load per lane-uniform element, which also frees the VGPRs that held them.

@@ -1970,7 +1970,7 @@ namespace sealhip
         std::vector<CompRun> comp_runs(const NttTables &t, const uint32_t *comp_prime, unsigned prime_first, unsigned ncomp)
         {
             std::vector<CompRun> runs;
-            static const bool split = !std::getenv("SEALHIP_NTT_NOSPLIT");
+            static const bool split = !shl_ab_getenv("SEALHIP_NTT_NOSPLIT");
             unsigned c = 0;
             while (c < ncomp)
             {
@@ -1999,7 +1999,7 @@ namespace sealhip
             bool ok = false;
             SideStream()
             {
-                ok = !std::getenv("SEALHIP_NTT_NOFORK") && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+                ok = !shl_ab_getenv("SEALHIP_NTT_NOFORK") && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
                      hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
                      hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
             }
@@ -2041,7 +2041,7 @@ namespace sealhip
         // single-launch kernels for the integer back end (N = 2^13, 2^14); SEALHIP_NTT_NOFUSED_INT=1 keeps its two-launch engine (A/B runs)
         inline bool fused_int()
         {
-            static const bool on = !std::getenv("SEALHIP_NTT_NOFUSED_INT");
+            static const bool on = !shl_ab_getenv("SEALHIP_NTT_NOFUSED_INT");
             return on;
         }
 
@@ -2063,7 +2063,7 @@ namespace sealhip
             unsigned fchunks = 1;
             if constexpr (D1 == 5 || D1 == 6)
             {
-                static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED");
+                static const bool fused_ok = !shl_ab_getenv("SEALHIP_NTT_NOFUSED");
                 if (fused_ok && (!a.src || a.src_mode == 0) && a.epi == 0)
                 {
                     static bool raised = false;
@@ -2115,7 +2115,7 @@ namespace sealhip
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess)
                     return e;
-                static const int p2_hoist = std::getenv("SEALHIP_P2_HOIST") ? std::atoi(std::getenv("SEALHIP_P2_HOIST")) : 4;
+                static const int p2_hoist = shl_ab_getenv("SEALHIP_P2_HOIST") ? std::atoi(shl_ab_getenv("SEALHIP_P2_HOIST")) : 4;
                 if (r.cls == 1 && a.epi == 0 && chunks < nouter && p2_hoist == 4)
                     hipLaunchKernelGGL((ntt2_fwd_p2<D1, 4>), grid, dim3(kThreads), (kLds2Words + 240) * 8, st, g);
                 else if (r.cls == 1 && a.epi == 0 && chunks < nouter && p2_hoist == 3)
@@ -2175,7 +2175,7 @@ namespace sealhip
             unsigned fchunks = 1;
             if constexpr (D1 == 5 || D1 == 6)
             {
-                static const bool fused_ok = !std::getenv("SEALHIP_NTT_NOFUSED");
+                static const bool fused_ok = !shl_ab_getenv("SEALHIP_NTT_NOFUSED");
                 if (fused_ok)
                 {
                     static bool raised = false;
@@ -2284,7 +2284,7 @@ namespace sealhip
             // The integer-back-end targets (60-bit moduli) are latency-bound at two waves per SIMD, the
             // double-precision ones are issue-bound: on two streams their workgroups share the CUs.
             SideStream &ss = side_stream();
-            static const bool fork_ok = !std::getenv("SEALHIP_KS_NOFORK");
+            static const bool fork_ok = !shl_ab_getenv("SEALHIP_KS_NOFORK");
             hipError_t e;
             if (n_int && n_fp && ss.ok && fork_ok)
             {
