@@ -78,8 +78,9 @@ def parse(argv=None):
     ap.add_argument("--ntt-only", action="store_true", help="only the NTT roofline leg (for rocprofv3 runs)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--step-child", action="store_true", help=argparse.SUPPRESS)  # the timed step alone, under rocprofv3 --pmc (roofline_step)
-    ap.add_argument("--streams", type=int, default=1, help="headline / bfv_c4: divide the GPU's batch over this many evaluators, each on its "
-                    "own HIP stream, so that one sub-batch's memory-bound phases overlap another's key switching")
+    ap.add_argument("--streams", type=int, default=1, help="divide the GPU's batch over this many evaluators, each on its own HIP stream, so "
+                    "that one sub-batch's memory-bound phases overlap another's key switching; rotate_c5: the sub-batches share the "
+                    "communicator, so that the digit-parallel exchange of one overlaps the key-switch kernels of the next")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured hipGraph (Evaluator_BeginCapture/EndCapture): "
                     "for launch-bound small batches; the default (eager) path is what the headline number uses")
     return ap.parse_args(argv)
@@ -227,7 +228,7 @@ def main():
     dev_sync()
 
     lanes = None
-    if args.streams > 1 and args.workload != "rotate_c5" and B >= args.streams:
+    if args.streams > 1 and B >= args.streams:
         # sub-batches [lo, hi) of the resident inputs, one evaluator + stream + output batch each
         lanes = []
         for si in range(args.streams):
@@ -245,11 +246,25 @@ def main():
                 ct.load_device(src.data_ptr(), src.numel())
                 dev_sync()
                 return ct
-            lanes.append(dict(ev=e, stream=st, lo=lo, cnt=cnt, x=sub(xs), y=sub(ys), work=S.Ciphertext(ctx, batch=cnt)))
+            lane = dict(ev=e, stream=st, lo=lo, cnt=cnt, x=sub(xs), y=sub(ys) if ys is not None else None, work=S.Ciphertext(ctx, batch=cnt))
+            if dp is not None:
+                # rotate_c5: every sub-batch has its own evaluator / stream and shares the communicator, so the exchange of
+                # sub-batch i (a collective queued on stream i) runs while sub-batch i + 1 is still in its key-switch kernels
+                lane["dp"] = shard.DigitParallel(e, torch, group, device, exchange=args.exchange, comm=dp.comm, native=dp.comm is not None)
+            lanes.append(lane)
         dev_sync()
 
     last_op = {"headline": "rescale_to_next_inplace", "bfv_c4": "mod_switch_to_next_inplace"}.get(args.workload)
-    if lanes:
+    if lanes and args.workload == "rotate_c5":
+        rot_scale = float(primes[K - 1]) * 2.0 ** 10
+
+        def step():
+            for ln in lanes:
+                w = ln["ev"].copy_to(ln["x"], ln["work"])   # the rotation works in place: stage the resident input on the lane's stream
+                w.set_scale(rot_scale)
+                ln["dp"].rotate_vector_inplace(w, 1, keys)
+                ln["ev"].rescale_to_next_inplace(w)
+    elif lanes:
         def step():
             for ln in lanes:
                 ln["ev"].multiply(ln["x"], ln["y"], ln["work"])
@@ -290,7 +305,7 @@ def main():
     verified = None
     if not args.ntt_only:
         elapsed = shard.timed_steps(step, args.steps, args.warmup, group, dev_sync, torch, device)
-        if args.workload == "rotate_c5":
+        if args.workload == "rotate_c5" and not lanes:
             work = holder["work"]
         if lanes:
             work = LaneView(lanes)
@@ -393,7 +408,12 @@ def main():
                         parallelism=par,
                         arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for primes below "
                                    "2^50, 64-bit Shoup/Barrett integer arithmetic for larger primes; results canonical u64",
-                        key_bytes=2 * K * L * n * 8, algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n),
+                        key_bytes=2 * K * L * n * 8, algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n,
+                        **(dict(exchange_bytes_per_ciphertext=2 * (K + 1) * n * 8,
+                                exchange_overlap=("%d sub-batches on %d streams sharing the communicator: the exchange of one runs while the "
+                                                  "next is in its key-switch kernels" % (len(lanes), len(lanes))) if lanes else
+                                "none: one batch, kernels and exchange in stream order (--streams S pipelines S sub-batches)")
+                           if args.workload == "rotate_c5" else {})),
             roofline=roofline, roofline_step=roofline_step, roofline_configs1=ntt_c1, cpu_baseline=cpu)
     # RCCL prints a version banner through C stdio when a communicator comes up; it sits in the C buffer until exit.  Tear
     # the process group down and flush the C streams first, so that the JSON line is the LAST thing on stdout.

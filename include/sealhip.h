@@ -268,6 +268,9 @@ SHL_FUNC Evaluator_Destroy(void *thisptr);
  * several evaluators may run on different streams concurrently.  The destination copy of the out-of-place forms
  * (destination != encrypted) runs on the same stream as the operation. */
 SHL_FUNC Evaluator_SetStream(void *thisptr, void *hip_stream);
+/* library extension: destination := encrypted, ordered on the evaluator's stream (Ciphertext_Set copies on the calling thread's
+ * stream); what a pipeline over several evaluators / streams uses to stage its inputs */
+SHL_FUNC Evaluator_CopyTo(void *thisptr, void *encrypted, void *destination);
 SHL_FUNC Evaluator_Synchronize(void *thisptr);
 /* SEAL_THROW_ON_TRANSPARENT_CIPHERTEXT (evaluator.cpp:386-392) costs a device->host round trip per
  * operation: off by default for device-resident batches, switch on for drop-in error parity. */

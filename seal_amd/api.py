@@ -824,6 +824,11 @@ class Evaluator:
         N.check(getattr(N.lib(), fn)(*args))
         return d
 
+    def copy_to(self, a, destination):
+        """destination := a on this evaluator's stream (library extension: Evaluator_CopyTo)"""
+        N.check(N.lib().Evaluator_CopyTo(self._h, a._h, destination._h))
+        return destination
+
     def negate_inplace(self, a):
         return self._u("Evaluator_Negate", a, None)
 

@@ -1534,6 +1534,19 @@ extern "C"
         as<Evaluator>(thisptr)->set_transparent_check(enabled);
         return SHL_S_OK;
     }
+    // destination := encrypted on the evaluator's stream (a pipeline with several evaluators / streams copies its inputs in
+    // stream order; Ciphertext_Set works on the calling thread's stream)
+    SHL_FUNC Evaluator_CopyTo(void *thisptr, void *encrypted, void *destination)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(encrypted, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
+        if (encrypted != destination)
+            *as<Ciphertext>(destination) = *as<Ciphertext>(encrypted);
+        SHL_CATCH
+    }
     SHL_FUNC Evaluator_Synchronize(void *thisptr)
     {
         IfNullRet(thisptr, SHL_E_POINTER);

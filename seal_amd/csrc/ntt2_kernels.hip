@@ -79,6 +79,49 @@ namespace sealhip
             else
                 body(std::integral_constant<int, 2>());
         }
+        // Which (tile, component, outer item) a workgroup of the two-pass kernels works on.  The hardware hands consecutive
+        // workgroups to consecutive XCDs (workgroup i -> XCD i mod 8).  With the tile index fastest, the eight XCDs stream eight
+        // NEIGHBOURING 32 KiB tiles at the same time - eight streams 32 KiB apart - and that is the one arrangement the memory
+        // system dislikes: a plain copy whose XCDs take runs of 8 / 16 / 32 KiB moves 6.0 / 5.9 / 5.5 TB/s where 4 KiB
+        // interleave, 256 KiB runs or one eighth of the buffer per XCD all move 6.3 (round 3,
+        // tools/microbench/copy_locality.hip, profiles/r03_microbench_copy_locality.txt).  So the XCDs are given different
+        // TRANSFORMS (N * 8 bytes apart) and each walks the tiles of its own: workgroup L -> XCD x = L mod 8, r = L / 8,
+        // tile = r mod TILES, slot = (r / TILES) * 8 + x, (component, outer) = slot; the last, incomplete group of 8 * TILES keeps
+        // the plain order.  MEASURED AND NOT KEPT (default 0): the 2^16 NTT leg 2.51 -> 2.49 TB/s, the headline step -0.6 %, BFV
+        // configs[3] -1 % (gpurun_out r3i, same box, alternating): the passes' workgroups are persistent loops that drift apart,
+        // so their concurrent streams are not the lock-step runs of the copy; what the copy shows is that the ceiling of a
+        // tile-shaped pass is ~5.4 TB/s, not the 6.3 of a 4 KiB-per-workgroup stream.
+#ifndef SEALHIP_XCD_SPREAD
+#define SEALHIP_XCD_SPREAD 0
+#endif
+        struct Blk
+        {
+            unsigned tile, y, z;
+        };
+        __device__ __forceinline__ Blk spread_blocks()
+        {
+#if SEALHIP_XCD_SPREAD
+            const unsigned tiles = gridDim.x, slots = gridDim.y * gridDim.z;
+            const unsigned L = blockIdx.x + tiles * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned group = 8 * tiles, full = (slots / 8) * group;
+            unsigned tile, slot;
+            if (L < full)
+            {
+                const unsigned x = L & 7, r = L >> 3;
+                tile = r % tiles;
+                slot = (r / tiles) * 8 + x;
+            }
+            else
+            {
+                tile = L % tiles;
+                slot = L / tiles;
+            }
+            return Blk{ tile, slot % gridDim.y, slot / gridDim.y };
+#else
+            return Blk{ blockIdx.x, blockIdx.y, blockIdx.z };
+#endif
+        }
+
         template <bool FP>
         __device__ __forceinline__ const typename Field<FP>::tw_t *tw_table(const NttTables &t, bool inverse, unsigned prime)
         {
@@ -649,11 +692,11 @@ namespace sealhip
         };
 
         template <bool FP, int D1, int ICLS = 0>
-        __device__ __forceinline__ void fwd_p1_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        __device__ __forceinline__ void fwd_p1_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds, unsigned tile)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
-            const unsigned tid = threadIdx.x, cg = blockIdx.x;
+            const unsigned tid = threadIdx.x, cg = tile;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
             SrcMap sm{ 0, 0, 0, 0 };
@@ -709,16 +752,17 @@ namespace sealhip
         __global__ void __launch_bounds__(kThreads, CLS == 1 ? SEALHIP_FP_WAVES_P1 : 2) ntt2_fwd_p1(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
+            const Blk blk = spread_blocks();
+            const unsigned comp = blk.y + a.comp0, outer = blk.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             if constexpr (CLS == 1)
-                fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
+                fwd_p1_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 0)
-                with_int_class(a.t, prime, [&](auto ic) { fwd_p1_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
+                with_int_class(a.t, prime, [&](auto ic) { fwd_p1_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds, blk.tile); });
             else if (a.t.fpd[prime].qi)
-                fwd_p1_body<true, D1>(a, prime, comp, outer, lds);
+                fwd_p1_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else
-                fwd_p1_body<false, D1, 2>(a, prime, comp, outer, lds); // mixed launches keep the guarded butterflies
+                fwd_p1_body<false, D1, 2>(a, prime, comp, outer, lds, blk.tile); // mixed launches keep the guarded butterflies
         }
 
         // HOIST (plain transforms of the double-precision back end, no epilogue): the tile's 30 twiddles stay in
@@ -728,11 +772,11 @@ namespace sealhip
         // HOIST_LDS (CLS 4): the row-shared phase-A twiddles are staged once in LDS and only the 15 per-thread phase-B twiddles
         // stay in registers: the same "no twiddle is re-read per transform" at 128 VGPRs (four waves per SIMD) instead of 214 (two)
         template <bool FP, int D1, bool HOIST = false, bool HOIST_LDS = false, int ICLS = 0>
-        __device__ __forceinline__ void fwd_p2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        __device__ __forceinline__ void fwd_p2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds, unsigned tile)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
-            const unsigned tid = threadIdx.x, hg = blockIdx.x;
+            const unsigned tid = threadIdx.x, hg = tile;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
             const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + tid;
@@ -813,20 +857,21 @@ namespace sealhip
         __global__ void __launch_bounds__(kThreads, (CLS == 1 || CLS == 4) ? SEALHIP_FP_WAVES_P2 : 2) ntt2_fwd_p2(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
+            const Blk blk = spread_blocks();
+            const unsigned comp = blk.y + a.comp0, outer = blk.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             if constexpr (CLS == 4) // as 3 with the row-shared half of the twiddles in LDS: four waves per SIMD
-                fwd_p2_body<true, D1, false, true>(a, prime, comp, outer, lds);
+                fwd_p2_body<true, D1, false, true>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 3) // double-precision back end, plain transform, twiddles hoisted
-                fwd_p2_body<true, D1, true>(a, prime, comp, outer, lds);
+                fwd_p2_body<true, D1, true>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 1)
-                fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
+                fwd_p2_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 0)
-                with_int_class(a.t, prime, [&](auto ic) { fwd_p2_body<false, D1, false, false, decltype(ic)::value>(a, prime, comp, outer, lds); });
+                with_int_class(a.t, prime, [&](auto ic) { fwd_p2_body<false, D1, false, false, decltype(ic)::value>(a, prime, comp, outer, lds, blk.tile); });
             else if (a.t.fpd[prime].qi)
-                fwd_p2_body<true, D1>(a, prime, comp, outer, lds);
+                fwd_p2_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else
-                fwd_p2_body<false, D1, false, false, 2>(a, prime, comp, outer, lds);
+                fwd_p2_body<false, D1, false, false, 2>(a, prime, comp, outer, lds, blk.tile);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -841,12 +886,12 @@ namespace sealhip
         };
 
         template <bool FP, int D1, int ICLS>
-        __device__ __forceinline__ void tail2_p1_body(const Tail2Args &t2, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        __device__ __forceinline__ void tail2_p1_body(const Tail2Args &t2, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds, unsigned tile)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
             const FwdArgs &a = t2.f;
-            const unsigned tid = threadIdx.x, cg = blockIdx.x;
+            const unsigned tid = threadIdx.x, cg = tile;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
             const int mode = t2.x.halves_added ? 3 : 2;
@@ -893,12 +938,12 @@ namespace sealhip
         }
 
         template <bool FP, int D1, int ICLS>
-        __device__ __forceinline__ void tail2_p2_body(const Tail2Args &t2, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        __device__ __forceinline__ void tail2_p2_body(const Tail2Args &t2, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds, unsigned tile)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
             const FwdArgs &a = t2.f;
-            const unsigned tid = threadIdx.x, hg = blockIdx.x;
+            const unsigned tid = threadIdx.x, hg = tile;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
             const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + tid;
@@ -952,31 +997,33 @@ namespace sealhip
         __global__ void __launch_bounds__(kThreads, 2) ntt2_tail2_p1(Tail2Args a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y + a.f.comp0, outer = blockIdx.z;
+            const Blk blk = spread_blocks();
+            const unsigned comp = blk.y + a.f.comp0, outer = blk.z;
             const unsigned prime = SHL_UNIFORM(a.f.prime_first + comp);
             if constexpr (CLS == 1)
-                tail2_p1_body<true, D1, 0>(a, prime, comp, outer, lds);
+                tail2_p1_body<true, D1, 0>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 0)
-                with_int_class(a.f.t, prime, [&](auto ic) { tail2_p1_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
+                with_int_class(a.f.t, prime, [&](auto ic) { tail2_p1_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds, blk.tile); });
             else if (a.f.t.fpd[prime].qi)
-                tail2_p1_body<true, D1, 0>(a, prime, comp, outer, lds);
+                tail2_p1_body<true, D1, 0>(a, prime, comp, outer, lds, blk.tile);
             else
-                tail2_p1_body<false, D1, 2>(a, prime, comp, outer, lds);
+                tail2_p1_body<false, D1, 2>(a, prime, comp, outer, lds, blk.tile);
         }
         template <int D1, int CLS>
         __global__ void __launch_bounds__(kThreads, 2) ntt2_tail2_p2(Tail2Args a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y + a.f.comp0, outer = blockIdx.z;
+            const Blk blk = spread_blocks();
+            const unsigned comp = blk.y + a.f.comp0, outer = blk.z;
             const unsigned prime = SHL_UNIFORM(a.f.prime_first + comp);
             if constexpr (CLS == 1)
-                tail2_p2_body<true, D1, 0>(a, prime, comp, outer, lds);
+                tail2_p2_body<true, D1, 0>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 0)
-                with_int_class(a.f.t, prime, [&](auto ic) { tail2_p2_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
+                with_int_class(a.f.t, prime, [&](auto ic) { tail2_p2_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds, blk.tile); });
             else if (a.f.t.fpd[prime].qi)
-                tail2_p2_body<true, D1, 0>(a, prime, comp, outer, lds);
+                tail2_p2_body<true, D1, 0>(a, prime, comp, outer, lds, blk.tile);
             else
-                tail2_p2_body<false, D1, 2>(a, prime, comp, outer, lds);
+                tail2_p2_body<false, D1, 2>(a, prime, comp, outer, lds, blk.tile);
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1010,11 +1057,11 @@ namespace sealhip
         constexpr int kInvE3 = inv_phase_exp<ICLS>(kInvE2<ICLS>, 4, 0);
 
         template <bool FP, int D1, int ICLS = 2>
-        __device__ __forceinline__ void inv_pa_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        __device__ __forceinline__ void inv_pa_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds, unsigned tile)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
-            const unsigned tid = threadIdx.x, hg = blockIdx.x;
+            const unsigned tid = threadIdx.x, hg = tile;
             const unsigned v = tid & 15, u = tid >> 4, ul = u & 3;
             const unsigned h = hg * 16 + u;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
@@ -1063,25 +1110,26 @@ namespace sealhip
         __global__ void __launch_bounds__(kThreads) ntt2_inv_pa(InvArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
+            const Blk blk = spread_blocks();
+            const unsigned comp = blk.y + a.comp0, outer = blk.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             if constexpr (CLS == 1)
-                inv_pa_body<true, D1>(a, prime, comp, outer, lds);
+                inv_pa_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 0)
-                with_int_class(a.t, prime, [&](auto ic) { inv_pa_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
+                with_int_class(a.t, prime, [&](auto ic) { inv_pa_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds, blk.tile); });
             else if (a.t.fpd[prime].qi)
-                inv_pa_body<true, D1>(a, prime, comp, outer, lds);
+                inv_pa_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else
-                inv_pa_body<false, D1, 2>(a, prime, comp, outer, lds); // mixed launches keep the guarded butterflies
+                inv_pa_body<false, D1, 2>(a, prime, comp, outer, lds, blk.tile); // mixed launches keep the guarded butterflies
         }
 
         template <bool FP, int D1, int ICLS = 2>
-        __device__ __forceinline__ void inv_pb_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds)
+        __device__ __forceinline__ void inv_pb_body(const InvArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds, unsigned tile)
         {
             typedef Field<FP> F;
             typedef Geo<D1> G;
             static_assert(G::rA >= 1, "the N^-1 stage is handled in phase A");
-            const unsigned tid = threadIdx.x, cg = blockIdx.x;
+            const unsigned tid = threadIdx.x, cg = tile;
             const unsigned c = tid & (G::C - 1), hi = tid >> G::LC;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, true, prime);
@@ -1144,16 +1192,17 @@ namespace sealhip
         __global__ void __launch_bounds__(kThreads) ntt2_inv_pb(InvArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
-            const unsigned comp = blockIdx.y + a.comp0, outer = blockIdx.z;
+            const Blk blk = spread_blocks();
+            const unsigned comp = blk.y + a.comp0, outer = blk.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
             if constexpr (CLS == 1)
-                inv_pb_body<true, D1>(a, prime, comp, outer, lds);
+                inv_pb_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 0)
-                with_int_class(a.t, prime, [&](auto ic) { inv_pb_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds); });
+                with_int_class(a.t, prime, [&](auto ic) { inv_pb_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds, blk.tile); });
             else if (a.t.fpd[prime].qi)
-                inv_pb_body<true, D1>(a, prime, comp, outer, lds);
+                inv_pb_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else
-                inv_pb_body<false, D1, 2>(a, prime, comp, outer, lds);
+                inv_pb_body<false, D1, 2>(a, prime, comp, outer, lds, blk.tile);
         }
 
         // ---------------------------------------------------------------------------------------

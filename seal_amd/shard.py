@@ -77,7 +77,7 @@ class DigitParallel:
     apply_galois_inplace on one GPU.  Keys: KSwitchKeys.set_key_digits(index, *digit_range(K), full_key[range])
     keeps only this rank's slice resident (a full key works too)."""
 
-    def __init__(self, ev, torch, dist, device, exchange="all_reduce", native=None):
+    def __init__(self, ev, torch, dist, device, exchange="all_reduce", native=None, comm=None):
         """exchange: "all_reduce" | "reduce_scatter" (the library's two shapes, sealhip.h section 1c).
         native: None = use the library's RCCL communicator when the tensors live on a GPU and RCCL loads, else
         torch.distributed; True / False forces either."""
@@ -88,7 +88,9 @@ class DigitParallel:
             raise ValueError("at most 8 partial sums fit a 64-bit word (residues are below 2^60)")
         self._acc = None
         self.exchange = {"all_reduce": 0, "reduce_scatter": 1}[exchange]
-        self.comm = None
+        self.comm = comm     # a communicator shared with other DigitParallel objects of this rank (one per stream of a pipeline)
+        if comm is not None:
+            return
         if native is None:
             from . import api
             native = self.world > 1 and getattr(device, "type", "cpu") == "cuda" and api.Comm.rccl_available()

@@ -91,3 +91,21 @@ def test_bench_streams_divides_the_batch(emu, workload):
     import sealref
     if sealref.available():
         assert line["verified_items"] >= 2
+
+
+def test_bench_rotate_c5_pipelined_exchange(emu):
+    """`bench.py --workload rotate_c5 --gpus 2 --streams 2`: two sub-batches per rank, each with its own evaluator / stream, sharing
+    the exchange; every rank's sampled items equal the reference's rotate + rescale (VERDICT r2 #7: the pipelined form)"""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SEALHIP_BENCH_EMU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "rotate_c5",
+                          "--streams", "2", "--batch", "4"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert "2 sub-batches on 2 streams" in line["config"]["exchange_overlap"] and line["config"]["exchange_bytes_per_ciphertext"] > 0
+    import sealref
+    if sealref.available():
+        assert line["verified_items"] == 8  # four items per rank
