@@ -89,11 +89,24 @@ namespace sealhip
         // scalar instructions (free for the vector unit); y = y1 2^32 + y0 < 2^61 then gives six products below 2^53 that go to
         // six 64-bit column sums (weights 2^0, 2^21, 2^42 for y0 and 2^32, 2^53, 2^74 for y1) by six v_mad_u64_u32 - no
         // carry, no register pair to build - and 64 terms stay below 2^59.  The columns are added up once per dot product.
+        // extra_y * extra_r (both below 2^61) is one more term of the sum when extra_r != 0 (wave-uniform)
         template <unsigned KM>
-        __device__ __forceinline__ uint64_t dot_reg(const uint64_t (&y)[KM], uconst_ptr row, unsigned count, const ModDesc &m)
+        __device__ __forceinline__ uint64_t dot_reg(const uint64_t (&y)[KM], uconst_ptr row, unsigned count, const ModDesc &m, uint64_t extra_y = 0,
+                                                    uint64_t extra_r = 0)
         {
-            static_assert(KM <= 128, "six column sums of terms below 2^53: 128 of them stay below 2^60");
+            static_assert(KM <= 128, "six column sums of terms below 2^53: 129 of them stay below 2^60");
             uint64_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+            if (extra_r)
+            {
+                const uint32_t ra = (uint32_t)extra_r & 0x1FFFFFu, rb = (uint32_t)(extra_r >> 21) & 0x1FFFFFu, rc = (uint32_t)(extra_r >> 42);
+                const uint32_t y0 = (uint32_t)extra_y, y1 = (uint32_t)(extra_y >> 32);
+                a0 = mad_uniform(y0, ra, 0);
+                a1 = mad_uniform(y0, rb, 0);
+                a2 = mad_uniform(y0, rc, 0);
+                b0 = mad_uniform(y1, ra, 0);
+                b1 = mad_uniform(y1, rb, 0);
+                b2 = mad_uniform(y1, rc, 0);
+            }
 #pragma unroll
             for (unsigned i = 0; i < KM; i++)
                 if (i < count)
@@ -250,26 +263,23 @@ namespace sealhip
                     y[i] = 0;
                     if (i < K)
                     {
+                        // x m~ (Q/q_i)^-1 mod q_i: the two constants of rns.cpp:1120 and 439-456 as one (LevelDev)
                         const uint64_t q = ld_u64(&mods[i].q);
-                        const ShoupOp m = ld_shoup(&lv.m_tilde_mod_q[i]), pq = ld_shoup(&lv.inv_punct_q[i]);
-                        y[i] = mul_shoup(mul_shoup(ip[i * N + j], m.w, m.wq, q), pq.w, pq.wq, q);
+                        const ShoupOp c = ld_shoup(&lv.mt_inv_punct_q[i]);
+                        y[i] = mul_shoup(ip[i * N + j], c.w, c.wq, q);
                         s += y[i] * ld_u64(&lv.q_to_mtilde[i]);
                     }
                 }
                 uint64_t r = (((s & (mt - 1)) * lv.neg_inv_prod_q_mod_mtilde)) & (mt - 1);
                 for (unsigned jj = 0; jj < lv.nBsk; jj++)
                 {
+                    // (conv + r_centered Q) m~^-1 mod p_j (sm_mrq, rns.cpp:1027-1037) as ONE exact sum: the matrix row and Q already
+                    // carry m~^-1, r_centered Q m~^-1 is one more term
                     const ModDesc md = ld_mod(&mods[ld_u32(&lv.bsk_prime[jj])]);
-                    uint64_t c = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk + jj * K), K, md);
                     uint64_t tmp = r;
                     if (tmp >= (mt >> 1))
                         tmp += md.q - mt;
-                    uint64_t lo, hi;
-                    mul_wide4(tmp, ld_u64(&lv.prod_q_mod_bsk[jj]), lo, hi);
-                    lo += c;
-                    hi += lo < c;
-                    const ShoupOp im = ld_shoup(&lv.inv_mtilde_mod_bsk[jj]);
-                    op[jj * N + j] = mul_shoup(barrett128(lo, hi, md), im.w, im.wq, md.q);
+                    op[jj * N + j] = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_lift + jj * K), K, md, tmp, ld_u64(&lv.prod_q_lift[jj]));
                 }
             }
         }
@@ -299,19 +309,22 @@ namespace sealhip
                     y[i] = 0;
                     if (i < K)
                     {
+                        // step (6), evaluator.cpp:554, and the (Q/q_i)^-1 of the base conversion as one constant
                         const uint64_t q = ld_u64(&mods[i].q);
-                        const ShoupOp tm = ld_shoup(&lv.t_mod_q[i]), pq = ld_shoup(&lv.inv_punct_q[i]);
-                        uint64_t z = mul_shoup(qp[i * N + j], tm.w, tm.wq, q); // step (6), evaluator.cpp:554
-                        y[i] = mul_shoup(z, pq.w, pq.wq, q);
+                        const ShoupOp c = ld_shoup(&lv.t_inv_punct_q[i]);
+                        y[i] = mul_shoup(qp[i * N + j], c.w, c.wq, q);
                     }
                 }
                 for (unsigned jj = 0; jj < nBsk; jj++)
                 {
+                    // step (7): (x_bsk t - conv) Q^-1 mod p_j, and for the primes of B also the (B/b_j)^-1 that step (8) applies next:
+                    // the matrix row and t carry those constants (LevelDev), one Shoup product and one exact sum remain.  f[jj]
+                    // is therefore step (8)'s input vector for jj < nB and the floor value itself for m_sk (jj = nB)
                     const ModDesc md = ld_mod(&mods[ld_u32(&lv.bsk_prime[jj])]);
-                    uint64_t conv = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk + jj * K), K, md);
-                    const ShoupOp tm = ld_shoup(&lv.t_mod_bsk[jj]), iq = ld_shoup(&lv.inv_prod_q_mod_bsk[jj]);
-                    uint64_t zb = mul_shoup(bp[jj * N + j], tm.w, tm.wq, md.q);
-                    f[jj * kBlock + threadIdx.x] = mul_shoup(zb + (md.q - conv), iq.w, iq.wq, md.q); // step (7)
+                    const uint64_t conv = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_floor + jj * K), K, md);
+                    const ShoupOp tm = ld_shoup(&lv.t_floor_bsk[jj]);
+                    const uint64_t zb = mul_shoup(bp[jj * N + j], tm.w, tm.wq, md.q);
+                    f[jj * kBlock + threadIdx.x] = csub(zb + (md.q - conv), md.q);
                 }
                 // step (8): Shenoy-Kumaresan (each thread reads back only what it wrote: no barrier)
 #pragma unroll
@@ -319,10 +332,7 @@ namespace sealhip
                 {
                     y[i] = 0;
                     if (i < nB)
-                    {
-                        const ShoupOp ib = ld_shoup(&lv.inv_punct_b[i]);
-                        y[i] = mul_shoup(f[i * kBlock + threadIdx.x], ib.w, ib.wq, ld_u64(&mods[ld_u32(&lv.bsk_prime[i])].q));
-                    }
+                        y[i] = f[i * kBlock + threadIdx.x];
                 }
                 const ModDesc msk = ld_mod(&mods[lv.msk_prime]);
                 uint64_t conv_sk = dot_reg<KM>(y, SHL_UCONST(lv.b_to_msk), nB, msk);

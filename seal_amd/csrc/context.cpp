@@ -322,7 +322,8 @@ namespace sealhip
         {
             size_t inv_q_last = 0, round_fix = 0, half_mod_q = 0, q_last_mod_q = 0, delta_mod_q = 0, upper_half_inc = 0, bsk_prime = 0, inv_punct_q = 0, m_tilde_mod_q = 0, q_to_bsk = 0, q_to_mtilde = 0,
                    prod_q_mod_bsk = 0, inv_mtilde_mod_bsk = 0, inv_prod_q_mod_bsk = 0, inv_punct_b = 0, b_to_q = 0,
-                   b_to_msk = 0, prod_b_mod_q = 0, t_mod_q = 0, t_mod_bsk = 0, dec_inv_punct_q = 0, dec_q_to_t = 0, dec_prod_t_gamma = 0,
+                   b_to_msk = 0, prod_b_mod_q = 0, t_mod_q = 0, t_mod_bsk = 0, mt_inv_punct_q = 0, q_to_bsk_lift = 0, prod_q_lift = 0,
+                   t_inv_punct_q = 0, q_to_bsk_floor = 0, t_floor_bsk = 0, dec_inv_punct_q = 0, dec_q_to_t = 0, dec_prod_t_gamma = 0,
                    dec_q_to_gamma = 0;
         } off;
 
@@ -475,6 +476,35 @@ namespace sealhip
             off.prod_b_mod_q = blk.put(prod_b_mod_q);
             off.t_mod_q = blk.put(t_mod_q);
             off.t_mod_bsk = blk.put(t_mod_bsk);
+            // products of the constants above (LevelDev: "multiplied together")
+            std::vector<ShoupOp> mt_ipq, t_ipq, t_floor;
+            std::vector<uint64_t> lift_m, lift_pq, floor_m;
+            for (unsigned i = 0; i < K; i++)
+            {
+                mt_ipq.push_back(make_shoup(mulmod(m_tilde % q[i], inv_punct_q[i].w, q[i]), q[i]));
+                t_ipq.push_back(make_shoup(mulmod(plain_modulus_ % q[i], inv_punct_q[i].w, q[i]), q[i]));
+            }
+            for (size_t j = 0; j < Bsk.size(); j++)
+            {
+                const uint64_t pj = Bsk[j];
+                const uint64_t im = inv_mtilde_mod_bsk[j].w;
+                uint64_t fl = inv_prod_q_mod_bsk[j].w;
+                if (j < nb)
+                    fl = mulmod(fl, inv_punct_b[j].w, pj);
+                for (unsigned i = 0; i < K; i++)
+                {
+                    lift_m.push_back(mulmod(q_to_bsk[j * K + i], im, pj));
+                    floor_m.push_back(mulmod(q_to_bsk[j * K + i], fl, pj));
+                }
+                lift_pq.push_back(mulmod(prod_q_mod_bsk[j], im, pj));
+                t_floor.push_back(make_shoup(mulmod(plain_modulus_ % pj, fl, pj), pj));
+            }
+            off.mt_inv_punct_q = blk.put(mt_ipq);
+            off.q_to_bsk_lift = blk.put(lift_m);
+            off.prod_q_lift = blk.put(lift_pq);
+            off.t_inv_punct_q = blk.put(t_ipq);
+            off.q_to_bsk_floor = blk.put(floor_m);
+            off.t_floor_bsk = blk.put(t_floor);
         }
 
         uint64_t *d = nullptr;
@@ -513,6 +543,12 @@ namespace sealhip
             lvl.dev.prod_b_mod_q = d + off.prod_b_mod_q;
             lvl.dev.t_mod_q = reinterpret_cast<const ShoupOp *>(d + off.t_mod_q);
             lvl.dev.t_mod_bsk = reinterpret_cast<const ShoupOp *>(d + off.t_mod_bsk);
+            lvl.dev.mt_inv_punct_q = reinterpret_cast<const ShoupOp *>(d + off.mt_inv_punct_q);
+            lvl.dev.q_to_bsk_lift = d + off.q_to_bsk_lift;
+            lvl.dev.prod_q_lift = d + off.prod_q_lift;
+            lvl.dev.t_inv_punct_q = reinterpret_cast<const ShoupOp *>(d + off.t_inv_punct_q);
+            lvl.dev.q_to_bsk_floor = d + off.q_to_bsk_floor;
+            lvl.dev.t_floor_bsk = reinterpret_cast<const ShoupOp *>(d + off.t_floor_bsk);
         }
     }
 } // namespace sealhip

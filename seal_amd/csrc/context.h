@@ -79,6 +79,15 @@ namespace sealhip
         const uint64_t *prod_b_mod_q = nullptr;    // [K]
         const ShoupOp *t_mod_q = nullptr;          // [K]     plain modulus as multiplier
         const ShoupOp *t_mod_bsk = nullptr;        // [nBsk]
+        // the same constants multiplied together where the reference applies them one after the other (round 3: every product by
+        // a constant that is followed by another product by a constant is one product by their product - the residues are the
+        // same, the kernels do 30 Shoup products per coefficient instead of 74)
+        const ShoupOp *mt_inv_punct_q = nullptr;   // [K]     m~ (Q/q_i)^-1 mod q_i                         (lift)
+        const uint64_t *q_to_bsk_lift = nullptr;   // [nBsk][K]   (Q/q_i) m~^-1 mod p_j                     (lift)
+        const uint64_t *prod_q_lift = nullptr;     // [nBsk]      Q m~^-1 mod p_j                           (lift)
+        const ShoupOp *t_inv_punct_q = nullptr;    // [K]     t (Q/q_i)^-1 mod q_i                          (floor)
+        const uint64_t *q_to_bsk_floor = nullptr;  // [nBsk][K]   (Q/q_i) Q^-1 [(B/b_j)^-1, j < nB] mod p_j (floor)
+        const ShoupOp *t_floor_bsk = nullptr;      // [nBsk]      t Q^-1 [(B/b_j)^-1, j < nB] mod p_j       (floor)
         ShoupOp inv_prod_b_mod_msk{ 0, 0 };
         uint64_t neg_inv_prod_q_mod_mtilde = 0;
         uint64_t m_tilde = 0;
