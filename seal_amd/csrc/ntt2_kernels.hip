@@ -1275,7 +1275,10 @@ namespace sealhip
             typedef typename F::tw_t tw_t;
             constexpr bool TWB_REGS = FP || (D1 == 5 && SEALHIP_FINT_FWD_TWB == 2); // 2^14: one 1024-thread workgroup, 128 registers
             constexpr bool TWB_EARLY = !FP && D1 == 5 && SEALHIP_FINT_FWD_TWB == 1;
-            constexpr bool PF = FP || (D1 == 6 && SEALHIP_FINT_FWD_PF14) || (D1 == 5 && SEALHIP_FINT_FWD_PF13);
+#ifndef SEALHIP_FP_FWD_PF13
+#define SEALHIP_FP_FWD_PF13 0 // as SEALHIP_FP_INV_PF: +2 % on the mixed chain, +5 % on a chain of primes below 2^50 (4.3 -> 4.5 TB/s)
+#endif
+            constexpr bool PF = FP ? (D1 != 5 || SEALHIP_FP_FWD_PF13) : ((D1 == 6 && SEALHIP_FINT_FWD_PF14) || (D1 == 5 && SEALHIP_FINT_FWD_PF13));
             const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const tw_t *tab = tw_table<FP>(a.t, false, prime);
@@ -1398,7 +1401,10 @@ namespace sealhip
             typedef FusedGeo<D1, F::tw_words> FG;
             typedef typename F::tw_t tw_t;
             static_assert(G::rA >= 1, "the N^-1 stage is handled in phase A");
-            constexpr bool PF = FP || (D1 == 5 && SEALHIP_FINT_INV_PF);
+#ifndef SEALHIP_FP_INV_PF
+#define SEALHIP_FP_INV_PF 0 // 2^13, double precision: two workgroups per CU cover the loads; without the 32 prefetch registers nothing spills: +10 %
+#endif
+            constexpr bool PF = FP ? (SEALHIP_FP_INV_PF || D1 != 5) : (D1 == 5 && SEALHIP_FINT_INV_PF);
             const unsigned team = threadIdx.x >> 8, tid = threadIdx.x & 255;
             const unsigned v = tid & 15, u = tid >> 4, ul = u & 3, lane = tid & 63;
             const unsigned h = team * 16 + u;
@@ -2101,7 +2107,10 @@ namespace sealhip
             // enough workgroups to fill the chip several times over, each looping over its share of
             // the outer items with the next tile in flight
             unsigned per = G::TILES * a.ncomp;
-            unsigned chunks = (4096 + per - 1) / per;
+#ifndef SEALHIP_NTT_WG_TARGET
+#define SEALHIP_NTT_WG_TARGET 4096
+#endif
+            unsigned chunks = (SEALHIP_NTT_WG_TARGET + per - 1) / per;
             if (chunks > nouter)
                 chunks = nouter;
             if (chunks > 65535)
