@@ -169,6 +169,8 @@ SHL_FUNC CKKSEncoder_Encode1(void *thisptr, uint64_t value_count, double *values
 SHL_FUNC CKKSEncoder_Encode2(void *thisptr, uint64_t value_count, double *complex_values, uint64_t *parms_id, double scale, void *destination,
                              void *pool);
 SHL_FUNC CKKSEncoder_Encode3(void *thisptr, double value, uint64_t *parms_id, double scale, void *destination, void *pool); /* one value in every slot */
+SHL_FUNC CKKSEncoder_Encode4(void *thisptr, double value_re, double value_im, uint64_t *parms_id, double scale, void *destination,
+                             void *pool); /* one complex value in every slot (c/ckksencoder.h:35) */
 SHL_FUNC CKKSEncoder_Encode5(void *thisptr, int64_t value, uint64_t *parms_id, void *destination);
 SHL_FUNC CKKSEncoder_Decode1(void *thisptr, void *plain, uint64_t *value_count, double *values, void *pool);
 SHL_FUNC CKKSEncoder_Decode2(void *thisptr, void *plain, uint64_t *value_count, double *values, void *pool);
@@ -208,7 +210,9 @@ SHL_FUNC Encryptor_EncryptZero1(void *thisptr, uint64_t *parms_id, void *destina
 SHL_FUNC Encryptor_Destroy(void *thisptr);
 /* INSECURE, parity tests only (see KeyGenerator_Create1): every call restarts from this seed.  NULL restores OS entropy. */
 SHL_FUNC Encryptor_SetSeed(void *thisptr, const uint64_t *seed);
+SHL_FUNC Encryptor_EncryptZero2(void *thisptr, void *destination, void *pool); /* at the first data level (c/encryptor.h:26) */
 SHL_FUNC Encryptor_EncryptZeroSymmetric1(void *thisptr, uint64_t *parms_id, bool save_seed, void *destination, void *pool);
+SHL_FUNC Encryptor_EncryptZeroSymmetric2(void *thisptr, bool save_seed, void *destination, void *pool); /* c/encryptor.h:34 */
 SHL_FUNC Encryptor_EncryptSymmetric(void *thisptr, void *plaintext, bool save_seed, void *destination, void *pool);
 SHL_FUNC Encryptor_SymmetricSaveSize(void *thisptr, uint64_t *parms_id, int64_t *result);
 SHL_FUNC Encryptor_EncryptZeroSymmetricSave(void *thisptr, uint64_t *parms_id, uint8_t *outptr, uint64_t size, int64_t *out_bytes);

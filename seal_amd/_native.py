@@ -68,10 +68,10 @@ KeyGenerator_Create1 KeyGenerator_Create2 KeyGenerator_Destroy KeyGenerator_Secr
 KeyGenerator_CreateRelinKeys KeyGenerator_CreateGaloisKeysFromSteps KeyGenerator_CreateGaloisKeysAll KeyGenerator_CreateGaloisKeysFromElts KeyGenerator_KeyToHost KeyGenerator_SeededSaveSize KeyGenerator_CreateRelinKeysSave KeyGenerator_CreateGaloisKeysFromEltsSave SecretKey_Get PublicKey_Get
 SecretKey_Create SecretKey_Destroy SecretKey_Set SecretKey_UnsafeLoad SecretKey_Load Decryptor_Create Decryptor_Destroy
 Decryptor_Decrypt Decryptor_InvariantNoiseBudget Decryptor_DecryptBatchWords Decryptor_DecryptBatch
-CKKSEncoder_Create CKKSEncoder_Destroy CKKSEncoder_SlotCount CKKSEncoder_Encode1 CKKSEncoder_Encode2 CKKSEncoder_Encode3 CKKSEncoder_Encode5 CKKSEncoder_Decode1 CKKSEncoder_Decode2
+CKKSEncoder_Create CKKSEncoder_Destroy CKKSEncoder_SlotCount CKKSEncoder_Encode1 CKKSEncoder_Encode2 CKKSEncoder_Encode3 CKKSEncoder_Encode4 CKKSEncoder_Encode5 CKKSEncoder_Decode1 CKKSEncoder_Decode2
 BatchEncoder_Create BatchEncoder_Destroy BatchEncoder_GetSlotCount BatchEncoder_Encode1 BatchEncoder_Encode2 BatchEncoder_Decode1
 BatchEncoder_Decode2 BatchEncoder_EncodeDevice BatchEncoder_DecodeDevice
-PublicKey_Create PublicKey_Destroy PublicKey_Set PublicKey_UnsafeLoad PublicKey_Load Encryptor_Encrypt Encryptor_EncryptZero1
+PublicKey_Create PublicKey_Destroy PublicKey_Set PublicKey_UnsafeLoad PublicKey_Load Encryptor_Encrypt Encryptor_EncryptZero1 Encryptor_EncryptZero2 Encryptor_EncryptZeroSymmetric2
 Encryptor_Create Encryptor_Destroy Encryptor_SetSeed Encryptor_EncryptZeroSymmetric1 Encryptor_EncryptSymmetric
 Encryptor_SymmetricSaveSize Encryptor_EncryptZeroSymmetricSave Encryptor_EncryptSymmetricSave
 Plaintext_Create1 Plaintext_Create5 Plaintext_Destroy Plaintext_Set4 Plaintext_SetFromDevice Plaintext_CoeffCount
@@ -81,7 +81,7 @@ Evaluator_AddMany Evaluator_AddPlain Evaluator_SubPlain Evaluator_MultiplyMany E
 Evaluator_TransformToNTT1 Evaluator_ModSwitchToNext2 Evaluator_ModSwitchTo2
 KSwitchKeys_Create1 KSwitchKeys_Destroy KSwitchKeys_Size KSwitchKeys_SetKey KSwitchKeys_SetKeyFromDevice
 KSwitchKeys_SetKeyDigits KSwitchKeys_HasKey RelinKeys_GetIndex GaloisKeys_GetIndex GaloisTool_GetEltFromStep
-Evaluator_Create Evaluator_Destroy Evaluator_SetStream Evaluator_Synchronize Evaluator_SetTransparentCheck
+Evaluator_Create Evaluator_Destroy Evaluator_SetStream Evaluator_Synchronize Evaluator_CopyTo Evaluator_SetTransparentCheck
 Evaluator_BeginCapture Evaluator_EndCapture Evaluator_LaunchGraph Graph_Destroy
 Evaluator_Negate Evaluator_Add Evaluator_Sub Evaluator_Multiply Evaluator_Square Evaluator_Relinearize
 Evaluator_ModSwitchToNext1 Evaluator_ModSwitchTo1 Evaluator_RescaleToNext Evaluator_RescaleTo

@@ -542,6 +542,9 @@ class CKKSEncoder:
         if isinstance(values, (float, int, np.floating, np.integer)):
             N.check(N.lib().CKKSEncoder_Encode3(self._h, C.c_double(float(values)), pid, C.c_double(scale), destination._h, None))
             return destination
+        if isinstance(values, (complex, np.complexfloating)):   # one complex value in every slot (c/ckksencoder.h:35)
+            N.check(N.lib().CKKSEncoder_Encode4(self._h, C.c_double(values.real), C.c_double(values.imag), pid, C.c_double(scale), destination._h, None))
+            return destination
         a = np.asarray(values)
         if np.iscomplexobj(a):
             a = np.ascontiguousarray(a, dtype=np.complex128)
@@ -735,14 +738,21 @@ class Encryptor:
         N.check(N.lib().Encryptor_Encrypt(self._h, plain._h, destination._h, None))
         return destination
 
-    def encrypt_zero(self, parms_id, destination=None):
+    def encrypt_zero(self, parms_id=None, destination=None):
+        """parms_id None: at the first data level (Encryptor_EncryptZero2, c/encryptor.h:26)"""
         destination = destination if destination is not None else Ciphertext(self.context)
-        N.check(N.lib().Encryptor_EncryptZero1(self._h, (C.c_uint64 * 4)(*parms_id), destination._h, None))
+        if parms_id is None:
+            N.check(N.lib().Encryptor_EncryptZero2(self._h, destination._h, None))
+        else:
+            N.check(N.lib().Encryptor_EncryptZero1(self._h, (C.c_uint64 * 4)(*parms_id), destination._h, None))
         return destination
 
-    def encrypt_zero_symmetric(self, parms_id, destination=None):
+    def encrypt_zero_symmetric(self, parms_id=None, destination=None):
         destination = destination if destination is not None else Ciphertext(self.context)
-        N.check(N.lib().Encryptor_EncryptZeroSymmetric1(self._h, (C.c_uint64 * 4)(*parms_id), C.c_bool(False), destination._h, None))
+        if parms_id is None:
+            N.check(N.lib().Encryptor_EncryptZeroSymmetric2(self._h, C.c_bool(False), destination._h, None))
+        else:
+            N.check(N.lib().Encryptor_EncryptZeroSymmetric1(self._h, (C.c_uint64 * 4)(*parms_id), C.c_bool(False), destination._h, None))
         return destination
 
     def encrypt_symmetric(self, plain, destination=None):

@@ -1105,6 +1105,24 @@ extern "C"
         as<CKKSEncoder>(thisptr)->encode_value(value, parms_id, scale, *as<Plaintext>(destination));
         SHL_CATCH
     }
+    // one complex value in every slot (c/ckksencoder.h:35; ckks.h:795-800: the reference fills `slots` copies and encodes them)
+    SHL_FUNC CKKSEncoder_Encode4(void *thisptr, double value_re, double value_im, uint64_t *parms_id, double scale, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(parms_id, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        const size_t slots = as<CKKSEncoder>(thisptr)->slot_count();
+        std::vector<double> v(2 * slots);
+        for (size_t i = 0; i < slots; i++)
+        {
+            v[2 * i] = value_re;
+            v[2 * i + 1] = value_im;
+        }
+        as<CKKSEncoder>(thisptr)->encode(v.data(), slots, true, parms_id, scale, *as<Plaintext>(destination));
+        SHL_CATCH
+    }
     SHL_FUNC CKKSEncoder_Encode5(void *thisptr, int64_t value, uint64_t *parms_id, void *destination)
     {
         IfNullRet(thisptr, SHL_E_POINTER);
@@ -1324,6 +1342,29 @@ extern "C"
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
         as<Encryptor>(thisptr)->encrypt_zero(parms_id, *as<Ciphertext>(destination));
+        SHL_CATCH
+    }
+    // the forms without a parms_id encrypt at the first data level (c/encryptor.h:26, 34; encryptor.h: encrypt_zero(destination))
+    SHL_FUNC Encryptor_EncryptZero2(void *thisptr, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        Encryptor &e = *as<Encryptor>(thisptr);
+        e.encrypt_zero(e.context().first_level().parms_id, *as<Ciphertext>(destination));
+        SHL_CATCH
+    }
+    SHL_FUNC Encryptor_EncryptZeroSymmetric2(void *thisptr, bool save_seed, void *destination, void *pool)
+    {
+        (void)pool;
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(destination, SHL_E_POINTER);
+        SHL_TRY
+        if (save_seed)
+            throw std::invalid_argument("a device ciphertext holds both polynomials: use Encryptor_EncryptZeroSymmetricSave for the seeded stream");
+        Encryptor &e = *as<Encryptor>(thisptr);
+        e.encrypt_zero_symmetric(e.context().first_level().parms_id, *as<Ciphertext>(destination));
         SHL_CATCH
     }
     SHL_FUNC Encryptor_Destroy(void *thisptr)

@@ -119,6 +119,7 @@ namespace sealhip
         // either key may be null (Encryptor(context, public_key) / (context, secret_key) / both)
         Encryptor(const Context &context, const PublicKey *public_key, const SecretKey *secret_key);
         Encryptor(const Context &context, const SecretKey &secret_key) : Encryptor(context, nullptr, &secret_key) {}
+        const Context &context() const { return context_; }
         // Encryptor::encrypt_zero(parms_id, destination) / encrypt(plain, destination): public-key encryption, batch of one
         void encrypt_zero(const uint64_t *parms_id, Ciphertext &destination);
         void encrypt(const Plaintext &plain, Ciphertext &destination);

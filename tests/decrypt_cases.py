@@ -161,6 +161,8 @@ def case_encrypt_symmetric(scheme, n, bits, seed=0x5EA1):
         assert enc.encrypt_zero_symmetric_save(pid) == ref.encrypt_zero_symmetric_save(ci, True), ("seeded zero", ci)
         ct = enc.encrypt_zero_symmetric(pid)
         assert ct.save_bytes() == ref.encrypt_zero_symmetric_save(ci, False), ("full zero", ci)
+    # the form without a parms_id works at the first data level (Encryptor_EncryptZeroSymmetric2, c/encryptor.h:34)
+    assert enc.encrypt_zero_symmetric().save_bytes() == ref.encrypt_zero_symmetric_save(ref.first_chain_index, False)
     rng = np.random.default_rng(29)
     if scheme == "ckks":
         rpt = ref.ckks_encode(rng.standard_normal(n // 2), max(ref.first_chain_index - 1, 0), 2.0 ** 25)
@@ -294,6 +296,7 @@ def case_encrypt_asymmetric(scheme, n, bits, seed=0x5EA1):
         for ci in range(ref.first_chain_index, -1, -1):
             ct = enc.encrypt_zero(d.ctx.parms_id_at(ci))
             assert ct.save_bytes() == ref.encrypt_asymmetric_save(None, ci), ("encrypt_zero", ci)
+        assert enc.encrypt_zero().save_bytes() == ref.encrypt_asymmetric_save(None, ref.first_chain_index)   # Encryptor_EncryptZero2
     rng = np.random.default_rng(37)
     if scheme == "ckks":
         rpt = ref.ckks_encode(rng.standard_normal(n // 2), ref.first_chain_index, 2.0 ** 25)
@@ -373,6 +376,13 @@ def case_ckks_encoder(n, bits, check_bits=True):
                     raise AssertionError("the reference rejected encode(%r, scale %r): %s" % (v, scale, err))
                 except want_cls:
                     continue
+            assert np.array_equal(enc.encode(v, pid, scale).to_numpy(), want), (v, scale)
+        # one complex value in every slot (CKKSEncoder_Encode4; ckks.h:795-800 fills `slots` copies and encodes them)
+        for v in (complex(0.5, -1.25), complex(-3.0, 2.0 ** -7)):
+            try:
+                want = ref.ckks_encode_complex(np.full(n // 2, v, dtype=np.complex128), ref.first_chain_index, scale).data()
+            except sealref.RefError:
+                continue
             assert np.array_equal(enc.encode(v, pid, scale).to_numpy(), want), (v, scale)
     # argument checks (ckks.h:463-509, 686-716)
     pid = d.ctx.parms_id_at(ref.first_chain_index)
