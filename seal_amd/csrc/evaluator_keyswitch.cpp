@@ -1,0 +1,672 @@
+// Evaluator, part 2: relinearize, switch_key_inplace in its two halves, digit-parallel key switching
+#include "evaluator_common.h"
+
+namespace sealhip
+{
+    // ---- relinearize (evaluator.cpp:1144-1199)
+    void Evaluator::relinearize_inplace(Ciphertext &e, const KSwitchKeys &relin_keys) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (relin_keys.context() != &context_)
+            throw std::invalid_argument("relin_keys is not valid for encryption parameters");
+        size_t size = e.size();
+        const size_t destination_size = 2;
+        if (destination_size > size)
+            throw std::invalid_argument("destination_size must be at least 2 and less than or equal to current count");
+        if (relin_keys.size() < size - 2)
+            throw std::invalid_argument("not enough relinearization keys");
+        if (destination_size == size)
+            return;
+        size_t relins_needed = size - destination_size;
+        // the reference passes the LAST polynomial as the target of every step (evaluator.cpp:1180-1188)
+        for (size_t I = 0; I < relins_needed; I++)
+            switch_key_inplace(e, e.plane(size - 1), relin_keys, relin_index(size - 1 - I));
+        e.resize(e.level(), destination_size, stream_);
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::relinearize_partial(Ciphertext &e, const KSwitchKeys &relin_keys, unsigned j0, unsigned j1, uint64_t *acc) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (relin_keys.context() != &context_ && !(j0 == j1 && !relin_keys.context())) // a rank without digits may hold no key
+            throw std::invalid_argument("relin_keys is not valid for encryption parameters");
+        if (e.size() != 3)
+            throw std::invalid_argument("digit-parallel relinearization takes a size-3 ciphertext");
+        switch_key_partial(e, e.plane(2), relin_keys, relin_index(2), j0, j1, acc);
+    }
+    void Evaluator::relinearize_finish(Ciphertext &e, uint64_t *acc, unsigned parts) const
+    {
+        if (&e.context() != &context_ || !e.level() || e.size() != 3)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        switch_key_finish(e, acc, parts);
+        e.resize(e.level(), 2, stream_);
+        throw_if_transparent(e);
+    }
+    void Evaluator::apply_galois_partial(
+        Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys, unsigned j0, unsigned j1, uint64_t *acc) const
+    {
+        check_valid(e, "encrypted");
+        if (galois_keys.context() != &context_ && !(j0 == j1 && !galois_keys.context()))
+            throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+        uint64_t m = 2 * (uint64_t)context_.n();
+        if (!(galois_elt & 1) || galois_elt >= m)
+            throw std::invalid_argument("Galois element is not valid");
+        if (j0 < j1 && !galois_keys.has_key(galois_index(galois_elt))) // a rank without digits holds no slice of the key
+            throw std::invalid_argument("Galois key not present");
+        if (e.size() != 2)
+            throw std::invalid_argument("encrypted size must be 2");
+        const Scheme scheme = context_.scheme();
+        PlaneGeom g{ (unsigned)context_.log_n(), e.level()->K, (unsigned)e.batch() };
+        const int ntt_form = scheme == Scheme::bfv ? 0 : 1;
+        if ((ntt_form != 0) != e.is_ntt_form())
+            throw std::invalid_argument(ntt_form ? "encrypted must be in NTT form" : "BFV encrypted cannot be in NTT form");
+        Scratch perm(2 * g.words()); // [pi(c0), pi(c1)]
+        ck(k_apply_galois(context_.dev_mods(), e.data(), perm.p, galois_elt, ntt_form, g, 2, stream_), "apply_galois");
+        ck(hipMemcpyAsync(e.plane(0), perm.p, g.words() * 8, hipMemcpyDeviceToDevice, stream_), "galois copy c0");
+        ck(hipMemsetAsync(e.plane(1), 0, g.words() * 8, stream_), "galois zero c1");
+        switch_key_partial(e, perm.p + g.words(), galois_keys, galois_index(galois_elt), j0, j1, acc);
+    }
+    void Evaluator::apply_galois_finish(Ciphertext &e, uint64_t *acc, unsigned parts) const
+    {
+        if (&e.context() != &context_ || !e.level() || e.size() != 2)
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        switch_key_finish(e, acc, parts);
+        throw_if_transparent(e);
+    }
+
+    // ---- switch_key_inplace (evaluator.cpp:2561-2867), in two halves so that the decomposition digits can be
+    // spread over the GPUs of a node: partial = the I/J loop restricted to the digits [j0, j1)
+    // (canonical partial sums S_k[I]), finish = mod-down by the special prime and accumulation into (c0, c1).
+    // Between the halves the caller may add the partial sums of several ranks (one all-reduce of 2(K+1)N words).
+    size_t Evaluator::switch_key_acc_words(const Ciphertext &e) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        return (size_t)e.batch() * 2 * (e.level()->K + 1) * context_.n();
+    }
+
+    void Evaluator::switch_key_partial(
+        const Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, unsigned j0, unsigned j1,
+        uint64_t *acc_out, unsigned split) const
+    {
+        check_valid(e, "encrypted");
+        if (!target)
+            throw std::invalid_argument("target_iter");
+        if (!acc_out)
+            throw std::invalid_argument("acc");
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        if (keys.context() != &context_ && !(j0 == j1 && !keys.context()))
+            throw std::invalid_argument("parameter mismatch");
+        if (j0 == j1 && j0 <= e.level()->K)
+        {
+            // a rank without digits (more ranks than digits) needs no key: its partial sums are zero
+            ck(hipMemsetAsync(acc_out, 0, switch_key_acc_words(e) * 8 * (split ? split : 1), stream_), "ks zero partial sums");
+            return;
+        }
+        if (key_index >= keys.slots())
+            throw std::out_of_range("kswitch_keys_index");
+        const Scheme scheme = context_.scheme();
+        if (scheme == Scheme::bfv && e.is_ntt_form())
+            throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+        if (scheme == Scheme::ckks && !e.is_ntt_form())
+            throw std::invalid_argument("CKKS encrypted must be in NTT form");
+        if (scheme == Scheme::bgv && !e.is_ntt_form())
+            throw std::invalid_argument("BGV encrypted must be in NTT form");
+        if (!keys.has_key(key_index))
+            throw std::invalid_argument("kswitch_keys is not valid for encryption parameters");
+        const KSwitchKeys::Key &key = keys.key(key_index);
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K;
+        if (j1 > K || j0 > j1)
+            throw std::invalid_argument("digit range");
+        if (j0 < j1 && (key.digit0 > j0 || key.digit0 + key.digits < j1))
+            throw std::invalid_argument("kswitch_keys inner dimension is too small");
+        if (e.size() < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+
+        const size_t N = context_.n();
+        const unsigned B = (unsigned)e.batch();
+        const unsigned n_log = (unsigned)context_.log_n();
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        const uint32_t *map = ks_comp_prime(K);
+        // t_target: coefficient form of every decomposition digit (evaluator.cpp:2651-2658)
+        const bool ntt_target = scheme == Scheme::ckks || scheme == Scheme::bgv; // the target is in NTT form
+        // BFV on the fused path: the target is in coefficient form already and the kernels only read it - no copy
+        const bool read_in_place = !ntt_target && key.register_order;
+        Scratch t(read_in_place ? 1 : (size_t)B * K * N);
+        const uint64_t *digits = read_in_place ? target : t.p;
+        if (read_in_place)
+            ;
+        else if (ntt_target && ntt2_supports(context_.log_n()))
+        {
+            // out-of-place: the two-pass engine reads the target and writes t
+            NttBatch bt = plain_batch(t.p, (size_t)K * N, K, B, 0);
+            bt.src = target;
+            bt.src_outer_stride = (size_t)K * N;
+            ck(ntt_inverse(tb, bt, 0, stream_), "ks intt target");
+        }
+        else
+        {
+            ck(hipMemcpyAsync(t.p, target, (size_t)B * K * N * 8, hipMemcpyDeviceToDevice, stream_), "ks copy target");
+            if (ntt_target)
+                ck(ntt_inverse(tb, plain_batch(t.p, (size_t)K * N, K, B, 0), 0, stream_), "ks intt target");
+        }
+
+        if (key.register_order)
+        {
+            // fused path (ntt2_kernels.hip): the K(K+1) raised digits go through HBM once, between
+            // the two passes, and are multiplied into the key inside the second pass
+            const KsTargets &kt = ks_targets(K);
+            Scratch mid((size_t)B * (K + 1) * K * N);
+            KsFusedArgs ka{};
+            ka.t = digits;
+            ka.target_ntt = ntt_target ? target : nullptr; // the I == J shortcut of evaluator.cpp:2682-2685
+            ka.key = key.dev;
+            ka.key_quot_off = key.quot_off;
+            ka.mid = mid.p;
+            ka.acc = acc_out;
+            ka.targets1 = kt.dev;
+            ka.targets2 = kt.dev + 2 * (kt.n_int + kt.n_fp);
+            ka.ntargets = kt.n_int + kt.n_fp;
+            ka.n_int = kt.n_int;
+            ka.K = K;
+            ka.L = L;
+            ka.batch = B;
+            ka.j0 = j0;
+            ka.j1 = j1;
+            ka.key_digit0 = (unsigned)key.digit0;
+            ka.parts = split ? split : 1;
+            ck(ks_fused(tb, ka, stream_), "ks fused");
+        }
+        else if (split > 1)
+            throw std::invalid_argument("in-launch digit groups need the fused key-switch path");
+        else
+        {
+            // u[b][I][J] = NTT_I(t_J mod q_I), I over the K data primes and the special prime
+            // (evaluator.cpp:2663-2701).  The reference skips the transform when I == J in CKKS because
+            // NTT_J(INTT_J(x)) = x; computing it gives the same canonical words.
+            Scratch u((size_t)B * (K + 1) * K * N);
+            NttBatch b{};
+            b.data = u.p;
+            b.outer_stride = (size_t)(K + 1) * K * N;
+            b.ncomp = (K + 1) * K;
+            b.nouter = B;
+            b.comp_prime = map;
+            b.prime_first = 0;
+            b.src = digits;
+            b.src_outer_stride = (size_t)K * N;
+            b.src_ncomp = K;
+            b.src_mode = 1;
+            ck(ntt_forward(tb, b, 0, stream_), "ks ntt digits");
+            // inner product with the key (evaluator.cpp:2703-2755)
+            ck(k_keyswitch_mac(mods, u.p, key.dev, acc_out, n_log, K, L, B, j0, j1, (unsigned)key.digit0, stream_), "ks mac");
+        }
+    }
+
+    void Evaluator::switch_key_finish(Ciphertext &e, uint64_t *acc_p, unsigned parts) const
+    {
+        check_valid(e, "encrypted");
+        if (!acc_p)
+            throw std::invalid_argument("acc");
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        if (e.size() < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+        if (parts < 1 || parts > 8)
+            throw std::invalid_argument("parts"); // 8 canonical residues below 2^60 still fit a 64-bit word
+        const Scheme scheme = context_.scheme();
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K;
+        const size_t N = context_.n();
+        const unsigned B = (unsigned)e.batch();
+        const unsigned n_log = (unsigned)context_.log_n();
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        const uint32_t *map = ks_comp_prime(K);
+        struct AccRef
+        {
+            uint64_t *p;
+        } acc{ acc_p };
+        if (parts > 1)
+            ck(k_keyswitch_reduce(mods, acc.p, n_log, K, L, B, stream_), "ks reduce partial sums");
+
+        // mod-down by the special prime P and accumulate into (c0, c1) (evaluator.cpp:2806-2864)
+        const uint64_t P = context_.coeff_modulus()[L - 1];
+        if (scheme == Scheme::bgv)
+        {
+            // evaluator.cpp:2762-2805: t_last = INTT_P(S_k[P]); delta = (-(t_last mod t) P^-1 mod t) P + t_last (mod q_i);
+            // ct_k[i] += (S_k[q_i] - NTT_i(delta)) P^-1
+            NttBatch bi = plain_batch(acc.p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
+            ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
+            Scratch delta((size_t)B * 2 * K * N);
+            ck(k_bgv_delta(mods, host::make_mod(context_.plain_modulus()), klvl.dev.inv_q_last_mod_t, klvl.dev.q_last_mod_q,
+                           acc.p + (size_t)K * N, (size_t)(K + 1) * N, delta.p, n_log, K, (size_t)2 * B, stream_),
+               "ks bgv delta");
+            bgv_correct_and_combine(delta, acc.p, (size_t)(K + 1) * N, klvl.dev.inv_q_last_mod_q, K, 2 * B, e.plane(0), e.plane(1),
+                                    (size_t)K * N, 2);
+        }
+        else if (scheme == Scheme::ckks)
+        {
+            NttBatch bi = plain_batch(acc.p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
+            ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
+            Scratch tt(ntt2_supports(context_.log_n()) ? 1 : (size_t)B * 2 * K * N);
+            NttBatch b{};
+            b.data = tt.p;
+            b.outer_stride = (size_t)K * N;
+            b.ncomp = K;
+            b.nouter = 2 * B;
+            b.comp_prime = nullptr;
+            b.prime_first = 0;
+            b.src = acc.p + (size_t)K * N;
+            b.src_outer_stride = (size_t)(K + 1) * N;
+            b.src_ncomp = 1;
+            b.src_mode = 2;
+            b.src_half = P >> 1;
+            b.src_q = P;
+            b.src_fix = klvl.dev.round_fix;
+            if (ntt2_supports(context_.log_n()))
+            {
+                // the tail is the epilogue of the transform: tt is never stored
+                b.data = nullptr;
+                b.epi = 2;
+                b.epi_a = acc.p;
+                b.epi_a_stride = (size_t)(K + 1) * N;
+                b.epi_mul = klvl.dev.inv_q_last_mod_q;
+                b.epi_out0 = e.plane(0);
+                b.epi_out1 = e.plane(1);
+                b.epi_out_stride = (size_t)K * N;
+                ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction + tail");
+            }
+            else
+            {
+                ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction");
+                ck(k_keyswitch_tail_ckks(mods, klvl.dev.inv_q_last_mod_q, e.plane(0), e.plane(1), acc.p, tt.p, n_log, K, B, stream_),
+                   "ks tail");
+            }
+        }
+        else
+        {
+            NttBatch bi = plain_batch(acc.p, (size_t)(K + 1) * N, K + 1, 2 * B, 0);
+            bi.comp_prime = map + (size_t)(K + 1) * K;
+            ck(ntt_inverse(tb, bi, 0, stream_), "ks intt all");
+            ck(k_keyswitch_tail_bfv(
+                   mods, klvl.dev.inv_q_last_mod_q, klvl.dev.round_fix, P >> 1, P, e.plane(0), e.plane(1), acc.p, n_log, K, B,
+                   stream_),
+               "ks tail bfv");
+        }
+    }
+
+    void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        // Small batches do not fill the chip: one workgroup per (target modulus, tile, batch item) is 16 (K+1) workgroups per
+        // ciphertext at N = 2^16, each looping over all K digits, and only 2 x 16 of them for the two 60-bit moduli.  Cut the
+        // digit loop into `split` in-launch groups (their partial sums are added by the reduce pass below): single-ciphertext
+        // latency of multiply+relinearize+rescale at C5 0.63 -> 0.40 ms.  SEALHIP_KS_SPLIT overrides (tests, A/B).
+        const unsigned K = e.level()->K;
+        unsigned split = 1;
+        if (keys.context() == &context_ && key_index < keys.slots() && keys.has_key(key_index) && keys.key(key_index).register_order)
+        {
+            const size_t wgs = e.batch() * (size_t)(K + 1) * (context_.n() >> 12);
+            split = (unsigned)(2048 / (wgs ? wgs : 1)); // measured at C5: best split 8 / 4 / 2 / 1 at batch 1 / 2 / 4 / >= 8
+            if (const char *f = std::getenv("SEALHIP_KS_SPLIT"))
+                split = (unsigned)std::atoi(f);
+            if (split > 8)
+                split = 8; // eight canonical residues below 2^61 still fit a 64-bit word
+            if (split > K)
+                split = K;
+            if (split < 1)
+                split = 1;
+        }
+        Scratch acc(switch_key_acc_words(e) * split);
+        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split);
+        if (split > 1)
+            ck(k_keyswitch_reduce(context_.dev_mods(), acc.p, (unsigned)context_.log_n(), K, context_.key_level().K, (unsigned)e.batch(),
+                                  stream_, split),
+               "ks add digit groups");
+        // CKKS at the two-pass sizes: leave the mod-down to whoever touches the ciphertext next (LazyTail) - a rescale on this
+        // evaluator then does both rounding divisions with one transform per component.  SEALHIP_KS_EAGER_TAIL=1: always now.
+        static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
+        if (lazy_ok && context_.scheme() == Scheme::ckks && ntt2_supports(context_.log_n()) && K >= 2)
+            defer_tail(e, acc.release());
+        else
+            switch_key_finish(e, acc.p, 1);
+    }
+
+    // relinearize (or a rotation) followed by rescale_to_next: acc = the key-switch sums, planes 0 and 1 of e = the addends.
+    // Reference steps being folded: evaluator.cpp:2806-2864 (mod-down by the special prime P), then rns.cpp:830-901 on the result
+    // (divide_and_round_q_last_ntt_inplace); see NttTail2 (ntt_kernels.h) for the algebra.
+    void Evaluator::switch_key_finish_rescale(Ciphertext &e, uint64_t *acc_p, const Level *next, double destination_scale) const
+    {
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K;
+        const size_t N = context_.n();
+        const unsigned B = (unsigned)e.batch();
+        const NttTables &tb = context_.ntt_tables();
+        const uint64_t P = context_.coeff_modulus()[L - 1];
+        uint64_t *c0 = e.data_, *c1 = e.data_ + (size_t)B * K * N; // no deferred tail left on e: the caller detached it
+        static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr;
+        if (trace)
+            std::fprintf(stderr, "[ks] folded tail\n");
+        g_tail_folded++;
+
+        // t_P: coefficient form of the special-prime sums, in place (component K of every (item, plane) of acc)
+        // plus P/2: the rounding's addend goes in here, once per coefficient (NttBatch::out_add; the maps below run in mode 3)
+        NttBatch bi = plain_batch(acc_p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
+        bi.out_add = P >> 1;
+        ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
+
+        // the relinearised ciphertext's LAST component (the one rescale divides by), completed alone: c += (S - NTT(v)) P^-1
+        {
+            NttBatch b{};
+            b.data = nullptr;
+            b.outer_stride = N;
+            b.ncomp = 1;
+            b.nouter = 2 * B;
+            b.comp_prime = nullptr;
+            b.prime_first = K - 1;
+            b.src = acc_p + (size_t)K * N;
+            b.src_outer_stride = (size_t)(K + 1) * N;
+            b.src_ncomp = 1;
+            b.src_mode = 3;
+            b.src_half = P >> 1;
+            b.src_q = P;
+            b.src_fix = klvl.dev.round_fix + (K - 1);
+            b.epi = 2;
+            b.epi_a = acc_p + (size_t)(K - 1) * N;
+            b.epi_a_stride = (size_t)(K + 1) * N;
+            b.epi_mul = klvl.dev.inv_q_last_mod_q + (K - 1);
+            b.epi_out0 = c0 + (size_t)(K - 1) * N;
+            b.epi_out1 = c1 + (size_t)(K - 1) * N;
+            b.epi_out_stride = (size_t)K * N;
+            ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction + tail, last component");
+        }
+        // t_last: its coefficient form, in place (that component is dropped by the rescale)
+        {
+            NttBatch bl = plain_batch(c0 + (size_t)(K - 1) * N, (size_t)K * N, 1, 2 * B, K - 1);
+            bl.out_add = lvl.dev.half_q_last;
+            ck(ntt_inverse(tb, bl, 0, stream_), "rescale intt last");
+        }
+
+        // components 0 .. K-2: out = (c + S P^-1 - NTT(v P^-1 + u)) q_last^-1, one transform each
+        const size_t words = (size_t)2 * B * (K - 1) * N;
+        uint64_t *out = DevicePool::global().alloc_words(words);
+        try
+        {
+            NttTail2 t2{};
+            t2.src2_0 = c0 + (size_t)(K - 1) * N;
+            t2.src2_1 = c1 + (size_t)(K - 1) * N;
+            t2.src2_stride = (size_t)K * N;
+            t2.src2_half = lvl.dev.half_q_last;
+            t2.src2_q = lvl.dev.q_last;
+            t2.src2_fix = lvl.dev.round_fix;
+            t2.pmul = klvl.dev.inv_q_last_mod_q;
+            t2.c0 = c0;
+            t2.c1 = c1;
+            t2.c_stride = (size_t)K * N;
+            t2.halves_added = 1;
+            NttBatch b{};
+            b.data = nullptr;
+            b.outer_stride = (size_t)(K - 1) * N;
+            b.ncomp = K - 1;
+            b.nouter = 2 * B;
+            b.comp_prime = nullptr;
+            b.prime_first = 0;
+            b.src = acc_p + (size_t)K * N;
+            b.src_outer_stride = (size_t)(K + 1) * N;
+            b.src_ncomp = 1;
+            b.src_mode = 3;
+            b.src_half = P >> 1;
+            b.src_q = P;
+            b.src_fix = klvl.dev.round_fix;
+            b.epi = 0;
+            b.epi_a = acc_p;
+            b.epi_a_stride = (size_t)(K + 1) * N;
+            b.epi_mul = lvl.dev.inv_q_last_mod_q;
+            b.epi_out0 = out;
+            b.epi_out1 = out + (size_t)B * (K - 1) * N;
+            b.epi_out_stride = (size_t)(K - 1) * N;
+            b.tail2 = &t2;
+            ck(ntt_forward(tb, b, 1, stream_), "mod-down + rescale in one transform");
+        }
+        catch (...)
+        {
+            DevicePool::global().free_words(out);
+            throw;
+        }
+        e.adopt(next, 2, out, words);
+        e.scale() = destination_scale;
+    }
+
+    // ---- digit-parallel key switching over the ranks of a communicator (the reference loop being split:
+    // evaluator.cpp:2663-2755 over the digits, 2806-2864 over the target moduli).  Everything is enqueued on stream_.
+    unsigned Evaluator::switch_key_slots(const Ciphertext &e, unsigned nranks) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (nranks < 1 || nranks > 8)
+            throw std::invalid_argument("nranks");
+        return (e.level()->K + nranks - 1) / nranks;
+    }
+
+    void Evaluator::switch_key_pack_targets(const Ciphertext &e, const uint64_t *acc, unsigned nranks, uint64_t *send, uint64_t *sp) const
+    {
+        const unsigned m = switch_key_slots(e, nranks);
+        if (!acc || !send || !sp)
+            throw std::invalid_argument("buffer");
+        ck(k_ks_pack_targets(acc, send, sp, (unsigned)context_.log_n(), e.level()->K, nranks, m, (unsigned)e.batch(), stream_), "ks pack targets");
+    }
+
+    void Evaluator::switch_key_finish_owned(
+        const Ciphertext &e, const uint64_t *recv, const uint64_t *sp, unsigned nranks, unsigned rank, uint64_t *own) const
+    {
+        const unsigned m = switch_key_slots(e, nranks);
+        if (rank >= nranks)
+            throw std::invalid_argument("rank");
+        if (!recv || !sp || !own)
+            throw std::invalid_argument("buffer");
+        if (context_.scheme() != Scheme::ckks)
+            throw std::logic_error("the reduce-scatter exchange is built for CKKS; BFV / BGV use the all-reduce exchange");
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K, B = (unsigned)e.batch(), n_log = (unsigned)context_.log_n();
+        const size_t N = context_.n();
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        unsigned first, count;
+        comm_split(K, nranks, rank, first, count);
+        if (!count)
+        {
+            // more ranks than moduli: nothing to reduce here, the chunk this rank contributes is zero
+            ck(hipMemsetAsync(own, 0, (size_t)m * B * 2 * N * 8, stream_), "ks zero own");
+            return;
+        }
+        // a key switch over this rank's `count` moduli: sums [batch][2][count+1][N], the special prime last
+        Scratch acc3((size_t)B * 2 * (count + 1) * N);
+        ck(k_ks_unpack_owned(mods, recv, sp, acc3.p, n_log, L, first, count, B, stream_), "ks unpack owned");
+        const uint64_t P = context_.coeff_modulus()[L - 1];
+        NttBatch bi = plain_batch(acc3.p + (size_t)count * N, (size_t)(count + 1) * N, 1, 2 * B, L - 1);
+        ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
+        // increments of the owned moduli, compact planes [2][batch][count][N] (the tail adds into them: start from zero)
+        Scratch inc((size_t)2 * B * count * N);
+        ck(hipMemsetAsync(inc.p, 0, (size_t)2 * B * count * N * 8, stream_), "ks zero increments");
+        Scratch tt(ntt2_supports(context_.log_n()) ? 1 : (size_t)B * 2 * count * N);
+        NttBatch b{};
+        b.data = tt.p;
+        b.outer_stride = (size_t)count * N;
+        b.ncomp = count;
+        b.nouter = 2 * B;
+        b.comp_prime = nullptr;
+        b.prime_first = first;
+        b.src = acc3.p + (size_t)count * N;
+        b.src_outer_stride = (size_t)(count + 1) * N;
+        b.src_ncomp = 1;
+        b.src_mode = 2;
+        b.src_half = P >> 1;
+        b.src_q = P;
+        b.src_fix = klvl.dev.round_fix + first;
+        uint64_t *inc0 = inc.p, *inc1 = inc.p + (size_t)B * count * N;
+        if (ntt2_supports(context_.log_n()))
+        {
+            b.data = nullptr;
+            b.epi = 2;
+            b.epi_a = acc3.p;
+            b.epi_a_stride = (size_t)(count + 1) * N;
+            b.epi_mul = klvl.dev.inv_q_last_mod_q + first;
+            b.epi_out0 = inc0;
+            b.epi_out1 = inc1;
+            b.epi_out_stride = (size_t)count * N;
+            ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction + tail (owned moduli)");
+        }
+        else
+        {
+            ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction (owned moduli)");
+            ck(k_keyswitch_tail_ckks(mods + first, klvl.dev.inv_q_last_mod_q + first, inc0, inc1, acc3.p, tt.p, n_log, count, B, stream_),
+               "ks tail (owned moduli)");
+        }
+        ck(k_ks_pack_owned(inc.p, own, n_log, count, m, B, stream_), "ks pack owned");
+    }
+
+    void Evaluator::switch_key_add_gathered(Ciphertext &e, const uint64_t *all, unsigned nranks) const
+    {
+        const unsigned m = switch_key_slots(e, nranks);
+        if (!all)
+            throw std::invalid_argument("buffer");
+        if (e.size() < 2)
+            throw std::invalid_argument("encrypted size must be at least 2");
+        ck(k_ks_add_gathered(context_.dev_mods(), e.plane(0), e.plane(1), all, (unsigned)context_.log_n(), e.level()->K, nranks, m,
+                             (unsigned)e.batch(), stream_),
+           "ks add gathered");
+    }
+
+    void Evaluator::switch_key_exchange_finish(Ciphertext &e, uint64_t *acc, Comm &comm, KsExchange how) const
+    {
+        const unsigned G = (unsigned)comm.size();
+        const size_t words = switch_key_acc_words(e);
+        if (how == KsExchange::all_reduce || context_.scheme() != Scheme::ckks)
+        {
+            comm.all_reduce_sum(acc, words, stream_);
+            switch_key_finish(e, acc, G);
+            return;
+        }
+        const unsigned m = switch_key_slots(e, G);
+        const size_t N = context_.n(), B = e.batch();
+        const size_t chunk = (size_t)m * B * 2 * N, spw = B * 2 * N;
+        Scratch send((size_t)G * chunk), sp(spw), recv(chunk), own(chunk), all((size_t)G * chunk);
+        switch_key_pack_targets(e, acc, G, send.p, sp.p);
+        comm.reduce_scatter_sum(send.p, recv.p, chunk, stream_);
+        comm.all_reduce_sum(sp.p, spw, stream_);
+        switch_key_finish_owned(e, recv.p, sp.p, G, (unsigned)comm.rank(), own.p);
+        comm.all_gather(own.p, all.p, chunk, stream_);
+        switch_key_add_gathered(e, all.p, G);
+    }
+
+    void Evaluator::relinearize_inplace(Ciphertext &e, const KSwitchKeys &relin_keys, Comm &comm, KsExchange how) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        unsigned first, count;
+        comm_split(e.level()->K, (unsigned)comm.size(), (unsigned)comm.rank(), first, count);
+        Scratch acc(switch_key_acc_words(e));
+        relinearize_partial(e, relin_keys, first, first + count, acc.p);
+        switch_key_exchange_finish(e, acc.p, comm, how);
+        e.resize(e.level(), 2, stream_);
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::apply_galois_inplace(Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys, Comm &comm, KsExchange how) const
+    {
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        unsigned first, count;
+        comm_split(e.level()->K, (unsigned)comm.size(), (unsigned)comm.rank(), first, count);
+        Scratch acc(switch_key_acc_words(e));
+        apply_galois_partial(e, galois_elt, galois_keys, first, first + count, acc.p);
+        switch_key_exchange_finish(e, acc.p, comm, how);
+        throw_if_transparent(e);
+    }
+
+    void Evaluator::rotate_vector_inplace(Ciphertext &e, int steps, const KSwitchKeys &galois_keys, Comm &comm, KsExchange how) const
+    {
+        if (context_.scheme() != Scheme::ckks)
+            throw std::logic_error("unsupported scheme");
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (steps == 0)
+            return;
+        // the digit-parallel form takes the exact key (evaluator.h:1209 with the key present); the NAF fallback of
+        // rotate_internal would need every rank to hold the power-of-two keys' digits as well
+        apply_galois_inplace(e, galois_elt_from_step(steps), galois_keys, comm, how);
+    }
+
+    void Evaluator::broadcast_key_digits(KSwitchKeys &keys, size_t index, uint64_t *staging, Comm &comm, int root) const
+    {
+        if (!staging)
+            throw std::invalid_argument("staging");
+        if (!context_.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        const size_t N = context_.n(), L = context_.key_level().K, K = context_.first_level().K;
+        const size_t digit_words = 2 * L * N;
+        comm.broadcast(staging, K * digit_words, root, stream_);
+        ck(hipStreamSynchronize(stream_), "broadcast key");
+        unsigned first, count;
+        comm_split((unsigned)K, (unsigned)comm.size(), (unsigned)comm.rank(), first, count);
+        if (count)
+            keys.set_key(context_, index, count, staging + first * digit_words, true, first);
+    }
+
+    // NTT the BGV correction polynomials `delta` ([items][ncomp][N], coefficient form, canonical) and fold them
+    // into the resident operand: v = (A - NTT(delta)) * mul  (mod q_i), A = a + item*a_stride + comp*N;
+    //   epi 1: out0[item][comp] = v;   epi 2: ct_{item&1}[item>>1][comp] += v
+    void Evaluator::bgv_correct_and_combine(
+        Scratch &delta, const uint64_t *a, size_t a_stride, const ShoupOp *mul, unsigned ncomp, size_t items, uint64_t *out0,
+        uint64_t *out1, size_t out_stride, int epi) const
+    {
+        const size_t N = context_.n();
+        const unsigned n_log = (unsigned)context_.log_n();
+        const NttTables &tb = context_.ntt_tables();
+        const ModDesc *mods = context_.dev_mods();
+        if (ntt2_supports(context_.log_n()))
+        {
+            NttBatch b{};
+            b.data = nullptr;
+            b.outer_stride = (size_t)ncomp * N;
+            b.ncomp = ncomp;
+            b.nouter = (unsigned)items;
+            b.prime_first = 0;
+            b.src = delta.p;
+            b.src_outer_stride = (size_t)ncomp * N;
+            b.src_ncomp = ncomp;
+            b.src_mode = 0;
+            b.epi = epi;
+            b.epi_a = a;
+            b.epi_a_stride = a_stride;
+            b.epi_mul = mul;
+            b.epi_out0 = out0;
+            b.epi_out1 = out1;
+            b.epi_out_stride = out_stride;
+            ck(ntt_forward(tb, b, 1, stream_), "bgv ntt correction + combine");
+            return;
+        }
+        ck(ntt_forward(tb, plain_batch(delta.p, (size_t)ncomp * N, ncomp, (unsigned)items, 0), 1, stream_), "bgv ntt correction");
+        if (epi == 1)
+        {
+            if (a_stride != (size_t)(ncomp + 1) * N)
+                throw std::logic_error("bgv combine layout");
+            ck(k_rescale_combine(mods, mul, a, delta.p, out0, n_log, ncomp + 1, items, stream_), "bgv combine");
+        }
+        else
+            ck(k_keyswitch_tail_ckks(mods, mul, out0, out1, a, delta.p, n_log, ncomp, (unsigned)(items / 2), stream_), "bgv ks tail");
+    }
+
+} // namespace sealhip

@@ -1,0 +1,291 @@
+// Ciphertext, Plaintext and KSwitchKeys: the device-resident objects of evaluator.h
+#include "evaluator_common.h"
+
+namespace sealhip
+{
+    // ---------------------------------------------------------------- Ciphertext
+    Ciphertext::~Ciphertext()
+    {
+        release();
+    }
+    namespace
+    {
+        // settle() runs from const accessors, and the reference lets several threads read one ciphertext at a time (evaluator.h:
+        // "concurrent calls on different destinations are safe"): exactly one of them may take the pending tail, the others wait
+        // until it has been launched.  One mutex per ciphertext would grow every object; a small table keyed by address does.
+        std::mutex g_settle_mu[64];
+        inline std::mutex &settle_mutex(const void *p)
+        {
+            return g_settle_mu[(reinterpret_cast<uintptr_t>(p) >> 6) & 63];
+        }
+        thread_local const Ciphertext *tl_settling = nullptr; // the tail's own kernels read the words through data() / plane()
+    } // namespace
+    void Ciphertext::settle() const
+    {
+        if (!__atomic_load_n(&lazy_, __ATOMIC_ACQUIRE) || tl_settling == this)
+            return;
+        std::lock_guard<std::mutex> lock(settle_mutex(this));
+        struct Marker
+        {
+            const Ciphertext *saved;
+            explicit Marker(const Ciphertext *c) : saved(tl_settling) { tl_settling = c; }
+            ~Marker() { tl_settling = saved; }
+        } marker(this);
+        LazyTail *pending = lazy_;
+        if (!pending)
+            return; // another thread completed it while this one waited
+        const LazyTail t = *pending;
+        // the words are valid once complete_tail() returns; only then may a reader that skips the lock see "nothing pending"
+        try
+        {
+            t.owner->complete_tail(const_cast<Ciphertext &>(*this), t);
+        }
+        catch (...)
+        {
+            __atomic_store_n(&lazy_, (LazyTail *)nullptr, __ATOMIC_RELEASE);
+            delete pending;
+            throw;
+        }
+        __atomic_store_n(&lazy_, (LazyTail *)nullptr, __ATOMIC_RELEASE);
+        delete pending;
+    }
+    void Ciphertext::drop_lazy()
+    {
+        if (!lazy_)
+            return;
+        const LazyTail t = *lazy_;
+        delete lazy_;
+        lazy_ = nullptr;
+        t.owner->forget_tail(*this, t);
+    }
+    void Ciphertext::release()
+    {
+        drop_lazy();
+        DevicePool::global().free_words(data_);
+        data_ = nullptr;
+        capacity_words_ = 0;
+        size_ = 0;
+        level_ = nullptr;
+    }
+    Ciphertext::Ciphertext(const Ciphertext &o) : ctx_(o.ctx_), batch_(o.batch_)
+    {
+        *this = o;
+    }
+    Ciphertext &Ciphertext::operator=(const Ciphertext &o)
+    {
+        if (this == &o)
+            return *this;
+        o.settle();  // the source's words are read below
+        drop_lazy(); // this object's words are replaced
+        if (ctx_ != o.ctx_ || batch_ != o.batch_)
+        {
+            release();
+            ctx_ = o.ctx_;
+            batch_ = o.batch_;
+        }
+        size_t words = o.word_count();
+        if (capacity_words_ < words)
+        {
+            DevicePool::global().free_words(data_);
+            data_ = DevicePool::global().alloc_words(words);
+            capacity_words_ = words;
+        }
+        level_ = o.level_;
+        size_ = o.size_;
+        is_ntt_form_ = o.is_ntt_form_;
+        scale_ = o.scale_;
+        correction_factor_ = o.correction_factor_;
+        if (words)
+            ck(hipMemcpyAsync(data_, o.data_, words * 8, hipMemcpyDeviceToDevice, DevicePool::thread_stream()), "Ciphertext copy");
+        return *this;
+    }
+    void Ciphertext::resize(const Level *level, size_t size, hipStream_t stream)
+    {
+        if (!level)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if ((size < 2 && size != 0) || size > 16) // SEAL_CIPHERTEXT_SIZE_MIN/MAX (defines.h)
+            throw std::invalid_argument("invalid size");
+        size_t pw = batch_ * level->K * ctx_->n();
+        size_t need = size * pw;
+        bool same_level = (level == level_);
+        // a deferred key-switch tail works on the first two polynomials in place: dropping trailing ones at the same level
+        // (relinearize: 3 -> 2) leaves it alone, anything else completes it first
+        if (lazy_ && !(same_level && size >= 2 && size <= size_))
+            settle();
+        size_t keep = same_level ? std::min(size_, size) * pw : 0;
+        if (need > capacity_words_)
+        {
+            uint64_t *nd = DevicePool::global().alloc_words(need);
+            if (keep)
+                ck(hipMemcpyAsync(nd, data_, keep * 8, hipMemcpyDeviceToDevice, stream), "Ciphertext resize copy");
+            DevicePool::global().free_words(data_);
+            data_ = nd;
+            capacity_words_ = need;
+        }
+        if (need > keep)
+            ck(hipMemsetAsync(data_ + keep, 0, (need - keep) * 8, stream), "Ciphertext resize zero");
+        level_ = level;
+        size_ = size;
+    }
+    void Ciphertext::reshape_uninitialized(const Level *level, size_t size)
+    {
+        drop_lazy();
+        size_t need = size * batch_ * level->K * ctx_->n();
+        if (need > capacity_words_)
+        {
+            DevicePool::global().free_words(data_);
+            data_ = DevicePool::global().alloc_words(need);
+            capacity_words_ = need;
+        }
+        level_ = level;
+        size_ = size;
+    }
+    void Ciphertext::adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words)
+    {
+        drop_lazy();
+        DevicePool::global().free_words(data_);
+        data_ = slab;
+        capacity_words_ = capacity_words;
+        level_ = level;
+        size_ = size;
+    }
+
+    // ---------------------------------------------------------------- Plaintext
+    Plaintext::~Plaintext()
+    {
+        DevicePool::global().free_words(data_);
+    }
+    Plaintext::Plaintext(const Plaintext &o) : ctx_(o.ctx_)
+    {
+        *this = o;
+    }
+    Plaintext &Plaintext::operator=(const Plaintext &o)
+    {
+        if (this == &o)
+            return *this;
+        ctx_ = o.ctx_;
+        if (capacity_words_ < o.coeff_count_)
+        {
+            DevicePool::global().free_words(data_);
+            data_ = DevicePool::global().alloc_words(o.coeff_count_);
+            capacity_words_ = o.coeff_count_;
+        }
+        coeff_count_ = o.coeff_count_;
+        level_ = o.level_;
+        scale_ = o.scale_;
+        if (coeff_count_)
+            ck(hipMemcpyAsync(data_, o.data_, coeff_count_ * 8, hipMemcpyDeviceToDevice, DevicePool::thread_stream()), "Plaintext copy");
+        return *this;
+    }
+    void Plaintext::resize(size_t coeff_count, hipStream_t stream)
+    {
+        if (level_)
+            throw std::logic_error("cannot resize an NTT transformed Plaintext"); // plaintext.h:274-277
+        if (coeff_count > capacity_words_)
+        {
+            uint64_t *nd = DevicePool::global().alloc_words(coeff_count);
+            if (coeff_count_)
+                ck(hipMemcpyAsync(nd, data_, coeff_count_ * 8, hipMemcpyDeviceToDevice, stream), "Plaintext resize copy");
+            DevicePool::global().free_words(data_);
+            data_ = nd;
+            capacity_words_ = coeff_count;
+        }
+        if (coeff_count > coeff_count_)
+            ck(hipMemsetAsync(data_ + coeff_count_, 0, (coeff_count - coeff_count_) * 8, stream), "Plaintext resize zero");
+        coeff_count_ = coeff_count;
+    }
+    void Plaintext::set(const uint64_t *words, size_t count, bool from_device)
+    {
+        level_ = nullptr;
+        coeff_count_ = 0;
+        resize(count, nullptr);
+        if (count && from_device)
+            ck(hipMemcpy(data_, words, count * 8, hipMemcpyDeviceToDevice), "Plaintext set");
+        else if (count)
+        {
+            ck(hipDeviceSynchronize(), "Plaintext set");
+            copy_h2d(data_, words, count * 8);
+        }
+    }
+    void Plaintext::adopt(uint64_t *slab, size_t count, size_t capacity_words)
+    {
+        DevicePool::global().free_words(data_);
+        data_ = slab;
+        coeff_count_ = count;
+        capacity_words_ = capacity_words;
+    }
+
+    // ---------------------------------------------------------------- KSwitchKeys
+    KSwitchKeys::~KSwitchKeys()
+    {
+        for (auto &k : keys_)
+            if (k.dev)
+                (void)hipFree(k.dev);
+    }
+    void KSwitchKeys::clear()
+    {
+        for (auto &k : keys_)
+            if (k.dev)
+                (void)hipFree(k.dev); // synchronises with the device: no queued key switch still reads it
+        keys_.clear();
+    }
+    size_t KSwitchKeys::size() const
+    {
+        size_t c = 0;
+        for (auto &k : keys_)
+            c += k.dev != nullptr;
+        return c;
+    }
+    void KSwitchKeys::set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device, size_t digit0)
+    {
+        if (!words)
+            throw std::invalid_argument("empty key");
+        const size_t bytes = digits * 2 * ctx.key_level().K * ctx.n() * 8;
+        set_key_with(
+            ctx, index, digits,
+            [&](uint64_t *dst) {
+                if (from_device)
+                    ck(hipMemcpy(dst, words, bytes, hipMemcpyDeviceToDevice), "upload key");
+                else
+                    copy_h2d(dst, words, bytes);
+            },
+            digit0);
+    }
+    void KSwitchKeys::set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0)
+    {
+        if (!ctx.using_keyswitching())
+            throw std::logic_error("keyswitching is not supported by the context");
+        if (ctx_ && ctx_ != &ctx)
+            throw std::invalid_argument("kswitch_keys belongs to another context");
+        if (digits == 0)
+            throw std::invalid_argument("empty key");
+        ctx_ = &ctx;
+        if (index >= keys_.size())
+            keys_.resize(index + 1);
+        size_t L = ctx.key_level().K;
+        size_t bytes = digits * 2 * L * ctx.n() * 8;
+        if (keys_[index].dev)
+            (void)hipFree(keys_[index].dev);
+        void *p = nullptr;
+        const bool reorder = ntt2_supports(ctx.log_n()) && !shl_ab_getenv("SEALHIP_OLD_KS");
+        // register order carries a second plane: the Shoup quotients of the integer back end's components
+        const size_t plane_words = bytes / 8;
+        ck(hipMalloc(&p, reorder ? key_register_order_words(ctx.log_n(), (unsigned)L, digits * 2) * 8 : bytes), "hipMalloc key");
+        if (reorder)
+        {
+            // upload to a staging block, then lay the key out for the fused kernel
+            Scratch stage(bytes / 8);
+            upload(stage.p);
+            ck(key_to_register_order(ctx.ntt_tables(), stage.p, (uint64_t *)p, (unsigned)L, digits * 2, nullptr), "key layout");
+            ck(hipDeviceSynchronize(), "key layout sync");
+        }
+        else
+            upload((uint64_t *)p);
+        keys_[index].dev = (uint64_t *)p;
+        keys_[index].digits = digits;
+        keys_[index].digit0 = digit0;
+        keys_[index].register_order = reorder;
+        keys_[index].quot_off = reorder ? plane_words : 0;
+    }
+
+} // namespace sealhip

@@ -1,6 +1,6 @@
 // The reference's wire format for the two objects that enter and leave the hot path — seal::Ciphertext and
 // seal::KSwitchKeys (RelinKeys / GaloisKeys) — parsed straight into the word layout the device slabs use
-// (SURVEY 8(f) N4).  Host side only; the C ABI (capi.cpp: Ciphertext_Load / _UnsafeLoad / _Save / _SaveSize,
+// (SURVEY 8(f) N4).  Host side only; the C ABI (capi_core.cpp: Ciphertext_Load / _UnsafeLoad / _Save / _SaveSize,
 // KSwitchKeys_Load / _UnsafeLoad) uploads the images.
 //
 // Format (all little-endian; every object is framed by a 16-byte SEALHeader whose `size` counts the header):
