@@ -509,8 +509,11 @@ namespace sealhip
         // accumulator stay below 7.2 q)
         // Integer back end: ICLS = modulus class, BIN = bound of the loaded values in units of q (kP1Out<ICLS, D1> for an
         // intermediate written by p1_tile); they leave below IntBounds<ICLS>::fwd_after(BIN, 8) q.
+        // TWB3_LDS (integer ks2, round 3): the eight per-thread twiddles of the LAST stage are read from twb[g * 256 + tid] (staged
+        // once per workgroup by the caller: they are the same for every digit and batch item), the seven of the stages before it
+        // from global memory where they are used
         template <bool FP, int D1, bool TW_LDS, bool LOWREG = false, bool HOIST = false, bool TWA_LDS = false, bool LEAN = false, int ICLS = 0,
-                  int BIN = 4>
+                  int BIN = 4, bool TWB3_LDS = false>
         __device__ __forceinline__ void p2_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const typename Field<FP>::tw_t *twa, const typename Field<FP>::tw_t *twb, uint64_t *lds_wave, unsigned hg, unsigned tid,
@@ -570,6 +573,12 @@ namespace sealhip
                     phase_fwd_fix<FP, 4, 2>(x, m, twf);
                 else
                     phase_fwd_end<FP, 4, true, ICLS, BMID>(x, m, twf);
+            }
+            else if constexpr (LOWREG && TWB3_LDS)
+            {
+                phase_fwd_end<FP, 4, !LEAN, ICLS, BMID>(x, m, [&](int t, int g) {
+                    return t == 3 ? twb[g * 256 + tid] : tab[(1u << (D1 + 4 + t)) + ((h * 16 + v) << t) + g];
+                });
             }
             else if constexpr (LOWREG)
             {
@@ -1717,6 +1726,9 @@ namespace sealhip
             NttTables tb;
         };
 
+#ifndef SEALHIP_KS2_INT_TWB3
+#define SEALHIP_KS2_INT_TWB3 1
+#endif
         template <bool FP, int D1, int ICLS = 0>
         __device__ __forceinline__ void ks2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg,
                                                  unsigned j0, unsigned j1, uint64_t *acc_part)
@@ -1740,6 +1752,14 @@ namespace sealhip
                     la[tid] = tab[(1u << (D1 + t)) + ((hg * 16) << t) + r];
                 }
                 twa = la;
+#if SEALHIP_KS2_INT_TWB3
+                // ... and the last stage's eight per-thread pairs (32 KiB: two workgroups per CU still fit): the same for every digit
+                typename F::tw_t *lb = la + 240;
+#pragma unroll
+                for (int g = 0; g < 8; g++)
+                    lb[g * 256 + tid] = tab[(1u << (D1 + 7)) + ((hg * 256 + tid) << 3) + g];
+                twb = lb;
+#endif
                 __syncthreads();
             }
             if constexpr (FP)
@@ -1860,7 +1880,7 @@ namespace sealhip
                 }
                 if (!is_diag)
                 {
-                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1>, ICLS, kP1Out<ICLS, D1>>(x, m, tab, twa, twb, lds_wave, hg, tid);
+                    p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1>, ICLS, kP1Out<ICLS, D1>, !FP && SEALHIP_KS2_INT_TWB3>(x, m, tab, twa, twb, lds_wave, hg, tid);
                     // integer back end: the Shoup product takes any 64-bit x (the transform's results are below kP2Out q); the
                     // guarded class (moduli of 2^60 and above: never a key-switch target, kept for completeness) works in [0, 2q)
                 }
@@ -1939,7 +1959,10 @@ namespace sealhip
 
         // CLS: 0 integer-back-end targets only, 1 double-precision targets only
         template <int D1, int CLS>
-        __global__ void __launch_bounds__(kThreads, 2) ks2_kernel(Ks2Args a)
+#ifndef SEALHIP_KS2_INT_WAVES
+#define SEALHIP_KS2_INT_WAVES 2
+#endif
+        __global__ void __launch_bounds__(kThreads, CLS == 0 ? SEALHIP_KS2_INT_WAVES : 2) ks2_kernel(Ks2Args a)
         {
             typedef Geo<D1> G;
             HIP_DYNAMIC_SHARED(uint64_t, lds)
@@ -2302,6 +2325,17 @@ namespace sealhip
             const unsigned groups = vbatch * G::TILES;
             const unsigned n_fp = a1.ntargets - n_int;
             const size_t l2_fp = kLds2Words * 8 + (240 + 3840) * sizeof(double); // the tile's twiddles staged in LDS
+            const size_t l2_int = kLds2Words * 8 + (240 + (SEALHIP_KS2_INT_TWB3 ? 2048 : 0)) * sizeof(ShoupOp);
+            if (n_int && l2_int > 65536)
+            {
+                static bool raised_int = false;
+                if (!raised_int)
+                {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void *>(&ks2_kernel<D1, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2_int) != hipSuccess)
+                        return hipErrorInvalidValue;
+                    raised_int = true;
+                }
+            }
             if (n_fp && l2_fp > 65536)
             {
                 // more than the default 64 KiB of dynamic LDS per workgroup (gfx950 has 160 KiB per CU)
@@ -2336,7 +2370,7 @@ namespace sealhip
                 if (fp)
                     hipLaunchKernelGGL((ks2_kernel<D1, 1>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), l2_fp, st, c2);
                 else
-                    hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), kLds2Words * 8 + 240 * sizeof(ShoupOp), st, c2);
+                    hipLaunchKernelGGL((ks2_kernel<D1, 0>), dim3(((ntile + 7) / 8) * vbatch * 8), dim3(kThreads), l2_int, st, c2);
                 return hipGetLastError();
             };
             // The integer-back-end targets (60-bit moduli) are latency-bound at two waves per SIMD, the

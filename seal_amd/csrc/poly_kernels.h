@@ -101,7 +101,7 @@ namespace sealhip
         unsigned L, unsigned batch, unsigned j0, unsigned j1, unsigned key_digit0, hipStream_t s);
     // acc <- acc mod q_I in place after partial sums of several ranks were added (each canonical, at most 8 of them)
     hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts = 1);
-    // Reduce-scatter exchange of the digit-parallel key switch (evaluator.cpp: switch_key_exchange_*).  The K data
+    // Reduce-scatter exchange of the digit-parallel key switch (evaluator_keyswitch.cpp: switch_key_exchange_*).  The K data
     // moduli are owned by the G ranks in contiguous ranges whose sizes differ by at most one (rank c: K/G (+1 for c < K%G)
     // moduli); m = ceil(K / G) slots per rank.
     //   pack_targets : send[c][s][b][k][N] = acc[b][k][first(c)+s] (zero padding), sp[b][k][N] = acc[b][k][K] (special prime)
