@@ -89,10 +89,27 @@ namespace sealhip
         // scalar instructions (free for the vector unit); y = y1 2^32 + y0 < 2^61 then gives six products below 2^53 that go to
         // six 64-bit column sums (weights 2^0, 2^21, 2^42 for y0 and 2^32, 2^53, 2^74 for y1) by six v_mad_u64_u32 - no
         // carry, no register pair to build - and 64 terms stay below 2^59.  The columns are added up once per dot product.
+        // (hi 2^64 + lo) mod p without the 128 x 128 -> 256 product of Barrett's reduction (79 instructions as compiled): the high word is
+        // folded in by a Shoup product with 2^64 mod p (field.h: mul_lazy4, any 64-bit operand, result below 4p), the low word by
+        // one with 1 (quotient operand floor(2^64 / p) = the high word of the Barrett ratio), and the sum - below 8p < 2^64 - is made
+        // canonical by the reciprocal estimate of canon_any: 12 + 12 + 1 + 12 instructions
+        __device__ __forceinline__ uint64_t fold128(uint64_t lo, uint64_t hi, const ModDesc &md, const ShoupOp *two64)
+        {
+            typedef Field<false> F;
+            const F::Mod m = F::make_mod(md, FpDesc{});
+            const ShoupOp c = ld_shoup(two64);
+            ShoupOpU c64, one;
+            c64.w = c.w;
+            c64.wq = c.wq;
+            one.w = 1;
+            one.wq = md.ratio_hi;
+            const uint64_t u = F::mul_lazy4(hi, c64, m), v = F::mul_lazy4(lo, one, m);
+            return F::canon_any<false>(u + v, m);
+        }
         // extra_y * extra_r (both below 2^61) is one more term of the sum when extra_r != 0 (wave-uniform)
         template <unsigned KM>
-        __device__ __forceinline__ uint64_t dot_reg(const uint64_t (&y)[KM], uconst_ptr row, unsigned count, const ModDesc &m, uint64_t extra_y = 0,
-                                                    uint64_t extra_r = 0)
+        __device__ __forceinline__ uint64_t dot_reg(const uint64_t (&y)[KM], uconst_ptr row, unsigned count, const ModDesc &m, const ShoupOp *two64,
+                                                    uint64_t extra_y = 0, uint64_t extra_r = 0)
         {
             static_assert(KM <= 128, "six column sums of terms below 2^53: 129 of them stay below 2^60");
             uint64_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
@@ -123,7 +140,7 @@ namespace sealhip
                 }
             typedef unsigned __int128 u128;
             const u128 t = (u128)a0 + ((u128)a1 << 21) + ((u128)a2 << 42) + ((u128)b0 << 32) + ((u128)b1 << 53) + ((u128)b2 << 74);
-            return barrett128((uint64_t)t, (uint64_t)(t >> 64), m);
+            return fold128((uint64_t)t, (uint64_t)(t >> 64), m, two64);
         }
 
         // ---- stage 0: q -> Bsk U {m~}   (fastbconv_m_tilde)
@@ -279,7 +296,7 @@ namespace sealhip
                     uint64_t tmp = r;
                     if (tmp >= (mt >> 1))
                         tmp += md.q - mt;
-                    op[jj * N + j] = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_lift + jj * K), K, md, tmp, ld_u64(&lv.prod_q_lift[jj]));
+                    op[jj * N + j] = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_lift + jj * K), K, md, &lv.two64_bsk[jj], tmp, ld_u64(&lv.prod_q_lift[jj]));
                 }
             }
         }
@@ -321,7 +338,7 @@ namespace sealhip
                     // the matrix row and t carry those constants (LevelDev), one Shoup product and one exact sum remain.  f[jj]
                     // is therefore step (8)'s input vector for jj < nB and the floor value itself for m_sk (jj = nB)
                     const ModDesc md = ld_mod(&mods[ld_u32(&lv.bsk_prime[jj])]);
-                    const uint64_t conv = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_floor + jj * K), K, md);
+                    const uint64_t conv = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_floor + jj * K), K, md, &lv.two64_bsk[jj]);
                     const ShoupOp tm = ld_shoup(&lv.t_floor_bsk[jj]);
                     const uint64_t zb = mul_shoup(bp[jj * N + j], tm.w, tm.wq, md.q);
                     f[jj * kBlock + threadIdx.x] = csub(zb + (md.q - conv), md.q);
@@ -335,22 +352,18 @@ namespace sealhip
                         y[i] = f[i * kBlock + threadIdx.x];
                 }
                 const ModDesc msk = ld_mod(&mods[lv.msk_prime]);
-                uint64_t conv_sk = dot_reg<KM>(y, SHL_UCONST(lv.b_to_msk), nB, msk);
+                uint64_t conv_sk = dot_reg<KM>(y, SHL_UCONST(lv.b_to_msk), nB, msk, &lv.two64_bsk[nB]);
                 uint64_t alpha = mul_shoup(
                     conv_sk + (msk.q - f[nB * kBlock + threadIdx.x]), lv.inv_prod_b_mod_msk.w, lv.inv_prod_b_mod_msk.wq, msk.q);
                 const bool negative = alpha > (msk.q >> 1);
                 const uint64_t mag = negative ? msk.q - alpha : alpha;
                 for (unsigned i = 0; i < K; i++)
                 {
+                    // conv +/- |alpha| B mod q_i (rns.cpp:962-975) as ONE exact sum: |alpha| B is one more term of the dot product, with
+                    // -|alpha| written as the non-negative (multiple of q_i above 2^60) - |alpha|   (|alpha| <= m_sk / 2 < 2^60)
                     const ModDesc md = ld_mod(&mods[i]);
-                    uint64_t g = dot_reg<KM>(y, SHL_UCONST(lv.b_to_q + i * nB), nB, md);
-                    uint64_t pb = ld_u64(&lv.prod_b_mod_q[i]);
-                    uint64_t factor = negative ? pb : md.q - pb;
-                    uint64_t lo, hi;
-                    mul_wide4(mag, factor, lo, hi);
-                    lo += g;
-                    hi += lo < g;
-                    op[i * N + j] = barrett128(lo, hi, md);
+                    const uint64_t ey = negative ? mag : ld_u64(&lv.neg_base_q[i]) - mag;
+                    op[i * N + j] = dot_reg<KM>(y, SHL_UCONST(lv.b_to_q + i * nB), nB, md, &lv.two64_q[i], ey, ld_u64(&lv.prod_b_mod_q[i]));
                 }
             }
         }

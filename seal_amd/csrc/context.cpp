@@ -323,7 +323,7 @@ namespace sealhip
             size_t inv_q_last = 0, round_fix = 0, half_mod_q = 0, q_last_mod_q = 0, delta_mod_q = 0, upper_half_inc = 0, bsk_prime = 0, inv_punct_q = 0, m_tilde_mod_q = 0, q_to_bsk = 0, q_to_mtilde = 0,
                    prod_q_mod_bsk = 0, inv_mtilde_mod_bsk = 0, inv_prod_q_mod_bsk = 0, inv_punct_b = 0, b_to_q = 0,
                    b_to_msk = 0, prod_b_mod_q = 0, t_mod_q = 0, t_mod_bsk = 0, mt_inv_punct_q = 0, q_to_bsk_lift = 0, prod_q_lift = 0,
-                   t_inv_punct_q = 0, q_to_bsk_floor = 0, t_floor_bsk = 0, dec_inv_punct_q = 0, dec_q_to_t = 0, dec_prod_t_gamma = 0,
+                   t_inv_punct_q = 0, q_to_bsk_floor = 0, t_floor_bsk = 0, two64_bsk = 0, two64_q = 0, neg_base_q = 0, dec_inv_punct_q = 0, dec_q_to_t = 0, dec_prod_t_gamma = 0,
                    dec_q_to_gamma = 0;
         } off;
 
@@ -505,6 +505,18 @@ namespace sealhip
             off.t_inv_punct_q = blk.put(t_ipq);
             off.q_to_bsk_floor = blk.put(floor_m);
             off.t_floor_bsk = blk.put(t_floor);
+            std::vector<ShoupOp> two64_b, two64_qv;
+            const auto two64 = [](uint64_t p) { return make_shoup((uint64_t)((((unsigned __int128)1) << 64) % p), p); };
+            for (size_t j = 0; j < Bsk.size(); j++)
+                two64_b.push_back(two64(Bsk[j]));
+            for (unsigned i = 0; i < K; i++)
+                two64_qv.push_back(two64(q[i]));
+            off.two64_bsk = blk.put(two64_b);
+            off.two64_q = blk.put(two64_qv);
+            std::vector<uint64_t> neg_base;
+            for (unsigned i = 0; i < K; i++)
+                neg_base.push_back(q[i] * ((((uint64_t)1 << 60) + q[i] - 1) / q[i])); // below 2^60 + q_i <= 2^61
+            off.neg_base_q = blk.put(neg_base);
         }
 
         uint64_t *d = nullptr;
@@ -549,6 +561,9 @@ namespace sealhip
             lvl.dev.t_inv_punct_q = reinterpret_cast<const ShoupOp *>(d + off.t_inv_punct_q);
             lvl.dev.q_to_bsk_floor = d + off.q_to_bsk_floor;
             lvl.dev.t_floor_bsk = reinterpret_cast<const ShoupOp *>(d + off.t_floor_bsk);
+            lvl.dev.two64_bsk = reinterpret_cast<const ShoupOp *>(d + off.two64_bsk);
+            lvl.dev.two64_q = reinterpret_cast<const ShoupOp *>(d + off.two64_q);
+            lvl.dev.neg_base_q = d + off.neg_base_q;
         }
     }
 } // namespace sealhip

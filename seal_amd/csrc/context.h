@@ -88,6 +88,10 @@ namespace sealhip
         const ShoupOp *t_inv_punct_q = nullptr;    // [K]     t (Q/q_i)^-1 mod q_i                          (floor)
         const uint64_t *q_to_bsk_floor = nullptr;  // [nBsk][K]   (Q/q_i) Q^-1 [(B/b_j)^-1, j < nB] mod p_j (floor)
         const ShoupOp *t_floor_bsk = nullptr;      // [nBsk]      t Q^-1 [(B/b_j)^-1, j < nB] mod p_j       (floor)
+        // 2^64 mod p as a Shoup operand: folds the high word of a 128-bit dot product into the low one (behz_kernels.hip)
+        const ShoupOp *two64_bsk = nullptr;        // [nBsk]
+        const ShoupOp *two64_q = nullptr;          // [K]
+        const uint64_t *neg_base_q = nullptr;      // [K] the multiple of q_i just above 2^60: (neg_base - x) is -x mod q_i, non-negative, for x <= 2^60
         ShoupOp inv_prod_b_mod_msk{ 0, 0 };
         uint64_t neg_inv_prod_q_mod_mtilde = 0;
         uint64_t m_tilde = 0;
