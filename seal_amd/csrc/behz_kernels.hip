@@ -112,6 +112,8 @@ namespace sealhip
                                                     uint64_t extra_y = 0, uint64_t extra_r = 0)
         {
             static_assert(KM <= 128, "six column sums of terms below 2^53: 129 of them stay below 2^60");
+            // row: the matrix entries cut into their three 21-bit limbs at context build (context.cpp: split21), two words per entry
+            // {limb0 | limb1 << 32, limb2} - cutting them here cost as many scalar instructions as the products cost vector ones
             uint64_t a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
             if (extra_r)
             {
@@ -128,8 +130,8 @@ namespace sealhip
             for (unsigned i = 0; i < KM; i++)
                 if (i < count)
                 {
-                    const uint64_t r = row[i];
-                    const uint32_t ra = (uint32_t)r & 0x1FFFFFu, rb = (uint32_t)(r >> 21) & 0x1FFFFFu, rc = (uint32_t)(r >> 42);
+                    const uint64_t r01 = row[2 * i], r2 = row[2 * i + 1];
+                    const uint32_t ra = (uint32_t)r01, rb = (uint32_t)(r01 >> 32), rc = (uint32_t)r2;
                     const uint32_t y0 = (uint32_t)y[i], y1 = (uint32_t)(y[i] >> 32);
                     a0 = mad_uniform(y0, ra, a0);
                     a1 = mad_uniform(y0, rb, a1);
@@ -296,7 +298,7 @@ namespace sealhip
                     uint64_t tmp = r;
                     if (tmp >= (mt >> 1))
                         tmp += md.q - mt;
-                    op[jj * N + j] = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_lift + jj * K), K, md, &lv.two64_bsk[jj], tmp, ld_u64(&lv.prod_q_lift[jj]));
+                    op[jj * N + j] = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_lift + 2 * jj * K), K, md, &lv.two64_bsk[jj], tmp, ld_u64(&lv.prod_q_lift[jj]));
                 }
             }
         }
@@ -338,7 +340,7 @@ namespace sealhip
                     // the matrix row and t carry those constants (LevelDev), one Shoup product and one exact sum remain.  f[jj]
                     // is therefore step (8)'s input vector for jj < nB and the floor value itself for m_sk (jj = nB)
                     const ModDesc md = ld_mod(&mods[ld_u32(&lv.bsk_prime[jj])]);
-                    const uint64_t conv = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_floor + jj * K), K, md, &lv.two64_bsk[jj]);
+                    const uint64_t conv = dot_reg<KM>(y, SHL_UCONST(lv.q_to_bsk_floor + 2 * jj * K), K, md, &lv.two64_bsk[jj]);
                     const ShoupOp tm = ld_shoup(&lv.t_floor_bsk[jj]);
                     const uint64_t zb = mul_shoup(bp[jj * N + j], tm.w, tm.wq, md.q);
                     f[jj * kBlock + threadIdx.x] = csub(zb + (md.q - conv), md.q);
@@ -352,7 +354,7 @@ namespace sealhip
                         y[i] = f[i * kBlock + threadIdx.x];
                 }
                 const ModDesc msk = ld_mod(&mods[lv.msk_prime]);
-                uint64_t conv_sk = dot_reg<KM>(y, SHL_UCONST(lv.b_to_msk), nB, msk, &lv.two64_bsk[nB]);
+                uint64_t conv_sk = dot_reg<KM>(y, SHL_UCONST(lv.b_to_msk3), nB, msk, &lv.two64_bsk[nB]);
                 uint64_t alpha = mul_shoup(
                     conv_sk + (msk.q - f[nB * kBlock + threadIdx.x]), lv.inv_prod_b_mod_msk.w, lv.inv_prod_b_mod_msk.wq, msk.q);
                 const bool negative = alpha > (msk.q >> 1);
@@ -363,7 +365,7 @@ namespace sealhip
                     // -|alpha| written as the non-negative (multiple of q_i above 2^60) - |alpha|   (|alpha| <= m_sk / 2 < 2^60)
                     const ModDesc md = ld_mod(&mods[i]);
                     const uint64_t ey = negative ? mag : ld_u64(&lv.neg_base_q[i]) - mag;
-                    op[i * N + j] = dot_reg<KM>(y, SHL_UCONST(lv.b_to_q + i * nB), nB, md, &lv.two64_q[i], ey, ld_u64(&lv.prod_b_mod_q[i]));
+                    op[i * N + j] = dot_reg<KM>(y, SHL_UCONST(lv.b_to_q3 + 2 * i * nB), nB, md, &lv.two64_q[i], ey, ld_u64(&lv.prod_b_mod_q[i]));
                 }
             }
         }

@@ -323,7 +323,7 @@ namespace sealhip
             size_t inv_q_last = 0, round_fix = 0, half_mod_q = 0, q_last_mod_q = 0, delta_mod_q = 0, upper_half_inc = 0, bsk_prime = 0, inv_punct_q = 0, m_tilde_mod_q = 0, q_to_bsk = 0, q_to_mtilde = 0,
                    prod_q_mod_bsk = 0, inv_mtilde_mod_bsk = 0, inv_prod_q_mod_bsk = 0, inv_punct_b = 0, b_to_q = 0,
                    b_to_msk = 0, prod_b_mod_q = 0, t_mod_q = 0, t_mod_bsk = 0, mt_inv_punct_q = 0, q_to_bsk_lift = 0, prod_q_lift = 0,
-                   t_inv_punct_q = 0, q_to_bsk_floor = 0, t_floor_bsk = 0, two64_bsk = 0, two64_q = 0, neg_base_q = 0, dec_inv_punct_q = 0, dec_q_to_t = 0, dec_prod_t_gamma = 0,
+                   t_inv_punct_q = 0, q_to_bsk_floor = 0, t_floor_bsk = 0, two64_bsk = 0, two64_q = 0, neg_base_q = 0, b_to_q3 = 0, b_to_msk3 = 0, dec_inv_punct_q = 0, dec_q_to_t = 0, dec_prod_t_gamma = 0,
                    dec_q_to_gamma = 0;
         } off;
 
@@ -499,6 +499,20 @@ namespace sealhip
                 lift_pq.push_back(mulmod(prod_q_mod_bsk[j], im, pj));
                 t_floor.push_back(make_shoup(mulmod(plain_modulus_ % pj, fl, pj), pj));
             }
+            // the matrices the dot products of behz_kernels.hip read, cut into three 21-bit limbs: {limb0 | limb1 << 32, limb2}
+            const auto split21 = [](const std::vector<uint64_t> &v) {
+                std::vector<uint64_t> out;
+                for (uint64_t r : v)
+                {
+                    out.push_back((r & 0x1FFFFFull) | (((r >> 21) & 0x1FFFFFull) << 32));
+                    out.push_back(r >> 42);
+                }
+                return out;
+            };
+            lift_m = split21(lift_m);
+            floor_m = split21(floor_m);
+            off.b_to_q3 = blk.put(split21(b_to_q));
+            off.b_to_msk3 = blk.put(split21(b_to_msk));
             off.mt_inv_punct_q = blk.put(mt_ipq);
             off.q_to_bsk_lift = blk.put(lift_m);
             off.prod_q_lift = blk.put(lift_pq);
@@ -564,6 +578,8 @@ namespace sealhip
             lvl.dev.two64_bsk = reinterpret_cast<const ShoupOp *>(d + off.two64_bsk);
             lvl.dev.two64_q = reinterpret_cast<const ShoupOp *>(d + off.two64_q);
             lvl.dev.neg_base_q = d + off.neg_base_q;
+            lvl.dev.b_to_q3 = d + off.b_to_q3;
+            lvl.dev.b_to_msk3 = d + off.b_to_msk3;
         }
     }
 } // namespace sealhip

@@ -83,14 +83,15 @@ namespace sealhip
         // a constant that is followed by another product by a constant is one product by their product - the residues are the
         // same, the kernels do 30 Shoup products per coefficient instead of 74)
         const ShoupOp *mt_inv_punct_q = nullptr;   // [K]     m~ (Q/q_i)^-1 mod q_i                         (lift)
-        const uint64_t *q_to_bsk_lift = nullptr;   // [nBsk][K]   (Q/q_i) m~^-1 mod p_j                     (lift)
+        const uint64_t *q_to_bsk_lift = nullptr;   // [nBsk][K][2] (Q/q_i) m~^-1 mod p_j, cut into 21-bit limbs      (lift)
         const uint64_t *prod_q_lift = nullptr;     // [nBsk]      Q m~^-1 mod p_j                           (lift)
         const ShoupOp *t_inv_punct_q = nullptr;    // [K]     t (Q/q_i)^-1 mod q_i                          (floor)
-        const uint64_t *q_to_bsk_floor = nullptr;  // [nBsk][K]   (Q/q_i) Q^-1 [(B/b_j)^-1, j < nB] mod p_j (floor)
+        const uint64_t *q_to_bsk_floor = nullptr;  // [nBsk][K][2] (Q/q_i) Q^-1 [(B/b_j)^-1, j < nB] mod p_j, limbs (floor)
         const ShoupOp *t_floor_bsk = nullptr;      // [nBsk]      t Q^-1 [(B/b_j)^-1, j < nB] mod p_j       (floor)
         // 2^64 mod p as a Shoup operand: folds the high word of a 128-bit dot product into the low one (behz_kernels.hip)
         const ShoupOp *two64_bsk = nullptr;        // [nBsk]
         const ShoupOp *two64_q = nullptr;          // [K]
+        const uint64_t *b_to_q3 = nullptr, *b_to_msk3 = nullptr; // b_to_q / b_to_msk cut into 21-bit limbs: two words per entry {limb0 | limb1 << 32, limb2}
         const uint64_t *neg_base_q = nullptr;      // [K] the multiple of q_i just above 2^60: (neg_base - x) is -x mod q_i, non-negative, for x <= 2^60
         ShoupOp inv_prod_b_mod_msk{ 0, 0 };
         uint64_t neg_inv_prod_q_mod_mtilde = 0;
