@@ -2116,6 +2116,9 @@ namespace sealhip
             return hipSuccess;
         }
 
+#ifndef SEALHIP_FUSED_FORK14
+#define SEALHIP_FUSED_FORK14 1 // 2^14: the single-launch kernels of the two classes side by side (a CU holds ONE 1024-thread workgroup of either)
+#endif
         // single-launch kernels for the integer back end (N = 2^13, 2^14); SEALHIP_NTT_NOFUSED_INT=1 keeps its two-launch engine (A/B runs)
         inline bool fused_int()
         {
@@ -2208,8 +2211,9 @@ namespace sealhip
                 else
                     hipLaunchKernelGGL((ntt2_fwd_p2<D1, 2>), grid, dim3(kThreads), kLds2Words * 8, st, g);
                 return hipGetLastError();
-            }, !(fused && fused_int()));
-            // single-launch kernels of both classes: one after the other.  Side by side a CU holds one workgroup of each (LDS), and
+            }, !(fused && fused_int()) || (D1 == 6 && SEALHIP_FUSED_FORK14));
+            // single-launch kernels of both classes at 2^13: one after the other (at 2^14 a CU holds ONE 1024-thread workgroup of either class,
+            // side by side costs nothing and the mixed chain {60,6x50,60} runs at 0.32 / 0.34 instead of 0.29 / 0.29).  Side by side at 2^13 a CU holds one workgroup of each (LDS), and
             // each class loses the partner workgroup that covers its latencies: measured at configs[1]'s chain {60,40,40,60}, 8192
             // polynomials: 2.83 / 3.02 TB/s forked, 2.97 / 3.12 in sequence (profiles/r03_configs1_chain.txt)
         }
@@ -2311,7 +2315,7 @@ namespace sealhip
                 else
                     hipLaunchKernelGGL((ntt2_inv_pb<D1, 2>), grid, dim3(kThreads), G::lds1_words * 8, st, g);
                 return hipGetLastError();
-            }, !(fused && fused_int()));
+            }, !(fused && fused_int()) || (D1 == 6 && SEALHIP_FUSED_FORK14));
         }
 
         template <int D1>
