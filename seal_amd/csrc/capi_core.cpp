@@ -395,11 +395,12 @@ extern "C"
     {
         IfNullRet(thisptr, SHL_E_POINTER);
         IfNullRet(data, SHL_E_POINTER);
+        SHL_TRY // data() completes a pending key-switch tail: kernel launches, a pool allocation - it can throw
         auto ct = as<Ciphertext>(thisptr);
         *data = ct->data();
         if (word_count)
             *word_count = ct->word_count();
-        return SHL_S_OK;
+        SHL_CATCH
     }
     SHL_FUNC Ciphertext_CopyFromHost(void *thisptr, const uint64_t *src, uint64_t word_count)
     {

@@ -92,6 +92,20 @@ namespace sealhip
         }
         catch (...)
         {
+            // a tail could not be completed (device error): no ciphertext may keep a LazyTail whose owner is gone - the pending
+            // sums are discarded, the objects stay what they were before their key switch's mod-down (their next use is still
+            // memory-safe; the device error itself is what the caller sees on its next call)
+            for (;;)
+            {
+                const Ciphertext *c = nullptr;
+                {
+                    std::lock_guard<std::mutex> lock(lazy_mu_);
+                    if (lazy_cts_.empty())
+                        break;
+                    c = lazy_cts_.back();
+                }
+                const_cast<Ciphertext *>(c)->drop_lazy(); // removes it from the list
+            }
         }
         for (auto &kv : ks_maps_)
             (void)hipFree(kv.second);

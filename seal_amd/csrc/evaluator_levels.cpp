@@ -37,7 +37,10 @@ namespace sealhip
             }
             catch (...)
             {
+                // the folded pass works in place on e's planes: after a failure they are neither the old nor the new ciphertext.
+                // Leave an EMPTY object behind (size 0: every later use is rejected) rather than words that look valid
                 DevicePool::global().free_words(t.acc, stream_);
+                e.release();
                 throw;
             }
             DevicePool::global().free_words(t.acc, stream_);
