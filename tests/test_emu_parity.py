@@ -2,6 +2,8 @@
 arithmetic, exercised by running the SAME kernel sources under the fiber emulator (tests/hipemu) at
 small sizes and checking them against the oracle.  This proves nothing about the GPU build — the
 `-m gpu` tests do that — but it lets the host side and every index formula be tested without a GPU."""
+import os
+
 import numpy as np
 import pytest
 
@@ -43,6 +45,22 @@ def test_ntt_two_pass_engine_integer_only(emu, monkeypatch):
     """SEALHIP_NO_FP=1: the same primes on the 64-bit integer back end give the same words."""
     monkeypatch.setenv("SEALHIP_NO_FP", "1")
     P.case_ntt(8192, [50, 30, 60], polys=1)
+
+
+def test_pipelines_integer_only_in_a_subprocess():
+    """SEALHIP_NO_FP=1 (read when the context is built): every prime on the integer back end, so the key switch runs its Shoup-key
+    sums for primes of 30 to 60 bits (both modulus classes, `hi32` estimates on and off) - CKKS and BFV pipelines, bit-exact"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import seal_amd as S; S.load(%r); import parity_cases as P\n"
+            "from oracle import coeff_modulus_create, plain_modulus_batching\n"
+            "P.case_ckks_pipeline(8192, [50, 30, 40, 60], batch=1, steps=(1,))\n"
+            "P.case_ckks_pipeline(8192, [36, 30, 33, 40], batch=2, steps=(-1,))\n"
+            "P.case_bfv_pipeline(8192, coeff_modulus_create(8192, [50, 55, 56]), plain_modulus_batching(8192, 20), batch=1)\n"
+            "print('integer-only ok')\n" % (here, os.path.dirname(here), os.path.join(here, "hipemu", "libsealhip_emu.so")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SEALHIP_NO_FP="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "integer-only ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_ntt_two_pass_engine_mixed_kernel(emu, monkeypatch):

@@ -10,7 +10,7 @@ for seed in range(int(os.environ.get("FUZZ_SEED0", "100")), int(os.environ.get("
         if cfg[1] >= 32768 and len(cfg[2]) > 4:
             cfg = cfg[:2] + (cfg[2][:4],) + cfg[3:]
         try:
-            F.run_sequence(*cfg); ok += 1
+            F.run_sequence(*cfg, wild_prob=float(os.environ.get("FUZZ_WILD", "0"))); ok += 1
         except sealref.RefError:
             rej += 1
         except Exception as e:
