@@ -139,8 +139,6 @@ namespace sealhip
             (void)hipFree(d_ninv_);
         if (d_fpd_)
             (void)hipFree(d_fpd_);
-        if (d_int_rank_)
-            (void)hipFree(d_int_rank_);
         if (d_fwd_d_)
             (void)hipFree(d_fwd_d_);
         if (d_inv_d_)
@@ -297,23 +295,6 @@ namespace sealhip
         for (size_t p = 0; p < np; p++)
             h_fp_flag_[p] = h_fpd_[p].qi != 0;
         tables_.fp_host = h_fp_flag_.data();
-        {
-            std::vector<uint32_t> rank(np);
-            uint32_t r = 0;
-            for (size_t p = 0; p < np; p++)
-            {
-                rank[p] = r;
-                if (!h_fp_flag_[p])
-                {
-                    r++;
-                    if (p < primes_.size())
-                        key_int_count_++;
-                }
-            }
-            check_hip(hipMalloc(&d_int_rank_, np * sizeof(uint32_t)), "hipMalloc int_rank");
-            check_hip(hipMemcpy(d_int_rank_, rank.data(), np * sizeof(uint32_t), hipMemcpyHostToDevice), "upload int_rank");
-            tables_.int_rank = d_int_rank_;
-        }
         tables_.fwd_d = d_fwd_d_;
         tables_.inv_d = d_inv_d_;
         tables_.ninv_d = d_ninv_d_;

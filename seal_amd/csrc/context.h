@@ -146,7 +146,6 @@ namespace sealhip
         // SEALContext::ContextData::plain_ntt_tables() (context.cpp:415-425 of the reference); -1 otherwise
         int plain_prime_index() const { return plain_prime_; }
         const NttTables &ntt_tables() const { return tables_; }
-        unsigned key_int_count() const { return key_int_count_; }
         const ModDesc *dev_mods() const { return d_mods_; }
         // host copies (tests / introspection)
         uint64_t ntt_root(unsigned pool_index) const { return roots_[pool_index]; }
@@ -182,8 +181,6 @@ namespace sealhip
         double *d_fwd_d_ = nullptr, *d_inv_d_ = nullptr, *d_ninv_d_ = nullptr;
         std::vector<FpDesc> h_fpd_;
         std::vector<unsigned char> h_fp_flag_;
-        uint32_t *d_int_rank_ = nullptr;
-        unsigned key_int_count_ = 0; // integer-back-end primes among the key level's (all of coeff_modulus)
         NttTables tables_{};
     };
 } // namespace sealhip

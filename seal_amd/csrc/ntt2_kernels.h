@@ -28,8 +28,7 @@ namespace sealhip
         const uint64_t *t;
         const uint64_t *target_ntt;
         const uint64_t *key;
-        size_t key_quot_off; // words from the key to its quotient plane [digits][2][key_n_int][N] (key_to_register_order)
-        unsigned key_n_int;  // integer-back-end components of the key level
+        size_t key_quot_off; // words from a key word to its Shoup quotient (integer-back-end components; key_register_order_words)
         uint64_t *mid; // [batch][K+1][K][N] scratch
         uint64_t *acc; // [batch][2][K+1][N]
         const uint32_t *targets1, *targets2;
@@ -49,12 +48,10 @@ namespace sealhip
     // end; for the integer back end's primes the words themselves and, polys * L * N words further on, floor(word * 2^64 / q):
     // the key is the precomputed operand of a Shoup product (round 3: the sums of ks2 then fit 64-bit words).  `out` holds
     // key_register_order_words(...) words.
-    // n_int = integer-back-end primes among the key level's L (Context::key_int_count): their quotients follow the words as
-    // [polys][n_int][N], component NttTables::int_rank[prime]
     hipError_t key_to_register_order(
-        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, unsigned n_int, size_t polys, hipStream_t stream);
-    inline size_t key_register_order_words(int log_n, unsigned L, unsigned n_int, size_t polys)
+        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream);
+    inline size_t key_register_order_words(int log_n, unsigned L, size_t polys)
     {
-        return (polys * (L + n_int)) << log_n;
+        return 2 * ((polys * L) << log_n);
     }
 } // namespace sealhip

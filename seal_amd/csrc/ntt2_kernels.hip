@@ -1715,8 +1715,7 @@ namespace sealhip
             const uint64_t *mid;     // [batch][K+1][K][N]
             const uint64_t *target;  // [batch][K][N] NTT form (CKKS diagonal shortcut) or null
             const uint64_t *key;     // [digits][2][L][N] register order
-            size_t key_quot_off;     // integer back end: the plane of Shoup quotients [digits][2][key_n_int][N] starts at key + key_quot_off
-            unsigned key_n_int;
+            size_t key_quot_off;     // integer back end: the Shoup quotient of key word w is at w + key_quot_off
             uint64_t *acc;           // [batch][2][K+1][N] natural order, canonical
             const uint32_t *targets; // [ntargets] triples (I, prime, key component)
             unsigned ntargets;
@@ -1896,13 +1895,11 @@ namespace sealhip
                 }
                 else
                 {
-                    // quotients of this digit's two key polynomials: plane [digit][2][key_n_int][N], component int_rank[prime]
-                    const uint64_t *q0 = key + a.key_quot_off + (((size_t)(J - a.key_digit0) * 2 + 0) * a.key_n_int + a.tb.int_rank[prime]) * N + ((size_t)hg << 12) + tid;
-                    const uint64_t *q1 = q0 + (size_t)a.key_n_int * N;
+                    const size_t qo = a.key_quot_off;
 #pragma unroll
                     for (int e = 0; e < 16; e++)
                     {
-                        const ShoupOp w0{ k0[e * 256], q0[e * 256] }, w1{ k1[e * 256], q1[e * 256] };
+                        const ShoupOp w0{ k0[e * 256], k0[e * 256 + qo] }, w1{ k1[e * 256], k1[e * 256 + qo] };
                         if constexpr (ICLS == 2)
                         {
                             acc0[e] = F::guard(acc0[e] + F::mul_lazy(x[e], w0, m), m);
@@ -1993,8 +1990,7 @@ namespace sealhip
 
         // natural order (u64) -> register order, optionally converted to double
         __global__ void __launch_bounds__(kThreads) key_layout_kernel(
-            const uint64_t *in, uint64_t *out, const FpDesc *fpd, const ModDesc *mods, const uint32_t *int_rank, unsigned L, unsigned n_int,
-            unsigned n_log, size_t polys)
+            const uint64_t *in, uint64_t *out, const FpDesc *fpd, const ModDesc *mods, unsigned L, unsigned n_log, size_t polys)
         {
             const size_t N = (size_t)1 << n_log;
             const size_t total = polys * L * N;
@@ -2032,7 +2028,7 @@ namespace sealhip
                         est++;
                     }
                     out[i] = v;
-                    out[total + (((slab / L) * n_int + int_rank[comp]) << n_log) + p] = est;
+                    out[total + i] = est;
                 }
             }
         }
@@ -2542,7 +2538,6 @@ namespace sealhip
         a2.target = k.target_ntt;
         a2.key = k.key;
         a2.key_quot_off = k.key_quot_off;
-        a2.key_n_int = k.key_n_int;
         a2.acc = k.acc;
         a2.targets = k.targets2;
         a2.ntargets = k.ntargets;
@@ -2570,13 +2565,13 @@ namespace sealhip
     }
 
     hipError_t key_to_register_order(
-        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, unsigned n_int, size_t polys, hipStream_t stream)
+        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream)
     {
         size_t total = (polys * L) << t.log_n;
         size_t blocks = (total + kThreads - 1) / kThreads;
         if (blocks > 4096)
             blocks = 4096;
-        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, t.mods, t.int_rank, L, n_int, (unsigned)t.log_n, polys);
+        hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, t.mods, L, (unsigned)t.log_n, polys);
         return hipGetLastError();
     }
 } // namespace sealhip

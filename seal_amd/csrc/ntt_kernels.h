@@ -32,9 +32,6 @@ namespace sealhip
         // HOST copy of "fpd[p].qi != 0" per prime (null = unknown): lets the launcher pick kernels
         // specialised for one back end, which need far fewer registers than the mixed ones
         const unsigned char *fp_host;
-        // rank of prime p among the integer-back-end primes below it (device array; meaningful where fpd[p].qi == 0): the Shoup
-        // quotients of switching keys are stored for those components only, one after the other (key_to_register_order)
-        const uint32_t *int_rank;
         int log_n;
     };
 

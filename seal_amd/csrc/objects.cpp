@@ -270,13 +270,13 @@ namespace sealhip
         const bool reorder = ntt2_supports(ctx.log_n()) && !shl_ab_getenv("SEALHIP_OLD_KS");
         // register order carries a second plane: the Shoup quotients of the integer back end's components
         const size_t plane_words = bytes / 8;
-        ck(hipMalloc(&p, reorder ? key_register_order_words(ctx.log_n(), (unsigned)L, ctx.key_int_count(), digits * 2) * 8 : bytes), "hipMalloc key");
+        ck(hipMalloc(&p, reorder ? key_register_order_words(ctx.log_n(), (unsigned)L, digits * 2) * 8 : bytes), "hipMalloc key");
         if (reorder)
         {
             // upload to a staging block, then lay the key out for the fused kernel
             Scratch stage(bytes / 8);
             upload(stage.p);
-            ck(key_to_register_order(ctx.ntt_tables(), stage.p, (uint64_t *)p, (unsigned)L, ctx.key_int_count(), digits * 2, nullptr), "key layout");
+            ck(key_to_register_order(ctx.ntt_tables(), stage.p, (uint64_t *)p, (unsigned)L, digits * 2, nullptr), "key layout");
             ck(hipDeviceSynchronize(), "key layout sync");
         }
         else
