@@ -146,7 +146,6 @@ namespace sealhip
             // true: every component is stored in the register order of the fused key-switch
             // kernel, as doubles for primes of the double-precision back end (ntt2_kernels.h)
             bool register_order = false;
-            size_t quot_off = 0; // register order: words from a key word to its Shoup quotient (ntt2_kernels.h)
         };
         ~KSwitchKeys();
         // words: `digits` digits starting at digit `digit0` of key `index`, each 2 x L x N words

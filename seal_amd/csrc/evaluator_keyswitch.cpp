@@ -167,7 +167,6 @@ namespace sealhip
             ka.t = digits;
             ka.target_ntt = ntt_target ? target : nullptr; // the I == J shortcut of evaluator.cpp:2682-2685
             ka.key = key.dev;
-            ka.key_quot_off = key.quot_off;
             ka.mid = mid.p;
             ka.acc = acc_out;
             ka.targets1 = kt.dev;

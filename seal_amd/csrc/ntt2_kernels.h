@@ -28,7 +28,6 @@ namespace sealhip
         const uint64_t *t;
         const uint64_t *target_ntt;
         const uint64_t *key;
-        size_t key_quot_off; // words from a key word to its Shoup quotient (integer-back-end components; key_register_order_words)
         uint64_t *mid; // [batch][K+1][K][N] scratch
         uint64_t *acc; // [batch][2][K+1][N]
         const uint32_t *targets1, *targets2;
@@ -44,10 +43,10 @@ namespace sealhip
     };
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);
 
-    // [polys][L][N] natural-order key words -> register order of ks2: doubles (balanced) for primes of the double-precision back
-    // end; for the integer back end's primes the words themselves and, polys * L * N words further on, floor(word * 2^64 / q):
-    // the key is the precomputed operand of a Shoup product (round 3: the sums of ks2 then fit 64-bit words).  `out` holds
-    // key_register_order_words(...) words.
+    // [polys][L][N] natural-order key words -> register order of ks2, 2 N words per component: N balanced doubles for primes of the
+    // double-precision back end (the second half unused); for the integer back end's primes N pairs (word, floor(word * 2^64 / q)):
+    // the key is the precomputed operand of a Shoup product (round 3: the sums of ks2 then fit 64-bit words) and a pair is one
+    // 16-byte load.  `out` holds key_register_order_words(...) words.
     hipError_t key_to_register_order(
         const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream);
     inline size_t key_register_order_words(int log_n, unsigned L, size_t polys)

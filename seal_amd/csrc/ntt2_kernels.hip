@@ -1714,8 +1714,7 @@ namespace sealhip
         {
             const uint64_t *mid;     // [batch][K+1][K][N]
             const uint64_t *target;  // [batch][K][N] NTT form (CKKS diagonal shortcut) or null
-            const uint64_t *key;     // [digits][2][L][N] register order
-            size_t key_quot_off;     // integer back end: the Shoup quotient of key word w is at w + key_quot_off
+            const uint64_t *key;     // [digits][2][L][2N] register order (key_to_register_order)
             uint64_t *acc;           // [batch][2][K+1][N] natural order, canonical
             const uint32_t *targets; // [ntargets] triples (I, prime, key component)
             unsigned ntargets;
@@ -1858,8 +1857,10 @@ namespace sealhip
                     for (int e = 0; e < 16; e++)
                         x[e] = F::unraw(nxt[e]);
                 }
-                const typename F::key_t *k0 = key + (((size_t)(J - a.key_digit0) * 2 + 0) * a.L + kc) * N + ((size_t)hg << 12) + tid;
-                const typename F::key_t *k1 = k0 + (size_t)a.L * N;
+                // every key component owns 2 N words: N doubles (double-precision primes) or N (word, Shoup quotient) pairs
+                const size_t kslab = (((size_t)(J - a.key_digit0) * 2 + 0) * a.L + kc) * 2 * N;
+                const typename F::key_t *k0 = key + kslab + ((size_t)hg << 12) + tid;
+                const typename F::key_t *k1 = k0 + (size_t)a.L * 2 * N;
                 typename F::key_t kr0[16], kr1[16];
                 if constexpr (FP)
                 {
@@ -1895,11 +1896,13 @@ namespace sealhip
                 }
                 else
                 {
-                    const size_t qo = a.key_quot_off;
+                    // the word and its quotient are neighbours: one 16-byte load each (register order in units of pairs)
+                    const ShoupOp *p0 = reinterpret_cast<const ShoupOp *>(a.key + kslab) + ((size_t)hg << 12) + tid;
+                    const ShoupOp *p1 = p0 + (size_t)a.L * N;
 #pragma unroll
                     for (int e = 0; e < 16; e++)
                     {
-                        const ShoupOp w0{ k0[e * 256], k0[e * 256 + qo] }, w1{ k1[e * 256], k1[e * 256 + qo] };
+                        const ShoupOp w0 = p0[e * 256], w1 = p1[e * 256];
                         if constexpr (ICLS == 2)
                         {
                             acc0[e] = F::guard(acc0[e] + F::mul_lazy(x[e], w0, m), m);
@@ -2003,13 +2006,14 @@ namespace sealhip
                 const unsigned e = (unsigned)(p >> 8) & 15, tid = (unsigned)p & 255;
                 size_t nat = (hg << 12) + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 4) + e;
                 const uint64_t v = in[(slab << n_log) + nat];
+                uint64_t *o = out + (slab << (n_log + 1)); // this component's 2 N words
                 if (fpd[comp].qi)
                 {
                     // balanced representative in (-q/2, q/2] (see Context: the same halving of the bound for the key products)
                     double d = fp_from_u52(v);
                     if (v > fpd[comp].qi / 2)
                         d -= fpd[comp].q;
-                    out[i] = fp_to_bits(d);
+                    o[p] = fp_to_bits(d);
                 }
                 else
                 {
@@ -2027,8 +2031,8 @@ namespace sealhip
                         rem -= md.q;
                         est++;
                     }
-                    out[i] = v;
-                    out[total + i] = est;
+                    o[2 * p] = v;
+                    o[2 * p + 1] = est;
                 }
             }
         }
@@ -2537,7 +2541,6 @@ namespace sealhip
         a2.mid = k.mid;
         a2.target = k.target_ntt;
         a2.key = k.key;
-        a2.key_quot_off = k.key_quot_off;
         a2.acc = k.acc;
         a2.targets = k.targets2;
         a2.ntargets = k.ntargets;

@@ -269,7 +269,6 @@ namespace sealhip
         void *p = nullptr;
         const bool reorder = ntt2_supports(ctx.log_n()) && !shl_ab_getenv("SEALHIP_OLD_KS");
         // register order carries a second plane: the Shoup quotients of the integer back end's components
-        const size_t plane_words = bytes / 8;
         ck(hipMalloc(&p, reorder ? key_register_order_words(ctx.log_n(), (unsigned)L, digits * 2) * 8 : bytes), "hipMalloc key");
         if (reorder)
         {
@@ -285,7 +284,6 @@ namespace sealhip
         keys_[index].digits = digits;
         keys_[index].digit0 = digit0;
         keys_[index].register_order = reorder;
-        keys_[index].quot_off = reorder ? plane_words : 0;
     }
 
 } // namespace sealhip
