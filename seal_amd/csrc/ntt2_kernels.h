@@ -43,8 +43,8 @@ namespace sealhip
     };
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);
 
-    // [polys][L][N] natural-order key words -> register order of ks2, 2 N words per component: N balanced doubles for primes of the
-    // double-precision back end (the second half unused); for the integer back end's primes N pairs (word, floor(word * 2^64 / q)):
+    // [polys][L][N] natural-order key words -> register order of ks2, 2 N words per component: for primes of the double-precision back end N pairs of
+    // balanced doubles (first, second key polynomial of the digit) in the first polynomial's slot (the second's unused); for the integer back end's primes N pairs (word, floor(word * 2^64 / q)):
     // the key is the precomputed operand of a Shoup product (round 3: the sums of ks2 then fit 64-bit words) and a pair is one
     // 16-byte load.  `out` holds key_register_order_words(...) words.
     hipError_t key_to_register_order(

@@ -1865,11 +1865,13 @@ namespace sealhip
                 if constexpr (FP)
                 {
                     // the key words of this digit and the next digit travel while this digit is transformed
+                    const double2 *kp = reinterpret_cast<const double2 *>(a.key + kslab) + ((size_t)hg << 12) + tid;
 #pragma unroll
                     for (int e = 0; e < 16; e++)
                     {
-                        kr0[e] = k0[e * 256];
-                        kr1[e] = k1[e * 256];
+                        const double2 kk = kp[e * 256]; // (first, second) key polynomial of this coefficient
+                        kr0[e] = kk.x;
+                        kr1[e] = kk.y;
                     }
                     if (J + 1 < j1)
                         fetch(J + 1);
@@ -2013,7 +2015,9 @@ namespace sealhip
                     double d = fp_from_u52(v);
                     if (v > fpd[comp].qi / 2)
                         d -= fpd[comp].q;
-                    o[p] = fp_to_bits(d);
+                    // the two polynomials of a digit side by side in the first one's slot: ks2 reads both with one 16-byte load
+                    const size_t poly = slab / L;
+                    out[((((poly & ~(size_t)1) * L + comp)) << (n_log + 1)) + 2 * p + (poly & 1)] = fp_to_bits(d);
                 }
                 else
                 {
