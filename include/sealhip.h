@@ -258,6 +258,11 @@ SHL_FUNC KSwitchKeys_HasKey(void *thisptr, uint64_t index, bool *has_key);
 /* KSwitchKeys::load / unsafe_load (native/src/seal/c/kswitchkeys.h:45-47; kswitchkeys.cpp:92-180): a serialized RelinKeys /
  * GaloisKeys stream (seeded or full, compr_mode none) goes straight into the device key slabs, every key index it holds. */
 SHL_FUNC KSwitchKeys_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+/* KSwitchKeys::save_size / save (native/src/seal/c/kswitchkeys.h:41-43; kswitchkeys.cpp:47-90): the FULL keys the object holds, each digit
+ * as its size-2 ciphertext stream, byte for byte the reference's stream for compr_mode none (the device words go back from the
+ * key-switch kernels' register order to canonical natural order first).  A digit-parallel slice is refused (logic_error). */
+SHL_FUNC KSwitchKeys_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+SHL_FUNC KSwitchKeys_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
 SHL_FUNC KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
 SHL_FUNC RelinKeys_GetIndex(uint64_t key_power, uint64_t *index);
 SHL_FUNC GaloisKeys_GetIndex(uint32_t galois_elt, uint64_t *index);

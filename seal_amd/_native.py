@@ -63,7 +63,7 @@ Ciphertext_IsNTTForm Ciphertext_SetIsNTTForm Ciphertext_Scale Ciphertext_SetScal
 Ciphertext_SetCorrectionFactor Ciphertext_IsTransparent Ciphertext_DevicePtr Ciphertext_CopyFromHost
 Ciphertext_CopyToHost Ciphertext_CopyWordsToHost Ciphertext_CopyFromDevice
 Ciphertext_SaveSize Ciphertext_Save Ciphertext_UnsafeLoad Ciphertext_Load Ciphertext_LoadItem Ciphertext_SaveItem
-KSwitchKeys_UnsafeLoad KSwitchKeys_Load
+KSwitchKeys_UnsafeLoad KSwitchKeys_Load KSwitchKeys_SaveSize KSwitchKeys_Save
 KeyGenerator_Create1 KeyGenerator_Create2 KeyGenerator_Destroy KeyGenerator_SecretKey KeyGenerator_CreatePublicKey
 KeyGenerator_CreateRelinKeys KeyGenerator_CreateGaloisKeysFromSteps KeyGenerator_CreateGaloisKeysAll KeyGenerator_CreateGaloisKeysFromElts KeyGenerator_KeyToHost KeyGenerator_SeededSaveSize KeyGenerator_CreateRelinKeysSave KeyGenerator_CreateGaloisKeysFromEltsSave SecretKey_Get PublicKey_Get
 SecretKey_Create SecretKey_Destroy SecretKey_Set SecretKey_UnsafeLoad SecretKey_Load Decryptor_Create Decryptor_Destroy

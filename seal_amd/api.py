@@ -418,6 +418,15 @@ class KSwitchKeys:
         N.check(fn(self._h, self.context._h, buf, C.c_uint64(len(data)), C.byref(n)))
         return n.value
 
+    def save_bytes(self, compr_mode=0):
+        """KSwitchKeys::save of the full keys (compr_mode 0 none, 1 zlib, 2 zstd)"""
+        cap = C.c_int64()
+        N.check(N.lib().KSwitchKeys_SaveSize(self._h, C.c_uint8(compr_mode), C.byref(cap)))
+        buf = (C.c_uint8 * cap.value)()
+        n = C.c_int64()
+        N.check(N.lib().KSwitchKeys_Save(self._h, buf, C.c_uint64(cap.value), C.c_uint8(compr_mode), C.byref(n)))
+        return C.string_at(buf, n.value)
+
     def has_index(self, index):
         b = C.c_bool()
         N.check(N.lib().KSwitchKeys_HasKey(self._h, C.c_uint64(index), C.byref(b)))

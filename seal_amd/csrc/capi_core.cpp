@@ -548,6 +548,7 @@ extern "C"
             *in_bytes = (int64_t)serial::load_kswitchkeys(*c, inptr, (size_t)size, check, img, true);
             auto keys = as<KSwitchKeys>(thisptr);
             keys->clear(); // the loaded object replaces the previous contents, indices absent from the stream included
+            keys->reserve_slots(img.keys.size());
             for (size_t index = 0; index < img.keys.size(); index++)
             {
                 auto &digits = img.keys[index];
@@ -713,6 +714,90 @@ extern "C"
             hip_ok(hipMemcpy(dst + data_offset, pt->data(), pt->coeff_count() * 8, hipMemcpyDeviceToHost), "D2H");
         if (compr_mode != 0)
             *out_bytes = (int64_t)serial::compress_stream(raw.data(), raw.size(), compr_mode, outptr, (size_t)size);
+        SHL_CATCH
+    }
+    namespace
+    {
+        // KSwitchKeys::save_members (kswitchkeys.cpp:47-90): parms_id, the slot count, per slot the digit count and every digit as
+        // the stream of its (full, size-2, key-level, NTT-form) ciphertext - the whole inside one SEALHeader
+        size_t ks_raw_size(const KSwitchKeys &keys)
+        {
+            size_t bytes = 16 + 32 + 8 + 8 * keys.slots();
+            if (const Context *c = keys.context())
+                for (size_t i = 0; i < keys.slots(); i++)
+                    if (keys.has_key(i))
+                        bytes += keys.key(i).digits * serial::ciphertext_save_size(2, c->n(), c->key_level().K);
+            return bytes;
+        }
+    } // namespace
+    SHL_FUNC KSwitchKeys_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(result, SHL_E_POINTER);
+        SHL_TRY
+        if (!serial::compr_mode_supported(compr_mode))
+            throw std::invalid_argument("unsupported compression mode");
+        *result = (int64_t)serial::compress_bound(ks_raw_size(*as<KSwitchKeys>(thisptr)), compr_mode);
+        SHL_CATCH
+    }
+    SHL_FUNC KSwitchKeys_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(outptr, SHL_E_POINTER);
+        IfNullRet(out_bytes, SHL_E_POINTER);
+        SHL_TRY
+        if (!serial::compr_mode_supported(compr_mode))
+            throw std::invalid_argument("unsupported compression mode");
+        auto keys = as<KSwitchKeys>(thisptr);
+        const Context *c = keys->context();
+        const size_t raw_bytes = ks_raw_size(*keys);
+        std::vector<uint8_t> raw;
+        uint8_t *dst = outptr;
+        if (compr_mode != 0)
+        {
+            raw.resize(raw_bytes);
+            dst = raw.data();
+        }
+        else if ((size_t)size < raw_bytes)
+            throw std::invalid_argument("capacity");
+        size_t pos = 16;
+        auto put64 = [&](uint64_t v) {
+            std::memcpy(dst + pos, &v, 8);
+            pos += 8;
+        };
+        static const uint64_t zero_id[4] = { 0, 0, 0, 0 };
+        std::memcpy(dst + pos, c ? c->key_level().parms_id : zero_id, 32);
+        pos += 32;
+        put64(keys->slots());
+        for (size_t index = 0; index < keys->slots(); index++)
+        {
+            if (!keys->has_key(index))
+            {
+                put64(0);
+                continue;
+            }
+            const auto &k = keys->key(index);
+            const size_t n = c->n(), L = c->key_level().K, words = 2 * L * n;
+            if (k.digit0 != 0 || k.digits != c->first_level().K)
+                throw std::logic_error("a digit-parallel slice of a key cannot be saved");
+            put64(k.digits);
+            Scratch natural(k.digits * words);
+            keys->key_words(index, natural.p);
+            for (size_t j = 0; j < k.digits; j++)
+            {
+                size_t off = 0;
+                const size_t bytes = serial::save_ciphertext(c->key_level().parms_id, true, 2, n, L, 1.0, 1, nullptr, dst + pos, raw_bytes - pos, &off);
+                hip_ok(hipMemcpy(dst + pos + off, natural.p + j * words, words * 8, hipMemcpyDeviceToHost), "D2H");
+                pos += bytes;
+            }
+        }
+        const uint8_t header[8] = { 0x5E, 0xA1, serial::kHeaderSize, serial::kVersionMajor, serial::kVersionMinor, 0, 0, 0 };
+        std::memcpy(dst, header, 8);
+        const uint64_t total = pos;
+        std::memcpy(dst + 8, &total, 8);
+        *out_bytes = (int64_t)pos;
+        if (compr_mode != 0)
+            *out_bytes = (int64_t)serial::compress_stream(raw.data(), pos, compr_mode, outptr, (size_t)size);
         SHL_CATCH
     }
     SHL_FUNC KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)

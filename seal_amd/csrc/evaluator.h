@@ -152,10 +152,18 @@ namespace sealhip
         void set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device, size_t digit0 = 0);
         // the same with the words delivered by `upload(device_destination)` (e.g. piecewise from a serialized stream)
         void set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0 = 0);
+        // the words of key `index` as set_key took them ([digits][2][L][N], canonical, natural order), written to device memory
+        void key_words(size_t index, uint64_t *device_out) const;
         void clear(); // drop every key (KSwitchKeys::load replaces the whole object, kswitchkeys.cpp:92-180)
         bool has_key(size_t index) const { return index < keys_.size() && keys_[index].dev != nullptr; }
         const Key &key(size_t index) const { return keys_[index]; }
         size_t slots() const { return keys_.size(); }
+        // KSwitchKeys::data().size() of the reference object: N for GaloisKeys (galoiskeys.h), what a stream said for a loaded one
+        void reserve_slots(size_t count)
+        {
+            if (keys_.size() < count)
+                keys_.resize(count);
+        }
         size_t size() const;
         const Context *context() const { return ctx_; }
 

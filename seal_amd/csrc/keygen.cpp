@@ -187,6 +187,7 @@ namespace sealhip
         if (count && !galois_elts)
             throw std::invalid_argument("galois_elts");
         Scratch key(key_words());
+        destination.reserve_slots(context_.n()); // GaloisKeys::data() has a slot for every odd element (keygenerator.cpp:209-214)
         for (size_t i = 0; i < count; i++)
         {
             const uint32_t elt = galois_elts[i];

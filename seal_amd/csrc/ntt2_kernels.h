@@ -49,6 +49,9 @@ namespace sealhip
     // 16-byte load.  `out` holds key_register_order_words(...) words.
     hipError_t key_to_register_order(
         const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream);
+    // the way back: [polys][L][N] canonical words in natural order (what a saved key holds)
+    hipError_t key_from_register_order(
+        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream);
     inline size_t key_register_order_words(int log_n, unsigned L, size_t polys)
     {
         return 2 * ((polys * L) << log_n);

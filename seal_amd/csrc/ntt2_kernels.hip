@@ -2041,6 +2041,34 @@ namespace sealhip
             }
         }
 
+        // register order -> natural order, canonical words: what KSwitchKeys::save writes (kswitchkeys.cpp:47-90)
+        __global__ void __launch_bounds__(kThreads) key_unlayout_kernel(
+            const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys)
+        {
+            const size_t N = (size_t)1 << n_log;
+            const size_t total = polys * L * N;
+            for (size_t i = blockIdx.x * (size_t)kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads)
+            {
+                const size_t p = i & (N - 1), slab = i >> n_log;
+                const unsigned comp = (unsigned)(slab % L);
+                const size_t hg = p >> 12;
+                const unsigned e = (unsigned)(p >> 8) & 15, tid = (unsigned)p & 255;
+                const size_t nat = (hg << 12) + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 4) + e;
+                uint64_t v;
+                if (fpd[comp].qi)
+                {
+                    const size_t poly = slab / L;
+                    double d = fp_from_bits(in[((((poly & ~(size_t)1) * L + comp)) << (n_log + 1)) + 2 * p + (poly & 1)]);
+                    if (d < 0)
+                        d += fpd[comp].q; // balanced -> [0, q)
+                    v = (uint64_t)d;
+                }
+                else
+                    v = in[(slab << (n_log + 1)) + 2 * p];
+                out[(slab << n_log) + nat] = v;
+            }
+        }
+
         // Components [c0, c0 + nc) of one launch, all of arithmetic class cls (0 int, 1 fp, 2 mixed)
         struct CompRun
         {
@@ -2579,6 +2607,16 @@ namespace sealhip
         if (blocks > 4096)
             blocks = 4096;
         hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, t.mods, L, (unsigned)t.log_n, polys);
+        return hipGetLastError();
+    }
+    hipError_t key_from_register_order(
+        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream)
+    {
+        size_t total = (polys * L) << t.log_n;
+        size_t blocks = (total + kThreads - 1) / kThreads;
+        if (blocks > 4096)
+            blocks = 4096;
+        hipLaunchKernelGGL(key_unlayout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, L, (unsigned)t.log_n, polys);
         return hipGetLastError();
     }
 } // namespace sealhip

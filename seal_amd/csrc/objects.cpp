@@ -251,6 +251,19 @@ namespace sealhip
             },
             digit0);
     }
+    void KSwitchKeys::key_words(size_t index, uint64_t *device_out) const
+    {
+        if (!has_key(index) || !ctx_)
+            throw std::invalid_argument("no such key");
+        const Key &k = keys_[index];
+        const size_t L = ctx_->key_level().K;
+        if (k.register_order)
+            ck(key_from_register_order(ctx_->ntt_tables(), k.dev, device_out, (unsigned)L, k.digits * 2, nullptr), "key layout");
+        else
+            ck(hipMemcpy(device_out, k.dev, k.digits * 2 * L * ctx_->n() * 8, hipMemcpyDeviceToDevice), "key copy");
+        ck(hipDeviceSynchronize(), "key layout sync");
+    }
+
     void KSwitchKeys::set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0)
     {
         if (!ctx.using_keyswitching())

@@ -166,6 +166,63 @@ def case_key_streams(scheme, n, bits, seeded, steps=(1,)):
         assert not glk.has_key(e), "key %d survived a load that does not contain it" % e
 
 
+def case_key_save(scheme, n, bits, steps=(1,)):
+    """KSwitchKeys::save (c/kswitchkeys.h:41-43): keys loaded from the reference's streams (full and seeded) and keys made by
+    the device KeyGenerator are written back as the reference's own bytes - the device slabs return from the key-switch
+    kernels' register order (doubles / Shoup pairs) to canonical words - and the compressed forms load on both sides"""
+    primes, t, ref, d = setup(scheme, n, bits)
+    full = ref.keys_save("relin", False)
+    rlk = S.RelinKeys(d.ctx)
+    assert rlk.load_bytes(full) == len(full)
+    assert rlk.save_bytes() == full, "full RelinKeys stream: load then save"
+    seeded = ref.keys_save("relin", True)          # the reference's object now holds this stream's (expanded) keys
+    assert rlk.load_bytes(seeded) == len(seeded)
+    assert rlk.save_bytes() == ref.keys_save_mode("relin", 0), "seeded RelinKeys stream saved in full"
+    elts = [ref.galois_elt_from_step(s) for s in steps] + [2 * n - 1]
+    seeded = ref.keys_save("galois", True, elts)
+    want = ref.keys_save_mode("galois", 0)
+    glk = S.GaloisKeys(d.ctx)
+    assert glk.load_bytes(seeded) == len(seeded)
+    mine = glk.save_bytes()
+    assert mine == want, "GaloisKeys (every slot, the empty ones included)"
+    for mode in (1, 2):
+        z = glk.save_bytes(compr_mode=mode)
+        assert z[5] == mode and len(z) < len(want)
+        if mode == 1:  # (the reference build here has zlib only: see case_compressed_streams)
+            assert ref.keys_load(z) == len(z), "the reference reads our compressed key stream"
+        g2 = S.GaloisKeys(d.ctx)
+        assert g2.load_bytes(z) == len(z) and g2.save_bytes() == want
+    # keys generated on the device: the reference installs our stream and key-switches to our words
+    kg = S.KeyGenerator(d.ctx)
+    own = kg.create_relin_keys()
+    stream = own.save_bytes()
+    assert ref.keys_load(stream) == len(stream)
+    ref.keys_install("relin", stream)
+    K = len(primes) - 1
+    rng = np.random.default_rng(11)
+    is_ntt, scale = scheme != "bfv", (2.0 ** 10 if scheme == "ckks" else 1.0)
+    x3 = rand_ct(rng, primes, K, n, size=3)
+    cx = d.ct(x3, scale=scale, is_ntt=is_ntt)
+    d.ev.relinearize_inplace(cx, own)
+    rx = ref.ct(ref.first_chain_index, x3, is_ntt, scale)
+    ref.relinearize_inplace(rx)
+    assert np.array_equal(cx.to_numpy()[:, 0], rx.data()), "the reference relinearizes with the keys we saved"
+    own_g = kg.create_galois_keys(galois_elts=elts)
+    stream = own_g.save_bytes()
+    assert struct.unpack_from("<Q", stream, 48)[0] == n, "GaloisKeys::data() has a slot per odd element"
+    ref.keys_install("galois", stream)
+    x2 = rand_ct(rng, primes, K, n)
+    cx = d.ct(x2, scale=scale, is_ntt=is_ntt)
+    d.ev.apply_galois_inplace(cx, elts[0], own_g)
+    rx = ref.ct(ref.first_chain_index, x2, is_ntt, scale)
+    ref.apply_galois_inplace(rx, elts[0])
+    assert np.array_equal(cx.to_numpy()[:, 0], rx.data()), "the reference rotates with the Galois keys we saved"
+    # an empty object saves as the reference's empty object does
+    empty = S.RelinKeys(d.ctx)
+    e = empty.save_bytes()
+    assert len(e) == 16 + 32 + 8 and struct.unpack_from("<Q", e, 48)[0] == 0
+
+
 def _walk_key_digits(stream):
     """offsets (start, size) of every digit (a framed seeded or full ciphertext) inside a KSwitchKeys stream"""
     pos = 16 + 32

@@ -35,6 +35,11 @@ def test_key_streams(gpu, scheme, n, bits, seeded):
     SC.case_key_streams(scheme, n, bits, seeded)
 
 
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 8192, [60, 40, 40, 60]), ("bfv", 8192, [50, 55, 56]), ("ckks", 32768, [60, 50, 50, 60])])
+def test_key_save(gpu, scheme, n, bits):
+    SC.case_key_save(scheme, n, bits)
+
+
 def test_key_stream_headline_size(gpu):
     """BASELINE's headline parameters: CKKS N = 65536, {60, 14 x 50, 60}; seeded RelinKeys + GaloisKeys streams"""
     SC.case_key_streams("ckks", 65536, [60] + [50] * 14 + [60], True)

@@ -53,6 +53,13 @@ def test_batch_items(emu, scheme, n, bits):
 
 
 @needs_ref
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 1024, [40, 30, 40]), ("bfv", 1024, [36, 36, 37]), ("ckks", 8192, [60, 40, 59])])
+def test_key_save(emu, scheme, n, bits):
+    import serial_cases as SC
+    SC.case_key_save(scheme, n, bits)
+
+
+@needs_ref
 @pytest.mark.parametrize("scheme,n,bits,seeded", [("ckks", 1024, [40, 30, 40], True), ("bfv", 1024, [36, 36, 37], False),
                                                   ("bgv", 2048, [40, 40, 45], True), ("ckks", 8192, [50, 40, 60], True),
                                                   ("ckks", 8192, [60, 59, 60], True)])
