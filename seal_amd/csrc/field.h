@@ -635,8 +635,8 @@ namespace sealhip
         }
 
         // key-switch inner product: each product is reduced to |r| <= q (0.5 + 0.1875 B) - balanced key words, |x| <= B q with
-        // B <= 1.8 (lean placement) - i.e. <= 0.84 q, and summed exactly; acc_fix() is called every 8 terms so the sum stays
-        // below 0.5 q + 8 * 0.84 q = 7.2 q < 2^53.
+        // B <= 2.64 (lean placement) - i.e. <= 0.995 q, and summed exactly; acc_fix() is called every 7 terms so the sum stays
+        // below 0.5 q + 7 * 0.995 q = 7.47 q < 2^53.
         typedef double Acc;
         typedef double key_t; // the key component is stored as doubles for eligible primes
         static SHL_HD Acc acc_zero()

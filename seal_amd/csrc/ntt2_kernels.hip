@@ -421,9 +421,10 @@ namespace sealhip
         // intermediate lives in LDS, so that the 16-lane runs of one wave instruction fall on different banks)
         // LEAN (double-precision back end, N = 2^16, key switching): with balanced twiddles a magnitude B q grows to
         // (1.1875 B + 0.5) q per stage (field.h), 0.5 -> 1.09 -> 1.80 -> 2.64 -> 3.63 -> 4.81 -> 6.21 -> 7.88 over seven stages
-        // (< 8 q <= 2^53: still exact).  The sixteen stages of a raised digit therefore need a fix() after global stage 7 (here,
-        // inside phase B) and after stage 14 (p2_tile) only: the input must come in with |x| <= q/2, the intermediate leaves
-        // with |x| <= 1.09 q, unfixed.
+        // (< 8 q <= 2^53: still exact).  Round 3: the fix() sit after global stage 6 (here, inside phase B) and after stage 13
+        // (p2_tile), so that a digit may come in UNFIXED with |x| <= kLeanEntry q (a residue of a digit modulus of about the
+        // target's size: 1.13 -> 1.84 -> 2.69 -> 3.69 -> 4.88 -> 6.30 -> 7.98, then 0.5 -> 1.09 -> 1.80): the intermediate
+        // leaves with |x| <= 1.80 q, unfixed, and the values leave p2_tile with |x| <= 2.64 q.
         // Integer back end: ICLS = modulus class; the sixteen values enter below 4 q and leave below kP1Out<ICLS, D1> q.
         template <bool FP, int D1, int BS = 256, bool LEAN = false, int ICLS = 0>
         __device__ __forceinline__ void p1_tile(
@@ -456,7 +457,7 @@ namespace sealhip
             if constexpr (FP && LEAN)
             {
                 static_assert(!LEAN || G::rA == 4, "the lean placement is worked out for eight stages per pass");
-                phase_fwd_fix<FP, 4, 3>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+                phase_fwd_fix<FP, 4, 2>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
             }
             else
             {
@@ -503,10 +504,10 @@ namespace sealhip
 
         // TWA_LDS: only phase A's row-shared twiddles come from LDS (twa), phase B's per-thread ones from global memory
         // (LOWREG) or from the caller's registers (HOIST && TWA_LDS: pre_b only)
-        // LEAN (see p1_tile): the input arrives with |x| <= 1.09 q; no fix() after phase A (-> 4.81 q), one after the second stage
-        // of phase B (global stage 14: 7.88 q -> q/2), none at the end: the values leave with |x| <= 1.80 q, which the key
-        // products take (|x k mod q| <= q (1/2 + 3/16 * 1.8) = 0.84 q with balanced key words; eight terms on top of a fixed
-        // accumulator stay below 7.2 q)
+        // LEAN (see p1_tile): the input arrives with |x| <= 1.80 q; no fix() after phase A (-> 6.21 q), one after the first stage
+        // of phase B (global stage 13: 7.88 q -> q/2), none at the end: the values leave with |x| <= 2.64 q, which the key
+        // products take (|x k mod q| <= q (1/2 + 3/16 * 2.64) = 0.995 q with balanced key words; seven terms on top of a fixed
+        // accumulator stay below 7.5 q)
         // Integer back end: ICLS = modulus class, BIN = bound of the loaded values in units of q (kP1Out<ICLS, D1> for an
         // intermediate written by p1_tile); they leave below IntBounds<ICLS>::fwd_after(BIN, 8) q.
         // TWB3_LDS (integer ks2, round 3): the eight per-thread twiddles of the LAST stage are read from twb[g * 256 + tid] (staged
@@ -570,7 +571,7 @@ namespace sealhip
             {
                 auto twf = [&](int t, int g) { return twb[((256u << t) - 256u) + g * 256 + tid]; };
                 if constexpr (LEAN)
-                    phase_fwd_fix<FP, 4, 2>(x, m, twf);
+                    phase_fwd_fix<FP, 4, 1>(x, m, twf);
                 else
                     phase_fwd_end<FP, 4, true, ICLS, BMID>(x, m, twf);
             }
@@ -1575,6 +1576,8 @@ namespace sealhip
         template <int D1>
         constexpr bool kLeanKs = D1 == 8;
 #endif
+        // the lean placement takes an unfixed digit of magnitude up to kLeanEntry q_I (p1_tile)
+        constexpr double kLeanEntry = 1.13;
 
         // ---------------------------------------------------------------------------------------
         // fused key switching, pass 1: one workgroup = (column tile cg, digit J, batch item b);
@@ -1640,12 +1643,16 @@ namespace sealhip
                     }
                     else
                     {
-                        // digit below 2^52: exact as a double, one fix() brings it under q_I / 2
+                        // digit below 2^52: exact as a double; one fix() brings it under q_I / 2 - which the lean placement does
+                        // not need when q_J <= 1.13 q_I (p1_tile: the first fix() sits after stage 6, 2.804 B + 4.811 < 8)
 #pragma unroll
                         for (int e = 0; e < 16; e++)
-                        {
                             x[e] = fp_from_u52(nxt[e]);
-                            F::fix(x[e], m);
+                        if (!kLeanKs<D1> || (double)src_q > kLeanEntry * m.q)
+                        {
+#pragma unroll
+                            for (int e = 0; e < 16; e++)
+                                F::fix(x[e], m);
                         }
                     }
                 }
@@ -1783,7 +1790,7 @@ namespace sealhip
                 __syncthreads();
             }
 
-            // double precision: sums of doubles, fixed every eight terms.  Integer back end (round 3): the key is the precomputed
+            // double precision: sums of doubles, fixed every seven terms.  Integer back end (round 3): the key is the precomputed
             // operand of a Shoup product (its quotient plane: key_to_register_order), so a term is x k mod q in [0, 4q) for any
             // 64-bit x and the sum stays a 64-bit word - 2 VGPRs instead of the 4 of a 128-bit sum, 12 instructions a term with the
             // addition riding in the remainder chain (field.h: mul_rem) - brought under 4 q every kAccRun terms.
@@ -1919,7 +1926,7 @@ namespace sealhip
                 }
                 if constexpr (FP)
                 {
-                    if (((J - j0) & 7) == 7)
+                    if ((J - j0) % 7 == 6)
                     {
 #pragma unroll
                         for (int e = 0; e < 16; e++)
