@@ -67,6 +67,54 @@ namespace sealhip
         uint64_t ratio_hi;
     };
 
+    // A read-only window of global memory whose base is the same in every lane (round 3): loads through it are gfx950 buffer
+    // loads - address = base (4 SGPRs) + a 32-bit per-lane byte offset + a wave-uniform byte offset (an SGPR or the 12-bit
+    // immediate) - so the strided loads of a tile (row e at e * 2 KiB or 4 KiB) cost no vector instruction for their
+    // addresses, where flat global loads needed a 64-bit VGPR add (v_add_co + v_addc and a VCC wait state) per row.
+    // Offsets are bytes, below 2^31 together.  The emulated build reads the same bytes through the pointer.
+    struct UniformView
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __amdgpu_buffer_rsrc_t rsrc;
+#else
+        const char *base;
+#endif
+    };
+    template <class T>
+    __device__ __forceinline__ UniformView uniform_view(const T *wave_uniform_base)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // raw buffer (stride 0), 2^31 - 1 bytes, word 3 = DATA_FORMAT 32 (the untyped-load setting of gfx90a / gfx94x / gfx950)
+        return UniformView{ __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(wave_uniform_base), 0, 0x7fffffff, 0x00020000) };
+#else
+        return UniformView{ reinterpret_cast<const char *>(wave_uniform_base) };
+#endif
+    }
+    __device__ __forceinline__ uint64_t view_load64(const UniformView &v, unsigned lane_bytes, unsigned uniform_bytes)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(v.rsrc, (int)lane_bytes, (int)uniform_bytes, 0);
+        return ((uint64_t)r.y << 32) | r.x;
+#else
+        return *reinterpret_cast<const uint64_t *>(v.base + lane_bytes + uniform_bytes);
+#endif
+    }
+    // two consecutive 64-bit words (16-byte aligned)
+    __device__ __forceinline__ void view_load128(const UniformView &v, unsigned lane_bytes, unsigned uniform_bytes, uint64_t &w0, uint64_t &w1)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(v.rsrc, (int)lane_bytes, (int)uniform_bytes, 0);
+        w0 = ((uint64_t)r.y << 32) | r.x;
+        w1 = ((uint64_t)r.w << 32) | r.z;
+#else
+        const uint64_t *p = reinterpret_cast<const uint64_t *>(v.base + lane_bytes + uniform_bytes);
+        w0 = p[0];
+        w1 = p[1];
+#endif
+    }
+
     SHL_HD uint64_t mul_hi64(uint64_t a, uint64_t b)
     {
 #if defined(__HIP_DEVICE_COMPILE__)

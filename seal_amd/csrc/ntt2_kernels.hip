@@ -1811,25 +1811,35 @@ namespace sealhip
                     acc1[e] = 0;
                 }
             }
-            const typename F::key_t *key = reinterpret_cast<const typename F::key_t *>(a.key);
             const size_t N = (size_t)1 << G::n;
-            const uint64_t *mid0 = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K) << G::n) + ((size_t)hg << 12) + tid;
+            // Every load of the digit loop goes through a wave-uniform window (modarith.h: UniformView): the tile's base is the
+            // same in every lane, the lane adds tid words, row e sits e * 2 KiB (intermediate) or e * 4 KiB (key pairs) further.
+            const uint64_t *mid0 = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K) << G::n) + ((size_t)hg << 12);
             // diagonal digit (CKKS): NTT_J(INTT_J(target_J)) = target_J (evaluator.cpp:2682-2685); read the
             // thread's 16 contiguous coefficients of row 16 hg + u straight from the input polynomial
-            const uint64_t *diag = a.target && I < a.K
-                                       ? a.target + (((size_t)b * a.K + I) << G::n) + ((size_t)hg << 12) + (size_t)tid * 16
-                                       : nullptr;
+            const uint64_t *mid0_lane = mid0 + tid;
+            const bool has_diag = a.target && I < a.K;
+            const UniformView diag_view = uniform_view(has_diag ? a.target + (((size_t)b * a.K + I) << G::n) + ((size_t)hg << 12) : a.mid);
             uint64_t nxt[16]; // digit J+1 is in flight while digit J is transformed
             auto fetch = [&](unsigned J) {
-                if (diag && J == I)
+                if (has_diag && J == I)
                 {
 #pragma unroll
+                    for (int e = 0; e < 16; e += 2)
+                        view_load128(diag_view, tid * 128, e * 8, nxt[e], nxt[e + 1]);
+                }
+                else if constexpr (FP)
+                {
+                    const UniformView mv = uniform_view(mid0 + ((size_t)J << G::n));
+#pragma unroll
                     for (int e = 0; e < 16; e++)
-                        nxt[e] = diag[e];
+                        nxt[e] = view_load64(mv, tid * 8, e * 2048);
                 }
                 else
                 {
-                    const uint64_t *mp = mid0 + ((size_t)J << G::n);
+                    // (the integer back end's loop is bound by latency, not by its instruction count: plain loads measured
+                    // 0.6 % faster at BFV configs[3])
+                    const uint64_t *mp = mid0_lane + ((size_t)J << G::n);
 #pragma unroll
                     for (int e = 0; e < 16; e++)
                         nxt[e] = mp[e * 256];
@@ -1849,7 +1859,7 @@ namespace sealhip
             for (unsigned J = j0; J < j1; J++)
             {
                 typename F::elem x[16];
-                const bool is_diag = diag && J == I;
+                const bool is_diag = has_diag && J == I;
                 if constexpr (!PF)
                     fetch(J);
                 if (is_diag)
@@ -1866,19 +1876,18 @@ namespace sealhip
                 }
                 // every key component owns 2 N words: N doubles (double-precision primes) or N (word, Shoup quotient) pairs
                 const size_t kslab = (((size_t)(J - a.key_digit0) * 2 + 0) * a.L + kc) * 2 * N;
-                const typename F::key_t *k0 = key + kslab + ((size_t)hg << 12) + tid;
-                const typename F::key_t *k1 = k0 + (size_t)a.L * 2 * N;
                 typename F::key_t kr0[16], kr1[16];
                 if constexpr (FP)
                 {
                     // the key words of this digit and the next digit travel while this digit is transformed
-                    const double2 *kp = reinterpret_cast<const double2 *>(a.key + kslab) + ((size_t)hg << 12) + tid;
+                    const UniformView kv = uniform_view(a.key + kslab + ((size_t)hg << 13));
 #pragma unroll
                     for (int e = 0; e < 16; e++)
                     {
-                        const double2 kk = kp[e * 256]; // (first, second) key polynomial of this coefficient
-                        kr0[e] = kk.x;
-                        kr1[e] = kk.y;
+                        uint64_t w0, w1; // (first, second) key polynomial of this coefficient
+                        view_load128(kv, tid * 16, e * 4096, w0, w1);
+                        kr0[e] = fp_from_bits(w0);
+                        kr1[e] = fp_from_bits(w1);
                     }
                     if (J + 1 < j1)
                         fetch(J + 1);
