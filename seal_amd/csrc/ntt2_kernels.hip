@@ -941,8 +941,8 @@ namespace sealhip
                         x[e] = mul_shoup(v, pm.w, pm.wq, q) + u; // below q + 2q: inside the forward input range [0, 4q)
                 }
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
-                // double precision, eight stages: x is fixed (|x| <= q/2), so one fix() after stage 7 does (p1_tile, LEAN); the
-                // intermediate leaves at 1.09 q, which pass 2's first phase takes (-> 4.81 q)
+                // double precision, eight stages: x is fixed (|x| <= q/2), so one fix() after stage 6 does (p1_tile, LEAN); the
+                // intermediate leaves at 1.80 q, which pass 2's first phase takes (-> 6.21 q)
                 p1_tile<FP, D1, 256, FP && G::rA == 4, ICLS>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
         }
@@ -960,6 +960,9 @@ namespace sealhip
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             const uint64_t q = a.t.mods[prime].q;
             const ShoupOp mul = a.epi_mul[comp], pm = t2.x.pmul[comp];
+            // the two constants as balanced doubles (exact: the primes of this back end are below 2^50)
+            [[maybe_unused]] const double pm_fp = pm.w > q / 2 ? -(double)(q - pm.w) : (double)pm.w;
+            [[maybe_unused]] const double mul_fp = mul.w > q / 2 ? -(double)(q - mul.w) : (double)mul.w;
             const size_t row0 = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
             uint64_t nxt[16];
             auto fetch = [&](unsigned z) {
@@ -991,14 +994,32 @@ namespace sealhip
                 }
                 p2_tile<FP, D1, false, false, false, false, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
                 uint64_t val[16];
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    val[e] = fwd_out_lazy<FP, ICLS, kP2Out<ICLS, D1>>(x[e], m); // < 4q
                 uint64_t *O = ((outer & 1) ? a.epi_out1 : a.epi_out0) + (size_t)(outer >> 1) * a.epi_out_stride + row0;
-                emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t tv) {
-                    const uint64_t s = add_mod(mul_shoup(av[k], pm.w, pm.wq, q), cv[k], q); // c + S P^-1, canonical
-                    O[off] = mul_shoup(s + 4 * q - tv, mul.w, mul.wq, q);
-                });
+                if constexpr (FP)
+                {
+                    // double-precision primes: the tail stays in the field the transform worked in (round 3).  S and c are canonical
+                    // (exact doubles), the constants balanced: |S P^-1 mod q| <= 0.69 q, + c < 1.69 q, - NTT(x) (|.| <= q/2) < 2.2 q,
+                    // times q_last^-1 -> 0.91 q, fixed and made canonical: 27 vector instructions a coefficient where the
+                    // 64-bit Shoup products of the integer form took 69 (llvm-objdump, round 3)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        val[e] = F::raw(x[e]);
+                    emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t tv) {
+                        const double s = fp_mulmod(fp_from_u52(av[k]), pm_fp, m.q, m.qinv) + fp_from_u52(cv[k]);
+                        const double r = fp_mulmod(s - fp_from_bits(tv), mul_fp, m.q, m.qinv);
+                        O[off] = fp_to_canon(fp_fix(r, m.q, m.qinv), m);
+                    });
+                }
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        val[e] = fwd_out_lazy<FP, ICLS, kP2Out<ICLS, D1>>(x[e], m); // < 4q
+                    emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t tv) {
+                        const uint64_t s = add_mod(mul_shoup(av[k], pm.w, pm.wq, q), cv[k], q); // c + S P^-1, canonical
+                        O[off] = mul_shoup(s + 4 * q - tv, mul.w, mul.wq, q);
+                    });
+                }
             }
         }
 
