@@ -17,7 +17,16 @@ def _same(dev_ct, ref_cts, what):
         assert got[b].shape == exp.shape, "%s: shape %s vs %s" % (what, got[b].shape, exp.shape)
         if not np.array_equal(got[b], exp):
             bad = np.argwhere(got[b] != exp)
-            raise AssertionError("%s item %d: %d of %d words differ, first at %s" % (what, b, len(bad), exp.size, tuple(bad[0])))
+            # what a rare failure looks like matters more than that it happened: where the words are, what they hold, and whether
+            # a second read of the same device memory sees them too (a wrong kernel result stays, a wrong transfer does not)
+            wrong = got[b][tuple(bad.T)]
+            again = DeviceSide.out(dev_ct)[b]
+            raise AssertionError(
+                "%s item %d: %d of %d words differ, first at %s, last at %s; %d of them are zero; first wrong words %s (expected %s); "
+                "a second read of the device memory %s" % (
+                    what, b, len(bad), exp.size, tuple(int(v) for v in bad[0]), tuple(int(v) for v in bad[-1]), int(np.sum(wrong == 0)),
+                    [hex(int(v)) for v in wrong[:3]], [hex(int(v)) for v in exp[tuple(bad.T)][:3]],
+                    "equals the first" if np.array_equal(again, got[b]) else ("is CORRECT" if np.array_equal(again, exp) else "differs from both")))
         assert dev_ct.is_ntt_form() == info["is_ntt_form"], what
         assert dev_ct.scale() == info["scale"], "%s: scale %r vs %r" % (what, dev_ct.scale(), info["scale"])
         assert dev_ct.correction_factor() == info["correction_factor"], what
