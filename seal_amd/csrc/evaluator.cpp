@@ -885,6 +885,26 @@ namespace sealhip
         multiply_inplace(e, e);
     }
 
+    // (c0, c1) x (d0, d1) -> three polynomials in e1, NTT form (evaluator.cpp:626-707).  When e1's slab has room the product is
+    // formed in place (every thread reads its four words before it writes its three); otherwise it goes straight into a new
+    // slab that e1 adopts - no copy of the two old polynomials, no zeroing of the third.
+    void Evaluator::tensor_2x2(Ciphertext &e1, const Ciphertext &e2, const Level &lvl, const PlaneGeom &g) const
+    {
+        const size_t words = 3 * g.words();
+        const uint64_t *x = e1.data(), *y = (&e1 == &e2) ? x : e2.data(); // (completes a pending key-switch tail)
+        if (e1.capacity_words() >= words)
+        {
+            e1.reshape_uninitialized(&lvl, 3); // enough room: the words stay where they are
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, x, y, e1.data(), g, stream_), "multiply 2x2");
+        }
+        else
+        {
+            uint64_t *out = DevicePool::global().alloc_words(words);
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, x, y, out, g, stream_), "multiply 2x2");
+            e1.adopt(&lvl, 3, out, words);
+        }
+    }
+
     void Evaluator::ckks_multiply(Ciphertext &e1, const Ciphertext &e2) const
     {
         if (!(e1.is_ntt_form() && e2.is_ntt_form()))
@@ -900,11 +920,7 @@ namespace sealhip
         double new_scale = e1.scale() * e2.scale();
         PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
         if (dest == 3)
-        {
-            e1.resize(&lvl, 3, stream_);
-            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, e1.data(), self ? e1.data() : e2.data(), e1.data(), g, stream_),
-               "ckks_multiply");
-        }
+            tensor_2x2(e1, self ? e1 : e2, lvl, g);
         else
         {
             size_t words = dest * g.words();
@@ -935,11 +951,7 @@ namespace sealhip
         const uint64_t cf = host::mulmod(e1.correction_factor(), e2.correction_factor(), context_.plain_modulus());
         PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
         if (dest == 3)
-        {
-            e1.resize(&lvl, 3, stream_);
-            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, e1.data(), self ? e1.data() : e2.data(), e1.data(), g, stream_),
-               "bgv_multiply");
-        }
+            tensor_2x2(e1, self ? e1 : e2, lvl, g);
         else
         {
             size_t words = dest * g.words();

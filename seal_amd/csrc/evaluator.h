@@ -78,6 +78,7 @@ namespace sealhip
         void adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words);
         // same shape change as resize() but the contents are left undefined (the caller overwrites them)
         void reshape_uninitialized(const Level *level, size_t size);
+        size_t capacity_words() const { return capacity_words_; }
         void release();
 
     private:
@@ -311,6 +312,7 @@ namespace sealhip
             Scratch &delta, const uint64_t *a, size_t a_stride, const ShoupOp *mul, unsigned ncomp, size_t items, uint64_t *out0,
             uint64_t *out1, size_t out_stride, int epi) const;
         void ckks_multiply(Ciphertext &e1, const Ciphertext &e2) const;
+        void tensor_2x2(Ciphertext &e1, const Ciphertext &e2, const Level &lvl, const struct PlaneGeom &g) const;
         void mod_switch_scale_to_next(Ciphertext &encrypted) const;
         void mod_switch_drop_to_next(Ciphertext &encrypted) const;
         void rotate_internal(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
