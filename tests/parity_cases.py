@@ -994,3 +994,45 @@ def case_deferred_tail_two_readers(n=8192, bits=(50, 40, 40, 60), rounds=6):
         _eq(d.out(out1)[0], (ref_relin + z1) % qk, "reader 1, round %d" % r)
         _eq(d.out(out2)[0], (ref_relin + z2) % qk, "reader 2, round %d" % r)
         _eq(d.out(a)[0], ref_relin, "the shared operand, round %d" % r)
+
+
+# ---- the 2 x 2 tensor product grows its first operand in two ways (evaluator.cpp: tensor_2x2)
+def case_product_growth(scheme, n, bits, tbits=20, batch=3, seed=51):
+    """multiply_inplace / square_inplace of a size-2 ciphertext: into a new slab when the operand's slab holds two polynomials
+    (a fresh ciphertext), in place when it has room for three (a ciphertext that was relinearized before) - word for word the
+    reference's product both times, for distinct operands and for the square (evaluator.cpp:626-707, 878-1142)"""
+    primes = coeff_modulus_create(n, list(bits))
+    t = plain_modulus_batching(n, tbits) if scheme != "ckks" else 0
+    K = len(primes) - 1
+    o = Oracle(scheme, n, primes, t)
+    d = DeviceSide(scheme, n, primes, t)
+    d.upload_keys(o)
+    rng = np.random.default_rng(seed)
+    ntt = scheme != "bfv"
+    scale = 2.0 ** 10 if scheme == "ckks" else 1.0
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    for square in (False, True):
+        a = d.ct(xs, scale=scale, is_ntt=ntt)
+        if square:
+            d.ev.square_inplace(a)                                    # fresh slab of two polynomials: new slab
+            want = [o.multiply(x, x) for x in xs]
+        else:
+            d.ev.multiply_inplace(a, d.ct(ys, scale=scale, is_ntt=ntt))
+            want = [o.multiply(x, y) for x, y in zip(xs, ys)]
+        got = DeviceSide.out(a)
+        for b in range(batch):
+            _eq(got[b], want[b], "%s product into a new slab (square=%s) item %d" % (scheme, square, b))
+        d.ev.relinearize_inplace(a, d.rlk)                             # back to two polynomials, the slab keeps room for three
+        if scheme == "ckks":
+            a.set_scale(scale)
+        two = [o.relinearize(w) for w in want]
+        if square:
+            d.ev.square_inplace(a)
+            want2 = [o.multiply(w, w) for w in two]
+        else:
+            d.ev.multiply_inplace(a, d.ct(ys, scale=scale, is_ntt=ntt))
+            want2 = [o.multiply(w, y) for w, y in zip(two, ys)]
+        got = DeviceSide.out(a)
+        for b in range(batch):
+            _eq(got[b], want2[b], "%s product in place (square=%s) item %d" % (scheme, square, b))

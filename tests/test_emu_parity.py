@@ -209,6 +209,14 @@ def test_mod_reduce(emu):
     P.case_mod_reduce(8192, [50, 40, 60, 50], batch=1)
 
 
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 4096, [54, 42, 55]), ("ckks", 8192, [50, 40, 60]), ("bgv", 2048, [40, 40, 45]),
+                                            ("bfv", 1024, [36, 36, 37])])
+def test_product_growth(emu, scheme, n, bits):
+    """the 2 x 2 product into a new slab and in place (the shape of the one device fuzz mismatch of round 3: CKKS, N = 4096,
+    three items, square of a fresh ciphertext)"""
+    P.case_product_growth(scheme, n, bits)
+
+
 def test_deferred_tail_two_readers(emu):
     P.case_deferred_tail_two_readers(8192, (50, 40, 60), rounds=2)
 

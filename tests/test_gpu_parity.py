@@ -492,6 +492,14 @@ def test_graph_capture_replay(gpu, n, bits, batch):
     d.ev.set_transparent_check(False)
 
 
+@pytest.mark.parametrize("scheme,n,bits", [("ckks", 4096, [54, 42, 55]), ("ckks", 16384, [60, 50, 50, 60]), ("bgv", 8192, [50, 40, 56]),
+                                            ("bfv", 4096, [36, 36, 37])])
+def test_product_growth(gpu, scheme, n, bits):
+    """the 2 x 2 product into a new slab and in place, distinct operands and squares, three items"""
+    for seed in (51, 52, 53):
+        P.case_product_growth(scheme, n, bits, seed=seed)
+
+
 def test_deferred_tail_two_readers(gpu):
     """two threads read one ciphertext whose key-switch tail is pending: it runs once, both see the completed words"""
     P.case_deferred_tail_two_readers(8192, (50, 40, 40, 60), rounds=8)
