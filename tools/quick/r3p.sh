@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 3: kernel table of BFV configs[3] at batch 256 (profiles/r03_bfv_c4_kernel_stats.txt)
 set -u
 export TMPDIR=/tmp
 R=$(pwd); O=$R/gpurun_out/r3p; mkdir -p $O

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 3: mixed chain at N = 2^14 (C3) and the per-size NTT table, round-2 base against the current build
 set -u
 export TMPDIR=/tmp
 cp seal_amd/lib/libsealhip.so /tmp/keep.so
