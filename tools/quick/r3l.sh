@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: double-precision forward single-launch kernel without prefetch at 2^13 (experiment (g))
+# round 3: double-precision forward single-launch kernel without prefetch at 2^13
 set -u
 export TMPDIR=/tmp
 cp seal_amd/lib/libsealhip.so /tmp/keep.so

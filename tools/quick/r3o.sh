@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: BEHZ with limbs split on the host (behz4) - BFV tests, then A/B on BFV configs[3] (experiment (k))
+# round 3: BEHZ with limbs split on the host (behz4) - BFV tests, then A/B on BFV configs[3]
 set -u
 export TMPDIR=/tmp
 R=$(pwd); O=$R/gpurun_out/r3q; mkdir -p $O
