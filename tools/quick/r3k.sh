@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: double-precision inverse single-launch kernel with / without prefetch and twiddle variants of profiles/r03_integer_backend_experiments.txt)
+# round 3: double-precision inverse single-launch kernel with / without prefetch and twiddle variants
 set -u
 export TMPDIR=/tmp
 R=$(pwd); O=$R/gpurun_out/r3k; mkdir -p $O

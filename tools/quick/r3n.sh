@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: last-stage twiddles of the integer ks2 in LDS (SEALHIP_KS2_INT_TWB3
+# round 3: last-stage twiddles of the integer ks2 in LDS (SEALHIP_KS2_INT_TWB3)
 set -u
 export TMPDIR=/tmp
 for r in 1 2; do for v in notwb3 twb3; do

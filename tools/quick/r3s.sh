@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: the two class runs of the single-launch kernels at N = 2^14 side by side or in sequence (SEALHIP_FUSED_FORK14
+# round 3: the two class runs of the single-launch kernels at N = 2^14 side by side or in sequence (SEALHIP_FUSED_FORK14)
 set -u
 export TMPDIR=/tmp
 cp seal_amd/lib/libsealhip.so /tmp/keep.so

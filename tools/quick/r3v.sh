@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: same-box A/B of seal_amd/lib/variants/{pre,now}.so on BFV configs[3] and the headline)
+# round 3: same-box A/B of seal_amd/lib/variants/{pre,now}.so on BFV configs[3] and the headline
 set -u
 export TMPDIR=/tmp
 cp seal_amd/lib/libsealhip.so /tmp/keep.so
