@@ -221,6 +221,17 @@ def case_key_save(scheme, n, bits, steps=(1,)):
     empty = S.RelinKeys(d.ctx)
     e = empty.save_bytes()
     assert len(e) == 16 + 32 + 8 and struct.unpack_from("<Q", e, 48)[0] == 0
+    # refusals: a buffer that is too small, an unknown compression mode, a digit-parallel slice (one rank's digits only)
+    import ctypes as C
+    from seal_amd import _native as N
+    small, nb = (C.c_uint8 * 64)(), C.c_int64()
+    assert _outcome(lambda: N.check(N.lib().KSwitchKeys_Save(own._h, small, C.c_uint64(64), C.c_uint8(0), C.byref(nb)))) == S.InvalidArgument
+    assert _outcome(lambda: own.save_bytes(compr_mode=9)) == S.InvalidArgument
+    if K >= 2:
+        words = np.zeros((1, 2, len(primes), n), dtype=np.uint64)
+        part = S.RelinKeys(d.ctx)
+        part.set_key_digits(0, 1, words)          # digit 1 only
+        assert _outcome(lambda: part.save_bytes()) == S.LogicError
 
 
 def _walk_key_digits(stream):
