@@ -1,0 +1,57 @@
+"""bench.py, CPU baseline: the reference's own Evaluator (oracle/_ref = Microsoft SEAL, HEXL off) timed on this host's cores on a
+bounded sample.  Checker / baseline only - never the thing measured."""
+import os
+import sys
+
+
+def physical_cores():
+    try:
+        import psutil
+        return psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(workload, scheme, n, primes, t_plain, args):
+    pipeline = {"headline": "ckks_mul_relin_rescale", "bfv_c4": "bfv_mul_relin_modswitch", "rotate_c5": "rotate"}[workload]
+    try:
+        import sealref
+        if sealref.available():
+            logical = args.cpu_threads or (os.cpu_count() or 1)
+            phys = min(physical_cores(), logical)
+            ref = sealref.RefContext(scheme, n, primes, t_plain)
+            ref.keygen_relin()
+            if pipeline == "rotate":
+                ref.keygen_galois_steps([1])
+            reps = args.cpu_reps
+            secs = ref.time_pipeline(pipeline, logical, reps)
+            out = dict(value=round(logical * reps / secs, 3), unit="ciphertexts/s", cores=logical, kind="reference",
+                       sample="%d threads x %d ciphertexts each; every thread builds its inputs, runs one untimed pass, waits at a "
+                              "start barrier; wall time from the barrier to the last thread's finish; per-thread "
+                              "MemoryPoolHandle::New(); seal::Evaluator, HEXL off, same parameters" % (logical, reps))
+            if phys != logical:
+                secs_p = ref.time_pipeline(pipeline, phys, reps)
+                out["physical_cores_run"] = dict(value=round(phys * reps / secs_p, 3), cores=phys)
+            one = ref.time_pipeline(pipeline, 1, 2)
+            out["single_thread_value"] = round(2 / one, 3)
+            return out
+    except Exception as e:  # the baseline must never take the benchmark down
+        sys.stderr.write("cpu_baseline(reference) unavailable: %r\n" % (e,))
+    if workload != "headline":
+        return None
+    try:
+        import numpy as np
+        import sealoracle
+        from oracle import rand_ct
+        rng = np.random.default_rng(0x5EA1)
+        K = len(primes) - 1
+        po = sealoracle.PortContext("ckks", n, primes)
+        a, b = rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)
+        rlk = np.stack([np.stack([np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in primes]) for _ in range(2)])
+                        for _ in range(K)])
+        secs, _ = po.time_ckks_pipeline(a, b, rlk, 1)
+        return dict(value=round(1 / secs, 4), unit="ciphertexts/s", cores=1, kind="port",
+                    sample="1 ciphertext, plain-C restatement (oracle/seal_oracle.c), 1 thread")
+    except Exception as e:
+        sys.stderr.write("cpu_baseline(port) unavailable: %r\n" % (e,))
+    return None

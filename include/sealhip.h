@@ -415,6 +415,13 @@ SHL_FUNC SealHip_ReleasePool(void);
  * change the protection of their own buffers (integration/seal_evaluator_hip.cpp); process-wide, off by default. */
 SHL_FUNC SealHip_SetStagedHostCopies(bool enabled);
 SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
+/* Diagnostics.  The library installs a std::terminate handler when it is loaded: an exception that escapes where none may
+ * (a destructor, a host worker thread) prints its message and the sticky HIP error before the process aborts.
+ * SealHip_InstallAbortTrace(path) - or SEALHIP_ABORT_TRACE=<path> in the environment - additionally catches SIGABRT, appends the
+ * call stack of the aborting thread to `path` (the ROCm runtime aborts the process itself when the device reports a memory
+ * fault: its handler on the stack tells that case from a C++ one) and then lets the abort proceed.  Opt-in: signal
+ * dispositions belong to the host program. */
+SHL_FUNC SealHip_InstallAbortTrace(const char *path);
 /* Environment.  The product library reads five variables, each exercised by a parity test; everything else that earlier
  * rounds could switch at run time (superseded kernels, fork / no-fork of the side streams, ...) only exists in development
  * builds made with -DSEALHIP_AB_SWITCHES (seal_amd/csrc/modarith.h: shl_ab_getenv).

@@ -7,6 +7,7 @@ with shared metadata; numpy arrays cross the boundary as [size][batch][K][N] uin
 (for batch == 1 that is Ciphertext::data(), ciphertext.h:337-349).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -1195,6 +1196,17 @@ def set_device(index):
 def release_pool():
     """return the library's cached HBM blocks to the driver"""
     N.check(N.lib().SealHip_ReleasePool())
+
+
+def set_staged_host_copies(enabled):
+    """host <-> device copies of ciphertext words through the library's pinned bounce buffers (sealhip.h) instead of a direct
+    hipMemcpy on the caller's pageable buffer; process-wide"""
+    N.check(N.lib().SealHip_SetStagedHostCopies(C.c_bool(enabled)))
+
+
+def install_abort_trace(path):
+    """append the call stack of an aborting thread to `path` before the process dies (sealhip.h: SealHip_InstallAbortTrace)"""
+    N.check(N.lib().SealHip_InstallAbortTrace(C.c_char_p(os.fsencode(path))))
 
 
 def pool_stats():

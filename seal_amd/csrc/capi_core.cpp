@@ -332,6 +332,7 @@ extern "C"
         auto c = as<Context>(context);
         if (&ct->context() != c)
             throw std::invalid_argument("ciphertext belongs to another context");
+        hip_ok(hipDeviceSynchronize(), "sync"); // the copy / zero fill below run on the NULL stream: nothing queued elsewhere may still touch the words
         ct->resize(c->level_by_parms_id(parms_id), size, nullptr);
         SHL_CATCH
     }

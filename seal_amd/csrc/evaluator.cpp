@@ -20,12 +20,14 @@ namespace sealhip
     }
     void Evaluator::defer_tail(Ciphertext &e, uint64_t *acc) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         e.lazy_ = new LazyTail{ this, acc };
         std::lock_guard<std::mutex> lock(lazy_mu_);
         lazy_cts_.push_back(&e);
     }
     LazyTail Evaluator::detach_tail(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const LazyTail t = *e.lazy_;
         delete e.lazy_;
         e.lazy_ = nullptr;
@@ -35,6 +37,7 @@ namespace sealhip
     }
     void Evaluator::forget_tail(const Ciphertext &e, LazyTail t) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         {
             std::lock_guard<std::mutex> lock(lazy_mu_);
             lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &e), lazy_cts_.end());
@@ -44,20 +47,20 @@ namespace sealhip
     }
     void Evaluator::complete_tail(Ciphertext &e, LazyTail t) const
     {
+        const hipStream_t caller = DevicePool::thread_stream(); // (read before this call's own scope replaces it)
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         {
             std::lock_guard<std::mutex> lock(lazy_mu_);
             lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &e), lazy_cts_.end());
         }
         // the sums were produced on this evaluator's stream: the tail runs there too; a caller working on another stream
         // (another evaluator, a host copy) continues only when it is done
-        const hipStream_t caller = DevicePool::thread_stream();
         static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr; // tests: which tail ran
         if (trace)
             std::fprintf(stderr, "[ks] plain tail\n");
         g_tail_plain++;
         try
         {
-            StreamScope scope(stream_);
             switch_key_finish(e, t.acc, 1);
         }
         catch (...)
@@ -359,6 +362,7 @@ namespace sealhip
     }
     void Evaluator::throw_if_transparent(const Ciphertext &ct) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (transparent_check_ && is_transparent(ct))
             throw std::logic_error("result ciphertext is transparent");
     }
@@ -366,6 +370,7 @@ namespace sealhip
     // ---- negate / add / sub (evaluator.cpp:130-350)
     void Evaluator::negate_inplace(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         PlaneGeom g{ (unsigned)context_.log_n(), e.level()->K, (unsigned)e.batch() };
         if (e.size())
@@ -375,6 +380,7 @@ namespace sealhip
 
     void Evaluator::add_inplace(Ciphertext &e1, const Ciphertext &e2) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e1, "encrypted1");
         check_valid(e2, "encrypted2");
         if (e1.level() != e2.level())
@@ -415,6 +421,7 @@ namespace sealhip
 
     void Evaluator::sub_inplace(Ciphertext &e1, const Ciphertext &e2) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e1, "encrypted1");
         check_valid(e2, "encrypted2");
         if (e1.level() != e2.level())
@@ -455,6 +462,7 @@ namespace sealhip
     // ---- transforms (evaluator.cpp:2289-2382)
     void Evaluator::transform_to_ntt_inplace(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (e.is_ntt_form())
             throw std::invalid_argument("encrypted is already in NTT form");
@@ -466,6 +474,7 @@ namespace sealhip
     }
     void Evaluator::transform_from_ntt_inplace(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (!e.is_ntt_form())
             throw std::invalid_argument("encrypted_ntt is not in NTT form");
@@ -498,6 +507,7 @@ namespace sealhip
     // coefficients modulo t -> [K][N] residues of the centred lift (evaluator.cpp:2098-2125, 2243-2282), times scale_by mod t
     void Evaluator::plain_to_rns(const Plaintext &plain, const Level &lvl, uint64_t scale_by, uint64_t *out) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (context_.scheme() == Scheme::ckks)
             throw std::invalid_argument("CKKS plain must be in NTT form");
         ck(k_plain_lift(context_.dev_mods(), host::make_mod(context_.plain_modulus()), plain.data(), plain.coeff_count(), scale_by,
@@ -507,6 +517,7 @@ namespace sealhip
 
     void Evaluator::transform_to_ntt_inplace(Plaintext &plain, const uint64_t *parms_id) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(plain);
         const Level *lvl = context_.level_by_parms_id(parms_id);
         if (!lvl)
@@ -531,6 +542,7 @@ namespace sealhip
 
     void Evaluator::mod_switch_to_next_inplace(Plaintext &plain) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         // mod_switch_drop_to_next(Plaintext) (evaluator.cpp:1369-1402): the flat [K][N] array keeps its first K-1 components
         check_valid(plain);
         if (!plain.is_ntt_form())
@@ -545,6 +557,7 @@ namespace sealhip
     }
     void Evaluator::mod_switch_to_inplace(Plaintext &plain, const uint64_t *parms_id) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(plain);
         const Level *target = context_.level_by_parms_id(parms_id);
         if (!plain.is_ntt_form())
@@ -559,6 +572,7 @@ namespace sealhip
 
     void Evaluator::add_plain_inplace(Ciphertext &e, const Plaintext &plain) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         // add_plain_inplace / sub_plain_inplace share everything but the sign
         check_valid(e, "encrypted");
         check_valid(plain);
@@ -566,12 +580,14 @@ namespace sealhip
     }
     void Evaluator::sub_plain_inplace(Ciphertext &e, const Plaintext &plain) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         check_valid(plain);
         addsub_plain(e, plain, 1);
     }
     void Evaluator::addsub_plain(Ciphertext &e, const Plaintext &plain, int op) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const Scheme scheme = context_.scheme();
         if (scheme == Scheme::bfv)
         {
@@ -631,6 +647,7 @@ namespace sealhip
 
     void Evaluator::multiply_plain_ntt(Ciphertext &e, const uint64_t *plain_rns, const Level *plain_level, double plain_scale) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         // multiply_plain_ntt (evaluator.cpp:2157-2194)
         if (e.level() != plain_level)
             throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
@@ -648,6 +665,7 @@ namespace sealhip
     // the branch has to be reproduced.  Costs one 24-byte read-back per coefficient-form multiply_plain.
     bool Evaluator::mul_plain_monomial(Ciphertext &e, const Plaintext &plain) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const Level &lvl = *e.level();
         Scratch stats(3);
         ck(k_plain_stats(plain.data(), plain.coeff_count(), stats.p, stream_), "plain stats");
@@ -690,6 +708,7 @@ namespace sealhip
 
     void Evaluator::multiply_plain_inplace(Ciphertext &e, const Plaintext &plain) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         check_valid(plain);
         const Level &lvl = *e.level();
@@ -740,6 +759,7 @@ namespace sealhip
 
     void Evaluator::add_many(const std::vector<const Ciphertext *> &encrypteds, Ciphertext &destination) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (encrypteds.empty())
             throw std::invalid_argument("encrypteds cannot be empty");
         for (const Ciphertext *c : encrypteds)
@@ -752,6 +772,7 @@ namespace sealhip
 
     void Evaluator::multiply_many(const std::vector<const Ciphertext *> &encrypteds, const KSwitchKeys &relin_keys, Ciphertext &destination) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         // the product tree of evaluator.cpp:1649-1723, every product relinearized
         if (encrypteds.empty())
             throw std::invalid_argument("encrypteds vector must not be empty");
@@ -798,6 +819,7 @@ namespace sealhip
 
     void Evaluator::exponentiate_inplace(Ciphertext &e, uint64_t exponent, const KSwitchKeys &relin_keys) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         if (relin_keys.context() != &context_)
@@ -816,6 +838,7 @@ namespace sealhip
     // ---- multiply (evaluator.cpp:352-708)
     void Evaluator::multiply_inplace(Ciphertext &e1, const Ciphertext &e2) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e1, "encrypted1");
         check_valid(e2, "encrypted2");
         if (e1.level() != e2.level())
@@ -840,6 +863,7 @@ namespace sealhip
     }
     void Evaluator::multiply(const Ciphertext &e1, const Ciphertext &e2, Ciphertext &dest) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         // evaluator.h:239-247: destination = encrypted1; multiply_inplace(destination, encrypted2).
         // Device-resident fast path: the common size-2 x size-2 CKKS product writes the three result
         // polynomials straight into `dest` instead of copying encrypted1 first.
@@ -879,6 +903,7 @@ namespace sealhip
 
     void Evaluator::square_inplace(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         // ckks_square / bfv_square compute (c0^2, 2 c0 c1, c1^2) = the product of e with itself
         // (evaluator.cpp:878-1142); canonical results coincide with multiply(e, e).
         check_valid(e, "encrypted");
@@ -890,6 +915,7 @@ namespace sealhip
     // slab that e1 adopts - no copy of the two old polynomials, no zeroing of the third.
     void Evaluator::tensor_2x2(Ciphertext &e1, const Ciphertext &e2, const Level &lvl, const PlaneGeom &g) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const size_t words = 3 * g.words();
         const uint64_t *x = e1.data(), *y = (&e1 == &e2) ? x : e2.data(); // (completes a pending key-switch tail)
         if (e1.capacity_words() >= words)
@@ -899,7 +925,7 @@ namespace sealhip
         }
         else
         {
-            uint64_t *out = DevicePool::global().alloc_words(words);
+            uint64_t *out = DevicePool::global().alloc_words(words, stream_);
             ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, x, y, out, g, stream_), "multiply 2x2");
             e1.adopt(&lvl, 3, out, words);
         }
@@ -907,6 +933,7 @@ namespace sealhip
 
     void Evaluator::ckks_multiply(Ciphertext &e1, const Ciphertext &e2) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (!(e1.is_ntt_form() && e2.is_ntt_form()))
             throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
         const Level &lvl = *e1.level();
@@ -938,6 +965,7 @@ namespace sealhip
     // NTT-form operands; the scale is untouched and the correction factors multiply modulo t.
     void Evaluator::bgv_multiply(Ciphertext &e1, const Ciphertext &e2) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (!(e1.is_ntt_form() && e2.is_ntt_form()))
             throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
         const Level &lvl = *e1.level();
@@ -965,6 +993,7 @@ namespace sealhip
 
     void Evaluator::bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (e1.is_ntt_form() || e2.is_ntt_form())
             throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
         const Level &lvl = *e1.level();

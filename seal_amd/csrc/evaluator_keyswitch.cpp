@@ -6,6 +6,7 @@ namespace sealhip
     // ---- relinearize (evaluator.cpp:1144-1199)
     void Evaluator::relinearize_inplace(Ciphertext &e, const KSwitchKeys &relin_keys) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         if (relin_keys.context() != &context_)
@@ -28,6 +29,7 @@ namespace sealhip
 
     void Evaluator::relinearize_partial(Ciphertext &e, const KSwitchKeys &relin_keys, unsigned j0, unsigned j1, uint64_t *acc) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         if (relin_keys.context() != &context_ && !(j0 == j1 && !relin_keys.context())) // a rank without digits may hold no key
@@ -38,6 +40,7 @@ namespace sealhip
     }
     void Evaluator::relinearize_finish(Ciphertext &e, uint64_t *acc, unsigned parts) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level() || e.size() != 3)
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         switch_key_finish(e, acc, parts);
@@ -47,6 +50,7 @@ namespace sealhip
     void Evaluator::apply_galois_partial(
         Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys, unsigned j0, unsigned j1, uint64_t *acc) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (galois_keys.context() != &context_ && !(j0 == j1 && !galois_keys.context()))
             throw std::invalid_argument("galois_keys is not valid for encryption parameters");
@@ -70,6 +74,7 @@ namespace sealhip
     }
     void Evaluator::apply_galois_finish(Ciphertext &e, uint64_t *acc, unsigned parts) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level() || e.size() != 2)
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         switch_key_finish(e, acc, parts);
@@ -91,6 +96,7 @@ namespace sealhip
         const Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, unsigned j0, unsigned j1,
         uint64_t *acc_out, unsigned split) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (!target)
             throw std::invalid_argument("target_iter");
@@ -209,6 +215,7 @@ namespace sealhip
 
     void Evaluator::switch_key_finish(Ciphertext &e, uint64_t *acc_p, unsigned parts) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (!acc_p)
             throw std::invalid_argument("acc");
@@ -303,6 +310,7 @@ namespace sealhip
 
     void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         // Small batches do not fill the chip: one workgroup per (target modulus, tile, batch item) is 16 (K+1) workgroups per
@@ -344,6 +352,7 @@ namespace sealhip
     // (divide_and_round_q_last_ntt_inplace); see NttTail2 (ntt_kernels.h) for the algebra.
     void Evaluator::switch_key_finish_rescale(Ciphertext &e, uint64_t *acc_p, const Level *next, double destination_scale) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const Level &lvl = *e.level();
         const Level &klvl = context_.key_level();
         const unsigned K = lvl.K, L = klvl.K;
@@ -458,6 +467,7 @@ namespace sealhip
 
     void Evaluator::switch_key_pack_targets(const Ciphertext &e, const uint64_t *acc, unsigned nranks, uint64_t *send, uint64_t *sp) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const unsigned m = switch_key_slots(e, nranks);
         if (!acc || !send || !sp)
             throw std::invalid_argument("buffer");
@@ -467,6 +477,7 @@ namespace sealhip
     void Evaluator::switch_key_finish_owned(
         const Ciphertext &e, const uint64_t *recv, const uint64_t *sp, unsigned nranks, unsigned rank, uint64_t *own) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const unsigned m = switch_key_slots(e, nranks);
         if (rank >= nranks)
             throw std::invalid_argument("rank");
@@ -538,6 +549,7 @@ namespace sealhip
 
     void Evaluator::switch_key_add_gathered(Ciphertext &e, const uint64_t *all, unsigned nranks) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const unsigned m = switch_key_slots(e, nranks);
         if (!all)
             throw std::invalid_argument("buffer");
@@ -550,6 +562,7 @@ namespace sealhip
 
     void Evaluator::switch_key_exchange_finish(Ciphertext &e, uint64_t *acc, Comm &comm, KsExchange how) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const unsigned G = (unsigned)comm.size();
         const size_t words = switch_key_acc_words(e);
         if (how == KsExchange::all_reduce || context_.scheme() != Scheme::ckks)
@@ -572,6 +585,7 @@ namespace sealhip
 
     void Evaluator::relinearize_inplace(Ciphertext &e, const KSwitchKeys &relin_keys, Comm &comm, KsExchange how) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         unsigned first, count;
@@ -585,6 +599,7 @@ namespace sealhip
 
     void Evaluator::apply_galois_inplace(Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys, Comm &comm, KsExchange how) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         unsigned first, count;
@@ -597,6 +612,7 @@ namespace sealhip
 
     void Evaluator::rotate_vector_inplace(Ciphertext &e, int steps, const KSwitchKeys &galois_keys, Comm &comm, KsExchange how) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (context_.scheme() != Scheme::ckks)
             throw std::logic_error("unsupported scheme");
         if (&e.context() != &context_ || !e.level())

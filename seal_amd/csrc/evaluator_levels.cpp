@@ -6,6 +6,7 @@ namespace sealhip
     // ---- modulus switching (evaluator.cpp:1201-1647)
     void Evaluator::mod_switch_scale_to_next(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const Scheme scheme = context_.scheme();
         if (scheme == Scheme::bfv && e.is_ntt_form())
             throw std::invalid_argument("BFV encrypted cannot be in NTT form");
@@ -126,6 +127,7 @@ namespace sealhip
 
     void Evaluator::mod_switch_drop_to_next(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const Scheme scheme = context_.scheme();
         if (scheme == Scheme::bfv && e.is_ntt_form())
             throw std::invalid_argument("BFV encrypted cannot be in NTT form");
@@ -148,6 +150,7 @@ namespace sealhip
 
     void Evaluator::mod_switch_to_next_inplace(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (e.level() == &context_.last_level())
             throw std::invalid_argument("end of modulus switching chain reached");
@@ -170,6 +173,7 @@ namespace sealhip
 
     void Evaluator::mod_switch_to_inplace(Ciphertext &e, const uint64_t *parms_id) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const Level *target = context_.level_by_parms_id(parms_id);
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
@@ -183,6 +187,7 @@ namespace sealhip
 
     void Evaluator::rescale_to_next_inplace(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (e.level() == &context_.last_level())
             throw std::invalid_argument("end of modulus switching chain reached");
@@ -202,6 +207,7 @@ namespace sealhip
 
     void Evaluator::rescale_to_inplace(Ciphertext &e, const uint64_t *parms_id) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         const Level *target = context_.level_by_parms_id(parms_id);
         if (!target)
@@ -217,6 +223,7 @@ namespace sealhip
 
     void Evaluator::mod_reduce_to_next_inplace(Ciphertext &e) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (e.level() == &context_.last_level())
             throw std::invalid_argument("end of modulus switching chain reached");
@@ -227,6 +234,7 @@ namespace sealhip
     // evaluator.cpp:1625-1647
     void Evaluator::mod_reduce_to_inplace(Ciphertext &e, const uint64_t *parms_id) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         const Level *target = context_.level_by_parms_id(parms_id);
@@ -241,6 +249,7 @@ namespace sealhip
     // ---- Galois automorphisms and rotations (evaluator.cpp:2384-2559, evaluator.h:1072-1375)
     void Evaluator::apply_galois_inplace(Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
         if (galois_keys.context() != &context_)
             throw std::invalid_argument("galois_keys is not valid for encryption parameters");
@@ -289,6 +298,7 @@ namespace sealhip
 
     void Evaluator::rotate_internal(Ciphertext &e, int steps, const KSwitchKeys &galois_keys) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         if (!context_.using_batching())
@@ -315,6 +325,7 @@ namespace sealhip
     }
     void Evaluator::conjugate_internal(Ciphertext &e, const KSwitchKeys &galois_keys) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
         if (!context_.using_batching())
@@ -323,24 +334,28 @@ namespace sealhip
     }
     void Evaluator::rotate_rows_inplace(Ciphertext &e, int steps, const KSwitchKeys &gk) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (context_.scheme() != Scheme::bfv && context_.scheme() != Scheme::bgv)
             throw std::logic_error("unsupported scheme");
         rotate_internal(e, steps, gk);
     }
     void Evaluator::rotate_columns_inplace(Ciphertext &e, const KSwitchKeys &gk) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (context_.scheme() != Scheme::bfv && context_.scheme() != Scheme::bgv)
             throw std::logic_error("unsupported scheme");
         conjugate_internal(e, gk);
     }
     void Evaluator::rotate_vector_inplace(Ciphertext &e, int steps, const KSwitchKeys &gk) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (context_.scheme() != Scheme::ckks)
             throw std::logic_error("unsupported scheme");
         rotate_internal(e, steps, gk);
     }
     void Evaluator::complex_conjugate_inplace(Ciphertext &e, const KSwitchKeys &gk) const
     {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (context_.scheme() != Scheme::ckks)
             throw std::logic_error("unsupported scheme");
         conjugate_internal(e, gk);

@@ -25,6 +25,20 @@ namespace sealhip
             static thread_local ThreadState s;
             return s;
         }
+#ifdef SEALHIP_POOL_EXACT
+        // sanitizer builds (tools/asan_emu.sh): a block is exactly the words that were asked for and a cached block serves only
+        // requests of exactly its size, so that the heap's red zones sit directly behind the last word a kernel may touch - the
+        // 256 KiB rounding below would swallow an overrun (a prefetch one tile past the end) without a report
+        constexpr size_t kGran = 8;
+        size_t round_bytes(size_t words)
+        {
+            return words ? words * 8 : kGran;
+        }
+        bool fits(size_t have, size_t want)
+        {
+            return have == want;
+        }
+#else
         constexpr size_t kGran = size_t(256) << 10;
         size_t round_bytes(size_t words)
         {
@@ -35,6 +49,7 @@ namespace sealhip
         {
             return have <= want + want / 4 + kGran;
         }
+#endif
     } // namespace
 
     StreamScope::StreamScope(hipStream_t s) : prev_(ts().stream), prev_set_(ts().scoped)

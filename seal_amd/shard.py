@@ -41,8 +41,9 @@ def sync_all(dist, device_sync):
         device_sync()
 
 
-def timed_steps(step, steps, warmup, dist, device_sync, torch=None, device=None):
-    """Run `warmup` untimed and `steps` timed calls of step(); return the MAX elapsed seconds over ranks."""
+def timed_steps(step, steps, warmup, dist, device_sync, torch=None, device=None, local=None):
+    """Run `warmup` untimed and `steps` timed calls of step(); return the MAX elapsed seconds over ranks (`local`, a dict,
+    receives this rank's own elapsed time)."""
     for _ in range(warmup):
         step()
     sync_all(dist, device_sync)
@@ -51,6 +52,8 @@ def timed_steps(step, steps, warmup, dist, device_sync, torch=None, device=None)
         step()
     sync_all(dist, device_sync)
     elapsed = time.perf_counter() - t0
+    if local is not None:
+        local["elapsed"] = elapsed
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

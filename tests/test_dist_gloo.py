@@ -66,6 +66,10 @@ def test_bench_gpus_2_starts_two_ranks(emu, workload):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["steps"] == 2
     assert line["scaling"] == ("weak" if workload == "headline" else "strong")
+    # the probe collective's rank count and every rank's own rate travel in the line
+    assert line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo"
+    assert [p["rank"] for p in line["per_rank"]] == [0, 1] and all(p["value"] > 0 for p in line["per_rank"])
+    assert line["workloads"] is None   # the appended BASELINE workloads belong to the one-GPU headline line only
     import sealref
     if sealref.available():
         assert line["verified_items"] == 4  # two items per rank
@@ -109,3 +113,30 @@ def test_bench_rotate_c5_pipelined_exchange(emu):
     import sealref
     if sealref.available():
         assert line["verified_items"] == 8  # four items per rank
+
+
+def test_bench_default_line_carries_configs3_and_configs4(emu):
+    """`python bench.py` (one GPU, headline): BASELINE configs[3] and configs[4] are timed by child runs and attached to the same
+    line with their own value / verified_items (VERDICT r3 #2); --no-children leaves them out"""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SEALHIP_BENCH_EMU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--child-steps", "2"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["value"] > 0
+    assert set(line["workloads"]) == {"bfv_c4", "rotate_c5"}
+    import sealref
+    for name, wl in line["workloads"].items():
+        assert "error" not in wl, wl
+        assert wl["value"] > 0 and wl["steps"] == 2 and wl["ms_per_step"] > 0, (name, wl)
+        assert ("configs[3]" if name == "bfv_c4" else "configs[4]") in wl["config"]["workload"]
+        if sealref.available():
+            assert wl["verified_items"] >= 2, (name, wl)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-children"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])["workloads"] is None

@@ -4,7 +4,7 @@
 # (device memory is host heap there).  Test infrastructure; output under /tmp/asan.  usage: tools/asan_emu.sh [cases...]
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd); O=/tmp/asan; mkdir -p $O/obj
-FL="-O1 -g -fsanitize=address -fno-omit-frame-pointer -DSEALHIP_CHECK_BOUNDS -DSEALHIP_AB_SWITCHES -std=c++17 -fPIC -ffp-contract=off -mfma -Wno-unknown-pragmas -I$ROOT/tests/hipemu/include"
+FL="-O1 -g -fsanitize=address -fno-omit-frame-pointer -DSEALHIP_CHECK_BOUNDS -DSEALHIP_AB_SWITCHES -DSEALHIP_POOL_EXACT -std=c++17 -fPIC -ffp-contract=off -mfma -Wno-unknown-pragmas -I$ROOT/tests/hipemu/include"
 cd $ROOT/seal_amd/csrc
 (for f in *.hip; do echo "g++ $FL -x c++ -c $f -o $O/obj/${f%.hip}.o"; done
  for f in *.cpp; do echo "g++ $FL -c $f -o $O/obj/${f%.cpp}.o"; done
