@@ -80,6 +80,17 @@ namespace sealhip
         void reshape_uninitialized(const Level *level, size_t size);
         size_t capacity_words() const { return capacity_words_; }
         void release();
+        // Ciphertext::reserve (ciphertext.cpp:38-78): room for `size_capacity` polynomials at `level`; the size shrinks to the capacity when
+        // it was larger, the leading words are kept (at the same level they are the leading polynomials).  2 <= size_capacity <= 16.
+        void reserve(const Level *level, size_t size_capacity, hipStream_t stream);
+        // Ciphertext::size_capacity (ciphertext.h:520-528): polynomials the slab has room for at the current level
+        size_t size_capacity() const { return plane_words() ? capacity_words_ / plane_words() : 0; }
+        // sealc Ciphertext_SetParmsId writes the member without any check (c/ciphertext.cpp:239-247); here a level is a pointer into the context
+        void set_level_unchecked(const Level *level)
+        {
+            settle();
+            level_ = level;
+        }
 
     private:
         const Context *ctx_;

@@ -467,9 +467,18 @@ namespace sealhip
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
             const unsigned col = cg * G::C + c;
             uint64_t *o = mid_tr + (size_t)(hi * 16 + (col >> 4)) * BS + (col & 15);
+#ifdef SEALHIP_KS_NOMEM
+            // measurement build (tools/ab.sh nomem): the tile is not stored - one word per thread keeps the arithmetic alive
+            uint64_t sink = 0;
+#pragma unroll
+            for (int rb = 0; rb < 16; rb++)
+                sink ^= F::raw(x[rb]);
+            o[0] = sink;
+#else
 #pragma unroll
             for (int rb = 0; rb < 16; rb++)
                 o[rb * 16] = F::raw(x[rb]);
+#endif
         }
 
         // ---------------------------------------------------------------------------------------
@@ -1639,7 +1648,11 @@ namespace sealhip
                 {
                     const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
                     const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+#ifdef SEALHIP_KS_NOMEM
+                    nxt[e] = (uint64_t)((tid << 4) + (unsigned)e + J * 4099u + R); // (any word below 2^50 does)
+#else
                     nxt[e] = in[(size_t)R * 256];
+#endif
                 }
             };
             const unsigned Jskip = a.skip_diag ? I : ~0u;
@@ -1854,7 +1867,13 @@ namespace sealhip
                     const UniformView mv = uniform_view(mid0 + ((size_t)J << G::n));
 #pragma unroll
                     for (int e = 0; e < 16; e++)
+                    {
+#ifdef SEALHIP_KS_NOMEM
+                        nxt[e] = fp_to_bits((double)(int)((tid * 16 + e + J * 4099u) & 0xFFFFF) - 524288.0);
+#else
                         nxt[e] = view_load64(mv, tid * 8, e * 2048);
+#endif
+                    }
                 }
                 else
                 {
@@ -1863,7 +1882,13 @@ namespace sealhip
                     const uint64_t *mp = mid0_lane + ((size_t)J << G::n);
 #pragma unroll
                     for (int e = 0; e < 16; e++)
+                    {
+#ifdef SEALHIP_KS_NOMEM
+                        nxt[e] = ((uint64_t)(tid * 16 + e + J * 4099u) * 0x9E3779B97F4A7C15ull) >> 6;
+#else
                         nxt[e] = mp[e * 256];
+#endif
+                    }
                 }
             };
             // Integer back end: with 128-bit sums there were no registers for the prefetch (round 2: the overflow spilled to
@@ -1906,7 +1931,11 @@ namespace sealhip
                     for (int e = 0; e < 16; e++)
                     {
                         uint64_t w0, w1; // (first, second) key polynomial of this coefficient
+#ifdef SEALHIP_KS_NOMEM
+                        w0 = fp_to_bits((double)(int)((tid * 7 + e * 31 + J) & 0xFFFFF) - 500000.0), w1 = fp_to_bits((double)(int)((tid * 3 + e * 17 + J) & 0xFFFFF) - 400000.0);
+#else
                         view_load128(kv, tid * 16, e * 4096, w0, w1);
+#endif
                         kr0[e] = fp_from_bits(w0);
                         kr1[e] = fp_from_bits(w1);
                     }
@@ -1941,7 +1970,11 @@ namespace sealhip
 #pragma unroll
                     for (int e = 0; e < 16; e++)
                     {
+#ifdef SEALHIP_KS_NOMEM
+                        const ShoupOp w0{ (uint64_t)(tid * 7 + e * 31 + J) * 0x9E3779B97F4A7C15ull >> 5, (uint64_t)(tid + e) * 0xD1B54A32D192ED03ull }, w1{ w0.wq >> 4, w0.w << 3 };
+#else
                         const ShoupOp w0 = p0[e * 256], w1 = p1[e * 256];
+#endif
                         if constexpr (ICLS == 2)
                         {
                             acc0[e] = F::guard(acc0[e] + F::mul_lazy(x[e], w0, m), m);

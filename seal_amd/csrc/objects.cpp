@@ -129,6 +129,30 @@ namespace sealhip
         level_ = level;
         size_ = size;
     }
+    void Ciphertext::reserve(const Level *level, size_t size_capacity, hipStream_t stream)
+    {
+        if (!level)
+            throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (size_capacity < 2 || size_capacity > 16) // SEAL_CIPHERTEXT_SIZE_MIN / _MAX (ciphertext.cpp:61-64)
+            throw std::invalid_argument("invalid size_capacity");
+        settle();
+        const size_t pw = batch_ * level->K * ctx_->n();
+        const size_t need = size_capacity * pw;
+        const size_t new_size = std::min(size_, size_capacity);
+        // reserve_internal keeps min(new capacity, old size) WORDS of the flat array whatever the new geometry is (ciphertext.cpp:66-72)
+        const size_t keep = std::min(need, word_count());
+        if (need != capacity_words_)
+        {
+            uint64_t *nd = DevicePool::global().alloc_words(need, stream);
+            if (keep)
+                ck(hipMemcpyAsync(nd, data_, keep * 8, hipMemcpyDeviceToDevice, stream), "Ciphertext reserve copy");
+            DevicePool::global().free_words(data_, stream);
+            data_ = nd;
+            capacity_words_ = need;
+        }
+        level_ = level;
+        size_ = new_size;
+    }
     void Ciphertext::reshape_uninitialized(const Level *level, size_t size)
     {
         drop_lazy();

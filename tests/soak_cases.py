@@ -12,7 +12,8 @@ operations below are the ones on that path and next to it:
   resize_grow      the C ABI's Ciphertext_Resize1 2 -> 3 on its own: copy + zero fill, nothing else
 Every phase runs them with direct host copies (hipMemcpy on the caller's pageable buffer) or with staged ones (pinned bounce
 buffers, SealHip_SetStagedHostCopies), on the NULL stream or on a non-blocking stream - a wrong kernel / ordering shows in every
-copy mode, a wrong pageable-memory transfer only in one.  Expected words come from the reference once per input set; the device
+copy mode, a wrong pageable-memory transfer only in one.  Every `churn_every` iterations the next operation runs on a context,
+evaluator and key that were created just before it and replace the old ones (the failing operation of round 3 was the first after exactly that).  Expected words come from the reference once per input set; the device
 side repeats.  On a mismatch the report says where the wrong words are, what they hold (the uploaded source word? zero? what
 the reference expects for ANOTHER input set, i.e. stale data?), whether a second download shows them too, and whether the same
 operation from a fresh upload is right the next time.  TEST INFRASTRUCTURE (imports the oracle)."""
@@ -39,6 +40,7 @@ class _Case:
         self.K = K = len(primes) - 1
         self.o = Oracle("ckks", n, primes, 0)
         self.d = DeviceSide("ckks", n, primes, 0)
+        self.rebuilds = 0
         ci = self.o._ci(K)
         self.scale = 2.0 ** 8
         self.sets = []
@@ -54,6 +56,15 @@ class _Case:
             exp["add_grow"] = [self.o.ref.add_inplace(ref(a), ref(c)).data() for a, c in zip(x, z)]
             exp["resize_grow"] = [np.concatenate([a, np.zeros((1, K, n), dtype=np.uint64)]) for a in x]
             self.sets.append({"x": x, "y": y, "z": z, "exp": {k: np.stack(v, axis=1) for k, v in exp.items()}})
+
+    def rebuild_device(self, stream):
+        """what the start of a fuzz sequence does (tests/fuzz_cases.py - the one wrong result of round 3 was the FIRST operation after it): a
+        new SEALContext and Evaluator (hipMalloc / hipMemcpy of the tables), the relinearization key uploaded again (hipMalloc + host copy),
+        the old context, evaluator and key destroyed (hipFree)"""
+        self.d = DeviceSide("ckks", self.n, self.primes, 0)
+        self.d.upload_keys(self.o)
+        self.d.ev.set_stream(stream)
+        self.rebuilds += 1
 
     def label(self):
         return "ckks n=%d bits=%s batch=%d" % (self.n, self.bits, self.batch)
@@ -131,7 +142,7 @@ def default_cases(small=False):
     ]
 
 
-def run_soak(seconds, cases=None, phases=None, seed=1, dump_dir=None, max_iterations=None):
+def run_soak(seconds, cases=None, phases=None, seed=1, dump_dir=None, max_iterations=None, churn_every=97):
     """-> dict of counters; raises AssertionError at the first mismatch (after writing its words to dump_dir)"""
     cases = cases or default_cases()
     if phases is None:
@@ -152,6 +163,8 @@ def run_soak(seconds, cases=None, phases=None, seed=1, dump_dir=None, max_iterat
             count = 0
             while time.time() < t_end and (max_iterations is None or count < max_iterations):
                 case = cases[int(rng.integers(0, len(cases)))]
+                if churn_every and count % churn_every == churn_every - 1:
+                    case.rebuild_device(stream.handle if nonblocking else None)
                 op = OPS[int(rng.integers(0, len(OPS)))]
                 s = int(rng.integers(0, len(case.sets)))
                 c = case.device_run(op, s)
@@ -175,4 +188,5 @@ def run_soak(seconds, cases=None, phases=None, seed=1, dump_dir=None, max_iterat
         for case in cases:
             case.d.ev.set_stream(None)
     stats["seconds"] = time.time() - t_begin
+    stats["context_rebuilds"] = sum(c.rebuilds for c in cases)
     return stats
