@@ -255,6 +255,10 @@ SHL_FUNC KSwitchKeys_SetKeyFromDevice(void *thisptr, void *context, uint64_t ind
 SHL_FUNC KSwitchKeys_SetKeyDigits(void *thisptr, void *context, uint64_t index, uint64_t digit_first, uint64_t digits,
                                   const uint64_t *host_words);
 SHL_FUNC KSwitchKeys_HasKey(void *thisptr, uint64_t index, bool *has_key);
+/* library extension: HBM held by the keys of the object.  At 2^13 <= N <= 2^16 a key is stored in the fused key-switch kernel's
+ * register order (pairs of balanced doubles for primes below 2^50, (word, Shoup quotient) pairs for larger ones): 284 MB per C5 key
+ * against 252 MB of natural words */
+SHL_FUNC KSwitchKeys_DeviceBytes(void *thisptr, uint64_t *bytes);
 /* KSwitchKeys::load / unsafe_load (native/src/seal/c/kswitchkeys.h:45-47; kswitchkeys.cpp:92-180): a serialized RelinKeys /
  * GaloisKeys stream (seeded or full, compr_mode none) goes straight into the device key slabs, every key index it holds. */
 SHL_FUNC KSwitchKeys_UnsafeLoad(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
@@ -407,6 +411,116 @@ SHL_FUNC shl_apply_galois(void *context, uint64_t chain_index, int ntt_form, uin
  *   4 divide_and_round_q_last_inplace         (rns.cpp:789)      in K,              out K-1
  *   5 divide_and_round_q_last_ntt_inplace     (rns.cpp:830)      in K,              out K-1 */
 SHL_FUNC shl_rns_stage(void *context, uint64_t chain_index, int which, const uint64_t *in, uint64_t *out, uint64_t polys, void *stream);
+/* ------------------------------------------------------------------------------------------------
+ * 1d. The container surface a sealc binding uses besides the hot path (seal_amd/csrc/capi_containers.cpp)
+ * ----------------------------------------------------------------------------------------------
+ * Same names and argument lists as native/src/seal/c/{ciphertext,kswitchkeys,sealcontext,contextdata,encryptionparameters,
+ * secretkey,publickey}.h unless a line says otherwise.  A word index addresses the device slab [poly][batch][K][N] (batch of one:
+ * Ciphertext::data()); every call drains the device first (these are not hot-path functions).
+ *
+ * DELIBERATELY ABSENT from those seven headers (tests/test_cabi.py keeps both lists honest against the reference's headers: a sealc
+ * function of these seven is declared in this file with the same argument types, or named in one of the two lists):
+ *   Ciphertext_Pool, KSwitchKeys_Pool, SecretKey_Pool, PublicKey_Pool
+ *                                     a MemoryPoolHandle has no device meaning (note (2) at the top)
+ *   Ciphertext_Create1, SecretKey_Create1, PublicKey_Create1
+ *                                     a device object is bound to a SEALContext when it is made: Ciphertext_Create3 /
+ *                                     SecretKey_Create / PublicKey_Create take the context
+ *   SecretKey_Data, PublicKey_Data    sealc returns a pointer to the member Plaintext / Ciphertext; the words are read with
+ *                                     SecretKey_Get / PublicKey_Get and written with SecretKey_Set / PublicKey_Set
+ *   EncParams_SetPlainModulus1        takes a Modulus handle; a Modulus travels as its 64-bit value here (EncParams_SetPlainModulus2)
+ * SAME NAME, DIFFERENT ARGUMENTS (each for the reason given where it is declared):
+ *   EncParams_GetCoeffModulus, EncParams_SetCoeffModulus, EncParams_GetPlainModulus     uint64_t values instead of Modulus handles
+ *   SecretKey_Set, PublicKey_Set      take host words (section 1a); sealc's object-to-object assignment is SecretKey_Assign /
+ *                                     PublicKey_Assign
+ * Everything else of those headers is here or in sections 1 / 1a / 1b. */
+/* Ciphertext (c/ciphertext.h:20-60).  Create4 / Create5: an empty ciphertext of batch 1 with parms_id set and room for 2 / `capacity`
+ * polynomials (ciphertext.h:128-149).  SetParmsId takes the ids of the context's chain or parms_id_zero (E_INVALIDARG otherwise: a
+ * device object names its level by pointer).  Resize4 is the .NET loader's resize(size, N, K): the geometry must be a level's. */
+SHL_FUNC Ciphertext_Create4(void *context, uint64_t *parms_id, void *pool, void **cipher);
+SHL_FUNC Ciphertext_Create5(void *context, uint64_t *parms_id, uint64_t capacity, void *pool, void **cipher);
+SHL_FUNC Ciphertext_Reserve1(void *thisptr, void *context, uint64_t *parms_id, uint64_t size_capacity);
+SHL_FUNC Ciphertext_Reserve2(void *thisptr, void *context, uint64_t size_capacity);
+SHL_FUNC Ciphertext_Reserve3(void *thisptr, uint64_t size_capacity);
+SHL_FUNC Ciphertext_SizeCapacity(void *thisptr, uint64_t *size_capacity);
+SHL_FUNC Ciphertext_SetParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC Ciphertext_Resize2(void *thisptr, void *context, uint64_t size);
+SHL_FUNC Ciphertext_Resize3(void *thisptr, uint64_t size);
+SHL_FUNC Ciphertext_Resize4(void *thisptr, uint64_t size, uint64_t polyModulusDegree, uint64_t coeffModCount);
+SHL_FUNC Ciphertext_GetDataAt1(void *thisptr, uint64_t index, uint64_t *data);
+SHL_FUNC Ciphertext_GetDataAt2(void *thisptr, uint64_t poly_index, uint64_t coeff_index, uint64_t *data); /* batch item 0 */
+SHL_FUNC Ciphertext_SetDataAt(void *thisptr, uint64_t index, uint64_t value);
+SHL_FUNC Ciphertext_Release(void *thisptr);
+/* KSwitchKeys (c/kswitchkeys.h:20-33).  GetKeyList: sealc hands out pointers into the object; here every digit of key `index` is
+ * given out as a NEW PublicKey (the device key is one slab in the kernels' order) which the caller destroys with PublicKey_Destroy;
+ * key_list == NULL returns the count only.  AddKeyList appends a key made of `count` PublicKey handles (0: an empty slot). */
+SHL_FUNC KSwitchKeys_Create2(void *copy, void **kswitch_keys);
+SHL_FUNC KSwitchKeys_Set(void *thisptr, void *assign);
+SHL_FUNC KSwitchKeys_RawSize(void *thisptr, uint64_t *key_count);
+SHL_FUNC KSwitchKeys_GetKeyList(void *thisptr, uint64_t index, uint64_t *count, void **key_list);
+SHL_FUNC KSwitchKeys_ClearDataAndReserve(void *thisptr, uint64_t size);
+SHL_FUNC KSwitchKeys_AddKeyList(void *thisptr, uint64_t count, void **key_list);
+SHL_FUNC KSwitchKeys_GetParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC KSwitchKeys_SetParmsId(void *thisptr, uint64_t *parms_id);
+/* SEALContext (c/sealcontext.h:28-40).  SEALContext_Create refuses what the reference would construct with parameters_set() ==
+ * false (E_INVALIDARG, including parameters that are insecure for a sec_level of 128 / 192 / 256): an existing handle is a valid
+ * context, ParametersSet is true and the error name / message are "success" / "valid".  A ContextData handle names one level of
+ * the chain; it is owned by the library and valid as long as its context (ContextData_Destroy is accepted and does nothing, as
+ * the pointers sealc returns belong to the SEALContext); NULL where the reference returns a null pointer. */
+SHL_FUNC SEALContext_ParametersSet(void *thisptr, bool *params_set);
+SHL_FUNC SEALContext_ParameterErrorName(void *thisptr, char *outstr, uint64_t *length);
+SHL_FUNC SEALContext_ParameterErrorMessage(void *thisptr, char *outstr, uint64_t *length);
+SHL_FUNC SEALContext_KeyContextData(void *thisptr, void **context_data);
+SHL_FUNC SEALContext_FirstContextData(void *thisptr, void **context_data);
+SHL_FUNC SEALContext_LastContextData(void *thisptr, void **context_data);
+SHL_FUNC SEALContext_GetContextData(void *thisptr, uint64_t *parms_id, void **context_data);
+/* ContextData (c/contextdata.h): array getters follow sealc's convention - *count carries the capacity in and the length out, a
+ * NULL array returns the length only, a length of 0 means "not computed for these parameters" (CKKS has no coeff_div_plain_modulus,
+ * BFV / BGV no upper_half_threshold).  ContextData_Parms returns a new EncryptionParameters (EncParams_Destroy), ContextData_Qualifiers
+ * a new EncryptionParameterQualifiers (EPQ_Destroy; c/encryptionparameterqualifiers.h). */
+SHL_FUNC ContextData_Destroy(void *thisptr);
+SHL_FUNC ContextData_TotalCoeffModulus(void *thisptr, uint64_t *count, uint64_t *total_coeff_modulus);
+SHL_FUNC ContextData_TotalCoeffModulusBitCount(void *thisptr, int *bit_count);
+SHL_FUNC ContextData_Parms(void *thisptr, void **parms);
+SHL_FUNC ContextData_Qualifiers(void *thisptr, void **epq);
+SHL_FUNC ContextData_CoeffDivPlainModulus(void *thisptr, uint64_t *count, uint64_t *coeff_div);
+SHL_FUNC ContextData_PlainUpperHalfThreshold(void *thisptr, uint64_t *puht);
+SHL_FUNC ContextData_PlainUpperHalfIncrement(void *thisptr, uint64_t *count, uint64_t *puhi);
+SHL_FUNC ContextData_UpperHalfThreshold(void *thisptr, uint64_t *count, uint64_t *uht);
+SHL_FUNC ContextData_UpperHalfIncrement(void *thisptr, uint64_t *count, uint64_t *uhi);
+SHL_FUNC ContextData_PrevContextData(void *thisptr, void **prev_data);
+SHL_FUNC ContextData_NextContextData(void *thisptr, void **next_data);
+SHL_FUNC ContextData_ChainIndex(void *thisptr, uint64_t *index);
+SHL_FUNC ContextData_ParmsId(void *thisptr, uint64_t *parms_id); /* library extension: the level's parms_id without the temporary */
+SHL_FUNC EPQ_Destroy(void *thisptr);
+SHL_FUNC EPQ_ParametersSet(void *thisptr, bool *parameters_set);
+SHL_FUNC EPQ_UsingFFT(void *thisptr, bool *using_fft);
+SHL_FUNC EPQ_UsingNTT(void *thisptr, bool *using_ntt);
+SHL_FUNC EPQ_UsingBatching(void *thisptr, bool *using_batching);
+SHL_FUNC EPQ_UsingFastPlainLift(void *thisptr, bool *using_fast_plain_lift);
+SHL_FUNC EPQ_UsingDescendingModulusChain(void *thisptr, bool *using_descending_modulus_chain);
+SHL_FUNC EPQ_SecLevel(void *thisptr, int *sec_level);
+/* EncryptionParameters (c/encryptionparameters.h:20-49): copy, assignment, parms_id (BLAKE2b-256, encryptionparams.cpp:117-147),
+ * equality, and the wire format of EncryptionParameters::save / load (encryptionparams.cpp:15-122; all three compression modes) */
+SHL_FUNC EncParams_Create2(void *copy, void **enc_params);
+SHL_FUNC EncParams_Set(void *thisptr, void *assign);
+SHL_FUNC EncParams_GetParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC EncParams_GetPlainModulus(void *thisptr, uint64_t *plain_modulus); /* (uint64_t, not a Modulus handle) */
+SHL_FUNC EncParams_Equals(void *thisptr, void *otherptr, bool *result);
+SHL_FUNC EncParams_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+SHL_FUNC EncParams_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+SHL_FUNC EncParams_Load(void *thisptr, uint8_t *inptr, uint64_t size, int64_t *in_bytes);
+/* SecretKey / PublicKey (c/secretkey.h, c/publickey.h): copies, parms_id, and SecretKey::save / PublicKey::save - the stream of the
+ * key's Plaintext (L*N coefficients at the key level) resp. Ciphertext (size 2, key level, NTT form), byte for byte the reference's */
+SHL_FUNC SecretKey_Create2(void *copy, void **secret_key);
+SHL_FUNC SecretKey_Assign(void *thisptr, void *assign);
+SHL_FUNC SecretKey_ParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC SecretKey_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+SHL_FUNC SecretKey_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
+SHL_FUNC PublicKey_Create2(void *copy, void **public_key);
+SHL_FUNC PublicKey_Assign(void *thisptr, void *assign);
+SHL_FUNC PublicKey_ParmsId(void *thisptr, uint64_t *parms_id);
+SHL_FUNC PublicKey_SaveSize(void *thisptr, uint8_t compr_mode, int64_t *result);
+SHL_FUNC PublicKey_Save(void *thisptr, uint8_t *outptr, uint64_t size, uint8_t compr_mode, int64_t *out_bytes);
 /* the pool of cached HBM blocks (the role of MemoryManager / MemoryPool, native/src/seal/memorymanager.h:75-265): give the
  * cached blocks back to the driver; counters for tests */
 SHL_FUNC SealHip_ReleasePool(void);

@@ -1140,6 +1140,140 @@ extern "C"
         *bytes = static_cast<uint64_t>(c->pk.save(reinterpret_cast<seal_byte *>(out), cap, compr_mode_type::none));
         REF_CATCH
     }
+    // ---- container surface (tests/container_cases.py): per-level constants of SEALContext::ContextData, the qualifiers, the stream
+    // of EncryptionParameters::save, and Ciphertext::reserve / resize bookkeeping
+    // which: 0 total_coeff_modulus, 1 coeff_div_plain_modulus (operands), 2 plain_upper_half_increment, 3 upper_half_threshold,
+    //        4 upper_half_increment.  *count = 0 when the reference did not compute it for these parameters.
+    int ref_ctx_data_words(void *ctx, uint64_t chain_index, int which, uint64_t *out, uint64_t *count)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 1;
+        const size_t k = l->parms().coeff_modulus().size();
+        *count = 0;
+        const uint64_t *src = nullptr;
+        std::vector<uint64_t> tmp;
+        switch (which)
+        {
+        case 0:
+            src = l->total_coeff_modulus();
+            break;
+        case 1:
+            if (l->coeff_div_plain_modulus())
+            {
+                for (size_t i = 0; i < k; i++)
+                    tmp.push_back(l->coeff_div_plain_modulus()[i].operand);
+                src = tmp.data();
+            }
+            break;
+        case 2:
+            src = l->plain_upper_half_increment();
+            break;
+        case 3:
+            src = l->upper_half_threshold();
+            break;
+        case 4:
+            src = l->upper_half_increment();
+            break;
+        default:
+            return 1;
+        }
+        if (src)
+        {
+            *count = k;
+            for (size_t i = 0; i < k; i++)
+                out[i] = src[i];
+        }
+        REF_CATCH
+    }
+    // out[0..7] = total_coeff_modulus_bit_count, using_fft, using_ntt, using_batching, using_fast_plain_lift,
+    //             using_descending_modulus_chain, sec_level, parameters_set; *puht = plain_upper_half_threshold
+    int ref_ctx_qualifiers(void *ctx, uint64_t chain_index, int *out, uint64_t *puht)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 1;
+        const auto q = l->qualifiers();
+        out[0] = l->total_coeff_modulus_bit_count();
+        out[1] = q.using_fft;
+        out[2] = q.using_ntt;
+        out[3] = q.using_batching;
+        out[4] = q.using_fast_plain_lift;
+        out[5] = q.using_descending_modulus_chain;
+        out[6] = static_cast<int>(q.sec_level);
+        out[7] = q.parameters_set();
+        *puht = l->plain_upper_half_threshold();
+        REF_CATCH
+    }
+    int ref_parms_save(void *ctx, uint64_t chain_index, int mode, uint8_t *out, uint64_t cap, uint64_t *bytes)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        auto l = c->level(chain_index);
+        if (!l)
+            return 1;
+        *bytes = static_cast<uint64_t>(l->parms().save(reinterpret_cast<seal_byte *>(out), cap, static_cast<compr_mode_type>(mode)));
+        REF_CATCH
+    }
+    // EncryptionParameters::load of a stream: scheme, degree, plain modulus and the primes (count in / out)
+    int ref_parms_load(const uint8_t *in, uint64_t size, int *scheme, uint64_t *degree, uint64_t *plain, uint64_t *primes, uint64_t *count)
+    {
+        REF_TRY
+        EncryptionParameters p;
+        p.load(reinterpret_cast<const seal_byte *>(in), size);
+        *scheme = static_cast<int>(p.scheme());
+        *degree = p.poly_modulus_degree();
+        *plain = p.plain_modulus().value();
+        if (p.coeff_modulus().size() > *count)
+            return 1;
+        *count = p.coeff_modulus().size();
+        for (size_t i = 0; i < p.coeff_modulus().size(); i++)
+            primes[i] = p.coeff_modulus()[i].value();
+        REF_CATCH
+    }
+    // op: 0 reserve(context, parms_id of chain_index, n)  1 reserve(n)  2 resize(context, parms_id of chain_index, n)  3 resize(n)  4 release()
+    // out[0..3] = size, size_capacity, coeff_modulus_size, poly_modulus_degree afterwards
+    int ref_ct_container_op(void *ctx, void *ct, int op, uint64_t chain_index, uint64_t n, uint64_t *out)
+    {
+        REF_TRY
+        auto c = static_cast<RefCtx *>(ctx);
+        Ciphertext &x = CT(ct);
+        auto l = c->level(chain_index);
+        switch (op)
+        {
+        case 0:
+            if (!l)
+                return 1;
+            x.reserve(*c->context, l->parms_id(), n);
+            break;
+        case 1:
+            x.reserve(n);
+            break;
+        case 2:
+            if (!l)
+                return 1;
+            x.resize(*c->context, l->parms_id(), n);
+            break;
+        case 3:
+            x.resize(n);
+            break;
+        case 4:
+            x.release();
+            break;
+        default:
+            return 1;
+        }
+        out[0] = x.size();
+        out[1] = x.size_capacity();
+        out[2] = x.coeff_modulus_size();
+        out[3] = x.poly_modulus_degree();
+        REF_CATCH
+    }
+
     // number of key slots (KSwitchKeys::data().size()) and which are populated
     int ref_key_slots(void *ctx, int kind, uint64_t *slots)
     {

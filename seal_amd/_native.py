@@ -80,7 +80,7 @@ Plaintext_SaveSize Plaintext_Save Plaintext_UnsafeLoad Plaintext_Load
 Evaluator_AddMany Evaluator_AddPlain Evaluator_SubPlain Evaluator_MultiplyMany Evaluator_MultiplyPlain Evaluator_Exponentiate
 Evaluator_TransformToNTT1 Evaluator_ModSwitchToNext2 Evaluator_ModSwitchTo2
 KSwitchKeys_Create1 KSwitchKeys_Destroy KSwitchKeys_Size KSwitchKeys_SetKey KSwitchKeys_SetKeyFromDevice
-KSwitchKeys_SetKeyDigits KSwitchKeys_HasKey RelinKeys_GetIndex GaloisKeys_GetIndex GaloisTool_GetEltFromStep
+KSwitchKeys_SetKeyDigits KSwitchKeys_HasKey KSwitchKeys_DeviceBytes RelinKeys_GetIndex GaloisKeys_GetIndex GaloisTool_GetEltFromStep
 Evaluator_Create Evaluator_Destroy Evaluator_SetStream Evaluator_Synchronize Evaluator_CopyTo Evaluator_SetTransparentCheck
 Evaluator_BeginCapture Evaluator_EndCapture Evaluator_LaunchGraph Graph_Destroy
 Evaluator_Negate Evaluator_Add Evaluator_Sub Evaluator_Multiply Evaluator_Square Evaluator_Relinearize
@@ -98,6 +98,18 @@ SealHip_ReleasePool SealHip_PoolStats SealHip_TailStats SealHip_SetStagedHostCop
 shl_ntt_forward shl_ntt_inverse shl_dyadic_product shl_apply_galois shl_rns_stage shl_malloc shl_free
 shl_memcpy_h2d shl_memcpy_d2h shl_device_synchronize shl_timer_create shl_timer_destroy shl_timer_start
 shl_timer_stop
+Ciphertext_Create4 Ciphertext_Create5 Ciphertext_GetDataAt1 Ciphertext_GetDataAt2 Ciphertext_Release Ciphertext_Reserve1
+Ciphertext_Reserve2 Ciphertext_Reserve3 Ciphertext_Resize2 Ciphertext_Resize3 Ciphertext_Resize4 Ciphertext_SetDataAt
+Ciphertext_SetParmsId Ciphertext_SizeCapacity ContextData_ChainIndex ContextData_CoeffDivPlainModulus ContextData_Destroy ContextData_NextContextData
+ContextData_Parms ContextData_ParmsId ContextData_PlainUpperHalfIncrement ContextData_PlainUpperHalfThreshold ContextData_PrevContextData ContextData_Qualifiers
+ContextData_TotalCoeffModulus ContextData_TotalCoeffModulusBitCount ContextData_UpperHalfIncrement ContextData_UpperHalfThreshold EPQ_Destroy EPQ_ParametersSet
+EPQ_SecLevel EPQ_UsingBatching EPQ_UsingDescendingModulusChain EPQ_UsingFFT EPQ_UsingFastPlainLift EPQ_UsingNTT
+EncParams_Create2 EncParams_Equals EncParams_GetParmsId EncParams_GetPlainModulus EncParams_Load EncParams_Save
+EncParams_SaveSize EncParams_Set KSwitchKeys_AddKeyList KSwitchKeys_ClearDataAndReserve KSwitchKeys_Create2 KSwitchKeys_GetKeyList
+KSwitchKeys_GetParmsId KSwitchKeys_RawSize KSwitchKeys_Set KSwitchKeys_SetParmsId PublicKey_Assign PublicKey_Create2
+PublicKey_ParmsId PublicKey_Save PublicKey_SaveSize SEALContext_FirstContextData SEALContext_GetContextData SEALContext_KeyContextData
+SEALContext_LastContextData SEALContext_ParameterErrorMessage SEALContext_ParameterErrorName SEALContext_ParametersSet SecretKey_Assign SecretKey_Create2
+SecretKey_ParmsId SecretKey_Save SecretKey_SaveSize
 """.split()
 
 _lib = None

@@ -71,6 +71,59 @@ class EncryptionParameters:
         N.check(N.lib().EncParams_GetCoeffModulus(self._h, C.byref(n), _p(out)))
         return [int(x) for x in out]
 
+    def plain_modulus(self):
+        v = C.c_uint64()
+        N.check(N.lib().EncParams_GetPlainModulus(self._h, C.byref(v)))
+        return v.value
+
+    def scheme_id(self):
+        v = C.c_uint8()
+        N.check(N.lib().EncParams_GetScheme(self._h, C.byref(v)))
+        return v.value
+
+    def parms_id(self):
+        out = (C.c_uint64 * 4)()
+        N.check(N.lib().EncParams_GetParmsId(self._h, out))
+        return tuple(out)
+
+    def copy(self):
+        h = C.c_void_p()
+        N.check(N.lib().EncParams_Create2(self._h, C.byref(h)))
+        return EncryptionParameters._wrap(h)
+
+    def assign(self, other):
+        N.check(N.lib().EncParams_Set(self._h, other._h))
+        self.scheme = {v: k for k, v in SCHEME.items()}[self.scheme_id()]
+
+    def equals(self, other):
+        b = C.c_bool()
+        N.check(N.lib().EncParams_Equals(self._h, other._h, C.byref(b)))
+        return b.value
+
+    @staticmethod
+    def _wrap(handle):
+        p = EncryptionParameters.__new__(EncryptionParameters)
+        p._h = handle
+        p.scheme = {v: k for k, v in SCHEME.items()}[p.scheme_id()]
+        return p
+
+    def save_bytes(self, compr_mode=0):
+        """EncryptionParameters::save (compr_mode 0 none, 1 zlib, 2 zstd)"""
+        cap = C.c_int64()
+        N.check(N.lib().EncParams_SaveSize(self._h, C.c_uint8(compr_mode), C.byref(cap)))
+        buf = (C.c_uint8 * cap.value)()
+        n = C.c_int64()
+        N.check(N.lib().EncParams_Save(self._h, buf, C.c_uint64(cap.value), C.c_uint8(compr_mode), C.byref(n)))
+        return C.string_at(buf, n.value)
+
+    def load_bytes(self, data):
+        """EncryptionParameters::load; returns the bytes read"""
+        data = bytes(data)
+        n = C.c_int64()
+        N.check(N.lib().EncParams_Load(self._h, C.cast(C.c_char_p(data), C.c_void_p), C.c_uint64(len(data)), C.byref(n)))
+        self.scheme = {v: k for k, v in SCHEME.items()}[self.scheme_id()]
+        return n.value
+
 
 class SEALContext:
     """SEALContext(parms, expand_mod_chain, sec_level) — builds and uploads every table."""
@@ -150,6 +203,122 @@ class SEALContext:
         N.check(N.lib().GaloisTool_GetEltFromStep(self._h, C.c_int(step), C.byref(v)))
         return v.value
 
+    # -- SEALContext::key_context_data / first_context_data / last_context_data / get_context_data (context.h:322-346)
+    def _cd(self, fn, *args):
+        h = C.c_void_p()
+        N.check(getattr(N.lib(), fn)(self._h, *args, C.byref(h)))
+        return ContextData(self, h) if h.value else None
+
+    def key_context_data(self):
+        return self._cd("SEALContext_KeyContextData")
+
+    def first_context_data(self):
+        return self._cd("SEALContext_FirstContextData")
+
+    def last_context_data(self):
+        return self._cd("SEALContext_LastContextData")
+
+    def get_context_data(self, parms_id):
+        return self._cd("SEALContext_GetContextData", (C.c_uint64 * 4)(*parms_id))
+
+    def parameters_set(self):
+        b = C.c_bool()
+        N.check(N.lib().SEALContext_ParametersSet(self._h, C.byref(b)))
+        return b.value
+
+    def parameter_error(self):
+        out = []
+        for fn in ("SEALContext_ParameterErrorName", "SEALContext_ParameterErrorMessage"):
+            n = C.c_uint64()
+            N.check(getattr(N.lib(), fn)(self._h, None, C.byref(n)))
+            buf = C.create_string_buffer(n.value + 1)
+            N.check(getattr(N.lib(), fn)(self._h, buf, C.byref(n)))
+            out.append(buf.value.decode())
+        return tuple(out)
+
+
+class ContextData:
+    """SEALContext::ContextData (context.h:181-319): one level of the modulus-switching chain; the handle belongs to the context"""
+
+    def __init__(self, context, handle):
+        self.context, self._h = context, handle
+
+    def _words(self, fn):
+        n = C.c_uint64(0)
+        N.check(getattr(N.lib(), fn)(self._h, C.byref(n), None))
+        out = np.zeros(n.value, dtype=np.uint64)
+        if n.value:
+            N.check(getattr(N.lib(), fn)(self._h, C.byref(n), _p(out)))
+        return [int(x) for x in out]
+
+    def _link(self, fn):
+        h = C.c_void_p()
+        N.check(getattr(N.lib(), fn)(self._h, C.byref(h)))
+        return ContextData(self.context, h) if h.value else None
+
+    def chain_index(self):
+        v = C.c_uint64()
+        N.check(N.lib().ContextData_ChainIndex(self._h, C.byref(v)))
+        return v.value
+
+    def parms_id(self):
+        out = (C.c_uint64 * 4)()
+        N.check(N.lib().ContextData_ParmsId(self._h, out))
+        return tuple(out)
+
+    def parms(self):
+        h = C.c_void_p()
+        N.check(N.lib().ContextData_Parms(self._h, C.byref(h)))
+        return EncryptionParameters._wrap(h)
+
+    def qualifiers(self):
+        h = C.c_void_p()
+        N.check(N.lib().ContextData_Qualifiers(self._h, C.byref(h)))
+        out = {}
+        try:
+            for key, fn, ctype in (("parameters_set", "EPQ_ParametersSet", C.c_bool), ("using_fft", "EPQ_UsingFFT", C.c_bool),
+                                   ("using_ntt", "EPQ_UsingNTT", C.c_bool), ("using_batching", "EPQ_UsingBatching", C.c_bool),
+                                   ("using_fast_plain_lift", "EPQ_UsingFastPlainLift", C.c_bool),
+                                   ("using_descending_modulus_chain", "EPQ_UsingDescendingModulusChain", C.c_bool),
+                                   ("sec_level", "EPQ_SecLevel", C.c_int)):
+                v = ctype()
+                N.check(getattr(N.lib(), fn)(h, C.byref(v)))
+                out[key] = int(v.value)
+        finally:
+            N.lib().EPQ_Destroy(h)
+        return out
+
+    def total_coeff_modulus(self):
+        return self._words("ContextData_TotalCoeffModulus")
+
+    def total_coeff_modulus_bit_count(self):
+        v = C.c_int()
+        N.check(N.lib().ContextData_TotalCoeffModulusBitCount(self._h, C.byref(v)))
+        return v.value
+
+    def coeff_div_plain_modulus(self):
+        return self._words("ContextData_CoeffDivPlainModulus")
+
+    def plain_upper_half_threshold(self):
+        v = C.c_uint64()
+        N.check(N.lib().ContextData_PlainUpperHalfThreshold(self._h, C.byref(v)))
+        return v.value
+
+    def plain_upper_half_increment(self):
+        return self._words("ContextData_PlainUpperHalfIncrement")
+
+    def upper_half_threshold(self):
+        return self._words("ContextData_UpperHalfThreshold")
+
+    def upper_half_increment(self):
+        return self._words("ContextData_UpperHalfIncrement")
+
+    def prev_context_data(self):
+        return self._link("ContextData_PrevContextData")
+
+    def next_context_data(self):
+        return self._link("ContextData_NextContextData")
+
 
 class Ciphertext:
     def __init__(self, context, batch=1, _copy_of=None):
@@ -218,6 +387,56 @@ class Ciphertext:
     def resize(self, parms_id, size):
         pid = (C.c_uint64 * 4)(*parms_id)
         N.check(N.lib().Ciphertext_Resize1(self._h, self.context._h, pid, C.c_uint64(size)))
+
+    # -- Ciphertext::reserve / resize / size_capacity / operator[] / release (ciphertext.h:154-592)
+    def reserve(self, size_capacity, parms_id=None, with_context=True):
+        if parms_id is not None:
+            N.check(N.lib().Ciphertext_Reserve1(self._h, self.context._h, (C.c_uint64 * 4)(*parms_id), C.c_uint64(size_capacity)))
+        elif with_context:
+            N.check(N.lib().Ciphertext_Reserve2(self._h, self.context._h, C.c_uint64(size_capacity)))
+        else:
+            N.check(N.lib().Ciphertext_Reserve3(self._h, C.c_uint64(size_capacity)))
+
+    def resize_same_level(self, size, with_context=True):
+        if with_context:
+            N.check(N.lib().Ciphertext_Resize2(self._h, self.context._h, C.c_uint64(size)))
+        else:
+            N.check(N.lib().Ciphertext_Resize3(self._h, C.c_uint64(size)))
+
+    def resize_geometry(self, size, poly_modulus_degree, coeff_modulus_size):
+        N.check(N.lib().Ciphertext_Resize4(self._h, C.c_uint64(size), C.c_uint64(poly_modulus_degree), C.c_uint64(coeff_modulus_size)))
+
+    def size_capacity(self):
+        return self._get("Ciphertext_SizeCapacity", C.c_uint64)
+
+    def set_parms_id(self, parms_id):
+        N.check(N.lib().Ciphertext_SetParmsId(self._h, (C.c_uint64 * 4)(*parms_id)))
+
+    def get_data_at(self, index, coeff_index=None):
+        v = C.c_uint64()
+        if coeff_index is None:
+            N.check(N.lib().Ciphertext_GetDataAt1(self._h, C.c_uint64(index), C.byref(v)))
+        else:
+            N.check(N.lib().Ciphertext_GetDataAt2(self._h, C.c_uint64(index), C.c_uint64(coeff_index), C.byref(v)))
+        return v.value
+
+    def set_data_at(self, index, value):
+        N.check(N.lib().Ciphertext_SetDataAt(self._h, C.c_uint64(index), C.c_uint64(value)))
+
+    def release(self):
+        N.check(N.lib().Ciphertext_Release(self._h))
+
+    @staticmethod
+    def with_parms_id(context, parms_id, capacity=None):
+        """Ciphertext(context, parms_id[, size_capacity]) (ciphertext.h:128-149)"""
+        ct = Ciphertext.__new__(Ciphertext)
+        ct.context, ct._h = context, C.c_void_p()
+        pid = (C.c_uint64 * 4)(*parms_id)
+        if capacity is None:
+            N.check(N.lib().Ciphertext_Create4(context._h, pid, None, C.byref(ct._h)))
+        else:
+            N.check(N.lib().Ciphertext_Create5(context._h, pid, C.c_uint64(capacity), None, C.byref(ct._h)))
+        return ct
 
     # -- data
     def shape(self):
@@ -433,6 +652,55 @@ class KSwitchKeys:
         N.check(N.lib().KSwitchKeys_HasKey(self._h, C.c_uint64(index), C.byref(b)))
         return b.value
 
+    def copy(self):
+        """KSwitchKeys(copy): every key slab duplicated in HBM"""
+        k = type(self).__new__(type(self))
+        k.context, k._h = self.context, C.c_void_p()
+        N.check(N.lib().KSwitchKeys_Create2(self._h, C.byref(k._h)))
+        return k
+
+    def assign(self, other):
+        N.check(N.lib().KSwitchKeys_Set(self._h, other._h))
+
+    def device_bytes(self):
+        """HBM held by the keys of this object (sealhip.h: KSwitchKeys_DeviceBytes)"""
+        v = C.c_uint64()
+        N.check(N.lib().KSwitchKeys_DeviceBytes(self._h, C.byref(v)))
+        return v.value
+
+    def raw_size(self):
+        v = C.c_uint64()
+        N.check(N.lib().KSwitchKeys_RawSize(self._h, C.byref(v)))
+        return v.value
+
+    def key_list(self, index):
+        """the digits of key `index` as PublicKey objects (KSwitchKeys::data()[index]); copies, owned by the caller"""
+        n = C.c_uint64()
+        N.check(N.lib().KSwitchKeys_GetKeyList(self._h, C.c_uint64(index), C.byref(n), None))
+        handles = (C.c_void_p * max(1, n.value))()
+        N.check(N.lib().KSwitchKeys_GetKeyList(self._h, C.c_uint64(index), C.byref(n), handles))
+        out = []
+        for i in range(n.value):
+            pk = PublicKey.__new__(PublicKey)
+            pk.context, pk._h = self.context, C.c_void_p(handles[i])
+            out.append(pk)
+        return out
+
+    def add_key_list(self, public_keys):
+        handles = (C.c_void_p * max(1, len(public_keys)))(*[pk._h.value for pk in public_keys])
+        N.check(N.lib().KSwitchKeys_AddKeyList(self._h, C.c_uint64(len(public_keys)), handles))
+
+    def clear_data_and_reserve(self, size):
+        N.check(N.lib().KSwitchKeys_ClearDataAndReserve(self._h, C.c_uint64(size)))
+
+    def parms_id(self):
+        out = (C.c_uint64 * 4)()
+        N.check(N.lib().KSwitchKeys_GetParmsId(self._h, out))
+        return tuple(out)
+
+    def set_parms_id(self, parms_id):
+        N.check(N.lib().KSwitchKeys_SetParmsId(self._h, (C.c_uint64 * 4)(*parms_id)))
+
     def size(self):
         v = C.c_uint64()
         N.check(N.lib().KSwitchKeys_Size(self._h, C.byref(v)))
@@ -484,6 +752,29 @@ class SecretKey:
         out = np.empty((L, n), dtype=np.uint64)
         N.check(N.lib().SecretKey_Get(self._h, _p(out)))
         return out
+
+    def save_bytes(self, compr_mode=0):
+        """SecretKey::save (compr_mode 0 none, 1 zlib, 2 zstd)"""
+        cap = C.c_int64()
+        N.check(N.lib().SecretKey_SaveSize(self._h, C.c_uint8(compr_mode), C.byref(cap)))
+        buf = (C.c_uint8 * cap.value)()
+        n = C.c_int64()
+        N.check(N.lib().SecretKey_Save(self._h, buf, C.c_uint64(cap.value), C.c_uint8(compr_mode), C.byref(n)))
+        return C.string_at(buf, n.value)
+
+    def parms_id(self):
+        out = (C.c_uint64 * 4)()
+        N.check(N.lib().SecretKey_ParmsId(self._h, out))
+        return tuple(out)
+
+    def copy(self):
+        k = SecretKey.__new__(SecretKey)
+        k.context, k._h = self.context, C.c_void_p()
+        N.check(N.lib().SecretKey_Create2(self._h, C.byref(k._h)))
+        return k
+
+    def assign(self, other):
+        N.check(N.lib().SecretKey_Assign(self._h, other._h))
 
     def load_bytes(self, data, unsafe=False):
         data = bytes(data)
@@ -592,6 +883,29 @@ class PublicKey:
         out = np.empty((2, L, n), dtype=np.uint64)
         N.check(N.lib().PublicKey_Get(self._h, _p(out)))
         return out
+
+    def save_bytes(self, compr_mode=0):
+        """PublicKey::save (compr_mode 0 none, 1 zlib, 2 zstd)"""
+        cap = C.c_int64()
+        N.check(N.lib().PublicKey_SaveSize(self._h, C.c_uint8(compr_mode), C.byref(cap)))
+        buf = (C.c_uint8 * cap.value)()
+        n = C.c_int64()
+        N.check(N.lib().PublicKey_Save(self._h, buf, C.c_uint64(cap.value), C.c_uint8(compr_mode), C.byref(n)))
+        return C.string_at(buf, n.value)
+
+    def parms_id(self):
+        out = (C.c_uint64 * 4)()
+        N.check(N.lib().PublicKey_ParmsId(self._h, out))
+        return tuple(out)
+
+    def copy(self):
+        k = PublicKey.__new__(PublicKey)
+        k.context, k._h = self.context, C.c_void_p()
+        N.check(N.lib().PublicKey_Create2(self._h, C.byref(k._h)))
+        return k
+
+    def assign(self, other):
+        N.check(N.lib().PublicKey_Assign(self._h, other._h))
 
     def load_bytes(self, data, unsafe=False):
         data = bytes(data)

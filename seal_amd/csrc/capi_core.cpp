@@ -1,5 +1,6 @@
 // extern "C" layer, part 1: library / device, parameter helpers, SEALContext, Ciphertext and Plaintext objects, wire format (include/sealhip.h)
 #include "capi_common.h"
+#include <memory>
 
 namespace sealhip
 {
@@ -147,7 +148,6 @@ extern "C"
     // ------------------------------------------------------------------ SEALContext
     SHL_FUNC SEALContext_Create(void *encryptionParams, bool expand_mod_chain, int sec_level, void **context)
     {
-        (void)sec_level;
         IfNullRet(encryptionParams, SHL_E_POINTER);
         IfNullRet(context, SHL_E_POINTER);
         SHL_TRY
@@ -155,7 +155,25 @@ extern "C"
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
             throw std::runtime_error("no HIP device visible: libsealhip has no CPU fallback");
         auto p = as<EncParams>(encryptionParams);
-        *context = new Context(static_cast<Scheme>(p->scheme), p->n, p->coeff_modulus, p->plain_modulus, expand_mod_chain);
+        // sec_level_type (0 none, 128, 192, 256): the reference marks parameters whose total coefficient modulus exceeds
+        // CoeffModulus::MaxBitCount(N, sec_level) (util/hestdparms.h:19-80; 0 for degrees the standard does not list) as
+        // invalid_parameters_insecure (context.cpp:219-231) and every later use throws; here the context is refused
+        int max_bits = 0;
+        if (sec_level != 0)
+        {
+            static const int table[3][6] = { { 27, 54, 109, 218, 438, 881 }, { 19, 37, 75, 152, 305, 611 }, { 14, 29, 58, 118, 237, 476 } };
+            const int row = sec_level == 128 ? 0 : sec_level == 192 ? 1 : sec_level == 256 ? 2 : -1;
+            if (row < 0)
+                throw std::invalid_argument("invalid security level");
+            for (int i = 0; i < 6; i++)
+                if (p->n == (uint64_t(1024) << i))
+                    max_bits = table[row][i];
+        }
+        std::unique_ptr<Context> c(new Context(static_cast<Scheme>(p->scheme), p->n, p->coeff_modulus, p->plain_modulus, expand_mod_chain));
+        if (sec_level != 0 && c->key_level().total_coeff_modulus_bit_count > max_bits)
+            throw std::invalid_argument("encryption parameters are not set correctly: not secure for the requested security level");
+        c->set_sec_level(sec_level);
+        *context = c.release();
         SHL_CATCH
     }
     SHL_FUNC SEALContext_Destroy(void *thisptr)
@@ -727,7 +745,12 @@ extern "C"
             if (const Context *c = keys.context())
                 for (size_t i = 0; i < keys.slots(); i++)
                     if (keys.has_key(i))
+                    {
+                        // (the same refusal as KSwitchKeys_Save: a size for a stream that cannot be written would be a trap)
+                        if (keys.key(i).digit0 != 0 || keys.key(i).digits != c->first_level().K)
+                            throw std::logic_error("a digit-parallel slice of a key cannot be saved");
                         bytes += keys.key(i).digits * serial::ciphertext_save_size(2, c->n(), c->key_level().K);
+                    }
             return bytes;
         }
     } // namespace
@@ -782,13 +805,13 @@ extern "C"
             if (k.digit0 != 0 || k.digits != c->first_level().K)
                 throw std::logic_error("a digit-parallel slice of a key cannot be saved");
             put64(k.digits);
-            Scratch natural(k.digits * words);
-            keys->key_words(index, natural.p);
+            Scratch natural(words); // one digit at a time: the transient device memory of a save is 2 L N words, not a whole key
             for (size_t j = 0; j < k.digits; j++)
             {
                 size_t off = 0;
                 const size_t bytes = serial::save_ciphertext(c->key_level().parms_id, true, 2, n, L, 1.0, 1, nullptr, dst + pos, raw_bytes - pos, &off);
-                hip_ok(hipMemcpy(dst + pos + off, natural.p + j * words, words * 8, hipMemcpyDeviceToHost), "D2H");
+                keys->digit_words(index, j, natural.p);
+                hip_ok(hipMemcpy(dst + pos + off, natural.p, words * 8, hipMemcpyDeviceToHost), "D2H");
                 pos += bytes;
             }
         }
@@ -800,6 +823,13 @@ extern "C"
         if (compr_mode != 0)
             *out_bytes = (int64_t)serial::compress_stream(raw.data(), pos, compr_mode, outptr, (size_t)size);
         SHL_CATCH
+    }
+    SHL_FUNC KSwitchKeys_DeviceBytes(void *thisptr, uint64_t *bytes)
+    {
+        IfNullRet(thisptr, SHL_E_POINTER);
+        IfNullRet(bytes, SHL_E_POINTER);
+        *bytes = as<KSwitchKeys>(thisptr)->device_bytes();
+        return SHL_S_OK;
     }
     SHL_FUNC KSwitchKeys_Load(void *thisptr, void *context, uint8_t *inptr, uint64_t size, int64_t *in_bytes)
     {

@@ -128,6 +128,10 @@ namespace sealhip
         const std::vector<uint64_t> &coeff_modulus() const { return primes_; }
         bool using_keyswitching() const { return using_keyswitching_; }
         bool using_batching() const { return using_batching_; }
+        // sec_level_type of SEALContext's constructor (0 none, 128, 192, 256): recorded for EncryptionParameterQualifiers; the
+        // C ABI checks it against CoeffModulus::MaxBitCount before it builds the context (context.cpp:219-231 of the reference)
+        int sec_level() const { return sec_level_; }
+        void set_sec_level(int s) { sec_level_ = s; }
 
         // chain: levels_[0] is the key level (chain_index = size-1) ... back() has chain_index 0
         const std::vector<Level> &levels() const { return levels_; }
@@ -171,6 +175,7 @@ namespace sealhip
         std::vector<Level> levels_;
         bool using_keyswitching_ = false;
         bool using_batching_ = false;
+        int sec_level_ = 0;
         int plain_prime_ = -1;
 
         ModDesc *d_mods_ = nullptr;

@@ -282,6 +282,7 @@ namespace sealhip
             t2[fp].push_back(I);
             t2[fp].push_back(prime);
             t2[fp].push_back(prime);
+            t2[fp].push_back(key_comp_offset_units(context_.ntt_tables(), prime)); // where the component sits inside a digit (ntt2_kernels.h)
         }
         KsTargets kt;
         kt.n_int = (unsigned)t1[0].size() / 2;

@@ -166,6 +166,10 @@ namespace sealhip
         void set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0 = 0);
         // the words of key `index` as set_key took them ([digits][2][L][N], canonical, natural order), written to device memory
         void key_words(size_t index, uint64_t *device_out) const;
+        // one digit of key `index` ([2][L][N] words, as key_words): the transient conversion buffer of a save is one digit, not a key
+        void digit_words(size_t index, size_t digit, uint64_t *device_out) const;
+        // HBM held by the keys (register order: ntt2_kernels.h - a C5 key is 284 MB, its natural words 252 MB)
+        size_t device_bytes() const;
         void clear(); // drop every key (KSwitchKeys::load replaces the whole object, kswitchkeys.cpp:92-180)
         bool has_key(size_t index) const { return index < keys_.size() && keys_[index].dev != nullptr; }
         const Key &key(size_t index) const { return keys_[index]; }
@@ -178,10 +182,18 @@ namespace sealhip
         }
         size_t size() const;
         const Context *context() const { return ctx_; }
+        // KSwitchKeys::operator= (kswitchkeys.h:74-101): a deep copy, every key slab duplicated in HBM
+        void assign(const KSwitchKeys &other);
+        // KSwitchKeys::parms_id (kswitchkeys.h:169-183): the key level's once a key is installed, unless the caller wrote another
+        void get_parms_id(uint64_t *out) const;
+        void set_parms_id(const uint64_t *id);
 
     private:
         std::vector<Key> keys_;
         const Context *ctx_ = nullptr;
+        uint64_t parms_id_[4] = { 0, 0, 0, 0 };
+        bool parms_id_written_ = false;
+        size_t key_bytes(const Key &k) const;
     };
 
     class Evaluator

@@ -43,17 +43,35 @@ namespace sealhip
     };
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);
 
-    // [polys][L][N] natural-order key words -> register order of ks2, 2 N words per component: for primes of the double-precision back end N pairs of
-    // balanced doubles (first, second key polynomial of the digit) in the first polynomial's slot (the second's unused); for the integer back end's primes N pairs (word, floor(word * 2^64 / q)):
-    // the key is the precomputed operand of a Shoup product (round 3: the sums of ks2 then fit 64-bit words) and a pair is one
-    // 16-byte load.  `out` holds key_register_order_words(...) words.
-    hipError_t key_to_register_order(
-        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream);
-    // the way back: [polys][L][N] canonical words in natural order (what a saved key holds)
-    hipError_t key_from_register_order(
-        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream);
-    inline size_t key_register_order_words(int log_n, unsigned L, size_t polys)
+    // Register order of a key-switching key (what ks2 reads).  A decomposition digit is `key_digit_units(t, L)` units of N words,
+    // its components one after the other: a prime of the double-precision back end takes 2 units - N pairs of balanced doubles,
+    // (first, second key polynomial) of a coefficient side by side - a prime of the integer back end 4 units - N pairs
+    // (word, floor(word 2^64 / q)) of the first polynomial, then N pairs of the second: the key is the precomputed operand of a Shoup
+    // product (round 3: ks2's sums fit 64-bit words) and a pair is one 16-byte load.  Inside a component the position of
+    // coefficient (tile hg, row-in-tile, column) is hg*4096 + e*256 + tid  <->  natural hg*4096 + (tid>>4)*256 + (tid&15)*16 + e.
+    // (Round 3 gave every (polynomial, component) 2 N words and left the odd polynomial's slot of a double-precision prime unused:
+    // 504 MB per C5 key instead of 284 - ADVICE r3.)
+    inline unsigned key_comp_units(const NttTables &t, unsigned comp)
     {
-        return 2 * ((polys * L) << log_n);
+        return t.fp_host && t.fp_host[comp] ? 2u : 4u;
     }
+    inline unsigned key_comp_offset_units(const NttTables &t, unsigned comp) // of component `comp` inside a digit
+    {
+        unsigned u = 0;
+        for (unsigned c = 0; c < comp; c++)
+            u += key_comp_units(t, c);
+        return u;
+    }
+    inline unsigned key_digit_units(const NttTables &t, unsigned L)
+    {
+        return key_comp_offset_units(t, L);
+    }
+    inline size_t key_register_order_words(const NttTables &t, unsigned L, size_t digits)
+    {
+        return (digits * key_digit_units(t, L)) << t.log_n;
+    }
+    // [digits][2][L][N] natural-order canonical key words -> register order (`out` holds key_register_order_words(t, L, digits) words)
+    hipError_t key_to_register_order(const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t digits, hipStream_t stream);
+    // the way back: what a saved key holds.  Digits are self-contained: `in` may point at any digit of a resident key.
+    hipError_t key_from_register_order(const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t digits, hipStream_t stream);
 } // namespace sealhip

@@ -44,6 +44,7 @@ namespace sealhip
     namespace
     {
         constexpr int kThreads = 256;
+        constexpr unsigned kMaxKeyComps = 64; // SEAL_COEFF_MOD_COUNT_MAX
         template <int D1>
         struct Geo
         {
@@ -1755,9 +1756,10 @@ namespace sealhip
         {
             const uint64_t *mid;     // [batch][K+1][K][N]
             const uint64_t *target;  // [batch][K][N] NTT form (CKKS diagonal shortcut) or null
-            const uint64_t *key;     // [digits][2][L][2N] register order (key_to_register_order)
+            const uint64_t *key;     // [digits][key_digit_words] register order (ntt2_kernels.h: key_to_register_order)
+            size_t key_digit_words;  // words of one digit
             uint64_t *acc;           // [batch][2][K+1][N] natural order, canonical
-            const uint32_t *targets; // [ntargets] triples (I, prime, key component)
+            const uint32_t *targets; // [ntargets] quads (I, prime, key component, its offset inside a digit in units of N words)
             unsigned ntargets;
             unsigned K, L;
             unsigned batch;
@@ -1770,7 +1772,7 @@ namespace sealhip
 #define SEALHIP_KS2_INT_TWB3 1
 #endif
         template <bool FP, int D1, int ICLS = 0>
-        __device__ __forceinline__ void ks2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned kc, unsigned b, unsigned hg,
+        __device__ __forceinline__ void ks2_body(const Ks2Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned koff, unsigned b, unsigned hg,
                                                  unsigned j0, unsigned j1, uint64_t *acc_part)
         {
             typedef Field<FP> F;
@@ -1920,8 +1922,8 @@ namespace sealhip
                     for (int e = 0; e < 16; e++)
                         x[e] = F::unraw(nxt[e]);
                 }
-                // every key component owns 2 N words: N doubles (double-precision primes) or N (word, Shoup quotient) pairs
-                const size_t kslab = (((size_t)(J - a.key_digit0) * 2 + 0) * a.L + kc) * 2 * N;
+                // this component of digit J: N pairs of doubles (double-precision primes) or 2 x N (word, Shoup quotient) pairs
+                const size_t kslab = (size_t)(J - a.key_digit0) * a.key_digit_words + (size_t)koff * N;
                 typename F::key_t kr0[16], kr1[16];
                 if constexpr (FP)
                 {
@@ -1966,7 +1968,7 @@ namespace sealhip
                 {
                     // the word and its quotient are neighbours: one 16-byte load each (register order in units of pairs)
                     const ShoupOp *p0 = reinterpret_cast<const ShoupOp *>(a.key + kslab) + ((size_t)hg << 12) + tid;
-                    const ShoupOp *p1 = p0 + (size_t)a.L * N;
+                    const ShoupOp *p1 = p0 + N; // the second key polynomial's pairs follow the first's
 #pragma unroll
                     for (int e = 0; e < 16; e++)
                     {
@@ -2056,48 +2058,64 @@ namespace sealhip
             if (tile >= ntile)
                 return;
             const unsigned it = tile / G::TILES, hg = tile % G::TILES;
-            const unsigned I = SHL_UNIFORM(a.targets[3 * it]), prime = SHL_UNIFORM(a.targets[3 * it + 1]), kc = SHL_UNIFORM(a.targets[3 * it + 2]);
+            const unsigned I = SHL_UNIFORM(a.targets[4 * it]), prime = SHL_UNIFORM(a.targets[4 * it + 1]), koff = SHL_UNIFORM(a.targets[4 * it + 3]);
             if constexpr (CLS == 1)
-                ks2_body<true, D1>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part);
+                ks2_body<true, D1>(a, lds, I, prime, koff, b, hg, j0, j1, acc_part);
             else
-                with_int_class(a.tb, prime, [&](auto ic) { ks2_body<false, D1, decltype(ic)::value>(a, lds, I, prime, kc, b, hg, j0, j1, acc_part); });
+                with_int_class(a.tb, prime, [&](auto ic) { ks2_body<false, D1, decltype(ic)::value>(a, lds, I, prime, koff, b, hg, j0, j1, acc_part); });
         }
 
-        // natural order (u64) -> register order, optionally converted to double
+        // per-component offsets of a digit in units of N words (ntt2_kernels.h: key_comp_offset_units), one table per workgroup
+        __device__ __forceinline__ void key_offsets(unsigned *off, const FpDesc *fpd, unsigned L)
+        {
+            if (threadIdx.x == 0)
+            {
+                unsigned u = 0;
+                for (unsigned c = 0; c < L; c++)
+                {
+                    off[c] = u;
+                    u += fpd[c].qi ? 2u : 4u;
+                }
+                off[L] = u;
+            }
+            __syncthreads();
+        }
+        // natural order (u64) [digits][2][L][N] -> register order (ntt2_kernels.h)
         __global__ void __launch_bounds__(kThreads) key_layout_kernel(
             const uint64_t *in, uint64_t *out, const FpDesc *fpd, const ModDesc *mods, unsigned L, unsigned n_log, size_t polys)
         {
+            __shared__ unsigned off[kMaxKeyComps + 1];
+            key_offsets(off, fpd, L);
             const size_t N = (size_t)1 << n_log;
             const size_t total = polys * L * N;
             for (size_t i = blockIdx.x * (size_t)kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads)
             {
                 const size_t p = i & (N - 1), slab = i >> n_log;
                 const unsigned comp = (unsigned)(slab % L);
+                const size_t poly = slab / L, digit = poly >> 1;
+                const unsigned k = (unsigned)(poly & 1);
                 // destination position p = hg*4096 + e*256 + tid  <-  natural hg*4096 + (tid>>4)*256 + (tid&15)*16 + e
                 const size_t hg = p >> 12;
                 const unsigned e = (unsigned)(p >> 8) & 15, tid = (unsigned)p & 255;
                 size_t nat = (hg << 12) + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 4) + e;
                 const uint64_t v = in[(slab << n_log) + nat];
-                uint64_t *o = out + (slab << (n_log + 1)); // this component's 2 N words
+                uint64_t *o = out + ((digit * off[L] + off[comp]) << n_log); // this component of this digit
                 if (fpd[comp].qi)
                 {
-                    // balanced representative in (-q/2, q/2] (see Context: the same halving of the bound for the key products)
+                    // balanced representative in (-q/2, q/2] (see Context: the same halving of the bound for the key products);
+                    // the two polynomials of a digit side by side: ks2 reads both with one 16-byte load
                     double d = fp_from_u52(v);
                     if (v > fpd[comp].qi / 2)
                         d -= fpd[comp].q;
-                    // the two polynomials of a digit side by side in the first one's slot: ks2 reads both with one 16-byte load
-                    const size_t poly = slab / L;
-                    out[((((poly & ~(size_t)1) * L + comp)) << (n_log + 1)) + 2 * p + (poly & 1)] = fp_to_bits(d);
+                    o[2 * p + k] = fp_to_bits(d);
                 }
                 else
                 {
-                    // integer back end: the word and, one plane further on, floor(v 2^64 / q) (exact: estimate from the
+                    // integer back end: the word and, next to it, floor(v 2^64 / q) (exact: estimate from the
                     // Barrett ratio floor(2^128 / q), then at most two corrections)
                     typedef unsigned __int128 u128;
                     const ModDesc md = mods[comp];
-                    const u128 ratio = ((u128)md.ratio_hi << 64) | md.ratio_lo;
                     const u128 vr = (u128)v * md.ratio_hi + (((u128)v * md.ratio_lo) >> 64); // floor(v * ratio / 2^64), below 2^64 + 1
-                    (void)ratio;
                     uint64_t est = vr > (u128)~(uint64_t)0 ? ~(uint64_t)0 : (uint64_t)vr;
                     u128 rem = ((u128)v << 64) - (u128)est * md.q;
                     while (rem >= md.q)
@@ -2105,6 +2123,7 @@ namespace sealhip
                         rem -= md.q;
                         est++;
                     }
+                    o += (size_t)k << (n_log + 1); // the second polynomial's N pairs follow the first's
                     o[2 * p] = v;
                     o[2 * p + 1] = est;
                 }
@@ -2115,26 +2134,30 @@ namespace sealhip
         __global__ void __launch_bounds__(kThreads) key_unlayout_kernel(
             const uint64_t *in, uint64_t *out, const FpDesc *fpd, unsigned L, unsigned n_log, size_t polys)
         {
+            __shared__ unsigned off[kMaxKeyComps + 1];
+            key_offsets(off, fpd, L);
             const size_t N = (size_t)1 << n_log;
             const size_t total = polys * L * N;
             for (size_t i = blockIdx.x * (size_t)kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads)
             {
                 const size_t p = i & (N - 1), slab = i >> n_log;
                 const unsigned comp = (unsigned)(slab % L);
+                const size_t poly = slab / L, digit = poly >> 1;
+                const unsigned k = (unsigned)(poly & 1);
                 const size_t hg = p >> 12;
                 const unsigned e = (unsigned)(p >> 8) & 15, tid = (unsigned)p & 255;
                 const size_t nat = (hg << 12) + ((size_t)(tid >> 4) << 8) + ((tid & 15) << 4) + e;
+                const uint64_t *o = in + ((digit * off[L] + off[comp]) << n_log);
                 uint64_t v;
                 if (fpd[comp].qi)
                 {
-                    const size_t poly = slab / L;
-                    double d = fp_from_bits(in[((((poly & ~(size_t)1) * L + comp)) << (n_log + 1)) + 2 * p + (poly & 1)]);
+                    double d = fp_from_bits(o[2 * p + k]);
                     if (d < 0)
                         d += fpd[comp].q; // balanced -> [0, q)
                     v = (uint64_t)d;
                 }
                 else
-                    v = in[(slab << (n_log + 1)) + 2 * p];
+                    v = o[((size_t)k << (n_log + 1)) + 2 * p];
                 out[(slab << n_log) + nat] = v;
             }
         }
@@ -2474,7 +2497,7 @@ namespace sealhip
                 if (e != hipSuccess)
                     return e;
                 Ks2Args c2 = a2;
-                c2.targets = a2.targets + 3 * t0;
+                c2.targets = a2.targets + 4 * t0;
                 c2.ntargets = nt;
                 const unsigned ntile = nt * G::TILES;
                 if (fp)
@@ -2643,6 +2666,7 @@ namespace sealhip
         a2.mid = k.mid;
         a2.target = k.target_ntt;
         a2.key = k.key;
+        a2.key_digit_words = (size_t)key_digit_units(t, k.L) << t.log_n;
         a2.acc = k.acc;
         a2.targets = k.targets2;
         a2.ntargets = k.ntargets;
@@ -2669,9 +2693,11 @@ namespace sealhip
         }
     }
 
-    hipError_t key_to_register_order(
-        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream)
+    hipError_t key_to_register_order(const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t digits, hipStream_t stream)
     {
+        if (L > kMaxKeyComps)
+            return hipErrorInvalidValue;
+        const size_t polys = 2 * digits;
         size_t total = (polys * L) << t.log_n;
         size_t blocks = (total + kThreads - 1) / kThreads;
         if (blocks > 4096)
@@ -2679,9 +2705,11 @@ namespace sealhip
         hipLaunchKernelGGL(key_layout_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, out, t.fpd, t.mods, L, (unsigned)t.log_n, polys);
         return hipGetLastError();
     }
-    hipError_t key_from_register_order(
-        const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t polys, hipStream_t stream)
+    hipError_t key_from_register_order(const NttTables &t, const uint64_t *in, uint64_t *out, unsigned L, size_t digits, hipStream_t stream)
     {
+        if (L > kMaxKeyComps)
+            return hipErrorInvalidValue;
+        const size_t polys = 2 * digits;
         size_t total = (polys * L) << t.log_n;
         size_t blocks = (total + kThreads - 1) / kThreads;
         if (blocks > 4096)

@@ -262,6 +262,56 @@ namespace sealhip
             c += k.dev != nullptr;
         return c;
     }
+    size_t KSwitchKeys::key_bytes(const Key &k) const
+    {
+        const size_t L = ctx_->key_level().K;
+        return k.register_order ? key_register_order_words(ctx_->ntt_tables(), (unsigned)L, k.digits) * 8 : k.digits * 2 * L * ctx_->n() * 8;
+    }
+    void KSwitchKeys::assign(const KSwitchKeys &o)
+    {
+        if (this == &o)
+            return;
+        std::vector<Key> fresh(o.keys_.size());
+        try
+        {
+            for (size_t i = 0; i < o.keys_.size(); i++)
+            {
+                if (!o.keys_[i].dev)
+                    continue;
+                fresh[i] = o.keys_[i];
+                fresh[i].dev = nullptr;
+                void *p = nullptr;
+                const size_t bytes = o.key_bytes(o.keys_[i]);
+                ck(hipMalloc(&p, bytes), "hipMalloc key");
+                fresh[i].dev = (uint64_t *)p;
+                ck(hipMemcpy(p, o.keys_[i].dev, bytes, hipMemcpyDeviceToDevice), "copy key");
+            }
+        }
+        catch (...)
+        {
+            for (auto &k : fresh)
+                if (k.dev)
+                    (void)hipFree(k.dev);
+            throw;
+        }
+        clear();
+        keys_ = std::move(fresh);
+        ctx_ = o.ctx_;
+        std::memcpy(parms_id_, o.parms_id_, sizeof(parms_id_));
+        parms_id_written_ = o.parms_id_written_;
+    }
+    void KSwitchKeys::get_parms_id(uint64_t *out) const
+    {
+        if (parms_id_written_ || !ctx_ || size() == 0)
+            std::memcpy(out, parms_id_, sizeof(parms_id_));
+        else
+            std::memcpy(out, ctx_->key_level().parms_id, sizeof(parms_id_));
+    }
+    void KSwitchKeys::set_parms_id(const uint64_t *id)
+    {
+        std::memcpy(parms_id_, id, sizeof(parms_id_));
+        parms_id_written_ = true;
+    }
     void KSwitchKeys::set_key(const Context &ctx, size_t index, size_t digits, const uint64_t *words, bool from_device, size_t digit0)
     {
         if (!words)
@@ -284,10 +334,34 @@ namespace sealhip
         const Key &k = keys_[index];
         const size_t L = ctx_->key_level().K;
         if (k.register_order)
-            ck(key_from_register_order(ctx_->ntt_tables(), k.dev, device_out, (unsigned)L, k.digits * 2, nullptr), "key layout");
+            ck(key_from_register_order(ctx_->ntt_tables(), k.dev, device_out, (unsigned)L, k.digits, nullptr), "key layout");
         else
             ck(hipMemcpy(device_out, k.dev, k.digits * 2 * L * ctx_->n() * 8, hipMemcpyDeviceToDevice), "key copy");
         ck(hipDeviceSynchronize(), "key layout sync");
+    }
+
+    void KSwitchKeys::digit_words(size_t index, size_t digit, uint64_t *device_out) const
+    {
+        if (!has_key(index) || !ctx_ || digit >= keys_[index].digits)
+            throw std::invalid_argument("no such key digit");
+        const Key &k = keys_[index];
+        const size_t L = ctx_->key_level().K, words = 2 * L * ctx_->n();
+        if (k.register_order)
+        {
+            const size_t stride = (size_t)key_digit_units(ctx_->ntt_tables(), (unsigned)L) << ctx_->log_n();
+            ck(key_from_register_order(ctx_->ntt_tables(), k.dev + digit * stride, device_out, (unsigned)L, 1, nullptr), "key layout");
+        }
+        else
+            ck(hipMemcpy(device_out, k.dev + digit * words, words * 8, hipMemcpyDeviceToDevice), "key copy");
+        ck(hipDeviceSynchronize(), "key layout sync");
+    }
+    size_t KSwitchKeys::device_bytes() const
+    {
+        size_t b = 0;
+        for (auto &k : keys_)
+            if (k.dev)
+                b += key_bytes(k);
+        return b;
     }
 
     void KSwitchKeys::set_key_with(const Context &ctx, size_t index, size_t digits, const std::function<void(uint64_t *)> &upload, size_t digit0)
@@ -308,13 +382,13 @@ namespace sealhip
         void *p = nullptr;
         const bool reorder = ntt2_supports(ctx.log_n()) && !shl_ab_getenv("SEALHIP_OLD_KS");
         // register order carries a second plane: the Shoup quotients of the integer back end's components
-        ck(hipMalloc(&p, reorder ? key_register_order_words(ctx.log_n(), (unsigned)L, digits * 2) * 8 : bytes), "hipMalloc key");
+        ck(hipMalloc(&p, reorder ? key_register_order_words(ctx.ntt_tables(), (unsigned)L, digits) * 8 : bytes), "hipMalloc key");
         if (reorder)
         {
             // upload to a staging block, then lay the key out for the fused kernel
             Scratch stage(bytes / 8);
             upload(stage.p);
-            ck(key_to_register_order(ctx.ntt_tables(), stage.p, (uint64_t *)p, (unsigned)L, digits * 2, nullptr), "key layout");
+            ck(key_to_register_order(ctx.ntt_tables(), stage.p, (uint64_t *)p, (unsigned)L, digits, nullptr), "key layout");
             ck(hipDeviceSynchronize(), "key layout sync");
         }
         else

@@ -755,6 +755,50 @@ namespace sealhip
             return true;
         }
 
+        size_t load_encryption_parameters(const uint8_t *in, size_t size, uint8_t &scheme, uint64_t &poly_modulus_degree,
+                                          std::vector<uint64_t> &coeff_modulus, uint64_t &plain_modulus)
+        {
+            if (!in)
+                throw std::invalid_argument("in cannot be null");
+            if (size < sizeof(Header))
+                throw std::invalid_argument("insufficient size");
+            Reader r{ in, size };
+            return framed(r, [&](Reader &m, Version) {
+                const uint8_t sch = m.get<uint8_t>();
+                if (sch > 3) // EncryptionParameters(uint8_t scheme) (encryptionparams.h:166-175)
+                    throw std::invalid_argument("unsupported scheme");
+                const uint64_t n = m.get<uint64_t>();
+                if (n > 131072) // SEAL_POLY_MOD_DEGREE_MAX
+                    throw std::logic_error("poly_modulus_degree is invalid");
+                const uint64_t k = m.get<uint64_t>();
+                if (k > kMaxComps) // SEAL_COEFF_MOD_COUNT_MAX
+                    throw std::logic_error("coeff_modulus is invalid");
+                // Modulus::load -> Modulus::set_value (modulus.cpp:71-93): at most 61 bits and not 1
+                auto modulus = [&](Reader &mm) {
+                    uint64_t v = 0;
+                    framed(mm, [&](Reader &inner, Version) { v = inner.get<uint64_t>(); });
+                    if ((v >> 61) != 0 || v == 1)
+                        throw std::invalid_argument("value can be at most 61-bit and cannot be 1");
+                    return v;
+                };
+                std::vector<uint64_t> q;
+                for (uint64_t i = 0; i < k; i++)
+                    q.push_back(modulus(m));
+                const uint64_t t = modulus(m);
+                // set_poly_modulus_degree / set_coeff_modulus / set_plain_modulus (encryptionparams.h:190-262)
+                if (sch == 0 && (n || k))
+                    throw std::logic_error(n ? "poly_modulus_degree is not supported for this scheme" : "coeff_modulus is not supported for this scheme");
+                if (sch != 0 && k < 1)
+                    throw std::invalid_argument("coeff_modulus is invalid");
+                if ((sch == 0 || sch == 2) && t != 0)
+                    throw std::logic_error("plain_modulus is not supported for this scheme");
+                scheme = sch;
+                poly_modulus_degree = n;
+                coeff_modulus = q;
+                plain_modulus = t;
+            });
+        }
+
         size_t plaintext_save_size(uint64_t coeff_count)
         {
             return sizeof(Header) + 32 + 8 + 8 + sizeof(Header) + 8 + (size_t)coeff_count * 8;

@@ -111,6 +111,12 @@ namespace sealhip
         size_t save_plaintext(const uint64_t *parms_id, uint64_t coeff_count, double scale, const uint64_t *words, uint8_t *out,
                               size_t capacity, size_t *data_offset = nullptr);
 
+        // EncryptionParameters::load (encryptionparams.cpp:51-122): scheme (u8), poly_modulus_degree, coeff_modulus_size (u64 each), every
+        // Modulus as its own SEALHeader + u64, then the plain modulus the same way.  Returns the bytes consumed; throws the reference's
+        // classes (logic_error for an invalid scheme / degree / modulus count, runtime_error("I/O error") for a short stream).
+        size_t load_encryption_parameters(const uint8_t *in, size_t size, uint8_t &scheme, uint64_t &poly_modulus_degree,
+                                          std::vector<uint64_t> &coeff_modulus, uint64_t &plain_modulus);
+
         // The reference's buffered PRNG (UniformRandomGenerator, randomgen.cpp:179-227): type 1 = Blake2xbPRNG, 2 = Shake256PRNG
         struct Prng
         {

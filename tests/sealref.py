@@ -61,6 +61,16 @@ def plain_modulus_batching(n, bits):
     return out.value
 
 
+def parms_load(data):
+    """EncryptionParameters::load -> (scheme, poly_modulus_degree, primes, plain_modulus); raises RefError with the reference's class"""
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(bytes(data))
+    scheme = C.c_int()
+    deg, plain, cnt = C.c_uint64(), C.c_uint64(), C.c_uint64(256)
+    primes = np.zeros(256, dtype=np.uint64)
+    _ck(lib().ref_parms_load(buf, C.c_uint64(len(data)), C.byref(scheme), C.byref(deg), C.byref(plain), _p(primes), C.byref(cnt)))
+    return scheme.value, deg.value, [int(x) for x in primes[: cnt.value]], plain.value
+
+
 def bfv_default(n):
     out = np.zeros(64, dtype=np.uint64)
     cnt = C.c_uint64()
@@ -196,6 +206,38 @@ class RefContext:
         _ck(lib().ref_key_set(self.h, C.c_int(k), C.c_uint64(index), _p(w)))
 
     # -- wire format
+    # -- container surface (tests/container_cases.py)
+    def data_words(self, chain_index, which):
+        """0 total_coeff_modulus, 1 coeff_div_plain_modulus, 2 plain_upper_half_increment, 3 upper_half_threshold, 4 upper_half_increment;
+        [] when the reference did not compute it for these parameters"""
+        out = np.zeros(256, dtype=np.uint64)
+        cnt = C.c_uint64()
+        _ck(lib().ref_ctx_data_words(self.h, C.c_uint64(chain_index), C.c_int(which), _p(out), C.byref(cnt)))
+        return [int(x) for x in out[: cnt.value]]
+
+    def qualifiers(self, chain_index):
+        out = (C.c_int * 8)()
+        puht = C.c_uint64()
+        _ck(lib().ref_ctx_qualifiers(self.h, C.c_uint64(chain_index), out, C.byref(puht)))
+        keys = ("total_coeff_modulus_bit_count", "using_fft", "using_ntt", "using_batching", "using_fast_plain_lift",
+                "using_descending_modulus_chain", "sec_level", "parameters_set")
+        d = {k: int(v) for k, v in zip(keys, out)}
+        d["plain_upper_half_threshold"] = puht.value
+        return d
+
+    def parms_save(self, chain_index, mode=0):
+        buf = (C.c_uint8 * 8192)()
+        n = C.c_uint64()
+        _ck(lib().ref_parms_save(self.h, C.c_uint64(chain_index), C.c_int(mode), buf, C.c_uint64(8192), C.byref(n)))
+        return bytes(buf[: n.value])
+
+    def ct_container_op(self, ct, op, chain_index, n):
+        """op: 0 reserve(context, parms_id, n)  1 reserve(n)  2 resize(context, parms_id, n)  3 resize(n)  4 release()
+        -> (size, size_capacity, coeff_modulus_size, poly_modulus_degree)"""
+        out = (C.c_uint64 * 4)()
+        _ck(lib().ref_ct_container_op(self.h, ct.h, C.c_int(op), C.c_uint64(chain_index), C.c_uint64(n), out))
+        return tuple(int(v) for v in out)
+
     def parms_id(self, chain_index):
         out = (C.c_uint64 * 4)()
         _ck(lib().ref_ctx_parms_id(self.h, C.c_uint64(chain_index), out))

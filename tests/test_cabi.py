@@ -70,3 +70,57 @@ def test_no_cpu_fallback_without_a_device(lib):
     else:
         assert hr == 0x80131620  # COR_E_IO: "no HIP device visible: libsealhip has no CPU fallback"
     lib.EncParams_Destroy(p)
+
+
+# ---- the container headers of sealc against include/sealhip.h
+REF_C = "/root/reference/native/src/seal/c"
+CONTAINER_HEADERS = ["ciphertext", "kswitchkeys", "sealcontext", "contextdata", "encryptionparameters", "secretkey", "publickey"]
+
+
+def _signatures(text, marker):
+    """{name: [argument types]} of every `marker name(args);` declaration; parameter names and const are dropped"""
+    out = {}
+    for name, args in re.findall(marker + r"\s+(\w+)\s*\(([^)]*)\)\s*;", text):
+        types = []
+        for a in [x.strip() for x in args.split(",")]:
+            if a in ("", "void"):
+                continue
+            a = re.sub(r"\bconst\b", "", a)
+            a = re.sub(r"\w+$", "", a.strip()) if not a.strip().endswith("*") else a   # drop the parameter name
+            types.append(re.sub(r"\s+", "", a))
+        out[name] = types
+    return out
+
+
+def _listed(text, heading):
+    """the function names in the comment block of sealhip.h that starts with `heading` (up to the next block)"""
+    start = text.index(heading)
+    end = min(i for i in (text.find("SAME NAME, DIFFERENT ARGUMENTS", start + 1), text.find("Everything else of those headers", start)) if i > 0)
+    return set(re.findall(r"\b(?:Ciphertext|KSwitchKeys|SEALContext|ContextData|EncParams|SecretKey|PublicKey)_\w+", text[start:end]))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_C), reason="the reference tree is only in the build container")
+def test_container_headers_are_covered_or_listed():
+    text = open(HEADER).read()
+    ours = _signatures(text, "SHL_FUNC")
+    absent = _listed(text, "DELIBERATELY ABSENT")
+    differ = _listed(text, "SAME NAME, DIFFERENT ARGUMENTS")
+    # the explanations may mention functions that DO exist here (what to use instead): only undeclared names count as absent
+    absent = {n for n in absent if n not in ours}
+    problems = []
+    for h in CONTAINER_HEADERS:
+        ref = _signatures(open(os.path.join(REF_C, h + ".h")).read(), "SEAL_C_FUNC")
+        assert ref, h
+        for name, types in ref.items():
+            if name in absent:
+                continue
+            if name not in ours:
+                problems.append("%s.h: %s is neither declared nor listed as deliberately absent" % (h, name))
+            elif name not in differ and ours[name] != types:
+                problems.append("%s.h: %s%r is declared here as %r" % (h, name, types, ours[name]))
+    assert not problems, "\n".join(problems)
+    # and the lists do not rot: every listed name is a sealc function of these headers
+    all_ref = set()
+    for h in CONTAINER_HEADERS:
+        all_ref |= set(_signatures(open(os.path.join(REF_C, h + ".h")).read(), "SEAL_C_FUNC"))
+    assert absent <= all_ref and {n for n in differ if n in ours} <= all_ref | {"SecretKey_Assign", "PublicKey_Assign"}, (absent - all_ref, differ - all_ref)
