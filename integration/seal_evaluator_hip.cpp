@@ -161,6 +161,7 @@ namespace
         std::map<std::uintptr_t, Mirror> by_begin;
         std::size_t page = 4096;
         bool eager = false, trace = false;
+        bool handler_installed = false, atexit_registered = false; // (guarded by mu like everything else here)
         struct sigaction previous{};
         // statistics (tests, tools): transfers avoided / done
         std::size_t uploads = 0, downloads = 0, reused = 0, faults = 0;
@@ -174,18 +175,22 @@ namespace
     // The default copies every result down before the call returns, which is what the reference's contract needs in general -
     // any thread, any kind of access to Ciphertext::data() (also from system calls, which do not fault on a protected page but
     // fail with EFAULT), no signal handler in the process.  See INTEGRATION.md section 2c for what resident mode asks of a host.
+    // (the caller holds mm.mu)
     void enable_resident(Mirrors &mm)
     {
-        static bool installed = false;
-        if (!installed)
+        if (!mm.handler_installed)
         {
-            installed = true;
+            mm.handler_installed = true;
             // the library must not register our (pageable) buffers with the driver: their protection changes
             SealHip_SetStagedHostCopies(true);
             // At process exit every shadow is settled while the HIP runtime is still alive (this handler is registered late, so
             // it runs before the destructors of the pools and of the runtime): afterwards nothing is protected any more and
             // later calls, if any, copy eagerly.
-            std::atexit(settle_all_at_exit);
+            if (!mm.atexit_registered)
+            {
+                mm.atexit_registered = true;
+                std::atexit(settle_all_at_exit);
+            }
             struct sigaction sa{};
             sa.sa_sigaction = segv_handler;
             sa.sa_flags = SA_SIGINFO | SA_NODEFER;
@@ -194,6 +199,24 @@ namespace
         }
         mm.eager = false;
     }
+    // the way back: every shadow settled by the caller, the process gets its SIGSEGV disposition and the library its
+    // direct host copies back - unless somebody installed another handler on top of ours in the meantime, which is then left alone
+    void disable_resident(Mirrors &mm)
+    {
+        mm.eager = true;
+        if (!mm.handler_installed)
+            return;
+        struct sigaction current{};
+        sigaction(SIGSEGV, nullptr, &current);
+        if ((current.sa_flags & SA_SIGINFO) && current.sa_sigaction == segv_handler)
+        {
+            sigaction(SIGSEGV, &mm.previous, nullptr);
+            mm.handler_installed = false;
+            SealHip_SetStagedHostCopies(false);
+        }
+        else if (mm.trace)
+            std::fprintf(stderr, "[sealhip dropin] another SIGSEGV handler sits on top of ours: left in place, ours stays installed underneath\n");
+    }
     Mirrors &mirrors()
     {
         static Mirrors *m = [] {
@@ -201,7 +224,9 @@ namespace
             mm->page = (std::size_t)sysconf(_SC_PAGESIZE);
             mm->eager = true;
             mm->trace = std::getenv("SEALHIP_DROPIN_TRACE") != nullptr;
-            if (std::getenv("SEALHIP_DROPIN_RESIDENT") && !std::getenv("SEALHIP_DROPIN_EAGER"))
+            if (std::getenv("SEALHIP_DROPIN_RESIDENT") && std::getenv("SEALHIP_DROPIN_EAGER"))
+                std::fprintf(stderr, "[sealhip dropin] SEALHIP_DROPIN_RESIDENT and SEALHIP_DROPIN_EAGER are both set: EAGER wins, results are copied down in every call\n");
+            else if (std::getenv("SEALHIP_DROPIN_RESIDENT"))
                 enable_resident(*mm);
             return mm;
         }();
@@ -1068,7 +1093,7 @@ extern "C" int sealhip_dropin_set_resident(int on)
     else if (!mm.eager)
     {
         resolve_range(0, ~(std::uintptr_t)0);
-        mm.eager = true;
+        disable_resident(mm);
     }
     return was;
 }

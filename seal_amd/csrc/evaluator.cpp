@@ -886,12 +886,29 @@ namespace sealhip
             const Level &lvl = *e1.level();
             PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
             dest.reshape_uninitialized(&lvl, 3);
-            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, e1.data(), e2.data(), dest.data(), g, stream_), "ckks_multiply");
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, e1.data(), e2.data(), dest.data(), g, stream_), "ckks_multiply");
             dest.is_ntt_form() = true;
             dest.correction_factor() = 1;
             dest.scale() = e1.scale() * e2.scale();
             if (!scale_within_bounds(dest.scale(), lvl))
                 throw std::invalid_argument("scale out of bounds");
+            throw_if_transparent(dest);
+            return;
+        }
+        if (context_.scheme() == Scheme::bfv && &dest.context() == &context_ && dest.batch() == e1.batch())
+        {
+            // BFV: the same checks as multiply_inplace, then the product straight into `dest` (no copy of encrypted1: 6.8 GB per
+            // step at BASELINE configs[3])
+            check_valid(e1, "encrypted1");
+            check_valid(e2, "encrypted2");
+            if (e1.level() != e2.level())
+                throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            if (e1.batch() != e2.batch())
+                throw std::invalid_argument("batch mismatch");
+            bfv_multiply_to(e1, e2, dest);
+            dest.is_ntt_form() = false;
+            dest.scale() = e1.scale();
+            dest.correction_factor() = e1.correction_factor();
             throw_if_transparent(dest);
             return;
         }
@@ -922,12 +939,12 @@ namespace sealhip
         if (e1.capacity_words() >= words)
         {
             e1.reshape_uninitialized(&lvl, 3); // enough room: the words stay where they are
-            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, x, y, e1.data(), g, stream_), "multiply 2x2");
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, x, y, e1.data(), g, stream_), "multiply 2x2");
         }
         else
         {
             uint64_t *out = DevicePool::global().alloc_words(words, stream_);
-            ck(k_ckks_multiply_2x2(context_.dev_mods(), nullptr, x, y, out, g, stream_), "multiply 2x2");
+            ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, x, y, out, g, stream_), "multiply 2x2");
             e1.adopt(&lvl, 3, out, words);
         }
     }
@@ -994,6 +1011,12 @@ namespace sealhip
 
     void Evaluator::bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const
     {
+        bfv_multiply_to(e1, e2, e1);
+    }
+    // the product of e1 and e2 into dest (dest may be e1): BEHZ reads its operands through the first transform pass and builds the
+    // result in a new slab, so an out-of-place product needs no copy of e1 (evaluator.h:239-247 copies it first)
+    void Evaluator::bfv_multiply_to(const Ciphertext &e1, const Ciphertext &e2, Ciphertext &dst) const
+    {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (e1.is_ntt_form() || e2.is_ntt_form())
             throw std::invalid_argument("encrypted1 or encrypted2 cannot be in NTT form");
@@ -1055,7 +1078,7 @@ namespace sealhip
         size_t words = dest * B * K * N;
         uint64_t *out = DevicePool::global().alloc_words(words);
         ck(k_behz_floor_sk(mods, lv, d_q.p, d_b.p, out, n_log, dest * B, stream_), "behz floor_sk");
-        e1.adopt(&lvl, dest, out, words);
+        dst.adopt(&lvl, dest, out, words);
     }
 
 } // namespace sealhip

@@ -325,6 +325,7 @@ namespace sealhip
         void check_valid(const Ciphertext &ct, const char *what) const;
         bool scale_within_bounds(double scale, const Level &lvl) const;
         void bfv_multiply(Ciphertext &e1, const Ciphertext &e2) const;
+        void bfv_multiply_to(const Ciphertext &e1, const Ciphertext &e2, Ciphertext &dst) const;
         void bgv_multiply(Ciphertext &e1, const Ciphertext &e2) const;
         void check_valid(const Plaintext &plain) const;
         void addsub_plain(Ciphertext &encrypted, const Plaintext &plain, int op) const;

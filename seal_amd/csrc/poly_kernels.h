@@ -24,8 +24,9 @@ namespace sealhip
 
     // out (size 3) = x (size 2) * y (size 2); out may be x (in place).  Planes are plane_words apart.
     // comp_prime (device, may be null = identity) maps a component to its pool prime.
+    // fpd (device, may be null = integer arithmetic for every prime): the double-precision back end's descriptors (ntt_kernels.h).
     hipError_t k_ckks_multiply_2x2(
-        const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out, PlaneGeom g,
+        const ModDesc *mods, const FpDesc *fpd, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out, PlaneGeom g,
         hipStream_t s);
     // out[I] = sum_a x[a] * y[I-a] for general sizes; out must not alias x or y.
     hipError_t k_multiply_general(

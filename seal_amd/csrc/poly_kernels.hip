@@ -28,16 +28,32 @@ namespace sealhip
             hi += ph + (lo < pl);
         }
 
+        // Primes of the double-precision back end (below 2^50, fpd[prime].qi != 0) take the exact-FMA products of field.h: 44 vector
+        // instructions per coefficient where the 128-bit Barrett path costs 331 - the kernel sat on the vector ALU and on HBM at
+        // once.  Canonical inputs are exact doubles, |a b| < q^2 keeps every residue below 0.875 q (fp_mulmod),
+        // the middle sum below 1.75 q takes one fix(); results leave as canonical words: the same bits as the integer path.
         __global__ void __launch_bounds__(kBlock) ckks_multiply_2x2_kernel(
-            const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out, unsigned n_log,
-            unsigned K, size_t plane_words)
+            const ModDesc *mods, const FpDesc *fpd, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out,
+            unsigned n_log, unsigned K, size_t plane_words)
         {
             for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < plane_words; i += (size_t)gridDim.x * kBlock)
             {
                 const unsigned comp = (unsigned)((i >> n_log) % K);
-                const ModDesc md = mods[comp_prime ? comp_prime[comp] : comp];
+                const unsigned prime = comp_prime ? comp_prime[comp] : comp;
                 uint64_t x0 = x[i], x1 = x[plane_words + i];
                 uint64_t y0 = y[i], y1 = y[plane_words + i];
+                if (fpd && fpd[prime].qi)
+                {
+                    const FpDesc f = fpd[prime];
+                    const double a0 = fp_from_u52(x0), a1 = fp_from_u52(x1), b0 = fp_from_u52(y0), b1 = fp_from_u52(y1);
+                    const double r00 = fp_mulmod(a0, b0, f.q, f.qinv), r11 = fp_mulmod(a1, b1, f.q, f.qinv);
+                    const double mid = fp_mulmod(a0, b1, f.q, f.qinv) + fp_mulmod(a1, b0, f.q, f.qinv);
+                    out[i] = fp_to_canon(r00, f);
+                    out[plane_words + i] = fp_to_canon(fp_fix(mid, f.q, f.qinv), f);
+                    out[2 * plane_words + i] = fp_to_canon(r11, f);
+                    continue;
+                }
+                const ModDesc md = mods[prime];
                 uint64_t lo = 0, hi = 0;
                 mac128(lo, hi, x0, y1);
                 mac128(lo, hi, x1, y0);
@@ -576,12 +592,12 @@ namespace sealhip
     } // namespace
 
     hipError_t k_ckks_multiply_2x2(
-        const ModDesc *mods, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out, PlaneGeom g,
+        const ModDesc *mods, const FpDesc *fpd, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out, PlaneGeom g,
         hipStream_t s)
     {
         size_t w = g.words();
         hipLaunchKernelGGL(
-            ckks_multiply_2x2_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, comp_prime, x, y, out, g.n_log, g.K, w);
+            ckks_multiply_2x2_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, fpd, comp_prime, x, y, out, g.n_log, g.K, w);
         return hipGetLastError();
     }
     hipError_t k_multiply_general(

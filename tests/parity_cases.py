@@ -306,6 +306,15 @@ def case_bfv_pipeline(n, primes, t, batch=2, seed=4):
     ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
     cx, cy = d.ct(xs), d.ct(ys)
 
+    # out of place first: the product goes straight into a third object (no copy of encrypted1), the operands stay what they were
+    dest = S.Ciphertext(d.ctx, batch=batch)
+    d.ev.multiply(cx, cy, dest)
+    assert dest.size() == 3 and not dest.is_ntt_form() and dest.scale() == cx.scale() and dest.correction_factor() == 1
+    away = d.out(dest)
+    kept = d.out(cx)
+    for b in range(batch):
+        _eq(away[b], o.multiply(xs[b], ys[b]), "bfv multiply (out of place) item %d" % b)
+        _eq(kept[b], xs[b], "bfv multiply (out of place) left encrypted1 alone, item %d" % b)
     d.ev.multiply_inplace(cx, cy)  # bfv_multiply, evaluator.cpp:395
     assert cx.size() == 3 and not cx.is_ntt_form()
     cur = d.out(cx)

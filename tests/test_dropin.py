@@ -253,6 +253,42 @@ def _device_resident_chain(lib_name, n, bits, emulated):
     assert s4["reused"] > s3["reused"], "an operand uploaded once is found on the device the second time"
 
 
+def test_dropin_resident_switch_is_symmetric_emulated(emu):
+    """sealhip_dropin_set_resident(0) gives the process its SIGSEGV disposition back: installed by the opt-in, restored by the
+    opt-out, installed again by a second opt-in.  In a process of its own: the disposition is process-wide state."""
+    import subprocess
+    import sys
+    path = os.path.join(BUILD, "libsealdropin_emu.so")
+    if not (R.available() and os.path.exists(path)):
+        pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")
+    code = ("import ctypes as C, sys\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import seal_amd as S; S.load(%r)\n"
+            "class SA(C.Structure):\n"
+            "    _fields_ = [('handler', C.c_void_p), ('mask', C.c_ubyte * 128), ('flags', C.c_int), ('restorer', C.c_void_p)]\n"
+            "libc = C.CDLL(None)\n"
+            "def handler():\n"
+            "    sa = SA(); assert libc.sigaction(11, None, C.byref(sa)) == 0; return sa.handler or 0\n"
+            "D = C.CDLL(%r)\n"
+            "before = handler()\n"
+            "assert D.sealhip_dropin_set_resident(1) == 0\n"
+            "inside = handler()\n"
+            "assert D.sealhip_dropin_set_resident(0) == 1\n"
+            "after = handler()\n"
+            "assert D.sealhip_dropin_set_resident(1) == 0\n"
+            "again = handler()\n"
+            "D.sealhip_dropin_set_resident(0)\n"
+            "print('HANDLERS', before, inside, after, again, handler())\n"
+            % (HERE, os.path.dirname(HERE), os.path.join(HERE, "hipemu", "libsealhip_emu.so"), path))
+    run = subprocess.run([sys.executable, "-X", "faulthandler=0", "-c", code], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, SEALHIP_COMM_NO_RCCL="1", PYTHONFAULTHANDLER=""))
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    before, inside, after, again, last = [int(v) for v in [ln for ln in run.stdout.splitlines() if ln.startswith("HANDLERS")][0].split()[1:]]
+    assert inside != before, "the opt-in installs the fault handler"
+    assert after == before and last == before, "the opt-out restores what was there"
+    assert again == inside
+
+
 def test_dropin_device_resident_chain_emulated(emu):
     if not (R.available() and os.path.exists(os.path.join(BUILD, "libsealdropin_emu.so"))):
         pytest.skip("needs oracle/_ref and integration/_build (make -C integration)")

@@ -39,3 +39,28 @@ def test_digit_parallel_over_real_ranks(gpu, exchange):
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     for r, out in enumerate(outs):
         assert "MULTI_GPU_OK rank=%d/%d exchange=%d" % (r, nranks, exchange) in out, out[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("headline", ["--batch", "8"]), ("bfv_c4", ["--total-batch", "16"]),
+                                            ("rotate_c5", ["--batch", "2", "--exchange", "reduce_scatter"])])
+def test_bench_over_real_ranks(gpu, workload, extra):
+    """`python bench.py --gpus 2` on real GPUs: the launcher starts one rank per GPU, the probe all-reduce reaches both
+    over RCCL (rccl_ranks in the line), every rank's sampled items equal the reference's, every rank reports its own rate.  Batch
+    sharding for the headline and configs[3], the digit-parallel exchange inside the library for configs[4]."""
+    import json
+    import seal_amd as S
+    if S.device_count() < 2:
+        pytest.skip("one GPU visible: the multi-rank bench needs at least two")
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload,
+                          "--no-cpu-baseline", "--no-pmc"] + extra, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "nccl", line
+    assert [p["rank"] for p in line["per_rank"]] == [0, 1] and all(p["value"] > 0 for p in line["per_rank"])
+    assert line["value"] > 0 and line["verified_items"] and line["verified_items"] >= 4, line
+    if workload == "rotate_c5":
+        assert "RCCL inside libsealhip" in line["config"]["parallelism"], line["config"]["parallelism"]
