@@ -11,16 +11,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BENCH_PY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
 
 
-def ntt_leg(S, ctx, xs, B, K, n, reps=20):
+def ntt_leg(S, ctx, xs, B, K, n, reps=40, warm=25):
     """the roofline leg: the batched forward NTT over the resident batch (2*B polynomials x K components), HIP events on the stream
-    the transform is launched on; achieved = algorithmic bytes (16*N per RNS-component transform) / time"""
+    the transform is launched on; achieved = algorithmic bytes (16*N per RNS-component transform) / time.
+    The leg follows the host-side reference check of the timed batch, i.e. ten seconds of an idle GPU: `warm` untimed launches (~75 ms)
+    bring the clocks back before the timed ones - with three of them the same build read 2.46 - 2.75 TB/s from run to run on one
+    box, 2.69 +- 0.01 when the leg runs on its own (profiles/r04_ntt_wave_major.txt)."""
     timer = S.HipTimer()
     polys = 2 * B
     assert xs.numel() == polys * K * n
 
     class _Buf:
         ptr = xs.data_ptr()
-    for _ in range(3):
+    for _ in range(warm):
         S.ntt_forward(ctx, _Buf, polys, K)
     timer.start()
     for _ in range(reps):

@@ -45,6 +45,17 @@ namespace sealhip
     {
         constexpr int kThreads = 256;
         constexpr unsigned kMaxKeyComps = 64; // SEAL_COEFF_MOD_COUNT_MAX
+        // Where word (e, tid) of a 4096-word row tile of the forward passes' intermediate sits (e = column block, tid = (row u = tid >> 4,
+        // column-in-block v = tid & 15)).  Tile order (default): e*256 + tid - the 16 rows of a workgroup interleaved in 2 KiB blocks, a
+        // workgroup of pass 2 reads one 32 KiB run.  -DSEALHIP_MID_WAVE_MAJOR (measured in round 4, profiles/r04_ntt_wave_major.txt): the
+        // four rows of a WAVE contiguous - wave*1024 + e*64 + lane - so that every wave of pass 2 reads its own 8 KiB run.
+#ifdef SEALHIP_MID_WAVE_MAJOR
+        __device__ __forceinline__ unsigned mid_lane(unsigned tid) { return (tid >> 6) * 1024 + (tid & 63); }
+        constexpr unsigned kMidRow = 64;
+#else
+        __device__ __forceinline__ unsigned mid_lane(unsigned tid) { return tid; }
+        constexpr unsigned kMidRow = 256;
+#endif
         template <int D1>
         struct Geo
         {
@@ -467,6 +478,17 @@ namespace sealhip
             }
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
             const unsigned col = cg * G::C + c;
+#ifdef SEALHIP_MID_WAVE_MAJOR
+            if constexpr (BS == 256)
+            {
+                // row hi*16 + rb of column col: wave rb >> 2 of tile hi, row-in-wave rb & 3, column block col >> 4
+                uint64_t *w = mid_tr + (size_t)hi * 4096 + (col >> 4) * 64 + (col & 15);
+#pragma unroll
+                for (int rb = 0; rb < 16; rb++)
+                    w[(rb >> 2) * 1024 + (rb & 3) * 16] = F::raw(x[rb]);
+                return;
+            }
+#endif
             uint64_t *o = mid_tr + (size_t)(hi * 16 + (col >> 4)) * BS + (col & 15);
 #ifdef SEALHIP_KS_NOMEM
             // measurement build (tools/ab.sh nomem): the tile is not stored - one word per thread keeps the arithmetic alive
@@ -799,14 +821,14 @@ namespace sealhip
             const unsigned tid = threadIdx.x, hg = tile;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
-            const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + tid;
+            const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + mid_lane(tid);
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             uint64_t nxt[16];
             auto fetch = [&](unsigned z) {
                 const uint64_t *mp = mid0 + (((size_t)z * a.ncomp) << G::n);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    nxt[e] = mp[e * 256];
+                    nxt[e] = mp[e * kMidRow];
             };
             const unsigned ostride = gridDim.z;
             TwRegs<FP> pre_a, pre_b;
@@ -966,7 +988,7 @@ namespace sealhip
             const unsigned tid = threadIdx.x, hg = tile;
             const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
             const typename F::tw_t *tab = tw_table<FP>(a.t, false, prime);
-            const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + tid;
+            const uint64_t *mid0 = a.mid + ((size_t)comp << G::n) + ((size_t)hg << 12) + mid_lane(tid);
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             const uint64_t q = a.t.mods[prime].q;
             const ShoupOp mul = a.epi_mul[comp], pm = t2.x.pmul[comp];
@@ -979,7 +1001,7 @@ namespace sealhip
                 const uint64_t *mp = mid0 + (((size_t)z * a.ncomp) << G::n);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    nxt[e] = mp[e * 256];
+                    nxt[e] = mp[e * kMidRow];
             };
             const unsigned ostride = gridDim.z;
             fetch(outer);
@@ -1853,7 +1875,7 @@ namespace sealhip
             const uint64_t *mid0 = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K) << G::n) + ((size_t)hg << 12);
             // diagonal digit (CKKS): NTT_J(INTT_J(target_J)) = target_J (evaluator.cpp:2682-2685); read the
             // thread's 16 contiguous coefficients of row 16 hg + u straight from the input polynomial
-            const uint64_t *mid0_lane = mid0 + tid;
+            const uint64_t *mid0_lane = mid0 + mid_lane(tid);
             const bool has_diag = a.target && I < a.K;
             const UniformView diag_view = uniform_view(has_diag ? a.target + (((size_t)b * a.K + I) << G::n) + ((size_t)hg << 12) : a.mid);
             uint64_t nxt[16]; // digit J+1 is in flight while digit J is transformed
@@ -1873,7 +1895,7 @@ namespace sealhip
 #ifdef SEALHIP_KS_NOMEM
                         nxt[e] = fp_to_bits((double)(int)((tid * 16 + e + J * 4099u) & 0xFFFFF) - 524288.0);
 #else
-                        nxt[e] = view_load64(mv, tid * 8, e * 2048);
+                        nxt[e] = view_load64(mv, mid_lane(tid) * 8, e * (kMidRow * 8));
 #endif
                     }
                 }
@@ -1888,7 +1910,7 @@ namespace sealhip
 #ifdef SEALHIP_KS_NOMEM
                         nxt[e] = ((uint64_t)(tid * 16 + e + J * 4099u) * 0x9E3779B97F4A7C15ull) >> 6;
 #else
-                        nxt[e] = mp[e * 256];
+                        nxt[e] = mp[e * kMidRow];
 #endif
                     }
                 }

@@ -42,9 +42,14 @@ namespace sealhip
                 const unsigned prime = comp_prime ? comp_prime[comp] : comp;
                 uint64_t x0 = x[i], x1 = x[plane_words + i];
                 uint64_t y0 = y[i], y1 = y[plane_words + i];
-                if (fpd && fpd[prime].qi)
+                // (the descriptor comes through the scalar cache: the 64 consecutive words of a wave belong to one component whenever
+                // N >= 64, and the double-precision back end only exists from N = 2^13 - a per-lane load of it, dependent on the
+                // per-lane test of its first word, made the kernel slower than the integer path it replaces: -1.4 % on the step)
+                FpDesc f{};
+                if (fpd && n_log >= 6)
+                    f = ld_uniform_fpd(&fpd[SHL_UNIFORM(prime)]);
+                if (f.qi)
                 {
-                    const FpDesc f = fpd[prime];
                     const double a0 = fp_from_u52(x0), a1 = fp_from_u52(x1), b0 = fp_from_u52(y0), b1 = fp_from_u52(y1);
                     const double r00 = fp_mulmod(a0, b0, f.q, f.qinv), r11 = fp_mulmod(a1, b1, f.q, f.qinv);
                     const double mid = fp_mulmod(a0, b1, f.q, f.qinv) + fp_mulmod(a1, b0, f.q, f.qinv);
