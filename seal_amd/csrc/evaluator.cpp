@@ -1065,8 +1065,18 @@ namespace sealhip
         // step (4): dyadic ciphertext product in both bases (evaluator.cpp:497-541)
         Scratch d_q(dest * B * K * N), d_b(dest * B * nBsk * N);
         PlaneGeom gq{ n_log, K, (unsigned)B }, gb{ n_log, nBsk, (unsigned)B };
-        ck(k_multiply_general(mods, nullptr, x_q.p, (unsigned)s1, yq, (unsigned)s2, d_q.p, gq, stream_), "bfv tensor q");
-        ck(k_multiply_general(mods, lv.bsk_prime, x_b.p, (unsigned)s1, yb, (unsigned)s2, d_b.p, gb, stream_), "bfv tensor Bsk");
+        if (s1 == 2 && s2 == 2)
+        {
+            // the common product: four loads, three reductions per coefficient (the general kernel: eight and four); the transforms
+            // around it leave canonical words, primes below 2^50 take the double-precision products, the 61-bit auxiliary base does not
+            ck(k_ckks_multiply_2x2(mods, tb.fpd, nullptr, x_q.p, yq, d_q.p, gq, stream_), "bfv tensor q");
+            ck(k_ckks_multiply_2x2(mods, tb.fpd, lv.bsk_prime, x_b.p, yb, d_b.p, gb, stream_), "bfv tensor Bsk");
+        }
+        else
+        {
+            ck(k_multiply_general(mods, nullptr, x_q.p, (unsigned)s1, yq, (unsigned)s2, d_q.p, gq, stream_), "bfv tensor q");
+            ck(k_multiply_general(mods, lv.bsk_prime, x_b.p, (unsigned)s1, yb, (unsigned)s2, d_b.p, gb, stream_), "bfv tensor Bsk");
+        }
 
         // step (5): back to coefficient form
         ck(ntt_inverse(tb, plain_batch(d_q.p, (size_t)K * N, K, (unsigned)(dest * B), 0), 0, stream_), "bfv intt q");
