@@ -19,6 +19,8 @@ namespace sealhip
 {
     // message of the calling thread's last failed call (SealHip_LastError); one instance for all capi_*.cpp files (capi_core.cpp)
     std::string &capi_last_error();
+    // SEALContext_Destroy: the ContextData handles given out for this context die with it (capi_containers.cpp)
+    void capi_forget_context(const class Context *context);
 }
 using namespace sealhip;
 

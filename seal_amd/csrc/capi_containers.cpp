@@ -66,19 +66,15 @@ namespace
         int sec_level = 0;
     };
 
-    const Level *as_level(void *p)
-    {
-        return static_cast<const Level *>(p);
-    }
-    // a ContextData handle is a Level of some context; the context is found through the level's parms_id owner table
+    // a ContextData handle names one Level of one context (a Level does not know its context)
     struct LevelRef
     {
         const Context *ctx;
         const Level *level;
     };
-    // Levels do not know their context: the handle given out is a heap LevelRef owned by the caller's context registry below
+    // the handles given out, owned here: one per (context, level) ever asked for
     std::mutex g_refs_mu;
-    std::vector<std::unique_ptr<LevelRef>> g_refs; // (a handful per context; released with the process)
+    std::vector<std::unique_ptr<LevelRef>> g_refs; // (a handful per context; released by SEALContext_Destroy)
     void *level_handle(const Context *c, const Level *l)
     {
         if (!l)
@@ -155,6 +151,15 @@ namespace
         put(&p.plain_modulus, 8);
     }
 } // namespace
+
+namespace sealhip
+{
+    void capi_forget_context(const Context *context)
+    {
+        std::lock_guard<std::mutex> g(g_refs_mu);
+        g_refs.erase(std::remove_if(g_refs.begin(), g_refs.end(), [&](const std::unique_ptr<LevelRef> &r) { return r->ctx == context; }), g_refs.end());
+    }
+} // namespace sealhip
 
 extern "C"
 {

@@ -179,6 +179,7 @@ extern "C"
     SHL_FUNC SEALContext_Destroy(void *thisptr)
     {
         IfNullRet(thisptr, SHL_E_POINTER);
+        sealhip::capi_forget_context(as<Context>(thisptr));
         delete as<Context>(thisptr);
         return SHL_S_OK;
     }
