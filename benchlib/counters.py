@@ -14,9 +14,10 @@ BENCH_PY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 def ntt_leg(S, ctx, xs, B, K, n, reps=40, warm=25):
     """the roofline leg: the batched forward NTT over the resident batch (2*B polynomials x K components), HIP events on the stream
     the transform is launched on; achieved = algorithmic bytes (16*N per RNS-component transform) / time.
-    The leg follows the host-side reference check of the timed batch, i.e. ten seconds of an idle GPU: `warm` untimed launches (~75 ms)
-    bring the clocks back before the timed ones - with three of them the same build read 2.46 - 2.75 TB/s from run to run on one
-    box, 2.69 +- 0.01 when the leg runs on its own (profiles/r04_ntt_wave_major.txt)."""
+    `warm` untimed launches precede the timed ones (the leg follows ten seconds of host-side reference checking).  The figure still
+    moves by +-7 % from run to run on one box: it depends on where the scratch block of the intermediate happens to lie relative to
+    the data - 2.44 TB/s with one block, 2.63 with another in the same process, every block of twenty launches alike
+    (profiles/r04_ntt_leg_placement.txt); the kernels' HBM traffic is 2.015x the algorithmic bytes either way."""
     timer = S.HipTimer()
     polys = 2 * B
     assert xs.numel() == polys * K * n
