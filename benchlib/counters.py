@@ -191,8 +191,8 @@ def step_counters(args, B):
                            "`bench.py --step-child --batch %d` (3 steps); utilisation = VALU wave instructions x %d cycles / (kernel time "
                            "x %d SIMDs x %.1f GHz).  The profiler SERIALISES the kernels: in the timed step the integer-class and the "
                            "double-precision key-switch kernels share the CUs on two streams, here each has the chip to itself - avg_ms "
-                           "is the kernel alone (ks2<8,1>: its loads fully hidden, profiles/r04_ks_handover.txt), and the sum over the "
-                           "kernels exceeds the step's wall time by what the overlap saves (~6 %%)" % (
+                           "is the kernel alone, and the sum over the kernels exceeds the step's wall time by what the overlap saves "
+                           "(~6 %%; profiles/r04_ks_handover.txt)" % (
                                child_batch, VALU_CYCLES_PER_WAVE_INST, SIMDS, ENGINE_HZ / 1e9),
                     kernels=out, serialised_gpu_ms_per_step=round(total_ns / 3e6, 3))
     except Exception as e:  # the counters must never take the benchmark down
