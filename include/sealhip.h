@@ -548,14 +548,15 @@ SHL_FUNC SealHip_InstallAbortTrace(const char *path);
  *                                    the per-workgroup loop at small batches with it
  *   SEALHIP_ENCRYPT_HOST_SAMPLING=1  encryption noise is sampled on the host with the reference's own sampler instead of the
  *                                    device kernels (same distribution and, for a seeded generator, the same words) */
-/* Deferred key-switch tails.  For CKKS at 2^13 <= N <= 2^16, Evaluator_Relinearize / ApplyGalois / RotateVector /
- * ComplexConjugate return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext
+/* Deferred key-switch tails.  For CKKS and BFV at 2^13 <= N <= 2^16, Evaluator_Relinearize / ApplyGalois / RotateVector / RotateRows /
+ * RotateColumns / ComplexConjugate return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext
  * object keeps the key-switch sums next to its two polynomials.  Whatever needs the words next completes it first -
  * every Evaluator_* call on the object, Ciphertext_CopyToHost / Save / copies, Decryptor_Decrypt, destroying the evaluator,
  * Evaluator_SetStream, Evaluator_BeginCapture (tails from before the recording) and Evaluator_EndCapture (tails deferred inside
  * it and not consumed there become the recording's last work) - except Evaluator_RescaleToNext (in place) on the same evaluator, which performs the mod-down and
  * its own division by q_last with ONE transform per component instead of two (rns.cpp:830-901 folded in by linearity of the
- * transform; same words as the two separate steps).  Metadata (size, parms_id, scale) is up to date at all times.  A deferred
+ * transform; same words as the two separate steps) - and, for BFV, Evaluator_ModSwitchToNext1 (in place) on the same evaluator,
+ * which does the mod-down and its own division (rns.cpp:789-828) in one element-wise pass over the inverse-transformed sums.  Metadata (size, parms_id, scale) is up to date at all times.  A deferred
  * tail runs on the stream of the evaluator that created it; a caller on another stream is made to wait for it.  Not thread
  * safe per object, like every other Ciphertext operation.  SEALHIP_KS_EAGER_TAIL=1 in the environment turns deferral off.
  * Counters for tests: tails folded into a rescale / completed on their own / discarded because the object was overwritten. */

@@ -368,6 +368,7 @@ namespace sealhip
         void settle_all() const;
         // mod-down by the special prime and rescale by q_last in one pass (NttTail2); e has two polynomials and a deferred tail
         void switch_key_finish_rescale(Ciphertext &e, uint64_t *acc, const Level *next, double destination_scale) const;
+        void switch_key_finish_modswitch_bfv(Ciphertext &e, uint64_t *acc, const Level *next) const;
         mutable std::mutex lazy_mu_;
         mutable std::vector<const Ciphertext *> lazy_cts_;
         mutable std::mutex cache_mu_;

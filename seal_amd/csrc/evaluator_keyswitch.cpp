@@ -340,11 +340,47 @@ namespace sealhip
                "ks add digit groups");
         // CKKS at the two-pass sizes: leave the mod-down to whoever touches the ciphertext next (LazyTail) - a rescale on this
         // evaluator then does both rounding divisions with one transform per component.  SEALHIP_KS_EAGER_TAIL=1: always now.
+        // BFV at the same sizes (round 4): a mod_switch_to_next on this evaluator folds the mod-down into its own division (one
+        // element-wise pass after the inverse transforms, switch_key_finish_modswitch_bfv); anything else completes it first.
         static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
-        if (lazy_ok && context_.scheme() == Scheme::ckks && ntt2_supports(context_.log_n()) && K >= 2)
+        const Scheme sch = context_.scheme();
+        if (lazy_ok && (sch == Scheme::ckks || sch == Scheme::bfv) && ntt2_supports(context_.log_n()) && K >= 2)
             defer_tail(e, acc.release());
         else
             switch_key_finish(e, acc.p, 1);
+    }
+
+    // BFV: relinearize (or a rotation) followed by mod_switch_to_next.  acc = the key-switch sums (NTT form, K + 1 components per
+    // polynomial), planes 0 and 1 of e = the addends (coefficient form).  Reference steps being folded: evaluator.cpp:2806-2864
+    // (inverse transforms of the sums, mod-down by P), then rns.cpp:789-828 (divide_and_round_q_last_inplace) on the result.
+    void Evaluator::switch_key_finish_modswitch_bfv(Ciphertext &e, uint64_t *acc_p, const Level *next) const
+    {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
+        const Level &lvl = *e.level();
+        const Level &klvl = context_.key_level();
+        const unsigned K = lvl.K, L = klvl.K;
+        const size_t N = context_.n();
+        const unsigned B = (unsigned)e.batch();
+        const NttTables &tb = context_.ntt_tables();
+        const uint64_t P = context_.coeff_modulus()[L - 1];
+        static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr;
+        if (trace)
+            std::fprintf(stderr, "[ks] folded tail (bfv)\n");
+        g_tail_folded++;
+        NttBatch bi = plain_batch(acc_p, (size_t)(K + 1) * N, K + 1, 2 * B, 0);
+        bi.comp_prime = ks_comp_prime(K) + (size_t)(K + 1) * K; // components 0 .. K-1 and the special prime
+        ck(ntt_inverse(tb, bi, 0, stream_), "ks intt all");
+        const size_t words = (size_t)2 * B * (K - 1) * N;
+        uint64_t *out = DevicePool::global().alloc_words(words, stream_);
+        const uint64_t *c0 = e.data_, *c1 = e.data_ + (size_t)B * K * N; // (no deferred tail left on e: the caller detached it)
+        hipError_t err = k_keyswitch_tail_modswitch_bfv(context_.dev_mods(), klvl.dev, P >> 1, P, lvl.dev, c0, c1, acc_p, out,
+                                                        (unsigned)context_.log_n(), K, B, stream_);
+        if (err != hipSuccess)
+        {
+            DevicePool::global().free_words(out, stream_);
+            ck(err, "ks tail + mod switch (bfv)");
+        }
+        e.adopt(next, 2, out, words);
     }
 
     // relinearize (or a rotation) followed by rescale_to_next: acc = the key-switch sums, planes 0 and 1 of e = the addends.

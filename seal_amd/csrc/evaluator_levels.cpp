@@ -47,6 +47,24 @@ namespace sealhip
             DevicePool::global().free_words(t.acc, stream_);
             return;
         }
+        if (scheme == Scheme::bfv && e.lazy_ && e.lazy_->owner == this && e.size() == 2 && K >= 2)
+        {
+            // BFV: the key switch that produced e left its mod-down undone: one element-wise pass does it and this division
+            const LazyTail t = detach_tail(e);
+            try
+            {
+                switch_key_finish_modswitch_bfv(e, t.acc, next);
+            }
+            catch (...)
+            {
+                // (e's planes are untouched by the folded pass - it writes a new slab - but the sums are gone: leave an EMPTY object)
+                DevicePool::global().free_words(t.acc, stream_);
+                e.release();
+                throw;
+            }
+            DevicePool::global().free_words(t.acc, stream_);
+            return;
+        }
         const size_t items = e.size() * e.batch();
         const unsigned n_log = (unsigned)context_.log_n();
         const ModDesc *mods = context_.dev_mods();

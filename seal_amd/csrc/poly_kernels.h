@@ -129,6 +129,12 @@ namespace sealhip
     hipError_t k_keyswitch_tail_bfv(
         const ModDesc *mods, const ShoupOp *inv_p, const uint64_t *round_fix, uint64_t half_p, uint64_t p,
         uint64_t *ct0, uint64_t *ct1, const uint64_t *acc, unsigned n_log, unsigned K, unsigned batch, hipStream_t s);
+    // The same tail followed by the BFV mod-switch to the next level in one pass: out [2][batch][K-1][N] = divide_and_round_q_last of
+    // the completed ciphertext (rns.cpp:789-828), which is never written.  klv = the key level's constants (P^-1, P/2 fixes), lv = the
+    // ciphertext's level (q_last^-1, q_last/2).
+    hipError_t k_keyswitch_tail_modswitch_bfv(
+        const ModDesc *mods, const LevelDev &klv, uint64_t half_p, uint64_t p, const LevelDev &lv, const uint64_t *ct0, const uint64_t *ct1,
+        const uint64_t *acc, uint64_t *out, unsigned n_log, unsigned K, unsigned batch, hipStream_t s);
     // BEHZ (BFV multiply) per-coefficient base conversions, util/rns.cpp:903-1131.
     // lift: fastbconv_m_tilde + sm_mrq.  in [items][K][N] canonical -> out [items][nBsk][N] canonical.
     hipError_t k_behz_lift(const ModDesc *mods, const LevelDev &lv, const uint64_t *in, uint64_t *out, unsigned n_log,

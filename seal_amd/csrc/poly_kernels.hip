@@ -586,6 +586,44 @@ namespace sealhip
             }
         }
 
+        // BFV: the key switch's mod-down by the special prime P and the mod-switch that follows it in one pass (round 4).  A thread
+        // owns coefficient j of one polynomial of one item: it completes the LAST component first (the mod-switch divides by it), then
+        // every other component - c' = c + (S - v) P^-1 as keyswitch_tail_bfv_kernel, out = (c' - u) q_last^-1 as bfv_modswitch_kernel -
+        // so the relinearised ciphertext is never written (evaluator.cpp:2806-2864 then rns.cpp:789-828 on its result: same words).
+        __global__ void __launch_bounds__(kBlock) keyswitch_tail_modswitch_bfv_kernel(
+            const ModDesc *mods, const ShoupOp *inv_p, const uint64_t *round_fix_p, uint64_t half_p, uint64_t p, const ShoupOp *inv_q_last,
+            const uint64_t *half_mod_q, uint64_t q_last, uint64_t half_q_last, const uint64_t *ct0, const uint64_t *ct1, const uint64_t *acc,
+            uint64_t *out, unsigned n_log, unsigned K, unsigned batch, size_t threads)
+        {
+            const unsigned Km1 = K - 1;
+            const size_t n_mask = (size_t(1) << n_log) - 1;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < threads; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t j = i & n_mask, bk = i >> n_log; // bk = k * batch + b: all items of polynomial 0, then of polynomial 1
+                const size_t b = bk % batch;
+                const unsigned k = (unsigned)(bk / batch);
+                const uint64_t *ct = (k ? ct1 : ct0) + ((b * K) << n_log) + j;
+                const uint64_t *a = acc + (((b * 2 + k) * (K + 1)) << n_log) + j;
+                uint64_t *o = out + (((size_t)k * batch + b) * Km1 << n_log) + j;
+                const uint64_t s = csub(a[(size_t)K << n_log] + half_p, p); // (r + P/2) mod P
+                auto completed = [&](unsigned comp) {
+                    const ModDesc md = mods[comp];
+                    const ShoupOp ip = inv_p[comp];
+                    const uint64_t uu = barrett64(s, md) + round_fix_p[comp]; // (s mod q_i) - (P/2 mod q_i) + q_i, in [1, 2q)
+                    const uint64_t v = mul_shoup(a[(size_t)comp << n_log] + 2 * md.q - uu, ip.w, ip.wq, md.q);
+                    return add_mod(ct[(size_t)comp << n_log], v, md.q);
+                };
+                const uint64_t rl = csub(completed(Km1) + half_q_last, q_last); // (c'_last + q_last/2) mod q_last
+                for (unsigned comp = 0; comp < Km1; comp++)
+                {
+                    const ModDesc md = mods[comp];
+                    const ShoupOp iq = inv_q_last[comp];
+                    const uint64_t u = sub_mod(barrett64(rl, md), half_mod_q[comp], md.q);
+                    o[(size_t)comp << n_log] = mul_shoup(sub_mod(completed(comp), u, md.q), iq.w, iq.wq, md.q);
+                }
+            }
+        }
+
         __global__ void __launch_bounds__(kBlock) any_nonzero_kernel(const uint64_t *data, size_t words, unsigned *flag)
         {
             unsigned nz = 0;
@@ -818,6 +856,18 @@ namespace sealhip
         hipLaunchKernelGGL(
             keyswitch_tail_bfv_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, inv_p, round_fix, half_p, p, ct0, ct1,
             acc, n_log, K, w);
+        return hipGetLastError();
+    }
+    hipError_t k_keyswitch_tail_modswitch_bfv(
+        const ModDesc *mods, const LevelDev &klv, uint64_t half_p, uint64_t p, const LevelDev &lv, const uint64_t *ct0, const uint64_t *ct1,
+        const uint64_t *acc, uint64_t *out, unsigned n_log, unsigned K, unsigned batch, hipStream_t s)
+    {
+        const size_t threads = ((size_t)batch * 2) << n_log;
+        if (!threads || K < 2)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(
+            keyswitch_tail_modswitch_bfv_kernel, dim3(grid_for(threads)), dim3(kBlock), 0, s, mods, klv.inv_q_last_mod_q, klv.round_fix, half_p,
+            p, lv.inv_q_last_mod_q, lv.half_mod_q, lv.q_last, lv.half_q_last, ct0, ct1, acc, out, n_log, K, batch, threads);
         return hipGetLastError();
     }
     hipError_t k_any_nonzero(const uint64_t *data, size_t words, unsigned *flag, hipStream_t s)

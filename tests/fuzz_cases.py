@@ -77,6 +77,8 @@ def run_sequence(scheme, n, bits, tb, batch, nops, seed, check_prob=1.0, scale0=
         op = ops[rng.integers(0, len(ops))]
         if check_prob < 1.0 and log and log[-1] in ("relinearize", "rotate", "conj") and "rescale" in ops and rng.random() < 0.7:
             op = "rescale"   # deferred-state runs: a key switch is often followed directly by a rescale
+        elif check_prob < 1.0 and scheme == "bfv" and log and log[-1] in ("relinearize", "rotate", "conj") and "mod_switch" in ops and rng.random() < 0.7:
+            op = "mod_switch"   # ... in BFV by a mod switch (the folded tail of round 4)
         # keep CKKS scales inside the level's modulus: skip products that would overflow it
         if scheme == "ckks" and op in ("square", "multiply", "multiply32"):
             budget = sum(bits[:Kc]) - 2

@@ -352,6 +352,50 @@ def case_bfv_pipeline(n, primes, t, batch=2, seed=4):
     for b in range(batch):
         _eq(nxt[b], o.multiply(cur[b], cur[b]), "bfv square item %d" % b)
 
+    if K >= 2:
+        # Deferred key-switch tail, BFV (round 4): relinearize / rotate_rows followed directly by mod_switch_to_next - nothing reads the
+        # ciphertext in between - does the mod-down by the special prime and the division by q_last in ONE element-wise pass
+        # (evaluator.cpp:2806-2864 then rns.cpp:789-828: the same words as the reference's two steps); a reader in between gets the
+        # completed ciphertext, a destination that is overwritten drops the pending sums.
+        defers = 13 <= n.bit_length() - 1 <= 16 and not os.environ.get("SEALHIP_KS_EAGER_TAIL")  # the two-pass sizes
+        folded0, plain0, dropped0 = S.tail_stats()
+        cz, cw = d.ct(xs), d.ct(ys)
+        d.ev.multiply_inplace(cz, cw)
+        d.ev.relinearize_inplace(cz, d.rlk)
+        d.ev.mod_switch_to_next_inplace(cz)
+        assert S.tail_stats()[0] - folded0 == (1 if defers else 0), "the folded BFV pass did not run where it should"
+        assert cz.size() == 2 and cz.coeff_modulus_size() == K - 1 and not cz.is_ntt_form()
+        got = d.out(cz)
+        for b in range(batch):
+            _eq(got[b], o.mod_switch_to_next(o.relinearize(o.multiply(xs[b], ys[b]))), "bfv relinearize + mod_switch folded, item %d" % b)
+        cr = d.ct(xs)
+        d.ev.rotate_rows_inplace(cr, 1, d.glk)
+        d.ev.mod_switch_to_next_inplace(cr)
+        got = d.out(cr)
+        for b in range(batch):
+            _eq(got[b], o.mod_switch_to_next(o.apply_galois(xs[b], elts[0])), "bfv rotate_rows + mod_switch folded, item %d" % b)
+        # completed by a copy, then the ordinary mod switch; and dropped unrun when the destination is overwritten
+        ca, cb = d.ct(xs), d.ct(ys)
+        d.ev.multiply_inplace(ca, cb)
+        d.ev.relinearize_inplace(ca, d.rlk)
+        cc = ca.copy()
+        d.ev.mod_switch_to_next_inplace(ca)
+        got, one = d.out(ca), d.out(cc)
+        for b in range(batch):
+            r = o.relinearize(o.multiply(xs[b], ys[b]))
+            _eq(one[b], r, "bfv copy of a ciphertext with a deferred tail, item %d" % b)
+            _eq(got[b], o.mod_switch_to_next(r), "bfv mod_switch after the tail was completed by a copy, item %d" % b)
+        f1, p1, dr1 = S.tail_stats()
+        ce, cf = d.ct(xs), d.ct(ys)
+        d.ev.multiply_inplace(ce, cf)
+        d.ev.relinearize_inplace(ce, d.rlk)
+        d.ev.multiply(d.ct(xs), cf, ce)        # ce is the destination: its pending tail is discarded
+        got = d.out(ce)
+        for b in range(batch):
+            _eq(got[b], o.multiply(xs[b], ys[b]), "bfv product written over a ciphertext with a deferred tail, item %d" % b)
+        if defers:
+            assert S.tail_stats()[2] - dr1 == 1, "the overwritten ciphertext's tail was not discarded"
+
 
 # ---- BGV: BGVEncryptMultiplyDecrypt / BGVRelinearize / BGVEncryptModSwitchToNextDecrypt / BGVEncryptRotateMatrixDecrypt /
 #      BGVEncryptAddDecrypt with unequal correction factors (native/tests/seal/evaluator.cpp, BGV cases) at ciphertext level.

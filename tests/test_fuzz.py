@@ -102,3 +102,36 @@ def test_random_sequences_with_deferred_state_gpu(gpu, cfg):
         F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30)
     except sealref.RefError as e:
         pytest.skip("reference rejected the parameters: %s" % e)
+
+
+def _bfv_configs(seed, count, degrees):
+    """BFV only, sequences that favour key switches followed by mod switches (the deferred BFV tail of round 4)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        n = int(degrees[rng.integers(0, len(degrees))])
+        L = int(rng.integers(4, 7))
+        bits = [int(b) for b in rng.integers(36, 61, L)]
+        out.append(("bfv", n, bits, 20, int(rng.integers(1, 3)), int(rng.integers(8, 13)), 7000 * seed + i))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _bfv_configs(5, 4, [8192, 8192, 16384]), ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+def test_bfv_sequences_with_deferred_state_emulated(emu, cfg):
+    if not sealref.available():
+        pytest.skip("needs the real reference (oracle/_ref)")
+    try:
+        F.run_sequence(*cfg, check_prob=0.25)
+    except sealref.RefError as e:
+        pytest.skip("reference rejected the parameters: %s" % e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", _bfv_configs(6, 16, [8192, 16384, 32768, 65536]), ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
+def test_bfv_sequences_with_deferred_state_gpu(gpu, cfg):
+    if not sealref.available():
+        pytest.skip("needs the real reference (oracle/_ref)")
+    try:
+        F.run_sequence(*cfg, check_prob=0.25)
+    except sealref.RefError as e:
+        pytest.skip("reference rejected the parameters: %s" % e)
