@@ -300,6 +300,17 @@ namespace sealhip
         return ks_targets_[K] = kt;
     }
 
+    // arithmetic class of the K data primes and the special prime together (NttBatch::cls_hint for batches that name them through
+    // ks_comp_prime's map): 0 all on the integer back end, 1 all on the double-precision one, -1 mixed
+    int Evaluator::ks_class_hint(unsigned K) const
+    {
+        const unsigned L = context_.key_level().K;
+        unsigned fp = context_.fp_prime(L - 1) ? 1 : 0;
+        for (unsigned i = 0; i < K; i++)
+            fp += context_.fp_prime(i) ? 1 : 0;
+        return fp == 0 ? 0 : (fp == K + 1 ? 1 : -1);
+    }
+
     bool Evaluator::scale_within_bounds(double scale, const Level &lvl) const
     {
         // is_scale_within_bounds (evaluator.cpp:29-48)
@@ -1048,6 +1059,7 @@ namespace sealhip
             ck(k_behz_lift(mods, lv, x.data(), xb.p, n_log, items, stream_), "behz lift");
             NttBatch bb = plain_batch(xb.p, (size_t)nBsk * N, nBsk, (unsigned)items, 0);
             bb.comp_prime = lv.bsk_prime;
+            bb.cls_hint = 0; // the auxiliary base is 61-bit primes: integer back end, single-class kernels (ntt_kernels.h)
             ck(ntt_forward(tb, bb, 0, stream_), "bfv ntt Bsk");
         };
         Scratch x_q(s1 * B * K * N), x_b(s1 * B * nBsk * N);
@@ -1082,6 +1094,7 @@ namespace sealhip
         ck(ntt_inverse(tb, plain_batch(d_q.p, (size_t)K * N, K, (unsigned)(dest * B), 0), 0, stream_), "bfv intt q");
         NttBatch ib = plain_batch(d_b.p, (size_t)nBsk * N, nBsk, (unsigned)(dest * B), 0);
         ib.comp_prime = lv.bsk_prime;
+        ib.cls_hint = 0;
         ck(ntt_inverse(tb, ib, 0, stream_), "bfv intt Bsk");
 
         // steps (6)-(8)

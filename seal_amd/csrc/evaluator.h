@@ -344,6 +344,7 @@ namespace sealhip
         void throw_if_transparent(const Ciphertext &ct) const;
         void switch_key_exchange_finish(Ciphertext &encrypted, uint64_t *acc, Comm &comm, KsExchange how) const;
         const uint32_t *ks_comp_prime(unsigned K) const;
+        int ks_class_hint(unsigned K) const;
         struct KsTargets
         {
             uint32_t *dev = nullptr; // [targets1: int, fp | targets2: int, fp]

@@ -300,6 +300,7 @@ namespace sealhip
         {
             NttBatch bi = plain_batch(acc.p, (size_t)(K + 1) * N, K + 1, 2 * B, 0);
             bi.comp_prime = map + (size_t)(K + 1) * K;
+            bi.cls_hint = ks_class_hint(K);
             ck(ntt_inverse(tb, bi, 0, stream_), "ks intt all");
             ck(k_keyswitch_tail_bfv(
                    mods, klvl.dev.inv_q_last_mod_q, klvl.dev.round_fix, P >> 1, P, e.plane(0), e.plane(1), acc.p, n_log, K, B,
@@ -369,6 +370,7 @@ namespace sealhip
         g_tail_folded++;
         NttBatch bi = plain_batch(acc_p, (size_t)(K + 1) * N, K + 1, 2 * B, 0);
         bi.comp_prime = ks_comp_prime(K) + (size_t)(K + 1) * K; // components 0 .. K-1 and the special prime
+        bi.cls_hint = ks_class_hint(K);
         ck(ntt_inverse(tb, bi, 0, stream_), "ks intt all");
         const size_t words = (size_t)2 * B * (K - 1) * N;
         uint64_t *out = DevicePool::global().alloc_words(words, stream_);

@@ -719,6 +719,7 @@ namespace sealhip
             uint64_t src_half, src_q;
             const uint64_t *src_fix;
             const uint32_t *comp_prime;
+            int cls_hint; // NttBatch::cls_hint (host side only: picks the kernels)
             unsigned prime_first;
             unsigned ncomp;
             unsigned comp0; // this launch covers components [comp0, comp0 + gridDim.y)
@@ -1101,6 +1102,7 @@ namespace sealhip
             size_t src_outer_stride;
             uint64_t *mid;
             const uint32_t *comp_prime;
+            int cls_hint; // NttBatch::cls_hint (host side only: picks the kernels)
             unsigned prime_first;
             unsigned ncomp;
             unsigned comp0; // as FwdArgs
@@ -2196,9 +2198,14 @@ namespace sealhip
         // Measured on MI355X (bench.py, C5): +2 % on the multiply+relinearize+rescale pipeline.  Two
         // alternatives were measured and dropped: a (tile, outer, comp) grid order (-5 % on the NTT) and
         // splitting a batch so that the intermediate stays below 128 MiB (-2 %).
-        std::vector<CompRun> comp_runs(const NttTables &t, const uint32_t *comp_prime, unsigned prime_first, unsigned ncomp)
+        std::vector<CompRun> comp_runs(const NttTables &t, const uint32_t *comp_prime, unsigned prime_first, unsigned ncomp, int cls_hint = -1)
         {
             std::vector<CompRun> runs;
+            if (comp_prime && (cls_hint == 0 || cls_hint == 1))
+            {
+                runs.push_back(CompRun{ 0, ncomp, cls_hint }); // the caller vouches for the class of every mapped prime (NttBatch::cls_hint)
+                return runs;
+            }
             static const bool split = !shl_ab_getenv("SEALHIP_NTT_NOSPLIT");
             unsigned c = 0;
             while (c < ncomp)
@@ -2323,7 +2330,7 @@ namespace sealhip
                         fchunks = 65535;
                 }
             }
-            return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp), s, [&](const CompRun &r, hipStream_t st) {
+            return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp, a.cls_hint), s, [&](const CompRun &r, hipStream_t st) {
                 FwdArgs g = a;
                 g.comp0 = r.c0;
                 if constexpr (D1 == 5 || D1 == 6)
@@ -2431,7 +2438,7 @@ namespace sealhip
                         fchunks = nouter;
                 }
             }
-            return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp), s, [&](const CompRun &r, hipStream_t st) {
+            return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp, a.cls_hint), s, [&](const CompRun &r, hipStream_t st) {
                 InvArgs g = a;
                 g.comp0 = r.c0;
                 g.nouter = nouter;
@@ -2570,6 +2577,7 @@ namespace sealhip
         a.src_q = b.src_q;
         a.src_fix = b.src_fix;
         a.comp_prime = b.comp_prime;
+        a.cls_hint = b.cls_hint;
         a.prime_first = b.prime_first;
         a.ncomp = b.ncomp;
         a.comp0 = 0;
@@ -2629,6 +2637,7 @@ namespace sealhip
         a.src_outer_stride = b.src ? b.src_outer_stride : b.outer_stride;
         a.mid = mid;
         a.comp_prime = b.comp_prime;
+        a.cls_hint = b.cls_hint;
         a.prime_first = b.prime_first;
         a.ncomp = b.ncomp;
         a.comp0 = 0;

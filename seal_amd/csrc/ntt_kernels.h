@@ -101,6 +101,11 @@ namespace sealhip
         // (v + out_add) mod q.  Used on the single component a rounding division is about to drop, so that the "+ q/2" of the
         // rounding is added once per coefficient instead of once per target modulus (NttTail2::halves_added).
         uint64_t out_add = 0;
+        // Two-pass engine: what the HOST knows about the arithmetic class of the components when they are named through comp_prime
+        // (the launcher reads the class of prime_first + comp itself, a device table it cannot): -1 unknown - the launch carries both
+        // back ends and guards every integer butterfly -, 0 every prime on the integer back end (single-class kernels, the
+        // unguarded butterflies where the prime's size allows), 1 every prime on the double-precision one.
+        int cls_hint = -1;
     };
 
     // out_range: 0 = canonical [0,q); 1 = lazy ([0,4q) forward / [0,2q) inverse).
