@@ -50,4 +50,12 @@ def gpu():
     seal_amd.load(GPU_LIB)
     name, cus, mem = seal_amd.device_info()
     assert cus > 0
+    # an abort of this process (a device memory fault makes the ROCm runtime call abort(); pytest keeps stderr in a file that dies
+    # with the process) leaves the aborting thread's call stack behind: gpurun_out/abort_trace_<pid>.txt, written only then
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        seal_amd.install_abort_trace(os.path.join(out, "abort_trace_%d.txt" % os.getpid()))
+    except Exception:
+        pass
     return seal_amd
