@@ -100,6 +100,18 @@ namespace sealhip
         return *reinterpret_cast<const uint64_t *>(v.base + lane_bytes + uniform_bytes);
 #endif
     }
+    // the same load with the non-temporal hint (gfx940+ cache-policy bit 1): data that is read once - the key switch's intermediate -
+    // is not to displace what the L2 holds for reuse (the key tile of a whole batch)
+    __device__ __forceinline__ uint64_t view_load64_nt(const UniformView &v, unsigned lane_bytes, unsigned uniform_bytes)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(v.rsrc, (int)lane_bytes, (int)uniform_bytes, 2);
+        return ((uint64_t)r.y << 32) | r.x;
+#else
+        return *reinterpret_cast<const uint64_t *>(v.base + lane_bytes + uniform_bytes);
+#endif
+    }
     // two consecutive 64-bit words (16-byte aligned)
     __device__ __forceinline__ void view_load128(const UniformView &v, unsigned lane_bytes, unsigned uniform_bytes, uint64_t &w0, uint64_t &w1)
     {

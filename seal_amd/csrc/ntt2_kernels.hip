@@ -49,6 +49,34 @@ namespace sealhip
         // column-in-block v = tid & 15)).  Tile order (default): e*256 + tid - the 16 rows of a workgroup interleaved in 2 KiB blocks, a
         // workgroup of pass 2 reads one 32 KiB run.  -DSEALHIP_MID_WAVE_MAJOR (measured in round 4, profiles/r04_ntt_wave_major.txt): the
         // four rows of a WAVE contiguous - wave*1024 + e*64 + lane - so that every wave of pass 2 reads its own 8 KiB run.
+        // Streaming hints (round 4): the intermediate of a two-pass transform is written once and read once, gigabytes later - it has no
+        // business displacing what the L2 holds for reuse (key tiles, digit tiles, twiddles).  SEALHIP_KS_NT is a bit mask of where the
+        // non-temporal form is used: 1 pass-1 stores, 2 ks2's double-precision loads, 4 the other forward pass-2 loads, 8 the inverse
+        // passes' intermediate (store and load), 16 single-use operands and results of the passes (plain sources, tail operands, final stores).  Measured in profiles/r04_nontemporal.txt; the default below is what won.
+#ifndef SEALHIP_KS_NT
+#define SEALHIP_KS_NT 31 // headline step 8.82 -> 9.18 k ct/s same-box (+4.0 %); 15: +2.5 %; with the tensor product's loads (32): +2.9 %
+#endif
+        template <int BIT>
+        __device__ __forceinline__ uint64_t mid_ld(const uint64_t *p)
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr ((SEALHIP_KS_NT & BIT) != 0)
+                return __builtin_nontemporal_load(p);
+#endif
+            return *p;
+        }
+        template <int BIT>
+        __device__ __forceinline__ void mid_st(uint64_t *p, uint64_t v)
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr ((SEALHIP_KS_NT & BIT) != 0)
+            {
+                __builtin_nontemporal_store(v, p);
+                return;
+            }
+#endif
+            *p = v;
+        }
 #ifdef SEALHIP_MID_WAVE_MAJOR
         __device__ __forceinline__ unsigned mid_lane(unsigned tid) { return (tid >> 6) * 1024 + (tid & 63); }
         constexpr unsigned kMidRow = 64;
@@ -490,6 +518,13 @@ namespace sealhip
             }
 #endif
             uint64_t *o = mid_tr + (size_t)(hi * 16 + (col >> 4)) * BS + (col & 15);
+            if constexpr (BS == 256 && (SEALHIP_KS_NT & 1) != 0)
+            {
+#pragma unroll
+                for (int rb = 0; rb < 16; rb++)
+                    mid_st<1>(o + rb * 16, F::raw(x[rb]));
+                return;
+            }
 #ifdef SEALHIP_KS_NOMEM
             // measurement build (tools/ab.sh nomem): the tile is not stored - one word per thread keeps the arithmetic alive
             uint64_t sink = 0;
@@ -649,7 +684,7 @@ namespace sealhip
             for (int k = 0; k < 16; k++)
             {
                 const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
-                rows[row * 256 + col] = lds_wave[row * kRowWords + col + 2 * (col >> 4)];
+                mid_st<16>(rows + row * 256 + col, lds_wave[row * kRowWords + col + 2 * (col >> 4)]);
             }
         }
         // the same transposition, handing each coalesced (offset, value) pair to `sink`
@@ -695,7 +730,7 @@ namespace sealhip
             for (int k = 0; k < 16; k++)
             {
                 const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
-                lds_wave[row * kRowWords + col + 2 * (col >> 4)] = rows[row * 256 + col];
+                lds_wave[row * kRowWords + col + 2 * (col >> 4)] = mid_ld<16>(rows + row * 256 + col);
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -771,7 +806,7 @@ namespace sealhip
                 {
                     const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
                     const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
-                    nxt[e] = in[(size_t)R * 256];
+                    nxt[e] = a.src ? in[(size_t)R * 256] : mid_ld<16>(in + (size_t)R * 256); // (a mapped source is shared by the components)
                 }
             };
             const unsigned ostride = gridDim.z;
@@ -829,7 +864,7 @@ namespace sealhip
                 const uint64_t *mp = mid0 + (((size_t)z * a.ncomp) << G::n);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    nxt[e] = mp[e * kMidRow];
+                    nxt[e] = mid_ld<4>(mp + e * kMidRow);
             };
             const unsigned ostride = gridDim.z;
             TwRegs<FP> pre_a, pre_b;
@@ -1002,7 +1037,7 @@ namespace sealhip
                 const uint64_t *mp = mid0 + (((size_t)z * a.ncomp) << G::n);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
-                    nxt[e] = mp[e * kMidRow];
+                    nxt[e] = mid_ld<4>(mp + e * kMidRow);
             };
             const unsigned ostride = gridDim.z;
             fetch(outer);
@@ -1022,8 +1057,8 @@ namespace sealhip
                 for (int k = 0; k < 16; k++)
                 {
                     const unsigned off = (k >> 2) * 256 + (k & 3) * 64 + (tid & 63);
-                    av[k] = A[off];
-                    cv[k] = C[off];
+                    av[k] = mid_ld<16>(A + off);
+                    cv[k] = mid_ld<16>(C + off);
                 }
                 p2_tile<FP, D1, false, false, false, false, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
                 uint64_t val[16];
@@ -1168,7 +1203,7 @@ namespace sealhip
             uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n) + ((size_t)hg << 12);
 #pragma unroll
             for (int e = 0; e < 16; e++)
-                mid_tr[e * 256 + tid] = F::raw(x[e]);
+                mid_st<8>(mid_tr + e * 256 + tid, F::raw(x[e]));
         }
 
         template <int D1, int CLS>
@@ -1203,7 +1238,7 @@ namespace sealhip
             typename F::elem x[16];
 #pragma unroll
             for (int rb = 0; rb < 16; rb++)
-                x[rb] = F::unraw(i[rb * 16]);
+                x[rb] = F::unraw(mid_ld<8>(i + rb * 16));
             {
                 TwRegs<FP> tw;
                 load_tw<FP, 4>(tw, tab, [&](int t) { return (1u << (G::rA + t)) + (hi << t); });
@@ -1249,7 +1284,7 @@ namespace sealhip
                 uint64_t v = a.lazy ? F::inv_to_lazy(x[e], m) : F::inv_to_canon(x[e], m);
                 if (a.out_add)
                     v = csub(v + a.out_add, a.t.mods[prime].q);
-                o[(size_t)R * 256 + col] = v;
+                mid_st<16>(o + (size_t)R * 256 + col, v);
             }
         }
 
@@ -1897,7 +1932,10 @@ namespace sealhip
 #ifdef SEALHIP_KS_NOMEM
                         nxt[e] = fp_to_bits((double)(int)((tid * 16 + e + J * 4099u) & 0xFFFFF) - 524288.0);
 #else
-                        nxt[e] = view_load64(mv, mid_lane(tid) * 8, e * (kMidRow * 8));
+                        if constexpr ((SEALHIP_KS_NT & 2) != 0)
+                            nxt[e] = view_load64_nt(mv, mid_lane(tid) * 8, e * (kMidRow * 8));
+                        else
+                            nxt[e] = view_load64(mv, mid_lane(tid) * 8, e * (kMidRow * 8));
 #endif
                     }
                 }
@@ -1912,7 +1950,7 @@ namespace sealhip
 #ifdef SEALHIP_KS_NOMEM
                         nxt[e] = ((uint64_t)(tid * 16 + e + J * 4099u) * 0x9E3779B97F4A7C15ull) >> 6;
 #else
-                        nxt[e] = mp[e * kMidRow];
+                        nxt[e] = mid_ld<4>(mp + e * kMidRow);
 #endif
                     }
                 }
