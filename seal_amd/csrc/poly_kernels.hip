@@ -40,13 +40,8 @@ namespace sealhip
             {
                 const unsigned comp = (unsigned)((i >> n_log) % K);
                 const unsigned prime = comp_prime ? comp_prime[comp] : comp;
-#if defined(SEALHIP_KS_NT) && (SEALHIP_KS_NT & 32) && defined(__HIP_DEVICE_COMPILE__)
-                uint64_t x0 = __builtin_nontemporal_load(x + i), x1 = __builtin_nontemporal_load(x + plane_words + i);
-                uint64_t y0 = __builtin_nontemporal_load(y + i), y1 = __builtin_nontemporal_load(y + plane_words + i);
-#else
                 uint64_t x0 = x[i], x1 = x[plane_words + i];
                 uint64_t y0 = y[i], y1 = y[plane_words + i];
-#endif
                 // (the descriptor comes through the scalar cache: the 64 consecutive words of a wave belong to one component whenever
                 // N >= 64, and the double-precision back end only exists from N = 2^13 - a per-lane load of it, dependent on the
                 // per-lane test of its first word, made the kernel slower than the integer path it replaces: -1.4 % on the step)
