@@ -2,6 +2,8 @@
 the reference's negative tests (native/tests/seal/evaluator.cpp:2505-2632, 5590 and the throw sites in
 native/src/seal/evaluator.cpp) and the C layer's exception -> HRESULT mapping
 (native/src/seal/c/defines.h:75-97)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -263,3 +265,30 @@ def test_bgv_correction_factor_validation(emu):
     y = d.ct(rand_ct(rng, primes, 2, n), is_ntt=False)
     with pytest.raises(S.InvalidArgument):   # "encrypted1 or encrypted2 must be in NTT form" evaluator.cpp:712
         d.ev.multiply_inplace(y, y.copy())
+
+
+def test_abort_leaves_a_call_stack_behind(emu, tmp_path):
+    """SealHip_InstallAbortTrace (sealhip.h, diagnostics.cpp): a process that aborts - here by hand; on a GPU box the ROCm runtime does it on
+    a device memory fault - appends the aborting thread's call stack to the named file before it dies, and an exception that reaches
+    std::terminate prints its message first (round 3's one aborted process left nothing behind: pytest keeps stderr in a file that dies
+    with the process)."""
+    import subprocess
+    import sys
+    trace = tmp_path / "abort_trace.txt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "import seal_amd as S\n"
+            "S.load(%r)\n"
+            "S.install_abort_trace(%r)\n"
+            "os.abort()\n" % (root, os.path.join(root, "tests", "hipemu", "libsealhip_emu.so"), str(trace)))
+    run = subprocess.run([sys.executable, "-X", "faulthandler=0", "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, SEALHIP_COMM_NO_RCCL="1"))
+    assert run.returncode != 0
+    text = trace.read_text()
+    assert "sealhip: SIGABRT in process" in text and "end of call stack" in text, text
+    # the environment form installs it at load time
+    trace2 = tmp_path / "abort_trace_env.txt"
+    run = subprocess.run([sys.executable, "-X", "faulthandler=0", "-c", code.replace("S.install_abort_trace(%r)\n" % str(trace), "")],
+                         capture_output=True, text=True, timeout=120, env=dict(os.environ, SEALHIP_COMM_NO_RCCL="1", SEALHIP_ABORT_TRACE=str(trace2)))
+    assert run.returncode != 0 and "SIGABRT" in trace2.read_text()
