@@ -536,7 +536,7 @@ SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
  * fault: its handler on the stack tells that case from a C++ one) and then lets the abort proceed.  Opt-in: signal
  * dispositions belong to the host program. */
 SHL_FUNC SealHip_InstallAbortTrace(const char *path);
-/* Environment.  The product library reads five variables, each exercised by a parity test; everything else that earlier
+/* Environment.  The product library reads six variables, each exercised by a test; everything else that earlier
  * rounds could switch at run time (superseded kernels, fork / no-fork of the side streams, ...) only exists in development
  * builds made with -DSEALHIP_AB_SWITCHES (seal_amd/csrc/modarith.h: shl_ab_getenv).
  *   SEALHIP_NO_FP=1                  every prime on the 64-bit integer back end (no exact double-precision arithmetic for
@@ -547,7 +547,8 @@ SHL_FUNC SealHip_InstallAbortTrace(const char *path);
  *   SEALHIP_NTT_FCHUNKS=<n>          workgroups per component of the single-launch transforms (N = 2^13, 2^14): tests force
  *                                    the per-workgroup loop at small batches with it
  *   SEALHIP_ENCRYPT_HOST_SAMPLING=1  encryption noise is sampled on the host with the reference's own sampler instead of the
- *                                    device kernels (same distribution and, for a seeded generator, the same words) */
+ *                                    device kernels (same distribution and, for a seeded generator, the same words)
+ *   SEALHIP_ABORT_TRACE=<file>       SealHip_InstallAbortTrace(<file>) when the library is loaded (Diagnostics, above) */
 /* Deferred key-switch tails.  For CKKS and BFV at 2^13 <= N <= 2^16, Evaluator_Relinearize / ApplyGalois / RotateVector / RotateRows /
  * RotateColumns / ComplexConjugate return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext
  * object keeps the key-switch sums next to its two polynomials.  Whatever needs the words next completes it first -
