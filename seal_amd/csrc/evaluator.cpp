@@ -18,10 +18,10 @@ namespace sealhip
         plain = g_tail_plain.load();
         dropped = g_tail_dropped.load();
     }
-    void Evaluator::defer_tail(Ciphertext &e, uint64_t *acc) const
+    void Evaluator::defer_tail(Ciphertext &e, uint64_t *acc, bool with_addend) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
-        e.lazy_ = new LazyTail{ this, acc };
+        e.lazy_ = new LazyTail{ this, acc, with_addend };
         std::lock_guard<std::mutex> lock(lazy_mu_);
         lazy_cts_.push_back(&e);
     }
@@ -57,11 +57,11 @@ namespace sealhip
         // (another evaluator, a host copy) continues only when it is done
         static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr; // tests: which tail ran
         if (trace)
-            std::fprintf(stderr, "[ks] plain tail\n");
+            std::fprintf(stderr, t.with_addend ? "[ks] plain tail, addend in the sums\n" : "[ks] plain tail\n");
         g_tail_plain++;
         try
         {
-            switch_key_finish(e, t.acc, 1);
+            switch_key_finish(e, t.acc, 1, t.with_addend);
         }
         catch (...)
         {

@@ -28,6 +28,9 @@ namespace sealhip
     {
         const Evaluator *owner;
         uint64_t *acc;
+        // CKKS on the fused path: the data-prime components of acc are c + S P^-1 already (ntt2_kernels.h: KsFusedArgs::fold_c0) -
+        // the tail, folded into a rescale or not, reads one operand where it read two
+        bool with_addend = false;
     };
     // process-wide counters (tests, tools): tails folded into a rescale / completed on their own / discarded unrun
     void lazy_tail_stats(uint64_t &folded, uint64_t &plain, uint64_t &dropped);
@@ -278,8 +281,10 @@ namespace sealhip
         // split > 1 (fused path only): the digit range is cut into `split` in-launch groups and acc holds `split` buffers
         // (ntt2_kernels.h: KsFusedArgs::parts); the caller adds them with k_keyswitch_reduce(..., local_parts = split)
         void switch_key_partial(const Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index,
-                                unsigned j0, unsigned j1, uint64_t *acc, unsigned split = 1) const;
-        void switch_key_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts) const;
+                                unsigned j0, unsigned j1, uint64_t *acc, unsigned split = 1, bool fold_addend = false) const;
+        // fold_addend (CKKS, fused path, the full digit range, split 1): the data-prime components of acc leave as c + S P^-1
+        // (KsFusedArgs::fold_c0); the matching finish call says so with acc_has_addend
+        void switch_key_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts, bool acc_has_addend = false) const;
         // relinearize (size 3 -> 2) and apply_galois (size 2) split the same way: *_partial leaves `encrypted` ready for
         // the finish call (for apply_galois: c0 <- pi(c0), c1 <- 0) and writes this rank's partial sums to acc
         void relinearize_partial(Ciphertext &encrypted, const KSwitchKeys &relin_keys, unsigned j0, unsigned j1, uint64_t *acc) const;
@@ -362,13 +367,13 @@ namespace sealhip
         // ciphertexts whose key-switch tail this evaluator deferred (LazyTail): completed before the evaluator goes away or starts
         // recording a graph
         friend class Ciphertext;
-        void defer_tail(Ciphertext &e, uint64_t *acc) const;
+        void defer_tail(Ciphertext &e, uint64_t *acc, bool with_addend) const;
         void complete_tail(Ciphertext &e, LazyTail t) const;     // the plain mod-down, then the sums go back to the pool
         void forget_tail(const Ciphertext &e, LazyTail t) const; // discard
         LazyTail detach_tail(Ciphertext &e) const;
         void settle_all() const;
         // mod-down by the special prime and rescale by q_last in one pass (NttTail2); e has two polynomials and a deferred tail
-        void switch_key_finish_rescale(Ciphertext &e, uint64_t *acc, const Level *next, double destination_scale) const;
+        void switch_key_finish_rescale(Ciphertext &e, uint64_t *acc, const Level *next, double destination_scale, bool acc_has_addend) const;
         void switch_key_finish_modswitch_bfv(Ciphertext &e, uint64_t *acc, const Level *next) const;
         mutable std::mutex lazy_mu_;
         mutable std::vector<const Ciphertext *> lazy_cts_;

@@ -94,7 +94,7 @@ namespace sealhip
 
     void Evaluator::switch_key_partial(
         const Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, unsigned j0, unsigned j1,
-        uint64_t *acc_out, unsigned split) const
+        uint64_t *acc_out, unsigned split, bool fold_addend) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
@@ -129,6 +129,8 @@ namespace sealhip
         const unsigned K = lvl.K, L = klvl.K;
         if (j1 > K || j0 > j1)
             throw std::invalid_argument("digit range");
+        if (fold_addend && !(scheme == Scheme::ckks && key.register_order && j0 == 0 && j1 == K && split <= 1))
+            throw std::invalid_argument("fold_addend"); // the addend may only join the complete sum, on the fused path
         if (j0 < j1 && (key.digit0 > j0 || key.digit0 + key.digits < j1))
             throw std::invalid_argument("kswitch_keys inner dimension is too small");
         if (e.size() < 2)
@@ -186,6 +188,12 @@ namespace sealhip
             ka.j1 = j1;
             ka.key_digit0 = (unsigned)key.digit0;
             ka.parts = split ? split : 1;
+            if (fold_addend)
+            {
+                ka.fold_c0 = e.plane(0);
+                ka.fold_c1 = e.plane(1);
+                ka.fold_pm = klvl.dev.inv_q_last_mod_q;
+            }
             ck(ks_fused(tb, ka, stream_), "ks fused");
         }
         else if (split > 1)
@@ -213,7 +221,7 @@ namespace sealhip
         }
     }
 
-    void Evaluator::switch_key_finish(Ciphertext &e, uint64_t *acc_p, unsigned parts) const
+    void Evaluator::switch_key_finish(Ciphertext &e, uint64_t *acc_p, unsigned parts, bool acc_has_addend) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
@@ -225,6 +233,8 @@ namespace sealhip
             throw std::invalid_argument("encrypted size must be at least 2");
         if (parts < 1 || parts > 8)
             throw std::invalid_argument("parts"); // 8 canonical residues below 2^60 still fit a 64-bit word
+        if (acc_has_addend && !(parts == 1 && context_.scheme() == Scheme::ckks && ntt2_supports(context_.log_n())))
+            throw std::invalid_argument("acc_has_addend");
         const Scheme scheme = context_.scheme();
         const Level &lvl = *e.level();
         const Level &klvl = context_.key_level();
@@ -280,7 +290,7 @@ namespace sealhip
             {
                 // the tail is the epilogue of the transform: tt is never stored
                 b.data = nullptr;
-                b.epi = 2;
+                b.epi = acc_has_addend ? 3 : 2; // 3: acc = c + S P^-1 already (switch_key_partial, fold_addend)
                 b.epi_a = acc.p;
                 b.epi_a_stride = (size_t)(K + 1) * N;
                 b.epi_mul = klvl.dev.inv_q_last_mod_q;
@@ -333,20 +343,26 @@ namespace sealhip
             if (split < 1)
                 split = 1;
         }
-        Scratch acc(switch_key_acc_words(e) * split);
-        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split);
-        if (split > 1)
-            ck(k_keyswitch_reduce(context_.dev_mods(), acc.p, (unsigned)context_.log_n(), K, context_.key_level().K, (unsigned)e.batch(),
-                                  stream_, split),
-               "ks add digit groups");
         // CKKS at the two-pass sizes: leave the mod-down to whoever touches the ciphertext next (LazyTail) - a rescale on this
         // evaluator then does both rounding divisions with one transform per component.  SEALHIP_KS_EAGER_TAIL=1: always now.
         // BFV at the same sizes (round 4): a mod_switch_to_next on this evaluator folds the mod-down into its own division (one
         // element-wise pass after the inverse transforms, switch_key_finish_modswitch_bfv); anything else completes it first.
         static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
         const Scheme sch = context_.scheme();
-        if (lazy_ok && (sch == Scheme::ckks || sch == Scheme::bfv) && ntt2_supports(context_.log_n()) && K >= 2)
-            defer_tail(e, acc.release());
+        const bool defer = lazy_ok && (sch == Scheme::ckks || sch == Scheme::bfv) && ntt2_supports(context_.log_n()) && K >= 2;
+        // CKKS, one digit group: the sums leave the key switch with the ciphertext's words already added (c + S P^-1), so that the
+        // tail reads one operand per component instead of two.  SEALHIP_KS_NO_FOLD=1: the round-3 form (A/B, tests)
+        static const bool fold_ok = !shl_ab_getenv("SEALHIP_KS_NO_FOLD");
+        const bool fold = fold_ok && defer && sch == Scheme::ckks && split == 1 && keys.context() == &context_ && key_index < keys.slots() &&
+                          keys.has_key(key_index) && keys.key(key_index).register_order;
+        Scratch acc(switch_key_acc_words(e) * split);
+        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split, fold);
+        if (split > 1)
+            ck(k_keyswitch_reduce(context_.dev_mods(), acc.p, (unsigned)context_.log_n(), K, context_.key_level().K, (unsigned)e.batch(),
+                                  stream_, split),
+               "ks add digit groups");
+        if (defer)
+            defer_tail(e, acc.release(), fold);
         else
             switch_key_finish(e, acc.p, 1);
     }
@@ -388,7 +404,7 @@ namespace sealhip
     // relinearize (or a rotation) followed by rescale_to_next: acc = the key-switch sums, planes 0 and 1 of e = the addends.
     // Reference steps being folded: evaluator.cpp:2806-2864 (mod-down by the special prime P), then rns.cpp:830-901 on the result
     // (divide_and_round_q_last_ntt_inplace); see NttTail2 (ntt_kernels.h) for the algebra.
-    void Evaluator::switch_key_finish_rescale(Ciphertext &e, uint64_t *acc_p, const Level *next, double destination_scale) const
+    void Evaluator::switch_key_finish_rescale(Ciphertext &e, uint64_t *acc_p, const Level *next, double destination_scale, bool acc_has_addend) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         const Level &lvl = *e.level();
@@ -401,7 +417,7 @@ namespace sealhip
         uint64_t *c0 = e.data_, *c1 = e.data_ + (size_t)B * K * N; // no deferred tail left on e: the caller detached it
         static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr;
         if (trace)
-            std::fprintf(stderr, "[ks] folded tail\n");
+            std::fprintf(stderr, acc_has_addend ? "[ks] folded tail, addend in the sums\n" : "[ks] folded tail\n");
         g_tail_folded++;
 
         // t_P: coefficient form of the special-prime sums, in place (component K of every (item, plane) of acc)
@@ -410,8 +426,20 @@ namespace sealhip
         bi.out_add = P >> 1;
         ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
 
-        // the relinearised ciphertext's LAST component (the one rescale divides by), completed alone: c += (S - NTT(v)) P^-1
+        if (acc_has_addend)
         {
+            // acc's data-prime components are A = c + S P^-1 (switch_key_partial, fold_addend).  The relinearised ciphertext's last
+            // component is A - NTT(v) P^-1; its coefficient form is INTT(A) - v P^-1 because the transform is linear: one inverse
+            // transform in place and one element-wise pass, no forward transform of v and nothing written to e's planes
+            NttBatch bw = plain_batch(acc_p + (size_t)(K - 1) * N, (size_t)(K + 1) * N, 1, 2 * B, K - 1);
+            ck(ntt_inverse(tb, bw, 0, stream_), "ks intt last component");
+            ck(k_ks_last_coeff(context_.dev_mods(), K - 1, klvl.dev.inv_q_last_mod_q + (K - 1), klvl.dev.round_fix + (K - 1),
+                               lvl.dev.half_q_last, acc_p, (unsigned)context_.log_n(), K, (size_t)2 * B, stream_),
+               "ks last component, coefficient form");
+        }
+        else
+        {
+            // the relinearised ciphertext's LAST component (the one rescale divides by), completed alone: c += (S - NTT(v)) P^-1
             NttBatch b{};
             b.data = nullptr;
             b.outer_stride = N;
@@ -436,6 +464,7 @@ namespace sealhip
             ck(ntt_forward(tb, b, 1, stream_), "ks ntt correction + tail, last component");
         }
         // t_last: its coefficient form, in place (that component is dropped by the rescale)
+        if (!acc_has_addend)
         {
             NttBatch bl = plain_batch(c0 + (size_t)(K - 1) * N, (size_t)K * N, 1, 2 * B, K - 1);
             bl.out_add = lvl.dev.half_q_last;
@@ -459,6 +488,14 @@ namespace sealhip
             t2.c1 = c1;
             t2.c_stride = (size_t)K * N;
             t2.halves_added = 1;
+            if (acc_has_addend)
+            {
+                // t_last sits in acc (component K - 1 of every (item, plane)); the sums carry the addend
+                t2.src2_0 = acc_p + (size_t)(K - 1) * N;
+                t2.src2_1 = acc_p + (size_t)(K + 1) * N + (size_t)(K - 1) * N;
+                t2.src2_stride = (size_t)2 * (K + 1) * N;
+                t2.a_has_c = 1;
+            }
             NttBatch b{};
             b.data = nullptr;
             b.outer_stride = (size_t)(K - 1) * N;

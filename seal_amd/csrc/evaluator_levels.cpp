@@ -34,7 +34,7 @@ namespace sealhip
             const LazyTail t = detach_tail(e);
             try
             {
-                switch_key_finish_rescale(e, t.acc, next, destination_scale);
+                switch_key_finish_rescale(e, t.acc, next, destination_scale, t.with_addend);
             }
             catch (...)
             {

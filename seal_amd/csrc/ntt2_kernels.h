@@ -40,6 +40,12 @@ namespace sealhip
         // separate workgroups, slice g writing its partial sums to acc + g * batch*2*(K+1)*N (acc holds `parts` such buffers,
         // added by k_keyswitch_reduce).  Multiplies the number of workgroups when batch * targets * tiles does not fill the chip.
         unsigned parts;
+        // Optional (parts <= 1, the full digit range only): the data-prime components leave as c_k[item][I] + S_k[item][I] P^-1 mod q_I
+        // instead of the bare sums - the first step of the key-switch tail (evaluator.cpp:2845-2863), taken while S is in
+        // registers.  fold_c0 / fold_c1 = the ciphertext's two planes [batch][K][N], fold_pm[I] = P^-1 mod q_I (device).  The
+        // special-prime component is the plain sum either way.
+        const uint64_t *fold_c0 = nullptr, *fold_c1 = nullptr;
+        const ShoupOp *fold_pm = nullptr;
     };
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);
 

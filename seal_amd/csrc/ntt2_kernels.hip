@@ -920,6 +920,14 @@ namespace sealhip
                     uint64_t *O = a.epi_out0 + (size_t)outer * a.epi_out_stride + row0;
                     emit_rows(val, lds_wave, tid, [&](unsigned off, uint64_t tv) { O[off] = mul_shoup(A[off] + 4 * q - tv, mul.w, mul.wq, q); });
                 }
+                else if (a.epi == 3)
+                {
+                    // A = c + S P^-1 already (KsFusedArgs::fold_c0): the ciphertext words are written, not updated
+                    uint64_t *O = ((outer & 1) ? a.epi_out1 : a.epi_out0) + (size_t)(outer >> 1) * a.epi_out_stride + row0;
+                    emit_rows(val, lds_wave, tid, [&](unsigned off, uint64_t tv) {
+                        O[off] = sub_mod(mid_ld<16>(A + off), mul_shoup(tv, mul.w, mul.wq, q), q);
+                    });
+                }
                 else
                 {
                     uint64_t *O = ((outer & 1) ? a.epi_out1 : a.epi_out0) + (size_t)(outer >> 1) * a.epi_out_stride + row0;
@@ -1052,13 +1060,14 @@ namespace sealhip
                 // the tail's two operands are requested before the transform, not at the stores that need them
                 const uint64_t *A = a.epi_a + (size_t)outer * a.epi_a_stride + row0;
                 const uint64_t *C = ((outer & 1) ? t2.x.c1 : t2.x.c0) + (size_t)(outer >> 1) * t2.x.c_stride + row0;
+                const bool folded = t2.x.a_has_c; // A = c + S P^-1 already: one operand
                 uint64_t av[16], cv[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++)
                 {
                     const unsigned off = (k >> 2) * 256 + (k & 3) * 64 + (tid & 63);
                     av[k] = mid_ld<16>(A + off);
-                    cv[k] = mid_ld<16>(C + off);
+                    cv[k] = folded ? 0 : mid_ld<16>(C + off);
                 }
                 p2_tile<FP, D1, false, false, false, false, false, ICLS, kP1Out<ICLS, D1>>(x, m, tab, nullptr, nullptr, lds_wave, hg, tid);
                 uint64_t val[16];
@@ -1073,7 +1082,7 @@ namespace sealhip
                     for (int e = 0; e < 16; e++)
                         val[e] = F::raw(x[e]);
                     emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t tv) {
-                        const double s = fp_mulmod(fp_from_u52(av[k]), pm_fp, m.q, m.qinv) + fp_from_u52(cv[k]);
+                        const double s = folded ? fp_from_u52(av[k]) : fp_mulmod(fp_from_u52(av[k]), pm_fp, m.q, m.qinv) + fp_from_u52(cv[k]);
                         const double r = fp_mulmod(s - fp_from_bits(tv), mul_fp, m.q, m.qinv);
                         O[off] = fp_to_canon(fp_fix(r, m.q, m.qinv), m);
                     });
@@ -1084,7 +1093,7 @@ namespace sealhip
                     for (int e = 0; e < 16; e++)
                         val[e] = fwd_out_lazy<FP, ICLS, kP2Out<ICLS, D1>>(x[e], m); // < 4q
                     emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t tv) {
-                        const uint64_t s = add_mod(mul_shoup(av[k], pm.w, pm.wq, q), cv[k], q); // c + S P^-1, canonical
+                        const uint64_t s = folded ? av[k] : add_mod(mul_shoup(av[k], pm.w, pm.wq, q), cv[k], q); // c + S P^-1, canonical
                         O[off] = mul_shoup(s + 4 * q - tv, mul.w, mul.wq, q);
                     });
                 }
@@ -1824,6 +1833,9 @@ namespace sealhip
             unsigned batch;
             unsigned j0, j1, key_digit0; // digits handled by this call; first digit resident in `key`
             unsigned parts;              // in-launch digit groups (as Ks1Args); group g writes acc + g * batch*2*(K+1)*N
+            // KsFusedArgs::fold_c0: components I < K leave as c_k + S_k P^-1 instead of S_k (fold_pm = P^-1 mod q_I); null = plain sums
+            const uint64_t *fold_c0, *fold_c1;
+            const ShoupOp *fold_pm;
             NttTables tb;
         };
 
@@ -2086,6 +2098,37 @@ namespace sealhip
                 else
                     return F::template canon_any<IntBounds<ICLS>::hi32>(s, m);
             };
+            if (a.fold_c0 && I < a.K)
+            {
+                // the key-switch tail's "c + S P^-1" happens here, where S is in registers: the tail then reads one operand, not two
+                // (evaluator.cpp:2845-2863 computes ct += (S - NTT(v)) P^-1 = (c + S P^-1) - NTT(v) P^-1; exact residue arithmetic)
+                const size_t crow = ((((size_t)b * a.K + I) << G::n)) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+                const uint64_t *C0 = a.fold_c0 + crow, *C1 = a.fold_c1 + crow;
+                const ShoupOp pm = a.fold_pm[I];
+                const uint64_t q = a.tb.mods[prime].q;
+                uint64_t cv0[16], cv1[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                {
+                    const unsigned off = (k >> 2) * 256 + (k & 3) * 64 + (tid & 63);
+                    cv0[k] = mid_ld<16>(C0 + off);
+                    cv1[k] = mid_ld<16>(C1 + off);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    val[e] = sum_to_canon(acc0[e]);
+                emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
+                    mid_st<16>(out + off, add_mod(mul_shoup(sv, pm.w, pm.wq, q), cv0[k], q));
+                });
+                uint64_t *out1 = out + ((size_t)(a.K + 1) << G::n);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    val[e] = sum_to_canon(acc1[e]);
+                emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
+                    mid_st<16>(out1 + off, add_mod(mul_shoup(sv, pm.w, pm.wq, q), cv1[k], q));
+                });
+                return;
+            }
 #pragma unroll
             for (int e = 0; e < 16; e++)
                 val[e] = sum_to_canon(acc0[e]);
@@ -2731,6 +2774,8 @@ namespace sealhip
         a1.j1 = k.j1;
         a1.parts = k.parts ? k.parts : 1;
         a1.tb = t;
+        if (k.fold_c0 && (a1.parts > 1 || !k.fold_c1 || !k.fold_pm || k.j0 != 0 || k.j1 != k.K))
+            return hipErrorInvalidValue; // the addend may only join the COMPLETE sum of a component
         Ks2Args a2;
         a2.mid = k.mid;
         a2.target = k.target_ntt;
@@ -2746,6 +2791,9 @@ namespace sealhip
         a2.j1 = k.j1;
         a2.key_digit0 = k.key_digit0;
         a2.parts = a1.parts;
+        a2.fold_c0 = k.fold_c0;
+        a2.fold_c1 = k.fold_c1;
+        a2.fold_pm = k.fold_pm;
         a2.tb = t;
         switch (t.log_n)
         {

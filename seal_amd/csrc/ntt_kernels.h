@@ -55,6 +55,7 @@ namespace sealhip
         const uint64_t *c0, *c1;         // ciphertext planes: + (outer >> 1) * c_stride + comp * N
         size_t c_stride;
         int halves_added;                // both sources were produced with out_add = their half: the maps skip that step
+        int a_has_c = 0;                 // epi_a holds c + S P^-1 (KsFusedArgs::fold_c0): c0 / c1 are not read
     };
 
     // One batched launch: transforms live at data + outer*outer_stride + comp*N, comp in
@@ -88,6 +89,8 @@ namespace sealhip
         //   v = (A[outer][comp] - T) * mul[comp]  mod q                        (A canonical)
         //   epi 1: out[outer][comp] = v                      rescale tail, rns.cpp:890-899
         //   epi 2: ct_{outer&1}[outer>>1][comp] += v         key-switch tail, evaluator.cpp:2845-2863
+        //   epi 3: ct_{outer&1}[outer>>1][comp] = A[outer][comp] - T * mul[comp]: the same tail when the key switch has left
+        //          A = c + S P^-1 behind (KsFusedArgs::fold_c0)
         // A = epi_a + outer*epi_a_stride + comp*N; epi 1 writes epi_out0 + outer*epi_out_stride + comp*N,
         // epi 2 updates epi_out{0,1} + (outer>>1)*epi_out_stride + comp*N.
         int epi;

@@ -102,6 +102,11 @@ namespace sealhip
         unsigned L, unsigned batch, unsigned j0, unsigned j1, unsigned key_digit0, hipStream_t s);
     // acc <- acc mod q_I in place after partial sums of several ranks were added (each canonical, at most 8 of them)
     hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts = 1);
+    // acc[outer][K+1][N], component K - 1 <- (it - (component K mod q + *fix) * *pinv + half_last) mod q, q = mods[prime]: the
+    // coefficient form of the key-switched ciphertext's last component, ready for the rescale (poly_kernels.hip)
+    hipError_t k_ks_last_coeff(
+        const ModDesc *mods, unsigned prime, const ShoupOp *pinv, const uint64_t *fix, uint64_t half_last, uint64_t *acc, unsigned n_log,
+        unsigned K, size_t nouter, hipStream_t s);
     // Reduce-scatter exchange of the digit-parallel key switch (evaluator_keyswitch.cpp: switch_key_exchange_*).  The K data
     // moduli are owned by the G ranks in contiguous ranges whose sizes differ by at most one (rank c: K/G (+1 for c < K%G)
     // moduli); m = ceil(K / G) slots per rank.

@@ -438,6 +438,29 @@ namespace sealhip
             }
         }
 
+        // Folded key-switch + rescale tail (Evaluator::switch_key_finish_rescale): coefficient form of the relinearised ciphertext's
+        // LAST component from the coefficient forms of its two ingredients.  The component is (c + S P^-1) - NTT(v) P^-1 with
+        // v = the mod-down correction (evaluator.cpp:2813-2832); the inverse transform is linear, so its coefficient form is
+        // w - v P^-1 with w = INTT(c + S P^-1): no forward transform of v.  In place over w, plus q_last / 2 (the rescale's rounding
+        // addend, rns.cpp:858-862).  acc[outer][K+1][N]: component K - 1 = w, component K = t_P + P/2 mod P.
+        __global__ void __launch_bounds__(kBlock) ks_last_coeff_kernel(
+            const ModDesc *mods, unsigned prime, const ShoupOp *pinv, const uint64_t *fix, uint64_t half_last, uint64_t *acc, unsigned n_log,
+            unsigned K, size_t words)
+        {
+            const ModDesc md = mods[prime];
+            const ShoupOp pm = *pinv;
+            const uint64_t f = *fix;
+            const size_t N = size_t(1) << n_log;
+            for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
+            {
+                const size_t outer = i >> n_log, j = i & (N - 1);
+                uint64_t *w = acc + ((outer * (K + 1) + (K - 1)) << n_log) + j;
+                const uint64_t v = barrett64(w[N], md) + f; // below 2 q
+                const uint64_t y = sub_mod(*w, mul_shoup(v, pm.w, pm.wq, md.q), md.q);
+                *w = csub(y + half_last, md.q);
+            }
+        }
+
         // ---- reduce-scatter exchange of the digit-parallel key switch.  The K data moduli are owned by the G
         // ranks in contiguous ranges (rank c: [c*base + min(c, extra), ...), sizes differ by at most one; m = ceil(K / G) slots).
         __device__ __forceinline__ unsigned ks_owner_first(unsigned K, unsigned G, unsigned c)
@@ -800,6 +823,16 @@ namespace sealhip
         if (!w)
             return hipSuccess;
         hipLaunchKernelGGL(keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w, local_parts);
+        return hipGetLastError();
+    }
+    hipError_t k_ks_last_coeff(
+        const ModDesc *mods, unsigned prime, const ShoupOp *pinv, const uint64_t *fix, uint64_t half_last, uint64_t *acc, unsigned n_log,
+        unsigned K, size_t nouter, hipStream_t s)
+    {
+        const size_t words = nouter << n_log;
+        if (!words)
+            return hipSuccess;
+        hipLaunchKernelGGL(ks_last_coeff_kernel, dim3(grid_for(words)), dim3(kBlock), 0, s, mods, prime, pinv, fix, half_last, acc, n_log, K, words);
         return hipGetLastError();
     }
     hipError_t k_ks_pack_targets(

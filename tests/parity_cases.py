@@ -136,7 +136,25 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
         for b in range(batch):
             _eq(back[b], cur[b], "transform_to_ntt(transform_from_ntt(x)) item %d" % b)
 
-    if K >= 2:
+    # twice: with the digit loop cut into in-launch groups where the batch is small (the default; the sums are then added by a
+    # reduce pass) and as ONE group - the form large batches run, in which the key switch leaves c + S P^-1 behind instead of the
+    # bare sums (KsFusedArgs::fold_c0) and both tails read one operand
+    for one_group in ((False, True) if K >= 2 else ()):
+        saved = os.environ.get("SEALHIP_KS_SPLIT")
+        if one_group:
+            os.environ["SEALHIP_KS_SPLIT"] = "1"
+        try:
+            _deferred_tails(d, o, xs, ys, primes, K, n, batch, steps, elts)
+        finally:
+            if one_group:
+                if saved is None:
+                    del os.environ["SEALHIP_KS_SPLIT"]
+                else:
+                    os.environ["SEALHIP_KS_SPLIT"] = saved
+
+
+def _deferred_tails(d, o, xs, ys, primes, K, n, batch, steps, elts):
+    if True:
         # Deferred key-switch tails (evaluator.h: LazyTail): the key switch leaves its mod-down undone, and a rescale that follows
         # without anything reading the ciphertext in between does both rounding divisions in one pass.  Same words as the
         # reference's two separate steps (evaluator.cpp:2806-2864, rns.cpp:830-901).

@@ -217,7 +217,11 @@ def test_product_growth(emu, scheme, n, bits):
     P.case_product_growth(scheme, n, bits)
 
 
-def test_deferred_tail_two_readers(emu):
+@pytest.mark.parametrize("groups", ["auto", "1"])
+def test_deferred_tail_two_readers(emu, monkeypatch, groups):
+    """groups "1": the key switch runs its digits as one group, the form that leaves c + S P^-1 behind (KsFusedArgs::fold_c0)"""
+    if groups != "auto":
+        monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_two_readers(8192, (50, 40, 60), rounds=2)
 
 
@@ -256,6 +260,10 @@ def test_ckks_pipeline_n65536_lean_key_switch(emu):
     P.case_ckks_pipeline(65536, [60, 50, 40, 50, 45, 60], batch=2, steps=(1,), check_transforms=False)
 
 
-def test_deferred_tail_lifecycle(emu):
-    """deferred key-switch tails (sealhip.h): folded into a rescale by their owner, completed by anyone else who needs the words"""
+@pytest.mark.parametrize("groups", ["auto", "1"])
+def test_deferred_tail_lifecycle(emu, monkeypatch, groups):
+    """deferred key-switch tails (sealhip.h): folded into a rescale by their owner, completed by anyone else who needs the words;
+    groups "1": with the addend already in the sums (KsFusedArgs::fold_c0)"""
+    if groups != "auto":
+        monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_lifecycle()

@@ -83,10 +83,13 @@ def _ckks_configs(seed, count, degrees):
 
 
 @pytest.mark.parametrize("cfg", _ckks_configs(3, 6, [8192, 8192, 16384]), ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
-def test_random_sequences_with_deferred_state_emulated(emu, cfg):
-    """the same sequences with the result read back only now and then: deferred key-switch tails reach the next operation"""
+def test_random_sequences_with_deferred_state_emulated(emu, cfg, monkeypatch):
+    """the same sequences with the result read back only now and then: deferred key-switch tails reach the next operation.
+    Every other sequence runs its key switches as ONE digit group, the form large batches take (c + S P^-1 left in the sums)"""
     if not sealref.available():
         pytest.skip("needs the real reference (oracle/_ref)")
+    if cfg[-1] % 2:
+        monkeypatch.setenv("SEALHIP_KS_SPLIT", "1")
     try:
         F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30)
     except sealref.RefError as e:
@@ -95,9 +98,11 @@ def test_random_sequences_with_deferred_state_emulated(emu, cfg):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", _ckks_configs(4, 24, [8192, 16384, 32768, 65536]), ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
-def test_random_sequences_with_deferred_state_gpu(gpu, cfg):
+def test_random_sequences_with_deferred_state_gpu(gpu, cfg, monkeypatch):
     if not sealref.available():
         pytest.skip("needs the real reference (oracle/_ref)")
+    if cfg[-1] % 2:
+        monkeypatch.setenv("SEALHIP_KS_SPLIT", "1")
     try:
         F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30)
     except sealref.RefError as e:

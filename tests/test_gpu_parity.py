@@ -500,8 +500,12 @@ def test_product_growth(gpu, scheme, n, bits):
         P.case_product_growth(scheme, n, bits, seed=seed)
 
 
-def test_deferred_tail_two_readers(gpu):
-    """two threads read one ciphertext whose key-switch tail is pending: it runs once, both see the completed words"""
+@pytest.mark.parametrize("groups", ["auto", "1"])
+def test_deferred_tail_two_readers(gpu, monkeypatch, groups):
+    """two threads read one ciphertext whose key-switch tail is pending: it runs once, both see the completed words (ADVICE r2);
+    groups "1": the digits as one group, the form that leaves c + S P^-1 behind (KsFusedArgs::fold_c0)"""
+    if groups != "auto":
+        monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_two_readers(8192, (50, 40, 40, 60), rounds=8)
     P.case_deferred_tail_two_readers(65536, (60, 50, 50, 60), rounds=3)
 
@@ -658,8 +662,11 @@ def test_two_evaluators_two_streams_share_the_pool(gpu):
     ev2.set_stream(None)
 
 
-def test_deferred_tail_lifecycle(gpu):
+@pytest.mark.parametrize("groups", ["auto", "1"])
+def test_deferred_tail_lifecycle(gpu, monkeypatch, groups):
     """deferred key-switch tails (sealhip.h): folded into a rescale by their owner, completed by anyone else who needs the words;
-    at N = 8192 and at the headline size"""
+    at N = 8192 and at the headline size; groups "1": with the addend already in the sums (KsFusedArgs::fold_c0)"""
+    if groups != "auto":
+        monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_lifecycle()
     P.case_deferred_tail_lifecycle(65536, (60, 50, 50, 50, 60))
