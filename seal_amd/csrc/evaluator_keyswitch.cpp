@@ -350,16 +350,18 @@ namespace sealhip
         static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
         const Scheme sch = context_.scheme();
         const bool defer = lazy_ok && (sch == Scheme::ckks || sch == Scheme::bfv) && ntt2_supports(context_.log_n()) && K >= 2;
-        // CKKS, one digit group: the sums leave the key switch with the ciphertext's words already added (c + S P^-1), so that the
-        // tail reads one operand per component instead of two.  SEALHIP_KS_NO_FOLD=1: the round-3 form (A/B, tests)
+        // CKKS on the fused path: the sums leave the key switch with the ciphertext's words already added (c + S P^-1), so that the
+        // tail reads one operand per component instead of two - from ks2's epilogue when the digits run as one group, from the pass
+        // that adds the groups otherwise.  SEALHIP_KS_NO_FOLD=1 (development builds): the round-3 form
         static const bool fold_ok = !shl_ab_getenv("SEALHIP_KS_NO_FOLD");
-        const bool fold = fold_ok && defer && sch == Scheme::ckks && split == 1 && keys.context() == &context_ && key_index < keys.slots() &&
+        const bool fold = fold_ok && defer && sch == Scheme::ckks && keys.context() == &context_ && key_index < keys.slots() &&
                           keys.has_key(key_index) && keys.key(key_index).register_order;
         Scratch acc(switch_key_acc_words(e) * split);
-        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split, fold);
-        if (split > 1)
+        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split, fold && split == 1);
+        if (split > 1) // several digit groups (small batches): the pass that adds them adds the ciphertext's words too
             ck(k_keyswitch_reduce(context_.dev_mods(), acc.p, (unsigned)context_.log_n(), K, context_.key_level().K, (unsigned)e.batch(),
-                                  stream_, split),
+                                  stream_, split, fold ? e.plane(0) : nullptr, fold ? e.plane(1) : nullptr,
+                                  context_.key_level().dev.inv_q_last_mod_q),
                "ks add digit groups");
         if (defer)
             defer_tail(e, acc.release(), fold);

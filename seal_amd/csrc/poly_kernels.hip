@@ -425,16 +425,30 @@ namespace sealhip
         // acc[item][I][j] <- acc mod q_I: the sum of `parts` canonical partial sums (digit-parallel key switching)
         // `local_parts` > 1: the summands are still separate buffers of `words` words each (in-launch digit groups of the
         // fused key switch at small batches); they are added here
+        // c0 != null: the data-prime components leave as c_k + S_k P^-1 (pm[I] = P^-1 mod q_I), the form the fused key switch writes
+        // itself when its digits run as one group (ntt2_kernels.h: KsFusedArgs::fold_c0); c_k = [batch][K][N]
         __global__ void __launch_bounds__(kBlock) keyswitch_reduce_kernel(
-            const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, size_t words, unsigned local_parts)
+            const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, size_t words, unsigned local_parts, const uint64_t *c0,
+            const uint64_t *c1, const ShoupOp *pm)
         {
+            const size_t N = size_t(1) << n_log;
             for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
             {
-                const unsigned I = (unsigned)((i >> n_log) % (K + 1));
+                const size_t poly = i >> n_log; // (item * 2 + k) * (K + 1) + I
+                const unsigned I = (unsigned)(poly % (K + 1));
                 uint64_t v = acc[i];
                 for (unsigned g = 1; g < local_parts; g++)
                     v += acc[i + g * words];
-                acc[i] = barrett64(v, mods[I == K ? L - 1 : I]);
+                const ModDesc md = mods[I == K ? L - 1 : I];
+                v = barrett64(v, md);
+                if (c0 && I < K)
+                {
+                    const size_t pk = poly / (K + 1), item = pk >> 1;
+                    const uint64_t c = ((pk & 1) ? c1 : c0)[((item * K + I) << n_log) + (i & (N - 1))];
+                    const ShoupOp p = pm[I];
+                    v = add_mod(mul_shoup(v, p.w, p.wq, md.q), c, md.q);
+                }
+                acc[i] = v;
             }
         }
 
@@ -817,12 +831,16 @@ namespace sealhip
         hipLaunchKernelGGL(keyswitch_mac_kernel, grid, dim3(kBlock), 0, s, mods, u, key, acc, n_log, K, L, batch, j0, j1, key_digit0);
         return hipGetLastError();
     }
-    hipError_t k_keyswitch_reduce(const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts)
+    hipError_t k_keyswitch_reduce(
+        const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts,
+        const uint64_t *c0, const uint64_t *c1, const ShoupOp *pm)
     {
         size_t w = ((size_t)batch * 2 * (K + 1)) << n_log;
         if (!w)
             return hipSuccess;
-        hipLaunchKernelGGL(keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w, local_parts);
+        if (c0 && (!c1 || !pm))
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w, local_parts, c0, c1, pm);
         return hipGetLastError();
     }
     hipError_t k_ks_last_coeff(

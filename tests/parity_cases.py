@@ -136,9 +136,9 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
         for b in range(batch):
             _eq(back[b], cur[b], "transform_to_ntt(transform_from_ntt(x)) item %d" % b)
 
-    # twice: with the digit loop cut into in-launch groups where the batch is small (the default; the sums are then added by a
-    # reduce pass) and as ONE group - the form large batches run, in which the key switch leaves c + S P^-1 behind instead of the
-    # bare sums (KsFusedArgs::fold_c0) and both tails read one operand
+    # twice: with the digit loop cut into in-launch groups where the batch is small (the default; the pass that adds the groups
+    # also adds the ciphertext's words) and as ONE group - the form large batches run, in which ks2's epilogue leaves c + S P^-1
+    # behind (KsFusedArgs::fold_c0).  Both tails read one operand either way
     for one_group in ((False, True) if K >= 2 else ()):
         saved = os.environ.get("SEALHIP_KS_SPLIT")
         if one_group:

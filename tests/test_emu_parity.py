@@ -63,6 +63,23 @@ def test_pipelines_integer_only_in_a_subprocess():
     assert out.returncode == 0 and "integer-only ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_tails_without_the_addend_in_a_subprocess():
+    """SEALHIP_KS_NO_FOLD=1 (development switch, read once; the emulated library is built with -DSEALHIP_AB_SWITCHES): the key switch
+    leaves the bare sums and both tails add the ciphertext's words themselves - the round-3 form the A/B of
+    profiles/r04_fold_addend.txt compares with, still the same words"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import seal_amd as S; S.load(%r); import parity_cases as P\n"
+            "P.case_ckks_pipeline(8192, [50, 30, 40, 60], batch=1, steps=(1,), check_transforms=False)\n"
+            "P.case_deferred_tail_lifecycle()\n"
+            "print('bare sums ok')\n" % (here, os.path.dirname(here), os.path.join(here, "hipemu", "libsealhip_emu.so")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SEALHIP_KS_NO_FOLD="1", SEALHIP_KS_TRACE="1"),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "bare sums ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "[ks] folded tail\n" in out.stderr and "addend in the sums" not in out.stderr, out.stderr[-1000:]
+
+
 def test_ntt_two_pass_engine_mixed_kernel(emu, monkeypatch):
     """SEALHIP_NTT_NOSPLIT=1: one mixed-back-end launch instead of one launch per class run."""
     monkeypatch.setenv("SEALHIP_NTT_NOSPLIT", "1")
@@ -219,7 +236,7 @@ def test_product_growth(emu, scheme, n, bits):
 
 @pytest.mark.parametrize("groups", ["auto", "1"])
 def test_deferred_tail_two_readers(emu, monkeypatch, groups):
-    """groups "1": the key switch runs its digits as one group, the form that leaves c + S P^-1 behind (KsFusedArgs::fold_c0)"""
+    """groups "1": the key switch runs its digits as one group (ks2 itself leaves c + S P^-1 behind: KsFusedArgs::fold_c0)"""
     if groups != "auto":
         monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_two_readers(8192, (50, 40, 60), rounds=2)
@@ -263,7 +280,7 @@ def test_ckks_pipeline_n65536_lean_key_switch(emu):
 @pytest.mark.parametrize("groups", ["auto", "1"])
 def test_deferred_tail_lifecycle(emu, monkeypatch, groups):
     """deferred key-switch tails (sealhip.h): folded into a rescale by their owner, completed by anyone else who needs the words;
-    groups "1": with the addend already in the sums (KsFusedArgs::fold_c0)"""
+    groups "1": the digits as one group (ks2 itself adds the ciphertext's words: KsFusedArgs::fold_c0)"""
     if groups != "auto":
         monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_lifecycle()

@@ -85,7 +85,7 @@ def _ckks_configs(seed, count, degrees):
 @pytest.mark.parametrize("cfg", _ckks_configs(3, 6, [8192, 8192, 16384]), ids=lambda c: "%s-%d-%s" % (c[0], c[1], "_".join(map(str, c[2]))))
 def test_random_sequences_with_deferred_state_emulated(emu, cfg, monkeypatch):
     """the same sequences with the result read back only now and then: deferred key-switch tails reach the next operation.
-    Every other sequence runs its key switches as ONE digit group, the form large batches take (c + S P^-1 left in the sums)"""
+    Every other sequence runs its key switches as ONE digit group, the form large batches take (ks2 adds the ciphertext's words)"""
     if not sealref.available():
         pytest.skip("needs the real reference (oracle/_ref)")
     if cfg[-1] % 2:

@@ -503,7 +503,7 @@ def test_product_growth(gpu, scheme, n, bits):
 @pytest.mark.parametrize("groups", ["auto", "1"])
 def test_deferred_tail_two_readers(gpu, monkeypatch, groups):
     """two threads read one ciphertext whose key-switch tail is pending: it runs once, both see the completed words (ADVICE r2);
-    groups "1": the digits as one group, the form that leaves c + S P^-1 behind (KsFusedArgs::fold_c0)"""
+    groups "1": the digits as one group (ks2 itself leaves c + S P^-1 behind: KsFusedArgs::fold_c0)"""
     if groups != "auto":
         monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_two_readers(8192, (50, 40, 40, 60), rounds=8)
@@ -665,7 +665,7 @@ def test_two_evaluators_two_streams_share_the_pool(gpu):
 @pytest.mark.parametrize("groups", ["auto", "1"])
 def test_deferred_tail_lifecycle(gpu, monkeypatch, groups):
     """deferred key-switch tails (sealhip.h): folded into a rescale by their owner, completed by anyone else who needs the words;
-    at N = 8192 and at the headline size; groups "1": with the addend already in the sums (KsFusedArgs::fold_c0)"""
+    at N = 8192 and at the headline size; groups "1": the digits as one group (ks2 itself adds the ciphertext's words: KsFusedArgs::fold_c0)"""
     if groups != "auto":
         monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_lifecycle()
