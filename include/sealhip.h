@@ -341,7 +341,9 @@ SHL_FUNC Evaluator_ContextUsingKeyswitching(void *thisptr, bool *using_keyswitch
  * e.g. torch.distributed.all_reduce over RCCL), and every rank finishes locally (`*Finish`: reduce mod q_I, mod-down by
  * the special prime, accumulate into (c0, c1)).  device_acc = caller-owned device buffer of Evaluator_SwitchKeyAccWords
  * 64-bit words; parts = number of summed buffers (<= 8: eight residues below 2^60 still fit one word).
- * Results equal Evaluator_Relinearize / Evaluator_ApplyGalois bit for bit. */
+ * Results equal Evaluator_Relinearize / Evaluator_ApplyGalois bit for bit.  CKKS at the two-pass sizes: `*Finish` may leave the
+ * mod-down pending exactly as Evaluator_Relinearize does (deferred key-switch tail, below: a rescale on the same evaluator then
+ * folds both divisions); the reduced sums are copied first, device_acc is not referenced once the call has been enqueued. */
 SHL_FUNC Evaluator_SwitchKeyAccWords(void *thisptr, void *encrypted, uint64_t *words);
 SHL_FUNC Evaluator_RelinearizePartial(void *thisptr, void *encrypted /* size 3 */, void *relinKeys, uint64_t digit_first,
                                       uint64_t digit_count, uint64_t *device_acc);

@@ -284,7 +284,10 @@ namespace sealhip
                                 unsigned j0, unsigned j1, uint64_t *acc, unsigned split = 1, bool fold_addend = false) const;
         // fold_addend (CKKS, fused path, the full digit range, split 1): the data-prime components of acc leave as c + S P^-1
         // (KsFusedArgs::fold_c0); the matching finish call says so with acc_has_addend
-        void switch_key_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts, bool acc_has_addend = false) const;
+        // may_defer (relinearize_finish / apply_galois_finish / the in-library exchange): CKKS at the two-pass sizes copies the reduced
+        // sums - with the ciphertext's words added - into a block of its own and leaves the mod-down pending like switch_key_inplace
+        // does (LazyTail), so that a rescale that follows folds both divisions; `acc` is not referenced after the call returns
+        void switch_key_finish(Ciphertext &encrypted, uint64_t *acc, unsigned parts, bool acc_has_addend = false, bool may_defer = false) const;
         // relinearize (size 3 -> 2) and apply_galois (size 2) split the same way: *_partial leaves `encrypted` ready for
         // the finish call (for apply_galois: c0 <- pi(c0), c1 <- 0) and writes this rank's partial sums to acc
         void relinearize_partial(Ciphertext &encrypted, const KSwitchKeys &relin_keys, unsigned j0, unsigned j1, uint64_t *acc) const;

@@ -43,7 +43,7 @@ namespace sealhip
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level() || e.size() != 3)
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
-        switch_key_finish(e, acc, parts);
+        switch_key_finish(e, acc, parts, false, true);
         e.resize(e.level(), 2, stream_);
         throw_if_transparent(e);
     }
@@ -77,7 +77,7 @@ namespace sealhip
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level() || e.size() != 2)
             throw std::invalid_argument("encrypted is not valid for encryption parameters");
-        switch_key_finish(e, acc, parts);
+        switch_key_finish(e, acc, parts, false, true);
         throw_if_transparent(e);
     }
 
@@ -221,7 +221,7 @@ namespace sealhip
         }
     }
 
-    void Evaluator::switch_key_finish(Ciphertext &e, uint64_t *acc_p, unsigned parts, bool acc_has_addend) const
+    void Evaluator::switch_key_finish(Ciphertext &e, uint64_t *acc_p, unsigned parts, bool acc_has_addend, bool may_defer) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
@@ -249,6 +249,25 @@ namespace sealhip
         {
             uint64_t *p;
         } acc{ acc_p };
+        // Digit-parallel callers (the sums of `parts` ranks in the caller's buffer): CKKS at the two-pass sizes takes the road of
+        // switch_key_inplace - the pass that reduces the sums adds the ciphertext's words and writes a block of the pool's, the
+        // mod-down stays pending (LazyTail) and a rescale on this evaluator folds both divisions (configs[4]: rotate + rescale)
+        static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
+        static const bool fold_ok = !shl_ab_getenv("SEALHIP_KS_NO_FOLD");
+        if (may_defer && lazy_ok && fold_ok && !acc_has_addend && scheme == Scheme::ckks && ntt2_supports(context_.log_n()) && K >= 2)
+        {
+            const size_t words = switch_key_acc_words(e);
+            uint64_t *own = DevicePool::global().alloc_words(words, stream_);
+            const hipError_t err = k_keyswitch_reduce(mods, acc.p, n_log, K, L, B, stream_, 1, e.plane(0), e.plane(1),
+                                                      klvl.dev.inv_q_last_mod_q, own);
+            if (err != hipSuccess)
+            {
+                DevicePool::global().free_words(own, stream_);
+                ck(err, "ks reduce partial sums + addend");
+            }
+            defer_tail(e, own, true);
+            return;
+        }
         if (parts > 1)
             ck(k_keyswitch_reduce(mods, acc.p, n_log, K, L, B, stream_), "ks reduce partial sums");
 
@@ -645,7 +664,7 @@ namespace sealhip
         if (how == KsExchange::all_reduce || context_.scheme() != Scheme::ckks)
         {
             comm.all_reduce_sum(acc, words, stream_);
-            switch_key_finish(e, acc, G);
+            switch_key_finish(e, acc, G, false, true);
             return;
         }
         const unsigned m = switch_key_slots(e, G);

@@ -102,10 +102,10 @@ namespace sealhip
         unsigned L, unsigned batch, unsigned j0, unsigned j1, unsigned key_digit0, hipStream_t s);
     // acc <- acc mod q_I in place after partial sums of several ranks were added (each canonical, at most 8 of them)
     // c0 / c1 / pm (optional): the data-prime components leave as c_k[item][I] + (the sum) pm[I] mod q_I - KsFusedArgs::fold_c0 for a
-    // key switch whose digits ran as several in-launch groups
+    // key switch whose digits ran as several in-launch groups or on several ranks.  out (optional): the result goes there, acc is only read
     hipError_t k_keyswitch_reduce(
         const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts = 1,
-        const uint64_t *c0 = nullptr, const uint64_t *c1 = nullptr, const ShoupOp *pm = nullptr);
+        const uint64_t *c0 = nullptr, const uint64_t *c1 = nullptr, const ShoupOp *pm = nullptr, uint64_t *out = nullptr);
     // acc[outer][K+1][N], component K - 1 <- (it - (component K mod q + *fix) * *pinv + half_last) mod q, q = mods[prime]: the
     // coefficient form of the key-switched ciphertext's last component, ready for the rescale (poly_kernels.hip)
     hipError_t k_ks_last_coeff(

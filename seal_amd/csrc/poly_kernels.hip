@@ -428,8 +428,8 @@ namespace sealhip
         // c0 != null: the data-prime components leave as c_k + S_k P^-1 (pm[I] = P^-1 mod q_I), the form the fused key switch writes
         // itself when its digits run as one group (ntt2_kernels.h: KsFusedArgs::fold_c0); c_k = [batch][K][N]
         __global__ void __launch_bounds__(kBlock) keyswitch_reduce_kernel(
-            const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, size_t words, unsigned local_parts, const uint64_t *c0,
-            const uint64_t *c1, const ShoupOp *pm)
+            const ModDesc *mods, const uint64_t *acc, unsigned n_log, unsigned K, unsigned L, size_t words, unsigned local_parts, const uint64_t *c0,
+            const uint64_t *c1, const ShoupOp *pm, uint64_t *out)
         {
             const size_t N = size_t(1) << n_log;
             for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < words; i += (size_t)gridDim.x * kBlock)
@@ -448,7 +448,7 @@ namespace sealhip
                     const ShoupOp p = pm[I];
                     v = add_mod(mul_shoup(v, p.w, p.wq, md.q), c, md.q);
                 }
-                acc[i] = v;
+                out[i] = v;
             }
         }
 
@@ -833,14 +833,15 @@ namespace sealhip
     }
     hipError_t k_keyswitch_reduce(
         const ModDesc *mods, uint64_t *acc, unsigned n_log, unsigned K, unsigned L, unsigned batch, hipStream_t s, unsigned local_parts,
-        const uint64_t *c0, const uint64_t *c1, const ShoupOp *pm)
+        const uint64_t *c0, const uint64_t *c1, const ShoupOp *pm, uint64_t *out)
     {
         size_t w = ((size_t)batch * 2 * (K + 1)) << n_log;
         if (!w)
             return hipSuccess;
         if (c0 && (!c1 || !pm))
             return hipErrorInvalidValue;
-        hipLaunchKernelGGL(keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w, local_parts, c0, c1, pm);
+        hipLaunchKernelGGL(
+            keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w, local_parts, c0, c1, pm, out ? out : acc);
         return hipGetLastError();
     }
     hipError_t k_ks_last_coeff(

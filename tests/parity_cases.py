@@ -563,6 +563,30 @@ def case_digit_parallel(scheme, n, primes, t=0, parts=2, batch=2, seed=7):
     for b in range(batch):
         exp = o.run("apply_galois_inplace", [(x2[b], 1)], elt)[0] if scheme == "bgv" else o.apply_galois(x2[b], elt)
         _eq(want[b], exp, "apply_galois item %d vs oracle" % b)
+    if scheme == "ckks" and K >= 2:
+        # BASELINE configs[4] is rotate + rescale: at the two-pass sizes `*Finish` leaves the mod-down pending like the single-GPU
+        # key switch does and the rescale folds both divisions (sealhip.h section 1b); smaller sizes finish at once
+        defers = 13 <= n.bit_length() - 1 <= 16 and not os.environ.get("SEALHIP_KS_EAGER_TAIL")
+        sc = float(primes[K - 1]) * 2.0 ** 10
+        words = d.ev.switch_key_acc_words(d.ct(x2, scale=sc))
+        total = np.zeros(words, dtype=np.uint64)
+        cts = []
+        for r, (first, count) in enumerate(ranges):
+            c = d.ct(x2, scale=sc)
+            acc = S.DeviceBuffer(words)
+            d.ev.apply_galois_partial(c, elt, glks[r], first, count, acc.ptr)
+            total += acc.to_numpy((words,))
+            cts.append(c)
+        for c in cts:
+            folded0 = S.tail_stats()[0]
+            acc = S.DeviceBuffer.from_numpy(total)
+            d.ev.apply_galois_finish(c, acc.ptr, parts)
+            del acc  # the caller's buffer is not referenced by the pending tail
+            d.ev.rescale_to_next_inplace(c)
+            assert S.tail_stats()[0] - folded0 == (1 if defers else 0), "digit-parallel finish + rescale: folded pass expected %s" % defers
+            got = d.out(c)
+            for b in range(batch):
+                _eq(got[b], o.rescale(o.apply_galois(x2[b], elt)), "digit-parallel rotate + rescale, item %d" % b)
 
 
 def case_digit_parallel_reduce_scatter(n, primes, parts=2, batch=2, seed=9):

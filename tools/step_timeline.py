@@ -21,17 +21,21 @@ def main():
     ap.add_argument("db")
     ap.add_argument("--anchor", default="ckks_multiply_2x2_kernel")
     ap.add_argument("--step", type=int, default=-2, help="index of the anchor dispatch that starts the step (default: the one before last)")
+    ap.add_argument("--tail", type=int, default=0, help="no anchor: list the last TAIL dispatches of the trace (workloads without the headline's first kernel)")
     args = ap.parse_args()
     db = sqlite3.connect(args.db)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
     q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
     rows = db.execute("select name, start, end, %s from kernels order by start" % q).fetchall()
     anchors = [i for i, r in enumerate(rows) if args.anchor in r[0]]
-    if len(anchors) < 2:
+    if args.tail:
+        a0, a1 = max(0, len(rows) - args.tail), len(rows)
+    elif len(anchors) < 2:
         raise SystemExit("need at least two dispatches of %s" % args.anchor)
-    a0 = anchors[args.step]
-    later = [a for a in anchors if a > a0]
-    a1 = later[0] if later else len(rows)
+    else:
+        a0 = anchors[args.step]
+        later = [a for a in anchors if a > a0]
+        a1 = later[0] if later else len(rows)
     step = rows[a0:a1]
     t0 = step[0][1]
     busy_end = t0
