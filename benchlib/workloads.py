@@ -243,11 +243,18 @@ def build(args, S, shard, torch, group, device, dev_sync, world, rank):
             ev.multiply(x, y, work)
             ev.relinearize_inplace(work, keys)
             ev.mod_switch_to_next_inplace(work)
+    elif world == 1 and (dp is None or dp.comm is None):
+        x.set_scale(float(primes[K - 1]) * 2.0 ** 10)
+        holder["work"] = work
+
+        def step():
+            ev.rotate_vector(x, 1, keys, work)   # one rank: nothing to split - the out-of-place rotation reads the resident batch
+            ev.rescale_to_next_inplace(work)
     else:
         rot_scale = float(primes[K - 1]) * 2.0 ** 10
 
         def step():
-            wk = x.copy()                    # device-to-device copy of the resident batch (the rotation works in place)
+            wk = x.copy()                    # device-to-device copy of the resident batch (the digit-parallel rotation works in place)
             wk.set_scale(rot_scale)
             dp.rotate_vector_inplace(wk, 1, keys)
             ev.rescale_to_next_inplace(wk)

@@ -279,7 +279,10 @@ SHL_FUNC Evaluator_Destroy(void *thisptr);
 /* Work of the evaluator is enqueued on `hip_stream` (NULL = the NULL stream), blocking or hipStreamNonBlocking alike.  Device
  * memory recycled through the library's pool is ordered across streams (an event wait when a block changes stream), so
  * several evaluators may run on different streams concurrently.  The destination copy of the out-of-place forms
- * (destination != encrypted) runs on the same stream as the operation. */
+ * (destination != encrypted) runs on the same stream as the operation.  Three families have no such copy - the result is written
+ * straight into `destination` and `encrypted` is only read: Evaluator_Multiply (CKKS 2 x 2 and BFV), and Evaluator_ApplyGalois /
+ * RotateRows / RotateColumns / RotateVector / ComplexConjugate when the exact Galois key is present (the reference's
+ * "destination = encrypted; op_inplace(destination)", evaluator.h:239-247, 1072-1315, gives the same words). */
 SHL_FUNC Evaluator_SetStream(void *thisptr, void *hip_stream);
 /* library extension: destination := encrypted, ordered on the evaluator's stream (Ciphertext_Set copies on the calling thread's
  * stream); what a pipeline over several evaluators / streams uses to stage its inputs */

@@ -1271,6 +1271,27 @@ class Evaluator:
         N.check(N.lib().Evaluator_RotateVector(self._h, a._h, C.c_int(steps), galois_keys._h, a._h, None))
         return a
 
+    # out-of-place forms: with the exact Galois key present the operand is read where it lies (no copy into the destination)
+    def apply_galois(self, a, galois_elt, galois_keys, destination):
+        N.check(N.lib().Evaluator_ApplyGalois(self._h, a._h, C.c_uint32(galois_elt), galois_keys._h, destination._h, None))
+        return destination
+
+    def rotate_rows(self, a, steps, galois_keys, destination):
+        N.check(N.lib().Evaluator_RotateRows(self._h, a._h, C.c_int(steps), galois_keys._h, destination._h, None))
+        return destination
+
+    def rotate_columns(self, a, galois_keys, destination):
+        N.check(N.lib().Evaluator_RotateColumns(self._h, a._h, galois_keys._h, destination._h, None))
+        return destination
+
+    def rotate_vector(self, a, steps, galois_keys, destination):
+        N.check(N.lib().Evaluator_RotateVector(self._h, a._h, C.c_int(steps), galois_keys._h, destination._h, None))
+        return destination
+
+    def complex_conjugate(self, a, galois_keys, destination):
+        N.check(N.lib().Evaluator_ComplexConjugate(self._h, a._h, galois_keys._h, destination._h, None))
+        return destination
+
     # ---- plaintext operands and many-operand forms
     def _pl(self, fn, a, plain, dest, pool=False):
         d = a if dest is None else dest

@@ -636,7 +636,7 @@ extern "C"
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
         StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
-        as<Evaluator>(thisptr)->apply_galois_inplace(prepare_dest(encrypted, destination), galois_elt, *as<KSwitchKeys>(galoisKeys));
+        as<Evaluator>(thisptr)->apply_galois(*as<Ciphertext>(encrypted), galois_elt, *as<KSwitchKeys>(galoisKeys), *as<Ciphertext>(destination));
         SHL_CATCH
     }
     SHL_FUNC Evaluator_RotateRows(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *destination, void *pool)
@@ -648,7 +648,7 @@ extern "C"
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
         StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
-        as<Evaluator>(thisptr)->rotate_rows_inplace(prepare_dest(encrypted, destination), steps, *as<KSwitchKeys>(galoisKeys));
+        as<Evaluator>(thisptr)->rotate_rows(*as<Ciphertext>(encrypted), steps, *as<KSwitchKeys>(galoisKeys), *as<Ciphertext>(destination));
         SHL_CATCH
     }
     SHL_FUNC Evaluator_RotateColumns(void *thisptr, void *encrypted, void *galois_keys, void *destination, void *pool)
@@ -660,7 +660,7 @@ extern "C"
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
         StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
-        as<Evaluator>(thisptr)->rotate_columns_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(galois_keys));
+        as<Evaluator>(thisptr)->rotate_columns(*as<Ciphertext>(encrypted), *as<KSwitchKeys>(galois_keys), *as<Ciphertext>(destination));
         SHL_CATCH
     }
     SHL_FUNC Evaluator_RotateVector(void *thisptr, void *encrypted, int steps, void *galoisKeys, void *destination, void *pool)
@@ -672,7 +672,7 @@ extern "C"
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
         StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
-        as<Evaluator>(thisptr)->rotate_vector_inplace(prepare_dest(encrypted, destination), steps, *as<KSwitchKeys>(galoisKeys));
+        as<Evaluator>(thisptr)->rotate_vector(*as<Ciphertext>(encrypted), steps, *as<KSwitchKeys>(galoisKeys), *as<Ciphertext>(destination));
         SHL_CATCH
     }
     SHL_FUNC Evaluator_ComplexConjugate(void *thisptr, void *encrypted, void *galoisKeys, void *destination, void *pool)
@@ -684,7 +684,7 @@ extern "C"
         IfNullRet(destination, SHL_E_POINTER);
         SHL_TRY
         StreamScope stream_scope(as<Evaluator>(thisptr)->stream());
-        as<Evaluator>(thisptr)->complex_conjugate_inplace(prepare_dest(encrypted, destination), *as<KSwitchKeys>(galoisKeys));
+        as<Evaluator>(thisptr)->complex_conjugate(*as<Ciphertext>(encrypted), *as<KSwitchKeys>(galoisKeys), *as<Ciphertext>(destination));
         SHL_CATCH
     }
     SHL_FUNC Evaluator_ContextUsingKeyswitching(void *thisptr, bool *using_keyswitching)

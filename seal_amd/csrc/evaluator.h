@@ -241,6 +241,13 @@ namespace sealhip
         void exponentiate_inplace(Ciphertext &encrypted, uint64_t exponent, const KSwitchKeys &relin_keys) const;
         void transform_from_ntt_inplace(Ciphertext &encrypted_ntt) const;
         void apply_galois_inplace(Ciphertext &encrypted, uint32_t galois_elt, const KSwitchKeys &galois_keys) const;
+        // out-of-place forms (evaluator.h:1072-1315 of the reference): with the exact Galois key present `encrypted` is read where
+        // it lies - no copy into the destination first
+        void apply_galois(const Ciphertext &encrypted, uint32_t galois_elt, const KSwitchKeys &galois_keys, Ciphertext &destination) const;
+        void rotate_rows(const Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys, Ciphertext &destination) const;
+        void rotate_columns(const Ciphertext &encrypted, const KSwitchKeys &galois_keys, Ciphertext &destination) const;
+        void rotate_vector(const Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys, Ciphertext &destination) const;
+        void complex_conjugate(const Ciphertext &encrypted, const KSwitchKeys &galois_keys, Ciphertext &destination) const;
         void rotate_rows_inplace(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
         void rotate_columns_inplace(Ciphertext &encrypted, const KSwitchKeys &galois_keys) const;
         void rotate_vector_inplace(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
@@ -348,6 +355,7 @@ namespace sealhip
         void mod_switch_scale_to_next(Ciphertext &encrypted) const;
         void mod_switch_drop_to_next(Ciphertext &encrypted) const;
         void rotate_internal(Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys) const;
+        void rotate_internal(const Ciphertext &encrypted, int steps, const KSwitchKeys &galois_keys, Ciphertext &destination) const;
         void conjugate_internal(Ciphertext &encrypted, const KSwitchKeys &galois_keys) const;
         void throw_if_transparent(const Ciphertext &ct) const;
         void switch_key_exchange_finish(Ciphertext &encrypted, uint64_t *acc, Comm &comm, KsExchange how) const;

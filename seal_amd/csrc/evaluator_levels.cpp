@@ -267,7 +267,18 @@ namespace sealhip
     // ---- Galois automorphisms and rotations (evaluator.cpp:2384-2559, evaluator.h:1072-1375)
     void Evaluator::apply_galois_inplace(Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys) const
     {
+        apply_galois(e, galois_elt, galois_keys, e);
+    }
+    // evaluator.h:1072-1087 (apply_galois): destination = encrypted; apply_galois_inplace(destination).  The permuted polynomials go
+    // into a new slab either way, so the out-of-place form reads `encrypted` where it lies: no copy of the operand
+    void Evaluator::apply_galois(const Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys, Ciphertext &dest) const
+    {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
+        if (&dest != &e && (&dest.context() != &context_ || dest.batch() != e.batch()))
+        {
+            dest = e; // a destination of another shape: the reference's two steps
+            return apply_galois(dest, galois_elt, galois_keys, dest);
+        }
         check_valid(e, "encrypted");
         if (galois_keys.context() != &context_)
             throw std::invalid_argument("galois_keys is not valid for encryption parameters");
@@ -309,11 +320,68 @@ namespace sealhip
             DevicePool::global().free_words(out);
             throw;
         }
-        e.adopt(&lvl, 2, out, words);
-        switch_key_inplace(e, perm.p, galois_keys, galois_index(galois_elt));
-        throw_if_transparent(e);
+        if (&dest != &e)
+        {
+            dest.is_ntt_form() = e.is_ntt_form();
+            dest.scale() = e.scale();
+            dest.correction_factor() = e.correction_factor();
+        }
+        dest.adopt(&lvl, 2, out, words);
+        switch_key_inplace(dest, perm.p, galois_keys, galois_index(galois_elt));
+        throw_if_transparent(dest);
     }
 
+    // out-of-place forms (evaluator.h:1130-1315: destination = encrypted; *_inplace(destination)): with the exact key present the
+    // operand is read where it lies; the NAF fallback copies first like the reference
+    void Evaluator::rotate_internal(const Ciphertext &e, int steps, const KSwitchKeys &galois_keys, Ciphertext &dest) const
+    {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
+        if (&dest == &e)
+            return rotate_internal(dest, steps, galois_keys);
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (!context_.using_batching())
+            throw std::logic_error("encryption parameters do not support batching");
+        if (galois_keys.context() != &context_)
+            throw std::invalid_argument("galois_keys is not valid for encryption parameters");
+        const uint32_t elt = steps ? galois_elt_from_step(steps) : 0;
+        if (steps && galois_keys.has_key(galois_index(elt)))
+            return apply_galois(e, elt, galois_keys, dest);
+        dest = e;
+        rotate_internal(dest, steps, galois_keys);
+    }
+    void Evaluator::rotate_rows(const Ciphertext &e, int steps, const KSwitchKeys &gk, Ciphertext &dest) const
+    {
+        if (context_.scheme() != Scheme::bfv && context_.scheme() != Scheme::bgv)
+            throw std::logic_error("unsupported scheme");
+        rotate_internal(e, steps, gk, dest);
+    }
+    void Evaluator::rotate_vector(const Ciphertext &e, int steps, const KSwitchKeys &gk, Ciphertext &dest) const
+    {
+        if (context_.scheme() != Scheme::ckks)
+            throw std::logic_error("unsupported scheme");
+        rotate_internal(e, steps, gk, dest);
+    }
+    void Evaluator::rotate_columns(const Ciphertext &e, const KSwitchKeys &gk, Ciphertext &dest) const
+    {
+        if (context_.scheme() != Scheme::bfv && context_.scheme() != Scheme::bgv)
+            throw std::logic_error("unsupported scheme");
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (!context_.using_batching())
+            throw std::logic_error("encryption parameters do not support batching");
+        apply_galois(e, galois_elt_from_step(0), gk, dest);
+    }
+    void Evaluator::complex_conjugate(const Ciphertext &e, const KSwitchKeys &gk, Ciphertext &dest) const
+    {
+        if (context_.scheme() != Scheme::ckks)
+            throw std::logic_error("unsupported scheme");
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (!context_.using_batching())
+            throw std::logic_error("encryption parameters do not support batching");
+        apply_galois(e, galois_elt_from_step(0), gk, dest);
+    }
     void Evaluator::rotate_internal(Ciphertext &e, int steps, const KSwitchKeys &galois_keys) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)

@@ -125,6 +125,8 @@ class DigitParallel:
         """size 3 -> 2 (Evaluator::relinearize_inplace, evaluator.cpp:1144-1199)"""
         if self.comm is not None:
             return self.ev.relinearize_inplace_dp(ct, relin_keys, self.comm, self.exchange)
+        if self.world == 1:   # nothing to split: the single-GPU key switch (no exchange buffer, no host synchronisation)
+            return self.ev.relinearize_inplace(ct, relin_keys)
         first, count = self.digit_range(ct.coeff_modulus_size())
         acc = self._buffer(self.ev.switch_key_acc_words(ct))
         self.ev.relinearize_partial(ct, relin_keys, first, count, acc.data_ptr())
@@ -136,6 +138,8 @@ class DigitParallel:
         """Evaluator::apply_galois_inplace (evaluator.cpp:2384-2502) on a size-2 ciphertext"""
         if self.comm is not None:
             return self.ev.apply_galois_inplace_dp(ct, galois_elt, galois_keys, self.comm, self.exchange)
+        if self.world == 1:
+            return self.ev.apply_galois_inplace(ct, galois_elt, galois_keys)
         first, count = self.digit_range(ct.coeff_modulus_size())
         acc = self._buffer(self.ev.switch_key_acc_words(ct))
         self.ev.apply_galois_partial(ct, galois_elt, galois_keys, first, count, acc.data_ptr())

@@ -111,9 +111,18 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
         cur = nxt
 
     for s in steps:
+        # out of place first (evaluator.h:1246: destination = encrypted; rotate_vector_inplace(destination) - here the operand is
+        # read where it lies): the destination gets the rotated words and the operand's metadata, the operand keeps its words
+        e = o.galois_elt_from_step(s)
+        dst = S.Ciphertext(d.ctx, batch=batch)
+        assert d.ev.rotate_vector(cx, s, d.glk, dst) is dst
+        assert dst.size() == 2 and dst.is_ntt_form() and dst.scale() == cx.scale() and dst.coeff_modulus_size() == cx.coeff_modulus_size()
+        got, kept = d.out(dst), d.out(cx)
+        for b in range(batch):
+            _eq(got[b], o.apply_galois(cur[b], e), "rotate_vector(%d) out of place, item %d" % (s, b))
+            _eq(kept[b], cur[b], "the operand of an out-of-place rotation, item %d" % b)
         d.ev.rotate_vector_inplace(cx, s, d.glk)  # evaluator.h:1209
         nxt = d.out(cx)
-        e = o.galois_elt_from_step(s)
         for b in range(batch):
             _eq(nxt[b], o.apply_galois(cur[b], e), "rotate_vector(%d) item %d" % (s, b))
         cur = nxt
@@ -344,6 +353,22 @@ def case_bfv_pipeline(n, primes, t, batch=2, seed=4):
     for b in range(batch):
         _eq(nxt[b], o.relinearize(cur[b]), "bfv relinearize item %d" % b)
     cur = nxt
+
+    # out of place: the destination (here one that held something else) gets the result, the operand keeps its words
+    dst = cx.copy()
+    d.ev.rotate_rows(cx, 1, d.glk, dst)
+    got, kept = d.out(dst), d.out(cx)
+    for b in range(batch):
+        _eq(got[b], o.apply_galois(cur[b], elts[0]), "rotate_rows(1) out of place, item %d" % b)
+        _eq(kept[b], cur[b], "the operand of an out-of-place rotation, item %d" % b)
+    d.ev.rotate_columns(cx, d.glk, dst)
+    got = d.out(dst)
+    for b in range(batch):
+        _eq(got[b], o.apply_galois(cur[b], elts[1]), "rotate_columns out of place, item %d" % b)
+    d.ev.apply_galois(cx, elts[0], d.glk, dst)
+    got = d.out(dst)
+    for b in range(batch):
+        _eq(got[b], o.apply_galois(cur[b], elts[0]), "apply_galois out of place, item %d" % b)
 
     d.ev.rotate_rows_inplace(cx, 1, d.glk)
     nxt = d.out(cx)
