@@ -24,14 +24,18 @@ def cpu_baseline(workload, scheme, n, primes, t_plain, args):
             if pipeline == "rotate":
                 ref.keygen_galois_steps([1])
             reps = args.cpu_reps
-            secs = ref.time_pipeline(pipeline, logical, reps)
-            out = dict(value=round(logical * reps / secs, 3), unit="ciphertexts/s", cores=logical, kind="reference",
+            # one thread per logical CPU and, where that differs, one per physical core: the host's BEST rate is the baseline
+            # (memory-bound NTTs often lose with SMT siblings: 32 vs 63 ct/s on a 128-core / 256-thread box), both runs are listed
+            runs = []
+            for threads in sorted({logical, phys}, reverse=True):
+                secs = ref.time_pipeline(pipeline, threads, reps)
+                runs.append(dict(value=round(threads * reps / secs, 3), cores=threads))
+            best = max(runs, key=lambda r: r["value"])
+            out = dict(value=best["value"], unit="ciphertexts/s", cores=best["cores"], kind="reference",
                        sample="%d threads x %d ciphertexts each; every thread builds its inputs, runs one untimed pass, waits at a "
                               "start barrier; wall time from the barrier to the last thread's finish; per-thread "
-                              "MemoryPoolHandle::New(); seal::Evaluator, HEXL off, same parameters" % (logical, reps))
-            if phys != logical:
-                secs_p = ref.time_pipeline(pipeline, phys, reps)
-                out["physical_cores_run"] = dict(value=round(phys * reps / secs_p, 3), cores=phys)
+                              "MemoryPoolHandle::New(); seal::Evaluator, HEXL off, same parameters" % (best["cores"], reps),
+                       runs=runs)
             one = ref.time_pipeline(pipeline, 1, 2)
             out["single_thread_value"] = round(2 / one, 3)
             return out
