@@ -83,6 +83,33 @@ def main():
         assert np.array_equal(got[i], o2.apply_galois(x2[i], e1)), "digit-parallel rotate item %d (rank %d)" % (i, rank)
     print("DIGIT_PARALLEL_OK rank=%d digits=[%d,%d)" % (rank, first, first + cnt), flush=True)
     dist.barrier()
+
+    # ---- the same at a two-pass size (BASELINE configs[4]'s shape: rotate + rescale): `*Finish` leaves the mod-down pending and the
+    #      rescale folds both divisions on every rank (sealhip.h section 1b); the all-reduce buffer is reused by the next key switch
+    n2, bits2 = 8192, [50, 40, 40, 60]
+    primes2 = coeff_modulus_create(n2, bits2)
+    K2 = len(primes2) - 1
+    probe = Oracle("ckks", n2, primes2)
+    e2 = probe.galois_elt_from_step(1)
+    o3 = Oracle("ckks", n2, primes2, galois_elts=[e2])
+    d3 = DeviceSide("ckks", n2, primes2)
+    dp3 = shard.DigitParallel(d3.ev, torch, dist, torch.device("cpu"))
+    f3, c3n = dp3.digit_range(K2)
+    glk3 = S.GaloisKeys(d3.ctx)
+    glk3.set_key_digits(S.GaloisKeys.get_index(e2), f3, o3.galois_key(e2)[f3:f3 + c3n])
+    rng3 = np.random.default_rng(0xC4)
+    sc = float(primes2[K2 - 1]) * 2.0 ** 10
+    folded0 = S.tail_stats()[0]
+    for rnd in range(2):
+        xr = [rand_ct(rng3, primes2, K2, n2)]
+        cr = d3.ct(xr, scale=sc)
+        dp3.rotate_vector_inplace(cr, 1, glk3)
+        d3.ev.rescale_to_next_inplace(cr)
+        assert np.array_equal(d3.out(cr)[0], o3.rescale(o3.apply_galois(xr[0], e2))), "digit-parallel rotate + rescale, round %d (rank %d)" % (rnd, rank)
+    if not os.environ.get("SEALHIP_KS_EAGER_TAIL"):
+        assert S.tail_stats()[0] - folded0 == 2, "the digit-parallel finish did not leave its tail to the rescale"
+    print("DIGIT_PARALLEL_FOLDED_OK rank=%d" % rank, flush=True)
+    dist.barrier()
     dist.destroy_process_group()
 
 

@@ -47,6 +47,8 @@ def test_world_size_2_gloo(emu):
     # digit-parallel key switching: ranks 0 and 1 served digits [0,2) and [2,3) of K = 3 and both match the oracle
     assert "DIGIT_PARALLEL_OK rank=0 digits=[0,2)" in outs[0], outs[0]
     assert "DIGIT_PARALLEL_OK rank=1 digits=[2,3)" in outs[1], outs[1]
+    # ... and at a two-pass size followed by a rescale: both ranks fold the pending mod-down into it
+    assert "DIGIT_PARALLEL_FOLDED_OK rank=0" in outs[0] and "DIGIT_PARALLEL_FOLDED_OK rank=1" in outs[1], outs[0] + outs[1]
 
 
 @pytest.mark.parametrize("workload", ["headline", "bfv_c4", "rotate_c5"])
