@@ -555,7 +555,8 @@ SHL_FUNC SealHip_InstallAbortTrace(const char *path);
  *                                    device kernels (same distribution and, for a seeded generator, the same words)
  *   SEALHIP_ABORT_TRACE=<file>       SealHip_InstallAbortTrace(<file>) when the library is loaded (Diagnostics, above) */
 /* Deferred key-switch tails.  For CKKS and BFV at 2^13 <= N <= 2^16, Evaluator_Relinearize / ApplyGalois / RotateVector / RotateRows /
- * RotateColumns / ComplexConjugate return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext
+ * RotateColumns / ComplexConjugate (and, CKKS, the digit-parallel Evaluator_RelinearizeFinish / ApplyGaloisFinish and the *DigitParallel
+ * forms with the all-reduce exchange) return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext
  * object keeps the key-switch sums next to its two polynomials.  Whatever needs the words next completes it first -
  * every Evaluator_* call on the object, Ciphertext_CopyToHost / Save / copies, Decryptor_Decrypt, destroying the evaluator,
  * Evaluator_SetStream, Evaluator_BeginCapture (tails from before the recording) and Evaluator_EndCapture (tails deferred inside

@@ -20,10 +20,11 @@ namespace sealhip
 {
     // A batch of `batch` ciphertexts sharing metadata; slab layout [poly][batch][K][N].
     class Evaluator;
-    // A key-switch tail that has not run yet (Evaluator::switch_key_inplace, CKKS at the two-pass sizes): the two planes of the
-    // ciphertext still hold the addends, `acc` the key-switch sums [batch][2][K+1][N].  Whoever touches the words next completes
-    // it - except rescale_to_next_inplace on the same evaluator, which folds the mod-down and its own division into one pass
-    // (ntt_kernels.h: NttTail2).  Results are the same words either way.
+    // A key-switch tail that has not run yet (Evaluator::switch_key_inplace and the digit-parallel switch_key_finish; CKKS and BFV at
+    // the two-pass sizes): the two planes of the ciphertext still hold the addends, `acc` the key-switch sums [batch][2][K+1][N].
+    // Whoever touches the words next completes it - except, on the same evaluator, CKKS rescale_to_next_inplace and BFV
+    // mod_switch_to_next_inplace, which fold the mod-down and their own division into one pass (ntt_kernels.h: NttTail2;
+    // switch_key_finish_modswitch_bfv).  Results are the same words either way.
     struct LazyTail
     {
         const Evaluator *owner;
