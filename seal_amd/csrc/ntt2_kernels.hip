@@ -1696,6 +1696,56 @@ namespace sealhip
             NttTables tb;
         };
 
+        // a digit's words (residues modulo data prime J, src_q = q_J) as field elements of the target modulus, ready for p1_tile
+        template <bool FP, int D1>
+        __device__ __forceinline__ void ks1_map(const uint64_t (&nxt)[16], typename Field<FP>::elem (&x)[16], uint64_t src_q, const typename Field<FP>::Mod &m)
+        {
+            typedef Field<FP> F;
+            if constexpr (FP)
+            {
+                if (src_q >> 52)
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                    {
+                        x[e] = F::from_any(nxt[e], m); // magnitude < q + 2^32
+                        if constexpr (kLeanKs<D1>)
+                            F::fix(x[e], m); // the lean placement starts from |x| <= q/2
+                    }
+                }
+                else
+                {
+                    // digit below 2^52: exact as a double; one fix() brings it under q_I / 2 - which the lean placement does
+                    // not need when q_J <= 1.13 q_I (p1_tile: the first fix() sits after stage 6, 2.804 B + 4.811 < 8)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = fp_from_u52(nxt[e]);
+                    if (!kLeanKs<D1> || (double)src_q > kLeanEntry * m.q)
+                    {
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            F::fix(x[e], m);
+                    }
+                }
+            }
+            else
+            {
+                if (src_q < 4 * m.q)
+                {
+                    // already inside the butterflies' lazy input range [0, 4 q_I)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = nxt[e];
+                }
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = F::from_any(nxt[e], m);
+                }
+            }
+        }
+
         template <bool FP, int D1, int ICLS = 0>
         __device__ __forceinline__ void ks1_body(const Ks1Args &a, uint64_t *lds, unsigned I, unsigned prime, unsigned b, unsigned cg, unsigned j0, unsigned j1)
         {
@@ -1732,49 +1782,7 @@ namespace sealhip
             {
                 const uint64_t src_q = a.tb.mods[J].q; // digit J is a residue modulo data prime J
                 typename F::elem x[16];
-                if constexpr (FP)
-                {
-                    if (src_q >> 52)
-                    {
-#pragma unroll
-                        for (int e = 0; e < 16; e++)
-                        {
-                            x[e] = F::from_any(nxt[e], m); // magnitude < q + 2^32
-                            if constexpr (kLeanKs<D1>)
-                                F::fix(x[e], m); // the lean placement starts from |x| <= q/2
-                        }
-                    }
-                    else
-                    {
-                        // digit below 2^52: exact as a double; one fix() brings it under q_I / 2 - which the lean placement does
-                        // not need when q_J <= 1.13 q_I (p1_tile: the first fix() sits after stage 6, 2.804 B + 4.811 < 8)
-#pragma unroll
-                        for (int e = 0; e < 16; e++)
-                            x[e] = fp_from_u52(nxt[e]);
-                        if (!kLeanKs<D1> || (double)src_q > kLeanEntry * m.q)
-                        {
-#pragma unroll
-                            for (int e = 0; e < 16; e++)
-                                F::fix(x[e], m);
-                        }
-                    }
-                }
-                else
-                {
-                    if (src_q < 4 * m.q)
-                    {
-                        // already inside the butterflies' lazy input range [0, 4 q_I)
-#pragma unroll
-                        for (int e = 0; e < 16; e++)
-                            x[e] = nxt[e];
-                    }
-                    else
-                    {
-#pragma unroll
-                        for (int e = 0; e < 16; e++)
-                            x[e] = F::from_any(nxt[e], m);
-                    }
-                }
+                ks1_map<FP, D1>(nxt, x, src_q, m);
                 unsigned Jn = J + 1;
                 if (Jn == Jskip)
                     Jn++;
@@ -1810,6 +1818,91 @@ namespace sealhip
                 ks1_body<FP, D1>(a, lds, I, prime, b, cg, j0, j1);
             else
                 with_int_class(a.tb, prime, [&](auto ic) { ks1_body<FP, D1, decltype(ic)::value>(a, lds, I, prime, b, cg, j0, j1); });
+        }
+
+        // The same pass with the loops exchanged (round 4): one workgroup = (column tile cg, DIGIT J, batch item), holding the digit's
+        // tile in registers and looping over the target moduli of its class.  Every digit tile is then fetched by two workgroups (one
+        // per arithmetic class) instead of sixteen - in the order above the sixteen targets of a tile meet in an XCD's L2, and that
+        // traffic, as large as the intermediate itself, was what pass 1 waited for (tools/microbench/ks_flow: pass 1 without its digit
+        // loads 1.5 instead of 2.35 ms per 64 items).  What is reloaded per target instead - modulus constants (scalar) and fifteen
+        // per-thread twiddles with four distinct addresses per wave - is small.  Used when (tiles x digits x batch) fills the chip;
+        // small batches keep the order above, whose in-launch digit groups make the workgroups they need.
+        template <bool FP, int D1>
+#ifndef SEALHIP_KS1T_FP_WAVES
+#define SEALHIP_KS1T_FP_WAVES 2
+#endif
+        __global__ void __launch_bounds__(kThreads, FP ? SEALHIP_KS1T_FP_WAVES : 2) ks1t_kernel(Ks1Args a)
+        {
+            typedef Field<FP> F;
+            typedef Geo<D1> G;
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            const unsigned tid = threadIdx.x;
+            const unsigned ndig = a.j1 - a.j0;
+            const unsigned grp = blockIdx.x; // (b * ndig + dj) * TILES + cg
+            if (grp >= a.batch * ndig * G::TILES)
+                return;
+            const unsigned cg = grp % G::TILES, bj = grp / G::TILES;
+            const unsigned J = a.j0 + bj % ndig, b = bj / ndig;
+            const unsigned c = tid & (G::C - 1), rbl = tid >> G::LC;
+            const uint64_t *in = a.t + (((size_t)b * a.K + J) << G::n) + cg * G::C + c;
+            uint64_t raw[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+            {
+                const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
+                const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+                raw[e] = in[(size_t)R * 256];
+            }
+            const uint64_t src_q = a.tb.mods[J].q; // digit J is a residue modulo data prime J
+            // double-precision targets, digit below 2^52: the words are converted ONCE and kept as doubles (left to the compiler, the
+            // loop-invariant conversion is hoisted next to the integers: 178 VGPRs, two waves per SIMD instead of four)
+            const bool as_doubles = FP && !(src_q >> 52);
+            if (as_doubles)
+            {
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    raw[e] = fp_to_bits(fp_from_u52(raw[e]));
+            }
+#pragma nounroll
+            for (unsigned it = 0; it < a.ntargets; it++)
+            {
+                const unsigned I = SHL_UNIFORM(a.targets[2 * it]), prime = SHL_UNIFORM(a.targets[2 * it + 1]);
+                if (a.skip_diag && I == J)
+                    continue;
+                uint64_t *mid_tr = a.mid + ((((size_t)b * (a.K + 1) + I) * a.K + J) << G::n);
+                auto one = [&](auto ic) {
+                    constexpr int ICLS = decltype(ic)::value;
+                    const typename F::Mod m = F::make_mod(ld_uniform_mod(&a.tb.mods[prime]), ld_uniform_fpd(&a.tb.fpd[prime]));
+                    const typename F::tw_t *tab = tw_table<FP>(a.tb, false, prime);
+                    TwRegs<FP> tw;
+                    p1_load_tw<FP, D1>(tw, tab, tid);
+                    typename F::elem x[16];
+                    if constexpr (FP)
+                    {
+                        if (as_doubles)
+                        {
+#pragma unroll
+                            for (int e = 0; e < 16; e++)
+                                x[e] = fp_from_bits(raw[e]);
+                            if (!kLeanKs<D1> || (double)src_q > kLeanEntry * m.q) // as ks1_map
+                            {
+#pragma unroll
+                                for (int e = 0; e < 16; e++)
+                                    F::fix(x[e], m);
+                            }
+                        }
+                        else
+                            ks1_map<FP, D1>(raw, x, src_q, m);
+                    }
+                    else
+                        ks1_map<FP, D1>(raw, x, src_q, m);
+                    p1_tile<FP, D1, 256, FP && kLeanKs<D1>, ICLS>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                };
+                if constexpr (FP)
+                    one(std::integral_constant<int, 0>());
+                else
+                    with_int_class(a.tb, prime, one);
+            }
         }
 
         // ---------------------------------------------------------------------------------------
@@ -2599,7 +2692,16 @@ namespace sealhip
                 c1.targets = a1.targets + 2 * t0;
                 c1.ntargets = nt;
                 const dim3 g1(((groups + 7) / 8) * nt * 8);
-                if (fp)
+                // digit-resident order (ks1t_kernel) when its grid fills the chip, and for the complete digit range only: a digit
+                // group or a rank's slice keeps the order whose grid does not shrink with the slice.  SEALHIP_KS1_ORDER=0 / 1 forces
+                static const char *order_env = shl_ab_getenv("SEALHIP_KS1_ORDER");
+                const unsigned g1t = batch * (a1.j1 - a1.j0) * G::TILES;
+                const bool digit_resident = order_env ? order_env[0] == '1' : (a1.parts == 1 && g1t >= 4096);
+                if (digit_resident && fp)
+                    hipLaunchKernelGGL((ks1t_kernel<true, D1>), dim3(g1t), dim3(kThreads), l1, st, c1);
+                else if (digit_resident)
+                    hipLaunchKernelGGL((ks1t_kernel<false, D1>), dim3(g1t), dim3(kThreads), l1, st, c1);
+                else if (fp)
                     hipLaunchKernelGGL((ks1_kernel<true, D1>), g1, dim3(kThreads), l1, st, c1);
                 else
                     hipLaunchKernelGGL((ks1_kernel<false, D1>), g1, dim3(kThreads), l1, st, c1);
