@@ -80,6 +80,24 @@ def test_tails_without_the_addend_in_a_subprocess():
     assert "[ks] folded tail\n" in out.stderr and "addend in the sums" not in out.stderr, out.stderr[-1000:]
 
 
+def test_key_switch_digit_resident_order_in_a_subprocess():
+    """SEALHIP_KS1_ORDER=1 (development switch, read once): pass 1 of the fused key switch with the digit's tile resident and the
+    targets in the loop (ks1t_kernel) - the order large batches take on the device (profiles/r04_ks1_order.txt) - at sizes the
+    emulator finishes: CKKS (both arithmetic classes, N = 2^13 and the lean placement of 2^16), BFV, a digit-parallel slice"""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import seal_amd as S; S.load(%r); import parity_cases as P\n"
+            "from oracle import coeff_modulus_create, plain_modulus_batching\n"
+            "P.case_ckks_pipeline(8192, [60, 40, 50, 60], batch=2, steps=(1,), check_transforms=False)\n"
+            "P.case_ckks_pipeline(65536, [60, 50, 50, 60], batch=1, steps=(1,), check_transforms=False)\n"
+            "P.case_bfv_pipeline(8192, coeff_modulus_create(8192, [50, 55, 56]), plain_modulus_batching(8192, 20), batch=1)\n"
+            "P.case_digit_parallel('ckks', 8192, coeff_modulus_create(8192, [50, 40, 60, 50, 50]), parts=3, batch=1)\n"
+            "print('digit-resident ok')\n" % (here, os.path.dirname(here), os.path.join(here, "hipemu", "libsealhip_emu.so")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SEALHIP_KS1_ORDER="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "digit-resident ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_ntt_two_pass_engine_mixed_kernel(emu, monkeypatch):
     """SEALHIP_NTT_NOSPLIT=1: one mixed-back-end launch instead of one launch per class run."""
     monkeypatch.setenv("SEALHIP_NTT_NOSPLIT", "1")
