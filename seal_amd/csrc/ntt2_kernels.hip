@@ -1827,12 +1827,14 @@ namespace sealhip
         // loads 1.5 instead of 2.35 ms per 64 items).  What is reloaded per target instead - modulus constants (scalar) and fifteen
         // per-thread twiddles with four distinct addresses per wave - is small.  Used when (tiles x digits x batch) fills the chip;
         // small batches keep the order above, whose in-launch digit groups make the workgroups they need.
-        template <bool FP, int D1>
-#ifndef SEALHIP_KS1T_FP_WAVES
-#define SEALHIP_KS1T_FP_WAVES 2
-#endif
-        __global__ void __launch_bounds__(kThreads, FP ? SEALHIP_KS1T_FP_WAVES : 2) ks1t_kernel(Ks1Args a)
+        // SMALL (double-precision targets only): every digit of the launch is below 2^52 - the words are converted to doubles once and
+        // the general mapping (from_any, whose component-independent half the compiler hoists out of the target loop: +68 VGPRs
+        // for every wave of a kernel that contains it) is not compiled in: 4 waves per SIMD instead of 3.  The launcher cuts the
+        // digit range into runs of one kind (C5: digit 0, a 60-bit prime, and digits 1..14).
+        template <bool FP, int D1, bool SMALL = false>
+        __global__ void __launch_bounds__(kThreads, 2) ks1t_kernel(Ks1Args a)
         {
+            static_assert(FP || !SMALL, "SMALL is a property of the double-precision launch");
             typedef Field<FP> F;
             typedef Geo<D1> G;
             HIP_DYNAMIC_SHARED(uint64_t, lds)
@@ -1856,7 +1858,7 @@ namespace sealhip
             const uint64_t src_q = a.tb.mods[J].q; // digit J is a residue modulo data prime J
             // double-precision targets, digit below 2^52: the words are converted ONCE and kept as doubles (left to the compiler, the
             // loop-invariant conversion is hoisted next to the integers: 178 VGPRs, two waves per SIMD instead of four)
-            const bool as_doubles = FP && !(src_q >> 52);
+            const bool as_doubles = SMALL || (FP && !(src_q >> 52));
             if (as_doubles)
             {
 #pragma unroll
@@ -1891,7 +1893,7 @@ namespace sealhip
                                     F::fix(x[e], m);
                             }
                         }
-                        else
+                        else if constexpr (!SMALL)
                             ks1_map<FP, D1>(raw, x, src_q, m);
                     }
                     else
@@ -2698,7 +2700,26 @@ namespace sealhip
                 const unsigned g1t = batch * (a1.j1 - a1.j0) * G::TILES;
                 const bool digit_resident = order_env ? order_env[0] == '1' : (a1.parts == 1 && g1t >= 4096);
                 if (digit_resident && fp)
-                    hipLaunchKernelGGL((ks1t_kernel<true, D1>), dim3(g1t), dim3(kThreads), l1, st, c1);
+                {
+                    // runs of digits of one kind: below 2^52 (known on the host as "a double-precision prime": below 2^50) or not
+                    const unsigned char *small = a1.tb.fp_host;
+                    for (unsigned ja = a1.j0; ja < a1.j1;)
+                    {
+                        const bool sm = small && small[ja];
+                        unsigned jb = ja + 1;
+                        while (jb < a1.j1 && (small && small[jb]) == sm)
+                            jb++;
+                        Ks1Args cr = c1;
+                        cr.j0 = ja;
+                        cr.j1 = jb;
+                        const dim3 gr(batch * (jb - ja) * G::TILES);
+                        if (sm)
+                            hipLaunchKernelGGL((ks1t_kernel<true, D1, true>), gr, dim3(kThreads), l1, st, cr);
+                        else
+                            hipLaunchKernelGGL((ks1t_kernel<true, D1, false>), gr, dim3(kThreads), l1, st, cr);
+                        ja = jb;
+                    }
+                }
                 else if (digit_resident)
                     hipLaunchKernelGGL((ks1t_kernel<false, D1>), dim3(g1t), dim3(kThreads), l1, st, c1);
                 else if (fp)
