@@ -1077,7 +1077,29 @@ namespace sealhip
         // step (4): dyadic ciphertext product in both bases (evaluator.cpp:497-541)
         Scratch d_q(dest * B * K * N), d_b(dest * B * nBsk * N);
         PlaneGeom gq{ n_log, K, (unsigned)B }, gb{ n_log, nBsk, (unsigned)B };
-        if (s1 == 2 && s2 == 2)
+        // Two-pass sizes, 2 x 2: steps (4) and (5) are ONE pair of passes per base - the inverse transform's first pass forms the
+        // product from the four operand polynomials as it loads them (NttBatch::prod_x), so the product is never stored in NTT form
+        // and read back: 7 plane crossings instead of 13 for the pair.  SEALHIP_BFV_NO_PRODUCT_SOURCE=1 (development builds): separate
+        static const bool product_source_ok = !shl_ab_getenv("SEALHIP_BFV_NO_PRODUCT_SOURCE");
+        const bool product_source = product_source_ok && s1 == 2 && s2 == 2 && ntt2_supports(context_.log_n());
+        if (product_source)
+        {
+            NttBatch iq = plain_batch(d_q.p, (size_t)K * N, K, (unsigned)(3 * B), 0);
+            iq.prod_x = x_q.p;
+            iq.prod_y = yq;
+            iq.prod_batch = (unsigned)B;
+            iq.src_outer_stride = (size_t)K * N;
+            ck(ntt_inverse(tb, iq, 0, stream_), "bfv tensor + intt q");
+            NttBatch ibp = plain_batch(d_b.p, (size_t)nBsk * N, nBsk, (unsigned)(3 * B), 0);
+            ibp.comp_prime = lv.bsk_prime;
+            ibp.cls_hint = 0;
+            ibp.prod_x = x_b.p;
+            ibp.prod_y = yb;
+            ibp.prod_batch = (unsigned)B;
+            ibp.src_outer_stride = (size_t)nBsk * N;
+            ck(ntt_inverse(tb, ibp, 0, stream_), "bfv tensor + intt Bsk");
+        }
+        else if (s1 == 2 && s2 == 2)
         {
             // the common product: four loads, three reductions per coefficient (the general kernel: eight and four); the transforms
             // around it leave canonical words, primes below 2^50 take the double-precision products, the 61-bit auxiliary base does not
@@ -1091,11 +1113,14 @@ namespace sealhip
         }
 
         // step (5): back to coefficient form
-        ck(ntt_inverse(tb, plain_batch(d_q.p, (size_t)K * N, K, (unsigned)(dest * B), 0), 0, stream_), "bfv intt q");
-        NttBatch ib = plain_batch(d_b.p, (size_t)nBsk * N, nBsk, (unsigned)(dest * B), 0);
-        ib.comp_prime = lv.bsk_prime;
-        ib.cls_hint = 0;
-        ck(ntt_inverse(tb, ib, 0, stream_), "bfv intt Bsk");
+        if (!product_source)
+        {
+            ck(ntt_inverse(tb, plain_batch(d_q.p, (size_t)K * N, K, (unsigned)(dest * B), 0), 0, stream_), "bfv intt q");
+            NttBatch ib = plain_batch(d_b.p, (size_t)nBsk * N, nBsk, (unsigned)(dest * B), 0);
+            ib.comp_prime = lv.bsk_prime;
+            ib.cls_hint = 0;
+            ck(ntt_inverse(tb, ib, 0, stream_), "bfv intt Bsk");
+        }
 
         // steps (6)-(8)
         size_t words = dest * B * K * N;

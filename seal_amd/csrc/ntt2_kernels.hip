@@ -1153,6 +1153,9 @@ namespace sealhip
             unsigned nouter; // used by the single-launch kernels, whose workgroups loop over outer items
             int lazy;
             uint64_t out_add; // NttBatch::out_add
+            // NttBatch::prod_x: the input is the 2 x 2 tensor product of two size-2 operands, formed while it is loaded (two-pass kernels)
+            const uint64_t *prod_x, *prod_y;
+            unsigned prod_batch, prod_outer0; // items per polynomial; outer index of this launch's first item
             NttTables t;
         };
 
@@ -1177,7 +1180,32 @@ namespace sealhip
             const typename F::tw_t *tab = tw_table<FP>(a.t, true, prime);
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             uint64_t raw[16];
-            load_rows(raw, lds_wave, a.src + (size_t)outer * a.src_outer_stride + ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8), tid);
+            const size_t rows = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+            if (a.prod_x)
+            {
+                // the dyadic ciphertext product (evaluator.cpp:497-541, sizes 2 x 2) formed here instead of being stored by one kernel
+                // and read back by this one: polynomial p of the result is x0 y0, x0 y1 + x1 y0 or x1 y1 of item b
+                const unsigned go = outer + a.prod_outer0, pp = go / a.prod_batch, b = go - pp * a.prod_batch;
+                const size_t plane = (size_t)a.prod_batch * a.src_outer_stride, off = (size_t)b * a.src_outer_stride + rows;
+                const ModDesc md = ld_uniform_mod(&a.t.mods[prime]);
+                uint64_t rb[16];
+                load_rows(raw, lds_wave, a.prod_x + (pp == 2 ? plane : 0) + off, tid);
+                load_rows(rb, lds_wave, a.prod_y + (pp == 0 ? 0 : plane) + off, tid);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    raw[e] = mul_mod(raw[e], rb[e], md);
+                if (pp == 1)
+                {
+                    uint64_t rc[16];
+                    load_rows(rc, lds_wave, a.prod_x + plane + off, tid);
+                    load_rows(rb, lds_wave, a.prod_y + off, tid);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        raw[e] = add_mod(raw[e], mul_mod(rc[e], rb[e], md), md.q);
+                }
+            }
+            else
+                load_rows(raw, lds_wave, a.src + (size_t)outer * a.src_outer_stride + rows, tid);
             typename F::elem x[16];
 #pragma unroll
             for (int e = 0; e < 16; e++)
@@ -2595,7 +2623,7 @@ namespace sealhip
             if constexpr (D1 == 5 || D1 == 6)
             {
                 static const bool fused_ok = !shl_ab_getenv("SEALHIP_NTT_NOFUSED");
-                if (fused_ok)
+                if (fused_ok && !a.prod_x) // (the product source is a feature of the two-pass kernels)
                 {
                     static bool raised = false;
                     if (!raised)
@@ -2850,12 +2878,21 @@ namespace sealhip
         if (b.out_add && out_lazy)
             return hipErrorInvalidValue;
         a.out_add = b.out_add;
+        a.prod_x = b.prod_x;
+        a.prod_y = b.prod_y;
+        a.prod_batch = b.prod_batch;
+        a.prod_outer0 = 0;
+        if (b.prod_x && (!b.prod_y || !b.prod_batch || b.nouter != 3 * b.prod_batch || !b.src_outer_stride))
+            return hipErrorInvalidValue;
+        if (b.prod_x)
+            a.src_outer_stride = b.src_outer_stride;
         a.t = t;
         const unsigned zmax = 65535;
         for (unsigned z0 = 0; z0 < b.nouter; z0 += zmax)
         {
             unsigned nz = b.nouter - z0 < zmax ? b.nouter - z0 : zmax;
             InvArgs az = a;
+            az.prod_outer0 = z0;
             az.data = a.data + (size_t)z0 * a.outer_stride;
             az.src = a.src + (size_t)z0 * a.src_outer_stride;
             az.mid = a.mid + (((size_t)z0 * a.ncomp) << t.log_n);

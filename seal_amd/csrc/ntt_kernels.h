@@ -104,6 +104,12 @@ namespace sealhip
         // (v + out_add) mod q.  Used on the single component a rounding division is about to drop, so that the "+ q/2" of the
         // rounding is added once per coefficient instead of once per target modulus (NttTail2::halves_added).
         uint64_t out_add = 0;
+        // Inverse transforms of the two-pass engine: the input is the 2 x 2 tensor product of two size-2 operands, formed while it is
+        // loaded (evaluator.cpp:497-541 followed by 543-547: the product is never stored in NTT form).  prod_x / prod_y = the
+        // operands [2][prod_batch][ncomp][N] (canonical, item stride src_outer_stride), nouter = 3 * prod_batch: outer item
+        // p * prod_batch + b is polynomial p of item b - x0 y0, x0 y1 + x1 y0, x1 y1.  `src` is not used.
+        const uint64_t *prod_x = nullptr, *prod_y = nullptr;
+        unsigned prod_batch = 0;
         // Two-pass engine: what the HOST knows about the arithmetic class of the components when they are named through comp_prime
         // (the launcher reads the class of prime_first + comp itself, a device table it cannot): -1 unknown - the launch carries both
         // back ends and guards every integer butterfly -, 0 every prime on the integer back end (single-class kernels, the

@@ -685,8 +685,8 @@ namespace sealhip
             Scratch mid(((size_t)b.nouter * b.ncomp) << t.log_n);
             return ntt2_inverse(t, b, out_lazy, mid.p, stream);
         }
-        if (b.src || b.out_add)
-            return hipErrorInvalidValue; // out-of-place input and out_add are features of the two-pass engine only
+        if (b.src || b.out_add || b.prod_x)
+            return hipErrorInvalidValue; // out-of-place input, out_add and the product source are features of the two-pass engine only
         return run(t, b, out_lazy, true, stream);
     }
 } // namespace sealhip
