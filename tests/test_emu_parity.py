@@ -83,15 +83,19 @@ def test_tails_without_the_addend_in_a_subprocess():
 def test_key_switch_digit_resident_order_in_a_subprocess():
     """SEALHIP_KS1_ORDER=1 (development switch, read once): pass 1 of the fused key switch with the digit's tile resident and the
     targets in the loop (ks1t_kernel) - the order large batches take on the device (profiles/r04_ks1_order.txt) - at sizes the
-    emulator finishes: CKKS (both arithmetic classes, N = 2^13 and the lean placement of 2^16), BFV, a digit-parallel slice"""
+    emulator finishes: CKKS (both arithmetic classes, every two-pass size, runs of small and large digits in either order), BFV (also
+    N = 2^15, the size of BASELINE configs[3], where the tensor product is formed inside the two-pass inverse), a digit-parallel slice"""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import seal_amd as S; S.load(%r); import parity_cases as P\n"
             "from oracle import coeff_modulus_create, plain_modulus_batching\n"
             "P.case_ckks_pipeline(8192, [60, 40, 50, 60], batch=2, steps=(1,), check_transforms=False)\n"
+            "P.case_ckks_pipeline(16384, [60, 45, 50, 60], batch=1, steps=(1,), check_transforms=False)\n"
+            "P.case_ckks_pipeline(32768, [50, 60, 50, 60], batch=1, steps=(1,), check_transforms=False)\n"
             "P.case_ckks_pipeline(65536, [60, 50, 50, 60], batch=1, steps=(1,), check_transforms=False)\n"
             "P.case_bfv_pipeline(8192, coeff_modulus_create(8192, [50, 55, 56]), plain_modulus_batching(8192, 20), batch=1)\n"
+            "P.case_bfv_pipeline(32768, coeff_modulus_create(32768, [55, 55, 56]), plain_modulus_batching(32768, 20), batch=1)\n"
             "P.case_digit_parallel('ckks', 8192, coeff_modulus_create(8192, [50, 40, 60, 50, 50]), parts=3, batch=1)\n"
             "print('digit-resident ok')\n" % (here, os.path.dirname(here), os.path.join(here, "hipemu", "libsealhip_emu.so")))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SEALHIP_KS1_ORDER="1"), capture_output=True, text=True, timeout=900)
