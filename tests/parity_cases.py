@@ -121,6 +121,13 @@ def case_ckks_pipeline(n, bits, batch=2, steps=(1,), seed=3, check_transforms=Tr
         for b in range(batch):
             _eq(got[b], o.apply_galois(cur[b], e), "rotate_vector(%d) out of place, item %d" % (s, b))
             _eq(kept[b], cur[b], "the operand of an out-of-place rotation, item %d" % b)
+        # a destination of another batch size takes the reference's two steps (copy, then in place) and its shape follows the operand
+        other = S.Ciphertext(d.ctx, batch=batch + 1)
+        d.ev.rotate_vector(cx, s, d.glk, other)
+        got = d.out(other)
+        assert len(got) == batch
+        for b in range(batch):
+            _eq(got[b], o.apply_galois(cur[b], e), "rotate_vector(%d) into a destination of another batch size, item %d" % (s, b))
         d.ev.rotate_vector_inplace(cx, s, d.glk)  # evaluator.h:1209
         nxt = d.out(cx)
         for b in range(batch):
