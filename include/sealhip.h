@@ -541,7 +541,7 @@ SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
  * fault: its handler on the stack tells that case from a C++ one) and then lets the abort proceed.  Opt-in: signal
  * dispositions belong to the host program. */
 SHL_FUNC SealHip_InstallAbortTrace(const char *path);
-/* Environment.  The product library reads six variables, each exercised by a test; everything else that earlier
+/* Environment.  The product library reads nine variables, each exercised by a test; everything else that earlier
  * rounds could switch at run time (superseded kernels, fork / no-fork of the side streams, ...) only exists in development
  * builds made with -DSEALHIP_AB_SWITCHES (seal_amd/csrc/modarith.h: shl_ab_getenv).
  *   SEALHIP_NO_FP=1                  every prime on the 64-bit integer back end (no exact double-precision arithmetic for
@@ -553,7 +553,20 @@ SHL_FUNC SealHip_InstallAbortTrace(const char *path);
  *                                    the per-workgroup loop at small batches with it
  *   SEALHIP_ENCRYPT_HOST_SAMPLING=1  encryption noise is sampled on the host with the reference's own sampler instead of the
  *                                    device kernels (same distribution and, for a seeded generator, the same words)
- *   SEALHIP_ABORT_TRACE=<file>       SealHip_InstallAbortTrace(<file>) when the library is loaded (Diagnostics, above) */
+ *   SEALHIP_ABORT_TRACE=<file>       SealHip_InstallAbortTrace(<file>) when the library is loaded (Diagnostics, above)
+ *   SEALHIP_KS_CHUNK=<items>         chunk size of a key switch over a large batch (below; 0 = never cut; default: the items
+ *                                    that make 8192 pass-2 workgroups - 32 at N = 2^16 with 16 moduli)
+ *   SEALHIP_KS_LANES=<1..4>          streams the chunks are dealt to (default 2; 1 = one after the other on the evaluator's stream)
+ *   SEALHIP_KS_SCRATCH_CAP_MIB=<n>   upper bound of the key switch's intermediate (default 16384); chunk / lanes shrink to fit */
+/* Chunked key switching (round 5).  switch_key_inplace needs K (K + 1) half-transformed digits per ciphertext between its two
+ * kernels (126 MB at N = 2^16, K = 15).  For a batch of 1.5 chunks or more (2^13 <= N <= 2^16, register-order keys, one digit group) the batch is cut
+ * into chunks dealt round-robin to `lanes` streams forked from and joined to the evaluator's stream: the intermediate held
+ * is lanes x chunk items whatever the batch (the reference holds O(K N) per ciphertext, evaluator.cpp:2561-2867), and one
+ * chunk's pass 2 (bound by vector-ALU issue) shares the chip with the next chunk's inverse transform and pass 1 (bound by the
+ * memory system).  Same words as the unchunked form.  While a graph is recorded the chunks stay on the recording stream.
+ * Counters for tests and bench.py: calls that ran in chunks, chunks issued, the largest intermediate (bytes) any fused key switch
+ * held since the previous query (the query resets it). */
+SHL_FUNC SealHip_KsChunkStats(uint64_t *calls, uint64_t *chunks, uint64_t *scratch_bytes_max);
 /* Deferred key-switch tails.  For CKKS and BFV at 2^13 <= N <= 2^16, Evaluator_Relinearize / ApplyGalois / RotateVector / RotateRows /
  * RotateColumns / ComplexConjugate (and, CKKS, the digit-parallel Evaluator_RelinearizeFinish / ApplyGaloisFinish and the *DigitParallel
  * forms with the all-reduce exchange) return with the mod-down by the special prime (evaluator.cpp:2806-2864) not yet run: the ciphertext

@@ -1558,6 +1558,13 @@ def tail_stats():
     return a.value, b.value, c.value
 
 
+def ks_chunk_stats():
+    """chunked key switching (sealhip.h: SealHip_KsChunkStats): (calls that ran in chunks, chunks issued, largest intermediate in bytes)"""
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    N.check(N.lib().SealHip_KsChunkStats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def device_synchronize():
     N.check(N.lib().shl_device_synchronize())
 

@@ -153,6 +153,15 @@ extern "C"
             *cross_stream_waits = DevicePool::global().cross_stream_waits();
         SHL_CATCH
     }
+    SHL_FUNC SealHip_KsChunkStats(uint64_t *calls, uint64_t *chunks, uint64_t *scratch_bytes_max)
+    {
+        SHL_TRY
+        uint64_t w = 0;
+        ks_chunk_stats(calls, chunks, &w);
+        if (scratch_bytes_max)
+            *scratch_bytes_max = w * 8;
+        SHL_CATCH
+    }
     SHL_FUNC SealHip_TailStats(uint64_t *folded, uint64_t *plain, uint64_t *dropped)
     {
         SHL_TRY

@@ -35,6 +35,8 @@ namespace sealhip
     };
     // process-wide counters (tests, tools): tails folded into a rescale / completed on their own / discarded unrun
     void lazy_tail_stats(uint64_t &folded, uint64_t &plain, uint64_t &dropped);
+    // chunked key switching (evaluator_keyswitch.cpp): calls that ran in chunks, chunks issued, largest intermediate held since the previous query (words)
+    void ks_chunk_stats(uint64_t *calls, uint64_t *chunks, uint64_t *scratch_words_max);
 
     class Ciphertext
     {

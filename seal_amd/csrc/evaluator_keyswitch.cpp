@@ -3,6 +3,100 @@
 
 namespace sealhip
 {
+    namespace
+    {
+        // ---- Chunked, lane-pipelined key switching (round 5; VERDICT r4 "missing" 4 and "weak" 3).
+        // The fused key switch is two kernels per arithmetic class: ks1t writes the K(K+1) half-transformed digits of every
+        // ciphertext (126 MB per C5 ciphertext) - it is bound by the store rate of the memory system - and ks2 reads them back
+        // and multiplies them into the key - it is bound by vector-ALU issue.  Run over the whole batch one after the other they
+        // leave the ALUs idle during the first and the memory system half idle during the second, and the intermediate of the
+        // WHOLE batch is resident (32 GB at batch 256, 258 GB at batch 2048) where the reference's switch_key_inplace holds
+        // O(K N) per ciphertext (evaluator.cpp:2561-2867).  So the batch is cut into chunks that go round-robin to `lanes`
+        // streams, each with its own chunk-sized intermediate: chunk c's ks2 shares the chip with chunk c+1's inverse transform
+        // and ks1t, and the scratch is lanes x chunk items whatever the batch.
+        struct KsPlan
+        {
+            unsigned chunk; // items per chunk
+            unsigned lanes; // streams the chunks are dealt to (1 = everything on the evaluator's stream)
+            unsigned chunks(unsigned batch) const { return (batch + chunk - 1) / chunk; }
+        };
+        unsigned env_unsigned(const char *name, unsigned fallback)
+        {
+            const char *v = std::getenv(name);
+            return v && *v ? (unsigned)std::strtoul(v, nullptr, 10) : fallback;
+        }
+        // words_per_item = (K + 1) K N; wgs_per_item = pass-2 workgroups of one ciphertext ((K + 1) tiles)
+        KsPlan ks_plan(unsigned batch, size_t words_per_item, size_t wgs_per_item, bool may_chunk, bool may_lane)
+        {
+            KsPlan p{ batch, 1 };
+            if (!may_chunk || batch < 2)
+                return p;
+            // a chunk must still fill the chip several times over (pass 2 keeps 512 workgroups resident; the kernels reach
+            // their rate from 18 - 64 C5 ciphertexts on, profiles/r03_ks_batch_sweep.txt): >= 8192 pass-2 workgroups
+            unsigned chunk = (unsigned)((8192 + wgs_per_item - 1) / (wgs_per_item ? wgs_per_item : 1));
+            chunk = env_unsigned("SEALHIP_KS_CHUNK", chunk < 8 ? 8 : chunk);
+            unsigned lanes = env_unsigned("SEALHIP_KS_LANES", 2);
+            if (lanes < 1 || !may_lane)
+                lanes = 1;
+            if (lanes > 4)
+                lanes = 4;
+            if (chunk == 0 || 2 * chunk > batch + chunk / 2) // fewer than ~1.5 chunks: not worth cutting
+                return p;
+            // scratch cap (default 16 GiB): lanes x chunk items of the intermediate
+            const double cap = (double)env_unsigned("SEALHIP_KS_SCRATCH_CAP_MIB", 16384) * 1048576.0;
+            while (chunk > 1 && (double)lanes * chunk * words_per_item * 8.0 > cap)
+            {
+                if (lanes > 2)
+                    lanes--;
+                else
+                    chunk = (chunk + 1) / 2;
+            }
+            p.chunk = chunk;
+            p.lanes = lanes;
+            if (p.chunks(batch) < p.lanes)
+                p.lanes = p.chunks(batch);
+            return p;
+        }
+        // the side streams of the lanes (lane 0 is the evaluator's own stream) and the events that fork / join them
+        struct KsLanes
+        {
+            static constexpr unsigned kSide = 3;
+            hipStream_t stream[kSide] = { nullptr, nullptr, nullptr };
+            hipEvent_t join[kSide] = { nullptr, nullptr, nullptr };
+            hipEvent_t fork = nullptr;
+            unsigned made = 0;
+            bool ensure(unsigned side)
+            {
+                if (!fork && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess)
+                    return false;
+                while (made < side && made < kSide)
+                {
+                    if (hipStreamCreateWithFlags(&stream[made], hipStreamNonBlocking) != hipSuccess ||
+                        hipEventCreateWithFlags(&join[made], hipEventDisableTiming) != hipSuccess)
+                        return false;
+                    made++;
+                }
+                return made >= side;
+            }
+        };
+        KsLanes &ks_lanes()
+        {
+            static thread_local KsLanes l;
+            return l;
+        }
+        std::atomic<uint64_t> g_ks_chunked_calls{ 0 }, g_ks_chunks{ 0 }, g_ks_scratch_words_max{ 0 };
+    } // namespace
+    // (SealHip_KsChunkStats: how often the key switch ran in chunks, how many chunks, the largest intermediate it held since the last query)
+    void ks_chunk_stats(uint64_t *calls, uint64_t *chunks, uint64_t *scratch_words_max)
+    {
+        if (calls)
+            *calls = g_ks_chunked_calls.load();
+        if (chunks)
+            *chunks = g_ks_chunks.load();
+        if (scratch_words_max)
+            *scratch_words_max = g_ks_scratch_words_max.exchange(0); // ... since the previous query
+    }
+
     // ---- relinearize (evaluator.cpp:1144-1199)
     void Evaluator::relinearize_inplace(Ciphertext &e, const KSwitchKeys &relin_keys) const
     {
@@ -148,7 +242,15 @@ namespace sealhip
         const bool read_in_place = !ntt_target && key.register_order;
         Scratch t(read_in_place ? 1 : (size_t)B * K * N);
         const uint64_t *digits = read_in_place ? target : t.p;
-        if (read_in_place)
+        // fused path, large batches: chunks dealt to lanes (above); the inverse transform of the target then runs per chunk
+        // inside its lane
+        const size_t ks_item_words = (size_t)(K + 1) * K * N;
+        const KsPlan plan = key.register_order
+                                ? ks_plan(B, ks_item_words, (size_t)(K + 1) * (N >> 12), split <= 1 && ntt2_supports(context_.log_n()), !capturing_)
+                                : KsPlan{ B, 1 };
+        const bool chunked = plan.chunk < B;
+        const bool inverse_in_lane = chunked && !read_in_place && ntt_target;
+        if (read_in_place || inverse_in_lane)
             ;
         else if (ntt_target && ntt2_supports(context_.log_n()))
         {
@@ -170,7 +272,13 @@ namespace sealhip
             // fused path (ntt2_kernels.hip): the K(K+1) raised digits go through HBM once, between
             // the two passes, and are multiplied into the key inside the second pass
             const KsTargets &kt = ks_targets(K);
-            Scratch mid((size_t)B * (K + 1) * K * N);
+            Scratch mid((size_t)plan.lanes * plan.chunk * ks_item_words);
+            Scratch inv_mid(inverse_in_lane ? (size_t)plan.lanes * plan.chunk * K * N : 1);
+            {
+                uint64_t w = (uint64_t)plan.lanes * plan.chunk * ks_item_words, seen = g_ks_scratch_words_max.load();
+                while (w > seen && !g_ks_scratch_words_max.compare_exchange_weak(seen, w))
+                    ;
+            }
             KsFusedArgs ka{};
             ka.t = digits;
             ka.target_ntt = ntt_target ? target : nullptr; // the I == J shortcut of evaluator.cpp:2682-2685
@@ -194,7 +302,61 @@ namespace sealhip
                 ka.fold_c1 = e.plane(1);
                 ka.fold_pm = klvl.dev.inv_q_last_mod_q;
             }
-            ck(ks_fused(tb, ka, stream_), "ks fused");
+            if (!chunked)
+                ck(ks_fused(tb, ka, stream_), "ks fused");
+            else
+            {
+                // which pass-1 kernel: decided for the whole batch (ntt2_kernels.hip: launch_ks decides from the grid it is given)
+                ka.order1 = (size_t)B * (j1 - j0) * (N >> 12) >= 4096 ? 1 : 0;
+                KsLanes &ln = ks_lanes();
+                unsigned lanes = plan.lanes;
+                if (lanes > 1 && !ln.ensure(lanes - 1))
+                    lanes = 1;
+                ka.no_class_fork = lanes > 1;
+                static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr;
+                if (trace)
+                    std::fprintf(stderr, "[ks] batch %u in chunks of %u on %u lane(s)\n", B, plan.chunk, lanes);
+                if (lanes > 1)
+                {
+                    ck(hipEventRecord(ln.fork, stream_), "ks lanes fork");
+                    for (unsigned l = 1; l < lanes; l++)
+                        ck(hipStreamWaitEvent(ln.stream[l - 1], ln.fork, 0), "ks lanes fork");
+                }
+                const size_t poly_words = (size_t)K * N; // one polynomial of one item in the [batch][K][N] planes
+                unsigned c = 0;
+                for (unsigned b0 = 0; b0 < B; b0 += plan.chunk, c++)
+                {
+                    const unsigned nb = B - b0 < plan.chunk ? B - b0 : plan.chunk;
+                    const unsigned l = c % lanes;
+                    hipStream_t st = l == 0 ? stream_ : ln.stream[l - 1];
+                    if (inverse_in_lane)
+                    {
+                        NttBatch bt = plain_batch(t.p + b0 * poly_words, poly_words, K, nb, 0);
+                        bt.src = target + b0 * poly_words;
+                        bt.src_outer_stride = poly_words;
+                        ck(ntt2_inverse(tb, bt, 0, inv_mid.p + (size_t)l * plan.chunk * poly_words, st), "ks intt target (chunk)");
+                    }
+                    KsFusedArgs kc = ka;
+                    kc.batch = nb;
+                    kc.t = digits + b0 * poly_words;
+                    kc.target_ntt = ka.target_ntt ? ka.target_ntt + b0 * poly_words : nullptr;
+                    kc.mid = mid.p + (size_t)l * plan.chunk * ks_item_words;
+                    kc.acc = acc_out + (size_t)b0 * 2 * (K + 1) * N;
+                    if (fold_addend)
+                    {
+                        kc.fold_c0 = ka.fold_c0 + b0 * poly_words;
+                        kc.fold_c1 = ka.fold_c1 + b0 * poly_words;
+                    }
+                    ck(ks_fused(tb, kc, st), "ks fused (chunk)");
+                }
+                for (unsigned l = 1; l < lanes; l++)
+                {
+                    ck(hipEventRecord(ln.join[l - 1], ln.stream[l - 1]), "ks lanes join");
+                    ck(hipStreamWaitEvent(stream_, ln.join[l - 1], 0), "ks lanes join");
+                }
+                g_ks_chunked_calls++;
+                g_ks_chunks += c;
+            }
         }
         else if (split > 1)
             throw std::invalid_argument("in-launch digit groups need the fused key-switch path");

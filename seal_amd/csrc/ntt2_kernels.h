@@ -46,6 +46,12 @@ namespace sealhip
         // special-prime component is the plain sum either way.
         const uint64_t *fold_c0 = nullptr, *fold_c1 = nullptr;
         const ShoupOp *fold_pm = nullptr;
+        // Callers that cut a batch into chunks (Evaluator::switch_key_partial, round 5) decide these for the WHOLE batch:
+        // order1 = which pass-1 kernel runs (-1: decided from this call's grid, 0: target-resident ks1_kernel, 1: digit-resident
+        // ks1t_kernel); no_class_fork = the two arithmetic classes run one after the other on `stream` (the caller's chunk
+        // streams provide the concurrency) instead of forking the integer class to the launcher's side stream.
+        int order1 = -1;
+        bool no_class_fork = false;
     };
     hipError_t ks_fused(const NttTables &t, const KsFusedArgs &k, hipStream_t stream);
 

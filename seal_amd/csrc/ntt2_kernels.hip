@@ -56,6 +56,20 @@ namespace sealhip
 #ifndef SEALHIP_KS_NT
 #define SEALHIP_KS_NT 31 // headline step 8.82 -> 9.18 k ct/s same-box (+4.0 %); 15: +2.5 %; with the tensor product's loads (32): +2.9 %
 #endif
+        // Wave priorities (round 5 experiment, profiles/r05_ldsdma_setprio.txt): a CU holds two to four workgroups of these kernels in
+        // different phases.  SEALHIP_PRIO = 0 none (default); 1: s_setprio 1 while a wave does arithmetic, 0 while it issues its
+        // loads; 2: the other way round (memory instructions first).
+#ifndef SEALHIP_PRIO
+#define SEALHIP_PRIO 0
+#endif
+        template <int WHEN> // 1 = entering the arithmetic, 2 = entering the load issue
+        __device__ __forceinline__ void prio_phase()
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (SEALHIP_PRIO != 0)
+                __builtin_amdgcn_s_setprio(SEALHIP_PRIO == WHEN ? 1 : 0);
+#endif
+        }
         template <int BIT>
         __device__ __forceinline__ uint64_t mid_ld(const uint64_t *p)
         {
@@ -817,8 +831,10 @@ namespace sealhip
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     x[e] = map_src<FP>(nxt[e], sm, m);
+                prio_phase<2>();
                 if (outer + ostride < a.nouter)
                     fetch(outer + ostride);
+                prio_phase<1>();
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
                 p1_tile<FP, D1, 256, false, ICLS>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
@@ -888,8 +904,10 @@ namespace sealhip
 #pragma unroll
             for (int e = 0; e < 16; e++)
                 x[e] = F::unraw(nxt[e]);
+            prio_phase<2>();
             if (outer + ostride < a.nouter)
                 fetch(outer + ostride);
+            prio_phase<1>();
             if constexpr (HOIST_LDS)
                 p2_tile<FP, D1, false, false, true, true>(x, m, tab, twa, nullptr, lds_wave, hg, tid, &pre_a, &pre_b);
             else if constexpr (HOIST)
@@ -2122,6 +2140,7 @@ namespace sealhip
                 // this component of digit J: N pairs of doubles (double-precision primes) or 2 x N (word, Shoup quotient) pairs
                 const size_t kslab = (size_t)(J - a.key_digit0) * a.key_digit_words + (size_t)koff * N;
                 typename F::key_t kr0[16], kr1[16];
+                prio_phase<2>();
                 if constexpr (FP)
                 {
                     // the key words of this digit and the next digit travel while this digit is transformed
@@ -2146,6 +2165,7 @@ namespace sealhip
                     if (J + 1 < j1)
                         fetch(J + 1);
                 }
+                prio_phase<1>();
                 if (!is_diag)
                 {
                     p2_tile<FP, D1, FP, true, false, !FP, FP && kLeanKs<D1>, ICLS, kP1Out<ICLS, D1>, !FP && SEALHIP_KS2_INT_TWB3>(x, m, tab, twa, twb, lds_wave, hg, tid);
@@ -2681,7 +2701,7 @@ namespace sealhip
         }
 
         template <int D1>
-        hipError_t launch_ks(const Ks1Args &a1, const Ks2Args &a2, unsigned batch, unsigned n_int, hipStream_t s)
+        hipError_t launch_ks(const Ks1Args &a1, const Ks2Args &a2, unsigned batch, unsigned n_int, hipStream_t s, int order1, bool no_class_fork)
         {
             typedef Geo<D1> G;
             if (a1.ntargets == 0)
@@ -2726,7 +2746,7 @@ namespace sealhip
                 // group or a rank's slice keeps the order whose grid does not shrink with the slice.  SEALHIP_KS1_ORDER=0 / 1 forces
                 static const char *order_env = shl_ab_getenv("SEALHIP_KS1_ORDER");
                 const unsigned g1t = batch * (a1.j1 - a1.j0) * G::TILES;
-                const bool digit_resident = order_env ? order_env[0] == '1' : (a1.parts == 1 && g1t >= 4096);
+                const bool digit_resident = order_env ? order_env[0] == '1' : order1 >= 0 ? (order1 == 1 && a1.parts == 1) : (a1.parts == 1 && g1t >= 4096);
                 if (digit_resident && fp)
                 {
                     // runs of digits of one kind: below 2^52 (known on the host as "a double-precision prime": below 2^50) or not
@@ -2772,7 +2792,7 @@ namespace sealhip
             SideStream &ss = side_stream();
             static const bool fork_ok = !shl_ab_getenv("SEALHIP_KS_NOFORK");
             hipError_t e;
-            if (n_int && n_fp && ss.ok && fork_ok)
+            if (n_int && n_fp && ss.ok && fork_ok && !no_class_fork)
             {
                 if ((e = hipEventRecord(ss.fork, s)) != hipSuccess || (e = hipStreamWaitEvent(ss.stream, ss.fork, 0)) != hipSuccess)
                     return e;
@@ -2958,13 +2978,13 @@ namespace sealhip
         switch (t.log_n)
         {
         case 13:
-            return launch_ks<5>(a1, a2, k.batch, k.n_int, stream);
+            return launch_ks<5>(a1, a2, k.batch, k.n_int, stream, k.order1, k.no_class_fork);
         case 14:
-            return launch_ks<6>(a1, a2, k.batch, k.n_int, stream);
+            return launch_ks<6>(a1, a2, k.batch, k.n_int, stream, k.order1, k.no_class_fork);
         case 15:
-            return launch_ks<7>(a1, a2, k.batch, k.n_int, stream);
+            return launch_ks<7>(a1, a2, k.batch, k.n_int, stream, k.order1, k.no_class_fork);
         case 16:
-            return launch_ks<8>(a1, a2, k.batch, k.n_int, stream);
+            return launch_ks<8>(a1, a2, k.batch, k.n_int, stream, k.order1, k.no_class_fork);
         default:
             return hipErrorInvalidValue;
         }

@@ -220,6 +220,91 @@ def _deferred_tails(d, o, xs, ys, primes, K, n, batch, steps, elts):
         assert (folded2, plain2) == (folded1, plain1) and dropped2 - dropped1 == (2 if defers else 0)
 
 
+# ---- chunked key switching (sealhip.h: SealHip_KsChunkStats): the batch cut into chunks dealt to lanes
+class _Env:
+    """set / restore environment variables the library reads per call"""
+
+    def __init__(self, **kv):
+        self.kv, self.saved = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.saved[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def case_ks_chunked(scheme, n, bits_or_primes, batch, chunk, lanes, t=None, seed=5, cap_mib=None):
+    """relinearize (+ rescale, CKKS: the folded tail; + mod_switch, BFV) and a rotation over a batch that the key switch cuts
+    into ceil(batch / chunk) chunks on `lanes` streams - ragged last chunk included - against the reference item by item, and
+    the same words as the unchunked run (evaluator.cpp:2561-2867)."""
+    primes = bits_or_primes if scheme != "ckks" else coeff_modulus_create(n, list(bits_or_primes))
+    K = len(primes) - 1
+    t = t or 0
+    probe = Oracle(scheme, n, primes, t)
+    elt = probe.galois_elt_from_step(1)
+    o = Oracle(scheme, n, primes, t, galois_elts=[elt])
+    d = DeviceSide(scheme, n, primes, t)
+    d.upload_keys(o)
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    env = dict(SEALHIP_KS_SPLIT=1, SEALHIP_KS_CHUNK=chunk, SEALHIP_KS_LANES=lanes)
+    if cap_mib is not None:
+        env["SEALHIP_KS_SCRATCH_CAP_MIB"] = cap_mib
+
+    def run():
+        if scheme == "ckks":
+            sc = float(primes[K - 1]) * 2.0 ** 10
+            a, b = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10)
+            d.ev.multiply_inplace(a, b)
+            d.ev.relinearize_inplace(a, d.rlk)
+            a.set_scale(sc)
+            d.ev.rescale_to_next_inplace(a)          # the folded tail reads the chunks' sums
+            r = d.ct(xs, scale=sc)
+            d.ev.rotate_vector_inplace(r, 1, d.glk)  # completed on its own (plain tail)
+            return d.out(a), d.out(r)
+        a, b = d.ct(xs), d.ct(ys)
+        d.ev.multiply_inplace(a, b)
+        d.ev.relinearize_inplace(a, d.rlk)
+        d.ev.mod_switch_to_next_inplace(a)
+        r = d.ct(xs)
+        d.ev.apply_galois_inplace(r, elt, d.glk)
+        return d.out(a), d.out(r)
+
+    c0, k0, _ = S.ks_chunk_stats()
+    with _Env(**env):
+        got_a, got_r = run()
+    c1, k1, held = S.ks_chunk_stats()
+    nchunks = (batch + chunk - 1) // chunk
+    if cap_mib is None:
+        assert (c1 - c0, k1 - k0) == (2, 2 * nchunks), ("the key switch did not run in chunks", c1 - c0, k1 - k0, nchunks)
+    else:
+        assert c1 - c0 == 2 and k1 - k0 >= 2 * nchunks, (c1 - c0, k1 - k0)
+        assert held <= cap_mib * 1048576, (held, cap_mib)
+    with _Env(SEALHIP_KS_SPLIT=1, SEALHIP_KS_CHUNK=0):
+        ref_a, ref_r = run()
+    assert S.ks_chunk_stats()[0] == c1, "SEALHIP_KS_CHUNK=0 must keep the batch whole"
+    for b in range(batch):
+        _eq(got_a[b], ref_a[b], "chunked vs whole key switch, relinearize, item %d" % b)
+        _eq(got_r[b], ref_r[b], "chunked vs whole key switch, rotation, item %d" % b)
+        if scheme == "ckks":
+            _eq(got_a[b], o.rescale(o.relinearize(o.multiply(xs[b], ys[b]))), "chunked relinearize + rescale, item %d" % b)
+            _eq(got_r[b], o.apply_galois(xs[b], elt), "chunked rotation, item %d" % b)
+        else:
+            _eq(got_a[b], o.mod_switch_to_next(o.relinearize(o.multiply(xs[b], ys[b]))), "chunked relinearize + mod_switch, item %d" % b)
+            _eq(got_r[b], o.apply_galois(xs[b], elt), "chunked apply_galois, item %d" % b)
+
+
 # ---- deferred key-switch tails: who completes them (sealhip.h: SealHip_TailStats)
 def case_deferred_tail_lifecycle(n=8192, bits=(50, 40, 60)):
     """K = 2 (the folded pass has ONE component to produce); a pending tail completed by a second evaluator, by the owner's
@@ -290,7 +375,29 @@ def host_uniform_words(primes, polys, batch, n, seed):
     return out
 
 
-def case_ckks_big_batch(n, bits, batch, check_items, seed=11, rotate=True):
+def _tiled_ciphertext(ctx, host, batch, pid, scale):
+    """a batch of `batch` items whose item b holds host[:, b % unique] (host: [polys][unique][K][n]): the host block is uploaded
+    batch / unique times into the planes, so that a large batch needs neither a large host array nor its generation time"""
+    import ctypes as C
+    from seal_amd import _native as N
+    polys, unique, K, n = host.shape
+    assert batch % unique == 0
+    ct = S.Ciphertext(ctx, batch=batch)
+    ct.resize(pid, polys)
+    ct.set_is_ntt_form(True)
+    ct.set_scale(scale)
+    ptr, words = ct.device_ptr()
+    assert words >= polys * batch * K * n
+    for p in range(polys):
+        block = np.ascontiguousarray(host[p])
+        for r in range(batch // unique):
+            dst = C.c_void_p(ptr + ((p * batch + r * unique) * K * n) * 8)
+            N.check(N.lib().shl_memcpy_h2d(dst, block.ctypes.data_as(C.c_void_p), C.c_uint64(block.nbytes)))
+    return ct
+
+
+def case_ckks_big_batch(n, bits, batch, check_items, seed=11, rotate=True, unique=None):
+    """unique: only that many distinct items are generated; item b repeats item b % unique (see _tiled_ciphertext)"""
     primes = coeff_modulus_create(n, bits)
     L = len(primes)
     K = L - 1
@@ -299,11 +406,25 @@ def case_ckks_big_batch(n, bits, batch, check_items, seed=11, rotate=True):
     o = Oracle("ckks", n, primes, galois_elts=[elt])
     d = DeviceSide("ckks", n, primes)
     d.upload_keys(o)
-    xs = host_uniform_words(primes[:K], 2, batch, n, seed)
-    ys = host_uniform_words(primes[:K], 2, batch, n, seed + 1)
     pid = d.parms_id_for_K(K)
-    cx = S.Ciphertext.from_numpy(d.ctx, xs, pid, True, 2.0 ** 10)
-    cy = S.Ciphertext.from_numpy(d.ctx, ys, pid, True, 2.0 ** 10)
+    if unique:
+        xu = host_uniform_words(primes[:K], 2, unique, n, seed)
+        yu = host_uniform_words(primes[:K], 2, unique, n, seed + 1)
+        cx = _tiled_ciphertext(d.ctx, xu, batch, pid, 2.0 ** 10)
+        cy = _tiled_ciphertext(d.ctx, yu, batch, pid, 2.0 ** 10)
+
+        class _Rep:  # xs[:, b] of the full batch
+            def __init__(self, a):
+                self.a = a
+
+            def __getitem__(self, key):
+                return self.a[:, key[1] % unique]
+        xs, ys = _Rep(xu), _Rep(yu)
+    else:
+        xs = host_uniform_words(primes[:K], 2, batch, n, seed)
+        ys = host_uniform_words(primes[:K], 2, batch, n, seed + 1)
+        cx = S.Ciphertext.from_numpy(d.ctx, xs, pid, True, 2.0 ** 10)
+        cy = S.Ciphertext.from_numpy(d.ctx, ys, pid, True, 2.0 ** 10)
     work = S.Ciphertext(d.ctx, batch=batch)
     d.ev.multiply(cx, cy, work)
     d.ev.relinearize_inplace(work, d.rlk)

@@ -291,6 +291,15 @@ def test_digit_parallel_reduce_scatter(emu, n, bits, parts, batch):
     assert P.case_digit_parallel_reduce_scatter(n, primes, parts=parts, batch=batch) is True  # loopback: no RCCL on this box
 
 
+def test_ks_chunked(emu):
+    """chunked key switching (sealhip.h: SEALHIP_KS_CHUNK / SEALHIP_KS_LANES / SEALHIP_KS_SCRATCH_CAP_MIB): pointer arithmetic of the
+    chunks, ragged last chunk, the folded CKKS tail over chunked sums, BFV's in-place target, the scratch cap"""
+    P.case_ks_chunked("ckks", 8192, [50, 40, 40, 50], batch=5, chunk=2, lanes=2)
+    pr = coeff_modulus_create(8192, [45, 40, 45])
+    P.case_ks_chunked("bfv", 8192, pr, batch=4, chunk=1, lanes=3, t=plain_modulus_batching(8192, 20))
+    P.case_ks_chunked("ckks", 8192, [50, 40, 40, 50], batch=7, chunk=4, lanes=2, cap_mib=2)
+
+
 def test_ckks_pipeline_n65536_lean_key_switch(emu):
     """N = 2^16 is the one size whose key-switch kernels use the lean fix() placement (two per sixteen stages, balanced
     tables; ntt2_kernels.hip p1_tile / p2_tile): multiply + relinearize + rescale + rotate word for word, incl. 60-bit digits

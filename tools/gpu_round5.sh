@@ -1,0 +1,55 @@
+#!/bin/bash
+# Round-5 measurements on one MI355X (run from the repo root on the GPU box: `gpurun -- tools/gpu_round5.sh <sections>`).
+# Output goes to gpurun_out/r05/; what is to be judged is copied into profiles/ afterwards.
+#   micro     tools/microbench/ldsdma_pass: LDS-DMA / s_setprio / spread-issue variants of a pass-shaped persistent tile loop
+#   chunk     same-box A/B of the chunked key switch (SEALHIP_KS_CHUNK / SEALHIP_KS_LANES) on the headline, rotate_c5, bfv_c4
+#   prio      same-box A/B of the s_setprio variants of the real kernels (seal_amd/lib/variants/prio1.so, prio2.so)
+#   c2        configs[1] chain: default vs -DSEALHIP_KS_NT=0 (variants/nt0.so), 5 processes each
+#   newtests  the GPU tests added this round
+#   bfvpmc    counter pass over the bfv_c4 workload (behz_*, ntt2_*<7,0>, ks2<7,0>)
+#   tests     pytest -m gpu + smoke
+#   bench     python bench.py (default line)
+#   trace     rocprofv3 --kernel-trace --stats of a short bench + the step's time line
+set -u
+export TMPDIR=/tmp
+REPO=$(pwd); O=$REPO/gpurun_out/r05; mkdir -p $O
+export SEALHIP_ABORT_TRACE=$O/abort_trace.txt
+common="--no-cpu-baseline --no-pmc --no-verify --no-children"
+[ $# -eq 0 ] && set -- micro chunk
+for what in "$@"; do
+  echo "=== $what $(date +%T)"
+  case $what in
+  micro)
+    timeout 300 tools/microbench/ldsdma_pass 4 > $O/ldsdma_pass.txt 2>&1; tail -80 $O/ldsdma_pass.txt ;;
+  chunk)
+    tools/ab.sh --rounds ${ROUNDS:-2} --out gpurun_out/r05/ab_chunk \
+      off:default:SEALHIP_KS_CHUNK=0 c32x2:default c32x1:default:SEALHIP_KS_LANES=1 c32x3:default:SEALHIP_KS_LANES=3 \
+      c64x2:default:SEALHIP_KS_CHUNK=64 c16x4:default:SEALHIP_KS_CHUNK=16,SEALHIP_KS_LANES=4 2>&1 | tee $O/ab_chunk.txt
+    tools/ab.sh --rounds 1 --workload rotate_c5 --out gpurun_out/r05/ab_chunk_rot off:default:SEALHIP_KS_CHUNK=0 c8x2:default:SEALHIP_KS_CHUNK=8 c16x2:default:SEALHIP_KS_CHUNK=16 2>&1 | tee $O/ab_chunk_rot.txt
+    tools/ab.sh --rounds 1 --workload bfv_c4 --out gpurun_out/r05/ab_chunk_bfv off:default:SEALHIP_KS_CHUNK=0 auto:default auto3:default:SEALHIP_KS_LANES=3 2>&1 | tee $O/ab_chunk_bfv.txt ;;
+  chunktrace)
+    tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
+  prio)
+    tools/ab.sh --rounds ${ROUNDS:-2} --out gpurun_out/r05/ab_prio --check "north_star_config or test_ntt" base:default prio1:prio1 prio2:prio2 2>&1 | tee $O/ab_prio.txt
+    tools/ab.sh --rounds ${ROUNDS:-2} --workload ntt --out gpurun_out/r05/ab_prio_ntt base:default prio1:prio1 prio2:prio2 2>&1 | tee $O/ab_prio_ntt.txt ;;
+  c2)
+    tools/ab.sh --rounds 5 --workload c2 --out gpurun_out/r05/ab_c2 nt31:default nt0:nt0 2>&1 | tee $O/ab_c2.txt ;;
+  newtests)
+    (timeout 1200 python -m pytest tests/test_gpu_parity.py -q -x -k "ks_chunked or batch512 or batch256 or batch1024" > $O/pytest_new.txt 2>&1; echo "rc=$?" >> $O/pytest_new.txt); tail -5 $O/pytest_new.txt ;;
+  bfvpmc)
+    timeout 900 python tools/pmc_table.py --bench-args "--workload bfv_c4 --steps 2 --warmup 1 $common" --filter "" --groups 0,1,7,8 > $O/bfv_c4_counters.txt 2>&1; tail -120 $O/bfv_c4_counters.txt ;;
+  tests)
+    (timeout 1800 python -m pytest tests -m gpu -q -rs > $O/pytest.txt 2>&1; echo "rc=$?" >> $O/pytest.txt); tail -6 $O/pytest.txt
+    (timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?" >> $O/smoke.txt); tail -1 $O/smoke.txt ;;
+  bench)
+    timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-400 $O/bench.json ;;
+  trace)
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $REPO/bench.py --steps 3 --warmup 1 $common > $O/prof.log 2>&1)
+    DB=$(find $O/prof -name "*.db" | head -1)
+    python tools/rocpd_summary.py $DB > $O/rocprof_bench_kernel_stats.txt; python tools/step_timeline.py $DB > $O/step_timeline.txt
+    find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -r -I{} cp {} $O/rocprofv3_stats_kernel_stats.csv; rm -rf $O/prof
+    tail -40 $O/step_timeline.txt ;;
+  esac
+done
+[ -s $O/abort_trace.txt ] && { echo "ABORT TRACE:"; cat $O/abort_trace.txt; }
+exit 0
