@@ -29,6 +29,8 @@ One JSON line is printed by rank 0 with, besides the contract fields:
   roofline_configs1  the same measurement at BASELINE configs[1] (CKKS N=8192, L=4: forward and inverse NTT over all RNS components)
   workloads    headline on one GPU only: BASELINE configs[3] (bfv_c4) and configs[4] (rotate_c5) timed by short child runs of this
                script after the headline (value, ms_per_step, verified_items, roofline of each); --no-children leaves them out
+  config.device_memory  bytes the library's pool held after the timed steps, the largest key-switch intermediate (the batch runs in
+               chunks on forked streams: sealhip.h "Chunked key switching"), how many key switches ran chunked and in how many chunks
   rccl_ranks, per_rank  how many ranks the probe all-reduce reached before anything was timed (a mismatch stops the job with
                the count in the message) and every rank's own rate
   cpu_baseline the reference's own Evaluator (oracle/_ref = Microsoft SEAL 4.4.3, HEXL off) timed on this host's cores on a
@@ -64,7 +66,9 @@ def main():
     if EMU:
         S.load(os.path.join(ROOT, "tests", "hipemu", "libsealhip_emu.so"))
 
-    w = workloads.build(args, S, shard, torch, group, device, dev_sync, world, rank)
+    cdev = r.coll_device   # where the helper collectives' tensors live (the GPU with RCCL, the host with gloo)
+    mem_check = launcher.check_device_memory(r, workloads.estimate_device_bytes(args, world, rank), "--workload %s" % args.workload)
+    w = workloads.build(args, S, shard, torch, group, device, dev_sync, world, rank, shared_gpu=r.shared_gpu)
     n, K, L, B, scaling = w.n, w.K, w.L, w.B, w.scaling
 
     result = {}
@@ -72,17 +76,17 @@ def main():
     per_rank = None
     if not args.ntt_only:
         local = {}
-        elapsed = shard.timed_steps(w.step, args.steps, args.warmup, group, dev_sync, torch, device, local=local)
+        elapsed = shard.timed_steps(w.step, args.steps, args.warmup, group, dev_sync, torch, cdev, local=local)
         work = workloads.result_batch(w, args)
         assert work.size() == 2 and work.coeff_modulus_size() == K - 1 and work.batch() == B
         per_step = B if args.workload != "rotate_c5" else float(B) / world  # rotate_c5: all ranks worked on the same B items
-        rate = shard.whole_job_rate(per_step, args.steps, elapsed, group, torch, device)
+        rate = shard.whole_job_rate(per_step, args.steps, elapsed, group, torch, cdev)
         result = dict(value=rate, ms_per_step=1e3 * elapsed / args.steps)
         per_rank = launcher.gather_per_rank(r, per_step * args.steps / local["elapsed"], 1e3 * local["elapsed"] / args.steps)
         if w.want_verify and B > 0:
             verified = workloads.verify_items(args.workload, w.scheme, n, w.primes, w.t_plain, w.key_host, w.xs, w.ys, work, B, w.scale)
             if group is not None:
-                v = torch.tensor([verified], dtype=torch.int64, device=device)
+                v = torch.tensor([verified], dtype=torch.int64, device=cdev)
                 dist.all_reduce(v)
                 verified = int(v.item())
         del work
@@ -97,6 +101,10 @@ def main():
     if rank == 0 and world == 1 and args.workload == "headline" and not EMU and not args.step_child:
         ntt_c1 = counters.ntt_configs1(S, torch, device)
 
+    # what the step held in HBM: the pool's blocks and the largest key-switch intermediate of the timed steps
+    ks_calls, ks_chunks, ks_scratch = S.ks_chunk_stats()
+    memory_note = dict(pool_bytes_held=S.pool_stats()[0], key_switch_scratch_bytes_max=ks_scratch,
+                       key_switch_chunked_calls=ks_calls, key_switch_chunks=ks_chunks, **(mem_check or {}))
     # free the device before the PMC child processes, the appended workloads and the CPU baseline start
     if world > 1:
         dist.barrier()
@@ -154,11 +162,13 @@ def main():
             scaling=scaling, vs_baseline=None, dtype="u64", data="synthetic",
             verified_items=verified, rccl_ranks=r.collective_ranks, collective_backend=r.backend, per_rank=per_rank,
             config=dict(workload=description + (" [EMULATED KERNELS, CPU test]" if EMU else ""),
-                        batch_per_gpu=B, key_switch_tail=tail_note, launch=("hipGraph replay" if args.graph else "eager") + lanes_note,
+                        batch_per_gpu=B, key_switch_tail=tail_note,
+                        **(dict(shared_gpu="TEST MODE: the %d ranks share one device over gloo (SEALHIP_BENCH_SHARE_GPU) - not a measurement" % world)
+                           if r.shared_gpu else {}), launch=("hipGraph replay" if args.graph else "eager") + lanes_note,
                         parallelism=par,
                         arithmetic="64-bit residues: exact double-precision (error-free FMA) arithmetic for primes below "
                                    "2^50, 64-bit Shoup/Barrett integer arithmetic for larger primes; results canonical u64",
-                        key_bytes=2 * K * L * n * 8, key_bytes_resident=key_resident,
+                        key_bytes=2 * K * L * n * 8, key_bytes_resident=key_resident, device_memory=memory_note,
                         algorithmic_bytes_per_ciphertext=(2 * K * K + 18 * K - 2) * 8 * n,
                         **(dict(exchange_bytes_per_ciphertext=2 * (K + 1) * n * 8,
                                 exchange_overlap=("%d sub-batches on %d streams sharing the communicator: the exchange of one runs while the "

@@ -11,29 +11,50 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 BENCH_PY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
 
 
-def ntt_leg(S, ctx, xs, B, K, n, reps=40, warm=25):
+def ntt_leg(S, ctx, xs, B, K, n, reps=10, warm=25, blocks=3):
     """the roofline leg: the batched forward NTT over the resident batch (2*B polynomials x K components), HIP events on the stream
     the transform is launched on; achieved = algorithmic bytes (16*N per RNS-component transform, SURVEY 8(d)) / time.
-    `warm` untimed launches precede the timed ones (the leg follows ten seconds of host-side reference checking).  The figure still
-    moves by +-7 % from run to run on one box: it depends on where the scratch block of the intermediate happens to lie relative to
-    the data - 2.44 TB/s with one block, 2.63 with another in the same process, every block of twenty launches alike
-    (profiles/r04_ntt_leg_placement.txt); the kernels' HBM traffic is 2.015x the algorithmic bytes either way."""
+    `warm` untimed launches precede the timed ones (the leg follows ten seconds of host-side reference checking).
+    The rate of one build moves by +-7 % with WHERE the scratch block of the intermediate happens to lie relative to the data
+    (profiles/r04_ntt_leg_placement.txt: 2.44 TB/s with the block the pool recycles, 2.63 with a freshly allocated one, same
+    process, every block of launches alike; the kernels' HBM traffic is 2.015x the algorithmic bytes either way).  So the leg is
+    timed in `blocks` blocks of `reps` launches with the pool's block AND again after SealHip_ReleasePool() (fresh block):
+    `frac` / `achieved` / `ms_per_launch` are the MEDIAN block, `frac_range` the slowest and the fastest, `frac_by_placement`
+    the two populations (VERDICT r4 next #3)."""
     timer = S.HipTimer()
     polys = 2 * B
     assert xs.numel() == polys * K * n
+    alg_bytes = 16.0 * n * K * polys
 
     class _Buf:
         ptr = xs.data_ptr()
+
+    def timed_blocks():
+        out = []
+        for _ in range(blocks):
+            timer.start()
+            for _ in range(reps):
+                S.ntt_forward(ctx, _Buf, polys, K)
+            out.append(timer.stop() / reps)
+        return out
     for _ in range(warm):
         S.ntt_forward(ctx, _Buf, polys, K)
-    timer.start()
-    for _ in range(reps):
+    pooled = timed_blocks()
+    S.device_synchronize()
+    S.release_pool()             # the next launch takes a newly allocated scratch block
+    for _ in range(3):
         S.ntt_forward(ctx, _Buf, polys, K)
-    ms = timer.stop() / reps
-    alg_bytes = 16.0 * n * K * polys
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    fresh = timed_blocks()
+    every = sorted(pooled + fresh)
+    ms = every[len(every) // 2] if len(every) % 2 else 0.5 * (every[len(every) // 2 - 1] + every[len(every) // 2])
+    gbs = lambda t: alg_bytes / (t * 1e-3) / 1e9  # noqa: E731
+    achieved = gbs(ms)
     return dict(bound="hbm", kernel="ntt_forward over %d transforms of 2^%d per launch" % (K * polys, n.bit_length() - 1),
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                frac_range=[round(gbs(every[-1]) / HBM_PEAK_GBS, 4), round(gbs(every[0]) / HBM_PEAK_GBS, 4)],
+                frac_by_placement=dict(pool_block=[round(gbs(t) / HBM_PEAK_GBS, 4) for t in pooled],
+                                       fresh_block=[round(gbs(t) / HBM_PEAK_GBS, 4) for t in fresh]),
+                frac_is="median of %d blocks of %d launches, half with the pool's scratch block, half with a fresh one" % (2 * blocks, reps),
                 traffic=None, ms_per_launch=round(ms, 4), algorithmic_bytes_per_launch=alg_bytes)
 
 
@@ -143,15 +164,39 @@ def pmc_traffic(args, B, K, n):
 # ---- roofline_step: the kernels that dominate the timed step, by this run's own counters --------------------------------
 VALU_CYCLES_PER_WAVE_INST = 4      # a wave64 VALU instruction occupies a SIMD16 for four cycles (MI355X_MICROARCH.md; measured 4.2-5)
 SIMDS, ENGINE_HZ = 256 * 4, 2.4e9
+XCDS = 8                            # GRBM_GUI_ACTIVE is summed over the eight XCDs of an MI355X (calibrated: 18.5 G "cycles"/s on a 343 us kernel)
+
+
+def _pmc_pass(exe, counters, child, tmp, tag):
+    """one rocprofv3 --kernel-trace --pmc pass over `child`; {kernel: {dispatches, ns, counter: sum}} for this library's kernels"""
+    import glob
+    import sqlite3
+    out = os.path.join(tmp, tag)
+    cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["-d", out, "-o", "r", "--"] + child
+    p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+    dbs = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+    if p.returncode != 0 or not dbs:
+        raise RuntimeError("rocprofv3 --pmc %s failed (rc %d): %s" % (" ".join(counters), p.returncode, (p.stderr or p.stdout)[-300:]))
+    cur = sqlite3.connect(dbs[0]).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), sum(value), sum(duration) from counters_collection "
+                       "group by kernel_name, counter_name").fetchall()
+    table = {}
+    for name, ctr, cnt, val, dur in rows:
+        if "sealhip" not in name:
+            continue  # torch's input generation, copies
+        short = name.replace("sealhip::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        e = table.setdefault(short, dict(dispatches=cnt, ns=float(dur)))
+        e[ctr] = float(val)
+    return table
 
 
 def step_counters(args, B):
-    """One rocprofv3 --kernel-trace --pmc pass over a child that runs the timed step alone (a smaller batch: the per-dispatch
-    figures scale with it, the utilisation does not once the chip is full).  Per kernel: share of the step's GPU time, wave
-    instructions on the vector ALU per dispatch, and issue utilisation = those x 4 cycles / (duration x 1024 SIMDs x 2.4 GHz)."""
-    import glob
+    """Two rocprofv3 --kernel-trace --pmc passes over a child that runs the timed step alone.  Per kernel: share of the step's GPU
+    time, wave instructions on the vector ALU per dispatch, issue utilisation = those x 4 cycles / (duration x 1024 SIMDs x 2.4 GHz)
+    - and, from the second pass (GRBM_GUI_ACTIVE = shader-engine clock cycles while the kernel ran), the clock the chip actually
+    SUSTAINED under that kernel and the utilisation against it (under the fp64 load of the key switch the
+    chip holds ~1.8 - 2.0 GHz, not the 2.4 GHz the first figure is quoted against)."""
     import shutil
-    import sqlite3
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
@@ -159,23 +204,17 @@ def step_counters(args, B):
     child_batch = max(1, B)   # the timed batch itself (round 3 profiled a batch of 64 and left a 36 % per-item gap to explain)
     tmp = tempfile.mkdtemp(prefix="sealhip_step_", dir="/tmp")
     try:
-        cmd = [exe, "--kernel-trace", "--pmc", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "-d", tmp, "-o", "r", "--",
-               sys.executable, BENCH_PY, "--step-child", "--workload", args.workload, "--batch", str(child_batch),
-               "--total-batch", str(child_batch), "--steps", "2", "--warmup", "1"]
-        p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
-        dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
-        if p.returncode != 0 or not dbs:
-            return dict(source="rocprofv3 --pmc pass failed (rc %d): %s" % (p.returncode, (p.stderr or p.stdout)[-300:]))
-        cur = sqlite3.connect(dbs[0]).cursor()
-        rows = cur.execute("select kernel_name, counter_name, count(*), sum(value), sum(duration) from counters_collection "
-                           "group by kernel_name, counter_name").fetchall()
-        table = {}
-        for name, ctr, cnt, val, dur in rows:
-            if "sealhip" not in name:
-                continue  # torch's input generation, copies
-            short = name.replace("sealhip::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-            e = table.setdefault(short, dict(dispatches=cnt, ns=float(dur)))
-            e[ctr] = float(val)
+        child = [sys.executable, BENCH_PY, "--step-child", "--workload", args.workload, "--batch", str(child_batch),
+                 "--total-batch", str(child_batch), "--steps", "2", "--warmup", "1"]
+        table = _pmc_pass(exe, ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY"], child, tmp, "sq")
+        try:
+            clocks = _pmc_pass(exe, ["GRBM_GUI_ACTIVE"], child, tmp, "grbm")
+        except Exception as e:  # the second pass is an extra: without it the line simply lacks the clock
+            clocks = {}
+            clock_note = "GRBM_GUI_ACTIVE pass failed: %r" % (e,)
+        else:
+            clock_note = ("second pass: GRBM_GUI_ACTIVE (summed over the %d XCDs) / %d / kernel time; the counter brackets a dispatch "
+                          "with a few tens of microseconds of its own, which is why it is only quoted for the long kernels" % (XCDS, XCDS))
         total_ns = sum(e["ns"] for e in table.values()) or 1.0
         out = []
         for k, e in sorted(table.items(), key=lambda kv: -kv[1]["ns"])[:8]:
@@ -186,14 +225,23 @@ def step_counters(args, B):
                        valu_issue_utilisation=round(util, 3))
             if e.get("SQ_WAVE_CYCLES"):
                 row["waiting_to_issue_frac_of_wave_cycles"] = round(e.get("SQ_WAIT_INST_ANY", 0.0) / e["SQ_WAVE_CYCLES"], 3)
+            c = clocks.get(k)
+            if c and c.get("GRBM_GUI_ACTIVE") and c["ns"] and c["ns"] / c["dispatches"] > 5e5:   # kernels of 0.5 ms and more
+                cycles = c["GRBM_GUI_ACTIVE"] / XCDS            # shader clock cycles over the same dispatches of the second pass
+                row["sclk_mhz_sustained"] = int(round(cycles / (c["ns"] * 1e-9) / 1e6))
+                if c["dispatches"] == e["dispatches"]:
+                    row["valu_issue_utilisation_at_sustained_clock"] = round(insts * VALU_CYCLES_PER_WAVE_INST / (cycles * SIMDS), 3)
             out.append(row)
-        return dict(source="live: one rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY pass over "
+        weighted = [(r["sclk_mhz_sustained"], r["share_of_gpu_time"]) for r in out if "sclk_mhz_sustained" in r]
+        sclk = int(round(sum(a * b for a, b in weighted) / sum(b for _, b in weighted))) if weighted else None
+        return dict(source="live: rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY over "
                            "`bench.py --step-child --batch %d` (3 steps); utilisation = VALU wave instructions x %d cycles / (kernel time "
                            "x %d SIMDs x %.1f GHz).  The profiler SERIALISES the kernels: in the timed step the integer-class and the "
-                           "double-precision key-switch kernels share the CUs on two streams, here each has the chip to itself - avg_ms "
-                           "is the kernel alone, and the sum over the kernels exceeds the step's wall time by what the overlap saves "
-                           "(~6 %%; profiles/r04_ks_handover.txt)" % (
+                           "double-precision key-switch kernels (and, round 5, the chunks of the key switch on their lanes) share the "
+                           "CUs, here each has the chip to itself - avg_ms is the kernel alone; serialised, the four key-switch "
+                           "kernels sum to about what they take overlapped (18.8 against 18.6 ms in round 4: the fork saves ~1 %%)" % (
                                child_batch, VALU_CYCLES_PER_WAVE_INST, SIMDS, ENGINE_HZ / 1e9),
+                    clock_source=clock_note, sclk_mhz_sustained=sclk,
                     kernels=out, serialised_gpu_ms_per_step=round(total_ns / 3e6, 3))
     except Exception as e:  # the counters must never take the benchmark down
         return dict(source="PMC pass failed: %r" % (e,))

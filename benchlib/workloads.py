@@ -112,7 +112,25 @@ class Workload:
         self.__dict__.clear()
 
 
-def build(args, S, shard, torch, group, device, dev_sync, world, rank):
+def estimate_device_bytes(args, world, rank):
+    """HBM this rank will hold for the workload, to within ~20 %: the torch input tensors, their ciphertext copies, the result, the
+    key-switch sums and its chunked intermediate (at most the cap), the largest transform scratch, keys and tables."""
+    scheme, n, bits, tbits, default_batch = WORKLOADS[args.workload]
+    L, K = len(bits), len(bits) - 1
+    if args.workload == "bfv_c4":
+        total = args.total_batch if not EMU else 4
+        B = total // world + (1 if rank < total % world else 0)
+    else:
+        B = args.batch or default_batch
+    poly = K * n * 8                                   # one polynomial of one item at the first level
+    operands = (1 if args.workload == "rotate_c5" else 2) * 2 * B * poly
+    cap = float(os.environ.get("SEALHIP_KS_SCRATCH_CAP_MIB", "16384")) * 2 ** 20
+    ks_mid = min(B * (K + 1) * K * n * 8, cap)
+    behz = 6 * B * (K + 3) * n * 8 * 3 if scheme == "bfv" else 0   # lifted operands in q + Bsk + m~ and the tensor product there
+    return int(2 * operands + 3 * B * poly + 2 * B * (K + 1) * n * 8 + B * poly + ks_mid + 3 * B * poly + behz + 2 * K * L * n * 8 * 2 + 2 ** 30)
+
+
+def build(args, S, shard, torch, group, device, dev_sync, world, rank, shared_gpu=False):
     w = Workload()
     scheme, n, bits, tbits, default_batch = WORKLOADS[args.workload]
     primes = S.CoeffModulus.Create(n, bits)
@@ -150,7 +168,8 @@ def build(args, S, shard, torch, group, device, dev_sync, world, rank):
     if args.workload == "rotate_c5":
         elt = ctx.galois_elt_from_step(1)
         keys = S.GaloisKeys(ctx)
-        dp = shard.DigitParallel(ev, torch, group, device, exchange=args.exchange, native=True if args.native_comm else None)
+        # (ranks sharing one device - the one-GPU test mode - cannot use RCCL: the partial sums go through torch.distributed)
+        dp = shard.DigitParallel(ev, torch, group, device, exchange=args.exchange, native=False if shared_gpu else (True if args.native_comm else None))
         d0, dc = dp.digit_range(K)
         if dp.comm is not None:
             # one-time key distribution inside the library: rank 0's key is broadcast over RCCL and every rank keeps its own

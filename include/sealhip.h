@@ -346,7 +346,10 @@ SHL_FUNC Evaluator_ContextUsingKeyswitching(void *thisptr, bool *using_keyswitch
  * 64-bit words; parts = number of summed buffers (<= 8: eight residues below 2^60 still fit one word).
  * Results equal Evaluator_Relinearize / Evaluator_ApplyGalois bit for bit.  CKKS at the two-pass sizes: `*Finish` may leave the
  * mod-down pending exactly as Evaluator_Relinearize does (deferred key-switch tail, below: a rescale on the same evaluator then
- * folds both divisions); the reduced sums are copied first, device_acc is not referenced once the call has been enqueued. */
+ * folds both divisions); the reduced sums are copied first, by a kernel QUEUED on the evaluator's stream: device_acc is read
+ * asynchronously, so a caller that owns the buffer on another stream (a torch tensor, a communicator's receive buffer) must
+ * not overwrite or free it before the evaluator's stream has passed this call - wait for an event recorded on that stream
+ * after `*Finish`, or reuse the buffer only from work queued on the same stream (seal_amd/shard.py does the latter). */
 SHL_FUNC Evaluator_SwitchKeyAccWords(void *thisptr, void *encrypted, uint64_t *words);
 SHL_FUNC Evaluator_RelinearizePartial(void *thisptr, void *encrypted /* size 3 */, void *relinKeys, uint64_t digit_first,
                                       uint64_t digit_count, uint64_t *device_acc);
@@ -534,12 +537,13 @@ SHL_FUNC SealHip_ReleasePool(void);
  * change the protection of their own buffers (integration/seal_evaluator_hip.cpp); process-wide, off by default. */
 SHL_FUNC SealHip_SetStagedHostCopies(bool enabled);
 SHL_FUNC SealHip_PoolStats(uint64_t *bytes_held, uint64_t *cross_stream_waits);
-/* Diagnostics.  The library installs a std::terminate handler when it is loaded: an exception that escapes where none may
- * (a destructor, a host worker thread) prints its message and the sticky HIP error before the process aborts.
- * SealHip_InstallAbortTrace(path) - or SEALHIP_ABORT_TRACE=<path> in the environment - additionally catches SIGABRT, appends the
- * call stack of the aborting thread to `path` (the ROCm runtime aborts the process itself when the device reports a memory
- * fault: its handler on the stack tells that case from a C++ one) and then lets the abort proceed.  Opt-in: signal
- * dispositions belong to the host program. */
+/* Diagnostics (opt-in: process-wide handlers belong to the host program, loading the library installs none).
+ * SealHip_InstallAbortTrace(path) - or SEALHIP_ABORT_TRACE=<path> in the environment when the library is loaded -
+ *   * installs a std::terminate handler: an exception that escapes where none may (a destructor, a host worker thread) prints its
+ *     message before the handler that was installed before it runs (no HIP call is made: the runtime may be gone by then);
+ *   * catches SIGABRT, appends the call stack of the aborting thread to `path` (the ROCm runtime aborts the process itself when the
+ *     device reports a memory fault: its handler on the stack tells that case from a C++ one) and then lets the abort proceed
+ *     with the default disposition.  A later call only changes the path. */
 SHL_FUNC SealHip_InstallAbortTrace(const char *path);
 /* Environment.  The product library reads nine variables, each exercised by a test; everything else that earlier
  * rounds could switch at run time (superseded kernels, fork / no-fork of the side streams, ...) only exists in development
@@ -556,7 +560,7 @@ SHL_FUNC SealHip_InstallAbortTrace(const char *path);
  *   SEALHIP_ABORT_TRACE=<file>       SealHip_InstallAbortTrace(<file>) when the library is loaded (Diagnostics, above)
  *   SEALHIP_KS_CHUNK=<items>         chunk size of a key switch over a large batch (below; 0 = never cut; default: the items
  *                                    that make 8192 pass-2 workgroups - 32 at N = 2^16 with 16 moduli)
- *   SEALHIP_KS_LANES=<1..4>          streams the chunks are dealt to (default 2; 1 = one after the other on the evaluator's stream)
+ *   SEALHIP_KS_LANES=<1..4>          streams the chunks are dealt to (default 3; 1 = one after the other on the evaluator's stream)
  *   SEALHIP_KS_SCRATCH_CAP_MIB=<n>   upper bound of the key switch's intermediate (default 16384); chunk / lanes shrink to fit */
 /* Chunked key switching (round 5).  switch_key_inplace needs K (K + 1) half-transformed digits per ciphertext between its two
  * kernels (126 MB at N = 2^16, K = 15).  For a batch of 1.5 chunks or more (2^13 <= N <= 2^16, register-order keys, one digit group) the batch is cut

@@ -251,6 +251,11 @@ extern "C"
             throw std::invalid_argument("parms_id is not valid for encryption parameters");
         if (l && ct->level() && l->K != ct->level()->K && ct->word_count())
             throw std::invalid_argument("parms_id names a level with another coeff_modulus_size than the stored polynomials");
+        // ... and never one whose polynomials would not fit the slab (parms_id_zero first and then a longer level's id
+        // passed the check above - no level, word_count() 0 - and left size x K x N beyond capacity_words()).  The reference's
+        // is_buffer_valid catches the same state later (valcheck.cpp:172-198); a device object refuses to enter it.
+        if (l && ct->size() * ct->batch() * l->K * ct->context().n() > ct->capacity_words())
+            throw std::invalid_argument("parms_id names a level whose polynomials do not fit the allocated capacity");
         ct->set_level_unchecked(l);
         SHL_CATCH
     }

@@ -4,11 +4,12 @@
 // host worker thread) reaches std::terminate, and the ROCm runtime calls abort() itself when the device reports a memory
 // access fault or a queue error.  Either way the host sees "Aborted" and nothing else if its stderr is captured (pytest
 // keeps fd 2 in a temporary file that dies with the process: the one unexplained abort of round 3 left no trace).
-//   * the terminate handler is installed when the library is loaded; it prints the exception's message and the sticky HIP
-//     error and then calls the handler that was there before;
-//   * SealHip_InstallAbortTrace(path) - or SEALHIP_ABORT_TRACE=<path> in the environment - additionally catches SIGABRT and
-//     appends the call stack of the aborting thread to `path` (a ROCm fault handler on the stack tells a device fault from a
-//     C++ one), then lets the abort proceed.  Opt-in because signal dispositions belong to the host program.
+// Both hooks are OPT-IN (round 5, ADVICE r4: process-wide handlers belong to the host program; loading a library must not
+// replace them): SealHip_InstallAbortTrace(path) - or SEALHIP_ABORT_TRACE=<path> in the environment when the library is loaded -
+//   * installs a terminate handler that prints the exception's message (nothing else: no HIP call - the runtime may be torn
+//     down by then) and chains to the handler that was there before;
+//   * catches SIGABRT and appends the call stack of the aborting thread to `path` (a ROCm fault handler on the stack tells a
+//     device fault from a C++ one), then lets the abort proceed with the DEFAULT disposition (not a saved, possibly stale one).
 #include "capi_common.h"
 #include <csignal>
 #include <cstdio>
@@ -17,13 +18,15 @@
 #include <execinfo.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <atomic>
 
 namespace
 {
     std::terminate_handler g_previous_terminate = nullptr;
-    char g_trace_path[512] = { 0 };
-    struct sigaction g_previous_abort;
-    bool g_abort_installed = false;
+    // two path buffers and the index of the live one: a handler on another thread reads a complete path whichever it sees
+    char g_trace_paths[2][512] = { { 0 }, { 0 } };
+    std::atomic<int> g_trace_live{ 0 };
+    std::atomic<bool> g_abort_installed{ false };
 
     void put(int fd, const char *s)
     {
@@ -66,8 +69,7 @@ namespace
                 std::fprintf(stderr, " with an uncaught exception that is not a std::exception");
             }
         }
-        const hipError_t sticky = hipGetLastError();
-        std::fprintf(stderr, "; last HIP error: %s\n", hipGetErrorString(sticky));
+        std::fprintf(stderr, "\n");
         std::fflush(stderr);
         if (g_previous_terminate)
             g_previous_terminate();
@@ -77,7 +79,8 @@ namespace
     // async-signal-safe apart from backtrace()'s first-call initialisation, which install() forces ahead of time
     void on_abort(int sig)
     {
-        int fd = g_trace_path[0] ? ::open(g_trace_path, O_WRONLY | O_CREAT | O_APPEND, 0644) : 2;
+        const char *path = g_trace_paths[g_trace_live.load(std::memory_order_acquire)];
+        int fd = path[0] ? ::open(path, O_WRONLY | O_CREAT | O_APPEND, 0644) : 2;
         if (fd < 0)
             fd = 2;
         put(fd, "sealhip: SIGABRT in process ");
@@ -89,8 +92,9 @@ namespace
         put(fd, "sealhip: end of call stack\n");
         if (fd != 2)
             ::close(fd);
-        // hand the signal on: the previous disposition (Python's faulthandler, the default core dump ...)
-        ::sigaction(sig, &g_previous_abort, nullptr);
+        // let the abort proceed: default disposition (a disposition saved at install time may be stale - the host may have
+        // installed its own handler since)
+        ::signal(sig, SIG_DFL);
         ::raise(sig);
     }
 
@@ -98,7 +102,6 @@ namespace
     {
         AtLoad()
         {
-            g_previous_terminate = std::set_terminate(on_terminate);
             if (const char *p = std::getenv("SEALHIP_ABORT_TRACE"))
                 if (*p)
                     SealHip_InstallAbortTrace(p);
@@ -112,11 +115,14 @@ extern "C"
     {
         IfNullRet(path, SHL_E_POINTER);
         size_t n = std::strlen(path);
-        if (n == 0 || n >= sizeof(g_trace_path))
+        if (n == 0 || n >= sizeof(g_trace_paths[0]))
             return SHL_E_INVALIDARG;
-        std::memcpy(g_trace_path, path, n + 1);
-        if (g_abort_installed)
+        const int spare = 1 - g_trace_live.load(std::memory_order_relaxed);
+        std::memcpy(g_trace_paths[spare], path, n + 1);
+        g_trace_live.store(spare, std::memory_order_release);
+        if (g_abort_installed.exchange(true))
             return SHL_S_OK; // only the path changes
+        g_previous_terminate = std::set_terminate(on_terminate);
         void *warm[4];
         (void)::backtrace(warm, 4); // loads libgcc now, not inside the handler
         struct sigaction sa;
@@ -124,9 +130,11 @@ extern "C"
         sa.sa_handler = on_abort;
         sigemptyset(&sa.sa_mask);
         sa.sa_flags = SA_NODEFER;
-        if (::sigaction(SIGABRT, &sa, &g_previous_abort) != 0)
+        if (::sigaction(SIGABRT, &sa, nullptr) != 0)
+        {
+            g_abort_installed = false;
             return SHL_E_UNEXPECTED;
-        g_abort_installed = true;
+        }
         return SHL_S_OK;
     }
 }

@@ -352,6 +352,7 @@ namespace sealhip
             else
                 ok = ok && cf == 1;
             ok = ok && (ct.word_count() == 0 || ct.has_storage());
+            ok = ok && ct.word_count() <= ct.capacity_words(); // is_buffer_valid (valcheck.cpp:172-198): size x K x N words are there
         }
         if (!ok)
             throw std::invalid_argument(std::string(what) + " is not valid for encryption parameters");

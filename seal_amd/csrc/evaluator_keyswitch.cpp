@@ -35,7 +35,7 @@ namespace sealhip
             // their rate from 18 - 64 C5 ciphertexts on, profiles/r03_ks_batch_sweep.txt): >= 8192 pass-2 workgroups
             unsigned chunk = (unsigned)((8192 + wgs_per_item - 1) / (wgs_per_item ? wgs_per_item : 1));
             chunk = env_unsigned("SEALHIP_KS_CHUNK", chunk < 8 ? 8 : chunk);
-            unsigned lanes = env_unsigned("SEALHIP_KS_LANES", 2);
+            unsigned lanes = env_unsigned("SEALHIP_KS_LANES", 3);
             if (lanes < 1 || !may_lane)
                 lanes = 1;
             if (lanes > 4)

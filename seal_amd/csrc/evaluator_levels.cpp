@@ -327,8 +327,21 @@ namespace sealhip
             dest.correction_factor() = e.correction_factor();
         }
         dest.adopt(&lvl, 2, out, words);
-        switch_key_inplace(dest, perm.p, galois_keys, galois_index(galois_elt));
-        throw_if_transparent(dest);
+        try
+        {
+            switch_key_inplace(dest, perm.p, galois_keys, galois_index(galois_elt));
+            throw_if_transparent(dest);
+        }
+        catch (...)
+        {
+            // a separate destination must not keep the half-built (pi(c0), 0) with valid-looking metadata: it is left
+            // EMPTY - the reference leaves a copy of the operand there (evaluator.h:1130-1135: destination = encrypted first),
+            // which this form never makes; in place the object is the caller's operand and stays what the failure left of it,
+            // as in the reference
+            if (&dest != &e)
+                dest.release();
+            throw;
+        }
     }
 
     // out-of-place forms (evaluator.h:1130-1315: destination = encrypted; *_inplace(destination)): with the exact key present the

@@ -672,6 +672,8 @@ namespace sealhip
             return hipErrorInvalidValue;
         if (ntt2_supports(t.log_n))
         {
+            // (round 5: chunks of the outer items sized to the Infinity Cache, dealt to forked streams, measured 4 - 27 % SLOWER than
+            // one launch over the whole batch - profiles/r05_ntt_mall_chunks.txt - and are not here)
             // two-pass engine; the scratch block goes back to the pool in stream order
             Scratch mid(((size_t)b.nouter * b.ncomp) << t.log_n);
             return ntt2_forward(t, b, out_lazy, mid.p, stream);

@@ -117,6 +117,14 @@ class DigitParallel:
         # the partial sums were written by kernels on the evaluator's stream: make them visible to the collective
         self.ev.synchronize()
         if self.world > 1:
+            if acc.is_cuda and self.dist.get_backend() == "gloo":
+                # device tensors behind a host-only process group (ranks sharing one GPU in tests/test_gpu_multi.py): stage through
+                # the host - the sums are what matters there, not the rate
+                host = acc.cpu()
+                self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM)
+                acc.copy_(host)
+                self.torch.cuda.synchronize()
+                return
             self.dist.all_reduce(acc, op=self.dist.ReduceOp.SUM)  # < 8 * 2^60 < 2^63: no overflow as int64
             if acc.is_cuda:
                 self.torch.cuda.current_stream().synchronize()

@@ -195,6 +195,21 @@ def case_ciphertext_container(scheme, n, bits, tb=20):
         raise AssertionError("unknown parms_id accepted")
     except S.InvalidArgument:
         pass
+    # ... and never a level whose polynomials would not fit the slab: a size-2 ciphertext at the LAST level (K = 1),
+    # parms_id_zero first (no level: nothing to compare K with), then the first level's id - size x K x N would exceed the capacity
+    if K >= 2:
+        last = d.ctx.parms_id_at(0)
+        f = S.Ciphertext(d.ctx)
+        f.resize(last, 2)
+        cap_words = f.size_capacity() * f.coeff_modulus_size() * n
+        f.set_parms_id((0, 0, 0, 0))
+        try:
+            f.set_parms_id(d.ctx.parms_id_at(ci))
+            raise AssertionError("a level that does not fit the slab was accepted: size %d K %d capacity %d words" % (f.size(), f.coeff_modulus_size(), cap_words))
+        except S.InvalidArgument:
+            pass
+        f.set_parms_id(last)  # the level it was allocated for is still fine
+        assert (f.size(), f.coeff_modulus_size(), f.size_capacity()) == (2, 1, 2)
     # release(): an empty object that can be used again
     c.release()
     o.ref.ct_container_op(r, 4, 0, 0)

@@ -64,3 +64,28 @@ def test_bench_over_real_ranks(gpu, workload, extra):
     assert line["value"] > 0 and line["verified_items"] and line["verified_items"] >= 4, line
     if workload == "rotate_c5":
         assert "RCCL inside libsealhip" in line["config"]["parallelism"], line["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("rotate_c5", ["--batch", "2"]), ("bfv_c4", ["--total-batch", "6"]), ("headline", ["--batch", "3"])])
+def test_two_processes_share_the_one_gpu(gpu, workload, extra):
+    """The only N > 1 evidence a one-GPU box can give (VERDICT r4 next #7b): `python bench.py --gpus 2` with both ranks on device 0
+    (SEALHIP_BENCH_SHARE_GPU=1: process group gloo, RCCL refuses two ranks on one device) and the REAL kernels - batch sharding for
+    the headline and configs[3] (uneven shards: 3 + 3 of 6, 3 each), and for configs[4] the digit-parallel key switch across a real
+    process boundary: each rank runs switch_key_partial on its digits, the partial sums are added by torch.distributed, each
+    rank runs the *Finish kernels (deferred tail, folded into the rescale).  Every rank's sampled items equal the reference's."""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", SEALHIP_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", workload,
+                          "--no-cpu-baseline", "--no-pmc", "--no-children"] + extra, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo", line
+    assert "shared_gpu" in line["config"], line["config"]
+    assert [p["rank"] for p in line["per_rank"]] == [0, 1] and all(p["value"] > 0 for p in line["per_rank"])
+    assert line["value"] > 0 and line["verified_items"] and line["verified_items"] >= 4, line
+    assert "free" in out.stderr and "GiB free of" in out.stderr, "the per-rank memory line is missing: " + out.stderr[-800:]
+    if workload == "rotate_c5":
+        assert "torch.distributed" in line["config"]["parallelism"], line["config"]["parallelism"]

@@ -27,6 +27,22 @@ for what in "$@"; do
       c64x2:default:SEALHIP_KS_CHUNK=64 c16x4:default:SEALHIP_KS_CHUNK=16,SEALHIP_KS_LANES=4 2>&1 | tee $O/ab_chunk.txt
     tools/ab.sh --rounds 1 --workload rotate_c5 --out gpurun_out/r05/ab_chunk_rot off:default:SEALHIP_KS_CHUNK=0 c8x2:default:SEALHIP_KS_CHUNK=8 c16x2:default:SEALHIP_KS_CHUNK=16 2>&1 | tee $O/ab_chunk_rot.txt
     tools/ab.sh --rounds 1 --workload bfv_c4 --out gpurun_out/r05/ab_chunk_bfv off:default:SEALHIP_KS_CHUNK=0 auto:default auto3:default:SEALHIP_KS_LANES=3 2>&1 | tee $O/ab_chunk_bfv.txt ;;
+  chunk2)
+    tools/ab.sh --rounds ${ROUNDS:-3} --out gpurun_out/r05/ab_chunk2 off:default:SEALHIP_KS_CHUNK=0 c32x3:default c64x2:default:SEALHIP_KS_CHUNK=64,SEALHIP_KS_LANES=2 c32x1:default:SEALHIP_KS_LANES=1 2>&1 | tee $O/ab_chunk2.txt ;;
+  mall)
+    tools/ab.sh --rounds ${ROUNDS:-2} --workload ntt --out gpurun_out/r05/ab_mall base:default m64x2:default:SEALHIP_NTT_CHUNK_MIB=64 m96x2:default:SEALHIP_NTT_CHUNK_MIB=96 \
+      m128x2:default:SEALHIP_NTT_CHUNK_MIB=128 m96x3:default:SEALHIP_NTT_CHUNK_MIB=96,SEALHIP_NTT_LANES=3 m64x3:default:SEALHIP_NTT_CHUNK_MIB=64,SEALHIP_NTT_LANES=3 \
+      m256x2:default:SEALHIP_NTT_CHUNK_MIB=256 m96x1:default:SEALHIP_NTT_CHUNK_MIB=96,SEALHIP_NTT_LANES=1 2>&1 | tee $O/ab_mall.txt ;;
+  bfvtrace)
+    bash tools/quick/timeline_other.sh > $O/timeline_other.log 2>&1; cp gpurun_out/tl_rot/*.txt $O/ 2>/dev/null; tail -60 $O/timeline_other.log ;;
+  bfvtrace2)
+    (cd /tmp && timeout 300 rocprofv3 --kernel-trace -d $O/prof_bfv -o t -- python $REPO/bench.py --workload bfv_c4 --steps 4 --warmup 1 $common > $O/prof_bfv.log 2>&1)
+    DB=$(find $O/prof_bfv -name "*.db" | head -1)
+    python tools/step_timeline.py $DB --anchor behz_floor_sk --step -3 > $O/timeline_bfv_step.txt 2>&1; rm -rf $O/prof_bfv; tail -70 $O/timeline_bfv_step.txt ;;
+  nttvar)
+    tools/ab.sh --rounds ${ROUNDS:-2} --workload ntt --out gpurun_out/r05/ab_nttvar base:default p2w2h3:p2w2:SEALHIP_P2_HOIST=3 p2w2h4:p2w2 p1w2:p1w2 wg2k:wg2k wg8k:wg8k wg16k:wg16k 2>&1 | tee $O/ab_nttvar.txt ;;
+  multi)
+    (timeout 1500 python -m pytest tests/test_gpu_multi.py -q -x -rs > $O/pytest_multi.txt 2>&1; echo "rc=$?" >> $O/pytest_multi.txt); tail -15 $O/pytest_multi.txt ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
