@@ -324,6 +324,10 @@ namespace sealhip
                 }
                 const size_t poly_words = (size_t)K * N; // one polynomial of one item in the [batch][K][N] planes
                 unsigned c = 0;
+                // (The lanes run in lockstep - forked together, equal work.  A two-stage form that staggers them by construction - one
+                // producer stream for inverse transform + pass 1, the evaluator's stream consuming a ring of intermediates with pass 2
+                // - was measured too: 9.24 k ct/s against 9.27 - 9.40 k, profiles/r05_ks_chunked.txt.  Both passes need the vector
+                // ALU; side by side each runs slower by what the other takes.)
                 for (unsigned b0 = 0; b0 < B; b0 += plan.chunk, c++)
                 {
                     const unsigned nb = B - b0 < plan.chunk ? B - b0 : plan.chunk;

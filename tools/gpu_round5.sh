@@ -43,6 +43,11 @@ for what in "$@"; do
     tools/ab.sh --rounds ${ROUNDS:-2} --workload ntt --out gpurun_out/r05/ab_nttvar base:default p2w2h3:p2w2:SEALHIP_P2_HOIST=3 p2w2h4:p2w2 p1w2:p1w2 wg2k:wg2k wg8k:wg8k wg16k:wg16k 2>&1 | tee $O/ab_nttvar.txt ;;
   multi)
     (timeout 1500 python -m pytest tests/test_gpu_multi.py -q -x -rs > $O/pytest_multi.txt 2>&1; echo "rc=$?" >> $O/pytest_multi.txt); tail -15 $O/pytest_multi.txt ;;
+  pipe)
+    tools/ab.sh --rounds ${ROUNDS:-2} --out gpurun_out/r05/ab_pipe off:default:SEALHIP_KS_CHUNK=0 c32x3:default p32r2:default:SEALHIP_KS_PIPE=1,SEALHIP_KS_LANES=2 p32r3:default:SEALHIP_KS_PIPE=1 \
+      p16r3:default:SEALHIP_KS_PIPE=1,SEALHIP_KS_CHUNK=16 p16r4:default:SEALHIP_KS_PIPE=1,SEALHIP_KS_CHUNK=16,SEALHIP_KS_LANES=4 p64r2:default:SEALHIP_KS_PIPE=1,SEALHIP_KS_CHUNK=64,SEALHIP_KS_LANES=2 2>&1 | tee $O/ab_pipe.txt
+    SEALHIP_KS_PIPE=1 tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_pipe_trace p32r3:default:SEALHIP_KS_PIPE=1 2>&1 | tail -45 | tee $O/ab_pipe_trace.txt
+    (SEALHIP_KS_PIPE=1 timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "ks_chunked or batch256" > $O/pytest_pipe.txt 2>&1; echo "rc=$?" >> $O/pytest_pipe.txt); tail -3 $O/pytest_pipe.txt ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
