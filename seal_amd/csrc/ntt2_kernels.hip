@@ -25,6 +25,7 @@
 // the 2x16 running sums of (digit x key) per thread in registers and writes only the reduced sums:
 // the K(K+1) transformed digits never reach HBM in NTT form.
 #include "ntt2_kernels.h"
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -2516,7 +2517,7 @@ namespace sealhip
             // the outer items with the next tile in flight
             unsigned per = G::TILES * a.ncomp;
 #ifndef SEALHIP_NTT_WG_TARGET
-#define SEALHIP_NTT_WG_TARGET 4096
+#define SEALHIP_NTT_WG_TARGET 8192 // round 5: 8192 workgroups per launch +1.3 % on the 2^16 leg over 4096 (four same-box rounds), 2048 -4 %, 16384 +1 % (profiles/r05_ntt_grid_variants.txt)
 #endif
             unsigned chunks = (SEALHIP_NTT_WG_TARGET + per - 1) / per;
             if (chunks > nouter)
@@ -2690,6 +2691,16 @@ namespace sealhip
                 hipError_t e = hipGetLastError();
                 if (e != hipSuccess)
                     return e;
+                // development builds, TIMING ONLY (wrong words): the step without the inverse transforms' last pass - the most that
+                // fusing it into the next kernel's prologue could return (profiles/r05_inv_pb_fusion_bound.txt)
+                // (value = number of inverse launches that still run it: the warm-up leaves realistic words in the recycled buffers -
+                // with stale zeros in them the key switch's arithmetic draws less power and the chip clocks 10 % higher, which is not
+                // the saving being measured)
+                static const char *skip_env = shl_ab_getenv("SEALHIP_AB_SKIP_INV_PB");
+                static long skip_after = skip_env ? std::atol(skip_env) : -1;
+                static std::atomic<long> inv_launches{ 0 };
+                if (skip_after >= 0 && inv_launches.fetch_add(1) >= skip_after)
+                    return hipSuccess;
                 if (r.cls == 1)
                     hipLaunchKernelGGL((ntt2_inv_pb<D1, 1>), grid, dim3(kThreads), G::lds1_words * 8, st, g);
                 else if (r.cls == 0)

@@ -48,6 +48,12 @@ for what in "$@"; do
       p16r3:default:SEALHIP_KS_PIPE=1,SEALHIP_KS_CHUNK=16 p16r4:default:SEALHIP_KS_PIPE=1,SEALHIP_KS_CHUNK=16,SEALHIP_KS_LANES=4 p64r2:default:SEALHIP_KS_PIPE=1,SEALHIP_KS_CHUNK=64,SEALHIP_KS_LANES=2 2>&1 | tee $O/ab_pipe.txt
     SEALHIP_KS_PIPE=1 tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_pipe_trace p32r3:default:SEALHIP_KS_PIPE=1 2>&1 | tail -45 | tee $O/ab_pipe_trace.txt
     (SEALHIP_KS_PIPE=1 timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "ks_chunked or batch256" > $O/pytest_pipe.txt 2>&1; echo "rc=$?" >> $O/pytest_pipe.txt); tail -3 $O/pytest_pipe.txt ;;
+  pbbound)
+    tools/ab.sh --rounds ${ROUNDS:-3} --out gpurun_out/r05/ab_pbbound base:ab nopb:ab:SEALHIP_AB_SKIP_INV_PB=38 nopb0:ab:SEALHIP_AB_SKIP_INV_PB=0 2>&1 | tee $O/ab_pbbound.txt ;;
+  wg8k)
+    tools/ab.sh --rounds ${ROUNDS:-4} --workload ntt --out gpurun_out/r05/ab_wg8k base:default wg8k:wg8k 2>&1 | tee $O/ab_wg8k.txt
+    tools/ab.sh --rounds 2 --out gpurun_out/r05/ab_wg8k_head base:default wg8k:wg8k 2>&1 | tee $O/ab_wg8k_head.txt
+    tools/ab.sh --rounds 2 --workload bfv_c4 --out gpurun_out/r05/ab_wg8k_bfv base:default wg8k:wg8k 2>&1 | tee $O/ab_wg8k_bfv.txt ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
