@@ -2700,7 +2700,7 @@ namespace sealhip
                 static long skip_after = skip_env ? std::atol(skip_env) : -1;
                 static std::atomic<long> inv_launches{ 0 };
                 if (skip_after >= 0 && inv_launches.fetch_add(1) >= skip_after)
-                    return hipSuccess;
+                    return (hipError_t)hipSuccess;
                 if (r.cls == 1)
                     hipLaunchKernelGGL((ntt2_inv_pb<D1, 1>), grid, dim3(kThreads), G::lds1_words * 8, st, g);
                 else if (r.cls == 0)
