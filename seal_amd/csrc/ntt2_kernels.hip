@@ -115,6 +115,60 @@ namespace sealhip
         constexpr int kRowWords = 16 * 18;
         constexpr size_t kLds2Words = 16 * kRowWords;
 
+        // ---- Packed intermediate of the plain double-precision forward transform at N = 2^16 (round 5, SEALHIP_MID_PACK).
+        // Between the passes a residue of a prime below 2^50 is an integer with |x| <= q/2 < 2^49 held in a double: 64 bits for 50.
+        // x + 1.5 * 2^52 has x + 2^51 in its 52 mantissa bits (offset binary; one v_add_f64 each way), and the 16 values a pass-1
+        // thread owns - rows h_lo = 0..15 of one column of a 16 x 16 block - are stored as 13 words instead of 16:
+        //   words 0..7   the low 32 bits of values 2k, 2k+1           words 8..11  bits 32..47 of values 4(k-8) .. 4(k-8)+3
+        //   word 12      bits 48..51 of value r at bit 4r
+        // block (row tile hg, column block cg) = 13 x 16 words at mid + (hg*16 + cg) * 208, word k of column v at k*16 + v: pass 1
+        // stores 13 instead of 16 128-byte runs per thread, pass 2 loads a block's 208 words with coalesced 8-byte loads (thread
+        // (e, v) takes pack (cg = e, v)), decodes all sixteen rows and hands them to their owners (u, v) through LDS.
+        // 13/16 of the intermediate's bytes in both directions; the values are the same doubles, so the results are the same words.
+        constexpr unsigned kPackWords = 13, kPackBlock = kPackWords * 16; // words per pack / per 16 x 16 block
+        constexpr double kPackMagic = 6755399441055744.0;                  // 2^52 + 2^51
+        constexpr unsigned kPackLdsRow = 272;                              // words between the rows u of the hand-over buffer
+        __device__ __forceinline__ void pack52(const double (&x)[16], uint64_t (&w)[13])
+        {
+            uint32_t lo[16], hi[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const uint64_t b = fp_to_bits(x[r] + kPackMagic);
+                lo[r] = (uint32_t)b;
+                hi[r] = (uint32_t)(b >> 32) & 0xFFFFFu;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                w[k] = (uint64_t)lo[2 * k] | ((uint64_t)lo[2 * k + 1] << 32);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+            {
+                const uint32_t d0 = (hi[4 * k] & 0xFFFFu) | (hi[4 * k + 1] << 16), d1 = (hi[4 * k + 2] & 0xFFFFu) | (hi[4 * k + 3] << 16);
+                w[8 + k] = (uint64_t)d0 | ((uint64_t)d1 << 32);
+            }
+            uint32_t t0 = 0, t1 = 0;
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+            {
+                t0 |= (hi[r] >> 16) << (4 * r);
+                t1 |= (hi[r + 8] >> 16) << (4 * r);
+            }
+            w[12] = (uint64_t)t0 | ((uint64_t)t1 << 32);
+        }
+        __device__ __forceinline__ void unpack52(const uint64_t (&w)[13], double (&x)[16])
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+            {
+                const uint32_t lo = (uint32_t)(w[r >> 1] >> (32 * (r & 1)));
+                const uint32_t mid = (uint32_t)(w[8 + (r >> 2)] >> (16 * (r & 3))) & 0xFFFFu;
+                const uint32_t top = (uint32_t)(w[12] >> (4 * r)) & 0xFu;
+                const uint64_t b = (uint64_t)lo | ((uint64_t)(0x43300000u | (top << 16) | mid) << 32);
+                x[r] = fp_from_bits(b) - kPackMagic;
+            }
+        }
+
         // modulus class of the integer back end (field.h, IntBounds): 0 tight (2^58 <= q < 2^60), 1 roomy (q < 2^58), 2 wide
         // (q >= 2^60: SEAL's 61-bit internal moduli, the BEHZ auxiliary base, keep the reference's guarded butterflies); wave-uniform
         __device__ __forceinline__ int int_class(const NttTables &t, unsigned prime)
@@ -481,7 +535,7 @@ namespace sealhip
         // target's size: 1.13 -> 1.84 -> 2.69 -> 3.69 -> 4.88 -> 6.30 -> 7.98, then 0.5 -> 1.09 -> 1.80): the intermediate
         // leaves with |x| <= 1.80 q, unfixed, and the values leave p2_tile with |x| <= 2.64 q.
         // Integer back end: ICLS = modulus class; the sixteen values enter below 4 q and leave below kP1Out<ICLS, D1> q.
-        template <bool FP, int D1, int BS = 256, bool LEAN = false, int ICLS = 0>
+        template <bool FP, int D1, int BS = 256, bool LEAN = false, int ICLS = 0, bool PACK = false>
         __device__ __forceinline__ void p1_tile(
             typename Field<FP>::elem (&x)[16], const typename Field<FP>::Mod &m, const typename Field<FP>::tw_t *tab,
             const TwRegs<FP> &tw, uint64_t *lds, uint64_t *mid_tr, unsigned cg, unsigned tid)
@@ -518,6 +572,18 @@ namespace sealhip
             {
                 // the intermediate is stored with |x| <= q/2 resp. below kP1Out<ICLS, D1> q
                 phase_fwd_end<FP, 4, true, ICLS, IntBounds<ICLS>::fwd_after(4, G::rA)>(x, m, [&](int t, int g) { return tw.get((1 << t) + g); });
+            }
+            if constexpr (PACK)
+            {
+                static_assert(!PACK || (FP && D1 == 8 && BS == 256 && !LEAN), "the packed intermediate is defined for the plain double-precision pass at N = 2^16");
+                // packed intermediate (above): this thread's sixteen rows of column c of block (hg = hi, cg)
+                uint64_t w[13];
+                pack52(x, w);
+                uint64_t *o = mid_tr + (size_t)(hi * 16 + cg) * kPackBlock + c;
+#pragma unroll
+                for (int k = 0; k < 13; k++)
+                    mid_st<1>(o + k * 16, w[k]);
+                return;
             }
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
             const unsigned col = cg * G::C + c;
@@ -701,6 +767,7 @@ namespace sealhip
                 const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
                 mid_st<16>(rows + row * 256 + col, lds_wave[row * kRowWords + col + 2 * (col >> 4)]);
             }
+            __builtin_amdgcn_wave_barrier(); // a looping caller's next tile rewrites the buffer (program order in hardware; the emulator's lanes need it said)
         }
         // the same transposition, handing each coalesced (offset, value) pair to `sink`
         template <class Sink>
@@ -718,6 +785,7 @@ namespace sealhip
                 const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
                 sink(row * 256 + col, lds_wave[row * kRowWords + col + 2 * (col >> 4)]);
             }
+            __builtin_amdgcn_wave_barrier();
         }
         // emit_rows with the index k of the (offset, value) pair: k-th pair = offset (k >> 2) * 256 + (k & 3) * 64 + lane, so that a
         // caller can have loaded its other operands of these offsets ahead of time
@@ -736,6 +804,7 @@ namespace sealhip
                 const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
                 sink(k, row * 256 + col, lds_wave[row * kRowWords + col + 2 * (col >> 4)]);
             }
+            __builtin_amdgcn_wave_barrier();
         }
         __device__ __forceinline__ void load_rows(uint64_t (&val)[16], uint64_t *lds_wave, const uint64_t *rows, unsigned tid)
         {
@@ -781,10 +850,11 @@ namespace sealhip
             const ShoupOp *epi_mul;
             uint64_t *epi_out0, *epi_out1;
             size_t epi_out_stride;
+            int mid_pack; // the double-precision components' intermediate is packed (N = 2^16, plain transform: launch_fwd decides)
             NttTables t;
         };
 
-        template <bool FP, int D1, int ICLS = 0>
+        template <bool FP, int D1, int ICLS = 0, bool PACK = false>
         __device__ __forceinline__ void fwd_p1_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds, unsigned tile)
         {
             typedef Field<FP> F;
@@ -837,20 +907,25 @@ namespace sealhip
                     fetch(outer + ostride);
                 prio_phase<1>();
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
-                p1_tile<FP, D1, 256, false, ICLS>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                p1_tile<FP, D1, 256, false, ICLS, PACK>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
         }
 
         // CLS: 0 = every component of the launch uses the integer back end, 1 = the double-precision one,
         // 2 = decided per workgroup (costs the registers of both bodies)
         template <int D1, int CLS>
-        __global__ void __launch_bounds__(kThreads, CLS == 1 ? SEALHIP_FP_WAVES_P1 : 2) ntt2_fwd_p1(FwdArgs a)
+#ifndef SEALHIP_PACK_WAVES_P1
+#define SEALHIP_PACK_WAVES_P1 3 // the packing pass needs ~150 VGPRs; at 128 it spills 64 bytes per lane and runs 6 % slower than the plain pass
+#endif
+        __global__ void __launch_bounds__(kThreads, CLS == 5 ? SEALHIP_PACK_WAVES_P1 : CLS == 1 ? SEALHIP_FP_WAVES_P1 : 2) ntt2_fwd_p1(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const Blk blk = spread_blocks();
             const unsigned comp = blk.y + a.comp0, outer = blk.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
-            if constexpr (CLS == 1)
+            if constexpr (CLS == 5) // as 1, storing the packed intermediate (kPackWords; N = 2^16 only)
+                fwd_p1_body<true, D1, 0, D1 == 8>(a, prime, comp, outer, lds, blk.tile);
+            else if constexpr (CLS == 1)
                 fwd_p1_body<true, D1>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 0)
                 with_int_class(a.t, prime, [&](auto ic) { fwd_p1_body<false, D1, decltype(ic)::value>(a, prime, comp, outer, lds, blk.tile); });
@@ -866,7 +941,7 @@ namespace sealhip
         // only here.
         // HOIST_LDS (CLS 4): the row-shared phase-A twiddles are staged once in LDS and only the 15 per-thread phase-B twiddles
         // stay in registers: the same "no twiddle is re-read per transform" at 128 VGPRs (four waves per SIMD) instead of 214 (two)
-        template <bool FP, int D1, bool HOIST = false, bool HOIST_LDS = false, int ICLS = 0>
+        template <bool FP, int D1, bool HOIST = false, bool HOIST_LDS = false, int ICLS = 0, bool PACK = false>
         __device__ __forceinline__ void fwd_p2_body(const FwdArgs &a, unsigned prime, unsigned comp, unsigned outer, uint64_t *lds, unsigned tile)
         {
             typedef Field<FP> F;
@@ -883,6 +958,16 @@ namespace sealhip
                 for (int e = 0; e < 16; e++)
                     nxt[e] = mid_ld<4>(mp + e * kMidRow);
             };
+            // packed intermediate (kPackWords above): thread (e = tid >> 4, v = tid & 15) loads pack (cg = e, v) of this row tile
+            constexpr bool packed = PACK;
+            static_assert(!PACK || (FP && D1 == 8), "the packed intermediate is defined for the double-precision pass at N = 2^16");
+            [[maybe_unused]] const uint64_t *pk0 = a.mid + ((size_t)comp << G::n) + (size_t)(hg * 16 + (tid >> 4)) * kPackBlock + (tid & 15);
+            [[maybe_unused]] auto fetch_packed = [&](unsigned z) {
+                const uint64_t *mp = pk0 + (((size_t)z * a.ncomp) << G::n);
+#pragma unroll
+                for (int k = 0; k < 13; k++)
+                    nxt[k] = mid_ld<4>(mp + k * 16);
+            };
             const unsigned ostride = gridDim.z;
             TwRegs<FP> pre_a, pre_b;
             const typename F::tw_t *twa = nullptr;
@@ -898,10 +983,39 @@ namespace sealhip
             }
             else if constexpr (HOIST)
                 p2_load_tw<FP, D1>(pre_a, pre_b, tab, hg, tid);
-            fetch(outer);
+            if constexpr (packed)
+                fetch_packed(outer);
+            else
+                fetch(outer);
             for (; outer < a.nouter; outer += ostride)
             {
             typename F::elem x[16];
+            if constexpr (packed)
+            {
+                {
+                    // decode the pack's sixteen rows and hand row r to thread (u = r, v) through the exchange buffer:
+                    // word (u, e, v) at u * kPackLdsRow + e * 16 + v (writes: a wave's 64 consecutive words; reads: conflict-free)
+                    uint64_t w[13];
+#pragma unroll
+                    for (int k = 0; k < 13; k++)
+                        w[k] = nxt[k];
+                    if (outer + ostride < a.nouter)
+                        fetch_packed(outer + ostride);
+                    double y[16];
+                    unpack52(w, y);
+                    __syncthreads(); // the previous tile's transposes are done with the buffer
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        lds[r * kPackLdsRow + tid] = fp_to_bits(y[r]);
+                    __syncthreads();
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = fp_from_bits(lds[(tid >> 4) * kPackLdsRow + e * 16 + (tid & 15)]);
+                    __syncthreads(); // before any wave's exchange writes land in it
+                }
+            }
+            if constexpr (!packed)
+            {
 #pragma unroll
             for (int e = 0; e < 16; e++)
                 x[e] = F::unraw(nxt[e]);
@@ -909,6 +1023,7 @@ namespace sealhip
             if (outer + ostride < a.nouter)
                 fetch(outer + ostride);
             prio_phase<1>();
+            }
             if constexpr (HOIST_LDS)
                 p2_tile<FP, D1, false, false, true, true>(x, m, tab, twa, nullptr, lds_wave, hg, tid, &pre_a, &pre_b);
             else if constexpr (HOIST)
@@ -959,13 +1074,15 @@ namespace sealhip
         }
 
         template <int D1, int CLS>
-        __global__ void __launch_bounds__(kThreads, (CLS == 1 || CLS == 4) ? SEALHIP_FP_WAVES_P2 : 2) ntt2_fwd_p2(FwdArgs a)
+        __global__ void __launch_bounds__(kThreads, (CLS == 1 || CLS == 4 || CLS == 5) ? SEALHIP_FP_WAVES_P2 : 2) ntt2_fwd_p2(FwdArgs a)
         {
             HIP_DYNAMIC_SHARED(uint64_t, lds)
             const Blk blk = spread_blocks();
             const unsigned comp = blk.y + a.comp0, outer = blk.z;
             const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
-            if constexpr (CLS == 4) // as 3 with the row-shared half of the twiddles in LDS: four waves per SIMD
+            if constexpr (CLS == 5) // as 4, reading the packed intermediate (N = 2^16 only)
+                fwd_p2_body<true, D1, false, true, 0, D1 == 8>(a, prime, comp, outer, lds, blk.tile);
+            else if constexpr (CLS == 4) // as 3 with the row-shared half of the twiddles in LDS: four waves per SIMD
                 fwd_p2_body<true, D1, false, true>(a, prime, comp, outer, lds, blk.tile);
             else if constexpr (CLS == 3) // double-precision back end, plain transform, twiddles hoisted
                 fwd_p2_body<true, D1, true>(a, prime, comp, outer, lds, blk.tile);
@@ -2520,6 +2637,8 @@ namespace sealhip
 #define SEALHIP_NTT_WG_TARGET 8192 // round 5: 8192 workgroups per launch +1.3 % on the 2^16 leg over 4096 (four same-box rounds), 2048 -4 %, 16384 +1 % (profiles/r05_ntt_grid_variants.txt)
 #endif
             unsigned chunks = (SEALHIP_NTT_WG_TARGET + per - 1) / per;
+            if (const char *f = shl_ab_getenv("SEALHIP_NTT_CHUNKS")) // development / emulated builds: force the per-workgroup loop at small batches
+                chunks = (unsigned)std::atoi(f) ? (unsigned)std::atoi(f) : 1;
             if (chunks > nouter)
                 chunks = nouter;
             if (chunks > 65535)
@@ -2558,6 +2677,12 @@ namespace sealhip
             return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp, a.cls_hint), s, [&](const CompRun &r, hipStream_t st) {
                 FwdArgs g = a;
                 g.comp0 = r.c0;
+#ifndef SEALHIP_MID_PACK
+#define SEALHIP_MID_PACK 1
+#endif
+                // N = 2^16, plain transform, double-precision components: the intermediate in 13 words per 16 values (kPackWords)
+                // (only together with the hoisted pass 2, i.e. when the workgroups loop: the small-batch kernels stay as they are)
+                g.mid_pack = SEALHIP_MID_PACK && D1 == 8 && r.cls == 1 && a.epi == 0 && chunks < nouter ? 1 : 0;
                 if constexpr (D1 == 5 || D1 == 6)
                 {
                     if (fused && r.cls == 1)
@@ -2573,6 +2698,18 @@ namespace sealhip
                     }
                 }
                 dim3 grid(G::TILES, r.nc, chunks);
+                if constexpr (D1 == 8)
+                {
+                    if (g.mid_pack)
+                    {
+                        hipLaunchKernelGGL((ntt2_fwd_p1<D1, 5>), grid, dim3(kThreads), l1, st, g);
+                        hipError_t ep = hipGetLastError();
+                        if (ep != hipSuccess)
+                            return ep;
+                        hipLaunchKernelGGL((ntt2_fwd_p2<D1, 5>), grid, dim3(kThreads), (kLds2Words + 240) * 8, st, g);
+                        return hipGetLastError();
+                    }
+                }
                 if (r.cls == 1)
                     hipLaunchKernelGGL((ntt2_fwd_p1<D1, 1>), grid, dim3(kThreads), l1, st, g);
                 else if (r.cls == 0)
@@ -2853,6 +2990,7 @@ namespace sealhip
         a.epi_out0 = b.epi_out0;
         a.epi_out1 = b.epi_out1;
         a.epi_out_stride = b.epi_out_stride;
+        a.mid_pack = 0;
         a.t = t;
         if (b.tail2)
         {

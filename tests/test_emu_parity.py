@@ -291,6 +291,15 @@ def test_digit_parallel_reduce_scatter(emu, n, bits, parts, batch):
     assert P.case_digit_parallel_reduce_scatter(n, primes, parts=parts, batch=batch) is True  # loopback: no RCCL on this box
 
 
+def test_ntt_two_pass_loop_packed_intermediate(emu, monkeypatch):
+    """N = 2^16 / 2^15 with the per-workgroup loop forced at a small batch (SEALHIP_NTT_CHUNKS, development builds): pass 2 with hoisted
+    twiddles and, at 2^16, the packed 52-bit intermediate of the double-precision components (ntt2_kernels.hip: kPackWords) next to an
+    integer-class component that keeps the plain one"""
+    monkeypatch.setenv("SEALHIP_NTT_CHUNKS", "1")
+    P.case_ntt(65536, [50, 60, 40], polys=3)
+    P.case_ntt(32768, [50, 45], polys=3)
+
+
 def test_ks_chunked(emu):
     """chunked key switching (sealhip.h: SEALHIP_KS_CHUNK / SEALHIP_KS_LANES / SEALHIP_KS_SCRATCH_CAP_MIB): pointer arithmetic of the
     chunks, ragged last chunk, the folded CKKS tail over chunked sums, BFV's in-place target, the scratch cap"""

@@ -52,6 +52,14 @@ def test_ntt_single_launch_loop(gpu, monkeypatch, n, bits, polys, chunks):
     P.case_ntt(n, bits, polys=polys)
 
 
+# two-pass engine at N = 2^15 / 2^16 with batches large enough that every workgroup LOOPS over its share (next tile in flight,
+# pass 2's twiddles hoisted: ntt2_fwd_p2<D1, 4>) - the shape of bench.py's roofline leg, which no other test compares with the
+# reference - and, at 2^16, the packed intermediate of the double-precision components (ntt2_kernels.hip: kPackWords)
+@pytest.mark.parametrize("n,bits,polys", [(65536, [50, 40, 60], 400), (65536, [45, 50], 700), (32768, [50, 60, 50], 500)])
+def test_ntt_two_pass_loop(gpu, n, bits, polys):
+    P.case_ntt(n, bits, polys=polys)
+
+
 def test_dyadic(gpu):
     P.case_dyadic(4096, [60, 40, 30])
 

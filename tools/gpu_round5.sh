@@ -54,6 +54,16 @@ for what in "$@"; do
     tools/ab.sh --rounds ${ROUNDS:-4} --workload ntt --out gpurun_out/r05/ab_wg8k base:default wg8k:wg8k 2>&1 | tee $O/ab_wg8k.txt
     tools/ab.sh --rounds 2 --out gpurun_out/r05/ab_wg8k_head base:default wg8k:wg8k 2>&1 | tee $O/ab_wg8k_head.txt
     tools/ab.sh --rounds 2 --workload bfv_c4 --out gpurun_out/r05/ab_wg8k_bfv base:default wg8k:wg8k 2>&1 | tee $O/ab_wg8k_bfv.txt ;;
+  pack)
+    (timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "test_ntt" > $O/pytest_pack.txt 2>&1; echo "rc=$?" >> $O/pytest_pack.txt); tail -4 $O/pytest_pack.txt
+    tools/ab.sh --rounds ${ROUNDS:-3} --workload ntt --out gpurun_out/r05/ab_pack nopack:nopack pack:default packw4:packw4 2>&1 | tee $O/ab_pack.txt ;;
+  packtrace)
+    for v in default; do
+      if [ $v = default ]; then cp seal_amd/lib/libsealhip.so /tmp/keep.so; else cp seal_amd/lib/libsealhip.so /tmp/keep.so; cp seal_amd/lib/variants/$v.so seal_amd/lib/libsealhip.so; fi
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$v -o t -- python $REPO/bench.py --ntt-only $common > $O/prof_$v.log 2>&1)
+      DB=$(find $O/prof_$v -name "*.db" | head -1); python tools/rocpd_summary.py $DB | grep -E 'kernel|ntt2_fwd' | head -8; rm -rf $O/prof_$v
+      cp /tmp/keep.so seal_amd/lib/libsealhip.so
+    done ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
