@@ -264,7 +264,7 @@ namespace sealhip
         // the addresses they had during capture, so the caller refreshes the operands' contents in place and reads the
         // destinations after each replay.  Run the sequence once eagerly first (lazily built tables, pool warm-up), keep the
         // captured objects alive and do not resize them between replays.  At small batches the step is launch-bound on the
-        // host (about 25 kernel launches + stream fork/join per multiply+relinearize+rescale): see DESIGN.md section 5.
+        // host (about 25 kernel launches + stream fork/join per multiply+relinearize+rescale): see profiles/HISTORY.md section 5 ("Small batches / latency").
         // an executable graph together with the scratch blocks whose addresses it replays on (kept out of the pool until
         // the graph is destroyed)
         struct Graph

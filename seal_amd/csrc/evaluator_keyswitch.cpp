@@ -512,7 +512,7 @@ namespace sealhip
         // Small batches do not fill the chip: one workgroup per (target modulus, tile, batch item) is 16 (K+1) workgroups per
         // ciphertext at N = 2^16, each looping over all K digits, and only 2 x 16 of them for the two 60-bit moduli.  Cut the
         // digit loop into `split` in-launch groups (their partial sums are added by the reduce pass below): single-ciphertext
-        // latency of multiply+relinearize+rescale at C5 0.63 -> 0.40 ms.  SEALHIP_KS_SPLIT overrides (tests, A/B).
+        // latency of multiply+relinearize+rescale at C5 0.63 -> 0.40 ms (profiles/HISTORY.md section 5, "Small batches / latency").  SEALHIP_KS_SPLIT overrides (tests, A/B).
         const unsigned K = e.level()->K;
         unsigned split = 1;
         if (keys.context() == &context_ && key_index < keys.slots() && keys.has_key(key_index) && keys.key(key_index).register_order)
