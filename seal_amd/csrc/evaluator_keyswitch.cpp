@@ -65,8 +65,19 @@ namespace sealhip
             hipEvent_t join[kSide] = { nullptr, nullptr, nullptr };
             hipEvent_t fork = nullptr;
             unsigned made = 0;
+            int device = -1; // streams belong to the device that was current when they were made
             bool ensure(unsigned side)
             {
+                int dev = -1;
+                if (hipGetDevice(&dev) != hipSuccess)
+                    return false;
+                if (device != dev)
+                {
+                    // first use, or this host thread moved to another GPU (one process per GPU is the model; a thread that drives
+                    // several devices gets a fresh set - the old one is left to its device)
+                    *this = KsLanes();
+                    device = dev;
+                }
                 if (!fork && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess)
                     return false;
                 while (made < side && made < kSide)

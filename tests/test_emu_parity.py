@@ -300,6 +300,17 @@ def test_ntt_two_pass_loop_packed_intermediate(emu, monkeypatch):
     P.case_ntt(32768, [50, 45], polys=3)
 
 
+def test_digit_parallel_key_switch_in_chunks(emu, monkeypatch):
+    """the digit-parallel halves (switch_key_partial over a rank's digit range, *Finish with the deferred tail) when the batch is
+    cut into chunks on lanes - what a multi-GPU rotate_c5 at batch >= 48 runs: every emulated rank's slice in chunks of one item"""
+    monkeypatch.setenv("SEALHIP_KS_CHUNK", "1")
+    monkeypatch.setenv("SEALHIP_KS_LANES", "2")
+    c0, k0, _ = emu.ks_chunk_stats()
+    P.case_digit_parallel("ckks", 8192, coeff_modulus_create(8192, [50, 40, 60, 50, 50]), parts=2, batch=3)
+    c1, k1, _ = emu.ks_chunk_stats()
+    assert c1 > c0 and k1 - k0 >= 3 * (c1 - c0), "the partial key switches did not run in chunks"
+
+
 def test_ks_chunked(emu):
     """chunked key switching (sealhip.h: SEALHIP_KS_CHUNK / SEALHIP_KS_LANES / SEALHIP_KS_SCRATCH_CAP_MIB): pointer arithmetic of the
     chunks, ragged last chunk, the folded CKKS tail over chunked sums, BFV's in-place target, the scratch cap"""
