@@ -64,6 +64,13 @@ for what in "$@"; do
       DB=$(find $O/prof_$v -name "*.db" | head -1); python tools/rocpd_summary.py $DB | grep -E 'kernel|ntt2_fwd' | head -8; rm -rf $O/prof_$v
       cp /tmp/keep.so seal_amd/lib/libsealhip.so
     done ;;
+  fuzzchunk)
+    # random operation sequences, deferred tails and the soak with every key switch forced into chunks of ONE item on three lanes
+    (SEALHIP_KS_SPLIT=1 SEALHIP_KS_CHUNK=1 SEALHIP_KS_LANES=3 timeout 1200 python -m pytest tests/test_fuzz.py tests/test_soak.py tests/test_gpu_parity.py -m gpu -q -x -k "fuzz or sequences or soak or pipeline or deferred or north_star_batch16" > $O/pytest_fuzzchunk.txt 2>&1; echo "rc=$?" >> $O/pytest_fuzzchunk.txt); tail -5 $O/pytest_fuzzchunk.txt
+    python - <<PY
+import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
+PY
+    ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
