@@ -580,9 +580,17 @@ namespace sealhip
                 uint64_t w[13];
                 pack52(x, w);
                 uint64_t *o = mid_tr + (size_t)(hi * 16 + cg) * kPackBlock + c;
+#ifdef SEALHIP_P1_NOSTORE
+                uint64_t sink = 0; // measurement build: one word per thread keeps the arithmetic alive
+#pragma unroll
+                for (int k = 0; k < 13; k++)
+                    sink ^= w[k];
+                mid_st<1>(o, sink);
+#else
 #pragma unroll
                 for (int k = 0; k < 13; k++)
                     mid_st<1>(o + k * 16, w[k]);
+#endif
                 return;
             }
             // tile order: ((hg*16 + col_hi)*16 + h_lo)*16 + col_lo, hg = ra, h_lo = rb, col = cg*C + c
@@ -891,7 +899,11 @@ namespace sealhip
                 {
                     const unsigned ra = e >> (4 - G::rA), rbh = e & ((1 << (4 - G::rA)) - 1);
                     const unsigned R = ra * 16 + (rbh << G::rA) + rbl;
+#ifdef SEALHIP_P1_NOLOAD
+                    nxt[e] = (uint64_t)(tid * 16 + e + z * 4099u + R) & 0xFFFFFFFFFFFFull; // measurement build: no loads (any word below 2^48 does)
+#else
                     nxt[e] = a.src ? in[(size_t)R * 256] : mid_ld<16>(in + (size_t)R * 256); // (a mapped source is shared by the components)
+#endif
                 }
             };
             const unsigned ostride = gridDim.z;

@@ -71,6 +71,14 @@ for what in "$@"; do
 import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
 PY
     ;;
+  p1bound)
+    # per-kernel averages of pass 1 with its loads / stores / both removed (timing only: wrong words)
+    for v in default p1noload p1nostore p1nomem; do
+      cp seal_amd/lib/libsealhip.so /tmp/keep.so; [ $v = default ] || cp seal_amd/lib/variants/$v.so seal_amd/lib/libsealhip.so
+      (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$v -o t -- python $REPO/bench.py --ntt-only $common > $O/prof_$v.log 2>&1)
+      DB=$(find $O/prof_$v -name "*.db" | head -1); echo "== $v: $(tail -1 $O/prof_$v.log | python -c 'import json,sys; j=json.loads(sys.stdin.read())["roofline"]; print(j["achieved"], "GB/s", j["ms_per_launch"], "ms per launch")')"; python tools/rocpd_summary.py $DB | grep -E 'ntt2_fwd_p' | head -4; rm -rf $O/prof_$v
+      cp /tmp/keep.so seal_amd/lib/libsealhip.so
+    done ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
