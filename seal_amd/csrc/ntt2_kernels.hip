@@ -116,7 +116,8 @@ namespace sealhip
         constexpr size_t kLds2Words = 16 * kRowWords;
 
         // ---- Packed intermediate of the plain double-precision forward transform at N = 2^16 (round 5, SEALHIP_MID_PACK).
-        // Between the passes a residue of a prime below 2^50 is an integer with |x| <= q/2 < 2^49 held in a double: 64 bits for 50.
+        // Between the passes a residue of a prime below 2^50 is an integer with |x| <= q/2 < 2^49 held in a double (1.80 q < 2^51 with
+        // the lean fix() placement): 64 bits for at most 52.
         // x + 1.5 * 2^52 has x + 2^51 in its 52 mantissa bits (offset binary; one v_add_f64 each way), and the 16 values a pass-1
         // thread owns - rows h_lo = 0..15 of one column of a 16 x 16 block - are stored as 13 words instead of 16:
         //   words 0..7   the low 32 bits of values 2k, 2k+1           words 8..11  bits 32..47 of values 4(k-8) .. 4(k-8)+3
@@ -575,7 +576,7 @@ namespace sealhip
             }
             if constexpr (PACK)
             {
-                static_assert(!PACK || (FP && D1 == 8 && BS == 256 && !LEAN), "the packed intermediate is defined for the plain double-precision pass at N = 2^16");
+                static_assert(!PACK || (FP && D1 == 8 && BS == 256), "the packed intermediate is defined for the plain double-precision pass at N = 2^16");
                 // packed intermediate (above): this thread's sixteen rows of column c of block (hg = hi, cg)
                 uint64_t w[13];
                 pack52(x, w);
@@ -919,7 +920,15 @@ namespace sealhip
                     fetch(outer + ostride);
                 prio_phase<1>();
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
-                p1_tile<FP, D1, 256, false, ICLS, PACK>(x, m, tab, tw, lds, mid_tr, cg, tid);
+                // SEALHIP_P1_PLAIN_LEAN=1 (measured, not kept: 2925 vs 2941 GB/s on the leg, profiles/r05_p1_bound.txt): double precision,
+                // eight stages - every source mapping hands over |x| <= q (+ 2^32) <= kLeanEntry q, so ONE fix() after stage 6 would do
+                // (1.0 -> 1.69 -> 2.50 -> 3.47 -> 4.63 -> 5.99 -> 7.61 < 8, fix, -> 1.09 -> 1.80; the intermediate then leaves at 1.80 q,
+                // 52 bits when packed, which pass 2's first phase takes): 48 of the ~700 vector instructions per wave and tile less, and
+                // no time - what the pass waits for without memory traffic is its LDS exchange and barriers, not its issue slots
+#ifndef SEALHIP_P1_PLAIN_LEAN
+#define SEALHIP_P1_PLAIN_LEAN 0
+#endif
+                p1_tile<FP, D1, 256, SEALHIP_P1_PLAIN_LEAN && FP && G::rA == 4, ICLS, PACK>(x, m, tab, tw, lds, mid_tr, cg, tid);
             }
         }
 

@@ -79,6 +79,10 @@ PY
       DB=$(find $O/prof_$v -name "*.db" | head -1); echo "== $v: $(tail -1 $O/prof_$v.log | python -c 'import json,sys; j=json.loads(sys.stdin.read())["roofline"]; print(j["achieved"], "GB/s", j["ms_per_launch"], "ms per launch")')"; python tools/rocpd_summary.py $DB | grep -E 'ntt2_fwd_p' | head -4; rm -rf $O/prof_$v
       cp /tmp/keep.so seal_amd/lib/libsealhip.so
     done ;;
+  lean1)
+    (timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "test_ntt or north_star_config or bfv_pipeline" > $O/pytest_lean1.txt 2>&1; echo "rc=$?" >> $O/pytest_lean1.txt); tail -3 $O/pytest_lean1.txt
+    tools/ab.sh --rounds ${ROUNDS:-3} --workload ntt --out gpurun_out/r05/ab_lean1 before:nolean1 lean:default 2>&1 | tee $O/ab_lean1.txt
+    tools/ab.sh --rounds 2 --out gpurun_out/r05/ab_lean1_head before:nolean1 lean:default 2>&1 | tee $O/ab_lean1_head.txt ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
