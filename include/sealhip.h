@@ -282,7 +282,11 @@ SHL_FUNC Evaluator_Destroy(void *thisptr);
  * (destination != encrypted) runs on the same stream as the operation.  Three families have no such copy - the result is written
  * straight into `destination` and `encrypted` is only read: Evaluator_Multiply (CKKS 2 x 2 and BFV), and Evaluator_ApplyGalois /
  * RotateRows / RotateColumns / RotateVector / ComplexConjugate when the exact Galois key is present (the reference's
- * "destination = encrypted; op_inplace(destination)", evaluator.h:239-247, 1072-1315, gives the same words). */
+ * "destination = encrypted; op_inplace(destination)", evaluator.h:239-247, 1072-1315, gives the same words).  What differs from
+ * the reference is the FAILURE path of these copy-free forms only: the reference has copied the operand into the destination
+ * before it validates, so a call that throws leaves a copy of `encrypted` there; here a call that fails its argument checks
+ * leaves a separate destination untouched, and a Galois form that fails later (key switch, transparent-ciphertext check) leaves
+ * it EMPTY (released) rather than half-built.  The HRESULT and the exception class are the reference's either way. */
 SHL_FUNC Evaluator_SetStream(void *thisptr, void *hip_stream);
 /* library extension: destination := encrypted, ordered on the evaluator's stream (Ciphertext_Set copies on the calling thread's
  * stream); what a pipeline over several evaluators / streams uses to stage its inputs */
