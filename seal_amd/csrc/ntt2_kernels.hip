@@ -2813,7 +2813,11 @@ namespace sealhip
                         raised = true;
                     }
                     fused = true;
-                    const unsigned want = D1 == 5 ? 2048 : 1024;
+#ifndef SEALHIP_FUSED_INV_WANT13
+#define SEALHIP_FUSED_INV_WANT13 8192 // round 5: the 2^13 INVERSE gains 3.4 % from four times the workgroups (shorter loops: its phase-B twiddles are
+                                      // re-read per transform anyway), the forward does not (profiles/r05_configs1_bisect.txt)
+#endif
+                    const unsigned want = D1 == 5 ? SEALHIP_FUSED_INV_WANT13 : 1024;
                     fchunks = (want + a.ncomp - 1) / a.ncomp;
                     if (const char *f = std::getenv("SEALHIP_NTT_FCHUNKS"))
                         fchunks = (unsigned)std::atoi(f) ? (unsigned)std::atoi(f) : 1;

@@ -83,6 +83,11 @@ PY
     (timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "test_ntt or north_star_config or bfv_pipeline" > $O/pytest_lean1.txt 2>&1; echo "rc=$?" >> $O/pytest_lean1.txt); tail -3 $O/pytest_lean1.txt
     tools/ab.sh --rounds ${ROUNDS:-3} --workload ntt --out gpurun_out/r05/ab_lean1 before:nolean1 lean:default 2>&1 | tee $O/ab_lean1.txt
     tools/ab.sh --rounds 2 --out gpurun_out/r05/ab_lean1_head before:nolean1 lean:default 2>&1 | tee $O/ab_lean1_head.txt ;;
+  fchunks)
+    tools/ab.sh --rounds 2 --workload c2 --out gpurun_out/r05/ab_fchunks def:default f256:default:SEALHIP_NTT_FCHUNKS=256 f512:default:SEALHIP_NTT_FCHUNKS=512 f2048:default:SEALHIP_NTT_FCHUNKS=2048 f4096:default:SEALHIP_NTT_FCHUNKS=4096 2>&1 | tee $O/ab_fchunks.txt ;;
+  invwant)
+    tools/ab.sh --rounds 3 --workload c2 --out gpurun_out/r05/ab_invwant before:invw2k after:default 2>&1 | tee $O/ab_invwant.txt
+    (timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "test_ntt" > $O/pytest_invwant.txt 2>&1; echo "rc=$?" >> $O/pytest_invwant.txt); tail -3 $O/pytest_invwant.txt ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
