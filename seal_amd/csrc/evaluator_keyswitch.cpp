@@ -5,15 +5,16 @@ namespace sealhip
 {
     namespace
     {
-        // ---- Chunked, lane-pipelined key switching (round 5; VERDICT r4 "missing" 4 and "weak" 3).
+        // ---- Chunked key switching on forked lanes (round 5; VERDICT r4 "missing" 4).
         // The fused key switch is two kernels per arithmetic class: ks1t writes the K(K+1) half-transformed digits of every
-        // ciphertext (126 MB per C5 ciphertext) - it is bound by the store rate of the memory system - and ks2 reads them back
-        // and multiplies them into the key - it is bound by vector-ALU issue.  Run over the whole batch one after the other they
-        // leave the ALUs idle during the first and the memory system half idle during the second, and the intermediate of the
-        // WHOLE batch is resident (32 GB at batch 256, 258 GB at batch 2048) where the reference's switch_key_inplace holds
-        // O(K N) per ciphertext (evaluator.cpp:2561-2867).  So the batch is cut into chunks that go round-robin to `lanes`
-        // streams, each with its own chunk-sized intermediate: chunk c's ks2 shares the chip with chunk c+1's inverse transform
-        // and ks1t, and the scratch is lanes x chunk items whatever the batch.
+        // ciphertext (126 MB per C5 ciphertext), ks2 reads them back and multiplies them into the key.  Run over the whole batch
+        // the intermediate of the WHOLE batch is resident (32 GB at batch 256, 258 GB at batch 2048) where the reference's
+        // switch_key_inplace holds O(K N) per ciphertext (evaluator.cpp:2561-2867).  So the batch is cut into chunks that go
+        // round-robin to `lanes` streams forked from / joined to the evaluator's stream, each lane with its own chunk-sized
+        // intermediate (and the inverse transform of its chunk's target): the scratch is lanes x chunk items whatever the batch.
+        // What the lanes buy is the launch tails of the chunks (one lane: -2.1 %; three: +0.7 % +- 0.7 against one launch over the
+        // batch) - NOT an overlap of the two passes: both need the vector ALU, side by side each runs slower by what the other
+        // takes, staggered or in lockstep (profiles/r05_ks_chunked.txt).
         struct KsPlan
         {
             unsigned chunk; // items per chunk

@@ -2764,7 +2764,10 @@ namespace sealhip
         {
             typedef Geo<D1> G;
             unsigned per = G::TILES * a.f.ncomp;
-            unsigned chunks = (4096 + per - 1) / per;
+#ifndef SEALHIP_TAIL2_WG_TARGET
+#define SEALHIP_TAIL2_WG_TARGET 4096
+#endif
+            unsigned chunks = (SEALHIP_TAIL2_WG_TARGET + per - 1) / per;
             if (chunks > nouter)
                 chunks = nouter;
             if (chunks > 65535)

@@ -88,6 +88,9 @@ PY
   invwant)
     tools/ab.sh --rounds 3 --workload c2 --out gpurun_out/r05/ab_invwant before:invw2k after:default 2>&1 | tee $O/ab_invwant.txt
     (timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "test_ntt" > $O/pytest_invwant.txt 2>&1; echo "rc=$?" >> $O/pytest_invwant.txt); tail -3 $O/pytest_invwant.txt ;;
+  t2wg)
+    tools/ab.sh --rounds 3 --out gpurun_out/r05/ab_t2wg base:default t2wg2k:t2wg2k t2wg8k:t2wg8k t2wg16k:t2wg16k 2>&1 | tee $O/ab_t2wg.txt
+    tools/ab.sh --rounds 2 --workload rotate_c5 --out gpurun_out/r05/ab_t2wg_rot base:default t2wg8k:t2wg8k t2wg16k:t2wg16k 2>&1 | tee $O/ab_t2wg_rot.txt ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)
