@@ -2816,12 +2816,13 @@ namespace sealhip
                         raised = true;
                     }
                     fused = true;
-#ifndef SEALHIP_FUSED_INV_WANT13
-#define SEALHIP_FUSED_INV_WANT13 8192 // round 5: the 2^13 INVERSE gains 3.4 % from four times the workgroups (shorter loops: its phase-B twiddles are
-                                      // re-read per transform anyway), the forward does not (profiles/r05_configs1_bisect.txt)
-#endif
-                    const unsigned want = D1 == 5 ? SEALHIP_FUSED_INV_WANT13 : 1024;
+                    const unsigned want = D1 == 5 ? 2048 : 1024;
                     fchunks = (want + a.ncomp - 1) / a.ncomp;
+                    // round 5 (profiles/r05_configs1_bisect.txt): the 2^13 inverse re-reads its phase-B twiddles per transform anyway, so
+                    // long loops buy it nothing - about FOUR transforms per workgroup is its optimum (8192 polynomials: 2048 workgroups
+                    // per component +3.3 % over 512; 4096 polynomials: 1024 = 512, 2048 - two transforms each - loses 5 %)
+                    if (D1 == 5 && nouter / 4 > fchunks)
+                        fchunks = nouter / 4;
                     if (const char *f = std::getenv("SEALHIP_NTT_FCHUNKS"))
                         fchunks = (unsigned)std::atoi(f) ? (unsigned)std::atoi(f) : 1;
                     if (fchunks > nouter)
