@@ -7,9 +7,19 @@
 #   c2        configs[1] chain: default vs -DSEALHIP_KS_NT=0 (variants/nt0.so), 5 processes each
 #   newtests  the GPU tests added this round
 #   bfvpmc    counter pass over the bfv_c4 workload (behz_*, ntt2_*<7,0>, ks2<7,0>)
+#   chunk2 chunktrace pipe mall nttvar wg8k pack packtrace p1bound lean1 pbbound fchunks invwant t2wg bfvtrace2 multi fuzzchunk
+#             the other A/Bs and traces of the round, each behind the profiles/r05_* file that quotes it
 #   tests     pytest -m gpu + smoke
 #   bench     python bench.py (default line)
 #   trace     rocprofv3 --kernel-trace --stats of a short bench + the step's time line
+# Library variants the A/B sections name (seal_amd/lib/variants/NAME.so; build first with tools/quick/build_variant.sh NAME "FLAGS"):
+#   prio1 / prio2   -DSEALHIP_PRIO=1 / =2            nt0      -DSEALHIP_KS_NT=0           p2w2 / p1w2  -DSEALHIP_FP_WAVES_P2=2 / _P1=2
+#   wg2k/8k/16k     -DSEALHIP_NTT_WG_TARGET=2048 ... (8192 is the default since)          nopack   -DSEALHIP_MID_PACK=0
+#   packw4          -DSEALHIP_PACK_WAVES_P1=4        nolean1  -DSEALHIP_P1_PLAIN_LEAN=0 (the default since; =1 is the variant now)
+#   p1noload / p1nostore / p1nomem   -DSEALHIP_P1_NOLOAD / -DSEALHIP_P1_NOSTORE / both      t2wg2k/8k/16k  -DSEALHIP_TAIL2_WG_TARGET=...
+#   ab              "" (development switches only: SEALHIP_AB_SKIP_INV_PB for pbbound)      invw2k   (removed: the inverse's rule is in the launcher)
+# Sections whose experiment code was removed again (pipe: SEALHIP_KS_PIPE; mall: SEALHIP_NTT_CHUNK_MIB) are kept as the record of the
+# command line behind profiles/r05_ks_chunked.txt / r05_ntt_mall_chunks.txt.
 set -u
 export TMPDIR=/tmp
 REPO=$(pwd); O=$REPO/gpurun_out/r05; mkdir -p $O
