@@ -2714,6 +2714,8 @@ namespace sealhip
                     if (fused && r.cls == 0 && fused_int())
                     {
                         constexpr size_t lds_int = FusedGeo<D1, 2>::lds_bytes;
+                        // (workgroups per component of the integer class alone, 256 ... 4096 at 4096 polynomials: the default is the best
+                        // or equal, profiles/r05_configs1_bisect.txt)
                         hipLaunchKernelGGL((ntt2_fwd_fused2<D1, 0>), dim3(1, r.nc, fchunks), dim3(FusedGeo<D1>::TEAMS * kThreads), lds_int, st, g);
                         return hipGetLastError();
                     }
