@@ -3,17 +3,21 @@
 // grid-stride over a capped grid (256 CUs x 8 workgroups).  See poly_kernels.h for the map to
 // the reference functions.
 #include "poly_kernels.h"
+#include <cstdlib>
 
 namespace sealhip
 {
     namespace
     {
         constexpr unsigned kBlock = 256;
+#ifndef SEALHIP_EW_GRID_CAP
+#define SEALHIP_EW_GRID_CAP 2048
+#endif
         inline unsigned grid_for(size_t work)
         {
             size_t b = (work + kBlock - 1) / kBlock;
-            if (b > 2048)
-                b = 2048;
+            if (b > SEALHIP_EW_GRID_CAP)
+                b = SEALHIP_EW_GRID_CAP;
             if (b == 0)
                 b = 1;
             return (unsigned)b;
@@ -66,6 +70,62 @@ namespace sealhip
                 out[plane_words + i] = barrett128(lo, hi, md);
                 out[2 * plane_words + i] = mul_mod(x1, y1, md);
             }
+        }
+
+        // The same product in the shape this memory system streams fastest (round 5): ONE 4 KiB chunk per workgroup, two consecutive
+        // words (16 bytes) per thread, no grid-stride loop - a float4 copy of that shape moves 6.2 - 6.3 TB/s where the persistent
+        // 2048-workgroup loop above moves 4.6 - 5.3 (profiles/r03_microbench_copy_shapes2.txt).  Same arithmetic, same words.
+        // words_pairs = plane_words / 2 (plane_words even, N >= 128: the 128 words of a wave belong to one component).
+        __global__ void __launch_bounds__(kBlock) ckks_multiply_2x2_wide_kernel(
+            const ModDesc *mods, const FpDesc *fpd, const uint32_t *comp_prime, const uint64_t *x, const uint64_t *y, uint64_t *out,
+            unsigned n_log, unsigned K, size_t plane_words)
+        {
+            const size_t p = blockIdx.x * (size_t)kBlock + threadIdx.x; // pair index
+            const size_t i = 2 * p;
+            if (i >= plane_words)
+                return;
+            const unsigned comp = (unsigned)((i >> n_log) % K);
+            const unsigned prime = comp_prime ? comp_prime[comp] : comp;
+            typedef ulonglong2 w2;
+            const w2 x0 = *reinterpret_cast<const w2 *>(x + i), x1 = *reinterpret_cast<const w2 *>(x + plane_words + i);
+            const w2 y0 = *reinterpret_cast<const w2 *>(y + i), y1 = *reinterpret_cast<const w2 *>(y + plane_words + i);
+            uint64_t r0[2], r1[2], r2[2];
+            const uint64_t xa[2] = { x0.x, x0.y }, xb[2] = { x1.x, x1.y }, ya[2] = { y0.x, y0.y }, yb[2] = { y1.x, y1.y };
+            FpDesc f{};
+            if (fpd)
+                f = ld_uniform_fpd(&fpd[SHL_UNIFORM(prime)]);
+            if (f.qi)
+            {
+                auto one = [&](uint64_t xa, uint64_t xb, uint64_t ya, uint64_t yb, uint64_t &r0, uint64_t &r1, uint64_t &r2) {
+                    const double a0 = fp_from_u52(xa), a1 = fp_from_u52(xb), b0 = fp_from_u52(ya), b1 = fp_from_u52(yb);
+                    const double r00 = fp_mulmod(a0, b0, f.q, f.qinv), r11 = fp_mulmod(a1, b1, f.q, f.qinv);
+                    const double mid = fp_mulmod(a0, b1, f.q, f.qinv) + fp_mulmod(a1, b0, f.q, f.qinv);
+                    r0 = fp_to_canon(r00, f);
+                    r1 = fp_to_canon(fp_fix(mid, f.q, f.qinv), f);
+                    r2 = fp_to_canon(r11, f);
+                };
+                one(xa[0], xb[0], ya[0], yb[0], r0[0], r1[0], r2[0]);
+                one(xa[1], xb[1], ya[1], yb[1], r0[1], r1[1], r2[1]);
+            }
+            else
+            {
+                const ModDesc md = mods[prime];
+                auto one = [&](uint64_t xa, uint64_t xb, uint64_t ya, uint64_t yb, uint64_t &r0, uint64_t &r1, uint64_t &r2) {
+                    uint64_t lo = 0, hi = 0;
+                    mac128(lo, hi, xa, yb);
+                    mac128(lo, hi, xb, ya);
+                    r0 = mul_mod(xa, ya, md);
+                    r1 = barrett128(lo, hi, md);
+                    r2 = mul_mod(xb, yb, md);
+                };
+                one(xa[0], xb[0], ya[0], yb[0], r0[0], r1[0], r2[0]);
+                one(xa[1], xb[1], ya[1], yb[1], r0[1], r1[1], r2[1]);
+            }
+            w2 o0, o1, o2;
+            o0.x = r0[0], o0.y = r0[1], o1.x = r1[0], o1.y = r1[1], o2.x = r2[0], o2.y = r2[1];
+            *reinterpret_cast<w2 *>(out + i) = o0;
+            *reinterpret_cast<w2 *>(out + plane_words + i) = o1;
+            *reinterpret_cast<w2 *>(out + 2 * plane_words + i) = o2;
         }
 
         __global__ void __launch_bounds__(kBlock) multiply_general_kernel(
@@ -676,6 +736,21 @@ namespace sealhip
         hipStream_t s)
     {
         size_t w = g.words();
+#ifndef SEALHIP_TENSOR_WIDE
+#define SEALHIP_TENSOR_WIDE 1
+#endif
+        // large batches: one 4 KiB chunk per workgroup, 16 bytes per thread (ckks_multiply_2x2_wide_kernel); the grid-stride kernel keeps
+        // the small ones, where a launch of a few workgroups is all there is
+        const size_t pairs = w / 2, wide_blocks = (pairs + kBlock - 1) / kBlock;
+        static const char *min_env = shl_ab_getenv("SEALHIP_TENSOR_WIDE_MIN"); // development / emulated builds: take the wide kernel from this many workgroups on
+        const size_t wide_min = min_env ? (size_t)std::atol(min_env) : 2048;
+        if (SEALHIP_TENSOR_WIDE && g.n_log >= 7 && w % 2 == 0 && wide_blocks > wide_min && wide_blocks < (size_t)0x7fffffff &&
+            ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)out % 16 == 0))
+        {
+            hipLaunchKernelGGL(ckks_multiply_2x2_wide_kernel, dim3((unsigned)wide_blocks), dim3(kBlock), 0, s, mods, fpd, comp_prime, x, y, out,
+                               g.n_log, g.K, w);
+            return hipGetLastError();
+        }
         hipLaunchKernelGGL(
             ckks_multiply_2x2_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, fpd, comp_prime, x, y, out, g.n_log, g.K, w);
         return hipGetLastError();

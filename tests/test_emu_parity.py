@@ -311,6 +311,14 @@ def test_digit_parallel_key_switch_in_chunks(emu, monkeypatch):
     assert c1 > c0 and k1 - k0 >= 3 * (c1 - c0), "the partial key switches did not run in chunks"
 
 
+def test_ckks_tensor_product_wide_kernel(emu, monkeypatch):
+    """the CKKS 2 x 2 product in its large-batch shape (one 4 KiB chunk per workgroup, 16 bytes per thread: poly_kernels.hip,
+    ckks_multiply_2x2_wide_kernel) forced at a small batch: both arithmetic classes, the ragged last workgroup"""
+    monkeypatch.setenv("SEALHIP_TENSOR_WIDE_MIN", "0")
+    P.case_ckks_pipeline(8192, [60, 40, 50, 60], batch=1, steps=(), check_transforms=False)
+    P.case_product_growth("ckks", 4096, [54, 42, 55])
+
+
 def test_ks_chunked(emu):
     """chunked key switching (sealhip.h: SEALHIP_KS_CHUNK / SEALHIP_KS_LANES / SEALHIP_KS_SCRATCH_CAP_MIB): pointer arithmetic of the
     chunks, ragged last chunk, the folded CKKS tail over chunked sums, BFV's in-place target, the scratch cap"""

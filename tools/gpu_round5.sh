@@ -101,6 +101,13 @@ PY
   t2wg)
     tools/ab.sh --rounds 3 --out gpurun_out/r05/ab_t2wg base:default t2wg2k:t2wg2k t2wg8k:t2wg8k t2wg16k:t2wg16k 2>&1 | tee $O/ab_t2wg.txt
     tools/ab.sh --rounds 2 --workload rotate_c5 --out gpurun_out/r05/ab_t2wg_rot base:default t2wg8k:t2wg8k t2wg16k:t2wg16k 2>&1 | tee $O/ab_t2wg_rot.txt ;;
+  wide)
+    (timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "north_star or batch1024 or ckks_pipeline" > $O/pytest_wide.txt 2>&1; echo "rc=$?" >> $O/pytest_wide.txt); tail -3 $O/pytest_wide.txt
+    tools/ab.sh --rounds ${ROUNDS:-3} --trace --out gpurun_out/r05/ab_wide before:nowide wide:default 2>&1 | grep -E 'round|ckks_multiply|== ' | tee $O/ab_wide.txt ;;
+  ewgrid)
+    tools/ab.sh --rounds 2 --workload bfv_c4 --out gpurun_out/r05/ab_ew_bfv base:default ewfull:ewfull ew16k:ew16k 2>&1 | tee $O/ab_ew_bfv.txt
+    tools/ab.sh --rounds 2 --workload rotate_c5 --out gpurun_out/r05/ab_ew_rot base:default ewfull:ewfull ew16k:ew16k 2>&1 | tee $O/ab_ew_rot.txt
+    tools/ab.sh --rounds 2 --out gpurun_out/r05/ab_ew_head base:default ewfull:ewfull ew16k:ew16k 2>&1 | tee $O/ab_ew_head.txt ;;
   chunktrace)
     tools/ab.sh --rounds 1 --trace --out gpurun_out/r05/ab_chunk_trace c32x2:default 2>&1 | tee $O/ab_chunk_trace.txt ;;
   prio)

@@ -19,7 +19,7 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
-    ap.add_argument("--anchor", default="ckks_multiply_2x2_kernel")
+    ap.add_argument("--anchor", default="ckks_multiply_2x2")
     ap.add_argument("--step", type=int, default=-2, help="index of the anchor dispatch that starts the step (default: the one before last)")
     ap.add_argument("--tail", type=int, default=0, help="no anchor: list the last TAIL dispatches of the trace (workloads without the headline's first kernel)")
     args = ap.parse_args()
