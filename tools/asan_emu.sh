@@ -27,6 +27,15 @@ for which in sys.argv[2:]:
         P.case_ckks_pipeline(65536, [60, 50, 50, 60], batch=1, steps=(1,), check_transforms=False)
     elif which == "bfv":
         primes, t = P.default_bfv_params(8192, [50, 55, 56], 20); P.case_bfv_pipeline(8192, primes, t, batch=1)
+    elif which == "chunks":   # round 5: chunked key switch on lanes, digit-parallel in chunks
+        from oracle import coeff_modulus_create, plain_modulus_batching
+        P.case_ks_chunked("ckks", 8192, [50, 40, 40, 50], batch=5, chunk=2, lanes=2)
+        P.case_ks_chunked("bfv", 8192, coeff_modulus_create(8192, [45, 40, 45]), batch=4, chunk=1, lanes=3, t=plain_modulus_batching(8192, 20))
+    elif which == "pack":     # round 5: looped two-pass transforms, packed intermediate at N = 2^16, wide tensor product
+        os.environ["SEALHIP_NTT_CHUNKS"] = "1"; os.environ["SEALHIP_TENSOR_WIDE_MIN"] = "0"
+        P.case_ntt(65536, [50, 60, 40], polys=3); P.case_ntt(32768, [50, 45], polys=3)
+        P.case_product_growth("ckks", 4096, [54, 42, 55])
+        del os.environ["SEALHIP_NTT_CHUNKS"]; del os.environ["SEALHIP_TENSOR_WIDE_MIN"]
     elif which == "fuzz":
         n = 0
         for seed in (11, 12):
