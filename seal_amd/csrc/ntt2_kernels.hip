@@ -1013,29 +1013,27 @@ namespace sealhip
             typename F::elem x[16];
             if constexpr (packed)
             {
-                {
-                    // decode the pack's sixteen rows and hand row r to thread (u = r, v) through the exchange buffer:
-                    // word (u, e, v) at u * kPackLdsRow + e * 16 + v (writes: a wave's 64 consecutive words; reads: conflict-free)
-                    uint64_t w[13];
+                // decode the pack's sixteen rows and hand row r to thread (u = r, v) through the exchange buffer:
+                // word (u, e, v) at u * kPackLdsRow + e * 16 + v (writes: a wave's 64 consecutive words; reads: conflict-free)
+                uint64_t w[13];
 #pragma unroll
-                    for (int k = 0; k < 13; k++)
-                        w[k] = nxt[k];
-                    if (outer + ostride < a.nouter)
-                        fetch_packed(outer + ostride);
-                    double y[16];
-                    unpack52(w, y);
-                    __syncthreads(); // the previous tile's transposes are done with the buffer
+                for (int k = 0; k < 13; k++)
+                    w[k] = nxt[k];
+                if (outer + ostride < a.nouter)
+                    fetch_packed(outer + ostride);
+                double y[16];
+                unpack52(w, y);
+                __syncthreads(); // the previous tile's transposes are done with the buffer
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        lds[r * kPackLdsRow + tid] = fp_to_bits(y[r]);
-                    __syncthreads();
+                for (int r = 0; r < 16; r++)
+                    lds[r * kPackLdsRow + tid] = fp_to_bits(y[r]);
+                __syncthreads();
 #pragma unroll
-                    for (int e = 0; e < 16; e++)
-                        x[e] = fp_from_bits(lds[(tid >> 4) * kPackLdsRow + e * 16 + (tid & 15)]);
-                    __syncthreads(); // before any wave's exchange writes land in it
-                }
+                for (int e = 0; e < 16; e++)
+                    x[e] = fp_from_bits(lds[(tid >> 4) * kPackLdsRow + e * 16 + (tid & 15)]);
+                __syncthreads(); // before any wave's exchange writes land in it
             }
-            if constexpr (!packed)
+            else
             {
 #pragma unroll
             for (int e = 0; e < 16; e++)
