@@ -324,7 +324,10 @@ namespace sealhip
                 unsigned lanes = plan.lanes;
                 if (lanes > 1 && !ln.ensure(lanes - 1))
                     lanes = 1;
-                ka.no_class_fork = lanes > 1;
+                // (the two arithmetic classes of a chunk one after the other on its lane; SEALHIP_KS_CLASS_FORK=1 in development builds
+                // forks the integer class to the launcher's side stream as the unchunked path does: profiles/r05_ks_chunked.txt)
+                static const bool class_fork = shl_ab_getenv("SEALHIP_KS_CLASS_FORK") != nullptr;
+                ka.no_class_fork = lanes > 1 && !class_fork;
                 static const bool trace = shl_ab_getenv("SEALHIP_KS_TRACE") != nullptr;
                 if (trace)
                     std::fprintf(stderr, "[ks] batch %u in chunks of %u on %u lane(s)\n", B, plan.chunk, lanes);
