@@ -992,8 +992,13 @@ namespace sealhip
         const size_t threads = ((size_t)batch * 2) << n_log;
         if (!threads || K < 2)
             return hipErrorInvalidValue;
+        // one workgroup per 256 coefficients, no grid-stride loop (round 5: the shape this memory system streams fastest,
+        // profiles/r05_tensor_wide.txt; this pass moves 21 GB per configs[3] step)
+        size_t blocks = (threads + kBlock - 1) / kBlock;
+        if (blocks > (size_t)0x7fffffff)
+            blocks = 0x7fffffff;
         hipLaunchKernelGGL(
-            keyswitch_tail_modswitch_bfv_kernel, dim3(grid_for(threads)), dim3(kBlock), 0, s, mods, klv.inv_q_last_mod_q, klv.round_fix, half_p,
+            keyswitch_tail_modswitch_bfv_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, mods, klv.inv_q_last_mod_q, klv.round_fix, half_p,
             p, lv.inv_q_last_mod_q, lv.half_mod_q, lv.q_last, lv.half_q_last, ct0, ct1, acc, out, n_log, K, batch, threads);
         return hipGetLastError();
     }
