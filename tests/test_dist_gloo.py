@@ -142,3 +142,28 @@ def test_bench_default_line_carries_configs3_and_configs4(emu):
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--no-children"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])["workloads"] is None
+
+
+def test_device_memory_estimate_tracks_the_workloads():
+    """bench.py refuses a run whose estimate exceeds the rank's free HBM (benchlib/launcher.py: check_device_memory): the estimate must be
+    of the right order - the headline at batch 256 holds ~50 GB on the device (profiles/r05_bench.json: device_memory) - and follow
+    the batch, the shard size and the scratch cap"""
+    import argparse
+    import importlib
+    from benchlib import workloads
+    importlib.reload(workloads)
+
+    def est(workload, world=1, rank=0, **kw):
+        a = argparse.Namespace(workload=workload, batch=kw.get("batch", 0), total_batch=kw.get("total_batch", 1024))
+        return workloads.estimate_device_bytes(a, world, rank)
+    gib = 2.0 ** 30
+    head = est("headline")
+    assert 35 * gib < head < 80 * gib, head / gib
+    assert est("headline", batch=512) > 1.5 * head and est("headline", batch=64) < 0.5 * head
+    assert est("bfv_c4", world=8, rank=3) < 0.25 * est("bfv_c4")          # 128 of 1024 ciphertexts per rank
+    assert est("rotate_c5") < 0.3 * head                                   # batch 32, one operand
+    os.environ["SEALHIP_KS_SCRATCH_CAP_MIB"] = "4096"
+    try:
+        assert est("headline") < head - 7 * gib                            # 12 GB of chunked intermediate -> at most 4 GiB
+    finally:
+        del os.environ["SEALHIP_KS_SCRATCH_CAP_MIB"]
