@@ -333,7 +333,7 @@ def test_ckks_pipeline_n65536_lean_key_switch(emu):
     tables; ntt2_kernels.hip p1_tile / p2_tile): multiply + relinearize + rescale + rotate word for word, incl. 60-bit digits
     feeding double-precision targets and the other way round"""
     P.case_ckks_pipeline(65536, [60, 50, 50, 60], batch=1, steps=(1,), check_transforms=False)
-    P.case_ckks_pipeline(65536, [60, 50, 40, 50, 45, 60], batch=2, steps=(1,), check_transforms=False)
+    P.case_ckks_pipeline(65536, [60, 50, 40, 50, 45, 60], batch=1, steps=(1,), check_transforms=False)
 
 
 @pytest.mark.parametrize("groups", ["auto", "1"])
