@@ -2,6 +2,8 @@
 #include "pool.h"
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <stdexcept>
@@ -199,6 +201,11 @@ namespace sealhip
                 throw std::bad_alloc();
             }
         }
+#ifdef SEALHIP_AB_SWITCHES
+        // development builds only (tools/quick/step_placement_probe.py): where the runtime put each block
+        if (std::getenv("SEALHIP_POOL_TRACE"))
+            std::fprintf(stderr, "[pool] hipMalloc %zu bytes at %p\n", bytes, p);
+#endif
         std::lock_guard<std::mutex> g(mu_);
         held_ += bytes;
         live_[static_cast<uint64_t *>(p)] = Live{ bytes, t.holding };
