@@ -76,11 +76,7 @@ for what in "$@"; do
     done ;;
   fuzzchunk)
     # random operation sequences, deferred tails and the soak with every key switch forced into chunks of ONE item on three lanes
-    (SEALHIP_KS_SPLIT=1 SEALHIP_KS_CHUNK=1 SEALHIP_KS_LANES=3 timeout 1200 python -m pytest tests/test_fuzz.py tests/test_soak.py tests/test_gpu_parity.py -m gpu -q -x -k "fuzz or sequences or soak or pipeline or deferred or north_star_batch16" > $O/pytest_fuzzchunk.txt 2>&1; echo "rc=$?" >> $O/pytest_fuzzchunk.txt); tail -5 $O/pytest_fuzzchunk.txt
-    python - <<PY
-import sys; sys.path.insert(0, "."); sys.path.insert(0, "tests")
-PY
-    ;;
+    (SEALHIP_KS_SPLIT=1 SEALHIP_KS_CHUNK=1 SEALHIP_KS_LANES=3 timeout 1200 python -m pytest tests/test_fuzz.py tests/test_soak.py tests/test_gpu_parity.py -m gpu -q -x -k "fuzz or sequences or soak or pipeline or deferred or north_star_batch16" > $O/pytest_fuzzchunk.txt 2>&1; echo "rc=$?" >> $O/pytest_fuzzchunk.txt); tail -5 $O/pytest_fuzzchunk.txt ;;
   p1bound)
     # per-kernel averages of pass 1 with its loads / stores / both removed (timing only: wrong words)
     for v in default p1noload p1nostore p1nomem; do
