@@ -9,7 +9,30 @@ namespace sealhip
 
     // Same contract as ntt_forward (ntt_kernels.h); `mid` is a scratch buffer of
     // nouter * ncomp * N words that holds the transforms between the two passes (tile order).
-    hipError_t ntt2_forward(const NttTables &t, const NttBatch &b, int out_lazy, uint64_t *mid, hipStream_t stream);
+    // `ring` (optional): scratch of ntt2_ring_words(t, b) words for the one-launch kernel of N = 2^16 (plain in-place transforms of
+    // double-precision components, batches large enough to loop: ntt2_kernels.hip, ntt2_fwd_ring).  ntt2_ring_words() is 0 when
+    // the batch does not qualify; without a ring the two-launch engine runs.
+    size_t ntt2_ring_words(const NttTables &t, const NttBatch &b);
+    hipError_t ntt2_forward(const NttTables &t, const NttBatch &b, int out_lazy, uint64_t *mid, hipStream_t stream, uint64_t *ring = nullptr, size_t ring_words = 0);
+
+    // The one-launch kernel's own interface (ntt2_ring.hip; used by ntt2_forward): a run of `nc` consecutive double-precision components
+    // [c0, c0 + nc) of a plain in-place batch.  ntt2_ring_teams() = teams per component the device holds for such a run (0: the run does
+    // not qualify - small batch, kernel switched off by SEALHIP_NTT_RING=0, emulated build), ntt2_ring_run_words() = the scratch it needs.
+    struct NttRingRun
+    {
+        uint64_t *data;
+        size_t outer_stride;
+        const uint32_t *comp_prime;
+        unsigned prime_first, ncomp, c0, nc, nouter;
+        int lazy;
+        unsigned teams_per_comp;
+        uint64_t *ring;
+        size_t ring_words;
+    };
+    unsigned ntt2_ring_teams(unsigned nc, unsigned nouter);
+    size_t ntt2_ring_run_words(unsigned nc, unsigned teams_per_comp);
+    bool ntt2_ring_stream_ok(hipStream_t stream); // false while `stream` is being captured into a graph
+    hipError_t ntt2_ring_launch(const NttTables &t, const NttRingRun &run, hipStream_t stream);
 
     // Same contract as ntt_inverse; when b.src is set the input is read from src (natural order,
     // same component layout as data, stride src_outer_stride) and data is only written.

@@ -676,6 +676,13 @@ namespace sealhip
             // one launch over the whole batch - profiles/r05_ntt_mall_chunks.txt - and are not here)
             // two-pass engine; the scratch block goes back to the pool in stream order
             Scratch mid(((size_t)b.nouter * b.ncomp) << t.log_n);
+            // N = 2^16, large plain batches: the double-precision components run as ONE launch through a re-used ring (round 6)
+            const size_t ring_words = ntt2_ring_words(t, b);
+            if (ring_words)
+            {
+                Scratch ring(ring_words);
+                return ntt2_forward(t, b, out_lazy, mid.p, stream, ring.p, ring_words);
+            }
             return ntt2_forward(t, b, out_lazy, mid.p, stream);
         }
         return run(t, b, out_lazy, false, stream);

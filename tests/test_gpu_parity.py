@@ -60,6 +60,23 @@ def test_ntt_two_pass_loop(gpu, n, bits, polys):
     P.case_ntt(n, bits, polys=polys)
 
 
+# the ONE-launch kernel of N = 2^16 (ntt2_ring.hip: both passes in every workgroup, the intermediate in a re-used ring, hand-over by
+# progress words) - opt-in (SEALHIP_NTT_RING=1, read once per process, hence the child), every polynomial against the reference;
+# ragged slices (301 = 16 teams x 18 or 19 iterations), one and three double-precision components next to integer ones
+@pytest.mark.parametrize("bits,polys", [([50, 45, 60, 50], 301), ([45, 60], 700), ([50] * 8, 160)])
+def test_ntt_ring_one_launch(gpu, bits, polys):
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path.insert(0, %r); import parity_cases as P; P.case_ntt(65536, %r, polys=%d)" % (here, bits, polys)
+    env = dict(os.environ, SEALHIP_NTT_RING="1", SEALHIP_RING_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ran = [line for line in r.stderr.splitlines() if line.startswith("ntt2_fwd_ring:")]
+    assert ran, "the ring kernel did not run: " + r.stderr[-2000:]
+    assert all(" lost 0," in line for line in ran), ran
+
+
 def test_dyadic(gpu):
     P.case_dyadic(4096, [60, 40, 30])
 
