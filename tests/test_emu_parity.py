@@ -343,3 +343,18 @@ def test_deferred_tail_lifecycle(emu, monkeypatch, groups):
     if groups != "auto":
         monkeypatch.setenv("SEALHIP_KS_SPLIT", groups)
     P.case_deferred_tail_lifecycle()
+
+
+# structured worst-case inputs (parity_cases.case_extremes_*): the emulated kernels assert the bounds of both back ends
+# (SEALHIP_CHECK_BOUNDS) on all q-1 / alternating / floor(q/2) slabs - the GPU suite runs the same cases at every plan
+@pytest.mark.parametrize("n,bits", [(1024, [36, 60, 55]), (8192, [50, 60, 58]), (65536, [49, 60, 57])])
+def test_extremes_ntt(emu, n, bits):
+    P.case_extremes_ntt(n, bits, 8)
+
+
+def test_extremes_ckks(emu):
+    P.case_extremes_ckks(8192, [60, 40, 58, 60], batch=8)
+
+
+def test_extremes_bfv(emu):
+    P.case_extremes_bfv(4096, coeff_modulus_create(4096, [36, 36, 37]), plain_modulus_batching(4096, 20))

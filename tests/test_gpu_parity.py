@@ -77,6 +77,32 @@ def test_ntt_ring_one_launch(gpu, bits, polys):
     assert all(" lost 0," in line for line in ran), ran
 
 
+# ---- structured worst-case inputs at every engine plan: all q-1, all 0, alternating, floor(q/2), floor(q/2)+1, a
+#      spike at N-1, a random mix of those, all ones - one prime below 2^50, one 60-bit, one of 51 .. 59 bits
+@pytest.mark.parametrize("n,bits,polys", [
+    (4096, [36, 60, 55], 8), (8192, [50, 60, 58], 8), (16384, [45, 60, 51], 8), (32768, [50, 60, 55], 8), (65536, [50, 60, 59], 8),
+    (8192, [50, 60, 58], 1104),      # single-launch kernels, looping workgroups
+    (65536, [49, 60, 57], 400),      # two-pass engine, looping workgroups, packed intermediate
+])
+def test_extremes_ntt(gpu, n, bits, polys):
+    P.case_extremes_ntt(n, bits, polys)
+
+
+@pytest.mark.parametrize("n,bits,batch,check", [
+    (4096, [50, 36, 36, 50], 8, None), (8192, [60, 40, 58, 60], 8, None), (16384, [60, 50, 55, 60], 8, None),
+    (65536, [60, 50, 49, 57, 60], 8, None),
+    (65536, [60] + [50] * 14 + [60], 64, (0, 1, 2, 3, 4, 5, 6, 7, 33, 63)),   # BASELINE configs[4] / the headline chain, chunked key switch
+])
+def test_extremes_ckks(gpu, n, bits, batch, check):
+    P.case_extremes_ckks(n, bits, batch=batch, check=check)
+
+
+@pytest.mark.parametrize("n,bits", [(4096, [36, 36, 37]), (8192, [50, 55, 60]), (16384, [55, 55, 55, 55])])
+def test_extremes_bfv(gpu, n, bits):
+    primes = coeff_modulus_create(n, bits)
+    P.case_extremes_bfv(n, primes, plain_modulus_batching(n, 20))
+
+
 def test_dyadic(gpu):
     P.case_dyadic(4096, [60, 40, 30])
 
