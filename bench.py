@@ -29,6 +29,8 @@ One JSON line is printed by rank 0 with, besides the contract fields:
   roofline_configs1  the same measurement at BASELINE configs[1] (CKKS N=8192, L=4: forward and inverse NTT over all RNS components)
   workloads    headline on one GPU only: BASELINE configs[3] (bfv_c4) and configs[4] (rotate_c5) timed by short child runs of this
                script after the headline (value, ms_per_step, verified_items, roofline of each); --no-children leaves them out
+  config.batch_sweep  headline on one GPU only: the same step at SURVEY 8(d)'s other batch sizes (--sweep, default 1, 8, 64, 1024; batch 1
+               eager and as a hipGraph replay = per-ciphertext latency) from one child process; --no-sweep leaves it out
   config.device_memory  bytes the library's pool held after the timed steps, the largest key-switch intermediate (the batch runs in
                chunks on forked streams: sealhip.h "Chunked key switching"), how many key switches ran chunked and in how many chunks
   rccl_ranks, per_rank  how many ranks the probe all-reduce reached before anything was timed (a mismatch stops the job with
@@ -57,6 +59,8 @@ def main():
         return counters.pmc_child(args)
     if args.step_child:
         args.no_cpu_baseline = args.no_pmc = args.no_verify = args.no_children = True
+    if args.sweep_child:
+        return sweep_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launcher.launch_ranks(args, os.path.abspath(__file__)))
     r = launcher.init_ranks(args)
@@ -143,11 +147,22 @@ def main():
             frac={k: round(v * cts_per_s_per_gpu / 1e9 / HBM_PEAK_GBS, 4) for k, v in sb.items()})
         if world == 1 and not args.no_pmc:
             roofline_step.update(counters.step_counters(args, B))
+            if roofline_step.get("hbm_counter_bytes_per_ciphertext"):
+                # the step's REAL fabric traffic next to the algorithmic figure: what fraction of the HBM peak the step draws
+                real = roofline_step["hbm_counter_bytes_per_ciphertext"]
+                roofline_step["hbm_counter_over_key_amortised"] = round(real / sb["key_amortised"], 3)
+                roofline_step["hbm_counter_gbs"] = round(real * cts_per_s_per_gpu / 1e9, 1)
+                roofline_step["hbm_counter_frac_of_peak"] = round(real * cts_per_s_per_gpu / 1e9 / HBM_PEAK_GBS, 4)
 
     # ---- BASELINE configs[3] and configs[4] in the same line: short child runs of this script, one GPU
     appended = None
     if solo and args.workload == "headline" and not args.no_children and not args.ntt_only:
         appended = {name: child_workload(name, args) for name in ("bfv_c4", "rotate_c5")}
+
+    # ---- SURVEY 8(d)'s other batch sizes (1 = latency; 64, 1024 = throughput) in the same line: one child process
+    batch_sweep = None
+    if solo and args.workload == "headline" and not args.no_sweep and not args.no_children and not args.ntt_only and not args.step_child:
+        batch_sweep = child_sweep(args)
 
     cpu_line = None
     if solo and not args.no_cpu_baseline and not args.ntt_only and not EMU:
@@ -162,7 +177,7 @@ def main():
             scaling=scaling, vs_baseline=None, dtype="u64", data="synthetic",
             verified_items=verified, rccl_ranks=r.collective_ranks, collective_backend=r.backend, per_rank=per_rank,
             config=dict(workload=description + (" [EMULATED KERNELS, CPU test]" if EMU else ""),
-                        batch_per_gpu=B, key_switch_tail=tail_note,
+                        batch_per_gpu=B, key_switch_tail=tail_note, batch_sweep=batch_sweep,
                         **(dict(shared_gpu="TEST MODE: the %d ranks share one device over gloo (SEALHIP_BENCH_SHARE_GPU) - not a measurement" % world)
                            if r.shared_gpu else {}), launch=("hipGraph replay" if args.graph else "eager") + lanes_note,
                         parallelism=par,
@@ -187,6 +202,57 @@ def main():
         pass
     if rank == 0:
         print(json.dumps(line), flush=True)
+
+
+def sweep_child(args):
+    """`--sweep-child`: the headline step at the batch sizes of --sweep, one after the other in this process (a context, a key and
+    a pair of resident input batches per size, freed before the next); batch 1 eager and as a hipGraph replay.  Prints one JSON
+    list.  Throughput / latency only: the parity of these batch sizes is the GPU test suite's business."""
+    import time
+    args.no_cpu_baseline = args.no_pmc = args.no_verify = args.no_children = args.no_sweep = True
+    args.workload, args.gpus = "headline", 1
+    r = launcher.init_ranks(args)
+    import seal_amd as S
+    from seal_amd import shard
+    out = []
+    for b in [int(x) for x in args.sweep.split(",") if x.strip()]:
+        for graph in ((False, True) if b == 1 else (False,)):
+            args.batch, args.graph = b, graph
+            steps = max(4, min(400, 4000 // b))
+            try:
+                w = workloads.build(args, S, shard, r.torch, r.group, r.device, r.dev_sync, 1, 0)
+                elapsed = shard.timed_steps(w.step, steps, max(2, steps // 10), r.group, r.dev_sync, r.torch, r.coll_device)
+                work = workloads.result_batch(w, args)
+                assert work.size() == 2 and work.coeff_modulus_size() == w.K - 1 and work.batch() == b
+                ms = 1e3 * elapsed / steps
+                out.append(dict(batch=b, launch="hipGraph replay" if graph else "eager", steps=steps, ms_per_step=round(ms, 4),
+                                ct_per_s=round(b / (ms * 1e-3), 1), latency_ms_per_ciphertext=round(ms, 4) if b == 1 else None))
+                del work
+                w.free()
+                del w
+            except BaseException as e:  # a size that does not fit or fails is reported, the others still run
+                out.append(dict(batch=b, launch="hipGraph replay" if graph else "eager", error=repr(e)[:300]))
+            r.torch.cuda.empty_cache()
+            S.release_pool()
+            time.sleep(0.05)
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(out), flush=True)
+
+
+def child_sweep(args):
+    """the batch sweep as a child run of this script (the parent has released its HBM): [{batch, launch, ms_per_step, ct_per_s}]"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--sweep-child", "--sweep", args.sweep]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ))
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("[")]
+        if p.returncode != 0 or not lines:
+            return dict(error="sweep child failed (rc %d): %s" % (p.returncode, (p.stderr or p.stdout)[-400:]))
+        return json.loads(lines[-1])
+    except Exception as e:
+        return dict(error="sweep child failed: %r" % (e,))
 
 
 def child_workload(name, args):

@@ -35,6 +35,10 @@ def parse(argv=None):
     ap.add_argument("--ntt-only", action="store_true", help="only the NTT roofline leg (for rocprofv3 runs)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--step-child", action="store_true", help=argparse.SUPPRESS)  # the timed step alone, under rocprofv3 --pmc (roofline_step)
+    ap.add_argument("--sweep", default="1,8,64,1024", help="headline on one GPU: batch sizes of the appended batch sweep (SURVEY 8(d): "
+                    "1 = latency, 64 / 256 / 1024 = throughput); batch 1 is timed eager and as a hipGraph replay")
+    ap.add_argument("--no-sweep", action="store_true", help="leave the batch sweep out (config.batch_sweep)")
+    ap.add_argument("--sweep-child", action="store_true", help=argparse.SUPPRESS)  # the sweep itself: one process, one context per batch size
     ap.add_argument("--streams", type=int, default=1, help="divide the GPU's batch over this many evaluators, each on its own HIP stream, so "
                     "that one sub-batch's memory-bound phases overlap another's key switching; rotate_c5: the sub-batches share the "
                     "communicator, so that the digit-parallel exchange of one overlaps the key-switch kernels of the next")

@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "oracle", "_ref", "libsealref.so")
+# SEALREF_LIB: another flavour of the same reference (bench.py's cpu_baseline times oracle/_ref/libsealref_clang.so in a child process)
+LIB_PATH = os.environ.get("SEALREF_LIB") or os.path.join(_HERE, "..", "oracle", "_ref", "libsealref.so")
+CLANG_LIB_PATH = os.path.join(_HERE, "..", "oracle", "_ref", "libsealref_clang.so")
 
 _lib = None
 
