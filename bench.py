@@ -81,18 +81,20 @@ def main():
     if not args.ntt_only:
         local = {}
         elapsed = shard.timed_steps(w.step, args.steps, args.warmup, group, dev_sync, torch, cdev, local=local)
-        work = workloads.result_batch(w, args)
-        assert work.size() == 2 and work.coeff_modulus_size() == K - 1 and work.batch() == B
+        work = workloads.result_batch(w, args) if B > 0 else None
+        assert B == 0 or (work.size() == 2 and work.coeff_modulus_size() == K - 1 and work.batch() == B)
         per_step = B if args.workload != "rotate_c5" else float(B) / world  # rotate_c5: all ranks worked on the same B items
         rate = shard.whole_job_rate(per_step, args.steps, elapsed, group, torch, cdev)
         result = dict(value=rate, ms_per_step=1e3 * elapsed / args.steps)
         per_rank = launcher.gather_per_rank(r, per_step * args.steps / local["elapsed"], 1e3 * local["elapsed"] / args.steps)
+        if group is not None and w.want_verify is False and not args.no_verify and workloads.reference_available():
+            verified = 0   # a rank with an empty shard has nothing to compare but joins the sum below
         if w.want_verify and B > 0:
             verified = workloads.verify_items(args.workload, w.scheme, n, w.primes, w.t_plain, w.key_host, w.xs, w.ys, work, B, w.scale)
-            if group is not None:
-                v = torch.tensor([verified], dtype=torch.int64, device=cdev)
-                dist.all_reduce(v)
-                verified = int(v.item())
+        if group is not None and verified is not None:
+            v = torch.tensor([verified], dtype=torch.int64, device=cdev)
+            dist.all_reduce(v)
+            verified = int(v.item())
         del work
     w.key_host = None
 
@@ -175,9 +177,12 @@ def main():
             metric=metric, value=round(result.get("value", 0.0), 2), unit="ciphertexts/s", n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=round(result.get("ms_per_step", 0.0), 3), higher_is_better=True,
             scaling=scaling, vs_baseline=None, dtype="u64", data="synthetic",
+            # rotate_c5 splits ONE key switch over the ranks: what it buys is time per ciphertext, so the line says that too
+            **(dict(latency_ms_per_ciphertext=round(result.get("ms_per_step", 0.0) / max(1, B), 4)) if args.workload == "rotate_c5" and B else {}),
             verified_items=verified, rccl_ranks=r.collective_ranks, collective_backend=r.backend, per_rank=per_rank,
             config=dict(workload=description + (" [EMULATED KERNELS, CPU test]" if EMU else ""),
                         batch_per_gpu=B, key_switch_tail=tail_note, batch_sweep=batch_sweep,
+                        cpus_per_rank=len(r.cpu_affinity) if r.cpu_affinity else None,
                         **(dict(shared_gpu="TEST MODE: the %d ranks share one device over gloo (SEALHIP_BENCH_SHARE_GPU) - not a measurement" % world)
                            if r.shared_gpu else {}), launch=("hipGraph replay" if args.graph else "eager") + lanes_note,
                         parallelism=par,

@@ -65,6 +65,25 @@ def launch_ranks(args, script):
     return subprocess.call(cmd, env=env)
 
 
+def pin_rank_to_its_share_of_the_host(local_rank, local_world):
+    """N ranks on one host: give each its own contiguous slice of the CPUs this process may run on, so that eight Python launch loops
+    and eight reference-check thread pools do not fight over the same cores (a rank's kernel launches stall when its thread is
+    descheduled: a one-GPU run never sees that).  Returns the CPU list, or None when nothing was changed (one rank, no
+    sched_setaffinity, SEALHIP_BENCH_NO_AFFINITY=1, fewer CPUs than ranks)."""
+    if local_world <= 1 or os.environ.get("SEALHIP_BENCH_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // local_world
+        if per < 1:
+            return None
+        mine = cpus[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except OSError:
+        return None
+
+
 class Ranks:
     """this process's place in the job: torch, the process group (None for one rank), device, and what the probe collective saw"""
 
@@ -79,6 +98,7 @@ def init_ranks(args):
     r.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if r.world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, r.world))
+    r.cpu_affinity = pin_rank_to_its_share_of_the_host(r.local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", r.world)))
     r.backend = None
     # SEALHIP_BENCH_SHARE_GPU=1 (tests/test_gpu_multi.py on the one-GPU boxes): the ranks are real processes with real kernels but
     # share device 0, so the process group is gloo (RCCL refuses two ranks on one device) and the helper collectives use host

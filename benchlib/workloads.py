@@ -94,7 +94,8 @@ def verify_items(workload, scheme, n, primes, t_plain, key_host, xs, ys, work, B
         return a.data(), a.info()["scale"]
 
     inputs_ready = [(b, work.item_to_numpy(b)) for b in items]      # device reads on this thread
-    with ThreadPoolExecutor(max_workers=min(len(items), os.cpu_count() or 1)) as pool:
+    cpus = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)   # this rank's share of the host
+    with ThreadPoolExecutor(max_workers=max(1, min(len(items), cpus))) as pool:
         results = list(pool.map(expected, items))
     for (b, got), (exp, ref_scale) in zip(inputs_ready, results):
         if got.shape != exp.shape or not np.array_equal(got, exp):
@@ -190,6 +191,13 @@ def build(args, S, shard, torch, group, device, dev_sync, world, rank, shared_gp
     # ---- synthetic size-2 ciphertext batches at the first data level (CKKS: NTT form, scale 2^24)
     ntt_form = scheme != "bfv"
     scale = 2.0 ** (50 // 2 - 1) if scheme == "ckks" else 1.0
+    if B == 0:
+        # more ranks than items of a sharded total batch (bfv_c4 --total-batch 4 on 8 ranks): this rank owns nothing, times an empty
+        # step and still takes part in every barrier and helper collective
+        w.__dict__.update(scheme=scheme, n=n, primes=primes, L=L, K=K, t_plain=t_plain, ctx=ctx, ev=ev, B=0, scaling=scaling, keys=keys,
+                          dp=dp, xs=None, ys=None, x=None, y=None, work=None, lanes=None, step=lambda: None, holder={}, key_host=None,
+                          scale=scale, want_verify=False)
+        return w
     xs = device_uniform(torch, primes[:K], (2, B), n, device)
     ys = device_uniform(torch, primes[:K], (2, B), n, device) if args.workload != "rotate_c5" else None
 

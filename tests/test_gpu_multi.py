@@ -89,3 +89,28 @@ def test_two_processes_share_the_one_gpu(gpu, workload, extra):
     assert "free" in out.stderr and "GiB free of" in out.stderr, "the per-rank memory line is missing: " + out.stderr[-800:]
     if workload == "rotate_c5":
         assert "torch.distributed" in line["config"]["parallelism"], line["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("headline", ["--batch", "1"]), ("bfv_c4", ["--total-batch", "9"]), ("rotate_c5", ["--batch", "2"])])
+def test_eight_processes_share_the_one_gpu(gpu, workload, extra):
+    """Eight-rank first contact as far as a one-GPU box allows: `python bench.py --gpus 8`, the eight ranks real
+    processes with the REAL kernels on device 0 (SEALHIP_BENCH_SHARE_GPU=1, gloo).  One item per rank for the headline; 9 items over 8
+    ranks for configs[3] (shards 2, 1, 1, ...); configs[4] with 15 digits over 8 ranks (2, 2, ..., 1).  Every rank pinned to its own
+    CPUs, every rank's items equal the reference's.  (The ring kernel is opt-in and stays off: processes that share a GPU must not
+    run workgroups that wait for each other.)"""
+    import json
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SEALHIP_NTT_RING")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", SEALHIP_BENCH_SHARE_GPU="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", workload,
+                          "--no-cpu-baseline", "--no-pmc", "--no-children"] + extra, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["collective_backend"] == "gloo", line
+    assert "shared_gpu" in line["config"], line["config"]
+    assert [p["rank"] for p in line["per_rank"]] == list(range(8)) and all(p["value"] > 0 for p in line["per_rank"])
+    assert line["value"] > 0 and line["verified_items"] and line["verified_items"] >= 8, line
+    assert line["config"]["cpus_per_rank"] and line["config"]["cpus_per_rank"] >= 1
+    if workload == "rotate_c5":
+        assert line["latency_ms_per_ciphertext"] > 0 and "torch.distributed" in line["config"]["parallelism"]
