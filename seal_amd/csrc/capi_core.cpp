@@ -169,7 +169,9 @@ extern "C"
                 if (p->n == (uint64_t(1024) << i))
                     max_bits = table[row][i];
         }
-        // ... before any device table is built: the verdict follows from the primes alone
+        // ... before any device table is built: the verdict follows from the primes alone - but behind the checks the
+        // reference makes first, so that malformed AND oversized parameters report the malformation
+        Context::check_basic_parameters(static_cast<Scheme>(p->scheme), p->n, p->coeff_modulus);
         if (sec_level != 0 && !p->coeff_modulus.empty() && host::significant_bits(host::product(p->coeff_modulus)) > max_bits)
             throw std::invalid_argument("encryption parameters are not set correctly: not secure for the requested security level");
         std::unique_ptr<Context> c(new Context(static_cast<Scheme>(p->scheme), p->n, p->coeff_modulus, p->plain_modulus, expand_mod_chain));

@@ -50,17 +50,16 @@ namespace sealhip
         };
     } // namespace
 
-    Context::Context(
-        Scheme scheme, size_t n, const std::vector<uint64_t> &coeff_modulus, uint64_t plain_modulus,
-        bool expand_mod_chain)
-        : scheme_(scheme), n_(n), plain_modulus_(plain_modulus), primes_(coeff_modulus)
+    // the checks SEALContext::validate makes BEFORE its security verdict (context.cpp:142-218): scheme, modulus count and sizes,
+    // primality, degree.  Host arithmetic only - SEALContext_Create runs them ahead of its early security check so that a parameter
+    // set that is both malformed and too large reports what the reference reports
+    void Context::check_basic_parameters(Scheme scheme, size_t n, const std::vector<uint64_t> &primes)
     {
-        // ---- validation, in the order of SEALContext::validate (context.cpp:142-460)
         if (scheme != Scheme::bfv && scheme != Scheme::ckks && scheme != Scheme::bgv)
             throw std::invalid_argument("invalid_scheme");
-        if (primes_.empty() || primes_.size() > kMaxComps)
+        if (primes.empty() || primes.size() > kMaxComps)
             throw std::invalid_argument("invalid_coeff_modulus_size");
-        for (uint64_t q : primes_)
+        for (uint64_t q : primes)
         {
             if ((q >> 60) || !(q >> 1))
                 throw std::invalid_argument("invalid_coeff_modulus_bit_count");
@@ -69,6 +68,15 @@ namespace sealhip
         }
         if (n < 2 || n > 131072 || (n & (n - 1)))
             throw std::invalid_argument("invalid_poly_modulus_degree");
+    }
+
+    Context::Context(
+        Scheme scheme, size_t n, const std::vector<uint64_t> &coeff_modulus, uint64_t plain_modulus,
+        bool expand_mod_chain)
+        : scheme_(scheme), n_(n), plain_modulus_(plain_modulus), primes_(coeff_modulus)
+    {
+        // ---- validation, in the order of SEALContext::validate (context.cpp:142-460)
+        check_basic_parameters(scheme, n, primes_);
         log_n_ = bit_count(n) - 1;
         for (size_t i = 0; i < primes_.size(); i++)
             for (size_t j = i + 1; j < primes_.size(); j++)

@@ -115,6 +115,8 @@ namespace sealhip
     public:
         // Throws std::invalid_argument / std::logic_error with the reference's conditions
         // (context.cpp:142-460) when the parameters are not usable.
+        // what SEALContext::validate checks before its security verdict; throws std::invalid_argument with the reference's error names
+        static void check_basic_parameters(Scheme scheme, size_t poly_modulus_degree, const std::vector<uint64_t> &coeff_modulus);
         Context(Scheme scheme, size_t poly_modulus_degree, const std::vector<uint64_t> &coeff_modulus,
                 uint64_t plain_modulus, bool expand_mod_chain);
         ~Context();

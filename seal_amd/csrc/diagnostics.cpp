@@ -122,7 +122,6 @@ extern "C"
         g_trace_live.store(spare, std::memory_order_release);
         if (g_abort_installed.exchange(true))
             return SHL_S_OK; // only the path changes
-        g_previous_terminate = std::set_terminate(on_terminate);
         void *warm[4];
         (void)::backtrace(warm, 4); // loads libgcc now, not inside the handler
         struct sigaction sa;
@@ -132,9 +131,15 @@ extern "C"
         sa.sa_flags = SA_NODEFER;
         if (::sigaction(SIGABRT, &sa, nullptr) != 0)
         {
+            // nothing was installed: a later call starts from scratch (the terminate handler used to stay behind here, and
+            // the next call then chained on_terminate to itself)
             g_abort_installed = false;
             return SHL_E_UNEXPECTED;
         }
+        // the terminate handler goes in LAST and exactly once per process, so that g_previous_terminate can never be on_terminate itself
+        static std::atomic<bool> terminate_installed{ false };
+        if (!terminate_installed.exchange(true))
+            g_previous_terminate = std::set_terminate(on_terminate);
         return SHL_S_OK;
     }
 }

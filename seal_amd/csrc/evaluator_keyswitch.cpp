@@ -1,5 +1,7 @@
 // Evaluator, part 2: relinearize, switch_key_inplace in its two halves, digit-parallel key switching
 #include "evaluator_common.h"
+#include <map>
+#include <memory>
 
 namespace sealhip
 {
@@ -67,34 +69,61 @@ namespace sealhip
             hipEvent_t fork = nullptr;
             unsigned made = 0;
             int device = -1; // streams belong to the device that was current when they were made
+            KsLanes() = default;
+            KsLanes(const KsLanes &) = delete;
+            KsLanes &operator=(const KsLanes &) = delete;
+            ~KsLanes()
+            {
+                //  a lane set owns its streams and events: short-lived worker threads must not leak one set each.  Best effort - at
+                // thread or process exit the runtime may already be gone, and errors are of no use here.
+                for (unsigned i = 0; i < kSide; i++)
+                {
+                    if (stream[i])
+                        (void)hipStreamDestroy(stream[i]);
+                    if (join[i])
+                        (void)hipEventDestroy(join[i]);
+                }
+                if (fork)
+                    (void)hipEventDestroy(fork);
+            }
             bool ensure(unsigned side)
             {
-                int dev = -1;
-                if (hipGetDevice(&dev) != hipSuccess)
-                    return false;
-                if (device != dev)
-                {
-                    // first use, or this host thread moved to another GPU (one process per GPU is the model; a thread that drives
-                    // several devices gets a fresh set - the old one is left to its device)
-                    *this = KsLanes();
-                    device = dev;
-                }
                 if (!fork && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess)
                     return false;
                 while (made < side && made < kSide)
                 {
-                    if (hipStreamCreateWithFlags(&stream[made], hipStreamNonBlocking) != hipSuccess ||
-                        hipEventCreateWithFlags(&join[made], hipEventDisableTiming) != hipSuccess)
+                    // stream and event of a lane are made together: a half-made lane is taken down again, not leaked
+                    hipStream_t st = nullptr;
+                    hipEvent_t ev = nullptr;
+                    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
                         return false;
+                    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+                    {
+                        (void)hipStreamDestroy(st);
+                        return false;
+                    }
+                    stream[made] = st;
+                    join[made] = ev;
                     made++;
                 }
                 return made >= side;
             }
         };
-        KsLanes &ks_lanes()
+        // one lane set per (host thread, device): a thread that alternates between GPUs keeps a set on each instead of dropping and
+        // re-making them at every switch; one process per GPU - the model - has exactly one
+        KsLanes *ks_lanes()
         {
-            static thread_local KsLanes l;
-            return l;
+            static thread_local std::map<int, std::unique_ptr<KsLanes>> sets;
+            int dev = -1;
+            if (hipGetDevice(&dev) != hipSuccess)
+                return nullptr;
+            std::unique_ptr<KsLanes> &slot = sets[dev];
+            if (!slot)
+            {
+                slot.reset(new KsLanes());
+                slot->device = dev;
+            }
+            return slot.get();
         }
         std::atomic<uint64_t> g_ks_chunked_calls{ 0 }, g_ks_chunks{ 0 }, g_ks_scratch_words_max{ 0 };
     } // namespace
@@ -320,10 +349,12 @@ namespace sealhip
             {
                 // which pass-1 kernel: decided for the whole batch (ntt2_kernels.hip: launch_ks decides from the grid it is given)
                 ka.order1 = (size_t)B * (j1 - j0) * (N >> 12) >= 4096 ? 1 : 0;
-                KsLanes &ln = ks_lanes();
+                KsLanes *lnp = ks_lanes();
                 unsigned lanes = plan.lanes;
-                if (lanes > 1 && !ln.ensure(lanes - 1))
+                if (lanes > 1 && (!lnp || !lnp->ensure(lanes - 1)))
                     lanes = 1;
+                KsLanes dummy_lanes_for_one_lane; // (never touched when lanes == 1)
+                KsLanes &ln = lnp ? *lnp : dummy_lanes_for_one_lane;
                 // (the two arithmetic classes of a chunk one after the other on its lane; SEALHIP_KS_CLASS_FORK=1 in development builds
                 // forks the integer class to the launcher's side stream as the unchunked path does: profiles/r05_ks_chunked.txt)
                 static const bool class_fork = shl_ab_getenv("SEALHIP_KS_CLASS_FORK") != nullptr;
@@ -339,6 +370,23 @@ namespace sealhip
                 }
                 const size_t poly_words = (size_t)K * N; // one polynomial of one item in the [batch][K][N] planes
                 unsigned c = 0;
+                //  a launch that fails half-way must not leave forked lanes running into scratch blocks that go back to
+                // the pool ordered on stream_ only: join whatever was forked before the exception travels on
+                auto join_lanes = [&](bool nothrow) {
+                    for (unsigned l = 1; l < lanes; l++)
+                    {
+                        const hipError_t e1 = hipEventRecord(ln.join[l - 1], ln.stream[l - 1]);
+                        const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(stream_, ln.join[l - 1], 0) : e1;
+                        if (e2 != hipSuccess)
+                        {
+                            if (!nothrow)
+                                ck(e2, "ks lanes join");
+                            (void)hipStreamSynchronize(ln.stream[l - 1]); // the event path failed too: wait for the lane outright
+                        }
+                    }
+                };
+                try
+                {
                 // (The lanes run in lockstep - forked together, equal work.  A two-stage form that staggers them by construction - one
                 // producer stream for inverse transform + pass 1, the evaluator's stream consuming a ring of intermediates with pass 2
                 // - was measured too: 9.24 k ct/s against 9.27 - 9.40 k, profiles/r05_ks_chunked.txt.  Both passes need the vector
@@ -368,11 +416,13 @@ namespace sealhip
                     }
                     ck(ks_fused(tb, kc, st), "ks fused (chunk)");
                 }
-                for (unsigned l = 1; l < lanes; l++)
-                {
-                    ck(hipEventRecord(ln.join[l - 1], ln.stream[l - 1]), "ks lanes join");
-                    ck(hipStreamWaitEvent(stream_, ln.join[l - 1], 0), "ks lanes join");
                 }
+                catch (...)
+                {
+                    join_lanes(true);
+                    throw;
+                }
+                join_lanes(false);
                 g_ks_chunked_calls++;
                 g_ks_chunks += c;
             }

@@ -2016,6 +2016,8 @@ namespace sealhip
                         fchunks = (unsigned)std::atoi(f) ? (unsigned)std::atoi(f) : 1;
                     if (fchunks > nouter)
                         fchunks = nouter;
+                    if (fchunks > 65535) // gridDim.z (nouter / 4 is not bounded by `want` any more)
+                        fchunks = 65535;
                 }
             }
             return launch_runs(comp_runs(a.t, a.comp_prime, a.prime_first, a.ncomp, a.cls_hint), s, [&](const CompRun &r, hipStream_t st) {

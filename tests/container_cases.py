@@ -121,6 +121,40 @@ def case_security_level():
     except S.InvalidArgument:
         pass
     assert S.SEALContext(p, True, 0).key_context_data().qualifiers()["sec_level"] == 0
+    # malformed AND too large: the reference checks the modulus before the security level (context.cpp:142-231), so the message names
+    # the malformation (the early security verdict used to win)
+    bad = coeff_modulus_create(n, [40, 40, 40])
+    bad[1] = bad[1] + 2   # even + 2 = not a prime any more (an odd composite or an even number)
+    while _is_probable_prime(bad[1]):
+        bad[1] += 2
+    p.set_coeff_modulus(bad)
+    try:
+        S.SEALContext(p, True, 128)
+        raise AssertionError("a composite modulus was accepted")
+    except S.InvalidArgument as e:
+        assert "non_prime" in str(e) and "secure" not in str(e), str(e)
+
+
+def _is_probable_prime(q):
+    if q < 2 or q % 2 == 0:
+        return q == 2
+    d, r = q - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if a % q == 0:
+            continue
+        x = pow(a, d, q)
+        if x in (1, q - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % q
+            if x == q - 1:
+                break
+        else:
+            return False
+    return True
 
 
 def case_ciphertext_container(scheme, n, bits, tb=20):
