@@ -240,9 +240,237 @@ namespace sealhip
             }
 #endif
         }
+
+        // ---------------------------------------------------------------------------------------
+        // The SPECIALISED form (SEALHIP_NTT_RING=2): pass-1 workgroups and pass-2 workgroups in one launch
+        // ---------------------------------------------------------------------------------------
+        // The fused kernel above pays for doing both passes in one workgroup with its registers (202 VGPRs: two waves per SIMD).  Here a
+        // workgroup has ONE role - a team is 16 pass-1 workgroups (column tile) + 16 pass-2 workgroups (row tile) of one (component,
+        // slice) - so either role keeps the register budget of the separate kernels (the kernel is compiled for four waves per SIMD) and
+        // a CU holds both roles side by side: whichever role is behind gets the CU, the other one sleeps on its progress word.
+        // Pass 1 runs ahead of pass 2 by at most R slots.  Same ring, same pair order, same write-through / L1-bypass hand-over, same
+        // one-publisher / one-poller-per-workgroup rule as above; what differs is that ONE side waits by construction, so the slow
+        // path is built for it: wave 0 polls with long sleeps, the other waves wait at a workgroup barrier.
+        //   prog[team][tile][0] = iterations whose pass-1 tile `tile` is in memory, [1] = iterations whose pass-2 tile has landed
+        // Block -> (role, team, tile): layers of 256 blocks alternate the roles (with dispatch going round the 8 XCDs x 32 CUs every
+        // CU gets both roles), the remainder is split in halves.
+        template <int WAVES>
+        __global__ void __launch_bounds__(kThreads, WAVES) ntt2_fwd_ring2(FwdArgs a, RingArgs r)
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef Field<true> F;
+            constexpr int D1 = 8;
+            typedef Geo<D1> G;
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            HIP_DYNAMIC_SHARED(uint64_t, lds)
+            __shared__ unsigned s_have[2]; // pass 1: [k & 1] unused, [*] = min landed; pass 2: [k & 1] = min complete
+            const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+            const unsigned Z = r.teams_per_comp, R = r.R;
+            const unsigned per_role = gridDim.x >> 1; // 16 * teams
+            unsigned role, idx;
+            {
+                const unsigned b = blockIdx.x, pairs = gridDim.x / 512, rest = gridDim.x - pairs * 512;
+                if (b < pairs * 512)
+                {
+                    const unsigned layer = b >> 8;
+                    role = layer & 1;
+                    idx = (layer >> 1) * 256 + (b & 255);
+                }
+                else
+                {
+                    const unsigned rb = b - pairs * 512;
+                    role = rb >= rest / 2 ? 1u : 0u;
+                    idx = pairs * 256 + rb - role * (rest / 2);
+                }
+            }
+            const unsigned team = idx >> 4, tile = idx & 15;
+            const unsigned comp = team / Z + a.comp0, slice = team % Z;
+            const unsigned prime = SHL_UNIFORM(a.comp_prime ? a.comp_prime[comp] : a.prime_first + comp);
+            const F::Mod m = F::make_mod(ld_uniform_mod(&a.t.mods[prime]), ld_uniform_fpd(&a.t.fpd[prime]));
+            const double *tab = tw_table<true>(a.t, false, prime);
+            const unsigned iters = slice < a.nouter ? (a.nouter - slice + Z - 1) / Z : 0;
+            uint64_t *ring = r.ring + (((size_t)team * R) << 16);
+            unsigned *prog = r.prog + (size_t)team * kRingProgStride;
+            unsigned *status = r.prog + (size_t)(per_role >> 4) * kRingProgStride;
+            auto window = [](const uint64_t *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint64_t *>(p), 0, 0x7fffffff, 0x00020000); };
+            // the whole workgroup waits until word `which` of all sixteen pairs of the team is >= target: wave 0 polls, the others sit at the barrier
+            auto wait_team = [&](unsigned which, unsigned target) {
+                if (wave == 0 && !(r.flags & 1))
+                {
+                    unsigned spins = 0;
+                    for (;;)
+                    {
+                        const unsigned have = lane < 16 ? __hip_atomic_load(prog + lane * 2 + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                        if (__all(have >= target))
+                            break;
+                        __builtin_amdgcn_s_sleep(64);
+                        if (++spins > (1u << 20))
+                        {
+                            if (lane == 0)
+                                __hip_atomic_fetch_add(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __builtin_trap(); // a lost dependency: fail the launch instead of hanging the queue
+                        }
+                    }
+                    if (lane == 0)
+                    {
+                        __hip_atomic_fetch_add(status + 1 + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (spins)
+                            __hip_atomic_fetch_add(status + 3 + which, spins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                __syncthreads();
+            };
+            // wave 0: min over the sixteen workgroups of word `which` of what was polled (lanes 0..31 hold the block's 32 words)
+            auto team_min = [&](unsigned polled, unsigned which) -> unsigned {
+                unsigned mn = (lane < 32 && (lane & 1) == which) ? polled : 0xffffffffu;
+#pragma unroll
+                for (int sft = 1; sft < 32; sft <<= 1)
+                    mn = min(mn, (unsigned)__shfl_xor((int)mn, sft));
+                return mn;
+            };
+            if (tid < 2)
+                s_have[tid] = 0;
+            uint64_t nxt[16];
+            unsigned polled = 0;
+            if (role == 0)
+            {
+                // ---------------- pass 1: column tile `tile` of every transform of the team
+                const unsigned c = tid & 15, hi = tid >> 4;
+                TwRegs<true> tw1;
+                p1_load_tw<true, D1>(tw1, tab, tid);
+                const uint64_t *in0 = a.data + ((size_t)comp << 16) + tile * 16 + c;
+                auto fetch = [&](unsigned k) {
+                    const uint64_t *in = in0 + (size_t)(slice + k * Z) * a.outer_stride;
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        nxt[e] = mid_ld<16>(in + (size_t)(e * 16 + hi) * 256);
+                };
+                __syncthreads(); // s_have
+                if (iters)
+                    fetch(0);
+                for (unsigned k = 0; k < iters; k++)
+                {
+                    double x[16];
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        x[e] = F::from_canon(nxt[e], m);
+                    if (k + 1 < iters)
+                        fetch(k + 1);
+                    phase_fwd_end<true, 4, true>(x, m, [&](int t, int g) { return ld_uniform(tab, (1u << t) + g); });
+                    if (wave == 0 && k > 0)
+                    {
+                        const unsigned mn = team_min(polled, 1);
+                        if (lane == 0)
+                            s_have[0] = mn;
+                    }
+                    // this wave's ring stores of iteration k - 1 are in memory: they were issued before the 16 prefetch loads above, and a
+                    // wave's vector memory operations complete in order
+                    if (k + 1 < iters)
+                        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                    else
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads(); // B1
+                    if (tid == 0 && k > 0)
+                        __hip_atomic_store(prog + tile * 2, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        lds[(e * 16 + hi) * G::CP + c] = F::raw(x[e]);
+                    const unsigned landed = s_have[0];
+                    __syncthreads(); // B2
+                    if (wave == 0 && lane < 32)
+                        polled = __hip_atomic_load(prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int rb = 0; rb < 16; rb++)
+                        x[rb] = F::unraw(lds[(hi * 16 + rb) * G::CP + c]);
+                    phase_fwd_end<true, 4, true>(x, m, [&](int t, int g) { return tw1.get((1 << t) + g); });
+                    // the slot's previous occupant (iteration k - R) must have been read by all sixteen pass-2 workgroups
+                    if (k >= R && landed < k - R + 1)
+                        wait_team(1, k - R + 1);
+                    const __amdgpu_buffer_rsrc_t rs = window(ring + ((size_t)(k % R) << 16) + (size_t)(hi * 16 + tile) * 256);
+#pragma unroll
+                    for (int j2 = 0; j2 < 8; j2++)
+                    {
+                        const uint64_t w0 = F::raw(x[2 * j2]), w1 = F::raw(x[2 * j2 + 1]);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{ (uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32) }, rs, (int)(c * 16), j2 * 256, 16);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0 && iters)
+                    __hip_atomic_store(prog + tile * 2, iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else
+            {
+                // ---------------- pass 2: row tile `tile`; thread (u, v) ends up with row u, column-in-block v of the sixteen blocks
+                const unsigned u = tid >> 4, v = tid & 15;
+                uint64_t *lds_wave = lds + wave * (4 * kRowWords);
+                TwRegs<true> pre_b;
+                double *twa = reinterpret_cast<double *>(lds + kLds2Words);
+                stage_twa<D1>(twa, tab, tile, tid);
+                load_tw<true, 4>(pre_b, tab, [&](int t) { return (1u << (D1 + 4 + t)) + (((tile * 16 + u) * 16 + v) << t); });
+                auto fetch = [&](unsigned j) {
+                    const __amdgpu_buffer_rsrc_t rs = window(ring + ((size_t)(j % R) << 16) + (size_t)tile * 4096);
+#pragma unroll
+                    for (int j2 = 0; j2 < 8; j2++)
+                    {
+                        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((u >> 1) * 256 + v * 16), (int)(((u & 1) * 8 + j2) * 2048), 16);
+                        nxt[2 * j2] = (uint64_t)w.x | ((uint64_t)w.y << 32);
+                        nxt[2 * j2 + 1] = (uint64_t)w.z | ((uint64_t)w.w << 32);
+                    }
+                };
+                __syncthreads(); // twa, s_have
+                if (iters)
+                {
+                    wait_team(0, 1);
+                    fetch(0);
+                }
+                for (unsigned k = 0; k < iters; k++)
+                {
+                    double x[16];
+#pragma unroll
+                    for (int j2 = 0; j2 < 8; j2++)
+                    {
+                        const auto lo = __builtin_amdgcn_permlane16_swap((uint32_t)nxt[2 * j2], (uint32_t)nxt[2 * j2 + 1], false, false);
+                        const auto hi32 = __builtin_amdgcn_permlane16_swap((uint32_t)(nxt[2 * j2] >> 32), (uint32_t)(nxt[2 * j2 + 1] >> 32), false, false);
+                        x[j2] = F::unraw((uint64_t)lo[0] | ((uint64_t)hi32[0] << 32));
+                        x[8 + j2] = F::unraw((uint64_t)lo[1] | ((uint64_t)hi32[1] << 32));
+                    }
+                    asm volatile("" ::"v"(x[15]), "v"(x[7]) : "memory"); // this wave's ring loads of iteration k have landed
+                    if (wave == 0 && k > 0)
+                    {
+                        const unsigned mn = team_min(polled, 0);
+                        if (lane == 0)
+                            s_have[k & 1] = mn;
+                    }
+                    __syncthreads(); // every wave has its tile: the slot may be rewritten
+                    if (tid == 0)
+                        __hip_atomic_store(prog + tile * 2 + 1, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (k + 1 < iters)
+                    {
+                        if (k == 0 || s_have[k & 1] < k + 2)
+                            wait_team(0, k + 2);
+                        fetch(k + 1);
+                        if (wave == 0 && lane < 32)
+                            polled = __hip_atomic_load(prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    p2_tile<true, D1, false, false, true, true>(x, m, tab, twa, nullptr, lds_wave, tile, tid, nullptr, &pre_b);
+                    constexpr int BOUT = kP2Out<0, D1>;
+                    uint64_t val[16];
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        val[e] = a.lazy ? fwd_out_lazy<true, 0, BOUT>(x[e], m) : fwd_out_canon<true, 0, BOUT>(x[e], m);
+                    const size_t row0 = ((size_t)comp << 16) + ((size_t)(tile * 16 + wave * 4) << 8);
+                    store_rows(val, lds_wave, a.data + (size_t)(slice + k * Z) * a.outer_stride + row0, tid);
+                }
+            }
+#endif
+        }
         // ---- host side of ntt2_fwd_ring
 #ifndef SEALHIP_RING_WAVES
 #define SEALHIP_RING_WAVES 3 // waves per SIMD = workgroups per CU the kernel is compiled for
+#endif
+#ifndef SEALHIP_RING2_WAVES
+#define SEALHIP_RING2_WAVES 4
 #endif
         // L, R: pass 2 runs three iterations behind pass 1, six slots per team.  What a workgroup polls after the second barrier of iteration k
         // is what its team published at the first barrier of iteration k (k pass-1 iterations complete, k - L pass-2 iterations landed) - or
@@ -251,9 +479,11 @@ namespace sealhip
         // took the slow path - a fresh poll behind every outstanding store - and the kernel ran three times slower).
         constexpr unsigned kRingLag = 3, kRingSlots = 6;
         constexpr size_t kRingLdsBytes = (4 * kRingQuarter + 240 + 256) * 8;
+        constexpr size_t kRing2LdsBytes = (kLds2Words + 240) * 8; // pass 2's wave-local buffers + its row-shared twiddles (pass 1's exchange is smaller)
         struct RingPlan
         {
-            unsigned capacity = 0; // workgroups of ntt2_fwd_ring the device holds at once (0: kernel not usable)
+            unsigned capacity = 0; // workgroups of the selected kernel the device holds at once (0: kernel not usable)
+            int mode = 0;          // SEALHIP_NTT_RING: 1 = fused workgroups (ntt2_fwd_ring), 2 = specialised workgroups (ntt2_fwd_ring2)
         };
         inline const RingPlan &ring_plan()
         {
@@ -266,15 +496,23 @@ namespace sealhip
                 const char *env = std::getenv("SEALHIP_NTT_RING");
                 if (!env || std::atoi(env) == 0)
                     return p;
+                const int mode = std::atoi(env) == 2 ? 2 : 1;
                 int dev = 0, cus = 0, per_cu = 0;
                 if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
                     return p;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&ntt2_fwd_ring<SEALHIP_RING_WAVES>), kThreads, kRingLdsBytes) != hipSuccess)
+                const int waves = mode == 2 ? SEALHIP_RING2_WAVES : SEALHIP_RING_WAVES;
+                const hipError_t e = mode == 2
+                    ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&ntt2_fwd_ring2<SEALHIP_RING2_WAVES>), kThreads, kRing2LdsBytes)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&ntt2_fwd_ring<SEALHIP_RING_WAVES>), kThreads, kRingLdsBytes);
+                if (e != hipSuccess)
                     return p;
-                if (per_cu > SEALHIP_RING_WAVES)
-                    per_cu = SEALHIP_RING_WAVES;
+                if (per_cu > waves)
+                    per_cu = waves;
                 if (per_cu > 0 && cus > 0)
+                {
                     p.capacity = (unsigned)per_cu * (unsigned)cus;
+                    p.mode = mode;
+                }
                 return p;
             }();
             return plan;
@@ -285,7 +523,7 @@ namespace sealhip
             const unsigned cap = ring_plan().capacity;
             if (!cap || !nc)
                 return 0;
-            unsigned z = cap / (16 * nc);
+            unsigned z = cap / ((ring_plan().mode == 2 ? 32 : 16) * nc); // a team is 16 workgroups, or 16 + 16 with one role each
             // every team needs a few iterations for the pipeline (lag + slots) to pay; small batches keep the two-launch kernels
             const unsigned min_iters = 2 * (kRingLag + kRingSlots);
             if (z > nouter / min_iters)
@@ -358,7 +596,10 @@ namespace sealhip
             return e;
         if ((e = hipMemsetAsync(ra.prog, 0, ((size_t)teams * kRingProgStride + 16) * 4, st)) != hipSuccess)
             return e;
-        hipLaunchKernelGGL((ntt2_fwd_ring<SEALHIP_RING_WAVES>), dim3(teams * 16), dim3(kThreads), kRingLdsBytes, st, f, ra);
+        if (ring_plan().mode == 2)
+            hipLaunchKernelGGL((ntt2_fwd_ring2<SEALHIP_RING2_WAVES>), dim3(teams * 32), dim3(kThreads), kRing2LdsBytes, st, f, ra);
+        else
+            hipLaunchKernelGGL((ntt2_fwd_ring<SEALHIP_RING_WAVES>), dim3(teams * 16), dim3(kThreads), kRingLdsBytes, st, f, ra);
         if ((e = hipGetLastError()) != hipSuccess)
             return e;
         if ((e = hipEventRecord(ch.last, st)) != hipSuccess)
@@ -369,7 +610,7 @@ namespace sealhip
         {
             unsigned h[5] = { 0, 0, 0, 0, 0 };
             if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h, ra.prog + (size_t)teams * kRingProgStride, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
-                std::fprintf(stderr, "ntt2_fwd_ring: %u teams x 16 workgroups, %u outer items, lost %u, slow waits (wave level) for pass 1 %u (%u sleeps) / for a free slot %u (%u sleeps)\n", teams, run.nouter, h[0], h[1], h[3], h[2], h[4]);
+                std::fprintf(stderr, "ntt2_fwd_ring: mode %d, %u teams, %u outer items, lost %u, slow waits (wave level) for pass 1 %u (%u sleeps) / for a free slot %u (%u sleeps)\n", ring_plan().mode, teams, run.nouter, h[0], h[1], h[3], h[2], h[4]);
         }
         return hipSuccess;
     }

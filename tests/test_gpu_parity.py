@@ -63,13 +63,14 @@ def test_ntt_two_pass_loop(gpu, n, bits, polys):
 # the ONE-launch kernel of N = 2^16 (ntt2_ring.hip: both passes in every workgroup, the intermediate in a re-used ring, hand-over by
 # progress words) - opt-in (SEALHIP_NTT_RING=1, read once per process, hence the child), every polynomial against the reference;
 # ragged slices (301 = 16 teams x 18 or 19 iterations), one and three double-precision components next to integer ones
+@pytest.mark.parametrize("mode", [1, 2])   # 1: every workgroup does both passes; 2: pass-1 and pass-2 workgroups side by side
 @pytest.mark.parametrize("bits,polys", [([50, 45, 60, 50], 301), ([45, 60], 700), ([50] * 8, 160)])
-def test_ntt_ring_one_launch(gpu, bits, polys):
+def test_ntt_ring_one_launch(gpu, bits, polys, mode):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     code = "import sys; sys.path.insert(0, %r); import parity_cases as P; P.case_ntt(65536, %r, polys=%d)" % (here, bits, polys)
-    env = dict(os.environ, SEALHIP_NTT_RING="1", SEALHIP_RING_DEBUG="1")
+    env = dict(os.environ, SEALHIP_NTT_RING=str(mode), SEALHIP_RING_DEBUG="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     ran = [line for line in r.stderr.splitlines() if line.startswith("ntt2_fwd_ring:")]
