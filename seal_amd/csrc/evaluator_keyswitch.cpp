@@ -583,7 +583,11 @@ namespace sealhip
         if (keys.context() == &context_ && key_index < keys.slots() && keys.has_key(key_index) && keys.key(key_index).register_order)
         {
             const size_t wgs = e.batch() * (size_t)(K + 1) * (context_.n() >> 12);
-            split = (unsigned)(2048 / (wgs ? wgs : 1)); // measured at C5: best split 8 / 4 / 2 / 1 at batch 1 / 2 / 4 / >= 8
+            split = (unsigned)(2048 / (wgs ? wgs : 1)); // measured at C5: best split 4 / 4 / 2 / 1 at batch 1 / 2 / 4 / >= 8
+            // (round 6, batch 1: split 8 / 6 / 5 / 4 / 3 / 2 = 0.338 / 0.334 / 0.330 / 0.328 / 0.337 / 0.360 ms eager, 0.315 / 0.312 / 0.300 /
+            // 0.296 / 0.307 / 0.316 ms as a graph replay: the pass that adds the groups reads `split` buffers of 16 MiB)
+            if (split > 4)
+                split = 4;
             if (const char *f = std::getenv("SEALHIP_KS_SPLIT"))
                 split = (unsigned)std::atoi(f);
             if (split > 8)
@@ -676,6 +680,9 @@ namespace sealhip
         // plus P/2: the rounding's addend goes in here, once per coefficient (NttBatch::out_add; the maps below run in mode 3)
         NttBatch bi = plain_batch(acc_p + (size_t)K * N, (size_t)(K + 1) * N, 1, 2 * B, L - 1);
         bi.out_add = P >> 1;
+        // (round 6, measured and not kept: at small batches this transform and the one of the last component below - different components,
+        // 2 B x 16 workgroups each - side by side on a forked lane: batch 1 eager 0.328 -> 0.360 ms because the pool has to order the lane's
+        // scratch across streams, graph replay 0.296 either way; profiles/r06_latency.txt)
         ck(ntt_inverse(tb, bi, 0, stream_), "ks intt special");
 
         if (acc_has_addend)

@@ -69,6 +69,37 @@ namespace sealhip
 #endif
             *p = v;
         }
+        // two adjacent words (16-byte aligned) with one 16-byte access
+        template <int BIT>
+        __device__ __forceinline__ void mid_ld2(const uint64_t *p, uint64_t &a, uint64_t &b)
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+            const u64x2 *q = reinterpret_cast<const u64x2 *>(p);
+            const u64x2 v = (SEALHIP_KS_NT & BIT) != 0 ? __builtin_nontemporal_load(q) : *q;
+            a = v.x;
+            b = v.y;
+#else
+            a = p[0];
+            b = p[1];
+#endif
+        }
+        template <int BIT>
+        __device__ __forceinline__ void mid_st2(uint64_t *p, uint64_t a, uint64_t b)
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 *q = reinterpret_cast<u64x2 *>(p);
+            const u64x2 v = { a, b };
+            if constexpr ((SEALHIP_KS_NT & BIT) != 0)
+                __builtin_nontemporal_store(v, q);
+            else
+                *q = v;
+#else
+            p[0] = a;
+            p[1] = b;
+#endif
+        }
 #ifdef SEALHIP_MID_WAVE_MAJOR
         __device__ __forceinline__ unsigned mid_lane(unsigned tid) { return (tid >> 6) * 1024 + (tid & 63); }
         constexpr unsigned kMidRow = 64;
@@ -104,6 +135,11 @@ namespace sealhip
         // (e, v) takes pack (cg = e, v)), decodes all sixteen rows and hands them to their owners (u, v) through LDS.
         // 13/16 of the intermediate's bytes in both directions; the values are the same doubles, so the results are the same words.
         constexpr unsigned kPackWords = 13, kPackBlock = kPackWords * 16; // words per pack / per 16 x 16 block
+        // SEALHIP_PACK_VEC16 (round 6): the twelve words 0..11 of a pack travel as six 16-byte pairs - pair j of column v at j*32 + v*2,
+        // word 12 at 192 + v - so that either pass issues 7 instead of 13 memory instructions per thread and the runs are 256 bytes
+#ifndef SEALHIP_PACK_VEC16
+#define SEALHIP_PACK_VEC16 1
+#endif
         constexpr double kPackMagic = 6755399441055744.0;                  // 2^52 + 2^51
         constexpr unsigned kPackLdsRow = 272;                              // words between the rows u of the hand-over buffer
         __device__ __forceinline__ void pack52(const double (&x)[16], uint64_t (&w)[13])
@@ -565,9 +601,17 @@ namespace sealhip
                     sink ^= w[k];
                 mid_st<1>(o, sink);
 #else
+#if SEALHIP_PACK_VEC16
+                uint64_t *o2 = o + c; // column c of the block: pair j at j*32 + c*2
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+                    mid_st2<1>(o2 + j * 32, w[2 * j], w[2 * j + 1]);
+                mid_st<1>(o + 192, w[12]);
+#else
 #pragma unroll
                 for (int k = 0; k < 13; k++)
                     mid_st<1>(o + k * 16, w[k]);
+#endif
 #endif
                 return;
             }

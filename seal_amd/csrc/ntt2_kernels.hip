@@ -161,9 +161,17 @@ namespace sealhip
             [[maybe_unused]] const uint64_t *pk0 = a.mid + ((size_t)comp << G::n) + (size_t)(hg * 16 + (tid >> 4)) * kPackBlock + (tid & 15);
             [[maybe_unused]] auto fetch_packed = [&](unsigned z) {
                 const uint64_t *mp = pk0 + (((size_t)z * a.ncomp) << G::n);
+#if SEALHIP_PACK_VEC16
+                const uint64_t *m2 = mp + (tid & 15); // pair j of this thread's column at j*32 + v*2 (mp already holds + v)
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+                    mid_ld2<4>(m2 + j * 32, nxt[2 * j], nxt[2 * j + 1]);
+                nxt[12] = mid_ld<4>(mp + 192);
+#else
 #pragma unroll
                 for (int k = 0; k < 13; k++)
                     nxt[k] = mid_ld<4>(mp + k * 16);
+#endif
             };
             const unsigned ostride = gridDim.z;
             TwRegs<FP> pre_a, pre_b;
