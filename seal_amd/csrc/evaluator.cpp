@@ -1,5 +1,6 @@
 // Evaluator, part 1: construction, streams and graph capture, deferred key-switch tails, negate / add / sub, transforms, plaintext operands, multiply
 #include "evaluator_common.h"
+#include <atomic>
 
 namespace sealhip
 {
@@ -898,6 +899,12 @@ namespace sealhip
             const Level &lvl = *e1.level();
             PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
             dest.reshape_uninitialized(&lvl, 3);
+            // (development builds, bound only: SEALHIP_AB_SKIP_TENSOR leaves the product unwritten - what fusing the tensor product into its
+            // consumers could save at most, profiles/r06_tensor_fusion_bound.txt)
+            // (the first two calls still run, so that the buffers hold residues, not zeros: the chip clocks higher on zero data)
+            static const bool skip_tensor = shl_ab_getenv("SEALHIP_AB_SKIP_TENSOR") != nullptr;
+            static std::atomic<unsigned> tensor_calls{ 0 };
+            if (!skip_tensor || tensor_calls.fetch_add(1) < 2)
             ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, e1.data(), e2.data(), dest.data(), g, stream_), "ckks_multiply");
             dest.is_ntt_form() = true;
             dest.correction_factor() = 1;

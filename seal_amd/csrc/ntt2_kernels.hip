@@ -2193,6 +2193,8 @@ namespace sealhip
     {
         if (t.log_n != 16 || b.src || b.epi || b.tail2 || b.ncomp == 0 || b.nouter == 0)
             return 0;
+        if (!ntt2_ring_teams(1, b.nouter)) // the kernels are opt-in (SEALHIP_NTT_RING) and need a batch that loops: nothing to plan otherwise
+            return 0;
         // the double-precision runs of the batch (one after the other on the launcher's stream: they share the scratch)
         size_t words = 0;
         for (const CompRun &r : comp_runs(t, b.comp_prime, b.prime_first, b.ncomp, b.cls_hint))
