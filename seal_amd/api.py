@@ -1558,6 +1558,13 @@ def tail_stats():
     return a.value, b.value, c.value
 
 
+def product_stats():
+    """deferred tensor products (sealhip.h: SealHip_ProductStats): (consumed by a fused relinearize, formed on their own, discarded)"""
+    a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    N.check(N.lib().SealHip_ProductStats(C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value
+
+
 def ks_chunk_stats():
     """chunked key switching (sealhip.h: SealHip_KsChunkStats): (calls that ran in chunks, chunks issued, largest intermediate in bytes)"""
     a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

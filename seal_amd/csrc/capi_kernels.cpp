@@ -162,6 +162,19 @@ extern "C"
             *scratch_bytes_max = w * 8;
         SHL_CATCH
     }
+    SHL_FUNC SealHip_ProductStats(uint64_t *fused, uint64_t *formed, uint64_t *dropped)
+    {
+        SHL_TRY
+        uint64_t f, p, d;
+        lazy_product_stats(f, p, d);
+        if (fused)
+            *fused = f;
+        if (formed)
+            *formed = p;
+        if (dropped)
+            *dropped = d;
+        SHL_CATCH
+    }
     SHL_FUNC SealHip_TailStats(uint64_t *folded, uint64_t *plain, uint64_t *dropped)
     {
         SHL_TRY

@@ -73,6 +73,65 @@ namespace sealhip
         if (caller != stream_ && !capturing_) // (a stream that is recording cannot be waited for: its work runs when the graph does)
             ck(hipStreamSynchronize(stream_), "deferred key-switch tail");
     }
+    // ---- deferred tensor products (evaluator.h: LazyProduct)
+    namespace
+    {
+        std::atomic<uint64_t> g_prod_fused{ 0 }, g_prod_formed{ 0 }, g_prod_dropped{ 0 };
+    }
+    void lazy_product_stats(uint64_t &fused, uint64_t &formed, uint64_t &dropped)
+    {
+        fused = g_prod_fused.load();
+        formed = g_prod_formed.load();
+        dropped = g_prod_dropped.load();
+    }
+    void Evaluator::defer_product(Ciphertext &dest, const Ciphertext &x, const Ciphertext &y) const
+    {
+        dest.lazy_prod_ = new LazyProduct{ this, &x, &y };
+        lazy_product_link(&dest, &x, &y, x.prod_readers_, x.prod_reader_count_, y.prod_readers_, y.prod_reader_count_);
+        std::lock_guard<std::mutex> lock(lazy_mu_);
+        lazy_cts_.push_back(&dest);
+    }
+    // (called by Ciphertext::settle_product, which unlinks the operands and deletes the record afterwards)
+    void Evaluator::complete_product(Ciphertext &dest, LazyProduct p) const
+    {
+        const hipStream_t caller = DevicePool::thread_stream();
+        StreamScope pool_scope(stream_);
+        {
+            std::lock_guard<std::mutex> lock(lazy_mu_);
+            lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &dest), lazy_cts_.end());
+        }
+        const Level &lvl = *dest.level_;
+        PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)dest.batch() };
+        g_prod_formed++;
+        ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, p.x->data(), p.y->data(), dest.data_, g, stream_), "ckks_multiply (deferred)");
+        // the product is formed on this evaluator's stream; a caller on another stream - the one about to read the words or to
+        // overwrite an operand - continues only when it is done
+        if (caller != stream_ && !capturing_)
+            ck(hipStreamSynchronize(stream_), "deferred tensor product");
+    }
+    // the fused relinearisation takes the record over: the destination is no longer pending, the operands are released
+    LazyProduct Evaluator::detach_product(Ciphertext &dest) const
+    {
+        const LazyProduct p = *dest.lazy_prod_;
+        delete dest.lazy_prod_;
+        dest.lazy_prod_ = nullptr;
+        lazy_product_unlink(&dest, p.x->prod_readers_, p.x->prod_reader_count_);
+        lazy_product_unlink(&dest, p.y->prod_readers_, p.y->prod_reader_count_);
+        std::lock_guard<std::mutex> lock(lazy_mu_);
+        lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &dest), lazy_cts_.end());
+        return p;
+    }
+    void Evaluator::forget_product(const Ciphertext &dest) const
+    {
+        std::lock_guard<std::mutex> lock(lazy_mu_);
+        lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &dest), lazy_cts_.end());
+        g_prod_dropped++;
+    }
+    void lazy_product_count_fused()
+    {
+        g_prod_fused++;
+    }
+
     void Evaluator::settle_all() const
     {
         for (;;)
@@ -108,7 +167,8 @@ namespace sealhip
                         break;
                     c = lazy_cts_.back();
                 }
-                const_cast<Ciphertext *>(c)->drop_lazy(); // removes it from the list
+                const_cast<Ciphertext *>(c)->drop_product(); // either removes it from the list
+                const_cast<Ciphertext *>(c)->drop_lazy();
             }
         }
         for (auto &kv : ks_maps_)
@@ -898,14 +958,27 @@ namespace sealhip
                 throw std::invalid_argument("encrypted1 or encrypted2 must be in NTT form");
             const Level &lvl = *e1.level();
             PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
+            // operands first: whatever is pending on them (a key-switch tail, a product of their own) is settled before their words are
+            // read - now or by the deferred product
+            const uint64_t *xw = e1.data(), *yw = e2.data();
             dest.reshape_uninitialized(&lvl, 3);
-            // (development builds, bound only: SEALHIP_AB_SKIP_TENSOR leaves the product unwritten - what fusing the tensor product into its
-            // consumers could save at most, profiles/r06_tensor_fusion_bound.txt)
-            // (the first two calls still run, so that the buffers hold residues, not zeros: the chip clocks higher on zero data)
+            // Round 6: batches whose key switch runs un-split at a two-pass size - the product is not formed now (LazyProduct): a
+            // relinearize_inplace that follows forms it inside its own kernels, anything else that needs the words forms it first
+            const char *lazy_env = std::getenv("SEALHIP_LAZY_PRODUCT"); // (read per call: the tests switch it)
+            const bool lazy_product_ok = !(lazy_env && std::atoi(lazy_env) == 0);
+            // (SEALHIP_LAZY_PRODUCT_MIN_WGS: tests reach the fused path at small batches together with SEALHIP_KS_SPLIT=1)
+            const char *min_env = std::getenv("SEALHIP_LAZY_PRODUCT_MIN_WGS");
+            const size_t min_wgs = min_env ? (size_t)std::atol(min_env) : 1024;
+            const bool defer = lazy_product_ok && !capturing_ && lvl.K >= 2 && ntt2_supports(context_.log_n()) &&
+                               (size_t)e1.batch() * (lvl.K + 1) * (context_.n() >> 12) > min_wgs && !transparent_check_;
+            // (development builds, bound only: SEALHIP_AB_SKIP_TENSOR leaves the product unwritten after two real calls - what fusing the
+            // tensor product into its consumers could save at most, profiles/r06_lazy_product.txt)
             static const bool skip_tensor = shl_ab_getenv("SEALHIP_AB_SKIP_TENSOR") != nullptr;
             static std::atomic<unsigned> tensor_calls{ 0 };
-            if (!skip_tensor || tensor_calls.fetch_add(1) < 2)
-            ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, e1.data(), e2.data(), dest.data(), g, stream_), "ckks_multiply");
+            if (defer)
+                defer_product(dest, e1, e2);
+            else if (!skip_tensor || tensor_calls.fetch_add(1) < 2)
+                ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, xw, yw, dest.data(), g, stream_), "ckks_multiply");
             dest.is_ntt_form() = true;
             dest.correction_factor() = 1;
             dest.scale() = e1.scale() * e2.scale();

@@ -33,6 +33,21 @@ namespace sealhip
         // the tail, folded into a rescale or not, reads one operand where it read two
         bool with_addend = false;
     };
+    // A CKKS 2 x 2 tensor product that has not been formed yet (round 6; Evaluator::multiply into a third object, batches large enough
+    // for the un-split key switch, two-pass sizes): the destination has its shape and metadata, its words are pending.  A
+    // relinearize_inplace on the same evaluator then never stores the product: the third polynomial is formed inside the inverse
+    // transform that opens the key switch (NttBatch::prod_x), the first two inside the key switch's last epilogue
+    // (KsFusedArgs::fold_x) - one kernel and 45 MB per ciphertext less at the headline size.  Anything else that touches the
+    // destination's words forms the product first (Ciphertext::settle), and anything that is about to WRITE, re-shape or destroy an
+    // operand forms the products that read it first (Ciphertext::before_write): same words either way.  SEALHIP_LAZY_PRODUCT=0 turns
+    // the deferral off.
+    class Ciphertext;
+    struct LazyProduct
+    {
+        const Evaluator *owner;
+        const Ciphertext *x, *y;
+    };
+    void lazy_product_stats(uint64_t &fused, uint64_t &formed, uint64_t &dropped);
     // process-wide counters (tests, tools): tails folded into a rescale / completed on their own / discarded unrun
     void lazy_tail_stats(uint64_t &folded, uint64_t &plain, uint64_t &dropped);
     // chunked key switching (evaluator_keyswitch.cpp): calls that ran in chunks, chunks issued, largest intermediate held since the previous query (words)
@@ -62,6 +77,7 @@ namespace sealhip
         uint64_t *data()
         {
             settle();
+            before_write(); // a mutable pointer is a write as far as pending products of THIS ciphertext's words are concerned
             return data_;
         }
         const uint64_t *data() const
@@ -74,6 +90,7 @@ namespace sealhip
         uint64_t *plane(size_t p) { return data() + p * plane_words(); }
         const uint64_t *plane(size_t p) const { return data() + p * plane_words(); }
         bool has_lazy_tail() const { return lazy_ != nullptr; }
+        bool has_lazy_product() const { return lazy_prod_ != nullptr; }
         bool has_storage() const { return data_ != nullptr; } // a question about the buffer, not about its words
 
         // Ciphertext::resize(context, parms_id, size) (ciphertext.cpp:101-116): keeps the leading
@@ -95,6 +112,7 @@ namespace sealhip
         void set_level_unchecked(const Level *level)
         {
             settle();
+            before_write();
             level_ = level;
         }
 
@@ -112,8 +130,25 @@ namespace sealhip
         mutable LazyTail *lazy_ = nullptr;
         void settle() const; // run it now
         void drop_lazy();    // the words are about to be replaced: discard it
+        // pending tensor product whose destination this is (owned; see LazyProduct), and the pending products that READ this object
+        mutable LazyProduct *lazy_prod_ = nullptr;
+        mutable std::vector<const Ciphertext *> prod_readers_;
+        mutable unsigned prod_reader_count_ = 0; // = prod_readers_.size(), readable without the list's lock
+        void settle_product() const;             // form it now
+        void drop_product();                     // the words are about to be replaced: discard it
+        void before_write() const                // form every pending product that reads this object's words
+        {
+            if (__atomic_load_n(&prod_reader_count_, __ATOMIC_ACQUIRE))
+                settle_readers();
+        }
+        void settle_readers() const;
         friend class Evaluator;
     };
+
+    // LazyProduct bookkeeping (objects.cpp): the reader lists are only touched under one global lock
+    void lazy_product_link(const Ciphertext *dest, const Ciphertext *x, const Ciphertext *y, std::vector<const Ciphertext *> &rx,
+                           unsigned &nx, std::vector<const Ciphertext *> &ry, unsigned &ny);
+    void lazy_product_unlink(const Ciphertext *dest, std::vector<const Ciphertext *> &r, unsigned &n);
 
     // seal::Plaintext (plaintext.h) resident in HBM: either coeff_count <= N coefficients modulo t (BFV/BGV,
     // parms_id_zero) or, in NTT form, K*N words at a level (CKKS always; BFV/BGV after transform_to_ntt_inplace).
@@ -290,8 +325,12 @@ namespace sealhip
         size_t switch_key_acc_words(const Ciphertext &encrypted) const;
         // split > 1 (fused path only): the digit range is cut into `split` in-launch groups and acc holds `split` buffers
         // (ntt2_kernels.h: KsFusedArgs::parts); the caller adds them with k_keyswitch_reduce(..., local_parts = split)
+        // product (round 6, CKKS, fused path, split 1, fold_addend): `encrypted` is a tensor product that was never stored - `target`
+        // is where its third polynomial is WRITTEN (by the inverse transform that forms it from the operands), the two leading
+        // polynomials are formed in the key switch's epilogue (KsFusedArgs::fold_x)
         void switch_key_partial(const Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index,
-                                unsigned j0, unsigned j1, uint64_t *acc, unsigned split = 1, bool fold_addend = false) const;
+                                unsigned j0, unsigned j1, uint64_t *acc, unsigned split = 1, bool fold_addend = false,
+                                const LazyProduct *product = nullptr) const;
         // fold_addend (CKKS, fused path, the full digit range, split 1): the data-prime components of acc leave as c + S P^-1
         // (KsFusedArgs::fold_c0); the matching finish call says so with acc_has_addend
         // may_defer (relinearize_finish / apply_galois_finish / the in-library exchange): CKKS at the two-pass sizes copies the reduced
@@ -383,6 +422,12 @@ namespace sealhip
         friend class Ciphertext;
         void defer_tail(Ciphertext &e, uint64_t *acc, bool with_addend) const;
         void complete_tail(Ciphertext &e, LazyTail t) const;     // the plain mod-down, then the sums go back to the pool
+        // deferred tensor products (LazyProduct): record / form now / take over for the fused relinearisation / discard
+        void defer_product(Ciphertext &dest, const Ciphertext &x, const Ciphertext &y) const;
+        void complete_product(Ciphertext &dest, LazyProduct p) const;
+        LazyProduct detach_product(Ciphertext &dest) const;
+        void forget_product(const Ciphertext &dest) const;
+        bool relinearize_from_product(Ciphertext &e, const KSwitchKeys &relin_keys) const; // false: conditions not met, nothing done
         void forget_tail(const Ciphertext &e, LazyTail t) const; // discard
         LazyTail detach_tail(Ciphertext &e) const;
         void settle_all() const;

@@ -154,12 +154,69 @@ namespace sealhip
             throw std::invalid_argument("not enough relinearization keys");
         if (destination_size == size)
             return;
+        if (size == 3 && e.has_lazy_product() && relinearize_from_product(e, relin_keys))
+            return;
         size_t relins_needed = size - destination_size;
         // the reference passes the LAST polynomial as the target of every step (evaluator.cpp:1180-1188)
         for (size_t I = 0; I < relins_needed; I++)
             switch_key_inplace(e, e.plane(size - 1), relin_keys, relin_index(size - 1 - I));
         e.resize(e.level(), destination_size, stream_);
         throw_if_transparent(e);
+    }
+
+    // relinearize_inplace of a product that was never stored (LazyProduct): the same key switch with the product formed inside it.
+    // Only the configuration the large-batch headline runs: the fused path with the full digit range in one group, the addend folded
+    // into the sums, the tail deferred.  Anything else returns false and the caller takes the ordinary path (which forms the product).
+    void lazy_product_count_fused();
+    bool Evaluator::relinearize_from_product(Ciphertext &e, const KSwitchKeys &relin_keys) const
+    {
+        static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL"), fold_ok = !shl_ab_getenv("SEALHIP_KS_NO_FOLD");
+        const size_t key_index = relin_index(2);
+        const LazyProduct *pending = e.lazy_prod_;
+        if (!pending || pending->owner != this || capturing_ || !lazy_ok || !fold_ok || context_.scheme() != Scheme::ckks || !e.is_ntt_form() ||
+            !ntt2_supports(context_.log_n()) || !context_.using_keyswitching())
+            return false;
+        const unsigned K = e.level()->K;
+        if (K < 2 || key_index >= relin_keys.slots() || !relin_keys.has_key(key_index) || !relin_keys.key(key_index).register_order)
+            return false;
+        {
+            // the rule of switch_key_inplace: the digit loop cut into groups (small batches) has a reduce pass that wants the product's words
+            const size_t wgs = e.batch() * (size_t)(K + 1) * (context_.n() >> 12);
+            unsigned split = (unsigned)(2048 / (wgs ? wgs : 1));
+            if (const char *f = std::getenv("SEALHIP_KS_SPLIT"))
+                split = (unsigned)std::atoi(f);
+            if (split > 1)
+                return false;
+        }
+        const KSwitchKeys::Key &key = relin_keys.key(key_index);
+        if (key.digit0 != 0 || key.digits < K)
+            return false;
+        const LazyProduct p = detach_product(e); // from here on e is an ordinary size-3 ciphertext whose words are not there yet
+        lazy_product_count_fused();
+        uint64_t *target = e.data_ + 2 * e.plane_words(); // written by the inverse transform that forms x1 y1
+        Scratch acc(switch_key_acc_words(e));
+        try
+        {
+            switch_key_partial(e, target, relin_keys, key_index, 0, K, acc.p, 1, true, &p);
+        }
+        catch (...)
+        {
+            // nothing of e has been written except, possibly, its third polynomial: form the product the ordinary way so that e is what
+            // multiply() promised, then let the error travel
+            try
+            {
+                PlaneGeom g{ (unsigned)context_.log_n(), K, (unsigned)e.batch() };
+                (void)k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, p.x->data(), p.y->data(), e.data_, g, stream_);
+            }
+            catch (...)
+            {
+            }
+            throw;
+        }
+        defer_tail(e, acc.release(), true);
+        e.resize(e.level(), 2, stream_);
+        throw_if_transparent(e);
+        return true;
     }
 
     void Evaluator::relinearize_partial(Ciphertext &e, const KSwitchKeys &relin_keys, unsigned j0, unsigned j1, uint64_t *acc) const
@@ -229,7 +286,7 @@ namespace sealhip
 
     void Evaluator::switch_key_partial(
         const Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, unsigned j0, unsigned j1,
-        uint64_t *acc_out, unsigned split, bool fold_addend) const
+        uint64_t *acc_out, unsigned split, bool fold_addend, const LazyProduct *product) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
@@ -270,6 +327,9 @@ namespace sealhip
             throw std::invalid_argument("kswitch_keys inner dimension is too small");
         if (e.size() < 2)
             throw std::invalid_argument("encrypted size must be at least 2");
+        if (product && !(fold_addend && ntt2_supports(context_.log_n()) && product->x->level() == e.level() && product->y->level() == e.level() &&
+                         product->x->batch() == e.batch() && product->y->batch() == e.batch()))
+            throw std::invalid_argument("product");
 
         const size_t N = context_.n();
         const unsigned B = (unsigned)e.batch();
@@ -299,10 +359,22 @@ namespace sealhip
             NttBatch bt = plain_batch(t.p, (size_t)K * N, K, B, 0);
             bt.src = target;
             bt.src_outer_stride = (size_t)K * N;
+            if (product)
+            {
+                // the target x1 y1 is formed while it is loaded and stored (NTT form) where `target` points: the diagonal terms read it
+                bt.prod_x = product->x->data();
+                bt.prod_y = product->y->data();
+                bt.prod_batch = B;
+                bt.prod_outer0 = 2 * B;
+                bt.prod_out = const_cast<uint64_t *>(target);
+                bt.prod_out_stride = (size_t)K * N;
+            }
             ck(ntt_inverse(tb, bt, 0, stream_), "ks intt target");
         }
         else
         {
+            if (product)
+                throw std::invalid_argument("product");
             ck(hipMemcpyAsync(t.p, target, (size_t)B * K * N * 8, hipMemcpyDeviceToDevice, stream_), "ks copy target");
             if (ntt_target)
                 ck(ntt_inverse(tb, plain_batch(t.p, (size_t)K * N, K, B, 0), 0, stream_), "ks intt target");
@@ -337,7 +409,14 @@ namespace sealhip
             ka.j1 = j1;
             ka.key_digit0 = (unsigned)key.digit0;
             ka.parts = split ? split : 1;
-            if (fold_addend)
+            if (fold_addend && product)
+            {
+                ka.fold_x = product->x->data();
+                ka.fold_y = product->y->data();
+                ka.fold_plane = product->x->plane_words();
+                ka.fold_pm = klvl.dev.inv_q_last_mod_q;
+            }
+            else if (fold_addend)
             {
                 ka.fold_c0 = e.plane(0);
                 ka.fold_c1 = e.plane(1);
@@ -401,6 +480,15 @@ namespace sealhip
                         NttBatch bt = plain_batch(t.p + b0 * poly_words, poly_words, K, nb, 0);
                         bt.src = target + b0 * poly_words;
                         bt.src_outer_stride = poly_words;
+                        if (product)
+                        {
+                            bt.prod_x = product->x->data();
+                            bt.prod_y = product->y->data();
+                            bt.prod_batch = B;
+                            bt.prod_outer0 = 2 * B + b0;
+                            bt.prod_out = const_cast<uint64_t *>(target) + b0 * poly_words;
+                            bt.prod_out_stride = poly_words;
+                        }
                         ck(ntt2_inverse(tb, bt, 0, inv_mid.p + (size_t)l * plan.chunk * poly_words, st), "ks intt target (chunk)");
                     }
                     KsFusedArgs kc = ka;
@@ -409,7 +497,12 @@ namespace sealhip
                     kc.target_ntt = ka.target_ntt ? ka.target_ntt + b0 * poly_words : nullptr;
                     kc.mid = mid.p + (size_t)l * plan.chunk * ks_item_words;
                     kc.acc = acc_out + (size_t)b0 * 2 * (K + 1) * N;
-                    if (fold_addend)
+                    if (fold_addend && product)
+                    {
+                        kc.fold_x = ka.fold_x + b0 * poly_words;
+                        kc.fold_y = ka.fold_y + b0 * poly_words;
+                    }
+                    else if (fold_addend)
                     {
                         kc.fold_c0 = ka.fold_c0 + b0 * poly_words;
                         kc.fold_c1 = ka.fold_c1 + b0 * poly_words;
@@ -427,8 +520,8 @@ namespace sealhip
                 g_ks_chunks += c;
             }
         }
-        else if (split > 1)
-            throw std::invalid_argument("in-launch digit groups need the fused key-switch path");
+        else if (split > 1 || product)
+            throw std::invalid_argument("in-launch digit groups and deferred products need the fused key-switch path");
         else
         {
             // u[b][I][J] = NTT_I(t_J mod q_I), I over the K data primes and the special prime

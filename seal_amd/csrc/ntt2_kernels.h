@@ -69,6 +69,11 @@ namespace sealhip
         // special-prime component is the plain sum either way.
         const uint64_t *fold_c0 = nullptr, *fold_c1 = nullptr;
         const ShoupOp *fold_pm = nullptr;
+        // Round 6, instead of fold_c0 / fold_c1: the addend is a 2 x 2 tensor product that was never stored (Evaluator::multiply deferred
+        // it, evaluator.h: LazyProduct) - c0 = x0 y0, c1 = x0 y1 + x1 y0 are formed in ks2's epilogue from the operands' planes
+        // (fold_x / fold_y = plane 0 of x / y, [batch][K][N]; plane 1 is fold_plane words further).  Same restrictions as fold_c0.
+        const uint64_t *fold_x = nullptr, *fold_y = nullptr;
+        size_t fold_plane = 0;
         // Callers that cut a batch into chunks (Evaluator::switch_key_partial, round 5) decide these for the WHOLE batch:
         // order1 = which pass-1 kernel runs (-1: decided from this call's grid, 0: target-resident ks1_kernel, 1: digit-resident
         // ks1t_kernel); no_class_fork = the two arithmetic classes run one after the other on `stream` (the caller's chunk

@@ -495,6 +495,8 @@ namespace sealhip
             // NttBatch::prod_x: the input is the 2 x 2 tensor product of two size-2 operands, formed while it is loaded (two-pass kernels)
             const uint64_t *prod_x, *prod_y;
             unsigned prod_batch, prod_outer0; // items per polynomial; outer index of this launch's first item
+            uint64_t *prod_out;               // NttBatch::prod_out (null: the product is not stored)
+            size_t prod_out_stride;
             NttTables t;
         };
 
@@ -542,6 +544,8 @@ namespace sealhip
                     for (int e = 0; e < 16; e++)
                         raw[e] = add_mod(raw[e], mul_mod(rc[e], rb[e], md), md.q);
                 }
+                if (a.prod_out)
+                    store_rows(raw, lds_wave, a.prod_out + (size_t)outer * a.prod_out_stride + rows, tid);
             }
             else
                 load_rows(raw, lds_wave, a.src + (size_t)outer * a.src_outer_stride + rows, tid);
@@ -1298,6 +1302,9 @@ namespace sealhip
             // KsFusedArgs::fold_c0: components I < K leave as c_k + S_k P^-1 instead of S_k (fold_pm = P^-1 mod q_I); null = plain sums
             const uint64_t *fold_c0, *fold_c1;
             const ShoupOp *fold_pm;
+            // KsFusedArgs::fold_x: the addend is the product of two size-2 operands, formed here (c0 = x0 y0, c1 = x0 y1 + x1 y0)
+            const uint64_t *fold_x, *fold_y;
+            size_t fold_plane;
             NttTables tb;
         };
 
@@ -1562,6 +1569,64 @@ namespace sealhip
                 else
                     return F::template canon_any<IntBounds<ICLS>::hi32>(s, m);
             };
+            if (a.fold_x && I < a.K)
+            {
+                // round 6: the ciphertext being relinearised is a product that was never stored (Evaluator::multiply deferred it): its two
+                // leading polynomials are formed here from the four operand polynomials, where they are needed - once
+                const size_t crow = ((((size_t)b * a.K + I) << G::n)) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
+                const uint64_t *X0 = a.fold_x + crow, *X1 = X0 + a.fold_plane, *Y0 = a.fold_y + crow, *Y1 = Y0 + a.fold_plane;
+                const ShoupOp pm = a.fold_pm[I];
+                const uint64_t q = a.tb.mods[prime].q;
+                [[maybe_unused]] const ModDesc md = ld_uniform_mod(&a.tb.mods[prime]);
+                auto load16 = [&](const uint64_t *P, uint64_t (&v)[16]) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        v[k] = mid_ld<16>(P + (k >> 2) * 256 + (k & 3) * 64 + (tid & 63));
+                };
+                // canonical product of two canonical residues (exact either way: the double-precision form for primes below 2^50)
+                auto prod = [&](uint64_t u, uint64_t w) -> uint64_t {
+                    if constexpr (FP)
+                    {
+                        typename F::elem a0 = F::from_canon(u, m), b0 = F::from_canon(w, m);
+                        F::fix(a0, m);
+                        F::fix(b0, m);
+                        typename F::elem t = fp_mulmod(a0, b0, m.q, m.qinv);
+                        F::fix(t, m);
+                        return F::fwd_to_canon(t, m);
+                    }
+                    else
+                        return mul_mod(u, w, md);
+                };
+                uint64_t p0[16], p1[16], cv[16];
+                load16(X0, p0);
+                load16(Y0, p1);
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    cv[k] = prod(p0[k], p1[k]);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    val[e] = sum_to_canon(acc0[e]);
+                emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
+                    mid_st<16>(out + off, add_mod(mul_shoup(sv, pm.w, pm.wq, q), cv[k], q));
+                });
+                load16(Y1, p1);
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    cv[k] = prod(p0[k], p1[k]);
+                load16(X1, p0);
+                load16(Y0, p1);
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    cv[k] = add_mod(cv[k], prod(p0[k], p1[k]), q);
+                uint64_t *out1 = out + ((size_t)(a.K + 1) << G::n);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    val[e] = sum_to_canon(acc1[e]);
+                emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
+                    mid_st<16>(out1 + off, add_mod(mul_shoup(sv, pm.w, pm.wq, q), cv[k], q));
+                });
+                return;
+            }
             if (a.fold_c0 && I < a.K)
             {
                 // the key-switch tail's "c + S P^-1" happens here, where S is in registers: the tail then reads one operand, not two
@@ -2298,8 +2363,14 @@ namespace sealhip
         a.prod_x = b.prod_x;
         a.prod_y = b.prod_y;
         a.prod_batch = b.prod_batch;
-        a.prod_outer0 = 0;
-        if (b.prod_x && (!b.prod_y || !b.prod_batch || b.nouter != 3 * b.prod_batch || !b.src_outer_stride))
+        a.prod_outer0 = b.prod_outer0;
+        a.prod_out = b.prod_out;
+        a.prod_out_stride = b.prod_out_stride;
+        if (b.prod_x && (!b.prod_y || !b.prod_batch || (size_t)b.nouter + b.prod_outer0 > (size_t)3 * b.prod_batch || !b.src_outer_stride))
+            return hipErrorInvalidValue;
+        if (b.prod_x && !b.prod_outer0 && b.nouter != 3 * b.prod_batch) // the whole product, as before round 6
+            return hipErrorInvalidValue;
+        if (b.prod_out && (!b.prod_x || !b.prod_out_stride))
             return hipErrorInvalidValue;
         if (b.prod_x)
             a.src_outer_stride = b.src_outer_stride;
@@ -2309,7 +2380,9 @@ namespace sealhip
         {
             unsigned nz = b.nouter - z0 < zmax ? b.nouter - z0 : zmax;
             InvArgs az = a;
-            az.prod_outer0 = z0;
+            az.prod_outer0 = b.prod_outer0 + z0;
+            if (az.prod_out)
+                az.prod_out = a.prod_out + (size_t)z0 * a.prod_out_stride;
             az.data = a.data + (size_t)z0 * a.outer_stride;
             az.src = a.src + (size_t)z0 * a.src_outer_stride;
             az.mid = a.mid + (((size_t)z0 * a.ncomp) << t.log_n);
@@ -2353,6 +2426,8 @@ namespace sealhip
         a1.tb = t;
         if (k.fold_c0 && (a1.parts > 1 || !k.fold_c1 || !k.fold_pm || k.j0 != 0 || k.j1 != k.K))
             return hipErrorInvalidValue; // the addend may only join the COMPLETE sum of a component
+        if (k.fold_x && (k.fold_c0 || !k.fold_y || !k.fold_plane || !k.fold_pm || a1.parts > 1 || k.j0 != 0 || k.j1 != k.K))
+            return hipErrorInvalidValue;
         Ks2Args a2;
         a2.mid = k.mid;
         a2.target = k.target_ntt;
@@ -2371,6 +2446,9 @@ namespace sealhip
         a2.fold_c0 = k.fold_c0;
         a2.fold_c1 = k.fold_c1;
         a2.fold_pm = k.fold_pm;
+        a2.fold_x = k.fold_x;
+        a2.fold_y = k.fold_y;
+        a2.fold_plane = k.fold_plane;
         a2.tb = t;
         switch (t.log_n)
         {

@@ -110,6 +110,13 @@ namespace sealhip
         // p * prod_batch + b is polynomial p of item b - x0 y0, x0 y1 + x1 y0, x1 y1.  `src` is not used.
         const uint64_t *prod_x = nullptr, *prod_y = nullptr;
         unsigned prod_batch = 0;
+        // round 6 (CKKS multiply fused into relinearize): the launch covers outer items prod_outer0 .. prod_outer0 + nouter - 1 of the
+        // 3 * prod_batch (prod_outer0 = 2 * prod_batch + b0: polynomial x1 y1 of the items from b0 on, and nothing else), and the
+        // product is additionally STORED in NTT form at prod_out + (outer item in the launch) * outer stride of the product's slab
+        // (prod_out_stride words; natural order, canonical) - the key switch reads it for its diagonal terms
+        unsigned prod_outer0 = 0;
+        uint64_t *prod_out = nullptr;
+        size_t prod_out_stride = 0;
         // Two-pass engine: what the HOST knows about the arithmetic class of the components when they are named through comp_prime
         // (the launcher reads the class of prime_first + comp itself, a device table it cannot): -1 unknown - the launch carries both
         // back ends and guards every integer butterfly -, 0 every prime on the integer back end (single-class kernels, the

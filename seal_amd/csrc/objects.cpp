@@ -1,5 +1,6 @@
 // Ciphertext, Plaintext and KSwitchKeys: the device-resident objects of evaluator.h
 #include "evaluator_common.h"
+#include <algorithm>
 
 namespace sealhip
 {
@@ -20,8 +21,98 @@ namespace sealhip
         }
         thread_local const Ciphertext *tl_settling = nullptr; // the tail's own kernels read the words through data() / plane()
     } // namespace
+    namespace
+    {
+        std::mutex g_prod_mu; // the reader lists of all ciphertexts (short critical sections, never held across a launch)
+    }
+    // LazyProduct bookkeeping: the destination owns the record, the operands list the destination as a reader
+    void lazy_product_link(const Ciphertext *dest, const Ciphertext *x, const Ciphertext *y, std::vector<const Ciphertext *> &rx,
+                           unsigned &nx, std::vector<const Ciphertext *> &ry, unsigned &ny)
+    {
+        std::lock_guard<std::mutex> lock(g_prod_mu);
+        rx.push_back(dest);
+        __atomic_store_n(&nx, (unsigned)rx.size(), __ATOMIC_RELEASE);
+        if (y != x)
+        {
+            ry.push_back(dest);
+            __atomic_store_n(&ny, (unsigned)ry.size(), __ATOMIC_RELEASE);
+        }
+    }
+    void lazy_product_unlink(const Ciphertext *dest, std::vector<const Ciphertext *> &r, unsigned &n)
+    {
+        std::lock_guard<std::mutex> lock(g_prod_mu);
+        r.erase(std::remove(r.begin(), r.end(), dest), r.end());
+        __atomic_store_n(&n, (unsigned)r.size(), __ATOMIC_RELEASE);
+    }
+    void Ciphertext::settle_readers() const
+    {
+        // form every pending product that reads this object's words (each removes itself from the list)
+        for (;;)
+        {
+            const Ciphertext *r = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(g_prod_mu);
+                if (prod_readers_.empty())
+                    return;
+                r = prod_readers_.back();
+            }
+            if (r == this || tl_settling == r)
+            {
+                // (a product never lists its own destination; a product being formed right now is past needing protection)
+                lazy_product_unlink(r, prod_readers_, prod_reader_count_);
+                continue;
+            }
+            r->settle_product();
+            // whoever formed it unlinked it; if another thread is still at it, settle_product() waited for that thread
+            lazy_product_unlink(r, prod_readers_, prod_reader_count_);
+        }
+    }
+    void Ciphertext::settle_product() const
+    {
+        if (!__atomic_load_n(&lazy_prod_, __ATOMIC_ACQUIRE) || tl_settling == this)
+            return;
+        std::lock_guard<std::mutex> lock(settle_mutex(this));
+        struct Marker
+        {
+            const Ciphertext *saved;
+            explicit Marker(const Ciphertext *c) : saved(tl_settling) { tl_settling = c; }
+            ~Marker() { tl_settling = saved; }
+        } marker(this);
+        LazyProduct *pending = lazy_prod_;
+        if (!pending)
+            return; // another thread formed it while this one waited
+        const LazyProduct p = *pending;
+        try
+        {
+            p.owner->complete_product(const_cast<Ciphertext &>(*this), p);
+        }
+        catch (...)
+        {
+            lazy_product_unlink(this, p.x->prod_readers_, p.x->prod_reader_count_);
+            lazy_product_unlink(this, p.y->prod_readers_, p.y->prod_reader_count_);
+            __atomic_store_n(&lazy_prod_, (LazyProduct *)nullptr, __ATOMIC_RELEASE);
+            delete pending;
+            throw;
+        }
+        lazy_product_unlink(this, p.x->prod_readers_, p.x->prod_reader_count_);
+        lazy_product_unlink(this, p.y->prod_readers_, p.y->prod_reader_count_);
+        __atomic_store_n(&lazy_prod_, (LazyProduct *)nullptr, __ATOMIC_RELEASE);
+        delete pending;
+    }
+    void Ciphertext::drop_product()
+    {
+        if (!lazy_prod_)
+            return;
+        const LazyProduct p = *lazy_prod_;
+        delete lazy_prod_;
+        lazy_prod_ = nullptr;
+        lazy_product_unlink(this, p.x->prod_readers_, p.x->prod_reader_count_);
+        lazy_product_unlink(this, p.y->prod_readers_, p.y->prod_reader_count_);
+        p.owner->forget_product(*this);
+    }
     void Ciphertext::settle() const
     {
+        settle_product(); // a pending tensor product (a ciphertext never has both: the key switch that leaves a tail consumed the product)
         if (!__atomic_load_n(&lazy_, __ATOMIC_ACQUIRE) || tl_settling == this)
             return;
         std::lock_guard<std::mutex> lock(settle_mutex(this));
@@ -60,6 +151,8 @@ namespace sealhip
     }
     void Ciphertext::release()
     {
+        before_write(); // products that read these words are formed before the words go away
+        drop_product();
         drop_lazy();
         DevicePool::global().free_words(data_);
         data_ = nullptr;
@@ -76,6 +169,8 @@ namespace sealhip
         if (this == &o)
             return *this;
         o.settle();  // the source's words are read below
+        before_write();
+        drop_product();
         drop_lazy(); // this object's words are replaced
         if (ctx_ != o.ctx_ || batch_ != o.batch_)
         {
@@ -105,6 +200,8 @@ namespace sealhip
             throw std::invalid_argument("parms_id is not valid for encryption parameters");
         if ((size < 2 && size != 0) || size > 16) // SEAL_CIPHERTEXT_SIZE_MIN/MAX (defines.h)
             throw std::invalid_argument("invalid size");
+        settle_product(); // (a fused relinearisation has taken the product over before it trims the size; anything else needs the words)
+        before_write();
         size_t pw = batch_ * level->K * ctx_->n();
         size_t need = size * pw;
         bool same_level = (level == level_);
@@ -136,6 +233,7 @@ namespace sealhip
         if (size_capacity < 2 || size_capacity > 16) // SEAL_CIPHERTEXT_SIZE_MIN / _MAX (ciphertext.cpp:61-64)
             throw std::invalid_argument("invalid size_capacity");
         settle();
+        before_write();
         const size_t pw = batch_ * level->K * ctx_->n();
         const size_t need = size_capacity * pw;
         const size_t new_size = std::min(size_, size_capacity);
@@ -155,6 +253,8 @@ namespace sealhip
     }
     void Ciphertext::reshape_uninitialized(const Level *level, size_t size)
     {
+        before_write();
+        drop_product();
         drop_lazy();
         size_t need = size * batch_ * level->K * ctx_->n();
         if (need > capacity_words_)
@@ -168,6 +268,8 @@ namespace sealhip
     }
     void Ciphertext::adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words)
     {
+        before_write();
+        drop_product();
         drop_lazy();
         DevicePool::global().free_words(data_);
         data_ = slab;

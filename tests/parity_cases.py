@@ -1457,3 +1457,171 @@ def case_extremes_bfv(n, primes, t):
     cur = d.out(cz)
     for b in range(U):
         _eq(cur[b], o.multiply(xs[b], xs[b]), "bfv square of extreme item %d (%s)" % (b, EXTREME_PATTERNS[b]))
+
+
+# ---- deferred tensor products (sealhip.h: SealHip_ProductStats; evaluator.h: LazyProduct): Evaluator::multiply into a third object does
+#      not form the product at once; a relinearize that follows forms it inside its kernels.  Every way the caller can observe the
+#      words - of the destination or of the operands - must give the reference's words (evaluator.cpp:569-708, 1144-1199).
+def case_lazy_product(n, bits, batch=3, seed=61):
+    primes = coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    o = Oracle("ckks", n, primes)
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    zs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    qk = np.array(primes[:K], dtype=np.uint64)[None, :, None]
+    sc = float(primes[K - 1]) * 2.0 ** 10
+    prod = [o.multiply(xs[b], ys[b]) for b in range(batch)]
+    relin = [o.relinearize(p) for p in prod]
+    resc = [o.rescale(r) for r in relin]
+    import gc
+    # the launcher's rule keeps small batches eager; the test reaches the deferred path with the two knobs it documents
+    with _Env(SEALHIP_KS_SPLIT=1, SEALHIP_LAZY_PRODUCT_MIN_WGS=0, SEALHIP_LAZY_PRODUCT=None):
+        defers = 13 <= n.bit_length() - 1 <= 16 and not os.environ.get("SEALHIP_KS_EAGER_TAIL")
+
+        def fresh():
+            return d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10), S.Ciphertext(d.ctx, batch=batch)
+
+        def check3(w, what):
+            got = d.out(w)
+            for b in range(batch):
+                _eq(got[b], prod[b], what + ", item %d" % b)
+
+        def check_relin(w, what):
+            got = d.out(w)
+            for b in range(batch):
+                _eq(got[b], relin[b], what + ", item %d" % b)
+
+        # 1. the fused path: multiply -> relinearize -> rescale with nothing in between
+        f0, m0, x0 = S.product_stats()
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        assert w.size() == 3 and w.is_ntt_form() and w.scale() == 2.0 ** 20
+        d.ev.relinearize_inplace(w, d.rlk)
+        assert w.size() == 2
+        w.set_scale(sc)
+        d.ev.rescale_to_next_inplace(w)
+        f1, m1, x1 = S.product_stats()
+        assert (f1 - f0, m1 - m0) == ((1, 0) if defers else (0, 0)), "the fused relinearisation did not run where it should: %r" % ((f1 - f0, m1 - m0),)
+        got = d.out(w)
+        for b in range(batch):
+            _eq(got[b], resc[b], "multiply + relinearize (fused) + rescale, item %d" % b)
+        kept_x, kept_y = d.out(cx), d.out(cy)
+        for b in range(batch):
+            _eq(kept_x[b], xs[b], "operand x after the fused path, item %d" % b)
+            _eq(kept_y[b], ys[b], "operand y after the fused path, item %d" % b)
+        # ... and relinearize alone (the tail completed by the read)
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        d.ev.relinearize_inplace(w, d.rlk)
+        check_relin(w, "multiply + relinearize (fused), read")
+
+        # 2. the product is read before anything else: it is formed then
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        check3(w, "a deferred product read at once")
+        d.ev.relinearize_inplace(w, d.rlk)
+        check_relin(w, "relinearize after the product was read")
+
+        # 3. an operand is written while the product is pending: the product is of the OLD words
+        cx, cy, w = fresh()
+        cz = d.ct(zs, scale=2.0 ** 10)
+        d.ev.multiply(cx, cy, w)
+        d.ev.add_inplace(cx, cz)
+        d.ev.negate_inplace(cy)
+        d.ev.relinearize_inplace(w, d.rlk)
+        check_relin(w, "relinearize after both operands were overwritten")
+        got = d.out(cx)
+        for b in range(batch):
+            _eq(got[b], (xs[b] + zs[b]) % qk, "the overwritten operand, item %d" % b)
+
+        # 4. an operand is destroyed / overwritten as a whole / re-shaped while the product is pending
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        del cy
+        gc.collect()
+        d.ev.relinearize_inplace(w, d.rlk)
+        check_relin(w, "relinearize after an operand was destroyed")
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        d.ev.multiply(cy, cy, cx)          # cx is now a destination (its own product pending), w's product must be of the old cx
+        d.ev.relinearize_inplace(w, d.rlk)
+        check_relin(w, "relinearize after an operand became a destination")
+        got = d.out(cx)
+        for b in range(batch):
+            _eq(got[b], o.multiply(ys[b], ys[b]), "the operand that became a product, item %d" % b)
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        cy.reserve(4)
+        cx.resize(d.parms_id_for_K(K), 3)
+        d.ev.relinearize_inplace(w, d.rlk)
+        check_relin(w, "relinearize after the operands were re-shaped")
+
+        # 5. the same operand twice; a pending product as an operand; a copy of a pending product
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cx, w)
+        d.ev.relinearize_inplace(w, d.rlk)
+        got = d.out(w)
+        for b in range(batch):
+            _eq(got[b], o.relinearize(o.multiply(xs[b], xs[b])), "x times x, fused, item %d" % b)
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        w2 = w.copy()
+        check3(w2, "copy of a pending product")
+        d.ev.relinearize_inplace(w, d.rlk)
+        check_relin(w, "the original after it was copied")
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        d.ev.add_inplace(w, w2)            # a pending product as the in-place operand of something else
+        got = d.out(w)
+        for b in range(batch):
+            _eq(got[b], (prod[b] + prod[b]) % qk, "add onto a pending product, item %d" % b)
+
+        # 6. the destination is overwritten before anyone needs it: the product is never formed
+        f2, m2, x2 = S.product_stats()
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        d.ev.multiply(cy, cy, w)
+        d.ev.relinearize_inplace(w, d.rlk)
+        got = d.out(w)
+        for b in range(batch):
+            _eq(got[b], o.relinearize(o.multiply(ys[b], ys[b])), "the second product into one destination, item %d" % b)
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        del w
+        gc.collect()
+        f3, m3, x3 = S.product_stats()
+        assert x3 - x2 == (2 if defers else 0) and m3 == m2, "discarded products: %r" % ((f3 - f2, m3 - m2, x3 - x2),)
+
+        # 7. an operand with a pending key-switch tail of its own: the tail completes first, then the product defers
+        ca, cb, w = fresh()
+        d.ev.multiply_inplace(ca, cb)
+        d.ev.relinearize_inplace(ca, d.rlk)      # ca: deferred tail
+        cz = d.ct(zs, scale=2.0 ** 20)
+        d.ev.multiply(ca, cz, w)
+        d.ev.relinearize_inplace(w, d.rlk)
+        got = d.out(w)
+        for b in range(batch):
+            _eq(got[b], o.relinearize(o.multiply(relin[b], zs[b])), "product of a relinearised operand, fused, item %d" % b)
+
+        # 8. another evaluator reads / writes while the first one's product is pending
+        ev2 = S.Evaluator(d.ctx)
+        cx, cy, w = fresh()
+        d.ev.multiply(cx, cy, w)
+        ev2.negate_inplace(cx)
+        ev2.relinearize_inplace(w, d.rlk)        # not the owner: the product is formed, the ordinary path runs
+        check_relin(w, "relinearize on another evaluator")
+        del ev2
+    # 9. and with the deferral switched off nothing is pending, same words
+    with _Env(SEALHIP_LAZY_PRODUCT=0, SEALHIP_KS_SPLIT=1, SEALHIP_LAZY_PRODUCT_MIN_WGS=0):
+        f4, m4, x4 = S.product_stats()
+        cx, cy, w = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10), S.Ciphertext(d.ctx, batch=batch)
+        d.ev.multiply(cx, cy, w)
+        d.ev.relinearize_inplace(w, d.rlk)
+        got = d.out(w)
+        for b in range(batch):
+            _eq(got[b], relin[b], "SEALHIP_LAZY_PRODUCT=0, item %d" % b)
+        assert S.product_stats() == (f4, m4, x4)

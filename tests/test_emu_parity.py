@@ -358,3 +358,9 @@ def test_extremes_ckks(emu):
 
 def test_extremes_bfv(emu):
     P.case_extremes_bfv(4096, coeff_modulus_create(4096, [36, 36, 37]), plain_modulus_batching(4096, 20))
+
+
+def test_lazy_product_life_cycle(emu):
+    """deferred tensor products (evaluator.h: LazyProduct): the fused relinearisation and every way the caller can observe the words of
+    the destination or the operands while a product is pending - both arithmetic classes in the chain"""
+    P.case_lazy_product(8192, [60, 40, 40, 60], batch=2)

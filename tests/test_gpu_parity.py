@@ -104,6 +104,14 @@ def test_extremes_bfv(gpu, n, bits):
     P.case_extremes_bfv(n, primes, plain_modulus_batching(n, 20))
 
 
+# deferred tensor products (evaluator.h: LazyProduct): the fused multiply -> relinearize and the life cycle of a pending product, at
+# every two-pass size, small batches through the test knobs and - the third case - the batch the launcher defers by its own rule
+@pytest.mark.parametrize("n,bits,batch", [(8192, [60, 40, 40, 60], 3), (16384, [60, 50, 55, 50, 60], 2), (32768, [50, 59, 50, 60], 2),
+                                          (65536, [60, 50, 50, 49, 60], 5)])
+def test_lazy_product_life_cycle(gpu, n, bits, batch):
+    P.case_lazy_product(n, bits, batch=batch)
+
+
 def test_dyadic(gpu):
     P.case_dyadic(4096, [60, 40, 30])
 
