@@ -120,6 +120,12 @@ def main():
         tail_note = ("deferred: relinearize leaves the mod-down by the special prime to the rescale that follows, which does both "
                      "rounding divisions with one transform per component (same words; %d folded / %d separate / %d discarded in "
                      "this process)" % (folded, plain, dropped)) if folded else "separate pass (%d tails completed on their own)" % plain
+    product_note = None
+    if args.workload == "headline":
+        fused, formed, dropped = S.product_stats()
+        product_note = ("deferred: multiply into the work object leaves the tensor product pending and the relinearize that follows forms it "
+                        "inside its own kernels (same words; %d fused / %d formed on their own / %d discarded in this process)"
+                        % (fused, formed, dropped)) if fused else "separate kernel"
     lanes_note = ""
     if w.lanes:
         lanes_note = ", %d evaluators x %d-item sub-batches on %d HIP streams" % (len(w.lanes), w.lanes[0]["cnt"], len(w.lanes))
@@ -181,7 +187,7 @@ def main():
             **(dict(latency_ms_per_ciphertext=round(result.get("ms_per_step", 0.0) / max(1, B), 4)) if args.workload == "rotate_c5" and B else {}),
             verified_items=verified, rccl_ranks=r.collective_ranks, collective_backend=r.backend, per_rank=per_rank,
             config=dict(workload=description + (" [EMULATED KERNELS, CPU test]" if EMU else ""),
-                        batch_per_gpu=B, key_switch_tail=tail_note, batch_sweep=batch_sweep,
+                        batch_per_gpu=B, key_switch_tail=tail_note, tensor_product=product_note, batch_sweep=batch_sweep,
                         cpus_per_rank=len(r.cpu_affinity) if r.cpu_affinity else None,
                         **(dict(shared_gpu="TEST MODE: the %d ranks share one device over gloo (SEALHIP_BENCH_SHARE_GPU) - not a measurement" % world)
                            if r.shared_gpu else {}), launch=("hipGraph replay" if args.graph else "eager") + lanes_note,

@@ -314,7 +314,7 @@ def describe(args, world, dp):
     """(metric, workload description, parallelism) of the JSON line"""
     names = {
         "headline": ("CKKS multiply+relinearize+rescale ciphertexts/sec @ N=2^16, L=16",
-                     "CKKS N=65536, coeff_modulus {60,14x50,60} (L=16, K=15): multiply_inplace + relinearize_inplace + "
+                     "CKKS N=65536, coeff_modulus {60,14x50,60} (L=16, K=15): multiply (x, y -> work, the operands stay resident) + relinearize_inplace + "
                      "rescale_to_next_inplace, device-resident batches"),
         "bfv_c4": ("BFV multiply+relinearize+mod_switch ciphertexts/sec @ N=32768, 14 primes",
                    "BASELINE configs[3]: BFV N=32768, 14x55-bit chain, t=Batching(32768,20): multiply + relinearize + "

@@ -33,13 +33,18 @@ def _same(dev_ct, ref_cts, what):
         assert dev_ct.coeff_modulus_size() == info["coeff_modulus_size"] and dev_ct.size() == info["size"], what
 
 
-def run_sequence(scheme, n, bits, tb, batch, nops, seed, check_prob=1.0, scale0=None, wild_prob=0.0):
-    """check_prob < 1: the device result is compared with the reference's only after some of the operations (always after the
+def run_sequence(scheme, n, bits, tb, batch, nops, seed, check_prob=1.0, scale0=None, wild_prob=0.0, three_object_prob=0.0):
+    """three_object_prob > 0 (CKKS): that share of the products is Evaluator::multiply(x, y, destination) instead of multiply_inplace -
+    the form whose tensor product the library may leave pending (sealhip.h: SealHip_ProductStats); the operands stay alive for a
+    while, or are dropped, or are written to, while the destination goes on through the sequence.
+    check_prob < 1: the device result is compared with the reference's only after some of the operations (always after the
     last), so that state the library defers between calls - the key-switch tail, sealhip.h: SealHip_TailStats - survives into
     the next operation instead of being completed by the comparison's read"""
     rng = np.random.default_rng(seed)
     check_rng = np.random.default_rng(seed + 77)
     wild_rng = np.random.default_rng(seed + 78)
+    form_rng = np.random.default_rng(seed + 79)
+    keep = []   # operands of three-object products that are kept alive (a pending product reads them)
     primes = coeff_modulus_create(n, bits)
     t = plain_modulus_batching(n, tb) if scheme != "ckks" else 0
     L, K = len(primes), len(primes) - 1
@@ -79,6 +84,12 @@ def run_sequence(scheme, n, bits, tb, batch, nops, seed, check_prob=1.0, scale0=
             op = "rescale"   # deferred-state runs: a key switch is often followed directly by a rescale
         elif check_prob < 1.0 and scheme == "bfv" and log and log[-1] in ("relinearize", "rotate", "conj") and "mod_switch" in ops and rng.random() < 0.7:
             op = "mod_switch"   # ... in BFV by a mod switch (the folded tail of round 4)
+        if three_object_prob > 0 and scheme == "ckks":
+            # sequences about pending products: a product is often followed directly by its relinearisation, and products are frequent
+            if log and "(x,y->w" in log[-1] and x.size() == 3 and form_rng.random() < 0.75:
+                op = "relinearize"
+            elif x.size() == 2 and form_rng.random() < 0.3:
+                op = "multiply"
         # keep CKKS scales inside the level's modulus: skip products that would overflow it
         if scheme == "ckks" and op in ("square", "multiply", "multiply32"):
             budget = sum(bits[:Kc]) - 2
@@ -130,7 +141,25 @@ def run_sequence(scheme, n, bits, tb, batch, nops, seed, check_prob=1.0, scale0=
             dev_call, ref_call = (lambda: d.ev.negate_inplace(x)), each("negate_inplace")
         elif op in ("multiply", "multiply32"):
             y, ry = second_operand(2)
-            dev_call = lambda: d.ev.multiply_inplace(x, y)
+            if scheme == "ckks" and x.size() == 2 and form_rng.random() < three_object_prob:
+                fate = int(form_rng.integers(0, 4))   # of the operands: 0 / 1 kept alive, 2 dropped at once, 3 written to while pending
+
+                def dev_call():
+                    nonlocal x
+                    w = S.Ciphertext(d.ctx, batch=batch)
+                    d.ev.multiply(x, y, w)
+                    if fate <= 1:
+                        keep.append((x, y))
+                        if len(keep) > 3:
+                            keep.pop(0)
+                    elif fate == 3:
+                        d.ev.negate_inplace(y)
+                        d.ev.add_inplace(x, y)
+                        keep.append((x, y))
+                    x = w
+                log[-1] += "(x,y->w:%d)" % fate
+            else:
+                dev_call = lambda: d.ev.multiply_inplace(x, y)
             ref_call = lambda: [o.ref.multiply_inplace(r, q) for r, q in zip(rx, ry)]
         elif op == "square":
             dev_call, ref_call = (lambda: d.ev.square_inplace(x)), each("square_inplace")

@@ -90,8 +90,9 @@ def test_random_sequences_with_deferred_state_emulated(emu, cfg, monkeypatch):
         pytest.skip("needs the real reference (oracle/_ref)")
     if cfg[-1] % 2:
         monkeypatch.setenv("SEALHIP_KS_SPLIT", "1")
+        monkeypatch.setenv("SEALHIP_LAZY_PRODUCT_MIN_WGS", "0")   # ... and leave three-object products pending (round 6) at these batches
     try:
-        F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30)
+        F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30, three_object_prob=0.6)
     except sealref.RefError as e:
         pytest.skip("reference rejected the parameters: %s" % e)
 
@@ -103,8 +104,9 @@ def test_random_sequences_with_deferred_state_gpu(gpu, cfg, monkeypatch):
         pytest.skip("needs the real reference (oracle/_ref)")
     if cfg[-1] % 2:
         monkeypatch.setenv("SEALHIP_KS_SPLIT", "1")
+        monkeypatch.setenv("SEALHIP_LAZY_PRODUCT_MIN_WGS", "0")   # ... and leave three-object products pending (round 6) at these batches
     try:
-        F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30)
+        F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30, three_object_prob=0.6)
     except sealref.RefError as e:
         pytest.skip("reference rejected the parameters: %s" % e)
 

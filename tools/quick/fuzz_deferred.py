@@ -11,6 +11,7 @@ seed = int(os.environ.get("FUZZ_SEED0", "300"))
 ok = rej = 0
 fails = []
 f0 = S.tail_stats()
+p0 = S.product_stats()
 while time.time() - t0 < budget:
     cfgs = T._ckks_configs(seed, 4, [8192, 16384, 32768, 65536]) + T._bfv_configs(seed, 2, [8192, 16384])
     for i, cfg in enumerate(cfgs):
@@ -18,10 +19,12 @@ while time.time() - t0 < budget:
             break
         if i % 2:
             os.environ["SEALHIP_KS_SPLIT"] = "1"
+            os.environ["SEALHIP_LAZY_PRODUCT_MIN_WGS"] = "0"   # three-object products stay pending at these small batches (round 6)
         else:
             os.environ.pop("SEALHIP_KS_SPLIT", None)
+            os.environ.pop("SEALHIP_LAZY_PRODUCT_MIN_WGS", None)
         try:
-            F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30 if cfg[0] == "ckks" else None); ok += 1
+            F.run_sequence(*cfg, check_prob=0.25, scale0=2.0 ** 30 if cfg[0] == "ckks" else None, three_object_prob=0.6); ok += 1
         except sealref.RefError:
             rej += 1
         except Exception as e:
@@ -29,6 +32,7 @@ while time.time() - t0 < budget:
     seed += 1
 f1 = S.tail_stats()
 print("sequences ok", ok, "rejected-by-reference", rej, "FAIL", len(fails), "seeds", int(os.environ.get("FUZZ_SEED0", "300")), "..", seed - 1,
-      "tails folded / plain / dropped:", [b - a for a, b in zip(f0, f1)], "seconds %.0f" % (time.time() - t0))
+      "tails folded / plain / dropped:", [b - a for a, b in zip(f0, f1)],
+      "products fused / formed / dropped:", [b - a for a, b in zip(p0, S.product_stats())], "seconds %.0f" % (time.time() - t0))
 for f in fails[:10]:
     print(f)
