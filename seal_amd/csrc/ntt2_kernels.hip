@@ -1583,26 +1583,49 @@ namespace sealhip
                     for (int k = 0; k < 16; k++)
                         v[k] = mid_ld<16>(P + (k >> 2) * 256 + (k & 3) * 64 + (tid & 63));
                 };
-                // canonical product of two canonical residues (exact either way: the double-precision form for primes below 2^50)
-                auto prod = [&](uint64_t u, uint64_t w) -> uint64_t {
-                    if constexpr (FP)
-                    {
-                        typename F::elem a0 = F::from_canon(u, m), b0 = F::from_canon(w, m);
-                        F::fix(a0, m);
-                        F::fix(b0, m);
-                        typename F::elem t = fp_mulmod(a0, b0, m.q, m.qinv);
-                        F::fix(t, m);
-                        return F::fwd_to_canon(t, m);
-                    }
-                    else
-                        return mul_mod(u, w, md);
-                };
-                uint64_t p0[16], p1[16], cv[16];
+                uint64_t p0[16], p1[16];
+                uint64_t *out1 = out + ((size_t)(a.K + 1) << G::n);
+                if constexpr (FP)
+                {
+                    // double-precision primes: the epilogue stays in the field the sums were formed in (as the tail's, round 3).  The
+                    // sum is fixed (|.| <= q/2) and multiplied by the balanced P^-1: <= 0.6 q; a product of two canonical residues is
+                    // <= 0.875 q (field.h: fp_mulmod, multiplier in [0, q)); c1 adds two of them: at most 2.35 q before the last fix()
+                    const double pmd = pm.w > q / 2 ? -(double)(q - pm.w) : (double)pm.w;
+                    double cd[16];
+                    load16(X0, p0);
+                    load16(Y0, p1);
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        cd[k] = fp_mulmod(fp_from_u52(p0[k]), fp_from_u52(p1[k]), m.q, m.qinv);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        val[e] = fp_to_bits(fp_mulmod(fp_fix(acc0[e], m.q, m.qinv), pmd, m.q, m.qinv));
+                    emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
+                        mid_st<16>(out + off, fp_to_canon(fp_fix(fp_from_bits(sv) + cd[k], m.q, m.qinv), m));
+                    });
+                    load16(Y1, p1);
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        cd[k] = fp_mulmod(fp_from_u52(p0[k]), fp_from_u52(p1[k]), m.q, m.qinv);
+                    load16(X1, p0);
+                    load16(Y0, p1);
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        cd[k] += fp_mulmod(fp_from_u52(p0[k]), fp_from_u52(p1[k]), m.q, m.qinv);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        val[e] = fp_to_bits(fp_mulmod(fp_fix(acc1[e], m.q, m.qinv), pmd, m.q, m.qinv));
+                    emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
+                        mid_st<16>(out1 + off, fp_to_canon(fp_fix(fp_from_bits(sv) + cd[k], m.q, m.qinv), m));
+                    });
+                    return;
+                }
+                uint64_t cv[16];
                 load16(X0, p0);
                 load16(Y0, p1);
 #pragma unroll
                 for (int k = 0; k < 16; k++)
-                    cv[k] = prod(p0[k], p1[k]);
+                    cv[k] = mul_mod(p0[k], p1[k], md);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     val[e] = sum_to_canon(acc0[e]);
@@ -1612,13 +1635,12 @@ namespace sealhip
                 load16(Y1, p1);
 #pragma unroll
                 for (int k = 0; k < 16; k++)
-                    cv[k] = prod(p0[k], p1[k]);
+                    cv[k] = mul_mod(p0[k], p1[k], md);
                 load16(X1, p0);
                 load16(Y0, p1);
 #pragma unroll
                 for (int k = 0; k < 16; k++)
-                    cv[k] = add_mod(cv[k], prod(p0[k], p1[k]), q);
-                uint64_t *out1 = out + ((size_t)(a.K + 1) << G::n);
+                    cv[k] = add_mod(cv[k], mul_mod(p0[k], p1[k], md), q);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     val[e] = sum_to_canon(acc1[e]);
@@ -1643,13 +1665,31 @@ namespace sealhip
                     cv0[k] = mid_ld<16>(C0 + off);
                     cv1[k] = mid_ld<16>(C1 + off);
                 }
+                uint64_t *out1 = out + ((size_t)(a.K + 1) << G::n);
+                if constexpr (FP)
+                {
+                    // (as above: S P^-1 in the field, <= 0.6 q, plus the canonical addend: <= 1.6 q before the last fix())
+                    const double pmd = pm.w > q / 2 ? -(double)(q - pm.w) : (double)pm.w;
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        val[e] = fp_to_bits(fp_mulmod(fp_fix(acc0[e], m.q, m.qinv), pmd, m.q, m.qinv));
+                    emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
+                        mid_st<16>(out + off, fp_to_canon(fp_fix(fp_from_bits(sv) + fp_from_u52(cv0[k]), m.q, m.qinv), m));
+                    });
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        val[e] = fp_to_bits(fp_mulmod(fp_fix(acc1[e], m.q, m.qinv), pmd, m.q, m.qinv));
+                    emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
+                        mid_st<16>(out1 + off, fp_to_canon(fp_fix(fp_from_bits(sv) + fp_from_u52(cv1[k]), m.q, m.qinv), m));
+                    });
+                    return;
+                }
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     val[e] = sum_to_canon(acc0[e]);
                 emit_rows_k(val, lds_wave, tid, [&](int k, unsigned off, uint64_t sv) {
                     mid_st<16>(out + off, add_mod(mul_shoup(sv, pm.w, pm.wq, q), cv0[k], q));
                 });
-                uint64_t *out1 = out + ((size_t)(a.K + 1) << G::n);
 #pragma unroll
                 for (int e = 0; e < 16; e++)
                     val[e] = sum_to_canon(acc1[e]);
