@@ -342,18 +342,32 @@ namespace sealhip
                     n2[e] = in2[(size_t)R * 256];
                 }
                 typename F::elem x[16];
-#pragma unroll
-                for (int e = 0; e < 16; e++)
+                if constexpr (FP)
                 {
-                    const typename F::elem v = map_src<FP>(n1[e], s1, m), u = map_src<FP>(n2[e], s2, m);
-                    if constexpr (FP)
+                    // Round 6: one fix() per coefficient instead of three.  v = (word + rounding fix) is below 2 q + 2^32 unfixed, its
+                    // product with the balanced P^-1 at most q (0.5 + 0.1875 * 2.1) < 0.9 q (field.h); u = (word + fix) is exact as a
+                    // double whatever the ratio of the moduli - below 2^52 + q when the source modulus is (the usual case: one
+                    // conversion instead of the split one), below q + 2^32 + q otherwise; the sum stays under 2^53 and is fixed once
+                    const double pinv = pm.w > q / 2 ? -(double)(q - pm.w) : (double)pm.w; // balanced, exact below 2^50
+                    const double f1 = fp_from_u52(s1.fix), f2 = fp_from_u52(s2.fix);
+                    const bool u_small = !(s2.src_q >> 52);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
                     {
-                        const double pinv = pm.w > q / 2 ? -(double)(q - pm.w) : (double)pm.w; // balanced, exact below 2^50
-                        x[e] = fp_mulmod(v, pinv, m.q, m.qinv) + u; // |v|, |u| <= q/2: |x| <= 1.1 q
+                        const uint64_t r1 = mode == 3 ? n1[e] : csub(n1[e] + s1.half, s1.src_q), r2 = mode == 3 ? n2[e] : csub(n2[e] + s2.half, s2.src_q);
+                        const double v = F::from_any(r1, m) + f1, u = (u_small ? fp_from_u52(r2) : F::from_any(r2, m)) + f2;
+                        x[e] = fp_mulmod(v, pinv, m.q, m.qinv) + u;
                         F::fix(x[e], m);
                     }
-                    else
+                }
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                    {
+                        const typename F::elem v = map_src<FP>(n1[e], s1, m), u = map_src<FP>(n2[e], s2, m);
                         x[e] = mul_shoup(v, pm.w, pm.wq, q) + u; // below q + 2q: inside the forward input range [0, 4q)
+                    }
                 }
                 uint64_t *mid_tr = a.mid + (((size_t)outer * a.ncomp + comp) << G::n);
                 // double precision, eight stages: x is fixed (|x| <= q/2), so one fix() after stage 6 does (p1_tile, LEAN); the
@@ -521,6 +535,8 @@ namespace sealhip
             const typename F::tw_t *tab = tw_table<FP>(a.t, true, prime);
             uint64_t *lds_wave = lds + (tid >> 6) * (4 * kRowWords);
             uint64_t raw[16];
+            typename F::elem x[16];
+            bool have_x = false; // the product branch of the double-precision back end leaves field elements, not words
             const size_t rows = ((size_t)comp << G::n) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
             if (a.prod_x)
             {
@@ -528,33 +544,67 @@ namespace sealhip
                 // and read back by this one: polynomial p of the result is x0 y0, x0 y1 + x1 y0 or x1 y1 of item b
                 const unsigned go = outer + a.prod_outer0, pp = go / a.prod_batch, b = go - pp * a.prod_batch;
                 const size_t plane = (size_t)a.prod_batch * a.src_outer_stride, off = (size_t)b * a.src_outer_stride + rows;
-                const ModDesc md = ld_uniform_mod(&a.t.mods[prime]);
+                [[maybe_unused]] const ModDesc md = ld_uniform_mod(&a.t.mods[prime]);
                 uint64_t rb[16];
                 load_rows(raw, lds_wave, a.prod_x + (pp == 2 ? plane : 0) + off, tid);
                 load_rows(rb, lds_wave, a.prod_y + (pp == 0 ? 0 : plane) + off, tid);
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    raw[e] = mul_mod(raw[e], rb[e], md);
-                if (pp == 1)
+                if constexpr (FP)
                 {
-                    uint64_t rc[16];
-                    load_rows(rc, lds_wave, a.prod_x + plane + off, tid);
-                    load_rows(rb, lds_wave, a.prod_y + off, tid);
+                    // round 6, double-precision primes: the products are formed in the field the transform works in (canonical words are exact
+                    // doubles; a product of two of them is at most 0.875 q, field.h) - 10 vector instructions a product instead of the
+                    // integer Barrett form's ~30, and no conversion back before the first butterflies
 #pragma unroll
                     for (int e = 0; e < 16; e++)
-                        raw[e] = add_mod(raw[e], mul_mod(rc[e], rb[e], md), md.q);
+                        x[e] = fp_mulmod(fp_from_u52(raw[e]), fp_from_u52(rb[e]), m.q, m.qinv);
+                    if (pp == 1)
+                    {
+                        uint64_t rc[16];
+                        load_rows(rc, lds_wave, a.prod_x + plane + off, tid);
+                        load_rows(rb, lds_wave, a.prod_y + off, tid);
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            x[e] += fp_mulmod(fp_from_u52(rc[e]), fp_from_u52(rb[e]), m.q, m.qinv);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        F::fix(x[e], m);
+                    if (a.prod_out)
+                    {
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            raw[e] = fp_to_canon(x[e], m);
+                        store_rows(raw, lds_wave, a.prod_out + (size_t)outer * a.prod_out_stride + rows, tid);
+                    }
+                    have_x = true;
                 }
-                if (a.prod_out)
-                    store_rows(raw, lds_wave, a.prod_out + (size_t)outer * a.prod_out_stride + rows, tid);
+                else
+                {
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        raw[e] = mul_mod(raw[e], rb[e], md);
+                    if (pp == 1)
+                    {
+                        uint64_t rc[16];
+                        load_rows(rc, lds_wave, a.prod_x + plane + off, tid);
+                        load_rows(rb, lds_wave, a.prod_y + off, tid);
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            raw[e] = add_mod(raw[e], mul_mod(rc[e], rb[e], md), md.q);
+                    }
+                    if (a.prod_out)
+                        store_rows(raw, lds_wave, a.prod_out + (size_t)outer * a.prod_out_stride + rows, tid);
+                }
             }
             else
                 load_rows(raw, lds_wave, a.src + (size_t)outer * a.src_outer_stride + rows, tid);
-            typename F::elem x[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++)
+            if (!have_x)
             {
-                x[e] = F::from_canon(raw[e], m);
-                F::fix(x[e], m);
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                {
+                    x[e] = F::from_canon(raw[e], m);
+                    F::fix(x[e], m);
+                }
             }
             {
                 TwRegs<FP> tw;
