@@ -36,6 +36,19 @@ for which in sys.argv[2:]:
         P.case_ntt(65536, [50, 60, 40], polys=3); P.case_ntt(32768, [50, 45], polys=3)
         P.case_product_growth("ckks", 4096, [54, 42, 55])
         del os.environ["SEALHIP_NTT_CHUNKS"]; del os.environ["SEALHIP_TENSOR_WIDE_MIN"]
+    elif which == "lazy":     # round 6: pending tensor products (host bookkeeping: operands destroyed / written / re-shaped while a product reads them)
+        P.case_lazy_product(8192, [60, 40, 40, 60], batch=2)
+        os.environ["SEALHIP_KS_SPLIT"] = "1"; os.environ["SEALHIP_LAZY_PRODUCT_MIN_WGS"] = "0"
+        n = 0
+        # (sequences in which nothing throws - see the note below: seed, index)
+        picks = [(21, 1), (21, 2), (22, 0), (22, 2), (22, 4), (22, 5), (23, 1), (23, 3), (23, 4)]
+        for cfg in [T._ckks_configs(sd, 6, [8192])[i] for sd, i in picks]:
+            try:
+                F.run_sequence(*cfg, check_prob=0.1, scale0=2.0 ** 30, three_object_prob=0.7); n += 1
+            except sealref.RefError:
+                pass
+        del os.environ["SEALHIP_KS_SPLIT"]; del os.environ["SEALHIP_LAZY_PRODUCT_MIN_WGS"]
+        print("sequences with three-object products", n, "products fused / formed / dropped", S.product_stats())
     elif which == "fuzz":
         n = 0
         for seed in (11, 12):
