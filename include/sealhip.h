@@ -589,15 +589,17 @@ SHL_FUNC SealHip_KsChunkStats(uint64_t *calls, uint64_t *chunks, uint64_t *scrat
  * safe per object, like every other Ciphertext operation.  SEALHIP_KS_EAGER_TAIL=1 in the environment turns deferral off.
  * Counters for tests: tails folded into a rescale / completed on their own / discarded because the object was overwritten. */
 SHL_FUNC SealHip_TailStats(uint64_t *folded, uint64_t *plain, uint64_t *dropped);
-/* Deferred tensor products (round 6).  Evaluator_Multiply of two size-2 CKKS ciphertexts into a THIRD object, at the two-pass sizes and
- * batches large enough for the un-split key switch, does not form the product at once: the destination has its shape and metadata
- * (size 3, scale, parms_id), its words are pending.  Evaluator_Relinearize on the same evaluator then never stores the product - the
- * third polynomial is formed inside the inverse transform that opens the key switch, the first two inside the key switch's last
- * epilogue (evaluator.cpp:604-663 folded into 2561-2867; one kernel and the product's round trip through HBM less).  Anything else
- * that touches the destination's words forms the product first, and anything that writes, re-shapes or destroys an OPERAND while a
- * product of it is pending forms that product first: the words are the reference's either way, at every point the caller can observe.
- * SEALHIP_LAZY_PRODUCT=0 in the environment turns the deferral off.  Counters for tests: products consumed by a fused relinearisation /
- * formed on their own / discarded because the destination was overwritten. */
+/* Deferred tensor products (round 6).  Evaluator_Multiply of two size-2 CKKS ciphertexts - into a THIRD object or in place (destination =
+ * encrypted1, Evaluator_Square included) -, at the two-pass sizes and batches large enough for the un-split key switch, does not form the
+ * product at once: the destination has its shape and metadata (size 3, scale, parms_id), its words are pending.  In the in-place forms
+ * the destination's previous slab - its two polynomials - stays with the pending record and the destination gets a fresh slab; nothing is
+ * copied.  Evaluator_Relinearize on the same evaluator then never stores the product - the third polynomial is formed inside the inverse
+ * transform that opens the key switch, the first two inside the key switch's last epilogue (evaluator.cpp:604-663 folded into
+ * 2561-2867; one kernel and the product's round trip through HBM less).  Anything else that touches the destination's words forms the
+ * product first, and anything that writes, re-shapes or destroys a live OPERAND while a product of it is pending forms that product
+ * first: the words are the reference's either way, at every point the caller can observe.  SEALHIP_LAZY_PRODUCT=0 in the environment
+ * turns the deferral off.  Counters for tests: products consumed by a fused relinearisation / formed on their own / discarded because
+ * the destination was overwritten. */
 SHL_FUNC SealHip_ProductStats(uint64_t *fused, uint64_t *formed, uint64_t *dropped);
 /* stream and device memory helpers for bindings without their own runtime (a PyTorch / HIP caller passes its own streams) */
 /* one process per GPU: select the calling thread's device before creating a SEALContext (a PyTorch caller uses

@@ -84,10 +84,22 @@ namespace sealhip
         formed = g_prod_formed.load();
         dropped = g_prod_dropped.load();
     }
-    void Evaluator::defer_product(Ciphertext &dest, const Ciphertext &x, const Ciphertext &y) const
+    // the launcher's rule: CKKS at a two-pass size, a batch whose key switch runs un-split (the fused relinearisation's configuration)
+    bool Evaluator::may_defer_product(const Level &lvl, size_t batch) const
     {
-        dest.lazy_prod_ = new LazyProduct{ this, &x, &y };
-        lazy_product_link(&dest, &x, &y, x.prod_readers_, x.prod_reader_count_, y.prod_readers_, y.prod_reader_count_);
+        const char *lazy_env = std::getenv("SEALHIP_LAZY_PRODUCT"); // (read per call: the tests switch it)
+        if (lazy_env && std::atoi(lazy_env) == 0)
+            return false;
+        // (SEALHIP_LAZY_PRODUCT_MIN_WGS: tests reach the fused path at small batches together with SEALHIP_KS_SPLIT=1)
+        const char *min_env = std::getenv("SEALHIP_LAZY_PRODUCT_MIN_WGS");
+        const size_t min_wgs = min_env ? (size_t)std::atol(min_env) : 1024;
+        return !capturing_ && !transparent_check_ && lvl.K >= 2 && ntt2_supports(context_.log_n()) &&
+               batch * (lvl.K + 1) * (context_.n() >> 12) > min_wgs;
+    }
+    void Evaluator::defer_product(Ciphertext &dest, const Ciphertext *x, const Ciphertext *y, uint64_t *own) const
+    {
+        dest.lazy_prod_ = new LazyProduct{ this, x, y, own };
+        lazy_product_link(&dest, *dest.lazy_prod_);
         std::lock_guard<std::mutex> lock(lazy_mu_);
         lazy_cts_.push_back(&dest);
     }
@@ -103,28 +115,43 @@ namespace sealhip
         const Level &lvl = *dest.level_;
         PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)dest.batch() };
         g_prod_formed++;
-        ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, p.x->data(), p.y->data(), dest.data_, g, stream_), "ckks_multiply (deferred)");
+        hipError_t err = hipSuccess;
+        try
+        {
+            err = k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, p.xw(), p.yw(), dest.data_, g, stream_);
+        }
+        catch (...)
+        {
+            DevicePool::global().free_words(p.own, stream_);
+            throw;
+        }
+        DevicePool::global().free_words(p.own, stream_); // (an in-place product's previous slab: read by the kernel just queued on this stream)
+        ck(err, "ckks_multiply (deferred)");
         // the product is formed on this evaluator's stream; a caller on another stream - the one about to read the words or to
         // overwrite an operand - continues only when it is done
         if (caller != stream_ && !capturing_)
             ck(hipStreamSynchronize(stream_), "deferred tensor product");
     }
-    // the fused relinearisation takes the record over: the destination is no longer pending, the operands are released
+    // the fused relinearisation takes the record over: the destination is no longer pending, the live operands are released (an owned
+    // slab is now the caller's to free)
     LazyProduct Evaluator::detach_product(Ciphertext &dest) const
     {
         const LazyProduct p = *dest.lazy_prod_;
         delete dest.lazy_prod_;
         dest.lazy_prod_ = nullptr;
-        lazy_product_unlink(&dest, p.x->prod_readers_, p.x->prod_reader_count_);
-        lazy_product_unlink(&dest, p.y->prod_readers_, p.y->prod_reader_count_);
+        lazy_product_unlink(&dest, p);
         std::lock_guard<std::mutex> lock(lazy_mu_);
         lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &dest), lazy_cts_.end());
         return p;
     }
-    void Evaluator::forget_product(const Ciphertext &dest) const
+    void Evaluator::forget_product(const Ciphertext &dest, LazyProduct p) const
     {
-        std::lock_guard<std::mutex> lock(lazy_mu_);
-        lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &dest), lazy_cts_.end());
+        StreamScope pool_scope(stream_);
+        {
+            std::lock_guard<std::mutex> lock(lazy_mu_);
+            lazy_cts_.erase(std::remove(lazy_cts_.begin(), lazy_cts_.end(), &dest), lazy_cts_.end());
+        }
+        DevicePool::global().free_words(p.own, stream_);
         g_prod_dropped++;
     }
     void lazy_product_count_fused()
@@ -964,19 +991,13 @@ namespace sealhip
             dest.reshape_uninitialized(&lvl, 3);
             // Round 6: batches whose key switch runs un-split at a two-pass size - the product is not formed now (LazyProduct): a
             // relinearize_inplace that follows forms it inside its own kernels, anything else that needs the words forms it first
-            const char *lazy_env = std::getenv("SEALHIP_LAZY_PRODUCT"); // (read per call: the tests switch it)
-            const bool lazy_product_ok = !(lazy_env && std::atoi(lazy_env) == 0);
-            // (SEALHIP_LAZY_PRODUCT_MIN_WGS: tests reach the fused path at small batches together with SEALHIP_KS_SPLIT=1)
-            const char *min_env = std::getenv("SEALHIP_LAZY_PRODUCT_MIN_WGS");
-            const size_t min_wgs = min_env ? (size_t)std::atol(min_env) : 1024;
-            const bool defer = lazy_product_ok && !capturing_ && lvl.K >= 2 && ntt2_supports(context_.log_n()) &&
-                               (size_t)e1.batch() * (lvl.K + 1) * (context_.n() >> 12) > min_wgs && !transparent_check_;
+            const bool defer = may_defer_product(lvl, e1.batch());
             // (development builds, bound only: SEALHIP_AB_SKIP_TENSOR leaves the product unwritten after two real calls - what fusing the
             // tensor product into its consumers could save at most, profiles/r06_lazy_product.txt)
             static const bool skip_tensor = shl_ab_getenv("SEALHIP_AB_SKIP_TENSOR") != nullptr;
             static std::atomic<unsigned> tensor_calls{ 0 };
             if (defer)
-                defer_product(dest, e1, e2);
+                defer_product(dest, &e1, &e2, nullptr);
             else if (!skip_tensor || tensor_calls.fetch_add(1) < 2)
                 ck(k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, xw, yw, dest.data(), g, stream_), "ckks_multiply");
             dest.is_ntt_form() = true;
@@ -1056,7 +1077,19 @@ namespace sealhip
         const bool self = (&e1 == &e2);
         double new_scale = e1.scale() * e2.scale();
         PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e1.batch() };
-        if (dest == 3)
+        if (dest == 3 && may_defer_product(lvl, e1.batch()))
+        {
+            // Round 6 (LazyProduct, in place): e1's slab - its two polynomials as they are now, whatever was pending on them completed -
+            // goes to the record, e1 gets a fresh slab of three whose words are pending.  Nothing is copied and nothing is computed here.
+            (void)e1.data();
+            if (!self)
+                (void)e2.data();
+            const size_t words = 3 * g.words();
+            uint64_t *fresh = DevicePool::global().alloc_words(words, stream_);
+            uint64_t *old = e1.exchange_slab(&lvl, 3, fresh, words);
+            defer_product(e1, nullptr, self ? nullptr : &e2, old);
+        }
+        else if (dest == 3)
             tensor_2x2(e1, self ? e1 : e2, lvl, g);
         else
         {

@@ -33,8 +33,9 @@ namespace sealhip
         // the tail, folded into a rescale or not, reads one operand where it read two
         bool with_addend = false;
     };
-    // A CKKS 2 x 2 tensor product that has not been formed yet (round 6; Evaluator::multiply into a third object, batches large enough
-    // for the un-split key switch, two-pass sizes): the destination has its shape and metadata, its words are pending.  A
+    // A CKKS 2 x 2 tensor product that has not been formed yet (round 6; Evaluator::multiply into a third object, multiply_inplace and
+    // square_inplace; batches large enough for the un-split key switch, two-pass sizes): the destination has its shape and metadata, its
+    // words are pending.  A
     // relinearize_inplace on the same evaluator then never stores the product: the third polynomial is formed inside the inverse
     // transform that opens the key switch (NttBatch::prod_x), the first two inside the key switch's last epilogue
     // (KsFusedArgs::fold_x) - one kernel and 45 MB per ciphertext less at the headline size.  Anything else that touches the
@@ -45,7 +46,13 @@ namespace sealhip
     struct LazyProduct
     {
         const Evaluator *owner;
+        // operands that are live objects; null = that operand's two polynomials are in `own`
         const Ciphertext *x, *y;
+        // in-place products (multiply_inplace, square_inplace): the destination's PREVIOUS slab - its two polynomials as they were -
+        // belongs to the record until the product is formed, consumed or discarded; the destination itself got a fresh slab of three
+        uint64_t *own;
+        const uint64_t *xw() const; // plane 0 of operand x (settles whatever is pending on a live operand)
+        const uint64_t *yw() const;
     };
     void lazy_product_stats(uint64_t &fused, uint64_t &formed, uint64_t &dropped);
     // process-wide counters (tests, tools): tails folded into a rescale / completed on their own / discarded unrun
@@ -142,13 +149,17 @@ namespace sealhip
                 settle_readers();
         }
         void settle_readers() const;
+        // the slab is replaced by `slab` (uninitialised, room for capacity_words) and handed to the caller instead of the pool
+        uint64_t *exchange_slab(const Level *level, size_t size, uint64_t *slab, size_t capacity_words);
         friend class Evaluator;
+        friend struct LazyProduct;
+        friend void lazy_product_link(const Ciphertext *, const LazyProduct &);
+        friend void lazy_product_unlink(const Ciphertext *, const LazyProduct &);
     };
 
-    // LazyProduct bookkeeping (objects.cpp): the reader lists are only touched under one global lock
-    void lazy_product_link(const Ciphertext *dest, const Ciphertext *x, const Ciphertext *y, std::vector<const Ciphertext *> &rx,
-                           unsigned &nx, std::vector<const Ciphertext *> &ry, unsigned &ny);
-    void lazy_product_unlink(const Ciphertext *dest, std::vector<const Ciphertext *> &r, unsigned &n);
+    // LazyProduct bookkeeping (objects.cpp): the reader lists of the live operands, only touched under one global lock
+    void lazy_product_link(const Ciphertext *dest, const LazyProduct &p);
+    void lazy_product_unlink(const Ciphertext *dest, const LazyProduct &p);
 
     // seal::Plaintext (plaintext.h) resident in HBM: either coeff_count <= N coefficients modulo t (BFV/BGV,
     // parms_id_zero) or, in NTT form, K*N words at a level (CKKS always; BFV/BGV after transform_to_ntt_inplace).
@@ -423,10 +434,11 @@ namespace sealhip
         void defer_tail(Ciphertext &e, uint64_t *acc, bool with_addend) const;
         void complete_tail(Ciphertext &e, LazyTail t) const;     // the plain mod-down, then the sums go back to the pool
         // deferred tensor products (LazyProduct): record / form now / take over for the fused relinearisation / discard
-        void defer_product(Ciphertext &dest, const Ciphertext &x, const Ciphertext &y) const;
+        bool may_defer_product(const Level &lvl, size_t batch) const;
+        void defer_product(Ciphertext &dest, const Ciphertext *x, const Ciphertext *y, uint64_t *own) const;
         void complete_product(Ciphertext &dest, LazyProduct p) const;
         LazyProduct detach_product(Ciphertext &dest) const;
-        void forget_product(const Ciphertext &dest) const;
+        void forget_product(const Ciphertext &dest, LazyProduct p) const;
         bool relinearize_from_product(Ciphertext &e, const KSwitchKeys &relin_keys) const; // false: conditions not met, nothing done
         void forget_tail(const Ciphertext &e, LazyTail t) const; // discard
         LazyTail detach_tail(Ciphertext &e) const;

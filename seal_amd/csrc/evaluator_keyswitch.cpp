@@ -194,10 +194,12 @@ namespace sealhip
         const LazyProduct p = detach_product(e); // from here on e is an ordinary size-3 ciphertext whose words are not there yet
         lazy_product_count_fused();
         uint64_t *target = e.data_ + 2 * e.plane_words(); // written by the inverse transform that forms x1 y1
-        Scratch acc(switch_key_acc_words(e));
+        StreamScope pool_scope(stream_);
         try
         {
+            Scratch acc(switch_key_acc_words(e));
             switch_key_partial(e, target, relin_keys, key_index, 0, K, acc.p, 1, true, &p);
+            defer_tail(e, acc.release(), true);
         }
         catch (...)
         {
@@ -206,14 +208,16 @@ namespace sealhip
             try
             {
                 PlaneGeom g{ (unsigned)context_.log_n(), K, (unsigned)e.batch() };
-                (void)k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, p.x->data(), p.y->data(), e.data_, g, stream_);
+                (void)k_ckks_multiply_2x2(context_.dev_mods(), context_.ntt_tables().fpd, nullptr, p.xw(), p.yw(), e.data_, g, stream_);
             }
             catch (...)
             {
             }
+            DevicePool::global().free_words(p.own, stream_);
             throw;
         }
-        defer_tail(e, acc.release(), true);
+        // an in-place product's previous slab: every kernel that reads it has been queued on (or joined to) this stream
+        DevicePool::global().free_words(p.own, stream_);
         e.resize(e.level(), 2, stream_);
         throw_if_transparent(e);
         return true;
@@ -327,9 +331,12 @@ namespace sealhip
             throw std::invalid_argument("kswitch_keys inner dimension is too small");
         if (e.size() < 2)
             throw std::invalid_argument("encrypted size must be at least 2");
-        if (product && !(fold_addend && ntt2_supports(context_.log_n()) && product->x->level() == e.level() && product->y->level() == e.level() &&
-                         product->x->batch() == e.batch() && product->y->batch() == e.batch()))
+        if (product && !(fold_addend && ntt2_supports(context_.log_n()) && (!product->x || (product->x->level() == e.level() && product->x->batch() == e.batch())) &&
+                         (!product->y || (product->y->level() == e.level() && product->y->batch() == e.batch())) &&
+                         (product->own || (product->x && product->y))))
             throw std::invalid_argument("product");
+        // (the operands' words: read once - a live operand's data() completes whatever is pending on it)
+        const uint64_t *prod_xw = product ? product->xw() : nullptr, *prod_yw = product ? product->yw() : nullptr;
 
         const size_t N = context_.n();
         const unsigned B = (unsigned)e.batch();
@@ -362,8 +369,8 @@ namespace sealhip
             if (product)
             {
                 // the target x1 y1 is formed while it is loaded and stored (NTT form) where `target` points: the diagonal terms read it
-                bt.prod_x = product->x->data();
-                bt.prod_y = product->y->data();
+                bt.prod_x = prod_xw;
+                bt.prod_y = prod_yw;
                 bt.prod_batch = B;
                 bt.prod_outer0 = 2 * B;
                 bt.prod_out = const_cast<uint64_t *>(target);
@@ -411,9 +418,9 @@ namespace sealhip
             ka.parts = split ? split : 1;
             if (fold_addend && product)
             {
-                ka.fold_x = product->x->data();
-                ka.fold_y = product->y->data();
-                ka.fold_plane = product->x->plane_words();
+                ka.fold_x = prod_xw;
+                ka.fold_y = prod_yw;
+                ka.fold_plane = e.plane_words();
                 ka.fold_pm = klvl.dev.inv_q_last_mod_q;
             }
             else if (fold_addend)
@@ -482,8 +489,8 @@ namespace sealhip
                         bt.src_outer_stride = poly_words;
                         if (product)
                         {
-                            bt.prod_x = product->x->data();
-                            bt.prod_y = product->y->data();
+                            bt.prod_x = prod_xw;
+                            bt.prod_y = prod_yw;
                             bt.prod_batch = B;
                             bt.prod_outer0 = 2 * B + b0;
                             bt.prod_out = const_cast<uint64_t *>(target) + b0 * poly_words;

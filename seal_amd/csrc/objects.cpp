@@ -25,24 +25,44 @@ namespace sealhip
     {
         std::mutex g_prod_mu; // the reader lists of all ciphertexts (short critical sections, never held across a launch)
     }
-    // LazyProduct bookkeeping: the destination owns the record, the operands list the destination as a reader
-    void lazy_product_link(const Ciphertext *dest, const Ciphertext *x, const Ciphertext *y, std::vector<const Ciphertext *> &rx,
-                           unsigned &nx, std::vector<const Ciphertext *> &ry, unsigned &ny)
+    // LazyProduct bookkeeping: the destination owns the record, the live operands list the destination as a reader
+    namespace
+    {
+        void unlink_one(const Ciphertext *dest, std::vector<const Ciphertext *> &r, unsigned &n)
+        {
+            std::lock_guard<std::mutex> lock(g_prod_mu);
+            r.erase(std::remove(r.begin(), r.end(), dest), r.end());
+            __atomic_store_n(&n, (unsigned)r.size(), __ATOMIC_RELEASE);
+        }
+    } // namespace
+    void lazy_product_link(const Ciphertext *dest, const LazyProduct &p)
     {
         std::lock_guard<std::mutex> lock(g_prod_mu);
-        rx.push_back(dest);
-        __atomic_store_n(&nx, (unsigned)rx.size(), __ATOMIC_RELEASE);
-        if (y != x)
+        if (p.x)
         {
-            ry.push_back(dest);
-            __atomic_store_n(&ny, (unsigned)ry.size(), __ATOMIC_RELEASE);
+            p.x->prod_readers_.push_back(dest);
+            __atomic_store_n(&p.x->prod_reader_count_, (unsigned)p.x->prod_readers_.size(), __ATOMIC_RELEASE);
+        }
+        if (p.y && p.y != p.x)
+        {
+            p.y->prod_readers_.push_back(dest);
+            __atomic_store_n(&p.y->prod_reader_count_, (unsigned)p.y->prod_readers_.size(), __ATOMIC_RELEASE);
         }
     }
-    void lazy_product_unlink(const Ciphertext *dest, std::vector<const Ciphertext *> &r, unsigned &n)
+    void lazy_product_unlink(const Ciphertext *dest, const LazyProduct &p)
     {
-        std::lock_guard<std::mutex> lock(g_prod_mu);
-        r.erase(std::remove(r.begin(), r.end(), dest), r.end());
-        __atomic_store_n(&n, (unsigned)r.size(), __ATOMIC_RELEASE);
+        if (p.x)
+            unlink_one(dest, p.x->prod_readers_, p.x->prod_reader_count_);
+        if (p.y && p.y != p.x)
+            unlink_one(dest, p.y->prod_readers_, p.y->prod_reader_count_);
+    }
+    const uint64_t *LazyProduct::xw() const
+    {
+        return x ? x->data() : own;
+    }
+    const uint64_t *LazyProduct::yw() const
+    {
+        return y ? y->data() : own;
     }
     void Ciphertext::settle_readers() const
     {
@@ -59,12 +79,12 @@ namespace sealhip
             if (r == this || tl_settling == r)
             {
                 // (a product never lists its own destination; a product being formed right now is past needing protection)
-                lazy_product_unlink(r, prod_readers_, prod_reader_count_);
+                unlink_one(r, prod_readers_, prod_reader_count_);
                 continue;
             }
             r->settle_product();
             // whoever formed it unlinked it; if another thread is still at it, settle_product() waited for that thread
-            lazy_product_unlink(r, prod_readers_, prod_reader_count_);
+            unlink_one(r, prod_readers_, prod_reader_count_);
         }
     }
     void Ciphertext::settle_product() const
@@ -88,14 +108,12 @@ namespace sealhip
         }
         catch (...)
         {
-            lazy_product_unlink(this, p.x->prod_readers_, p.x->prod_reader_count_);
-            lazy_product_unlink(this, p.y->prod_readers_, p.y->prod_reader_count_);
+            lazy_product_unlink(this, p);
             __atomic_store_n(&lazy_prod_, (LazyProduct *)nullptr, __ATOMIC_RELEASE);
             delete pending;
             throw;
         }
-        lazy_product_unlink(this, p.x->prod_readers_, p.x->prod_reader_count_);
-        lazy_product_unlink(this, p.y->prod_readers_, p.y->prod_reader_count_);
+        lazy_product_unlink(this, p);
         __atomic_store_n(&lazy_prod_, (LazyProduct *)nullptr, __ATOMIC_RELEASE);
         delete pending;
     }
@@ -106,9 +124,8 @@ namespace sealhip
         const LazyProduct p = *lazy_prod_;
         delete lazy_prod_;
         lazy_prod_ = nullptr;
-        lazy_product_unlink(this, p.x->prod_readers_, p.x->prod_reader_count_);
-        lazy_product_unlink(this, p.y->prod_readers_, p.y->prod_reader_count_);
-        p.owner->forget_product(*this);
+        lazy_product_unlink(this, p);
+        p.owner->forget_product(*this, p);
     }
     void Ciphertext::settle() const
     {
@@ -265,6 +282,18 @@ namespace sealhip
         }
         level_ = level;
         size_ = size;
+    }
+    uint64_t *Ciphertext::exchange_slab(const Level *level, size_t size, uint64_t *slab, size_t capacity_words)
+    {
+        before_write();
+        drop_product();
+        drop_lazy();
+        uint64_t *old = data_;
+        data_ = slab;
+        capacity_words_ = capacity_words;
+        level_ = level;
+        size_ = size;
+        return old;
     }
     void Ciphertext::adopt(const Level *level, size_t size, uint64_t *slab, size_t capacity_words)
     {

@@ -1615,6 +1615,80 @@ def case_lazy_product(n, bits, batch=3, seed=61):
         ev2.relinearize_inplace(w, d.rlk)        # not the owner: the product is formed, the ordinary path runs
         check_relin(w, "relinearize on another evaluator")
         del ev2
+        # 10. the in-place forms (multiply_inplace, square_inplace): the destination's previous slab is the operand, kept by the record
+        sq = [o.multiply(xs[b], xs[b]) for b in range(batch)]
+        f5, m5, x5 = S.product_stats()
+        cx, cy, _ = fresh()
+        d.ev.multiply_inplace(cx, cy)
+        assert cx.size() == 3 and cx.scale() == 2.0 ** 20
+        d.ev.relinearize_inplace(cx, d.rlk)
+        cx.set_scale(sc)
+        d.ev.rescale_to_next_inplace(cx)
+        got = d.out(cx)
+        for b in range(batch):
+            _eq(got[b], resc[b], "multiply_inplace + relinearize (fused) + rescale, item %d" % b)
+        got = d.out(cy)
+        for b in range(batch):
+            _eq(got[b], ys[b], "the second operand after the fused in-place path, item %d" % b)
+        cx, cy, _ = fresh()
+        d.ev.square_inplace(cx)
+        d.ev.relinearize_inplace(cx, d.rlk)
+        got = d.out(cx)
+        for b in range(batch):
+            _eq(got[b], o.relinearize(sq[b]), "square_inplace + relinearize (fused), item %d" % b)
+        f6, m6, x6 = S.product_stats()
+        assert (f6 - f5, m6 - m5) == ((2, 0) if defers else (0, 0)), "in-place products fused / formed: %r" % ((f6 - f5, m6 - m5),)
+        # read at once; the second operand written / destroyed while pending; the destination an operand of something else while pending
+        cx, cy, _ = fresh()
+        d.ev.multiply_inplace(cx, cy)
+        check3(cx, "an in-place product read at once")
+        cx, cy, _ = fresh()
+        d.ev.multiply_inplace(cx, cy)
+        d.ev.negate_inplace(cy)
+        d.ev.relinearize_inplace(cx, d.rlk)
+        check_relin(cx, "in-place product, second operand written while pending")
+        cx, cy, _ = fresh()
+        d.ev.multiply_inplace(cx, cy)
+        del cy
+        gc.collect()
+        d.ev.relinearize_inplace(cx, d.rlk)
+        check_relin(cx, "in-place product, second operand destroyed while pending")
+        cx, cy, w = fresh()
+        d.ev.multiply_inplace(cx, cy)
+        d.ev.add(cx, cx, w)                 # a pending in-place product read as an operand of another operation
+        got = d.out(w)
+        for b in range(batch):
+            _eq(got[b], (prod[b] + prod[b]) % qk, "sum of a pending in-place product with itself, item %d" % b)
+        # a pending in-place product as the OPERAND of a three-object product that is pending too, then both consumed
+        cx, cy, w = fresh()
+        cz = d.ct(zs, scale=2.0 ** 10)
+        d.ev.multiply_inplace(cx, cy)
+        c2 = cx.copy()                      # (forms it: the copy needs the words)
+        check3(c2, "copy of a pending in-place product")
+        d.ev.relinearize_inplace(cx, d.rlk)
+        check_relin(cx, "the in-place original after it was copied")
+        # discarded: overwritten as a whole / destroyed before anyone needs the words (the kept slab goes back to the pool)
+        f7, m7, x7 = S.product_stats()
+        cx, cy, _ = fresh()
+        d.ev.multiply_inplace(cx, cy)
+        d.ev.multiply(cy, cz, cx)
+        d.ev.relinearize_inplace(cx, d.rlk)
+        got = d.out(cx)
+        for b in range(batch):
+            _eq(got[b], o.relinearize(o.multiply(ys[b], zs[b])), "a three-object product over a pending in-place one, item %d" % b)
+        cx, cy, _ = fresh()
+        d.ev.square_inplace(cx)
+        del cx
+        gc.collect()
+        f8, m8, x8 = S.product_stats()
+        assert x8 - x7 == (2 if defers else 0) and m8 == m7, "discarded in-place products: %r" % ((f8 - f7, m8 - m7, x8 - x7),)
+        # another evaluator relinearises: the product is formed, the ordinary path runs
+        ev3 = S.Evaluator(d.ctx)
+        cx, cy, _ = fresh()
+        d.ev.multiply_inplace(cx, cy)
+        ev3.relinearize_inplace(cx, d.rlk)
+        check_relin(cx, "in-place product relinearised on another evaluator")
+        del ev3
     # 9. and with the deferral switched off nothing is pending, same words
     with _Env(SEALHIP_LAZY_PRODUCT=0, SEALHIP_KS_SPLIT=1, SEALHIP_LAZY_PRODUCT_MIN_WGS=0):
         f4, m4, x4 = S.product_stats()
