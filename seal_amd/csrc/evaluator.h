@@ -329,7 +329,9 @@ namespace sealhip
 
         // switch_key_inplace (evaluator.cpp:2561): encrypted (size >= 2) += KS(target), target = one
         // plane [batch][K][N] in the scheme's native form.
-        void switch_key_inplace(Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const;
+        // c1_zero_unwritten: the caller's ciphertext is (c0, 0) and its second polynomial has NOT been written (rotations); it is zeroed here
+        // only when somebody is going to read it
+        void switch_key_inplace(Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, bool c1_zero_unwritten = false) const;
         // the two halves of switch_key_inplace for digit-parallel key switching over several GPUs:
         // acc = [batch][2][K+1][N] words (switch_key_acc_words); partial fills it with the canonical partial sums of
         // the digits [j0, j1); finish reduces the sum of `parts` such buffers and applies the mod-down to encrypted.
@@ -341,7 +343,7 @@ namespace sealhip
         // polynomials are formed in the key switch's epilogue (KsFusedArgs::fold_x)
         void switch_key_partial(const Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index,
                                 unsigned j0, unsigned j1, uint64_t *acc, unsigned split = 1, bool fold_addend = false,
-                                const LazyProduct *product = nullptr) const;
+                                const LazyProduct *product = nullptr, bool addend1_zero = false) const;
         // fold_addend (CKKS, fused path, the full digit range, split 1): the data-prime components of acc leave as c + S P^-1
         // (KsFusedArgs::fold_c0); the matching finish call says so with acc_has_addend
         // may_defer (relinearize_finish / apply_galois_finish / the in-library exchange): CKKS at the two-pass sizes copies the reduced

@@ -290,7 +290,7 @@ namespace sealhip
 
     void Evaluator::switch_key_partial(
         const Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, unsigned j0, unsigned j1,
-        uint64_t *acc_out, unsigned split, bool fold_addend, const LazyProduct *product) const
+        uint64_t *acc_out, unsigned split, bool fold_addend, const LazyProduct *product, bool addend1_zero) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
@@ -426,7 +426,7 @@ namespace sealhip
             else if (fold_addend)
             {
                 ka.fold_c0 = e.plane(0);
-                ka.fold_c1 = e.plane(1);
+                ka.fold_c1 = addend1_zero ? nullptr : e.plane(1);
                 ka.fold_pm = klvl.dev.inv_q_last_mod_q;
             }
             if (!chunked)
@@ -512,7 +512,7 @@ namespace sealhip
                     else if (fold_addend)
                     {
                         kc.fold_c0 = ka.fold_c0 + b0 * poly_words;
-                        kc.fold_c1 = ka.fold_c1 + b0 * poly_words;
+                        kc.fold_c1 = ka.fold_c1 ? ka.fold_c1 + b0 * poly_words : nullptr;
                     }
                     ck(ks_fused(tb, kc, st), "ks fused (chunk)");
                 }
@@ -669,7 +669,7 @@ namespace sealhip
         }
     }
 
-    void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index) const
+    void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, bool c1_zero_unwritten) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         if (&e.context() != &context_ || !e.level())
@@ -710,11 +710,16 @@ namespace sealhip
         static const bool fold_ok = !shl_ab_getenv("SEALHIP_KS_NO_FOLD");
         const bool fold = fold_ok && defer && sch == Scheme::ckks && keys.context() == &context_ && key_index < keys.slots() &&
                           keys.has_key(key_index) && keys.key(key_index).register_order;
+        // c1_zero_unwritten (rotations: the ciphertext is (pi(c0), 0) and its second polynomial has not been written): with the addend
+        // folded into the sums nobody reads that polynomial before the tail writes it - the zeros are neither stored nor loaded
+        if (c1_zero_unwritten && !fold)
+            ck(hipMemsetAsync(e.plane(1), 0, e.plane_words() * 8, stream_), "zero c1");
+        const bool a1z = c1_zero_unwritten && fold;
         Scratch acc(switch_key_acc_words(e) * split);
-        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split, fold && split == 1);
+        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split, fold && split == 1, nullptr, a1z);
         if (split > 1) // several digit groups (small batches): the pass that adds them adds the ciphertext's words too
             ck(k_keyswitch_reduce(context_.dev_mods(), acc.p, (unsigned)context_.log_n(), K, context_.key_level().K, (unsigned)e.batch(),
-                                  stream_, split, fold ? e.plane(0) : nullptr, fold ? e.plane(1) : nullptr,
+                                  stream_, split, fold ? e.plane(0) : nullptr, fold && !a1z ? e.plane(1) : nullptr,
                                   context_.key_level().dev.inv_q_last_mod_q),
                "ks add digit groups");
         if (defer)

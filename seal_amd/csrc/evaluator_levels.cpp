@@ -313,7 +313,7 @@ namespace sealhip
         {
             ck(k_apply_galois(context_.dev_mods(), e.plane(0), out, galois_elt, ntt_form, g, 1, stream_), "apply_galois c0");
             ck(k_apply_galois(context_.dev_mods(), e.plane(1), perm.p, galois_elt, ntt_form, g, 1, stream_), "apply_galois c1");
-            ck(hipMemsetAsync(out + g.words(), 0, g.words() * 8, stream_), "galois zero c1");
+            // (c1 = 0 is left unwritten: switch_key_inplace zeroes it only on the paths that read it, round 6)
         }
         catch (...)
         {
@@ -329,7 +329,7 @@ namespace sealhip
         dest.adopt(&lvl, 2, out, words);
         try
         {
-            switch_key_inplace(dest, perm.p, galois_keys, galois_index(galois_elt));
+            switch_key_inplace(dest, perm.p, galois_keys, galois_index(galois_elt), true);
             throw_if_transparent(dest);
         }
         catch (...)

@@ -65,7 +65,7 @@ namespace sealhip
         unsigned parts;
         // Optional (parts <= 1, the full digit range only): the data-prime components leave as c_k[item][I] + S_k[item][I] P^-1 mod q_I
         // instead of the bare sums - the first step of the key-switch tail (evaluator.cpp:2845-2863), taken while S is in
-        // registers.  fold_c0 / fold_c1 = the ciphertext's two planes [batch][K][N], fold_pm[I] = P^-1 mod q_I (device).  The
+        // registers.  fold_c0 / fold_c1 = the ciphertext's two planes [batch][K][N] (fold_c1 null: the second addend is zero), fold_pm[I] = P^-1 mod q_I (device).  The
         // special-prime component is the plain sum either way.
         const uint64_t *fold_c0 = nullptr, *fold_c1 = nullptr;
         const ShoupOp *fold_pm = nullptr;

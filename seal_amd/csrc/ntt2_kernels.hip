@@ -1704,7 +1704,7 @@ namespace sealhip
                 // the key-switch tail's "c + S P^-1" happens here, where S is in registers: the tail then reads one operand, not two
                 // (evaluator.cpp:2845-2863 computes ct += (S - NTT(v)) P^-1 = (c + S P^-1) - NTT(v) P^-1; exact residue arithmetic)
                 const size_t crow = ((((size_t)b * a.K + I) << G::n)) + ((size_t)(hg * 16 + (tid >> 6) * 4) << 8);
-                const uint64_t *C0 = a.fold_c0 + crow, *C1 = a.fold_c1 + crow;
+                const uint64_t *C0 = a.fold_c0 + crow, *C1 = a.fold_c1 ? a.fold_c1 + crow : nullptr; // null: that addend is zero (rotations)
                 const ShoupOp pm = a.fold_pm[I];
                 const uint64_t q = a.tb.mods[prime].q;
                 uint64_t cv0[16], cv1[16];
@@ -1713,7 +1713,7 @@ namespace sealhip
                 {
                     const unsigned off = (k >> 2) * 256 + (k & 3) * 64 + (tid & 63);
                     cv0[k] = mid_ld<16>(C0 + off);
-                    cv1[k] = mid_ld<16>(C1 + off);
+                    cv1[k] = C1 ? mid_ld<16>(C1 + off) : 0;
                 }
                 uint64_t *out1 = out + ((size_t)(a.K + 1) << G::n);
                 if constexpr (FP)
@@ -2514,7 +2514,7 @@ namespace sealhip
         a1.j1 = k.j1;
         a1.parts = k.parts ? k.parts : 1;
         a1.tb = t;
-        if (k.fold_c0 && (a1.parts > 1 || !k.fold_c1 || !k.fold_pm || k.j0 != 0 || k.j1 != k.K))
+        if (k.fold_c0 && (a1.parts > 1 || !k.fold_pm || k.j0 != 0 || k.j1 != k.K))
             return hipErrorInvalidValue; // the addend may only join the COMPLETE sum of a component
         if (k.fold_x && (k.fold_c0 || !k.fold_y || !k.fold_plane || !k.fold_pm || a1.parts > 1 || k.j0 != 0 || k.j1 != k.K))
             return hipErrorInvalidValue;

@@ -504,7 +504,8 @@ namespace sealhip
                 if (c0 && I < K)
                 {
                     const size_t pk = poly / (K + 1), item = pk >> 1;
-                    const uint64_t c = ((pk & 1) ? c1 : c0)[((item * K + I) << n_log) + (i & (N - 1))];
+                    const uint64_t *cp = (pk & 1) ? c1 : c0; // c1 == null: the second polynomial's addend is zero (a rotation's pi(c0), 0)
+                    const uint64_t c = cp ? cp[((item * K + I) << n_log) + (i & (N - 1))] : 0;
                     const ShoupOp p = pm[I];
                     v = add_mod(mul_shoup(v, p.w, p.wq, md.q), c, md.q);
                 }
@@ -913,7 +914,7 @@ namespace sealhip
         size_t w = ((size_t)batch * 2 * (K + 1)) << n_log;
         if (!w)
             return hipSuccess;
-        if (c0 && (!c1 || !pm))
+        if (c0 && !pm)
             return hipErrorInvalidValue;
         hipLaunchKernelGGL(
             keyswitch_reduce_kernel, dim3(grid_for(w)), dim3(kBlock), 0, s, mods, acc, n_log, K, L, w, local_parts, c0, c1, pm, out ? out : acc);
