@@ -601,6 +601,12 @@ SHL_FUNC SealHip_TailStats(uint64_t *folded, uint64_t *plain, uint64_t *dropped)
  * turns the deferral off.  Counters for tests: products consumed by a fused relinearisation / formed on their own / discarded because
  * the destination was overwritten. */
 SHL_FUNC SealHip_ProductStats(uint64_t *fused, uint64_t *formed, uint64_t *dropped);
+/* Rotations (round 6).  Evaluator_ApplyGalois / RotateVector / ComplexConjugate of a CKKS ciphertext, at the two-pass sizes and batches
+ * large enough for the un-split key switch, run no permutation kernel: the key switch's own kernels read the operand's two polynomials
+ * through the automorphism's index map (util/galois.cpp:18-51 folded into evaluator.cpp:2561-2867), and the result's second polynomial -
+ * zero before the key switch - is neither written nor read.  Same words.  Counters for tests: rotations that took that path / that ran
+ * the permutation kernels. */
+SHL_FUNC SealHip_GaloisStats(uint64_t *gathered, uint64_t *permuted);
 /* stream and device memory helpers for bindings without their own runtime (a PyTorch / HIP caller passes its own streams) */
 /* one process per GPU: select the calling thread's device before creating a SEALContext (a PyTorch caller uses
  * torch.cuda.set_device instead) */

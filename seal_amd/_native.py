@@ -94,7 +94,7 @@ Comm_GetUniqueId Comm_RcclAvailable Comm_Create Comm_Destroy Comm_Info Comm_Digi
 Evaluator_RelinearizeDigitParallel Evaluator_ApplyGaloisDigitParallel Evaluator_RotateVectorDigitParallel
 Evaluator_BroadcastKeyDigits Evaluator_SwitchKeySlots Evaluator_SwitchKeyPackTargets Evaluator_SwitchKeyFinishOwned
 Evaluator_SwitchKeyAddGathered
-SealHip_ReleasePool SealHip_PoolStats SealHip_TailStats SealHip_ProductStats SealHip_KsChunkStats SealHip_SetStagedHostCopies SealHip_InstallAbortTrace shl_stream_create shl_stream_destroy shl_device_count shl_set_device
+SealHip_ReleasePool SealHip_PoolStats SealHip_TailStats SealHip_ProductStats SealHip_GaloisStats SealHip_KsChunkStats SealHip_SetStagedHostCopies SealHip_InstallAbortTrace shl_stream_create shl_stream_destroy shl_device_count shl_set_device
 shl_ntt_forward shl_ntt_inverse shl_dyadic_product shl_apply_galois shl_rns_stage shl_malloc shl_free
 shl_memcpy_h2d shl_memcpy_d2h shl_device_synchronize shl_timer_create shl_timer_destroy shl_timer_start
 shl_timer_stop

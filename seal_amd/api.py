@@ -1565,6 +1565,13 @@ def product_stats():
     return a.value, b.value, c.value
 
 
+def galois_stats():
+    """rotations (sealhip.h: SealHip_GaloisStats): (operand read through the index map inside the key switch, permutation kernels run)"""
+    a, b = C.c_uint64(), C.c_uint64()
+    N.check(N.lib().SealHip_GaloisStats(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def ks_chunk_stats():
     """chunked key switching (sealhip.h: SealHip_KsChunkStats): (calls that ran in chunks, chunks issued, largest intermediate in bytes)"""
     a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()

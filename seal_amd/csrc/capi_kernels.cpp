@@ -175,6 +175,17 @@ extern "C"
             *dropped = d;
         SHL_CATCH
     }
+    SHL_FUNC SealHip_GaloisStats(uint64_t *gathered, uint64_t *permuted)
+    {
+        SHL_TRY
+        uint64_t g, p;
+        galois_path_stats(g, p);
+        if (gathered)
+            *gathered = g;
+        if (permuted)
+            *permuted = p;
+        SHL_CATCH
+    }
     SHL_FUNC SealHip_TailStats(uint64_t *folded, uint64_t *plain, uint64_t *dropped)
     {
         SHL_TRY

@@ -55,6 +55,8 @@ namespace sealhip
         const uint64_t *yw() const;
     };
     void lazy_product_stats(uint64_t &fused, uint64_t &formed, uint64_t &dropped);
+    // rotations that read their operand through the automorphism's index map inside the key switch / that ran the permutation kernels
+    void galois_path_stats(uint64_t &gathered, uint64_t &permuted);
     // process-wide counters (tests, tools): tails folded into a rescale / completed on their own / discarded unrun
     void lazy_tail_stats(uint64_t &folded, uint64_t &plain, uint64_t &dropped);
     // chunked key switching (evaluator_keyswitch.cpp): calls that ran in chunks, chunks issued, largest intermediate held since the previous query (words)
@@ -331,7 +333,14 @@ namespace sealhip
         // plane [batch][K][N] in the scheme's native form.
         // c1_zero_unwritten: the caller's ciphertext is (c0, 0) and its second polynomial has NOT been written (rotations); it is zeroed here
         // only when somebody is going to read it
-        void switch_key_inplace(Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, bool c1_zero_unwritten = false) const;
+        // galois_elt / galois_c0 (round 6, rotations at the batches that fold the addend into un-split sums, ks_gathers()): `target` and
+        // galois_c0 are the UNPERMUTED c1 and c0 of the operand, read through the NTT-domain automorphism inside the key switch's
+        // kernels; encrypted's own polynomials are then never read
+        void switch_key_inplace(Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, bool c1_zero_unwritten = false,
+                                uint32_t galois_elt = 0, const uint64_t *galois_c0 = nullptr) const;
+        // the rules of switch_key_inplace, for callers that prepare their operands differently per path
+        unsigned ks_split(const Ciphertext &encrypted, const KSwitchKeys &keys, size_t key_index) const;
+        bool ks_folds(const KSwitchKeys &keys, size_t key_index, unsigned K) const;
         // the two halves of switch_key_inplace for digit-parallel key switching over several GPUs:
         // acc = [batch][2][K+1][N] words (switch_key_acc_words); partial fills it with the canonical partial sums of
         // the digits [j0, j1); finish reduces the sum of `parts` such buffers and applies the mod-down to encrypted.
@@ -343,7 +352,8 @@ namespace sealhip
         // polynomials are formed in the key switch's epilogue (KsFusedArgs::fold_x)
         void switch_key_partial(const Ciphertext &encrypted, const uint64_t *target, const KSwitchKeys &keys, size_t key_index,
                                 unsigned j0, unsigned j1, uint64_t *acc, unsigned split = 1, bool fold_addend = false,
-                                const LazyProduct *product = nullptr, bool addend1_zero = false) const;
+                                const LazyProduct *product = nullptr, bool addend1_zero = false, uint32_t galois_elt = 0,
+                                const uint64_t *galois_c0 = nullptr) const;
         // fold_addend (CKKS, fused path, the full digit range, split 1): the data-prime components of acc leave as c + S P^-1
         // (KsFusedArgs::fold_c0); the matching finish call says so with acc_has_addend
         // may_defer (relinearize_finish / apply_galois_finish / the in-library exchange): CKKS at the two-pass sizes copies the reduced

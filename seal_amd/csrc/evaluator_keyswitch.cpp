@@ -290,7 +290,8 @@ namespace sealhip
 
     void Evaluator::switch_key_partial(
         const Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, unsigned j0, unsigned j1,
-        uint64_t *acc_out, unsigned split, bool fold_addend, const LazyProduct *product, bool addend1_zero) const
+        uint64_t *acc_out, unsigned split, bool fold_addend, const LazyProduct *product, bool addend1_zero, uint32_t galois_elt,
+        const uint64_t *galois_c0) const
     {
         StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
         check_valid(e, "encrypted");
@@ -335,6 +336,8 @@ namespace sealhip
                          (!product->y || (product->y->level() == e.level() && product->y->batch() == e.batch())) &&
                          (product->own || (product->x && product->y))))
             throw std::invalid_argument("product");
+        if (galois_elt && !(fold_addend && addend1_zero && !product && galois_c0 && scheme == Scheme::ckks && ntt2_supports(context_.log_n())))
+            throw std::invalid_argument("galois_elt"); // the gather lives in the two-pass inverse transform and in ks2's folded epilogue
         // (the operands' words: read once - a live operand's data() completes whatever is pending on it)
         const uint64_t *prod_xw = product ? product->xw() : nullptr, *prod_yw = product ? product->yw() : nullptr;
 
@@ -366,6 +369,7 @@ namespace sealhip
             NttBatch bt = plain_batch(t.p, (size_t)K * N, K, B, 0);
             bt.src = target;
             bt.src_outer_stride = (size_t)K * N;
+            bt.src_galois_elt = galois_elt;
             if (product)
             {
                 // the target x1 y1 is formed while it is loaded and stored (NTT form) where `target` points: the diagonal terms read it
@@ -425,9 +429,10 @@ namespace sealhip
             }
             else if (fold_addend)
             {
-                ka.fold_c0 = e.plane(0);
+                ka.fold_c0 = galois_elt ? galois_c0 : e.plane(0);
                 ka.fold_c1 = addend1_zero ? nullptr : e.plane(1);
                 ka.fold_pm = klvl.dev.inv_q_last_mod_q;
+                ka.galois_elt = galois_elt;
             }
             if (!chunked)
                 ck(ks_fused(tb, ka, stream_), "ks fused");
@@ -487,6 +492,7 @@ namespace sealhip
                         NttBatch bt = plain_batch(t.p + b0 * poly_words, poly_words, K, nb, 0);
                         bt.src = target + b0 * poly_words;
                         bt.src_outer_stride = poly_words;
+                        bt.src_galois_elt = galois_elt;
                         if (product)
                         {
                             bt.prod_x = prod_xw;
@@ -669,15 +675,12 @@ namespace sealhip
         }
     }
 
-    void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, bool c1_zero_unwritten) const
+    // Small batches do not fill the chip: one workgroup per (target modulus, tile, batch item) is 16 (K+1) workgroups per
+    // ciphertext at N = 2^16, each looping over all K digits, and only 2 x 16 of them for the two 60-bit moduli.  Cut the
+    // digit loop into `split` in-launch groups (their partial sums are added by the reduce pass below): single-ciphertext
+    // latency of multiply+relinearize+rescale at C5 0.63 -> 0.40 ms (profiles/HISTORY.md section 5, "Small batches / latency").  SEALHIP_KS_SPLIT overrides (tests, A/B).
+    unsigned Evaluator::ks_split(const Ciphertext &e, const KSwitchKeys &keys, size_t key_index) const
     {
-        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
-        if (&e.context() != &context_ || !e.level())
-            throw std::invalid_argument("encrypted is not valid for encryption parameters");
-        // Small batches do not fill the chip: one workgroup per (target modulus, tile, batch item) is 16 (K+1) workgroups per
-        // ciphertext at N = 2^16, each looping over all K digits, and only 2 x 16 of them for the two 60-bit moduli.  Cut the
-        // digit loop into `split` in-launch groups (their partial sums are added by the reduce pass below): single-ciphertext
-        // latency of multiply+relinearize+rescale at C5 0.63 -> 0.40 ms (profiles/HISTORY.md section 5, "Small batches / latency").  SEALHIP_KS_SPLIT overrides (tests, A/B).
         const unsigned K = e.level()->K;
         unsigned split = 1;
         if (keys.context() == &context_ && key_index < keys.slots() && keys.has_key(key_index) && keys.key(key_index).register_order)
@@ -697,6 +700,27 @@ namespace sealhip
             if (split < 1)
                 split = 1;
         }
+        return split;
+    }
+    // CKKS on the fused path: the sums leave the key switch with the ciphertext's words already added (c + S P^-1), so that the
+    // tail reads one operand per component instead of two - from ks2's epilogue when the digits run as one group, from the pass
+    // that adds the groups otherwise.  SEALHIP_KS_NO_FOLD=1 (development builds): the round-3 form
+    bool Evaluator::ks_folds(const KSwitchKeys &keys, size_t key_index, unsigned K) const
+    {
+        static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
+        static const bool fold_ok = !shl_ab_getenv("SEALHIP_KS_NO_FOLD");
+        return fold_ok && lazy_ok && context_.scheme() == Scheme::ckks && ntt2_supports(context_.log_n()) && K >= 2 && keys.context() == &context_ &&
+               key_index < keys.slots() && keys.has_key(key_index) && keys.key(key_index).register_order;
+    }
+
+    void Evaluator::switch_key_inplace(Ciphertext &e, const uint64_t *target, const KSwitchKeys &keys, size_t key_index, bool c1_zero_unwritten,
+                                       uint32_t galois_elt, const uint64_t *galois_c0) const
+    {
+        StreamScope pool_scope(stream_); // pool traffic of this call is ordered on the evaluator's stream whoever calls (pool.h)
+        if (&e.context() != &context_ || !e.level())
+            throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        const unsigned K = e.level()->K;
+        const unsigned split = ks_split(e, keys, key_index);
         // CKKS at the two-pass sizes: leave the mod-down to whoever touches the ciphertext next (LazyTail) - a rescale on this
         // evaluator then does both rounding divisions with one transform per component.  SEALHIP_KS_EAGER_TAIL=1: always now.
         // BFV at the same sizes (round 4): a mod_switch_to_next on this evaluator folds the mod-down into its own division (one
@@ -704,19 +728,16 @@ namespace sealhip
         static const bool lazy_ok = !std::getenv("SEALHIP_KS_EAGER_TAIL");
         const Scheme sch = context_.scheme();
         const bool defer = lazy_ok && (sch == Scheme::ckks || sch == Scheme::bfv) && ntt2_supports(context_.log_n()) && K >= 2;
-        // CKKS on the fused path: the sums leave the key switch with the ciphertext's words already added (c + S P^-1), so that the
-        // tail reads one operand per component instead of two - from ks2's epilogue when the digits run as one group, from the pass
-        // that adds the groups otherwise.  SEALHIP_KS_NO_FOLD=1 (development builds): the round-3 form
-        static const bool fold_ok = !shl_ab_getenv("SEALHIP_KS_NO_FOLD");
-        const bool fold = fold_ok && defer && sch == Scheme::ckks && keys.context() == &context_ && key_index < keys.slots() &&
-                          keys.has_key(key_index) && keys.key(key_index).register_order;
+        const bool fold = ks_folds(keys, key_index, K);
+        if (galois_elt && !(fold && split == 1 && c1_zero_unwritten))
+            throw std::logic_error("the automorphism is read inside the key switch only on its un-split folded path");
         // c1_zero_unwritten (rotations: the ciphertext is (pi(c0), 0) and its second polynomial has not been written): with the addend
         // folded into the sums nobody reads that polynomial before the tail writes it - the zeros are neither stored nor loaded
         if (c1_zero_unwritten && !fold)
             ck(hipMemsetAsync(e.plane(1), 0, e.plane_words() * 8, stream_), "zero c1");
         const bool a1z = c1_zero_unwritten && fold;
         Scratch acc(switch_key_acc_words(e) * split);
-        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split, fold && split == 1, nullptr, a1z);
+        switch_key_partial(e, target, keys, key_index, 0, K, acc.p, split, fold && split == 1, nullptr, a1z, galois_elt, galois_c0);
         if (split > 1) // several digit groups (small batches): the pass that adds them adds the ciphertext's words too
             ck(k_keyswitch_reduce(context_.dev_mods(), acc.p, (unsigned)context_.log_n(), K, context_.key_level().K, (unsigned)e.batch(),
                                   stream_, split, fold ? e.plane(0) : nullptr, fold && !a1z ? e.plane(1) : nullptr,

@@ -1,5 +1,6 @@
 // Evaluator, part 3: modulus switching / rescaling and the Galois automorphisms
 #include "evaluator_common.h"
+#include <atomic>
 
 namespace sealhip
 {
@@ -265,6 +266,15 @@ namespace sealhip
     }
 
     // ---- Galois automorphisms and rotations (evaluator.cpp:2384-2559, evaluator.h:1072-1375)
+    namespace
+    {
+        std::atomic<uint64_t> g_galois_gathered{ 0 }, g_galois_permuted{ 0 };
+    }
+    void galois_path_stats(uint64_t &gathered, uint64_t &permuted)
+    {
+        gathered = g_galois_gathered.load();
+        permuted = g_galois_permuted.load();
+    }
     void Evaluator::apply_galois_inplace(Ciphertext &e, uint32_t galois_elt, const KSwitchKeys &galois_keys) const
     {
         apply_galois(e, galois_elt, galois_keys, e);
@@ -305,7 +315,49 @@ namespace sealhip
 
         PlaneGeom g{ (unsigned)context_.log_n(), lvl.K, (unsigned)e.batch() };
         const int ntt_form = scheme == Scheme::bfv ? 0 : 1;
+        const size_t key_index = galois_index(galois_elt);
+        static const bool gather_ok = !shl_ab_getenv("SEALHIP_GALOIS_KERNELS"); // development builds: the permutation kernels always (A/B)
+        if (gather_ok && scheme == Scheme::ckks && ks_folds(galois_keys, key_index, lvl.K) && ks_split(e, galois_keys, key_index) == 1)
+        {
+            // Round 6: batches whose key switch runs un-split with the addend folded into its sums - neither pi(c0) nor pi(c1) is ever
+            // stored: the key switch's own kernels read c0 and c1 through the automorphism's index map (the opening inverse transform
+            // and the diagonal terms: c1; ks2's epilogue: c0), and the result's polynomials are written by the tail alone.
+            g_galois_gathered++;
+            const size_t words = 2 * g.words();
+            const uint64_t *c0 = e.plane(0), *c1 = e.plane(1); // (completes whatever is pending on the operand)
+            uint64_t *out = DevicePool::global().alloc_words(words, stream_);
+            uint64_t *old = nullptr; // in place: the operand's slab has to outlive the kernels that read it
+            if (&dest == &e)
+                old = dest.exchange_slab(&lvl, 2, out, words);
+            else
+            {
+                dest.is_ntt_form() = e.is_ntt_form();
+                dest.scale() = e.scale();
+                dest.correction_factor() = e.correction_factor();
+                dest.adopt(&lvl, 2, out, words);
+            }
+            try
+            {
+                switch_key_inplace(dest, c1, galois_keys, key_index, true, galois_elt, c0);
+                throw_if_transparent(dest);
+            }
+            catch (...)
+            {
+                if (&dest != &e)
+                    dest.release(); // (as below: no half-built destination with valid-looking metadata)
+                else
+                {
+                    // in place: the operand's words are still in `old` - give them back to the object, as the failure left nothing else
+                    dest.drop_lazy();
+                    DevicePool::global().free_words(dest.exchange_slab(&lvl, 2, old, words), stream_);
+                }
+                throw;
+            }
+            DevicePool::global().free_words(old, stream_);
+            return;
+        }
         // pi(c0) goes straight into the result slab, pi(c1) into scratch as the key-switch target, c1 starts at zero
+        g_galois_permuted++;
         Scratch perm(g.words());
         const size_t words = 2 * g.words();
         uint64_t *out = DevicePool::global().alloc_words(words);
@@ -329,7 +381,7 @@ namespace sealhip
         dest.adopt(&lvl, 2, out, words);
         try
         {
-            switch_key_inplace(dest, perm.p, galois_keys, galois_index(galois_elt), true);
+            switch_key_inplace(dest, perm.p, galois_keys, key_index, true);
             throw_if_transparent(dest);
         }
         catch (...)

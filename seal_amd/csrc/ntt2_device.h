@@ -853,6 +853,36 @@ namespace sealhip
             __builtin_amdgcn_wave_barrier();
         }
 
+        // NTT-domain automorphism as an index map (galois.cpp:18-51; poly_kernels.hip: galois_ntt_kernel): result[j] = operand[T(j)],
+        // T(j) = bitrev_n(((elt * bitrev_{n+1}(j + N)) >> 1) & (N - 1)).  The low bits of j are the high bits of the reversed word, a
+        // product with an odd element only carries upwards, so an aligned block of 2^m positions maps onto an aligned block of 2^m
+        // positions: a gather through T touches the lines a plain read of the same block would.
+        __device__ __forceinline__ unsigned galois_src_index(unsigned j, uint32_t elt, unsigned n_log)
+        {
+            const unsigned N = 1u << n_log;
+            const unsigned rev = __brev(j + N) >> (32 - (n_log + 1));
+            const unsigned idx = (unsigned)(((uint64_t)elt * rev) >> 1) & (N - 1);
+            return __brev(idx) >> (32 - n_log);
+        }
+        // load_rows through the automorphism: `poly` = the polynomial's first word, j0 = natural index of this wave's first row
+        __device__ __forceinline__ void load_rows_galois(uint64_t (&val)[16], uint64_t *lds_wave, const uint64_t *poly, unsigned j0, uint32_t elt,
+                                                         unsigned n_log, unsigned tid)
+        {
+            const unsigned v = tid & 15, ul = (tid >> 4) & 3, lane = tid & 63;
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+            {
+                const unsigned row = k >> 2, col = (k & 3) * 64 + lane;
+                lds_wave[row * kRowWords + col + 2 * (col >> 4)] = mid_ld<16>(poly + galois_src_index(j0 + row * 256 + col, elt, n_log));
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                val[e] = lds_wave[ul * kRowWords + v * 18 + e];
+            __builtin_amdgcn_wave_barrier();
+        }
+
         // ---------------------------------------------------------------------------------------
         // generic forward transform kernels
         // ---------------------------------------------------------------------------------------

@@ -74,6 +74,9 @@ namespace sealhip
         // (fold_x / fold_y = plane 0 of x / y, [batch][K][N]; plane 1 is fold_plane words further).  Same restrictions as fold_c0.
         const uint64_t *fold_x = nullptr, *fold_y = nullptr;
         size_t fold_plane = 0;
+        // Round 6, rotations without the permutation kernels: target_ntt and fold_c0 are the UNPERMUTED polynomials c1 and c0, read
+        // through the NTT-domain automorphism of this Galois element (ntt2_device.h: galois_src_index); fold_c1 must be null (zero)
+        uint32_t galois_elt = 0;
         // Callers that cut a batch into chunks (Evaluator::switch_key_partial, round 5) decide these for the WHOLE batch:
         // order1 = which pass-1 kernel runs (-1: decided from this call's grid, 0: target-resident ks1_kernel, 1: digit-resident
         // ks1t_kernel); no_class_fork = the two arithmetic classes run one after the other on `stream` (the caller's chunk

@@ -511,6 +511,7 @@ namespace sealhip
             unsigned prod_batch, prod_outer0; // items per polynomial; outer index of this launch's first item
             uint64_t *prod_out;               // NttBatch::prod_out (null: the product is not stored)
             size_t prod_out_stride;
+            uint32_t src_gal; // NttBatch::src_galois_elt (0: plain source)
             NttTables t;
         };
 
@@ -595,6 +596,8 @@ namespace sealhip
                         store_rows(raw, lds_wave, a.prod_out + (size_t)outer * a.prod_out_stride + rows, tid);
                 }
             }
+            else if (a.src_gal)
+                load_rows_galois(raw, lds_wave, a.src + (size_t)outer * a.src_outer_stride + ((size_t)comp << G::n), (hg * 16 + (tid >> 6) * 4) << 8, a.src_gal, G::n, tid);
             else
                 load_rows(raw, lds_wave, a.src + (size_t)outer * a.src_outer_stride + rows, tid);
             if (!have_x)
@@ -1355,6 +1358,8 @@ namespace sealhip
             // KsFusedArgs::fold_x: the addend is the product of two size-2 operands, formed here (c0 = x0 y0, c1 = x0 y1 + x1 y0)
             const uint64_t *fold_x, *fold_y;
             size_t fold_plane;
+            // KsFusedArgs::galois_elt: `target` (the diagonal terms) and fold_c0 are read through the NTT-domain automorphism
+            uint32_t gal;
             NttTables tb;
         };
 
@@ -1450,9 +1455,20 @@ namespace sealhip
             auto fetch = [&](unsigned J) {
                 if (has_diag && J == I)
                 {
+                    if (a.gal)
+                    {
+                        // a rotation's target is pi(c1), never stored: the thread's sixteen words come through the index map
+                        const uint64_t *poly = a.target + (((size_t)b * a.K + I) << G::n);
 #pragma unroll
-                    for (int e = 0; e < 16; e += 2)
-                        view_load128(diag_view, tid * 128, e * 8, nxt[e], nxt[e + 1]);
+                        for (int e = 0; e < 16; e++)
+                            nxt[e] = poly[galois_src_index((hg << 12) + tid * 16 + e, a.gal, G::n)];
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 2)
+                            view_load128(diag_view, tid * 128, e * 8, nxt[e], nxt[e + 1]);
+                    }
                 }
                 else if constexpr (FP)
                 {
@@ -1712,7 +1728,10 @@ namespace sealhip
                 for (int k = 0; k < 16; k++)
                 {
                     const unsigned off = (k >> 2) * 256 + (k & 3) * 64 + (tid & 63);
-                    cv0[k] = mid_ld<16>(C0 + off);
+                    if (a.gal) // the first addend is pi(c0) of a rotation, read through the index map
+                        cv0[k] = mid_ld<16>(a.fold_c0 + (((size_t)b * a.K + I) << G::n) + galois_src_index(((hg * 16 + (tid >> 6) * 4) << 8) + off, a.gal, G::n));
+                    else
+                        cv0[k] = mid_ld<16>(C0 + off);
                     cv1[k] = C1 ? mid_ld<16>(C1 + off) : 0;
                 }
                 uint64_t *out1 = out + ((size_t)(a.K + 1) << G::n);
@@ -2157,7 +2176,7 @@ namespace sealhip
             if constexpr (D1 == 5 || D1 == 6)
             {
                 static const bool fused_ok = !shl_ab_getenv("SEALHIP_NTT_NOFUSED");
-                if (fused_ok && !a.prod_x) // (the product source is a feature of the two-pass kernels)
+                if (fused_ok && !a.prod_x && !a.src_gal) // (the product and automorphism sources are features of the two-pass kernels)
                 {
                     static bool raised = false;
                     if (!raised)
@@ -2456,6 +2475,9 @@ namespace sealhip
         a.prod_outer0 = b.prod_outer0;
         a.prod_out = b.prod_out;
         a.prod_out_stride = b.prod_out_stride;
+        a.src_gal = b.src_galois_elt;
+        if (b.src_galois_elt && (!b.src || b.prod_x || !(b.src_galois_elt & 1)))
+            return hipErrorInvalidValue;
         if (b.prod_x && (!b.prod_y || !b.prod_batch || (size_t)b.nouter + b.prod_outer0 > (size_t)3 * b.prod_batch || !b.src_outer_stride))
             return hipErrorInvalidValue;
         if (b.prod_x && !b.prod_outer0 && b.nouter != 3 * b.prod_batch) // the whole product, as before round 6
@@ -2539,6 +2561,9 @@ namespace sealhip
         a2.fold_x = k.fold_x;
         a2.fold_y = k.fold_y;
         a2.fold_plane = k.fold_plane;
+        a2.gal = k.galois_elt;
+        if (k.galois_elt && (!(k.galois_elt & 1) || !k.target_ntt || !k.fold_c0 || k.fold_c1 || k.fold_x))
+            return hipErrorInvalidValue; // a rotation: target and first addend through the index map, the second addend zero
         a2.tb = t;
         switch (t.log_n)
         {

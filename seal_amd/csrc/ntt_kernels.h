@@ -117,6 +117,10 @@ namespace sealhip
         unsigned prod_outer0 = 0;
         uint64_t *prod_out = nullptr;
         size_t prod_out_stride = 0;
+        // round 6 (rotations without the permutation kernels; inverse transform of the two-pass engine, plain `src` only): the input is
+        // the NTT-domain automorphism of `src` with this Galois element - word j of a polynomial is read from position T(j) of the
+        // same polynomial (galois.cpp:18-51; T keeps aligned blocks together, so the gather stays inside the lines a plain read touches)
+        uint32_t src_galois_elt = 0;
         // Two-pass engine: what the HOST knows about the arithmetic class of the components when they are named through comp_prime
         // (the launcher reads the class of prime_first + comp itself, a device table it cannot): -1 unknown - the launch carries both
         // back ends and guards every integer butterfly -, 0 every prime on the integer back end (single-class kernels, the

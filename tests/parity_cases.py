@@ -1699,3 +1699,70 @@ def case_lazy_product(n, bits, batch=3, seed=61):
         for b in range(batch):
             _eq(got[b], relin[b], "SEALHIP_LAZY_PRODUCT=0, item %d" % b)
         assert S.product_stats() == (f4, m4, x4)
+
+
+def case_rotate_gather(n, bits, batch=3, steps=(1, -1), seed=71):
+    """Round 6: rotations at the batches whose key switch runs un-split with the addend folded in read c0 and c1 through the
+    automorphism's index map inside the key switch's kernels (evaluator_levels.cpp: apply_galois; no permutation kernels, the operand's
+    slab kept alive in the in-place form).  Out of place, in place, conjugation, each followed by a rescale (folded tail) or read at once
+    (plain tail), against the reference; the switch SEALHIP_KS_SPLIT=1 brings small test batches onto that path."""
+    primes = coeff_modulus_create(n, bits)
+    K = len(primes) - 1
+    probe = Oracle("ckks", n, primes)
+    elts = sorted({probe.galois_elt_from_step(s) for s in steps} | {2 * n - 1})
+    o = Oracle("ckks", n, primes, galois_elts=elts)
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(seed)
+    xs = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+    sc = float(primes[K - 1]) * 2.0 ** 10
+    g0 = S.galois_stats()
+    with _Env(SEALHIP_KS_SPLIT=1):
+        for s in steps:
+            e = o.galois_elt_from_step(s)
+            want = [o.apply_galois(xs[b], e) for b in range(batch)]
+            # out of place, read at once: the operand keeps its words
+            cx = d.ct(xs, scale=sc)
+            dst = S.Ciphertext(d.ctx, batch=batch)
+            d.ev.rotate_vector(cx, s, d.glk, dst)
+            got, kept = d.out(dst), d.out(cx)
+            for b in range(batch):
+                _eq(got[b], want[b], "rotate_vector(%d) out of place, item %d" % (s, b))
+                _eq(kept[b], xs[b], "operand of the out-of-place rotation, item %d" % b)
+            # out of place + rescale (folded tail), the operand destroyed right after the call
+            cx = d.ct(xs, scale=sc)
+            dst = S.Ciphertext(d.ctx, batch=batch)
+            d.ev.rotate_vector(cx, s, d.glk, dst)
+            del cx
+            d.ev.rescale_to_next_inplace(dst)
+            got = d.out(dst)
+            for b in range(batch):
+                _eq(got[b], o.rescale(want[b]), "rotate_vector(%d) + rescale, item %d" % (s, b))
+            # in place twice (the second rotation reads a ciphertext whose tail is pending), then rescale
+            cx = d.ct(xs, scale=sc)
+            d.ev.rotate_vector_inplace(cx, s, d.glk)
+            d.ev.rotate_vector_inplace(cx, s, d.glk)
+            d.ev.rescale_to_next_inplace(cx)
+            got = d.out(cx)
+            for b in range(batch):
+                _eq(got[b], o.rescale(o.apply_galois(want[b], e)), "rotate_vector(%d) in place twice + rescale, item %d" % (s, b))
+        cx = d.ct(xs, scale=sc)
+        d.ev.complex_conjugate_inplace(cx, d.glk)
+        got = d.out(cx)
+        for b in range(batch):
+            _eq(got[b], o.apply_galois(xs[b], 2 * n - 1), "complex_conjugate in place, item %d" % b)
+        # a product relinearised, rotated and rescaled: pending product -> pending tail -> gather -> folded tail
+        ys = [rand_ct(rng, primes, K, n) for _ in range(batch)]
+        cx, cy = d.ct(xs, scale=2.0 ** 10), d.ct(ys, scale=2.0 ** 10)
+        d.ev.multiply_inplace(cx, cy)
+        d.ev.relinearize_inplace(cx, d.rlk)
+        d.ev.rotate_vector_inplace(cx, steps[0], d.glk)
+        cx.set_scale(sc)
+        d.ev.rescale_to_next_inplace(cx)
+        got = d.out(cx)
+        e0 = o.galois_elt_from_step(steps[0])
+        for b in range(batch):
+            _eq(got[b], o.rescale(o.apply_galois(o.relinearize(o.multiply(xs[b], ys[b])), e0)), "multiply + relinearize + rotate + rescale, item %d" % b)
+    g1 = S.galois_stats()
+    two_pass = 13 <= n.bit_length() - 1 <= 16 and not os.environ.get("SEALHIP_KS_EAGER_TAIL")
+    assert (g1[0] - g0[0], g1[1] - g0[1]) == ((4 * len(steps) + 2, 0) if two_pass else (0, 4 * len(steps) + 2)), "rotation paths: %r" % ((g1[0] - g0[0], g1[1] - g0[1]),)

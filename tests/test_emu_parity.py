@@ -364,3 +364,8 @@ def test_lazy_product_life_cycle(emu):
     """deferred tensor products (evaluator.h: LazyProduct): the fused relinearisation and every way the caller can observe the words of
     the destination or the operands while a product is pending - both arithmetic classes in the chain"""
     P.case_lazy_product(8192, [60, 40, 40, 60], batch=2)
+
+
+def test_rotate_gather(emu):
+    """rotations that read their operand through the automorphism's index map inside the key switch (both arithmetic classes)"""
+    P.case_rotate_gather(8192, [60, 40, 40, 60], batch=2)

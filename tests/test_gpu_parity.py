@@ -112,6 +112,14 @@ def test_lazy_product_life_cycle(gpu, n, bits, batch):
     P.case_lazy_product(n, bits, batch=batch)
 
 
+# rotations without the permutation kernels (round 6): every two-pass size, small batches through SEALHIP_KS_SPLIT=1 and - the last
+# case - a batch the launcher takes there by its own rule (chunked key switch on lanes at 2^16)
+@pytest.mark.parametrize("n,bits,batch", [(8192, [60, 40, 40, 60], 3), (16384, [60, 50, 55, 50, 60], 2), (32768, [50, 59, 50, 60], 2),
+                                          (65536, [60, 50, 50, 49, 60], 5), (65536, [60, 50, 50, 60], 70)])
+def test_rotate_gather(gpu, n, bits, batch):
+    P.case_rotate_gather(n, bits, batch=batch, steps=(1, -1) if batch < 10 else (1,))
+
+
 def test_dyadic(gpu):
     P.case_dyadic(4096, [60, 40, 30])
 
