@@ -12,6 +12,7 @@ ok = rej = 0
 fails = []
 f0 = S.tail_stats()
 p0 = S.product_stats()
+g0 = S.galois_stats()
 while time.time() - t0 < budget:
     cfgs = T._ckks_configs(seed, 4, [8192, 16384, 32768, 65536]) + T._bfv_configs(seed, 2, [8192, 16384])
     for i, cfg in enumerate(cfgs):
@@ -33,6 +34,7 @@ while time.time() - t0 < budget:
 f1 = S.tail_stats()
 print("sequences ok", ok, "rejected-by-reference", rej, "FAIL", len(fails), "seeds", int(os.environ.get("FUZZ_SEED0", "300")), "..", seed - 1,
       "tails folded / plain / dropped:", [b - a for a, b in zip(f0, f1)],
-      "products fused / formed / dropped:", [b - a for a, b in zip(p0, S.product_stats())], "seconds %.0f" % (time.time() - t0))
+      "products fused / formed / dropped:", [b - a for a, b in zip(p0, S.product_stats())],
+      "rotations gathered / permuted:", [b - a for a, b in zip(g0, S.galois_stats())], "seconds %.0f" % (time.time() - t0))
 for f in fails[:10]:
     print(f)
