@@ -193,7 +193,7 @@ namespace sealhip
             return false;
         const LazyProduct p = detach_product(e); // from here on e is an ordinary size-3 ciphertext whose words are not there yet
         lazy_product_count_fused();
-        uint64_t *target = e.data_ + 2 * e.plane_words(); // written by the inverse transform that forms x1 y1
+        uint64_t *target = e.data_ + 2 * e.plane_words(); // (names the polynomial; neither read nor written: x1 y1 is formed from the operands where it is used)
         StreamScope pool_scope(stream_);
         try
         {
@@ -372,13 +372,11 @@ namespace sealhip
             bt.src_galois_elt = galois_elt;
             if (product)
             {
-                // the target x1 y1 is formed while it is loaded and stored (NTT form) where `target` points: the diagonal terms read it
+                // the target x1 y1 is formed while it is loaded; it is not stored (ks2 forms its diagonal terms from the operands too)
                 bt.prod_x = prod_xw;
                 bt.prod_y = prod_yw;
                 bt.prod_batch = B;
                 bt.prod_outer0 = 2 * B;
-                bt.prod_out = const_cast<uint64_t *>(target);
-                bt.prod_out_stride = (size_t)K * N;
             }
             ck(ntt_inverse(tb, bt, 0, stream_), "ks intt target");
         }
@@ -405,7 +403,8 @@ namespace sealhip
             }
             KsFusedArgs ka{};
             ka.t = digits;
-            ka.target_ntt = ntt_target ? target : nullptr; // the I == J shortcut of evaluator.cpp:2682-2685
+            // the I == J shortcut of evaluator.cpp:2682-2685 (a deferred product: x1 y1 is formed where it is needed, ks2 takes it from fold_x / fold_y)
+            ka.target_ntt = ntt_target && !product ? target : nullptr;
             ka.key = key.dev;
             ka.mid = mid.p;
             ka.acc = acc_out;
@@ -499,8 +498,6 @@ namespace sealhip
                             bt.prod_y = prod_yw;
                             bt.prod_batch = B;
                             bt.prod_outer0 = 2 * B + b0;
-                            bt.prod_out = const_cast<uint64_t *>(target) + b0 * poly_words;
-                            bt.prod_out_stride = poly_words;
                         }
                         ck(ntt2_inverse(tb, bt, 0, inv_mid.p + (size_t)l * plan.chunk * poly_words, st), "ks intt target (chunk)");
                     }

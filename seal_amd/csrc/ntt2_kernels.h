@@ -72,6 +72,7 @@ namespace sealhip
         // Round 6, instead of fold_c0 / fold_c1: the addend is a 2 x 2 tensor product that was never stored (Evaluator::multiply deferred
         // it, evaluator.h: LazyProduct) - c0 = x0 y0, c1 = x0 y1 + x1 y0 are formed in ks2's epilogue from the operands' planes
         // (fold_x / fold_y = plane 0 of x / y, [batch][K][N]; plane 1 is fold_plane words further).  Same restrictions as fold_c0.
+        // With target_ntt null the diagonal terms (I == J) are x1 y1 formed in ks2 as well: the product is then never stored at all.
         const uint64_t *fold_x = nullptr, *fold_y = nullptr;
         size_t fold_plane = 0;
         // Round 6, rotations without the permutation kernels: target_ntt and fold_c0 are the UNPERMUTED polynomials c1 and c0, read

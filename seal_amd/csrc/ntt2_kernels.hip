@@ -1449,8 +1449,11 @@ namespace sealhip
             // diagonal digit (CKKS): NTT_J(INTT_J(target_J)) = target_J (evaluator.cpp:2682-2685); read the
             // thread's 16 contiguous coefficients of row 16 hg + u straight from the input polynomial
             const uint64_t *mid0_lane = mid0 + mid_lane(tid);
-            const bool has_diag = a.target && I < a.K;
-            const UniformView diag_view = uniform_view(has_diag ? a.target + (((size_t)b * a.K + I) << G::n) + ((size_t)hg << 12) : a.mid);
+            // (round 6) a deferred product's diagonal terms are x1 y1, formed here from the operands: diag_prod = the product is not stored
+            const bool diag_prod = a.fold_x && !a.target && I < a.K;
+            const bool has_diag = (a.target || diag_prod) && I < a.K;
+            const size_t diag_off = (((size_t)b * a.K + I) << G::n) + ((size_t)hg << 12);
+            const UniformView diag_view = uniform_view(diag_prod ? a.fold_x + a.fold_plane + diag_off : has_diag ? a.target + diag_off : a.mid);
             uint64_t nxt[16]; // digit J+1 is in flight while digit J is transformed
             auto fetch = [&](unsigned J) {
                 if (has_diag && J == I)
@@ -1519,7 +1522,29 @@ namespace sealhip
                 const bool is_diag = has_diag && J == I;
                 if constexpr (!PF)
                     fetch(J);
-                if (is_diag)
+                if (is_diag && diag_prod)
+                {
+                    // nxt holds x1's sixteen words of this thread; y1's are loaded here, once per tile (the product's round trip through
+                    // HBM - stored by the inverse transform, read back here - is what this replaces)
+                    const UniformView yv = uniform_view(a.fold_y + a.fold_plane + diag_off);
+                    uint64_t yw[16];
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2)
+                        view_load128(yv, tid * 128, e * 8, yw[e], yw[e + 1]);
+                    [[maybe_unused]] const ModDesc mdd = ld_uniform_mod(&a.tb.mods[prime]);
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                    {
+                        if constexpr (FP)
+                        {
+                            x[e] = fp_mulmod(fp_from_u52(nxt[e]), fp_from_u52(yw[e]), m.q, m.qinv); // <= 0.875 q (field.h)
+                            F::fix(x[e], m);
+                        }
+                        else
+                            x[e] = F::from_canon(mul_mod(nxt[e], yw[e], mdd), m);
+                    }
+                }
+                else if (is_diag)
                 {
 #pragma unroll
                     for (int e = 0; e < 16; e++)
@@ -2531,7 +2556,7 @@ namespace sealhip
         a1.ntargets = k.ntargets;
         a1.K = k.K;
         a1.batch = k.batch;
-        a1.skip_diag = k.target_ntt != nullptr;
+        a1.skip_diag = k.target_ntt != nullptr || k.fold_x != nullptr; // (a deferred product: the diagonal terms are x1 y1, formed in ks2)
         a1.j0 = k.j0;
         a1.j1 = k.j1;
         a1.parts = k.parts ? k.parts : 1;
