@@ -49,6 +49,8 @@ for which in sys.argv[2:]:
                 pass
         del os.environ["SEALHIP_KS_SPLIT"]; del os.environ["SEALHIP_LAZY_PRODUCT_MIN_WGS"]
         print("sequences with three-object products", n, "products fused / formed / dropped", S.product_stats())
+    elif which == "rot":      # round 6: rotations read through the automorphism's index map inside the key switch (in place: the operand's slab kept)
+        P.case_rotate_gather(8192, [60, 40, 40, 60], batch=2)
     elif which == "fuzz":
         n = 0
         for seed in (11, 12):
