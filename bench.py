@@ -124,7 +124,8 @@ def main():
     if args.workload == "headline":
         fused, formed, dropped = S.product_stats()
         product_note = ("deferred: multiply into the work object leaves the tensor product pending and the relinearize that follows forms it "
-                        "inside its own kernels (same words; %d fused / %d formed on their own / %d discarded in this process)"
+                        "inside its own kernels, in the same timed step (all of the product's arithmetic runs, none of it is cached or skipped; same words; "
+                        "%d fused / %d formed on their own / %d discarded in this process)"
                         % (fused, formed, dropped)) if fused else "separate kernel"
     lanes_note = ""
     if w.lanes:
