@@ -1244,6 +1244,81 @@ def case_deferred_tail_two_readers(n=8192, bits=(50, 40, 40, 60), rounds=6):
         _eq(d.out(a)[0], ref_relin, "the shared operand, round %d" % r)
 
 
+def case_pending_product_threads(n=8192, bits=(50, 40, 40, 60), rounds=4):
+    """Pending tensor products and host threads (the reference lets several threads use one ciphertext as an operand at the same time):
+    (a) two threads read one destination whose product is pending - exactly one of them forms it (SealHip_ProductStats), both see the
+    words; (b) two threads, each on its own evaluator / stream, multiply their own operand with ONE shared second operand and relinearise
+    (the shared operand's reader list is touched from both), fused on both."""
+    import threading
+    primes = coeff_modulus_create(n, list(bits))
+    K = len(primes) - 1
+    o = Oracle("ckks", n, primes)
+    d = DeviceSide("ckks", n, primes)
+    d.upload_keys(o)
+    rng = np.random.default_rng(23)
+    x, x2, y = rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n), rand_ct(rng, primes, K, n)
+    z1, z2 = rand_ct(rng, primes, K, n, size=3), rand_ct(rng, primes, K, n, size=3)
+    ref_prod, ref_prod2 = o.multiply(x, y), o.multiply(x2, y)
+    qk = np.array(primes[:K], dtype=np.uint64)[None, :, None]
+    defers = 13 <= n.bit_length() - 1 <= 16 and not os.environ.get("SEALHIP_KS_EAGER_TAIL")
+    ev2 = S.Evaluator(d.ctx)
+    with _Env(SEALHIP_KS_SPLIT=1, SEALHIP_LAZY_PRODUCT_MIN_WGS=0, SEALHIP_LAZY_PRODUCT=None):
+        for r in range(rounds):
+            # (a)
+            a, b, w = d.ct([x], scale=2.0 ** 10), d.ct([y], scale=2.0 ** 10), S.Ciphertext(d.ctx)
+            if r & 1:
+                d.ev.multiply(a, b, w)
+            else:
+                d.ev.multiply_inplace(a, b)
+                w = a
+            c1, c2 = d.ct([z1], scale=2.0 ** 20), d.ct([z2], scale=2.0 ** 20)
+            out1, out2 = S.Ciphertext(d.ctx), S.Ciphertext(d.ctx)
+            f0, m0, x0 = S.product_stats()
+            start = threading.Barrier(2)
+            errs = []
+
+            def reader(ev, other, out):
+                try:
+                    start.wait()
+                    ev.add(w, other, out)
+                except Exception as e:   # noqa: BLE001 - reported below
+                    errs.append(e)
+            t1 = threading.Thread(target=reader, args=(d.ev, c1, out1))
+            t2 = threading.Thread(target=reader, args=(d.ev if r & 2 else ev2, c2, out2))
+            t1.start(); t2.start(); t1.join(); t2.join()
+            assert not errs, errs
+            S.device_synchronize()
+            f1, m1, x1 = S.product_stats()
+            assert (f1 - f0, m1 - m0, x1 - x0) == ((0, 1, 0) if defers else (0, 0, 0)), "the pending product must be formed exactly once"
+            _eq(d.out(out1)[0], (ref_prod + z1) % qk, "reader 1, round %d" % r)
+            _eq(d.out(out2)[0], (ref_prod + z2) % qk, "reader 2, round %d" % r)
+            _eq(d.out(w)[0], ref_prod, "the shared destination, round %d" % r)
+            # (b)
+            a1, a2, b = d.ct([x], scale=2.0 ** 10), d.ct([x2], scale=2.0 ** 10), d.ct([y], scale=2.0 ** 10)
+            w1, w2 = S.Ciphertext(d.ctx), S.Ciphertext(d.ctx)
+            f0, m0, x0 = S.product_stats()
+            start = threading.Barrier(2)
+
+            def worker(ev, xa, wa):
+                try:
+                    start.wait()
+                    ev.multiply(xa, b, wa)
+                    ev.relinearize_inplace(wa, d.rlk)
+                except Exception as e:   # noqa: BLE001
+                    errs.append(e)
+            t1 = threading.Thread(target=worker, args=(d.ev, a1, w1))
+            t2 = threading.Thread(target=worker, args=(ev2, a2, w2))
+            t1.start(); t2.start(); t1.join(); t2.join()
+            assert not errs, errs
+            S.device_synchronize()
+            f1, m1, x1 = S.product_stats()
+            assert (f1 - f0, m1 - m0) == ((2, 0) if defers else (0, 0)), "both products fused: %r" % ((f1 - f0, m1 - m0),)
+            _eq(d.out(w1)[0], o.relinearize(ref_prod), "worker 1, round %d" % r)
+            _eq(d.out(w2)[0], o.relinearize(ref_prod2), "worker 2, round %d" % r)
+            _eq(d.out(b)[0], y, "the shared operand, round %d" % r)
+    del ev2
+
+
 # ---- the 2 x 2 tensor product grows its first operand in two ways (evaluator.cpp: tensor_2x2)
 def case_product_growth(scheme, n, bits, tbits=20, batch=3, seed=51):
     """multiply_inplace / square_inplace of a size-2 ciphertext: into a new slab when the operand's slab holds two polynomials

@@ -369,3 +369,8 @@ def test_lazy_product_life_cycle(emu):
 def test_rotate_gather(emu):
     """rotations that read their operand through the automorphism's index map inside the key switch (both arithmetic classes)"""
     P.case_rotate_gather(8192, [60, 40, 40, 60], batch=2)
+
+
+def test_pending_product_threads(emu):
+    """two host threads around pending tensor products: one destination read by both, one operand shared by two fused relinearisations"""
+    P.case_pending_product_threads(8192, (50, 40, 60), rounds=2)

@@ -120,6 +120,13 @@ def test_rotate_gather(gpu, n, bits, batch):
     P.case_rotate_gather(n, bits, batch=batch, steps=(1, -1) if batch < 10 else (1,))
 
 
+def test_pending_product_threads(gpu):
+    """two host threads around pending tensor products (one destination read by both: formed once; one operand shared by two fused
+    relinearisations on two evaluators / streams)"""
+    P.case_pending_product_threads(8192, (50, 40, 40, 60), rounds=8)
+    P.case_pending_product_threads(65536, (60, 50, 50, 60), rounds=3)
+
+
 def test_dyadic(gpu):
     P.case_dyadic(4096, [60, 40, 30])
 
